@@ -1,0 +1,36 @@
+"""CPU oracle for the mvector embedding-extraction hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and there only as the checker / timed CPU baseline.  The
+product path (``voiceprintrecognition-pytorch_amd/``) never imports this
+package and fails loudly when its HIP library is missing.
+
+What is restated here (torch-CPU fp32, written from the algorithm, not copied):
+
+* ``frontend.py``  -- ``torchaudio.compliance.kaldi.fbank`` and
+  ``torchaudio.transforms.MelSpectrogram`` (torchaudio 2.4.0 is the version the
+  reference pins in prose, README.md:163; it is NOT vendored in /root/reference
+  and NOT installed here) plus ``AudioFeaturizer.forward``
+  (mvector/data_utils/featurizer.py:53-91, 114-132).
+* ``models.py``    -- functional forwards of EcapaTdnn (mvector/models/ecapa_tdnn.py),
+  CAMPPlus (mvector/models/campplus.py) and TDNN (mvector/models/tdnn.py) with
+  their pooling layers (mvector/models/pooling.py) over a plain state_dict.
+* ``scoring.py``   -- cosine scoring (mvector/predict.py:165-183, 275-279;
+  mvector/trainer.py:454-461).
+
+Pin status
+----------
+* models / scoring: PINNED.  ``make_golden.py`` imports the reference's own
+  modules from /root/reference (loguru stubbed), loads weights produced by
+  ``weights.py`` and stores their outputs in ``tests/golden/*.npz``;
+  ``tests/test_oracle_models.py`` checks this restatement against them.
+* front-end (Fbank / MelSpectrogram): the reference has no tests and its
+  arithmetic lives in torchaudio, which cannot be run here, so there is no
+  reference-produced vector to pin to: **parity unpinned against torchaudio
+  itself**.  The restatement is instead cross-checked against two independent
+  implementations that ARE available: ``transformers.audio_utils.spectrogram``
+  (the numpy code HuggingFace ships as the replacement for ``ta_kaldi.fbank``)
+  and, for MelSpectrogram, ``torch.stft`` (the very op torchaudio calls) plus
+  ``transformers.audio_utils.mel_filter_bank``.
+"""

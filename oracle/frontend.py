@@ -1,0 +1,192 @@
+"""Oracle front-end: Kaldi Fbank, MelSpectrogram and the AudioFeaturizer wrapper.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows, step by step and in fp32 on the CPU:
+
+* ``torchaudio.compliance.kaldi.fbank`` (torchaudio 2.4.0, not vendored) as
+  called from mvector/data_utils/featurizer.py:128 with
+  ``method_args = {sample_frequency: 16000, num_mel_bins: 80}``
+  (configs/ecapa_tdnn.yml:49-51) -- algorithm in SURVEY.md section 8(c);
+* ``torchaudio.transforms.MelSpectrogram(**method_args)`` as built at
+  mvector/data_utils/featurizer.py:41-42;
+* ``KaldiFbank.forward`` (featurizer.py:119-132: per-utterance loop, transpose,
+  stack) and ``AudioFeaturizer.forward`` (featurizer.py:53-91: transpose to
+  [B,T,F], time-mean subtraction over ALL frames, optional length mask with
+  round-half-to-even).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FBANK_DEFAULTS = dict(
+    blackman_coeff=0.42, channel=-1, dither=0.0, energy_floor=1.0, frame_length=25.0,
+    frame_shift=10.0, high_freq=0.0, htk_compat=False, low_freq=20.0, min_duration=0.0,
+    num_mel_bins=23, preemphasis_coefficient=0.97, raw_energy=True, remove_dc_offset=True,
+    round_to_power_of_two=True, sample_frequency=16000.0, snip_edges=True, subtract_mean=False,
+    use_energy=False, use_log_fbank=True, use_power=True, vtln_high=-500.0, vtln_low=100.0,
+    vtln_warp=1.0, window_type='povey')
+
+MELSPEC_DEFAULTS = dict(
+    sample_rate=16000, n_fft=400, win_length=None, hop_length=None, f_min=0.0, f_max=None,
+    pad=0, n_mels=128, power=2.0, normalized=False, center=True, pad_mode='reflect',
+    onesided=None, norm=None, mel_scale='htk')
+
+EPS_F32 = float(torch.finfo(torch.float32).eps)  # 1.1920929e-07, the Kaldi log floor
+
+
+def _next_pow2(n):
+    return 1 if n == 0 else 2 ** (n - 1).bit_length()
+
+
+def kaldi_mel_banks(num_bins, padded, sample_freq, low_freq, high_freq):
+    """Kaldi triangular filters, triangles in MEL space, no normalisation.
+
+    Returns [num_bins, padded//2] fp32 (the caller appends the zero Nyquist column).
+    """
+    num_fft_bins = padded // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    fft_bin_width = sample_freq / padded
+    mel_lo = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    mel_hi = 1127.0 * math.log(1.0 + high_freq / 700.0)
+    delta = (mel_hi - mel_lo) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left = mel_lo + b * delta
+    center = mel_lo + (b + 1.0) * delta
+    right = mel_lo + (b + 2.0) * delta
+    mel = (1127.0 * (1.0 + (fft_bin_width * torch.arange(num_fft_bins)) / 700.0).log()).unsqueeze(0)
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    return torch.max(torch.zeros(1), torch.min(up, down))
+
+
+def povey_window(n):
+    return torch.hann_window(n, periodic=False).pow(0.85)
+
+
+def kaldi_fbank(waveform, **kwargs):
+    """waveform: fp32 tensor [1, L] or [L] -> [m, num_mel_bins] log-mel energies."""
+    a = dict(FBANK_DEFAULTS)
+    unknown = set(kwargs) - set(a)
+    if unknown:
+        raise TypeError(f'unexpected fbank arguments {sorted(unknown)}')
+    a.update(kwargs)
+    for k, v in (('window_type', 'povey'), ('use_energy', False), ('vtln_warp', 1.0), ('dither', 0.0),
+                 ('snip_edges', True), ('subtract_mean', False), ('htk_compat', False)):
+        if a[k] != v:
+            raise NotImplementedError(f'oracle restates only {k}={v!r}')
+    w = torch.as_tensor(waveform, dtype=torch.float32)
+    if w.dim() == 2:
+        w = w[max(a['channel'], 0)]
+    sf = a['sample_frequency']
+    shift = int(sf * a['frame_shift'] * 0.001)
+    size = int(sf * a['frame_length'] * 0.001)
+    padded = _next_pow2(size) if a['round_to_power_of_two'] else size
+    L = w.shape[0]
+    nbins = a['num_mel_bins']
+    if L < a['min_duration'] * sf or L < size:
+        return torch.empty(0, nbins)
+    m = 1 + (L - size) // shift
+    frames = w.as_strided((m, size), (shift, 1)).clone()
+    if a['remove_dc_offset']:
+        frames = frames - frames.mean(dim=1, keepdim=True)
+    pc = a['preemphasis_coefficient']
+    if pc != 0.0:
+        prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)  # replicate-pad on the left
+        frames = frames - pc * prev
+    frames = frames * povey_window(size).unsqueeze(0)
+    if padded != size:
+        frames = F.pad(frames, (0, padded - size))
+    spec = torch.fft.rfft(frames).abs()
+    if a['use_power']:
+        spec = spec.pow(2.0)
+    banks = kaldi_mel_banks(nbins, padded, sf, a['low_freq'], a['high_freq'])
+    banks = F.pad(banks, (0, 1))
+    mel = torch.mm(spec, banks.T)
+    if a['use_log_fbank']:
+        mel = torch.max(mel, torch.tensor(EPS_F32)).log()
+    return mel
+
+
+def htk_mel_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+def mel_spectrogram(waveforms, **kwargs):
+    """waveforms fp32 [B, L] -> [B, n_mels, 1 + L // hop] raw-power mel spectrogram."""
+    a = dict(MELSPEC_DEFAULTS)
+    unknown = set(kwargs) - set(a)
+    if unknown:
+        raise TypeError(f'unexpected MelSpectrogram arguments {sorted(unknown)}')
+    a.update(kwargs)
+    if a['mel_scale'] != 'htk' or a['norm'] is not None or a['pad'] != 0 or a['normalized']:
+        raise NotImplementedError('oracle restates only the htk / un-normalised MelSpectrogram')
+    n_fft = a['n_fft']
+    win = a['win_length'] if a['win_length'] is not None else n_fft
+    hop = a['hop_length'] if a['hop_length'] is not None else win // 2
+    sr = a['sample_rate']
+    f_max = a['f_max'] if a['f_max'] is not None else float(sr // 2)
+    x = torch.as_tensor(waveforms, dtype=torch.float32)
+    spec = torch.stft(x, n_fft, hop, win, torch.hann_window(win), center=a['center'],
+                      pad_mode=a['pad_mode'], normalized=False, onesided=True, return_complex=True)
+    spec = spec.abs() if a['power'] == 1.0 else spec.abs().pow(a['power'])
+    fb = htk_mel_fbanks(n_fft // 2 + 1, a['f_min'], f_max, a['n_mels'], sr)
+    return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
+
+
+def audio_featurizer(waveforms, input_lens_ratio=None, feature_method='Fbank', method_args=None):
+    """AudioFeaturizer.forward: [B, L] (or [L]) fp32 -> [B, T, F] fp32."""
+    method_args = dict(method_args or {})
+    x = torch.as_tensor(waveforms, dtype=torch.float32)
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if feature_method == 'Fbank':
+        # per-utterance loop, [m, F] -> [F, m] -> stack (featurizer.py:125-131)
+        feats = torch.stack([kaldi_fbank(row.unsqueeze(0), **method_args).transpose(0, 1) for row in x])
+    elif feature_method == 'MelSpectrogram':
+        feats = mel_spectrogram(x, **method_args)
+    else:
+        raise Exception(f'oracle has no restatement of feature_method {feature_method}')
+    feats = feats.transpose(2, 1)
+    feats = feats - feats.mean(1, keepdim=True)
+    if input_lens_ratio is not None:
+        ratio = torch.as_tensor(input_lens_ratio, dtype=torch.float32)
+        mask_lens = torch.round(ratio * feats.shape[1]).long().unsqueeze(1)
+        idxs = torch.arange(feats.shape[1]).repeat(feats.shape[0], 1)
+        mask = (idxs < mask_lens).unsqueeze(-1)
+        feats = torch.where(mask, feats, torch.zeros_like(feats))
+    return feats
+
+
+def feature_dim(feature_method, method_args=None):
+    """AudioFeaturizer.feature_dim (featurizer.py:93-111)."""
+    method_args = method_args or {}
+    if feature_method == 'MelSpectrogram':
+        return method_args.get('n_mels', 128)
+    if feature_method == 'Fbank':
+        return method_args.get('num_mel_bins', 23)
+    raise Exception(f'no feature_dim for {feature_method}')
+
+
+def synth_waveforms(batch, length, seed=1234, amplitude=0.1):
+    """BASELINE.md section 3 input recipe: (0.1 * randn).clamp(-1, 1), Generator seed 1234."""
+    g = torch.Generator().manual_seed(seed)
+    return (amplitude * torch.randn([batch, length], generator=g)).clamp(-1, 1)
+
+
+def as_numpy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)

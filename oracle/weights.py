@@ -1,0 +1,46 @@
+"""Seeded weights keyed by state_dict name (oracle/test infrastructure only).
+
+No trained checkpoint of the reference is obtainable offline (README.md:74-85), so every
+parity check runs on synthetic weights.  They are drawn per tensor from a numpy PCG64
+stream seeded by crc32(name) ^ seed, i.e. independent of module construction order, so the
+reference modules (make_golden.py), the oracle and the HIP-backed modules all see identical
+values from the key -> shape manifest alone.  BatchNorm statistics are randomised
+(SURVEY.md section 8(d)): default-initialised BN is the identity and would hide BN bugs.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def make_state_dict(shapes, seed=0):
+    """shapes: {key: tuple}.  Returns {key: torch fp32 tensor (int64 for num_batches_tracked)}."""
+    out = {}
+    keys = set(shapes)
+    for name in sorted(shapes):
+        shape = tuple(shapes[name])
+        rng = np.random.Generator(np.random.PCG64((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
+        stem, _, leaf = name.rpartition('.')
+        is_bn = (stem + '.running_mean') in keys
+        if leaf == 'num_batches_tracked':
+            out[name] = torch.tensor(100, dtype=torch.int64)
+            continue
+        if leaf == 'running_mean':
+            v = rng.normal(0.0, 0.1, shape)
+        elif leaf == 'running_var':
+            v = rng.uniform(0.5, 1.5, shape)
+        elif is_bn and leaf == 'weight':
+            v = rng.uniform(0.8, 1.2, shape)
+        elif leaf == 'bias':
+            v = rng.normal(0.0, 0.1, shape)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            v = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)
+        else:
+            v = rng.normal(0.0, 0.1, shape)
+        out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
+    return out
+
+
+def shapes_of(state_dict):
+    return {k: tuple(v.shape) for k, v in state_dict.items()}

@@ -1,0 +1,24 @@
+"""Shared helpers for the test-suite (loads golden fixtures and seeded weights)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_case(case):
+    """-> (manifest dict, state_dict, x [B,T,F] tensor, reference embedding tensor, npz)."""
+    from oracle import weights
+    with open(os.path.join(GOLDEN, f'manifest_{case}.json')) as f:
+        man = json.load(f)
+    sd = weights.make_state_dict(man['shapes'], man['seed'])
+    z = np.load(os.path.join(GOLDEN, f'{case}.npz'))
+    return man, sd, torch.from_numpy(z['x']), torch.from_numpy(z['emb']), z
+
+
+def cos_dist(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return (1.0 - torch.nn.functional.cosine_similarity(a, b, dim=-1))

@@ -1,0 +1,91 @@
+"""CPU tests pinning the oracle: models against the reference-generated golden vectors,
+front-end against transformers' independent Kaldi/HTK implementations and the fixtures."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_case, cos_dist
+from oracle import frontend, models as omodels, scoring
+
+FB = dict(sample_frequency=16000, num_mel_bins=80)
+
+
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_mel128', 'campp_short', 'tdnn'])
+def test_oracle_models_match_reference_golden(case):
+    man, sd, x, emb_ref, _ = load_case(case)
+    emb = omodels.FORWARDS[man['model']](sd, x)
+    assert emb.shape == emb_ref.shape
+    assert torch.allclose(emb, emb_ref, rtol=1e-4, atol=1e-4), (emb - emb_ref).abs().max()
+    assert cos_dist(emb, emb_ref).max() < 1e-6
+
+
+def test_oracle_ecapa_layers_match_reference_golden():
+    man, sd, x, emb_ref, z = load_case('ecapa_tiny')
+    emb, layers = omodels.ecapa_tdnn(sd, x, return_layers=True)
+    assert np.allclose(layers['blocks'][0].numpy(), z['l_block0'], atol=1e-4)
+    assert np.allclose(layers['blocks'][1].numpy(), z['l_block1'], atol=1e-4)
+
+
+def test_oracle_fbank_matches_hf_kaldi_port():
+    from transformers.audio_utils import spectrogram, mel_filter_bank
+    wav = frontend.synth_waveforms(2, 16000, seed=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        mf = mel_filter_bank(257, 80, 20, 8000, 16000, norm=None, mel_scale='kaldi', triangularize_in_mel_space=True)
+    win = frontend.povey_window(400).numpy().astype(np.float64)
+    for b in range(2):
+        hf = spectrogram(wav[b].numpy().astype(np.float64), win, frame_length=400, hop_length=160, fft_length=512,
+                         power=2.0, center=False, preemphasis=0.97, mel_filters=mf, log_mel='log',
+                         mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+        mine = frontend.kaldi_fbank(wav[b:b + 1], **FB).numpy()
+        assert mine.shape == (98, 80)
+        assert np.abs(mine - hf).max() < 1e-3
+
+
+def test_oracle_melspec_filterbank_matches_hf():
+    from transformers.audio_utils import mel_filter_bank
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fb = mel_filter_bank(201, 128, 0, 8000, 16000, norm=None, mel_scale='htk')
+    mine = frontend.htk_mel_fbanks(201, 0.0, 8000.0, 128, 16000).numpy()
+    assert np.abs(fb - mine).max() < 1e-4
+    assert int((mine.sum(0) == 0).sum()) == 4  # 4 all-zero filters at n_fft=400
+
+
+def test_oracle_frontend_fixtures_and_quirks():
+    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    feats = frontend.audio_featurizer(wav, None, 'Fbank', FB).numpy()
+    assert feats.shape == (4, 298, 80)
+    assert np.abs(feats - z['fbank']).max() < 1e-4
+    assert np.abs(feats.mean(1)).max() < 1e-4  # CMN
+    lens = z['lens']
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(lens):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    fv = frontend.audio_featurizer(wav_var, torch.from_numpy(z['ratio']), 'Fbank', FB).numpy()
+    assert np.abs(fv - z['fbank_var']).max() < 1e-4
+    # Q3: round-half-even mask length; Q2: frames beyond it are exactly zero
+    for i, n in enumerate(lens):
+        ml = int(torch.round(torch.tensor(n / 48000, dtype=torch.float32) * 298).item())
+        assert np.all(fv[i, ml:] == 0)
+        assert np.any(fv[i, ml - 1] != 0)
+    mel = frontend.audio_featurizer(wav[:2], None, 'MelSpectrogram', {}).numpy()
+    assert mel.shape == (2, 241, 128)
+    assert np.allclose(mel, z['mel'], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_empty_and_short_inputs():
+    assert frontend.kaldi_fbank(torch.zeros(1, 399), **FB).shape == (0, 80)
+    assert frontend.kaldi_fbank(torch.zeros(1, 400), **FB).shape == (1, 80)
+    silent = frontend.kaldi_fbank(torch.zeros(1, 1600), **FB)
+    assert torch.allclose(silent, torch.full_like(silent, float(np.log(np.float32(1.1920929e-07)))))
+
+
+def test_oracle_cosine_matches_sklearn_golden():
+    z = np.load(os.path.join(GOLDEN, 'cosine.npz'))
+    assert np.abs(scoring.cosine_similarity(z['a'], z['b']) - z['sim']).max() < 1e-6
+    assert abs(scoring.contrast(z['a'][0], z['b'][0]) - z['sim'][0, 0]) < 1e-6
