@@ -1,0 +1,224 @@
+/* libmvector_hip.so -- C ABI of the MI355X-native (gfx950) embedding-extraction hot path.
+ *
+ * The reference (yeyupiaoling/VoiceprintRecognition-Pytorch, mvector 1.1.1) is pure Python and has
+ * NO native / FFI / operator boundary for this path (setup.py:56 ``ext_modules=[]``), so there is no
+ * reference FFI to mirror symbol-for-symbol.  The drop-in boundary is the Python surface
+ * (AudioFeaturizer / build_model / model classes / MVectorPredictor); this header is the C ABI that a
+ * maintainer binds UNDER that surface (ctypes stub shown in INTEGRATION.md).  Each entry point cites
+ * the reference code whose device work it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer on the current HIP
+ *     device unless its name ends in ``_host``;
+ *   - the caller (PyTorch) owns inputs, outputs and workspaces; handles own only derived constants
+ *     (window / filterbank tables, pre-packed fp16 weights) allocated at create time;
+ *   - stream-ordered: work is enqueued on ``stream`` (a hipStream_t passed as void*), nothing in a
+ *     ``*_forward`` call synchronises the device; ``*_create`` / ``*_destroy`` may synchronise;
+ *   - every function returns MV_OK (0) or a negative MV_ERR_* code and records a message readable
+ *     through mv_last_error() (thread-local).  Handles are immutable after create, so forwards on
+ *     different streams with different workspaces may run concurrently.
+ */
+#ifndef MVECTOR_HIP_H
+#define MVECTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_OK 0
+#define MV_ERR_INVALID_ARGUMENT (-1)
+#define MV_ERR_HIP (-2)
+#define MV_ERR_UNSUPPORTED (-3)
+#define MV_ERR_WORKSPACE (-4)
+#define MV_ERR_MISSING_TENSOR (-5)
+
+#define MV_ABI_VERSION 1
+
+typedef void* mv_stream_t; /* hipStream_t */
+
+const char* mv_last_error(void);
+int mv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front-end 1: Kaldi log-mel filterbank + per-utterance time-mean subtraction + length mask.
+ * Replaces KaldiFbank.forward (mvector/data_utils/featurizer.py:119-132 ->
+ * torchaudio.compliance.kaldi.fbank) fused with AudioFeaturizer.forward's normalisation and mask
+ * (featurizer.py:77-90).  Arithmetic as restated in oracle/frontend.py::kaldi_fbank.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct MvFbankCfg {
+    float sample_frequency;       /* 16000 */
+    float frame_length_ms;        /* 25 */
+    float frame_shift_ms;         /* 10 */
+    int32_t num_mel_bins;         /* 80 (<= 128) */
+    float low_freq;               /* 20 */
+    float high_freq;              /* 0 => Nyquist (+ high_freq if <= 0, as Kaldi) */
+    float preemphasis_coefficient;/* 0.97 */
+    int32_t remove_dc_offset;     /* 1 */
+    int32_t use_power;            /* 1 */
+    int32_t use_log_fbank;        /* 1 */
+    int32_t subtract_time_mean;   /* 1: featurizer.py:79 (mean over ALL frames, padded ones included) */
+} MvFbankCfg;
+
+typedef struct MvFbank MvFbank;
+
+void mv_fbank_default_cfg(MvFbankCfg* cfg);
+int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out);
+int mv_fbank_destroy(MvFbank* h);
+/* T = 1 + (L - window) / shift, or 0 when L < window (snip_edges=True) */
+int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_frames);
+/* wav: [B, L] fp32 rows ``wav_stride`` elements apart.  lens_ratio: [B] fp32 or NULL
+ * (featurizer.py:80-90: frames t >= round_half_even(ratio * T) are zeroed).  out: [B, T, num_mel_bins]
+ * fp32, contiguous. */
+int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
+                     const float* lens_ratio, float* out, mv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front-end 2: MelSpectrogram (power STFT, centre/reflect padding, HTK mel filterbank, NO log) +
+ * time-mean subtraction + mask.  Replaces torchaudio.transforms.MelSpectrogram(**method_args)
+ * (featurizer.py:41-42) and featurizer.py:77-90.  Oracle: oracle/frontend.py::mel_spectrogram.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct MvMelSpecCfg {
+    int32_t sample_rate; /* 16000 */
+    int32_t n_fft;       /* 400 */
+    int32_t win_length;  /* 400 (<= n_fft) */
+    int32_t hop_length;  /* 200 */
+    float f_min;         /* 0 */
+    float f_max;         /* sample_rate / 2 */
+    int32_t n_mels;      /* 128 */
+    float power;         /* 2.0 (1.0 also supported) */
+    int32_t center;      /* 1 */
+    int32_t subtract_time_mean;
+} MvMelSpecCfg;
+
+typedef struct MvMelSpec MvMelSpec;
+
+void mv_melspec_default_cfg(MvMelSpecCfg* cfg);
+int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out);
+int mv_melspec_destroy(MvMelSpec* h);
+int mv_melspec_num_frames(const MvMelSpec* h, int64_t num_samples, int64_t* num_frames);
+size_t mv_melspec_workspace_bytes(const MvMelSpec* h, int32_t B, int64_t L);
+int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
+                       const float* lens_ratio, float* out, void* workspace, size_t workspace_bytes,
+                       mv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backbones.  A model handle is built from the reference-layout fp32 ``state_dict`` (same key names
+ * and shapes as the reference modules, so ``model.pth`` loads unchanged: mvector/utils/checkpoint.py:
+ * 11-51).  create() folds eval-mode BatchNorm into per-channel scale/shift, packs conv weights to the
+ * fp16 [Cout][tap][Cin] layout the MFMA kernels read, and keeps fp32 copies of the small dense layers.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct MvTensorRef {
+    const char* name;   /* state_dict key relative to the backbone, e.g. "blocks.0.conv.conv.weight" */
+    const float* data;  /* device pointer, fp32, contiguous */
+    int64_t numel;
+} MvTensorRef;
+
+typedef struct MvModel MvModel;
+
+/* EcapaTdnn.forward (mvector/models/ecapa_tdnn.py:253-283), pooling_type "ASP". */
+typedef struct MvEcapaCfg {
+    int32_t input_size;          /* F */
+    int32_t embd_dim;            /* 192 */
+    int32_t channels[5];         /* {512,512,512,512,1536} */
+    int32_t kernel_sizes[5];     /* {5,3,3,3,1} */
+    int32_t dilations[5];        /* {1,2,3,4,1} */
+    int32_t attention_channels;  /* 128 */
+    int32_t res2net_scale;       /* 8 */
+    int32_t se_channels;         /* 128 */
+    int32_t global_context;      /* 1 */
+} MvEcapaCfg;
+int mv_ecapa_create(const MvEcapaCfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
+
+/* CAMPPlus.forward (mvector/models/campplus.py:353-357). */
+typedef struct MvCamppCfg {
+    int32_t input_size;    /* F (80) */
+    int32_t embd_dim;      /* 192 in configs/cam++.yml:58; class default 512 */
+    int32_t growth_rate;   /* 32 */
+    int32_t bn_size;       /* 4 */
+    int32_t init_channels; /* 128 */
+} MvCamppCfg;
+int mv_campp_create(const MvCamppCfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
+
+/* TDNN.forward (mvector/models/tdnn.py:46-68), pooling_type "ASP". */
+typedef struct MvTdnnCfg {
+    int32_t input_size;
+    int32_t channels; /* 512 */
+    int32_t embd_dim; /* 192 */
+} MvTdnnCfg;
+int mv_tdnn_create(const MvTdnnCfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
+
+int mv_model_destroy(MvModel* m);
+int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
+int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes);
+/* feats: [B, T, F] fp32 (the AudioFeaturizer output layout); emb: [B, embd_dim] fp32. */
+int mv_model_forward(const MvModel* m, const float* feats, int32_t B, int32_t T, float* emb, void* workspace,
+                     size_t workspace_bytes, mv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cosine scoring: S[i, j] = <a_i, b_j> / (|a_i| |b_j|).  Replaces sklearn cosine_similarity at
+ * mvector/predict.py:174 and mvector/trainer.py:457-459, and predict.py:275-279 (contrast).
+ * ------------------------------------------------------------------------------------------------ */
+int mv_cosine_f32(const float* a, int32_t n, const float* b, int32_t m, int32_t dim, float* scores,
+                  mv_stream_t stream);
+/* in-place row L2 normalisation (predict.py:165-166) */
+int mv_l2_normalize_f32(float* x, int32_t n, int32_t dim, mv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layer-level entry points (same kernels the model forwards launch; exported so that the parity
+ * tests can pin each kernel against the oracle layer by layer).
+ * ------------------------------------------------------------------------------------------------ */
+#define MV_PAD_ZERO 0
+#define MV_PAD_REFLECT 1
+#define MV_ACT_NONE 0
+#define MV_ACT_RELU 1
+#define MV_ACT_TANH 2
+#define MV_ACT_SIGMOID 3
+#define MV_DT_F32 0
+#define MV_DT_F16 1
+
+/* pack [Cout][Cin][k] fp32 (nn.Conv1d layout) -> fp16 [Cout_pad][k][Cin_pad]; returns element count */
+int64_t mv_conv1d_packed_elems(int32_t cout, int32_t cin, int32_t k);
+int mv_conv1d_pack_weight(const float* w, int32_t cout, int32_t cin, int32_t k, void* packed_f16, mv_stream_t stream);
+
+typedef struct MvConv1dDesc {
+    /* y[b, t, co] = epilogue( sum_{j, ci} W[co, j, ci] * in(b, t*stride - pad + j*dilation, ci) )
+     * in(.) = x (+ x2) optionally passed through relu(x*in_scale+in_shift); channel-last tensors. */
+    const void* x;        /* [B, T_in, ldx] */
+    const void* x2;       /* optional second input added to x (Res2Net: ecapa_tdnn.py:47), same ld/dtype */
+    int32_t x_dtype;      /* MV_DT_F32 | MV_DT_F16 */
+    int64_t ldx;          /* elements between consecutive time steps of x (>= cin) */
+    int64_t ldx2;
+    const float* in_scale; /* optional [cin]: pre-activation BatchNorm folded (campplus.py:139-141) */
+    const float* in_shift;
+    const void* w_packed; /* from mv_conv1d_pack_weight */
+    const float* bias;    /* optional [cout] */
+    const float* row_bias;/* optional [B, cout]: per-utterance bias (hoisted ASP context, pooling.py:110-117) */
+    int32_t pre_act;      /* activation applied to (acc + bias) BEFORE the affine (TDNNBlock: ReLU, models/utils.py:138) */
+    const float* scale;   /* optional [cout] folded BatchNorm scale */
+    const float* shift;
+    int32_t post_act;     /* activation after the affine */
+    const float* gate;    /* optional [B, n_seg, cout] multiplicative gate (CAM mask, campplus.py:94-99) */
+    int32_t gate_seg_len; /* frames per gate segment */
+    void* y;              /* [B, T_out, ldy] */
+    int32_t y_dtype;
+    int64_t ldy;
+    int32_t B, T_in, T_out, cin, cout, k, dilation, stride, pad, pad_mode;
+} MvConv1dDesc;
+int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
+
+/* y[b, o] = act( sum_k x[b, k] * w[o, k] + bias[o] ) in exact fp32 (f32 MFMA). */
+int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
+                  int32_t B, int32_t K, int32_t O, mv_stream_t stream);
+
+/* mean (and optionally std = sqrt(clamp(E[(x-mean)^2], eps)), or unbiased std) over time of a
+ * channel-last fp16 tensor [B, T, ld] -> fp32 [B, C].  std may be NULL. */
+int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
+                      int32_t unbiased, float clamp_eps, mv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVECTOR_HIP_H */

@@ -1,0 +1,47 @@
+"""Build tests/emu/build/libmvector_emu.so: the csrc/*.hip kernels compiled for the HOST against
+hip_emu.h (SIMT emulator).  Test infrastructure only -- see hip_emu.h."""
+import glob
+import hashlib
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd', 'csrc')
+OUT = os.path.join(HERE, 'build')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+
+
+def build(verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+    deps = srcs + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip_emu.h'),
+                                                                   os.path.join(ROOT, 'include', 'mvector_hip.h')]
+    h = hashlib.sha1()
+    for d in deps:
+        h.update(open(d, 'rb').read())
+    lib = os.path.join(OUT, 'libmvector_emu.so')
+    stamp = os.path.join(OUT, 'stamp')
+    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+        return lib
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(OUT, os.path.basename(s) + '.o')
+        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-DMV_EMU', '-include',
+               os.path.join(HERE, 'hip_emu.h'), '-Wno-unused-value', '-c', s, '-o', o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('emu build failed:\n' + ' '.join(cmd) + '\n' + out.decode())
+        if verbose and out:
+            print(out.decode())
+    subprocess.check_call([CLANG, '-shared', '-o', lib] + objs)
+    open(stamp, 'w').write(h.hexdigest())
+    return lib
+
+
+if __name__ == '__main__':
+    print(build(verbose=True))

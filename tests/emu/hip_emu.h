@@ -1,0 +1,355 @@
+// Minimal SIMT emulator for the HIP dialect used by csrc/*.hip.  TEST INFRASTRUCTURE ONLY.
+//
+// There is no GPU in the build container, so the kernels' *source* is additionally compiled for the
+// host (clang++ -x c++ -DMV_EMU -include hip_emu.h) and executed by this emulator in the CPU test-suite:
+// every thread of a block is a ucontext fiber, blocks run one after another, __syncthreads / wave
+// collectives (shuffles, MFMA) are cooperative barriers.  It checks indexing, fragment layouts, LDS
+// addressing and host orchestration -- not performance, and it is never reachable from the product
+// path: only tests/ builds and loads tests/emu/build/libmvector_emu.so.
+//
+// Layouts emulated (cdna_hip_programming.md section 3):
+//   mfma_f32_16x16x32_f16 : A[i=lane&15][k=8*(lane>>4)+e], B[k=8*(lane>>4)+e][j=lane&15],
+//                           D[row=4*(lane>>4)+r][col=lane&15]
+//   mfma_f32_32x32x16_f16 : A[i=lane&31][k=8*(lane>>5)+e], B[k][j=lane&31],
+//                           D[row=(r&3)+8*(r>>2)+4*(lane>>5)][col=lane&31]
+//   mfma_f32_16x16x4f32   : A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D as 16x16 above
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct emu_dim3 {
+    unsigned x, y, z;
+    emu_dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef emu_dim3 dim3;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+
+namespace emu {
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+
+struct State {
+    emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    int cur = 0;
+    int nthreads = 0;
+    unsigned long bar_gen = 0;
+    int bar_count = 0;
+    std::vector<unsigned long> wave_gen;
+    std::vector<int> wave_count;
+    std::vector<int> wave_live;
+    unsigned long progress = 0;
+    std::vector<char> dyn_smem;
+    std::function<void()> body;
+    // wave scratch for collectives: 64 lanes x 64 bytes x 2 operands
+    std::vector<unsigned char> scratch;
+};
+
+inline State& S() {
+    static State s;
+    return s;
+}
+
+static const size_t kStack = 256 * 1024;
+
+inline void yield() {
+    State& s = S();
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline int flat_tid() {
+    State& s = S();
+    return s.threadIdx.x + s.blockDim.x * (s.threadIdx.y + s.blockDim.y * s.threadIdx.z);
+}
+
+inline void syncthreads() {
+    State& s = S();
+    unsigned long gen = s.bar_gen;
+    if (++s.bar_count == s.nthreads) {
+        s.bar_count = 0;
+        s.bar_gen++;
+        s.progress++;
+    } else {
+        while (s.bar_gen == gen) yield();
+    }
+}
+
+inline void wave_sync() {
+    State& s = S();
+    int w = flat_tid() / 64;
+    unsigned long gen = s.wave_gen[w];
+    if (++s.wave_count[w] == s.wave_live[w]) {
+        s.wave_count[w] = 0;
+        s.wave_gen[w]++;
+        s.progress++;
+    } else {
+        while (s.wave_gen[w] == gen) yield();
+    }
+}
+
+inline unsigned char* wave_slot(int operand, int lane) {
+    State& s = S();
+    int w = flat_tid() / 64;
+    return s.scratch.data() + ((size_t)(w * 2 + operand) * 64 + lane) * 64;
+}
+
+inline void trampoline() {
+    State& s = S();
+    s.body();
+    s.fibers[s.cur].done = true;
+    s.progress++;
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<void()> body) {
+    State& s = S();
+    s.gridDim = grid;
+    s.blockDim = block;
+    s.nthreads = block.x * block.y * block.z;
+    int nwaves = (s.nthreads + 63) / 64;
+    s.body = body;
+    if ((int)s.fibers.size() < s.nthreads) {
+        size_t old = s.fibers.size();
+        s.fibers.resize(s.nthreads);
+        for (size_t i = old; i < s.fibers.size(); ++i) s.fibers[i].stack = (char*)malloc(kStack);
+    }
+    s.scratch.assign((size_t)nwaves * 2 * 64 * 64, 0);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                s.blockIdx = emu_dim3(bx, by, bz);
+                s.dyn_smem.assign(shmem + 64, 0);
+                s.bar_count = 0;
+                s.wave_gen.assign(nwaves, 0);
+                s.wave_count.assign(nwaves, 0);
+                s.wave_live.assign(nwaves, 0);
+                for (int t = 0; t < s.nthreads; ++t) s.wave_live[t / 64]++;
+                for (int t = 0; t < s.nthreads; ++t) {
+                    Fiber& f = s.fibers[t];
+                    f.done = false;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                int live = s.nthreads;
+                while (live > 0) {
+                    unsigned long before = s.progress;
+                    live = 0;
+                    for (int t = 0; t < s.nthreads; ++t) {
+                        if (s.fibers[t].done) continue;
+                        s.cur = t;
+                        s.threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        swapcontext(&s.sched, &s.fibers[t].ctx);
+                        if (!s.fibers[t].done) live++;
+                    }
+                    if (live > 0 && s.progress == before) {
+                        fprintf(stderr, "hip_emu: deadlock in block (%u,%u,%u): %d threads stuck at a barrier\n", bx, by,
+                                bz, live);
+                        abort();
+                    }
+                }
+            }
+}
+
+template <typename T>
+inline T shfl_from(T v, int src_lane) {
+    static_assert(sizeof(T) <= 64, "shuffle payload too large");
+    int lane = flat_tid() & 63;
+    memcpy(wave_slot(0, lane), &v, sizeof(T));
+    wave_sync();
+    T r;
+    memcpy(&r, wave_slot(0, src_lane & 63), sizeof(T));
+    wave_sync();
+    return r;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::S().threadIdx)
+#define blockIdx (emu::S().blockIdx)
+#define blockDim (emu::S().blockDim)
+#define gridDim (emu::S().gridDim)
+#define warpSize 64
+
+inline void __syncthreads() { emu::syncthreads(); }
+
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = emu::flat_tid() & 63;
+    return emu::shfl_from(v, lane ^ mask);
+}
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+    int lane = emu::flat_tid() & 63;
+    int base = lane & ~(width - 1);
+    return emu::shfl_from(v, base + (src & (width - 1)));
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int lane = emu::flat_tid() & 63;
+    int in = lane & (width - 1);
+    int src = (in + (int)delta < width) ? lane + (int)delta : lane;
+    return emu::shfl_from(v, src);
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    int lane = emu::flat_tid() & 63;
+    int in = lane & (width - 1);
+    int src = (in >= (int)delta) ? lane - (int)delta : lane;
+    return emu::shfl_from(v, src);
+}
+
+inline float atomicAdd(float* p, float v) {
+    float o = *p;
+    *p = o + v;
+    return o;
+}
+inline int atomicAdd(int* p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+inline unsigned atomicAdd(unsigned* p, unsigned v) {
+    unsigned o = *p;
+    *p = o + v;
+    return o;
+}
+
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float __frcp_rn(float a) { return 1.0f / a; }
+inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
+// ---- MFMA emulation ---------------------------------------------------------------------------
+typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
+typedef float emu_float4 __attribute__((ext_vector_type(4)));
+typedef float emu_float16 __attribute__((ext_vector_type(16)));
+
+inline emu_float4 emu_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_float4 c) {
+    int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 16);
+    memcpy(emu::wave_slot(1, lane), &b, 16);
+    emu::wave_sync();
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            emu_half8 av, bv;
+            memcpy(&av, emu::wave_slot(0, row + 16 * (k / 8)), 16);
+            memcpy(&bv, emu::wave_slot(1, col + 16 * (k / 8)), 16);
+            acc += (float)av[k % 8] * (float)bv[k % 8];
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
+inline emu_float16 emu_mfma_f32_32x32x16_f16(emu_half8 a, emu_half8 b, emu_float16 c) {
+    int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 16);
+    memcpy(emu::wave_slot(1, lane), &b, 16);
+    emu::wave_sync();
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            emu_half8 av, bv;
+            memcpy(&av, emu::wave_slot(0, row + 32 * (k / 8)), 16);
+            memcpy(&bv, emu::wave_slot(1, col + 32 * (k / 8)), 16);
+            acc += (float)av[k % 8] * (float)bv[k % 8];
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
+inline emu_float4 emu_mfma_f32_16x16x4f32(float a, float b, emu_float4 c) {
+    int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 4);
+    memcpy(emu::wave_slot(1, lane), &b, 4);
+    emu::wave_sync();
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, emu::wave_slot(0, row + 16 * k), 4);
+            memcpy(&bv, emu::wave_slot(1, col + 16 * k), 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_f16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_f16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
+
+// ---- tiny runtime shim (device memory == host memory) ---------------------------------------------
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = malloc(n ? n : 1);
+    return *p ? 0 : 2;
+}
+inline hipError_t hipFree(void* p) {
+    free(p);
+    return 0;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) {
+    memmove(d, s, n);
+    return 0;
+}
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) {
+    memmove(d, s, n);
+    return 0;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    memset(d, v, n);
+    return 0;
+}
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetDevice(int* d) {
+    *d = 0;
+    return 0;
+}
+
+#define MV_EMU_DYN_SMEM() (reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(emu::S().dyn_smem.data()) + 63) & ~uintptr_t(63)))

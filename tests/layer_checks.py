@@ -1,0 +1,197 @@
+"""Layer-level parity checks shared by the emulator tests (CPU tensors, emu library) and the GPU tests (CUDA
+tensors, product library).  Every check drives one exported C-ABI entry point with seeded inputs and compares
+with a plain torch fp32 reference of the same op (inputs rounded to fp16 exactly as the kernel sees them)."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from mvector import _hip
+
+ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
+
+
+def _stream(t):
+    return _hip.current_stream(t)
+
+
+def pack_weight(cdll, w):
+    """w: [Cout, Cin, k] fp32 on device -> packed fp16 buffer (torch.float16 tensor)."""
+    cout, cin, k = w.shape
+    n = cdll.mv_conv1d_packed_elems(cout, cin, k)
+    packed = torch.zeros(n, dtype=torch.float16, device=w.device)
+    _hip.check(cdll.mv_conv1d_pack_weight(w.contiguous().data_ptr(), cout, cin, k, packed.data_ptr(), _stream(w)), cdll)
+    return packed
+
+
+def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
+                x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
+                row_bias=False, gate_seg=0, extra_ld=8, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    ldx = cin + extra_ld
+    xfull = rn(B, T, ldx)
+    x2full = rn(B, T, ldx) if with_x2 else None
+    w = rn(cout, cin, k) * (2.0 / (cin * k)) ** 0.5
+    bias = rn(cout) * 0.1
+    scale = torch.rand(cout, generator=g) + 0.5 if affine else None
+    shift = rn(cout) * 0.1 if affine else None
+    in_s = torch.rand(cin, generator=g) + 0.5 if in_affine else None
+    in_t = rn(cin) * 0.2 if in_affine else None
+    pad = 0 if valid else dil * (k - 1) // 2
+    T_out = (T + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    rb = rn(B, cout) * 0.3 if row_bias else None
+    nseg = -(-T_out // gate_seg) if gate_seg else 0
+    gate = torch.rand(B, nseg, cout, generator=g) if gate_seg else None
+
+    xdt = torch.float32 if x_f32 else torch.float16
+    xd = xfull.to(xdt).to(device)
+    x2d = x2full.to(xdt).to(device) if with_x2 else None
+    ldy = cout + extra_ld
+    y = torch.full((B, T_out, ldy), 7.0, dtype=torch.float32 if y_f32 else torch.float16, device=device)
+    wd = w.to(device)
+    packed = pack_weight(cdll, wd)
+    dev = lambda t: None if t is None else t.to(device).contiguous()
+    biasd, scaled, shiftd, in_sd, in_td, rbd, gated = map(dev, (bias, scale, shift, in_s, in_t, rb, gate))
+    d = _hip.MvConv1dDesc()
+    d.x, d.x2 = xd.data_ptr(), (x2d.data_ptr() if with_x2 else None)
+    d.x_dtype = _hip.MV_DT_F32 if x_f32 else _hip.MV_DT_F16
+    d.ldx = d.ldx2 = ldx
+    d.in_scale, d.in_shift = (in_sd.data_ptr(), in_td.data_ptr()) if in_affine else (None, None)
+    d.w_packed, d.bias = packed.data_ptr(), biasd.data_ptr()
+    d.row_bias = rbd.data_ptr() if row_bias else None
+    d.pre_act, d.post_act = pre_act, post_act
+    d.scale, d.shift = (scaled.data_ptr(), shiftd.data_ptr()) if affine else (None, None)
+    d.gate, d.gate_seg_len = (gated.data_ptr(), gate_seg) if gate_seg else (None, 0)
+    d.y, d.y_dtype, d.ldy = y.data_ptr(), (_hip.MV_DT_F32 if y_f32 else _hip.MV_DT_F16), ldy
+    d.B, d.T_in, d.T_out, d.cin, d.cout, d.k = B, T, T_out, cin, cout, k
+    d.dilation, d.stride, d.pad = dil, stride, pad
+    d.pad_mode = _hip.MV_PAD_REFLECT if pad_mode == 'reflect' else _hip.MV_PAD_ZERO
+    _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xd)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+
+    # ---- torch fp32 reference on the values the kernel actually consumes ----
+    xin = xd.cpu().float()[..., :cin]
+    if with_x2:
+        xin = xin + x2d.cpu().float()[..., :cin]
+    if in_affine:
+        xin = torch.relu(xin * in_s + in_t)
+    xin = xin.half().float().transpose(1, 2)
+    if pad:
+        xin = F.pad(xin, (pad, pad), mode='reflect' if pad_mode == 'reflect' else 'constant')
+    ref = F.conv1d(xin, w.half().float(), bias, stride=stride, dilation=dil)
+    if row_bias:
+        ref = ref + rb.unsqueeze(2)
+    ref = ACT[pre_act](ref)
+    if affine:
+        ref = ref * scale.view(1, -1, 1) + shift.view(1, -1, 1)
+    ref = ACT[post_act](ref).transpose(1, 2)
+    if gate_seg:
+        seg = torch.arange(T_out) // gate_seg
+        ref = ref * gate[:, seg, :]
+    got = y.cpu().float()
+    assert torch.all(got[..., cout:] == 7.0), 'kernel wrote outside its channel slice'
+    err = (got[..., :cout] - ref).abs().max().item()
+    tol = 2e-4 if y_f32 else 4e-3 * max(1.0, ref.abs().max().item())
+    assert err < tol, f'conv1d mismatch {err} (tol {tol})'
+    return err
+
+
+CONV_CASES = [
+    dict(),                                                           # reflect k3 d2
+    dict(k=5, dil=1, cin=80, cout=64, x_f32=True, T=50),              # first layer: fp32 features in
+    dict(k=1, dil=1, cin=136, cout=200, T=70, B=3),                   # 1x1, several K stages, 2 co tiles
+    dict(k=3, dil=4, with_x2=True, cin=16, cout=16),                  # Res2Net step
+    dict(k=3, dil=3, valid=True, pad_mode='zero', T=40),              # TDNN unpadded conv
+    dict(k=5, dil=1, stride=2, pad_mode='zero', cin=320, cout=128, T=61),  # CAM++ strided TDNN
+    dict(k=1, dil=1, in_affine=True, pre_act=0, affine=True, post_act=1, cin=160, cout=128),  # CAM++ dense bottleneck
+    dict(k=3, dil=2, pad_mode='zero', pre_act=0, affine=False, gate_seg=10, cin=128, cout=32, T=45),  # CAM layer
+    dict(k=1, dil=1, row_bias=True, post_act=2, cin=192, cout=128, T=33),  # ASP attention hidden layer
+    dict(k=1, dil=1, y_f32=True, pre_act=0, affine=False, cin=64, cout=20, T=9, B=5),  # fp32 out, ragged cout
+    dict(k=3, dil=1, B=1, T=300, cin=8, cout=8, extra_ld=56),         # many n tiles, narrow slice of a wide row
+]
+
+
+def linear_case(cdll, device, B=5, K=100, O=37, act=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(O, K, generator=g) / K ** 0.5
+    b = torch.randn(O, generator=g)
+    xd, wd, bd = x.to(device), w.to(device), b.to(device)
+    y = torch.empty(B, O, device=device)
+    _hip.check(cdll.mv_linear_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), act, y.data_ptr(), O, B, K, O, _stream(xd)), cdll)
+    ref = ACT[act](x.double() @ w.double().t() + b.double()).float()
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()) + 1e-5, err
+    return err
+
+
+def cosine_case(cdll, device, a, b, expect):
+    s = _hip.cosine(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), cdll=cdll).cpu().numpy()
+    err = np.abs(s - expect).max()
+    assert err < 2e-6, err
+    return err
+
+
+def time_stats_case(cdll, device, B=3, T=29, C=520, ld=528, unbiased=0, eps=1e-12, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, T, ld, generator=g) * 2 + 0.5).half()
+    x[:, :, 3] = 1.25  # constant channel: variance must be exactly clamped
+    xd = x.to(device)
+    mean = torch.empty(B, C, device=device)
+    std = torch.empty(B, C, device=device)
+    _hip.check(cdll.mv_time_stats_f16(xd.data_ptr(), ld, B, T, C, mean.data_ptr(), std.data_ptr(), unbiased, eps, _stream(xd)), cdll)
+    xf = x.float()[..., :C]
+    rm = xf.mean(1)
+    var = ((xf - rm.unsqueeze(1)) ** 2).sum(1) / (T - 1 if unbiased else T)
+    rs = torch.sqrt(var.clamp(eps) if eps > 0 else var)
+    e1 = (mean.cpu() - rm).abs().max().item()
+    e2 = (std.cpu() - rs).abs().max().item()
+    assert e1 < 1e-5 and e2 < 1e-5, (e1, e2)
+    return e1, e2
+
+
+def fbank_case(cdll, device, wav, ratio, method_args):
+    from oracle import frontend
+    fb = _hip.Fbank(method_args, cdll=cdll)
+    out = fb(wav.to(device), None if ratio is None else ratio.to(device)).cpu()
+    ref = frontend.audio_featurizer(wav, ratio, 'Fbank', method_args)
+    assert out.shape == ref.shape
+    d = (out - ref).abs()
+    # near the log floor both fp32 implementations carry ~3e-4 of noise against an fp64 evaluation
+    assert d.max().item() < 2e-3, d.max().item()
+    assert d.mean().item() < 2e-5, d.mean().item()
+    return d.max().item()
+
+
+def model_case(cdll, device, case, tol=1e-4):
+    """Golden case through the native model handle (weights from the manifest, reference embedding from golden)."""
+    from helpers import load_case, cos_dist
+    man, sd, x, emb_ref, _ = load_case(case)
+    kw = man['kwargs']
+    if man['model'] == 'EcapaTdnn':
+        cfg = _hip.MvEcapaCfg()
+        cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 192)
+        ch = kw.get('channels', [512, 512, 512, 512, 1536])
+        for i in range(5):
+            cfg.channels[i], cfg.kernel_sizes[i], cfg.dilations[i] = ch[i], [5, 3, 3, 3, 1][i], [1, 2, 3, 4, 1][i]
+        cfg.attention_channels, cfg.res2net_scale, cfg.se_channels, cfg.global_context = 128, 8, 128, 1
+        kind = 'ecapa'
+    elif man['model'] == 'TDNN':
+        cfg = _hip.MvTdnnCfg()
+        cfg.input_size, cfg.channels, cfg.embd_dim = kw['input_size'], kw.get('channels', 512), kw.get('embd_dim', 192)
+        kind = 'tdnn'
+    else:
+        cfg = _hip.MvCamppCfg()
+        cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 512)
+        cfg.growth_rate, cfg.bn_size, cfg.init_channels = 32, 4, 128
+        kind = 'campp'
+    sd_dev = {k: v.to(device) for k, v in sd.items()}
+    m = _hip.Model(kind, cfg, sd_dev, cdll=cdll)
+    emb = m.forward(x.to(device)).cpu()
+    cd = cos_dist(emb, emb_ref).max().item()
+    rel = ((emb - emb_ref).norm(dim=1) / emb_ref.norm(dim=1)).max().item()
+    assert cd < tol, f'{case}: 1-cos {cd}'
+    return cd, rel

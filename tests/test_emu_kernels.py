@@ -1,0 +1,76 @@
+"""CPU tests that execute the HIP kernel SOURCES under the SIMT emulator (tests/emu/hip_emu.h): indexing,
+MFMA fragment layouts, LDS addressing and the native model orchestration are checked against the oracle / golden
+vectors without a GPU.  The emulator library is test infrastructure; the product never loads it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import layer_checks as lc
+from emu_lib import emu_cdll
+from helpers import GOLDEN
+from oracle import frontend
+
+FB = dict(sample_frequency=16000, num_mel_bins=80)
+
+
+@pytest.mark.parametrize('idx', range(len(lc.CONV_CASES)))
+def test_emu_conv1d(idx):
+    lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
+
+
+def test_emu_conv1d_rejects_bad_arguments():
+    with pytest.raises(RuntimeError, match='reflect padding'):
+        lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)
+
+
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2)])
+def test_emu_linear(shape):
+    B, K, O, act = shape
+    lc.linear_case(emu_cdll(), 'cpu', B, K, O, act)
+
+
+def test_emu_cosine_matches_sklearn_golden():
+    z = np.load(os.path.join(GOLDEN, 'cosine.npz'))
+    lc.cosine_case(emu_cdll(), 'cpu', z['a'], z['b'], z['sim'])
+
+
+@pytest.mark.parametrize('unbiased,eps', [(0, 1e-12), (1, 0.0)])
+def test_emu_time_stats(unbiased, eps):
+    lc.time_stats_case(emu_cdll(), 'cpu', unbiased=unbiased, eps=eps)
+
+
+def test_emu_fbank_fixed_and_ragged():
+    wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)  # odd stride -> scalar-load path
+    wav[2, 9000:] = 0
+    ratio = torch.tensor([1.0, 0.61, 9000 / 16037])
+    lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)
+    wav2 = frontend.synth_waveforms(2, 8000, seed=4)        # aligned float2 path, no mask
+    lc.fbank_case(emu_cdll(), 'cpu', wav2, None, FB)
+
+
+def test_emu_fbank_real_audio_golden():
+    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    wav = torch.from_numpy(z['pcm16'][:2].astype(np.float32) / 32768.0)
+    fb = lc._hip.Fbank(FB, cdll=emu_cdll())
+    out = fb(wav)
+    assert np.abs(out.numpy() - z['fbank'][:2]).max() < 2e-3
+
+
+def test_emu_fbank_edge_cases():
+    fb = lc._hip.Fbank(FB, cdll=emu_cdll())
+    assert fb(torch.zeros(2, 399)).shape == (2, 0, 80)           # shorter than one window: empty
+    out = fb(torch.zeros(1, 400 + 160 * 5))                       # silence: log floor everywhere -> zero after CMN
+    assert out.shape == (1, 6, 80) and out.abs().max() < 1e-5
+    fb23 = lc._hip.Fbank(dict(sample_frequency=16000), cdll=emu_cdll())  # torchaudio default 23 bins
+    w = frontend.synth_waveforms(1, 4000, seed=9)
+    ref = frontend.audio_featurizer(w, None, 'Fbank', dict(sample_frequency=16000))
+    assert (fb23(w) - ref).abs().max() < 2e-3
+    with pytest.raises(RuntimeError, match='512-point'):
+        lc._hip.Fbank(dict(sample_frequency=8000, num_mel_bins=40), cdll=emu_cdll())
+
+
+def test_emu_ecapa_tiny_end_to_end():
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'ecapa_tiny')
+    assert rel < 5e-3

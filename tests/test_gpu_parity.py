@@ -1,0 +1,172 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against the oracle and the committed golden
+vectors.  Tolerances: Fbank features max-abs 2e-3 (both fp32 evaluations sit ~3e-4 from an fp64 evaluation near
+the log floor) and mean-abs 2e-5; embeddings 1 - cos <= 1e-4 (north_star); cosine scores 2e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import layer_checks as lc
+from helpers import GOLDEN, cos_dist, load_case
+from oracle import frontend, models as omodels
+
+pytestmark = pytest.mark.gpu
+FB = dict(sample_frequency=16000, num_mel_bins=80)
+DEV = 'cuda'
+
+
+def product_lib():
+    from mvector import _hip
+    return _hip.lib()
+
+
+def test_gpu_library_is_the_hip_build():
+    from mvector import _hip
+    lib = product_lib()
+    assert lib.mv_abi_version() == 1
+    assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
+
+
+@pytest.mark.parametrize('idx', range(len(lc.CONV_CASES)))
+def test_gpu_conv1d(idx):
+    lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])
+
+
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2)])
+def test_gpu_linear(shape):
+    lc.linear_case(product_lib(), DEV, *shape)
+
+
+def test_gpu_cosine_matches_sklearn_golden():
+    z = np.load(os.path.join(GOLDEN, 'cosine.npz'))
+    lc.cosine_case(product_lib(), DEV, z['a'], z['b'], z['sim'])
+
+
+@pytest.mark.parametrize('unbiased,eps', [(0, 1e-12), (1, 0.0)])
+def test_gpu_time_stats(unbiased, eps):
+    lc.time_stats_case(product_lib(), DEV, unbiased=unbiased, eps=eps)
+    lc.time_stats_case(product_lib(), DEV, B=7, T=298, C=3072, ld=3072, unbiased=unbiased, eps=eps, seed=2)
+
+
+def test_gpu_fbank_golden_fixed_and_ragged():
+    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    out = fb(wav.to(DEV)).cpu().numpy()
+    d = np.abs(out - z['fbank'])
+    assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+    lens = z['lens']
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(lens):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    outv = fb(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy()
+    dv = np.abs(outv - z['fbank_var'])
+    assert dv.max() < 2e-3 and dv.mean() < 2e-5, (dv.max(), dv.mean())
+    for i, n in enumerate(lens):  # frames beyond round_half_even(ratio*T) are exactly zero (Q2/Q3)
+        ml = int(torch.round(torch.tensor(n / 48000, dtype=torch.float32) * 298).item())
+        assert np.all(outv[i, ml:] == 0) and np.any(outv[i, ml - 1] != 0)
+
+
+def test_gpu_fbank_ragged_strides_and_edges():
+    wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)
+    wav[2, 9000:] = 0
+    lc.fbank_case(product_lib(), DEV, wav, torch.tensor([1.0, 0.61, 9000 / 16037]), FB)
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    assert fb(torch.zeros(2, 399, device=DEV)).shape == (2, 0, 80)
+    assert fb(torch.zeros(1, 1200, device=DEV)).abs().max().item() < 1e-5
+    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    real = torch.from_numpy(z['pcm16'].astype(np.float32) / 32768.0).to(DEV)
+    assert np.abs(fb(real).cpu().numpy() - z['fbank']).max() < 2e-3
+
+
+def test_gpu_fbank_full_batch_properties():
+    """BASELINE size (256 x 3 s): size-independent properties + spot check against the oracle."""
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    wav = frontend.synth_waveforms(256, 48000).to(DEV)
+    out = fb(wav)
+    assert out.shape == (256, 298, 80)
+    assert out.mean(1).abs().max().item() < 2e-4            # CMN: zero time-mean per (utterance, bin)
+    assert torch.equal(out, fb(wav))                         # deterministic
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    assert torch.equal(fb(wav[perm]), out[perm])             # utterances are independent
+    ref = frontend.audio_featurizer(wav[250:].cpu(), None, 'Fbank', FB)
+    assert (out[250:].cpu() - ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'tdnn'])
+def test_gpu_native_model_matches_reference_golden(case):
+    cd, rel = lc.model_case(product_lib(), DEV, case)
+    assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
+
+
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'tdnn'])
+def test_gpu_module_forward_uses_native_and_tracks_weights(case):
+    import mvector.models as M
+    man, sd, x, emb_ref, _ = load_case(case)
+    m = getattr(M, man['model'])(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    emb = m(x.to(DEV))
+    assert m.__dict__.get('_native_handles'), 'native handle was not created: forward did not take the HIP path'
+    assert cos_dist(emb.cpu(), emb_ref).max() < 1e-4
+    # loading different weights must invalidate the derived native copy
+    from oracle import weights
+    sd2 = weights.make_state_dict(man['shapes'], man['seed'] + 11)
+    m.load_state_dict(sd2)
+    emb2 = m(x.to(DEV)).cpu()
+    ref2 = omodels.FORWARDS[man['model']](sd2, x)
+    assert cos_dist(emb2, ref2).max() < 1e-4
+
+
+def test_gpu_end_to_end_waveform_to_embedding_full_batch():
+    """Config 2 shape (EcapaTdnn c=1024, bs=256, 3 s): spot parity vs the oracle + batch-invariance property."""
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    from mvector.models import EcapaTdnn
+    man, sd, _, _, _ = load_case('ecapa_c1024')
+    model = EcapaTdnn(**man['kwargs'])
+    model.load_state_dict(sd)
+    model.eval().to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+    wav = frontend.synth_waveforms(256, 48000)
+    emb = model(fz(wav.to(DEV)))
+    assert emb.shape == (256, 192) and torch.isfinite(emb).all()
+    ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[:2], None, 'Fbank', FB))
+    assert cos_dist(emb[:2].cpu(), ref).max() < 1e-4
+    small = model(fz(wav[100:104].to(DEV)))
+    assert cos_dist(small.cpu(), emb[100:104].cpu()).max() < 1e-6  # an utterance's embedding does not depend on its batch
+
+
+def test_gpu_predictor_matches_cpu_predictor(tmp_path):
+    """MVectorPredictor(use_gpu=True) vs (use_gpu=False) on the reference's sample audio (config 1: TDNN + Fbank)."""
+    import scipy.io.wavfile as wavfile
+    from mvector.predict import MVectorPredictor
+    from mvector.models import TDNN
+    man, sd, _, _, _ = load_case('tdnn')
+    model_dir = tmp_path / 'model'
+    model_dir.mkdir()
+    torch.save({'0.' + k: v for k, v in sd.items()}, str(model_dir / 'model.pth'))
+    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    paths = []
+    for i, pcm in enumerate(z['pcm16']):
+        p = str(tmp_path / f'u{i}.wav')
+        wavfile.write(p, 16000, pcm[: 16000 - 1500 * i])
+        paths.append(p)
+    cfg = dict(dataset_conf=dict(dataset=dict(min_duration=0.3, sample_rate=16000, use_dB_normalization=True, target_dB=-20),
+                                 eval_conf=dict(batch_size=2)),
+               preprocess_conf=dict(feature_method='Fbank', method_args=dict(sample_frequency=16000, num_mel_bins=80)),
+               model_conf=dict(model='TDNN', model_args=dict(embd_dim=192)))
+    gpu = MVectorPredictor(cfg, model_path=str(model_dir), use_gpu=True)
+    e_gpu = gpu.predict_batch(paths)
+    one = gpu.predict(paths[1])
+    c_gpu = gpu.contrast(paths[0], paths[2])
+    cpu = MVectorPredictor(cfg, model_path=str(model_dir), use_gpu=False)
+    e_cpu = cpu.predict_batch(paths)
+    assert e_gpu.shape == (4, 192)
+    assert cos_dist(e_gpu, e_cpu).max() < 1e-4
+    assert cos_dist(one, cpu.predict(paths[1])).max() < 1e-4
+    assert abs(c_gpu - cpu.contrast(paths[0], paths[2])) < 1e-3

@@ -1,0 +1,49 @@
+"""CPU checks of the built product library: it exists, exports every symbol include/mvector_hip.h declares,
+and the Python binding refuses to run without it (no fallback).  No compute calls are made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, PKG
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'mvector_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mv_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_built_and_exports_every_declared_symbol():
+    import __graft_entry__
+    lib = __graft_entry__.build()
+    cdll = ctypes.CDLL(lib)
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(cdll, s)]
+    assert not missing, missing
+    from mvector import _hip
+    assert set(_hip.EXPORTED_SYMBOLS) == set(syms)
+    _hip.bind(cdll)
+    assert cdll.mv_abi_version() == 1
+    assert cdll.mv_conv1d_packed_elems(192, 80, 5) == 192 * 5 * 128
+
+
+def test_binding_fails_loudly_without_library(monkeypatch):
+    from mvector import _hip
+    monkeypatch.setattr(_hip, '_lib', None)
+    monkeypatch.setattr(_hip, 'LIB_PATH', os.path.join(PKG, 'mvector', 'lib', 'does_not_exist.so'))
+    with pytest.raises(RuntimeError, match='has not been built'):
+        _hip.lib()
+
+
+def test_product_package_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cpp', '.h')):
+                src = open(os.path.join(dirpath, f), errors='ignore').read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M) or 'oracle/' in src and f.endswith('.py') and 'import' in src and re.search(r'import.*oracle', src):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,60 @@
+"""Build mvector/lib/libmvector_hip.so: every csrc/*.hip / *.cpp compiled by hipcc for gfx950 (MI355X).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is git-ignored but travels
+to the GPU box with the tree.  No other architecture, no CPU build of the product library."""
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT_DIR = os.path.join(HERE, 'mvector', 'lib')
+OBJ_DIR = os.path.join(HERE, 'build')
+LIB = os.path.join(OUT_DIR, 'libmvector_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG']
+
+
+def _digest(paths):
+    h = hashlib.sha1(' '.join(FLAGS).encode())
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'mvector_hip.h')]
+    hdr_digest = _digest(headers)
+    procs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ_DIR, os.path.basename(s) + '.o')
+        stamp = o + '.stamp'
+        want = _digest([s]) + hdr_digest
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == want:
+            continue
+        cmd = [HIPCC] + FLAGS + ['-x', 'hip', '-c', s, '-o', o]
+        procs.append((s, cmd, stamp, want, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    rebuilt = False
+    for s, cmd, stamp, want, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n' + out.decode())
+        if verbose and out:
+            print(out.decode())
+        with open(stamp, 'w') as f:
+            f.write(want)
+        rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,23 @@
+// Internal launch functions shared between the layer-level C ABI and the model forwards.
+#pragma once
+#include "common.h"
+
+namespace mv {
+
+int conv1d_cin_pad(int cin);
+int conv1d_cout_pad(int cout);
+int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream);
+
+int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
+                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream);
+
+int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
+                      int unbiased, float clamp_eps, hipStream_t stream);
+int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream);
+int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
+                            int64_t ldo, int B, int T, int C, hipStream_t stream);
+int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream);
+int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,
+                    const float* gmean, int64_t gmean_ld, float* out, int B, int T, int C, int A, hipStream_t stream);
+
+}  // namespace mv

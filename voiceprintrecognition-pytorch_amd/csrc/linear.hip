@@ -1,0 +1,149 @@
+// Small exact-fp32 dense layers on the f32 MFMA (v_mfma_f32_16x16x4_f32) and cosine scoring.
+//
+// Used for the parts of the path whose inputs are per-utterance vectors, where precision matters more
+// than rate and the work is tiny:
+//   * SE excitation FCs (mvector/models/ecapa_tdnn.py:81-82), CAM context FCs (campplus.py:97-98),
+//   * the hoisted ASP context term W[:, C:3C] . [mean; std] (pooling.py:110-117),
+//   * asp_bn folded into fc (ecapa_tdnn.py:278-281), TDNN linear + bn6 (tdnn.py:66-67),
+//     CAM++ dense layer (campplus.py:200-216),
+//   * cosine scoring (predict.py:169-183, 275-279; trainer.py:454-461).
+//
+// One workgroup (4 waves) computes one 16 (rows of x) x 16 (outputs) tile; the four waves split K and
+// reduce through LDS.  Each lane loads float4 of x and of w along K (16 rows x 64 B per instruction) and
+// feeds the four components to four MFMAs, which is a consistent permutation of the K index for both
+// operands.
+#include "common.h"
+
+namespace mv {
+
+__device__ __forceinline__ float lin_act(float v, int act) {
+    if (act == MV_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == MV_ACT_TANH) return tanhf(v);
+    if (act == MV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ float4v load4_guard(const float* row, int k, int K, bool vec_ok) {
+    if (vec_ok && k + 3 < K) return *reinterpret_cast<const float4v*>(row + k);
+    float4v v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? row[k + e] : 0.0f;
+    return v;
+}
+
+// y[b, o] = act( sum_k x[b,k] w[o,k] + bias[o] );  with `cosine` set the dot product is divided by the two
+// row norms |x_b| |w_o| (accumulated in the same K loop), i.e. sklearn's cosine_similarity.
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                                                         const float* bias, int act, float* y, int64_t ldy, int B,
+                                                         int K, int O, int cosine) {
+    __shared__ float red[4][16][17];
+    __shared__ float nrm[2][4][16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int g = lane >> 4;
+    const int o0 = blockIdx.x * 16;
+    const int b0 = blockIdx.y * 16;
+    const int br = (b0 + i < B) ? b0 + i : B - 1;  // clamp: duplicates are masked at the store
+    const int oc = (o0 + i < O) ? o0 + i : O - 1;
+    const float* xrow = x + (int64_t)br * ldx;
+    const float* wrow = w + (int64_t)oc * ldw;
+    const bool xvec = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    float4v acc = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    float sqx = 0.0f, sqw = 0.0f;
+    // wave `wave` takes K blocks of 16 with index == wave (mod 4)
+    for (int k0 = wave * 16; k0 < K; k0 += 64) {
+        const int k = k0 + 4 * g;
+        const float4v xa = load4_guard(xrow, k, K, xvec);
+        const float4v wb = load4_guard(wrow, k, K, wvec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], wb[e], acc, 0, 0, 0);
+        if (cosine) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sqx += xa[e] * xa[e];
+                sqw += wb[e] * wb[e];
+            }
+        }
+    }
+    if (cosine) {
+        sqx += __shfl_xor(sqx, 16);
+        sqx += __shfl_xor(sqx, 32);
+        sqw += __shfl_xor(sqw, 16);
+        sqw += __shfl_xor(sqw, 32);
+        if (g == 0) {
+            nrm[0][wave][i] = sqx;
+            nrm[1][wave][i] = sqw;
+        }
+    }
+    // lane holds D[row = 4g + r][col = i]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * g + r][i] = acc[r];
+    __syncthreads();
+    {
+        const int r = tid >> 4, c = tid & 15;
+        const int b = b0 + r, o = o0 + c;
+        if (b < B && o < O) {
+            float v = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
+            if (cosine) {
+                const float nx = sqrtf(nrm[0][0][r] + nrm[0][1][r] + nrm[0][2][r] + nrm[0][3][r]);
+                const float nw = sqrtf(nrm[1][0][c] + nrm[1][1][c] + nrm[1][2][c] + nrm[1][3][c]);
+                v = v / (fmaxf(nx, 1.17549435e-38f) * fmaxf(nw, 1.17549435e-38f));
+            }
+            if (bias != nullptr) v += bias[o];
+            y[(int64_t)b * ldy + o] = lin_act(v, act);
+        }
+    }
+}
+
+// inv[r] = 1 / max(|x_r|, tiny); optionally normalise in place
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(float* x, int n, int dim, float* inv, int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float* p = x + (int64_t)row * dim;
+    float s = 0.0f;
+    for (int k = lane; k < dim; k += 64) s += p[k] * p[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    const float nrm = sqrtf(s);
+    const float iv = 1.0f / fmaxf(nrm, 1.17549435e-38f);
+    if (inv != nullptr && lane == 0) inv[row] = iv;
+    if (normalize)
+        for (int k = lane; k < dim; k += 64) p[k] = p[k] / nrm;  // features / np.linalg.norm (predict.py:165-166)
+}
+
+int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
+                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "linear_f32: null tensor");
+    MV_REQUIRE(B > 0 && K > 0 && O > 0 && ldx >= K && ldw >= K && ldy >= O, "linear_f32: bad geometry");
+    MV_LAUNCH(linear_f32_kernel, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (256, 1, 1), 0, stream, x, ldx, w,
+              ldw, bias, act, y, ldy, B, K, O, cosine);
+    return check_launch("linear_f32_kernel");
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
+                  int32_t B, int32_t K, int32_t O, mv_stream_t stream) {
+    return mv::linear_f32_launch(x, ldx, w, K, bias, act, y, ldy, B, K, O, 0, static_cast<hipStream_t>(stream));
+}
+
+int mv_cosine_f32(const float* a, int32_t n, const float* b, int32_t m, int32_t dim, float* scores, mv_stream_t stream) {
+    if (n == 0 || m == 0) return MV_OK;
+    return mv::linear_f32_launch(a, dim, b, dim, nullptr, MV_ACT_NONE, scores, m, n, dim, m, 1,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int mv_l2_normalize_f32(float* x, int32_t n, int32_t dim, mv_stream_t stream) {
+    MV_REQUIRE(x != nullptr && n > 0 && dim > 0, "mv_l2_normalize_f32: bad argument");
+    MV_LAUNCH(mv::row_inv_norm_kernel, ((unsigned)mv::ceil_div(n, 4), 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), x, n,
+              dim, static_cast<float*>(nullptr), 1);
+    return mv::check_launch("row_inv_norm_kernel");
+}
+
+}  // extern "C"

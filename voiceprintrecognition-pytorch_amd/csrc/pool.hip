@@ -1,0 +1,412 @@
+// Time-axis reductions and the SE / attentive-statistics pooling kernels (channel-last fp16 activations).
+//
+//   time_stats_kernel    mean (and std) over T per (utterance, channel): SE squeeze (ecapa_tdnn.py:79),
+//                        ASP global context (pooling.py:104-109), CAM++ StatsPool (campplus.py:27-33)
+//   seg_mean_kernel      CAM context = mean over T + mean over 100-frame segments (campplus.py:94-111)
+//   se_gate_residual     out = gate[b, c] * y + residual (ecapa_tdnn.py:84,143), written into a channel slice
+//                        of the aggregation buffer so torch.cat (ecapa_tdnn.py:273) never materialises
+//   asp_pool_kernel      attention logits (128 -> C projection on MFMA), softmax over time and the weighted
+//                        mean / std (pooling.py:117-125) in one kernel: the [B, C, T] logits never exist
+#include "common.h"
+
+namespace mv {
+
+// ------------------------------------------------------------------------------------------------
+// mean / std over time.  Workgroup = (utterance, 512-channel group); lane owns 8 channels, waves split T.
+// Two passes (mean, then centred second moment) exactly like the reference's (x - mean)^2 form.
+__global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
+                                                         float* stdv, int64_t ld_out, int unbiased, float clamp_eps) {
+    __shared__ float red[4][512];
+    __shared__ float mu[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const bool active = c0 < C;
+    const int nvalid = active ? (C - c0 < 8 ? C - c0 : 8) : 0;
+    const half_t* xb = x + (int64_t)b * T * ld + c0;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+    if (active) {
+        for (int t = wave; t < T; t += 4) {
+            const half_t* p = xb + (int64_t)t * ld;
+            if (nvalid == 8) {
+                const half8v v = *reinterpret_cast<const half8v*>(p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            } else {
+                for (int e = 0; e < nvalid; ++e) s[e] += (float)p[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+    __syncthreads();
+    for (int c = tid; c < 512; c += 256) mu[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)T;
+    __syncthreads();
+    for (int c = tid; c < 512; c += 256)
+        if (blockIdx.x * 512 + c < C) mean[(int64_t)b * ld_out + blockIdx.x * 512 + c] = mu[c];
+    if (stdv == nullptr) return;
+    float m8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m8[e] = mu[lane * 8 + e];
+        s[e] = 0.0f;
+    }
+    if (active) {
+        for (int t = wave; t < T; t += 4) {
+            const half_t* p = xb + (int64_t)t * ld;
+            if (nvalid == 8) {
+                const half8v v = *reinterpret_cast<const half8v*>(p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)v[e] - m8[e];
+                    s[e] += d * d;
+                }
+            } else {
+                for (int e = 0; e < nvalid; ++e) {
+                    const float d = (float)p[e] - m8[e];
+                    s[e] += d * d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+    __syncthreads();
+    const float denom = unbiased ? (float)(T - 1) : (float)T;
+    for (int c = tid; c < 512; c += 256) {
+        if (blockIdx.x * 512 + c < C) {
+            float var = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / denom;
+            if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
+            stdv[(int64_t)b * ld_out + blockIdx.x * 512 + c] = sqrtf(var);
+        }
+    }
+}
+
+int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
+                      int unbiased, float clamp_eps, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && mean != nullptr && B > 0 && T > 0 && C > 0, "time_stats: bad argument");
+    MV_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
+    MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
+    if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
+    MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 512), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
+              ld_out, unbiased, clamp_eps);
+    return check_launch("time_stats_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CAM context: ctx[b, s, c] = mean_t x[b, t, c] + mean_{t in segment s} x[b, t, c]  (last segment divides by its
+// true length, campplus.py:103 avg_pool1d(ceil_mode=True)).  Workgroup = (utterance, 64-channel group... 8 ch/lane).
+__global__ __launch_bounds__(256) void seg_mean_kernel(const half_t* x, int64_t ld, int T, int C, int seg_len, int nseg,
+                                                       float* ctx) {
+    // each thread owns one channel; threads of a wave read 64 consecutive channels (128 B) per time step
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= C) return;
+    const half_t* xb = x + (int64_t)b * T * ld + c;
+    float total = 0.0f;
+    for (int s = 0; s < nseg; ++s) {
+        const int t0 = s * seg_len;
+        const int t1 = t0 + seg_len < T ? t0 + seg_len : T;
+        float acc = 0.0f;
+        for (int t = t0; t < t1; ++t) acc += (float)xb[(int64_t)t * ld];
+        total += acc;
+        ctx[((int64_t)b * nseg + s) * C + c] = acc / (float)(t1 - t0);
+    }
+    const float gm = total / (float)T;
+    for (int s = 0; s < nseg; ++s) ctx[((int64_t)b * nseg + s) * C + c] += gm;
+}
+
+int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && ctx != nullptr && B > 0 && T > 0 && C > 0 && seg_len > 0, "seg_mean: bad argument");
+    const int nseg = (int)ceil_div(T, seg_len);
+    MV_LAUNCH(seg_mean_kernel, ((unsigned)ceil_div(C, 256), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, seg_len, nseg,
+              ctx);
+    return check_launch("seg_mean_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[n, c] = gate[b(n), c] * y[n, c] + res[n, c]   (8 channels per thread, grid-stride)
+__global__ __launch_bounds__(256) void se_gate_residual_kernel(const half_t* y, int64_t ldy, const float* gate,
+                                                               const half_t* res, int64_t ldr, half_t* out, int64_t ldo,
+                                                               int T, int C, int64_t n_rows) {
+    const int cgroups = C / 8;
+    const int64_t total = n_rows * cgroups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / cgroups;
+        const int c = (int)(i - n * cgroups) * 8;
+        const int b = (int)(n / T);
+        const half8v yv = *reinterpret_cast<const half8v*>(y + n * ldy + c);
+        const half8v rv = *reinterpret_cast<const half8v*>(res + n * ldr + c);
+        const float4v g0 = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c);
+        const float4v g1 = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c + 4);
+        half8v ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = e < 4 ? g0[e] : g1[e - 4];
+            float v = g * (float)yv[e] + (float)rv[e];
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            ov[e] = (half_t)v;
+        }
+        *reinterpret_cast<half8v*>(out + n * ldo + c) = ov;
+    }
+}
+
+int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
+                            int64_t ldo, int B, int T, int C, hipStream_t stream) {
+    MV_REQUIRE(y != nullptr && gate != nullptr && res != nullptr && out != nullptr, "se_gate_residual: null tensor");
+    MV_REQUIRE(C % 8 == 0 && ldy % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0, "se_gate_residual: channels must be a multiple of 8");
+    const int64_t n_rows = (int64_t)B * T;
+    const int64_t total = n_rows * (C / 8);
+    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    MV_LAUNCH(se_gate_residual_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, y, ldy, gate, res, ldr, out, ldo, T, C, n_rows);
+    return check_launch("se_gate_residual_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// dst[n, 0:C] = src[n, 0:C] for channel-last fp16 rows with different leading dimensions (Res2Net slice 0
+// pass-through, ecapa_tdnn.py:43-44).
+__global__ __launch_bounds__(256) void copy_slice_kernel(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C,
+                                                         int64_t n_rows) {
+    const int cgroups = C / 8;
+    const int64_t total = n_rows * cgroups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / cgroups;
+        const int c = (int)(i - n * cgroups) * 8;
+        *reinterpret_cast<half8v*>(dst + n * ldd + c) = *reinterpret_cast<const half8v*>(src + n * lds_ + c);
+    }
+}
+
+int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream) {
+    MV_REQUIRE(C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_slice: channels must be a multiple of 8");
+    const int64_t total = n_rows * (C / 8);
+    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    MV_LAUNCH(copy_slice_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, lds_, dst, ldd, C, n_rows);
+    return check_launch("copy_slice_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attentive statistics pooling tail.  Workgroup = (utterance b, 64-channel tile); wave w walks the 16-row time
+// tiles w, w+4, ...  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :] + b2[c]  on MFMA 16x16x32 (A = W2 rows held in
+// registers for the whole kernel, B = h rows loaded straight into fragment layout), so each lane holds 4 consecutive
+// channels of one time step.  Pass 1 finds the per-channel max over T, pass 2 recomputes the logits (K is only the
+// attention width, 128) and accumulates  s0 = sum e, s1 = sum e*(x - g), s2 = sum e*(x - g)^2  with e = exp(l - max)
+// and g the global mean of the channel (keeps the second moment well conditioned; exact zero variance for
+// constant channels).   mean = g + s1/s0,  std = sqrt(clamp(s2/s0 - (s1/s0)^2, 1e-12)).
+// KS = K steps of 32 (attention width padded to a multiple of 64, at most 256).
+
+struct AspArgs {
+    const half_t* h;    // [B, T, A]
+    const half_t* w2;   // packed [C_pad][1][A_pad]
+    const float* b2;    // [C]
+    const half_t* x;    // [B, T, ldx]
+    int64_t ldx;
+    const float* gmean; // [B, gmean_ld] or null
+    int64_t gmean_ld;
+    float* out;         // [B, 2C]: mean | std
+    int T, C, C_pad, A, A_pad;
+    float eps;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
+    __shared__ float red[4][4][64];  // [wave][quantity][channel]
+    __shared__ float cmax[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int fr = lane & 15, fg = lane >> 4;
+    // A fragments: W2 rows c0 + mi*16 + fr, k = kk*32 + 8*fg .. +8
+    half8v wf[4][KS];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int row = c0 + mi * 16 + fr;
+            if (row < a.C_pad) {
+                wf[mi][kk] = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * fg);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[mi][kk][e] = (half_t)0.0f;
+            }
+        }
+    float bias[4][4], g[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = c0 + mi * 16 + 4 * fg + r;
+            bias[mi][r] = c < a.C ? a.b2[c] : 0.0f;
+            g[mi][r] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+        }
+    const half_t* hb = a.h + (int64_t)b * a.T * a.A;
+    const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
+    const int ntiles = (a.T + 15) / 16;
+
+    auto logits = [&](int t0, float4v (&l)[4]) {
+        const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
+        half8v hf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int k = kk * 32 + 8 * fg;
+            if (k + 8 <= a.A) {
+                hf[kk] = *reinterpret_cast<const half8v*>(hb + (int64_t)t * a.A + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hf[kk][e] = (k + e < a.A) ? hb[(int64_t)t * a.A + k + e] : (half_t)0.0f;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            l[mi] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
+        }
+    };
+
+    // ---- pass 1: per-channel max over time ----
+    float mx[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[mi][r] = -3.0e38f;
+    for (int tt = wave; tt < ntiles; tt += 4) {
+        float4v l[4];
+        logits(tt * 16, l);
+        if (tt * 16 + fr < a.T) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = mx[mi][r];
+            v = fmaxf(v, __shfl_xor(v, 1));
+            v = fmaxf(v, __shfl_xor(v, 2));
+            v = fmaxf(v, __shfl_xor(v, 4));
+            v = fmaxf(v, __shfl_xor(v, 8));
+            if (fr == 0) red[wave][0][mi * 16 + 4 * fg + r] = v;
+        }
+    __syncthreads();
+    if (tid < 64) cmax[tid] = fmaxf(fmaxf(red[0][0][tid], red[1][0][tid]), fmaxf(red[2][0][tid], red[3][0][tid]));
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[mi][r] = cmax[mi * 16 + 4 * fg + r];
+
+    // ---- pass 2: weights and shifted moments ----
+    float s0[4][4], s1[4][4], s2[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
+    for (int tt = wave; tt < ntiles; tt += 4) {
+        float4v l[4];
+        logits(tt * 16, l);
+        const int t = tt * 16 + fr;
+        if (t < a.T) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int c = c0 + mi * 16 + 4 * fg;
+                half4v xv;
+                if (c + 3 < a.C) {
+                    xv = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = expf(l[mi][r] - mx[mi][r]);
+                    const float d = (float)xv[r] - g[mi][r];
+                    s0[mi][r] += e;
+                    s1[mi][r] += e * d;
+                    s2[mi][r] += e * d * d;
+                }
+            }
+        }
+    }
+    __syncthreads();  // red[.][0] readers are done
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v0 = s0[mi][r], v1 = s1[mi][r], v2 = s2[mi][r];
+#pragma unroll
+            for (int m = 1; m <= 8; m <<= 1) {
+                v0 += __shfl_xor(v0, m);
+                v1 += __shfl_xor(v1, m);
+                v2 += __shfl_xor(v2, m);
+            }
+            if (fr == 0) {
+                const int ch = mi * 16 + 4 * fg + r;
+                red[wave][1][ch] = v0;
+                red[wave][2][ch] = v1;
+                red[wave][3][ch] = v2;
+            }
+        }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = c0 + tid;
+        if (c < a.C) {
+            const float z0 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            const float z1 = red[0][2][tid] + red[1][2][tid] + red[2][2][tid] + red[3][2][tid];
+            const float z2 = red[0][3][tid] + red[1][3][tid] + red[2][3][tid] + red[3][3][tid];
+            const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+            const float m1 = z1 / z0;
+            const float var = z2 / z0 - m1 * m1;
+            a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
+            a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+        }
+    }
+}
+
+int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,
+                    const float* gmean, int64_t gmean_ld, float* out, int B, int T, int C, int A, hipStream_t stream) {
+    MV_REQUIRE(h != nullptr && w2_packed != nullptr && b2 != nullptr && x != nullptr && out != nullptr, "asp_pool: null tensor");
+    MV_REQUIRE(B > 0 && T > 0 && C > 0 && A > 0, "asp_pool: bad geometry");
+    MV_REQUIRE(A % 8 == 0 && A <= 256, "asp_pool: attention width must be a multiple of 8 and <= 256");
+    MV_REQUIRE(ldx % 4 == 0 && C % 4 == 0, "asp_pool: channels must be a multiple of 4");
+    AspArgs a;
+    a.h = h;
+    a.w2 = w2_packed;
+    a.b2 = b2;
+    a.x = x;
+    a.ldx = ldx;
+    a.gmean = gmean;
+    a.gmean_ld = gmean_ld;
+    a.out = out;
+    a.T = T;
+    a.C = C;
+    a.A = A;
+    a.C_pad = (int)round_up(C, 32);
+    a.A_pad = (int)round_up(A, 64);
+    a.eps = 1e-12f;
+    const unsigned gx = (unsigned)ceil_div(C, 64);
+    switch (a.A_pad / 32) {
+        case 2: MV_LAUNCH(asp_pool_kernel<2>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
+        case 4: MV_LAUNCH(asp_pool_kernel<4>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
+        case 6: MV_LAUNCH(asp_pool_kernel<6>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
+        default: MV_LAUNCH(asp_pool_kernel<8>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
+    }
+    return check_launch("asp_pool_kernel");
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
+                      int32_t unbiased, float clamp_eps, mv_stream_t stream) {
+    return mv::time_stats_launch(reinterpret_cast<const half_t*>(x), ld, B, T, C, mean, std, C, unbiased, clamp_eps,
+                                 static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

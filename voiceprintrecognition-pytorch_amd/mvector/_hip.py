@@ -1,0 +1,332 @@
+"""ctypes binding of libmvector_hip.so (the C ABI declared in include/mvector_hip.h).
+
+This is the only place the Python package touches native code.  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError carrying ``mv_last_error()`` is raised.  Tensors are passed as raw
+``data_ptr()`` values together with the current HIP stream; PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmvector_hip.so')
+
+MV_ACT_NONE, MV_ACT_RELU, MV_ACT_TANH, MV_ACT_SIGMOID = 0, 1, 2, 3
+MV_PAD_ZERO, MV_PAD_REFLECT = 0, 1
+MV_DT_F32, MV_DT_F16 = 0, 1
+
+c_i32, c_i64, c_f32, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class MvFbankCfg(ctypes.Structure):
+    _fields_ = [('sample_frequency', c_f32), ('frame_length_ms', c_f32), ('frame_shift_ms', c_f32),
+                ('num_mel_bins', c_i32), ('low_freq', c_f32), ('high_freq', c_f32),
+                ('preemphasis_coefficient', c_f32), ('remove_dc_offset', c_i32), ('use_power', c_i32),
+                ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32)]
+
+
+class MvMelSpecCfg(ctypes.Structure):
+    _fields_ = [('sample_rate', c_i32), ('n_fft', c_i32), ('win_length', c_i32), ('hop_length', c_i32),
+                ('f_min', c_f32), ('f_max', c_f32), ('n_mels', c_i32), ('power', c_f32), ('center', c_i32),
+                ('subtract_time_mean', c_i32)]
+
+
+class MvTensorRef(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char_p), ('data', c_vp), ('numel', c_i64)]
+
+
+class MvEcapaCfg(ctypes.Structure):
+    _fields_ = [('input_size', c_i32), ('embd_dim', c_i32), ('channels', c_i32 * 5), ('kernel_sizes', c_i32 * 5),
+                ('dilations', c_i32 * 5), ('attention_channels', c_i32), ('res2net_scale', c_i32),
+                ('se_channels', c_i32), ('global_context', c_i32)]
+
+
+class MvCamppCfg(ctypes.Structure):
+    _fields_ = [('input_size', c_i32), ('embd_dim', c_i32), ('growth_rate', c_i32), ('bn_size', c_i32),
+                ('init_channels', c_i32)]
+
+
+class MvTdnnCfg(ctypes.Structure):
+    _fields_ = [('input_size', c_i32), ('channels', c_i32), ('embd_dim', c_i32)]
+
+
+class MvConv1dDesc(ctypes.Structure):
+    _fields_ = [('x', c_vp), ('x2', c_vp), ('x_dtype', c_i32), ('ldx', c_i64), ('ldx2', c_i64), ('in_scale', c_vp),
+                ('in_shift', c_vp), ('w_packed', c_vp), ('bias', c_vp), ('row_bias', c_vp), ('pre_act', c_i32),
+                ('scale', c_vp), ('shift', c_vp), ('post_act', c_i32), ('gate', c_vp), ('gate_seg_len', c_i32),
+                ('y', c_vp), ('y_dtype', c_i32), ('ldy', c_i64), ('B', c_i32), ('T_in', c_i32), ('T_out', c_i32),
+                ('cin', c_i32), ('cout', c_i32), ('k', c_i32), ('dilation', c_i32), ('stride', c_i32), ('pad', c_i32),
+                ('pad_mode', c_i32)]
+
+
+_SIGNATURES = {
+    'mv_last_error': (ctypes.c_char_p, []),
+    'mv_abi_version': (c_i32, []),
+    'mv_fbank_default_cfg': (None, [ctypes.POINTER(MvFbankCfg)]),
+    'mv_fbank_create': (c_i32, [ctypes.POINTER(MvFbankCfg), ctypes.POINTER(c_vp)]),
+    'mv_fbank_destroy': (c_i32, [c_vp]),
+    'mv_fbank_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    'mv_fbank_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'mv_melspec_default_cfg': (None, [ctypes.POINTER(MvMelSpecCfg)]),
+    'mv_melspec_create': (c_i32, [ctypes.POINTER(MvMelSpecCfg), ctypes.POINTER(c_vp)]),
+    'mv_melspec_destroy': (c_i32, [c_vp]),
+    'mv_melspec_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    'mv_melspec_workspace_bytes': (c_sz, [c_vp, c_i32, c_i64]),
+    'mv_melspec_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    'mv_ecapa_create': (c_i32, [ctypes.POINTER(MvEcapaCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
+    'mv_campp_create': (c_i32, [ctypes.POINTER(MvCamppCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
+    'mv_tdnn_create': (c_i32, [ctypes.POINTER(MvTdnnCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
+    'mv_model_destroy': (c_i32, [c_vp]),
+    'mv_model_embd_dim': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
+    'mv_model_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_sz)]),
+    'mv_model_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    'mv_cosine_f32': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    'mv_l2_normalize_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    'mv_conv1d_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
+    'mv_conv1d_pack_weight': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'mv_conv1d_forward': (c_i32, [ctypes.POINTER(MvConv1dDesc), c_vp]),
+    'mv_linear_f32': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def bind(cdll):
+    """Attach prototypes to a loaded library (also used by the test-suite for its emulator build)."""
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(cdll, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return cdll
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """The bound library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` or '
+                f'`python voiceprintrecognition-pytorch_amd/build_native.py`). There is no non-HIP device path.')
+        cdll = bind(ctypes.CDLL(LIB_PATH))
+        if cdll.mv_abi_version() != 1:
+            raise RuntimeError('libmvector_hip.so ABI version mismatch')
+        _lib = cdll
+    return _lib
+
+
+def check(rc, cdll=None):
+    if rc != 0:
+        cdll = cdll or lib()
+        raise RuntimeError(f'libmvector_hip: {cdll.mv_last_error().decode(errors="replace")} (code {rc})')
+
+
+def current_stream(tensor):
+    if tensor.is_cuda:
+        return torch.cuda.current_stream(tensor.device).cuda_stream
+    return None
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class Fbank:
+    """Handle of the fused Fbank + CMN + mask kernel (mv_fbank_*)."""
+
+    def __init__(self, method_args=None, subtract_time_mean=True, cdll=None):
+        self._cdll = cdll or lib()
+        cfg = MvFbankCfg()
+        self._cdll.mv_fbank_default_cfg(ctypes.byref(cfg))
+        args = dict(method_args or {})
+        mapping = {'sample_frequency': 'sample_frequency', 'frame_length': 'frame_length_ms',
+                   'frame_shift': 'frame_shift_ms', 'num_mel_bins': 'num_mel_bins', 'low_freq': 'low_freq',
+                   'high_freq': 'high_freq', 'preemphasis_coefficient': 'preemphasis_coefficient',
+                   'remove_dc_offset': 'remove_dc_offset', 'use_power': 'use_power', 'use_log_fbank': 'use_log_fbank'}
+        fixed = {'dither': 0.0, 'window_type': 'povey', 'snip_edges': True, 'use_energy': False, 'vtln_warp': 1.0,
+                 'subtract_mean': False, 'htk_compat': False, 'round_to_power_of_two': True, 'channel': (-1, 0),
+                 'min_duration': 0.0, 'raw_energy': True, 'energy_floor': (0.0, 1.0), 'blackman_coeff': 0.42,
+                 'vtln_low': 100.0, 'vtln_high': -500.0}
+        for k, v in args.items():
+            if k in mapping:
+                field = mapping[k]
+                typ = dict(MvFbankCfg._fields_)[field]
+                setattr(cfg, field, int(v) if typ is c_i32 else float(v))
+            elif k in fixed:
+                allowed = fixed[k] if isinstance(fixed[k], tuple) else (fixed[k],)
+                if v not in allowed:
+                    raise NotImplementedError(f'Fbank argument {k}={v!r} is not implemented by the HIP kernel')
+            else:
+                raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
+        cfg.subtract_time_mean = 1 if subtract_time_mean else 0
+        self.num_mel_bins = cfg.num_mel_bins
+        self._h = c_vp()
+        check(self._cdll.mv_fbank_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
+
+    def num_frames(self, num_samples):
+        t = c_i64()
+        check(self._cdll.mv_fbank_num_frames(self._h, num_samples, ctypes.byref(t)), self._cdll)
+        return t.value
+
+    def __call__(self, wav, lens_ratio=None):
+        assert wav.dim() == 2 and wav.dtype == torch.float32
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, L = wav.shape
+        T = self.num_frames(L)
+        out = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=wav.device)
+        if B == 0 or T == 0:
+            return out
+        if lens_ratio is not None:
+            lens_ratio = lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
+        check(self._cdll.mv_fbank_forward(self._h, wav.data_ptr(), B, L, wav.stride(0), _ptr(lens_ratio), out.data_ptr(),
+                                          current_stream(wav)), self._cdll)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._cdll.mv_fbank_destroy(self._h)
+        except Exception:
+            pass
+
+
+class MelSpec:
+    """Handle of the MelSpectrogram + CMN + mask path (mv_melspec_*)."""
+
+    def __init__(self, method_args=None, subtract_time_mean=True, cdll=None):
+        self._cdll = cdll or lib()
+        cfg = MvMelSpecCfg()
+        self._cdll.mv_melspec_default_cfg(ctypes.byref(cfg))
+        a = dict(method_args or {})
+        allowed = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
+                   'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale'}
+        for k in a:
+            if k not in allowed:
+                raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
+        if a.get('pad', 0) != 0 or a.get('normalized', False) or a.get('norm') is not None or \
+                a.get('mel_scale', 'htk') != 'htk' or a.get('pad_mode', 'reflect') != 'reflect' or \
+                a.get('onesided') not in (None, True):
+            raise NotImplementedError('MelSpectrogram option not implemented by the HIP kernel')
+        cfg.sample_rate = int(a.get('sample_rate', 16000))
+        cfg.n_fft = int(a.get('n_fft', 400))
+        win = a.get('win_length')
+        cfg.win_length = int(win if win is not None else cfg.n_fft)
+        hop = a.get('hop_length')
+        cfg.hop_length = int(hop if hop is not None else cfg.win_length // 2)
+        cfg.f_min = float(a.get('f_min', 0.0))
+        f_max = a.get('f_max')
+        cfg.f_max = float(f_max if f_max is not None else cfg.sample_rate // 2)
+        cfg.n_mels = int(a.get('n_mels', 128))
+        cfg.power = float(a.get('power', 2.0))
+        cfg.center = 1 if a.get('center', True) else 0
+        cfg.subtract_time_mean = 1 if subtract_time_mean else 0
+        self.n_mels = cfg.n_mels
+        self._h = c_vp()
+        check(self._cdll.mv_melspec_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
+
+    def num_frames(self, num_samples):
+        t = c_i64()
+        check(self._cdll.mv_melspec_num_frames(self._h, num_samples, ctypes.byref(t)), self._cdll)
+        return t.value
+
+    def __call__(self, wav, lens_ratio=None):
+        assert wav.dim() == 2 and wav.dtype == torch.float32
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, L = wav.shape
+        T = self.num_frames(L)
+        out = torch.empty((B, T, self.n_mels), dtype=torch.float32, device=wav.device)
+        if B == 0 or T == 0:
+            return out
+        if lens_ratio is not None:
+            lens_ratio = lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
+        nbytes = self._cdll.mv_melspec_workspace_bytes(self._h, B, L)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=wav.device)
+        check(self._cdll.mv_melspec_forward(self._h, wav.data_ptr(), B, L, wav.stride(0), _ptr(lens_ratio), out.data_ptr(),
+                                            ws.data_ptr(), nbytes, current_stream(wav)), self._cdll)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._cdll.mv_melspec_destroy(self._h)
+        except Exception:
+            pass
+
+
+class Model:
+    """Handle of a native backbone (mv_*_create / mv_model_forward) built from a reference-layout state_dict."""
+
+    def __init__(self, kind, cfg, state_dict, cdll=None):
+        self._cdll = cdll or lib()
+        names, tensors = [], []
+        for k, v in state_dict.items():
+            if not torch.is_floating_point(v):
+                continue  # num_batches_tracked
+            t = v.detach().to(torch.float32).contiguous()
+            names.append(k.encode())
+            tensors.append(t)
+        refs = (MvTensorRef * len(tensors))()
+        for i, (n, t) in enumerate(zip(names, tensors)):
+            refs[i].name = n
+            refs[i].data = t.data_ptr()
+            refs[i].numel = t.numel()
+        self._h = c_vp()
+        create = {'ecapa': self._cdll.mv_ecapa_create, 'campp': self._cdll.mv_campp_create,
+                  'tdnn': self._cdll.mv_tdnn_create}[kind]
+        if tensors and tensors[0].is_cuda:
+            torch.cuda.current_stream(tensors[0].device).synchronize()  # weights fully written before create() reads them
+        check(create(ctypes.byref(cfg), refs, len(tensors), ctypes.byref(self._h)), self._cdll)
+        e = c_i32()
+        check(self._cdll.mv_model_embd_dim(self._h, ctypes.byref(e)), self._cdll)
+        self.embd_dim = e.value
+        self._ws = None
+
+    def workspace_bytes(self, B, T):
+        n = c_sz()
+        check(self._cdll.mv_model_workspace_bytes(self._h, B, T, ctypes.byref(n)), self._cdll)
+        return n.value
+
+    def forward(self, feats):
+        assert feats.dim() == 3 and feats.dtype == torch.float32
+        feats = feats.contiguous()
+        B, T, _ = feats.shape
+        emb = torch.empty((B, self.embd_dim), dtype=torch.float32, device=feats.device)
+        if B == 0:
+            return emb
+        nbytes = self.workspace_bytes(B, T)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != feats.device:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
+        check(self._cdll.mv_model_forward(self._h, feats.data_ptr(), B, T, emb.data_ptr(), self._ws.data_ptr(),
+                                          self._ws.numel(), current_stream(feats)), self._cdll)
+        return emb
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._cdll.mv_model_destroy(self._h)
+        except Exception:
+            pass
+
+
+def cosine(a, b, cdll=None):
+    """[N, D] x [M, D] -> [N, M] cosine similarity on the device of ``a``."""
+    cdll = cdll or lib()
+    a = a.to(torch.float32).contiguous()
+    b = b.to(device=a.device, dtype=torch.float32).contiguous()
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if out.numel():
+        check(cdll.mv_cosine_f32(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1], out.data_ptr(),
+                                 current_stream(a)), cdll)
+    return out

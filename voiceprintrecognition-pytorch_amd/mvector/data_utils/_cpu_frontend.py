@@ -1,0 +1,127 @@
+"""Host-tensor front-end: batched torch implementation of Kaldi Fbank / MelSpectrogram + CMN + mask.
+
+Used only for CPU tensors (``use_gpu=False`` predictors and DataLoader worker processes, exactly where the
+reference runs its featurizer, mvector/data_utils/featurizer.py:53-91).  CUDA tensors never come here: they go
+to the HIP kernels.  The arithmetic is the one of torchaudio 2.4.0's ``kaldi.fbank`` / ``MelSpectrogram`` with
+whole-batch tensor ops instead of the reference's per-utterance Python loop.
+"""
+import functools
+import math
+
+import torch
+
+_FBANK_KEYS = {'sample_frequency': 16000.0, 'frame_length': 25.0, 'frame_shift': 10.0, 'num_mel_bins': 23,
+               'low_freq': 20.0, 'high_freq': 0.0, 'preemphasis_coefficient': 0.97, 'remove_dc_offset': True,
+               'use_power': True, 'use_log_fbank': True}
+_FBANK_FIXED = {'dither': (0.0,), 'window_type': ('povey',), 'snip_edges': (True,), 'use_energy': (False,),
+                'vtln_warp': (1.0,), 'subtract_mean': (False,), 'htk_compat': (False,),
+                'round_to_power_of_two': (True,), 'channel': (-1, 0), 'min_duration': (0.0,), 'raw_energy': (True,),
+                'energy_floor': (0.0, 1.0), 'blackman_coeff': (0.42,), 'vtln_low': (100.0,), 'vtln_high': (-500.0,)}
+_MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
+             'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale'}
+
+
+def validate_args(method, args):
+    if method == 'Fbank':
+        for k, v in args.items():
+            if k in _FBANK_KEYS:
+                continue
+            if k in _FBANK_FIXED:
+                if v not in _FBANK_FIXED[k]:
+                    raise NotImplementedError(f'Fbank argument {k}={v!r} is not implemented')
+            else:
+                raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
+    elif method == 'MelSpectrogram':
+        for k in args:
+            if k not in _MEL_KEYS:
+                raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
+        if args.get('pad', 0) != 0 or args.get('normalized', False) or args.get('norm') is not None or \
+                args.get('mel_scale', 'htk') != 'htk' or args.get('pad_mode', 'reflect') != 'reflect' or \
+                args.get('onesided') not in (None, True):
+            raise NotImplementedError('MelSpectrogram option not implemented')
+
+
+@functools.lru_cache(maxsize=8)
+def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high):
+    size = int(sf * frame_length * 0.001)
+    shift = int(sf * frame_shift * 0.001)
+    padded = 1 << (size - 1).bit_length()
+    window = torch.hann_window(size, periodic=False).pow(0.85)
+    nfft_bins = padded // 2
+    high = high + 0.5 * sf if high <= 0.0 else high
+    mel_lo = 1127.0 * math.log(1.0 + low / 700.0)
+    mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
+    delta = (mel_hi - mel_lo) / (nbins + 1)
+    idx = torch.arange(nbins).unsqueeze(1)
+    left, center, right = mel_lo + idx * delta, mel_lo + (idx + 1.0) * delta, mel_lo + (idx + 2.0) * delta
+    mel = (1127.0 * (1.0 + (sf / padded) * torch.arange(nfft_bins) / 700.0).log()).unsqueeze(0)
+    banks = torch.clamp(torch.min((mel - left) / (center - left), (right - mel) / (right - center)), min=0.0)
+    banks = torch.nn.functional.pad(banks, (0, 1))  # zero weight on the Nyquist bin
+    return size, shift, padded, window, banks.t().contiguous()
+
+
+def fbank_batch(wav, args):
+    """[B, L] -> [B, m, num_mel_bins] log-mel energies (no CMN)."""
+    a = dict(_FBANK_KEYS)
+    a.update({k: v for k, v in args.items() if k in _FBANK_KEYS})
+    size, shift, padded, window, banks_t = _fbank_tables(float(a['sample_frequency']), float(a['frame_length']),
+                                                          float(a['frame_shift']), int(a['num_mel_bins']),
+                                                          float(a['low_freq']), float(a['high_freq']))
+    B, L = wav.shape
+    if L < size:
+        return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
+    frames = wav.unfold(1, size, shift)  # [B, m, size]
+    if a['remove_dc_offset']:
+        frames = frames - frames.mean(dim=2, keepdim=True)
+    pc = float(a['preemphasis_coefficient'])
+    if pc != 0.0:
+        frames = frames - pc * torch.cat([frames[..., :1], frames[..., :-1]], dim=2)
+    frames = frames * window
+    spec = torch.fft.rfft(frames, n=padded).abs()
+    if a['use_power']:
+        spec = spec.pow(2.0)
+    mel = spec @ banks_t
+    if a['use_log_fbank']:
+        mel = torch.clamp(mel, min=torch.finfo(torch.float32).eps).log()
+    return mel
+
+
+@functools.lru_cache(maxsize=8)
+def _mel_tables(sr, n_fft, win, f_min, f_max, n_mels):
+    all_freqs = torch.linspace(0, sr // 2, n_fft // 2 + 1)
+    m_pts = torch.linspace(2595.0 * math.log10(1.0 + f_min / 700.0), 2595.0 * math.log10(1.0 + f_max / 700.0), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+    return torch.hann_window(win), fb
+
+
+def melspec_batch(wav, args):
+    """[B, L] -> [B, frames, n_mels] raw-power mel spectrogram (no log, no CMN)."""
+    sr = int(args.get('sample_rate', 16000))
+    n_fft = int(args.get('n_fft', 400))
+    win = args.get('win_length')
+    win = int(win if win is not None else n_fft)
+    hop = args.get('hop_length')
+    hop = int(hop if hop is not None else win // 2)
+    f_max = args.get('f_max')
+    f_max = float(f_max if f_max is not None else sr // 2)
+    power = float(args.get('power', 2.0))
+    window, fb = _mel_tables(sr, n_fft, win, float(args.get('f_min', 0.0)), f_max, int(args.get('n_mels', 128)))
+    spec = torch.stft(wav, n_fft, hop, win, window, center=bool(args.get('center', True)), pad_mode='reflect',
+                      normalized=False, onesided=True, return_complex=True).abs()
+    if power != 1.0:
+        spec = spec.pow(power)
+    return spec.transpose(1, 2) @ fb
+
+
+def featurize(wav, lens_ratio, method, args):
+    feats = fbank_batch(wav, args) if method == 'Fbank' else melspec_batch(wav, args)
+    feats = feats - feats.mean(1, keepdim=True)  # time mean over ALL frames (featurizer.py:79)
+    if lens_ratio is not None:
+        T = feats.shape[1]
+        mask_lens = torch.round(lens_ratio.to(torch.float32) * T).long().view(-1, 1, 1)  # half-to-even
+        keep = torch.arange(T).view(1, T, 1) < mask_lens
+        feats = torch.where(keep, feats, torch.zeros_like(feats))
+    return feats
