@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--model', default='ecapa1024', choices=sorted(MODELS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=32, help='utterances timed on the CPU oracle')
+    ap.add_argument('--cpu-threads', type=int, default=32, help='torch CPU threads for the oracle baseline')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -176,7 +177,8 @@ def main():
             cosd = (1 - torch.nn.functional.cosine_similarity(emb[:n_par].cpu().double(), ref.double(), dim=1)).max().item()
             out['parity'] = {'max_one_minus_cos': cosd, 'utterances': n_par, 'tolerance': 1e-4}
             if not args.no_cpu_baseline:
-                torch.set_num_threads(os.cpu_count())
+                # all host cores oversubscribe badly on the 256-thread GPU host (0.3 utt/s): cap the pool, report the count
+                torch.set_num_threads(min(os.cpu_count(), args.cpu_threads))
                 n_cpu = max(1, min(args.cpu_sample, B))
                 sample = wav[:n_cpu].cpu()
                 with torch.no_grad():

@@ -205,6 +205,9 @@ typedef struct MvConv1dDesc {
     void* y;              /* [B, T_out, ldy] */
     int32_t y_dtype;
     int64_t ldy;
+    const void* add_src;  /* optional fp16 [B, T_out, ld_add]: second output sum_dst = y + add_src, i.e. the input */
+    void* sum_dst;        /* x_{j+1} + y_j of the next Res2Net step (ecapa_tdnn.py:47) produced by this step's epilogue */
+    int64_t ld_add, ld_sum;
     int32_t B, T_in, T_out, cin, cout, k, dilation, stride, pad, pad_mode;
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);

@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, seed=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, seed=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -65,6 +65,10 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     d.scale, d.shift = (scaled.data_ptr(), shiftd.data_ptr()) if affine else (None, None)
     d.gate, d.gate_seg_len = (gated.data_ptr(), gate_seg) if gate_seg else (None, 0)
     d.y, d.y_dtype, d.ldy = y.data_ptr(), (_hip.MV_DT_F32 if y_f32 else _hip.MV_DT_F16), ldy
+    if second_out:
+        addsrc = (rn(B, T_out, ldy)).half().to(device)
+        sumdst = torch.full((B, T_out, ldy), 5.0, dtype=torch.float16, device=device)
+        d.add_src, d.sum_dst, d.ld_add, d.ld_sum = addsrc.data_ptr(), sumdst.data_ptr(), ldy, ldy
     d.B, d.T_in, d.T_out, d.cin, d.cout, d.k = B, T, T_out, cin, cout, k
     d.dilation, d.stride, d.pad = dil, stride, pad
     d.pad_mode = _hip.MV_PAD_REFLECT if pad_mode == 'reflect' else _hip.MV_PAD_ZERO
@@ -96,6 +100,11 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     err = (got[..., :cout] - ref).abs().max().item()
     tol = 2e-4 if y_f32 else 4e-3 * max(1.0, ref.abs().max().item())
     assert err < tol, f'conv1d mismatch {err} (tol {tol})'
+    if second_out:
+        want = (y.cpu().float()[..., :cout] + addsrc.cpu().float()[..., :cout]).half().float()
+        got2 = sumdst.cpu().float()
+        assert torch.all(got2[..., cout:] == 5.0)
+        assert (got2[..., :cout] - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
     return err
 
 
@@ -111,6 +120,7 @@ CONV_CASES = [
     dict(k=1, dil=1, row_bias=True, post_act=2, cin=192, cout=128, T=33),  # ASP attention hidden layer
     dict(k=1, dil=1, y_f32=True, pre_act=0, affine=False, cin=64, cout=20, T=9, B=5),  # fp32 out, ragged cout
     dict(k=3, dil=1, B=1, T=300, cin=8, cout=8, extra_ld=56),         # many n tiles, narrow slice of a wide row
+    dict(k=3, dil=2, cin=16, cout=16, second_out=True, T=41),          # Res2Net step emitting the next step's input
 ]
 
 

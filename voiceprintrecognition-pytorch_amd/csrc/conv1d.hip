@@ -43,6 +43,9 @@ struct ConvArgs {
     const float* gate;
     void* y;
     int64_t ldy;
+    const half_t* add_src;  // optional second output: sum_dst = y + add_src
+    half_t* sum_dst;
+    int64_t ld_add, ld_sum;
     int B, T_in, T_out, cin, cin_pad, cout, cout_pad, k, dil, stride, pad, pad_mode;
     int pre_act, post_act, y_f16, gate_seg_len, gate_nseg;
     int n_rows, n_tiles, co_tiles;
@@ -58,6 +61,227 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][64] fp16 tile
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// 256 zero bytes: source of every padded / out-of-range 16-byte chunk, so the loaders never branch
+__device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
+
+__device__ __forceinline__ half_t to_half_sat(float v) {
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);  // saturate instead of producing inf
+    return (half_t)v;
+}
+
+// One 16-byte global -> LDS transfer per lane: the wave writes 1 KiB at lds_wave_base + lane*16, the global
+// address is per lane (swizzles are applied to the SOURCE address).  No VGPR staging.
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef MV_EMU
+    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ void wait_all_loads() {
+#ifndef MV_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+struct RowMap {  // where the rows (time steps) of this lane live
+    int b, t;    // b < 0: row beyond the tensor
+};
+
+// input time index of output step t for tap `tap`; returns -1 for zero padding
+__device__ __forceinline__ int input_time(const ConvArgs& a, int t, int tap) {
+    int tin = t * a.stride - a.pad + tap * a.dil;
+    if (tin < 0 || tin >= a.T_in) {
+        if (a.pad_mode == MV_PAD_REFLECT)
+            tin = tin < 0 ? -tin : 2 * (a.T_in - 1) - tin;
+        else
+            tin = -1;
+    }
+    return tin;
+}
+
+// ---- shared MFMA stage and epilogue ---------------------------------------------------------------------------
+__device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int wc, int wn, int lane, float4v (&acc)[4][4]) {
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        half8v af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off(wc * 64 + mi * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off(wn * 64 + ni * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// lane holds channels co..co+3 (rows) of time step n (column); cout is a multiple of 4, so a lane's four channels are
+// all valid or all invalid and every per-channel parameter is one float4 load (uniform branches only).
+__device__ __forceinline__ float4v act4(float4v v, int act) {
+    if (act == MV_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+    } else if (act == MV_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+    } else if (act == MV_ACT_SIGMOID) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+    }
+    return v;
+}
+
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0, int wc, int wn, int lane,
+                                              float4v (&acc)[4][4]) {
+    const int crow = 4 * (lane >> 4);
+    int nn[4], nb[4], nt[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        nn[ni] = n0 + wn * 64 + ni * 16 + (lane & 15);
+        nb[ni] = 0;
+        nt[ni] = 0;
+        if (a.row_bias != nullptr || a.gate != nullptr) {
+            nb[ni] = nn[ni] / a.T_out;
+            nt[ni] = nn[ni] - nb[ni] * a.T_out;
+        }
+    }
+    const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    const float4v one4 = float4v{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int co = co0 + wc * 64 + mi * 16 + crow;
+        if (co >= a.cout) continue;
+        const float4v bias4 = a.bias != nullptr ? *reinterpret_cast<const float4v*>(a.bias + co) : zero4;
+        const float4v scale4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.scale + co) : one4;
+        const float4v shift4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.shift + co) : zero4;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = nn[ni];
+            if (n >= a.n_rows) continue;
+            float4v v = acc[mi][ni] + bias4;
+            if (a.row_bias != nullptr) v += *reinterpret_cast<const float4v*>(a.row_bias + (int64_t)nb[ni] * a.cout + co);
+            v = act4(v, a.pre_act);
+            v = v * scale4 + shift4;
+            v = act4(v, a.post_act);
+            if (a.gate != nullptr)
+                v *= *reinterpret_cast<const float4v*>(a.gate + ((int64_t)nb[ni] * a.gate_nseg + nt[ni] / a.gate_seg_len) * a.cout + co);
+            half4v hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = to_half_sat(v[r]);
+            if (a.y_f16) {
+                *reinterpret_cast<half4v*>(reinterpret_cast<half_t*>(a.y) + (int64_t)n * a.ldy + co) = hv;
+            } else {
+                *reinterpret_cast<float4v*>(reinterpret_cast<float*>(a.y) + (int64_t)n * a.ldy + co) = v;
+            }
+            if (a.sum_dst != nullptr) {
+                // second output: y + add_src (the next Res2Net step's input x_{j+1} + y_j, ecapa_tdnn.py:47)
+                const half4v sv = *reinterpret_cast<const half4v*>(a.add_src + (int64_t)n * a.ld_add + co);
+                half4v ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = to_half_sat((float)hv[r] + (float)sv[r]);
+                *reinterpret_cast<half4v*>(a.sum_dst + (int64_t)n * a.ld_sum + co) = ov;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
+    // XCD-aware assignment: all co-tiles of one n-tile run on the same XCD (block id mod 8)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int seq = bid >> 3;
+    n_tile = xcd + 8 * (seq / a.co_tiles);
+    co_tile = seq % a.co_tiles;
+    return n_tile < a.n_tiles;
+}
+
+// ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
+__global__ __launch_bounds__(CV_THREADS) void conv1d_glds_kernel(ConvArgs a) {
+    MV_DYN_SMEM(smem);
+    int n_tile, co_tile;
+    if (!tile_of_block(a, n_tile, co_tile)) return;  // whole workgroup leaves before any barrier
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;
+    const int n0 = n_tile * CV_TN;
+    const int co0 = co_tile * CV_TC;
+
+    // Wave w issues 4 transfers of 8 rows x 128 B for each operand: transfer i covers rows (w*4+i)*8 .. +8.
+    // Lane l lands at LDS position (row = l>>3, slot = l&7) and therefore fetches source chunk slot ^ (row & 7).
+    const int lrow = lane >> 3;
+    const int kc = (lane & 7) ^ (lrow & 7);  // (row & 7) == lrow because transfers start at multiples of 8
+    RowMap rm[4];
+    const half_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int n = n0 + row;
+        if (n < a.n_rows) {
+            rm[i].b = n / a.T_out;
+            rm[i].t = n - rm[i].b * a.T_out;
+        } else {
+            rm[i].b = -1;
+            rm[i].t = 0;
+        }
+        const int co = co0 + row;
+        wsrc[i] = co < a.cout_pad ? a.w + (int64_t)co * a.k * a.cin_pad + kc * 8 : nullptr;
+    }
+    const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
+    const int kstages_per_tap = a.cin_pad / CV_BK;
+    const int nstages = a.k * kstages_per_tap;
+
+    auto issue = [&](int s, int buf) {
+        char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
+        char* xtile = wt + CV_TC * CV_BK * 2;
+        const int tap = s / kstages_per_tap;
+        const int c0 = (s - tap * kstages_per_tap) * CV_BK;
+        const int c = c0 + kc * 8;
+        const bool ch_ok = c < a.cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tin = input_time(a, rm[i].t, tap);
+            const half_t* src = zero;
+            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
+            glds16(src, xtile + (wave * 4 + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const half_t* src = wsrc[i] != nullptr ? wsrc[i] + (int64_t)tap * a.cin_pad + c0 : zero;
+            glds16(src, wt + (wave * 4 + i) * 1024);
+        }
+    };
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    issue(0, 0);
+    wait_all_loads();
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
+        const char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
+        mma_stage(wt, wt + CV_TC * CV_BK * 2, wc, wn, lane, acc);
+        wait_all_loads();
+        __syncthreads();
+    }
+    conv_epilogue(a, n0, co0, wc, wn, lane, acc);
+}
+
+// ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
 template <typename InT>
 struct RawChunk;
 template <>
@@ -68,127 +292,67 @@ template <>
 struct RawChunk<float> {
     float4v lo, hi;
 };
-
-template <typename InT>
-__device__ __forceinline__ void load_raw(RawChunk<InT>& r, const InT* p, int nvalid);
-
-template <>
-__device__ __forceinline__ void load_raw<half_t>(RawChunk<half_t>& r, const half_t* p, int nvalid) {
-    if (nvalid >= 8) {
-        r.v = *reinterpret_cast<const half8v*>(p);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r.v[e] = e < nvalid ? p[e] : (half_t)0.0f;
-    }
+__device__ __forceinline__ void load_raw(RawChunk<half_t>& r, const half_t* p) { r.v = *reinterpret_cast<const half8v*>(p); }
+__device__ __forceinline__ void load_raw(RawChunk<float>& r, const float* p) {
+    r.lo = *reinterpret_cast<const float4v*>(p);
+    r.hi = *reinterpret_cast<const float4v*>(p + 4);
 }
-template <>
-__device__ __forceinline__ void load_raw<float>(RawChunk<float>& r, const float* p, int nvalid) {
-    if (nvalid >= 8) {
-        r.lo = *reinterpret_cast<const float4v*>(p);
-        r.hi = *reinterpret_cast<const float4v*>(p + 4);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r.lo[e] = e < nvalid ? p[e] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r.hi[e] = (e + 4) < nvalid ? p[e + 4] : 0.0f;
-    }
-}
-
-__device__ __forceinline__ void zero_raw(RawChunk<half_t>& r) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r.v[e] = (half_t)0.0f;
-}
-__device__ __forceinline__ void zero_raw(RawChunk<float>& r) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r.lo[e] = 0.0f;
-        r.hi[e] = 0.0f;
-    }
-}
-
 __device__ __forceinline__ float raw_get(const RawChunk<half_t>& r, int e) { return (float)r.v[e]; }
 __device__ __forceinline__ float raw_get(const RawChunk<float>& r, int e) { return e < 4 ? r.lo[e] : r.hi[e - 4]; }
 
-__device__ __forceinline__ half_t to_half_sat(float v) {
-    v = fminf(fmaxf(v, -65504.0f), 65504.0f);  // saturate instead of producing inf
-    return (half_t)v;
-}
-
-template <typename InT>
+template <typename InT, bool HAS_X2, bool IN_AFFINE>
 __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
     MV_DYN_SMEM(smem);
-    // ---- XCD-aware tile assignment: workgroup id -> (n_tile, co_tile) ----
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int seq = bid >> 3;
-    const int n_tile = xcd + 8 * (seq / a.co_tiles);
-    const int co_tile = seq % a.co_tiles;
-    if (n_tile >= a.n_tiles) return;  // whole workgroup leaves before any barrier
-
+    int n_tile, co_tile;
+    if (!tile_of_block(a, n_tile, co_tile)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = wave >> 1;  // wave position along co
-    const int wn = wave & 1;   // wave position along n
+    const int wc = wave >> 1, wn = wave & 1;
     const int n0 = n_tile * CV_TN;
     const int co0 = co_tile * CV_TC;
 
-    // ---- loader mapping: thread owns 16-byte chunk kc of rows lrow + 32*i ----
+    // loader mapping: thread owns 16-byte chunk kc of rows lrow + 32*i
     const int kc = tid & 7;
     const int lrow = tid >> 3;
-    int xb[4], xt[4];  // batch index / output time of the 4 activation rows of this thread (-1: out of range)
+    RowMap rm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + lrow + 32 * i;
         if (n < a.n_rows) {
-            xb[i] = n / a.T_out;
-            xt[i] = n - xb[i] * a.T_out;
+            rm[i].b = n / a.T_out;
+            rm[i].t = n - rm[i].b * a.T_out;
         } else {
-            xb[i] = -1;
-            xt[i] = 0;
+            rm[i].b = -1;
+            rm[i].t = 0;
         }
     }
     const InT* xbase = reinterpret_cast<const InT*>(a.x);
     const InT* x2base = reinterpret_cast<const InT*>(a.x2);
+    const InT* zero = reinterpret_cast<const InT*>(g_zero_page);
+    const half_t* zero_h = reinterpret_cast<const half_t*>(g_zero_page);
     const int kstages_per_tap = a.cin_pad / CV_BK;
     const int nstages = a.k * kstages_per_tap;
 
     RawChunk<InT> xr[4], x2r[4];
     half8v wr[4];
 
-    auto issue_loads = [&](int s) {
+    auto issue_loads = [&](int s) {  // branch-free: padded / out-of-range chunks read the zero page
         const int tap = s / kstages_per_tap;
         const int c = (s - tap * kstages_per_tap) * CV_BK + kc * 8;
-        const int nvalid = a.cin - c;  // channels of this chunk that exist
+        const bool ch_ok = c < a.cin;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bool ok = xb[i] >= 0 && nvalid > 0;
-            int tin = xt[i] * a.stride - a.pad + tap * a.dil;
-            if (tin < 0 || tin >= a.T_in) {
-                if (a.pad_mode == MV_PAD_REFLECT) {
-                    tin = tin < 0 ? -tin : 2 * (a.T_in - 1) - tin;
-                } else {
-                    ok = false;
-                }
-            }
-            if (ok) {
-                const int64_t row = (int64_t)xb[i] * a.T_in + tin;
-                load_raw<InT>(xr[i], xbase + row * a.ldx + c, nvalid);
-                if (x2base != nullptr) load_raw<InT>(x2r[i], x2base + row * a.ldx2 + c, nvalid);
-            } else {
-                zero_raw(xr[i]);
-                if (x2base != nullptr) zero_raw(x2r[i]);
-            }
+            const int tin = input_time(a, rm[i].t, tap);
+            const bool ok = rm[i].b >= 0 && tin >= 0 && ch_ok;
+            const int64_t row = (int64_t)rm[i].b * a.T_in + tin;
+            load_raw(xr[i], ok ? xbase + row * a.ldx + c : zero);
+            if (HAS_X2) load_raw(x2r[i], ok ? x2base + row * a.ldx2 + c : zero);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + lrow + 32 * i;
-            if (co < a.cout_pad) {
-                wr[i] = *reinterpret_cast<const half8v*>(a.w + ((int64_t)co * a.k + tap) * a.cin_pad + c);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) wr[i][e] = (half_t)0.0f;
-            }
+            wr[i] = *reinterpret_cast<const half8v*>(co < a.cout_pad ? a.w + ((int64_t)co * a.k + tap) * a.cin_pad + c : zero_h);
         }
     };
 
@@ -197,6 +361,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
         char* xtile = wt + CV_TC * CV_BK * 2;
         const int tap = s / kstages_per_tap;
         const int c = (s - tap * kstages_per_tap) * CV_BK + kc * 8;
+        float isc[8], ish[8];
+        if (IN_AFFINE) {
+            // channels beyond cin meet zero weights, any finite value will do
+            const int cc = c + 8 <= a.cin ? c : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                isc[e] = a.in_scale[cc + e];
+                ish[e] = a.in_shift[cc + e];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = lrow + 32 * i;
@@ -204,13 +378,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = raw_get(xr[i], e);
-                if (x2base != nullptr) v += raw_get(x2r[i], e);
-                if (a.in_scale != nullptr) {
-                    const int ch = c + e;
-                    if (ch < a.cin) v = fmaxf(v * a.in_scale[ch] + a.in_shift[ch], 0.0f);
-                    // rows that are zero padding must stay zero AFTER the pre-activation (the reference pads
-                    // the already-activated tensor): handled by the caller-visible rule below
-                }
+                if (HAS_X2) v += raw_get(x2r[i], e);
+                if (IN_AFFINE) v = fmaxf(v * isc[e] + ish[e], 0.0f);
                 hv[e] = to_half_sat(v);
             }
             *reinterpret_cast<half8v*>(xtile + lds_off(row, kc)) = hv;
@@ -227,83 +396,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
     issue_loads(0);
     store_lds(0, 0);
     __syncthreads();
-
-    const int frow = lane & 15;
-    const int fchunk = lane >> 4;
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstages) issue_loads(s + 1);
         const char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
-        const char* xtile = wt + CV_TC * CV_BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8v af[4], bf[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off(wc * 64 + mi * 16 + frow, kk * 4 + fchunk));
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off(wn * 64 + ni * 16 + frow, kk * 4 + fchunk));
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        }
+        mma_stage(wt, wt + CV_TC * CV_BK * 2, wc, wn, lane, acc);
         if (s + 1 < nstages) store_lds(s + 1, buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue: lane holds channels co..co+3 (rows) of time step n (column) ----
-    const int crow = 4 * (lane >> 4);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + (lane & 15);
-        if (n >= a.n_rows) continue;
-        int b = 0, t = 0;
-        if (a.row_bias != nullptr || a.gate != nullptr) {
-            b = n / a.T_out;
-            t = n - b * a.T_out;
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int co = co0 + wc * 64 + mi * 16 + crow;
-            if (co >= a.cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = co + r;
-                float x = acc[mi][ni][r];
-                if (c < a.cout) {
-                    if (a.bias != nullptr) x += a.bias[c];
-                    if (a.row_bias != nullptr) x += a.row_bias[(int64_t)b * a.cout + c];
-                    x = apply_act(x, a.pre_act);
-                    if (a.scale != nullptr) x = x * a.scale[c] + a.shift[c];
-                    x = apply_act(x, a.post_act);
-                    if (a.gate != nullptr) x *= a.gate[((int64_t)b * a.gate_nseg + t / a.gate_seg_len) * a.cout + c];
-                }
-                v[r] = x;
-            }
-            if (a.y_f16) {
-                half_t* yp = reinterpret_cast<half_t*>(a.y) + (int64_t)n * a.ldy + co;
-                if (co + 3 < a.cout) {
-                    half4v hv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[r] = to_half_sat(v[r]);
-                    *reinterpret_cast<half4v*>(yp) = hv;
-                } else {
-                    for (int r = 0; r < 4 && co + r < a.cout; ++r) yp[r] = to_half_sat(v[r]);
-                }
-            } else {
-                float* yp = reinterpret_cast<float*>(a.y) + (int64_t)n * a.ldy + co;
-                if (co + 3 < a.cout) {
-                    *reinterpret_cast<float4v*>(yp) = float4v{v[0], v[1], v[2], v[3]};
-                } else {
-                    for (int r = 0; r < 4 && co + r < a.cout; ++r) yp[r] = v[r];
-                }
-            }
-        }
-    }
+    conv_epilogue(a, n0, co0, wc, wn, lane, acc);
 }
 
 // fp32 [Cout][Cin][k] -> fp16 [Cout_pad][k][Cin_pad], zero padded
@@ -336,12 +437,22 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     MV_REQUIRE((d.scale == nullptr) == (d.shift == nullptr), "conv1d: scale/shift go together");
     // vector-access contract of the loader / epilogue
     const int xalign = d.x_dtype == MV_DT_F16 ? 8 : 4;
+    MV_REQUIRE(d.cin % 8 == 0, "conv1d: input channels must be a multiple of 8");
+    MV_REQUIRE(d.cout % 4 == 0, "conv1d: output channels must be a multiple of 4");
+    for (const float* p : {d.bias, d.row_bias, d.scale, d.shift, d.gate})
+        MV_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "conv1d: per-channel parameter arrays must be 16-byte aligned");
     MV_REQUIRE(d.ldx % xalign == 0 && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0, "conv1d: x must be 16-byte aligned per row");
     if (d.x2 != nullptr)
         MV_REQUIRE(d.ldx2 % xalign == 0 && (reinterpret_cast<uintptr_t>(d.x2) & 15) == 0, "conv1d: x2 alignment");
     const int yalign_bytes = d.y_dtype == MV_DT_F16 ? 8 : 16;
     MV_REQUIRE(d.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(d.y) & (yalign_bytes - 1)) == 0, "conv1d: y alignment");
     if (d.gate != nullptr) MV_REQUIRE(d.gate_seg_len > 0, "conv1d: gate needs a segment length");
+    if (d.in_scale != nullptr) MV_REQUIRE(d.pad == 0, "conv1d: the pre-activation on load is only defined for unpadded (1x1) convs");
+    MV_REQUIRE((d.add_src == nullptr) == (d.sum_dst == nullptr), "conv1d: add_src/sum_dst go together");
+    if (d.sum_dst != nullptr)
+        MV_REQUIRE(d.ld_add % 4 == 0 && d.ld_sum % 4 == 0 && (reinterpret_cast<uintptr_t>(d.add_src) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(d.sum_dst) & 7) == 0,
+                   "conv1d: second output alignment");
     MV_REQUIRE((int64_t)d.B * d.T_out < ((int64_t)1 << 31) - CV_TN, "conv1d: too many rows for 32-bit indexing");
 
     ConvArgs a;
@@ -359,6 +470,10 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.gate = d.gate;
     a.y = d.y;
     a.ldy = d.ldy;
+    a.add_src = reinterpret_cast<const half_t*>(d.add_src);
+    a.sum_dst = reinterpret_cast<half_t*>(d.sum_dst);
+    a.ld_add = d.ld_add;
+    a.ld_sum = d.ld_sum;
     a.B = d.B;
     a.T_in = d.T_in;
     a.T_out = d.T_out;
@@ -382,15 +497,25 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
     static bool smem_set = false;
     if (!smem_set) {
-        if (MV_SET_MAX_SMEM(conv1d_mfma_kernel<half_t>, CV_LDS_BYTES) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_mfma_kernel<float>, CV_LDS_BYTES) != hipSuccess)
+        if (MV_SET_MAX_SMEM(conv1d_glds_kernel, CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    if (d.x_dtype == MV_DT_F16) {
-        MV_LAUNCH(conv1d_mfma_kernel<half_t>, (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+    const bool f16 = d.x_dtype == MV_DT_F16;
+    const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
+    if (f16 && !has_x2 && !in_aff) {
+        MV_LAUNCH(conv1d_glds_kernel, (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+    } else if (f16 && has_x2 && !in_aff) {
+        MV_LAUNCH((conv1d_mfma_kernel<half_t, true, false>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+    } else if (f16 && !has_x2 && in_aff) {
+        MV_LAUNCH((conv1d_mfma_kernel<half_t, false, true>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+    } else if (!f16 && !has_x2 && !in_aff) {
+        MV_LAUNCH((conv1d_mfma_kernel<float, false, false>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else {
-        MV_LAUNCH(conv1d_mfma_kernel<float>, (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+        return fail(MV_ERR_UNSUPPORTED, "conv1d: this combination of input dtype / second input / pre-activation is not built");
     }
     return check_launch("conv1d_mfma_kernel");
 }

@@ -12,10 +12,17 @@ int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream);
 
 int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
-                      int unbiased, float clamp_eps, hipStream_t stream);
+                      int unbiased, float clamp_eps, hipStream_t stream, const float* in_scale = nullptr,
+                      const float* in_shift = nullptr);
+int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F,
+                     hipStream_t stream);
+int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F2, int sf2, int mode2, const half_t* w,
+                       const float* bias, half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, int Fout,
+                       hipStream_t stream);
 int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream);
 int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
                             int64_t ldo, int B, int T, int C, hipStream_t stream);
+int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_t ldd, int64_t n_rows, int C, hipStream_t stream);
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream);
 int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,
                     const float* gmean, int64_t gmean_ld, float* out, int B, int T, int C, int A, hipStream_t stream);

@@ -46,7 +46,23 @@ int fold_final_linear(MvModelBase* m, const Weights& w, const std::string& weigh
 
 int run_conv(const ConvLayer& L, const void* x, int x_dtype, int64_t ldx, const void* x2, int64_t ldx2, void* y, int y_dtype,
              int64_t ldy, int B, int T_in, int T_out, int dil, int pad, int pad_mode, int pre_act, const float* scale,
-             const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream);
+             const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream,
+             const half_t* add_src = nullptr, int64_t ld_add = 0, half_t* sum_dst = nullptr, int64_t ld_sum = 0);
+
+// bump allocator over the caller-provided workspace (256-byte aligned slices)
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+    size_t total() const { return (off + 255) & ~size_t(255); }
+};
 
 // attentive statistics pooling (mvector/models/pooling.py:68-127)
 struct AspLayer {

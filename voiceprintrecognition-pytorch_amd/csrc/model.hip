@@ -128,9 +128,14 @@ int MvModelBase::make_bn(const Weights& w, const std::string& prefix, int C, flo
 // y = BN(ReLU(conv(x)))  -- TDNNBlock (models/utils.py:138) and TDNN.forward (tdnn.py:57-64)
 int run_conv(const ConvLayer& L, const void* x, int x_dtype, int64_t ldx, const void* x2, int64_t ldx2, void* y, int y_dtype,
              int64_t ldy, int B, int T_in, int T_out, int dil, int pad, int pad_mode, int pre_act, const float* scale,
-             const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream) {
+             const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream,
+             const half_t* add_src, int64_t ld_add, half_t* sum_dst, int64_t ld_sum) {
     MvConv1dDesc d;
     memset(&d, 0, sizeof(d));
+    d.add_src = add_src;
+    d.sum_dst = sum_dst;
+    d.ld_add = ld_add;
+    d.ld_sum = ld_sum;
     d.x = x;
     d.x2 = x2;
     d.x_dtype = x_dtype;
@@ -254,20 +259,6 @@ int fold_final_linear(MvModelBase* m, const Weights& w, const std::string& weigh
     return MV_OK;
 }
 
-struct Carver {
-    char* base;
-    size_t off = 0;
-    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
-    template <typename T>
-    T* take(size_t n) {
-        off = (off + 255) & ~size_t(255);
-        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-        off += n * sizeof(T);
-        return p;
-    }
-    size_t total() const { return (off + 255) & ~size_t(255); }
-};
-
 // --------------------------------------------------------------------------------------- EcapaTdnn
 
 struct EcapaModel : MvModelBase {
@@ -355,7 +346,7 @@ struct EcapaModel : MvModelBase {
     }
 
     struct Ws {
-        half_t *a0, *cat, *t1, *r2, *t2, *sc, *mfa, *h;
+        half_t *x16, *a0, *cat, *t1, *r2, *t2, *sc, *mfa, *h, *rs[2];
         float *se_mean, *se_hid, *gate, *asp_f, *pooled;
         size_t bytes;
     };
@@ -364,8 +355,11 @@ struct EcapaModel : MvModelBase {
         const size_t N = (size_t)B * T;
         Carver c(base);
         Ws s;
+        s.x16 = c.take<half_t>(N * round_up(cfg.input_size, 8));
         s.a0 = c.take<half_t>(N * cfg.channels[0]);
         s.cat = c.take<half_t>(N * ccat);
+        s.rs[0] = c.take<half_t>(N * (cmax / cfg.res2net_scale));
+        s.rs[1] = c.take<half_t>(N * (cmax / cfg.res2net_scale));
         s.t1 = c.take<half_t>(N * cmax);
         s.r2 = c.take<half_t>(N * cmax);
         s.t2 = c.take<half_t>(N * cmax);
@@ -400,8 +394,10 @@ struct EcapaModel : MvModelBase {
         if (s.bytes > ws_bytes) return fail(MV_ERR_WORKSPACE, "ecapa forward: workspace too small");
         int rc;
         const int R = MV_PAD_REFLECT;
-        // blocks.0: [B,T,F] fp32 -> a0
-        if ((rc = run_conv(block0.conv, feats, MV_DT_F32, cfg.input_size, nullptr, 0, s.a0, MV_DT_F16, cfg.channels[0], B, T, T,
+        // features to fp16 once (12 MB), then blocks.0 on the direct-to-LDS path
+        const int64_t ldf = round_up(cfg.input_size, 8);
+        if ((rc = cast_rows_f32_f16_launch(feats, cfg.input_size, s.x16, ldf, (int64_t)B * T, cfg.input_size, st))) return rc;
+        if ((rc = run_conv(block0.conv, s.x16, MV_DT_F16, ldf, nullptr, 0, s.a0, MV_DT_F16, cfg.channels[0], B, T, T,
                            cfg.dilations[0], cfg.dilations[0] * (cfg.kernel_sizes[0] - 1) / 2, R, MV_ACT_RELU, block0.scale,
                            block0.shift, MV_ACT_NONE, nullptr, true, st)))
             return rc;
@@ -423,15 +419,18 @@ struct EcapaModel : MvModelBase {
             if ((rc = run_conv(b.tdnn1.conv, xin, MV_DT_F16, ldin, nullptr, 0, s.t1, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
                                b.tdnn1.scale, b.tdnn1.shift, MV_ACT_NONE, nullptr, true, st)))
                 return rc;
-            // Res2Net: slice 0 passes through, slice j = blk_{j-1}(x_j [+ y_{j-1}])
+            // Res2Net: slice 0 passes through, slice j = blk_{j-1}(x_j [+ y_{j-1}]).  Step j's epilogue also emits the next
+            // step's input x_{j+1} + y_j into a ping-pong scratch slice, so every step reads one plain fp16 tensor.
             if ((rc = copy_slice_launch(s.t1, C, s.r2, C, b.width, (int64_t)B * T, st))) return rc;
             const int pad = b.dil * (b.k - 1) / 2;
             for (int j = 1; j < cfg.res2net_scale; ++j) {
-                const half_t* xj = s.t1 + (size_t)j * b.width;
-                const half_t* yprev = j >= 2 ? s.r2 + (size_t)(j - 1) * b.width : nullptr;
-                if ((rc = run_conv(b.res2[j - 1].conv, xj, MV_DT_F16, C, yprev, C, s.r2 + (size_t)j * b.width, MV_DT_F16, C, B, T,
-                                   T, b.dil, pad, R, MV_ACT_RELU, b.res2[j - 1].scale, b.res2[j - 1].shift, MV_ACT_NONE, nullptr,
-                                   true, st)))
+                const half_t* in = j == 1 ? s.t1 + (size_t)b.width : s.rs[j & 1];
+                const int64_t ldin_j = j == 1 ? C : b.width;
+                const bool more = j + 1 < cfg.res2net_scale;
+                if ((rc = run_conv(b.res2[j - 1].conv, in, MV_DT_F16, ldin_j, nullptr, 0, s.r2 + (size_t)j * b.width, MV_DT_F16, C, B,
+                                   T, T, b.dil, pad, R, MV_ACT_RELU, b.res2[j - 1].scale, b.res2[j - 1].shift, MV_ACT_NONE, nullptr,
+                                   true, st, more ? s.t1 + (size_t)(j + 1) * b.width : nullptr, C, more ? s.rs[(j + 1) & 1] : nullptr,
+                                   b.width)))
                     return rc;
             }
             if ((rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,

@@ -14,8 +14,10 @@ namespace mv {
 // ------------------------------------------------------------------------------------------------
 // mean / std over time.  Workgroup = (utterance, 512-channel group); lane owns 8 channels, waves split T.
 // Two passes (mean, then centred second moment) exactly like the reference's (x - mean)^2 form.
+// Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
-                                                         float* stdv, int64_t ld_out, int unbiased, float clamp_eps) {
+                                                         float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
+                                                         const float* in_scale, const float* in_shift) {
     __shared__ float red[4][512];
     __shared__ float mu[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -24,18 +26,27 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
     const bool active = c0 < C;
     const int nvalid = active ? (C - c0 < 8 ? C - c0 : 8) : 0;
     const half_t* xb = x + (int64_t)b * T * ld + c0;
-    float s[8];
+    float s[8], isc[8], ish[8];
+    const bool pre = in_scale != nullptr;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = 0.0f;
+    for (int e = 0; e < 8; ++e) {
+        s[e] = 0.0f;
+        isc[e] = (pre && e < nvalid) ? in_scale[c0 + e] : 1.0f;
+        ish[e] = (pre && e < nvalid) ? in_shift[c0 + e] : 0.0f;
+    }
+    auto val = [&](half_t h, int e) {
+        const float v = (float)h;
+        return pre ? fmaxf(v * isc[e] + ish[e], 0.0f) : v;
+    };
     if (active) {
         for (int t = wave; t < T; t += 4) {
             const half_t* p = xb + (int64_t)t * ld;
             if (nvalid == 8) {
                 const half8v v = *reinterpret_cast<const half8v*>(p);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+                for (int e = 0; e < 8; ++e) s[e] += val(v[e], e);
             } else {
-                for (int e = 0; e < nvalid; ++e) s[e] += (float)p[e];
+                for (int e = 0; e < nvalid; ++e) s[e] += val(p[e], e);
             }
         }
     }
@@ -60,12 +71,12 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
                 const half8v v = *reinterpret_cast<const half8v*>(p);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = (float)v[e] - m8[e];
+                    const float d = val(v[e], e) - m8[e];
                     s[e] += d * d;
                 }
             } else {
                 for (int e = 0; e < nvalid; ++e) {
-                    const float d = (float)p[e] - m8[e];
+                    const float d = val(p[e], e) - m8[e];
                     s[e] += d * d;
                 }
             }
@@ -86,13 +97,13 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
 }
 
 int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
-                      int unbiased, float clamp_eps, hipStream_t stream) {
+                      int unbiased, float clamp_eps, hipStream_t stream, const float* in_scale, const float* in_shift) {
     MV_REQUIRE(x != nullptr && mean != nullptr && B > 0 && T > 0 && C > 0, "time_stats: bad argument");
     MV_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
     MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 512), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
-              ld_out, unbiased, clamp_eps);
+              ld_out, unbiased, clamp_eps, in_scale, in_shift);
     return check_launch("time_stats_kernel");
 }
 
@@ -177,6 +188,28 @@ __global__ __launch_bounds__(256) void copy_slice_kernel(const half_t* src, int6
         const int c = (int)(i - n * cgroups) * 8;
         *reinterpret_cast<half8v*>(dst + n * ldd + c) = *reinterpret_cast<const half8v*>(src + n * lds_ + c);
     }
+}
+
+// dst[n, 0:C] = (fp16) src[n, 0:C]; columns C..ldd-1 of dst are zero-filled (row padding up to a multiple of 8)
+__global__ __launch_bounds__(256) void cast_rows_f32_f16_kernel(const float* src, int64_t lds_, half_t* dst, int64_t ldd,
+                                                                int64_t n_rows, int C) {
+    const int64_t total = n_rows * ldd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / ldd;
+        const int c = (int)(i - n * ldd);
+        float v = c < C ? src[n * lds_ + c] : 0.0f;
+        v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+        dst[i] = (half_t)v;
+    }
+}
+
+int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_t ldd, int64_t n_rows, int C,
+                             hipStream_t stream) {
+    MV_REQUIRE(src != nullptr && dst != nullptr && ldd >= C, "cast_rows: bad argument");
+    const int64_t total = n_rows * ldd;
+    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    MV_LAUNCH(cast_rows_f32_f16_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, lds_, dst, ldd, n_rows, C);
+    return check_launch("cast_rows_f32_f16_kernel");
 }
 
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream) {
@@ -406,7 +439,7 @@ extern "C" {
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
                       int32_t unbiased, float clamp_eps, mv_stream_t stream) {
     return mv::time_stats_launch(reinterpret_cast<const half_t*>(x), ld, B, T, C, mean, std, C, unbiased, clamp_eps,
-                                 static_cast<hipStream_t>(stream));
+                                 static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -7,5 +7,4 @@ int mv_melspec_destroy(MvMelSpec*) { return MV_OK; }
 int mv_melspec_num_frames(const MvMelSpec*, int64_t, int64_t*) { return mv::fail(MV_ERR_UNSUPPORTED, "melspec: not built yet"); }
 size_t mv_melspec_workspace_bytes(const MvMelSpec*, int32_t, int64_t) { return 0; }
 int mv_melspec_forward(const MvMelSpec*, const float*, int32_t, int64_t, int64_t, const float*, float*, void*, size_t, mv_stream_t) { return mv::fail(MV_ERR_UNSUPPORTED, "melspec: not built yet"); }
-int mv_campp_create(const MvCamppCfg*, const MvTensorRef*, int32_t, MvModel**) { return mv::fail(MV_ERR_UNSUPPORTED, "campp: not built yet"); }
 }

@@ -55,7 +55,8 @@ class MvConv1dDesc(ctypes.Structure):
     _fields_ = [('x', c_vp), ('x2', c_vp), ('x_dtype', c_i32), ('ldx', c_i64), ('ldx2', c_i64), ('in_scale', c_vp),
                 ('in_shift', c_vp), ('w_packed', c_vp), ('bias', c_vp), ('row_bias', c_vp), ('pre_act', c_i32),
                 ('scale', c_vp), ('shift', c_vp), ('post_act', c_i32), ('gate', c_vp), ('gate_seg_len', c_i32),
-                ('y', c_vp), ('y_dtype', c_i32), ('ldy', c_i64), ('B', c_i32), ('T_in', c_i32), ('T_out', c_i32),
+                ('y', c_vp), ('y_dtype', c_i32), ('ldy', c_i64), ('add_src', c_vp), ('sum_dst', c_vp), ('ld_add', c_i64),
+                ('ld_sum', c_i64), ('B', c_i32), ('T_in', c_i32), ('T_out', c_i32),
                 ('cin', c_i32), ('cout', c_i32), ('k', c_i32), ('dilation', c_i32), ('stride', c_i32), ('pad', c_i32),
                 ('pad_mode', c_i32)]
 

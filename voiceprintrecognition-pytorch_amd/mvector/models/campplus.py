@@ -229,8 +229,8 @@ class CAMPPlus(NativeBackbone, nn.Module):
     def _native_supported(self):
         if self._cfg['config_str'] != 'batchnorm-relu':
             return False, f"config_str={self._cfg['config_str']!r}"
-        if self._cfg['input_size'] % 8 != 0:
-            return False, 'an input_size that is not a multiple of 8'
+        if self._cfg['growth_rate'] != 32 or self._cfg['bn_size'] != 4 or self._cfg['init_channels'] % 64 != 0:
+            return False, 'growth_rate/bn_size/init_channels other than 32/4/multiple of 64'
         return True, ''
 
     def _native_cfg(self):
