@@ -74,3 +74,9 @@ def test_emu_fbank_edge_cases():
 def test_emu_ecapa_tiny_end_to_end():
     cd, rel = lc.model_case(emu_cdll(), 'cpu', 'ecapa_tiny')
     assert rel < 5e-3
+
+
+@pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~90 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
+def test_emu_campp_short_end_to_end():
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short')
+    assert rel < 1e-2

@@ -98,13 +98,13 @@ def test_gpu_fbank_full_batch_properties():
     assert (out[250:].cpu() - ref).abs().max().item() < 2e-3
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'tdnn'])
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'tdnn', 'campp', 'campp_short'])
 def test_gpu_native_model_matches_reference_golden(case):
     cd, rel = lc.model_case(product_lib(), DEV, case)
     assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'tdnn'])
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'tdnn', 'campp_short'])
 def test_gpu_module_forward_uses_native_and_tracks_weights(case):
     import mvector.models as M
     man, sd, x, emb_ref, _ = load_case(case)
