@@ -205,3 +205,15 @@ def model_case(cdll, device, case, tol=1e-4):
     rel = ((emb - emb_ref).norm(dim=1) / emb_ref.norm(dim=1)).max().item()
     assert cd < tol, f'{case}: 1-cos {cd}'
     return cd, rel
+
+
+def melspec_case(cdll, device, wav, ratio, method_args, rtol=2e-4):
+    from oracle import frontend
+    ms = _hip.MelSpec(method_args, cdll=cdll)
+    out = ms(wav.to(device), None if ratio is None else ratio.to(device)).cpu()
+    ref = frontend.audio_featurizer(wav, ratio, 'MelSpectrogram', method_args)
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    assert err <= rtol * scale + 1e-6, (err, scale)
+    return err / scale

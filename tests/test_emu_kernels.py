@@ -80,3 +80,14 @@ def test_emu_ecapa_tiny_end_to_end():
 def test_emu_campp_short_end_to_end():
     cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short')
     assert rel < 1e-2
+
+
+def test_emu_melspec_default_and_masked():
+    wav = frontend.synth_waveforms(2, 2000, seed=12)
+    lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([1.0, 0.45]), {})
+
+
+def test_emu_melspec_other_geometry():
+    wav = frontend.synth_waveforms(1, 1500, seed=13)
+    lc.melspec_case(emu_cdll(), 'cpu', wav, None, dict(sample_rate=16000, n_fft=256, win_length=200, hop_length=80, f_min=50,
+                                                      f_max=7000, n_mels=40))

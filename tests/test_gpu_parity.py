@@ -170,3 +170,37 @@ def test_gpu_predictor_matches_cpu_predictor(tmp_path):
     assert cos_dist(e_gpu, e_cpu).max() < 1e-4
     assert cos_dist(one, cpu.predict(paths[1])).max() < 1e-4
     assert abs(c_gpu - cpu.contrast(paths[0], paths[2])) < 1e-3
+
+
+def test_gpu_melspec_golden_and_variants():
+    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    from mvector import _hip
+    ms = _hip.MelSpec({})
+    out = ms(wav[:2].to(DEV)).cpu().numpy()
+    assert out.shape == (2, 241, 128)
+    assert np.abs(out - z['mel']).max() <= 2e-4 * np.abs(z['mel']).max()
+    lens = z['lens']
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(lens):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    outv = ms(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy()[2:]
+    assert np.abs(outv - z['mel_var']).max() <= 2e-4 * np.abs(z['mel_var']).max()
+    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    lc.melspec_case(product_lib(), DEV, wav[:1], None, readme)
+    lc.melspec_case(product_lib(), DEV, frontend.synth_waveforms(3, 16000 + 37, seed=5), torch.tensor([1.0, 0.3, 0.81]), {})
+
+
+def test_gpu_ecapa_on_melspectrogram_end_to_end():
+    """Config 3 shape: EcapaTdnn(128) on MelSpectrogram defaults, waveform -> embedding vs the oracle."""
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    from mvector.models import EcapaTdnn
+    man, sd, _, _, _ = load_case('ecapa_mel128')
+    model = EcapaTdnn(**man['kwargs'])
+    model.load_state_dict(sd)
+    model.eval().to(DEV)
+    fz = AudioFeaturizer('MelSpectrogram', method_args={})
+    wav = frontend.synth_waveforms(8, 48000, seed=77)
+    emb = model(fz(wav.to(DEV)))
+    ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[:3], None, 'MelSpectrogram', {}))
+    assert cos_dist(emb[:3].cpu(), ref).max() < 1e-4
