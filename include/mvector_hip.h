@@ -212,6 +212,14 @@ typedef struct MvConv1dDesc {
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
 
+/* Fused Res2Net chain (mvector/models/ecapa_tdnn.py:39-51): x, y fp16 [B, T, C]; `groups` channel groups of width C/groups;
+ * y[..., 0:w] = x[..., 0:w];  y_j = BN(ReLU(conv_j(x_j + y_{j-1}))) for j = 1..groups-1 with reflect "same" padding.
+ * Arrays of groups-1 pointers (host arrays of device pointers): packed weights, bias, folded BN scale / shift.
+ * One workgroup per utterance; returns MV_ERR_UNSUPPORTED unless width is 64 or 128 and T <= 320. */
+int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, const float* const* bias,
+                         const float* const* scale, const float* const* shift, int32_t B, int32_t T, int32_t C,
+                         int32_t groups, int32_t k, int32_t dilation, mv_stream_t stream);
+
 /* y[b, o] = act( sum_k x[b, k] * w[o, k] + bias[o] ) in exact fp32 (f32 MFMA). */
 int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
                   int32_t B, int32_t K, int32_t O, mv_stream_t stream);

@@ -217,3 +217,39 @@ def melspec_case(cdll, device, wav, ratio, method_args, rtol=2e-4):
     err = (out - ref).abs().max().item()
     assert err <= rtol * scale + 1e-6, (err, scale)
     return err / scale
+
+
+def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0):
+    """Fused Res2Net chain vs a torch fp32 evaluation that rounds to fp16 exactly where the kernel does."""
+    g = torch.Generator().manual_seed(seed)
+    C = width * groups
+    x = torch.randn(B, T, C, generator=g).half()
+    ws = [torch.randn(width, width, k, generator=g) * (2.0 / (width * k)) ** 0.5 for _ in range(groups - 1)]
+    bs = [torch.randn(width, generator=g) * 0.1 for _ in range(groups - 1)]
+    ss = [torch.rand(width, generator=g) + 0.5 for _ in range(groups - 1)]
+    ts = [torch.randn(width, generator=g) * 0.1 for _ in range(groups - 1)]
+    xd = x.to(device)
+    y = torch.full((B, T, C), 9.0, dtype=torch.float16, device=device)
+    packed = [pack_weight(cdll, w.to(device)) for w in ws]
+    dev = [[t.to(device).contiguous() for t in lst] for lst in (bs, ss, ts)]
+    arr = lambda lst: (ctypes.c_void_p * len(lst))(*[t.data_ptr() for t in lst])
+    _hip.check(cdll.mv_res2net_chain_f16(xd.data_ptr(), y.data_ptr(), arr(packed), arr(dev[0]), arr(dev[1]), arr(dev[2]), B, T, C,
+                                         groups, k, dil, _stream(xd)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    xs = x.float().transpose(1, 2)  # [B, C, T]
+    outs = [xs[:, :width]]
+    prev = None
+    pad = dil * (k - 1) // 2
+    for j in range(1, groups):
+        inp = xs[:, j * width:(j + 1) * width]
+        if j > 1:
+            inp = (inp + prev).half().float()
+        z = F.conv1d(F.pad(inp, (pad, pad), mode='reflect'), ws[j - 1].half().float(), bs[j - 1], dilation=dil)
+        z = torch.relu(z) * ss[j - 1].view(1, -1, 1) + ts[j - 1].view(1, -1, 1)
+        prev = z.half().float()
+        outs.append(prev)
+    ref = torch.cat(outs, 1).transpose(1, 2)
+    err = (y.cpu().float() - ref).abs().max().item()
+    assert err < 1e-2 * max(1.0, ref.abs().max().item()), err
+    return err

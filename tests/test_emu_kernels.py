@@ -91,3 +91,8 @@ def test_emu_melspec_other_geometry():
     wav = frontend.synth_waveforms(1, 1500, seed=13)
     lc.melspec_case(emu_cdll(), 'cpu', wav, None, dict(sample_rate=16000, n_fft=256, win_length=200, hop_length=80, f_min=50,
                                                       f_max=7000, n_mels=40))
+
+
+@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1)])
+def test_emu_res2net_fused_chain(cfg):
+    lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)

@@ -204,3 +204,9 @@ def test_gpu_ecapa_on_melspectrogram_end_to_end():
     emb = model(fz(wav.to(DEV)))
     ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[:3], None, 'MelSpectrogram', {}))
     assert cos_dist(emb[:3].cpu(), ref).max() < 1e-4
+
+
+@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
+                                 dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
+def test_gpu_res2net_fused_chain(cfg):
+    lc.res2_chain_case(product_lib(), DEV, **cfg)

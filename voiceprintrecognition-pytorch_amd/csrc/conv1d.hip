@@ -194,12 +194,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0
 }
 
 __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
-    // XCD-aware assignment: all co-tiles of one n-tile run on the same XCD (block id mod 8)
+    // XCD-aware super-tiles.  Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with a private L2.
+    // XCD x owns the n-tiles x, x+8, ...; inside an XCD the blocks walk groups of <= 8 co-tiles: for each group, for each
+    // owned n-tile, for each co-tile of the group.  The ~64 workgroups resident on an XCD therefore cover ~8 n-tiles x 8
+    // co-tiles and stream K in near lockstep, so every activation slice and every weight slice fetched into that L2
+    // is reused ~8 times before it is evicted.
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int seq = bid >> 3;
-    n_tile = xcd + 8 * (seq / a.co_tiles);
-    co_tile = seq % a.co_tiles;
+    const int nx = (a.n_tiles + 7) >> 3;          // n-tiles per XCD (upper bound)
+    const int group = seq / (nx * 8);             // full groups come first
+    const int base = group * 8;
+    const int gw = a.co_tiles - base < 8 ? a.co_tiles - base : 8;
+    const int idx = seq - nx * base;
+    const int n_local = idx / gw;
+    co_tile = base + idx - n_local * gw;
+    n_tile = xcd + 8 * n_local;
     return n_tile < a.n_tiles;
 }
 

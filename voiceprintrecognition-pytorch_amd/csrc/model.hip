@@ -419,19 +419,33 @@ struct EcapaModel : MvModelBase {
             if ((rc = run_conv(b.tdnn1.conv, xin, MV_DT_F16, ldin, nullptr, 0, s.t1, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
                                b.tdnn1.scale, b.tdnn1.shift, MV_ACT_NONE, nullptr, true, st)))
                 return rc;
-            // Res2Net: slice 0 passes through, slice j = blk_{j-1}(x_j [+ y_{j-1}]).  Step j's epilogue also emits the next
-            // step's input x_{j+1} + y_j into a ping-pong scratch slice, so every step reads one plain fp16 tensor.
-            if ((rc = copy_slice_launch(s.t1, C, s.r2, C, b.width, (int64_t)B * T, st))) return rc;
-            const int pad = b.dil * (b.k - 1) / 2;
-            for (int j = 1; j < cfg.res2net_scale; ++j) {
-                const half_t* in = j == 1 ? s.t1 + (size_t)b.width : s.rs[j & 1];
-                const int64_t ldin_j = j == 1 ? C : b.width;
-                const bool more = j + 1 < cfg.res2net_scale;
-                if ((rc = run_conv(b.res2[j - 1].conv, in, MV_DT_F16, ldin_j, nullptr, 0, s.r2 + (size_t)j * b.width, MV_DT_F16, C, B,
-                                   T, T, b.dil, pad, R, MV_ACT_RELU, b.res2[j - 1].scale, b.res2[j - 1].shift, MV_ACT_NONE, nullptr,
-                                   true, st, more ? s.t1 + (size_t)(j + 1) * b.width : nullptr, C, more ? s.rs[(j + 1) & 1] : nullptr,
-                                   b.width)))
-                    return rc;
+            const int steps = cfg.res2net_scale - 1;
+            if (res2_chain_supported(T, b.width, steps, b.k)) {
+                // whole chain in one launch, one workgroup per utterance (res2.hip)
+                const half_t* wp[16];
+                const float *bp[16], *sp[16], *tp[16];
+                for (int j = 0; j < steps; ++j) {
+                    wp[j] = b.res2[j].conv.w;
+                    bp[j] = b.res2[j].conv.bias;
+                    sp[j] = b.res2[j].scale;
+                    tp[j] = b.res2[j].shift;
+                }
+                if ((rc = res2_chain_launch(s.t1, s.r2, wp, bp, sp, tp, B, T, C, b.width, steps, b.k, b.dil, st))) return rc;
+            } else {
+                // Res2Net: slice 0 passes through, slice j = blk_{j-1}(x_j [+ y_{j-1}]).  Step j's epilogue also emits the next
+                // step's input x_{j+1} + y_j into a ping-pong scratch slice, so every step reads one plain fp16 tensor.
+                if ((rc = copy_slice_launch(s.t1, C, s.r2, C, b.width, (int64_t)B * T, st))) return rc;
+                const int pad = b.dil * (b.k - 1) / 2;
+                for (int j = 1; j < cfg.res2net_scale; ++j) {
+                    const half_t* in = j == 1 ? s.t1 + (size_t)b.width : s.rs[j & 1];
+                    const int64_t ldin_j = j == 1 ? C : b.width;
+                    const bool more = j + 1 < cfg.res2net_scale;
+                    if ((rc = run_conv(b.res2[j - 1].conv, in, MV_DT_F16, ldin_j, nullptr, 0, s.r2 + (size_t)j * b.width, MV_DT_F16, C, B,
+                                       T, T, b.dil, pad, R, MV_ACT_RELU, b.res2[j - 1].scale, b.res2[j - 1].shift, MV_ACT_NONE, nullptr,
+                                       true, st, more ? s.t1 + (size_t)(j + 1) * b.width : nullptr, C, more ? s.rs[(j + 1) & 1] : nullptr,
+                                       b.width)))
+                        return rc;
+                }
             }
             if ((rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
                                b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st)))

@@ -12,20 +12,25 @@
 namespace mv {
 
 // ------------------------------------------------------------------------------------------------
-// mean / std over time.  Workgroup = (utterance, 512-channel group); lane owns 8 channels, waves split T.
-// Two passes (mean, then centred second moment) exactly like the reference's (x - mean)^2 form.
+// mean / std over time.  Workgroup = (utterance, 128-channel group): lane (c16 = lane & 15) owns 8 channels, the four
+// 16-lane groups of a wave and the four waves take interleaved time steps (16 rows in flight per workgroup), so a
+// [B=256, C=1024] reduction runs 2048 workgroups.  Two passes (mean, then centred second moment) exactly like the
+// reference's (x - mean)^2 form.
 // Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
                                                          float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
                                                          const float* in_scale, const float* in_shift) {
-    __shared__ float red[4][512];
-    __shared__ float mu[512];
+    __shared__ float red[4][128];
+    __shared__ float mu[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, rp = lane >> 4;
     const int b = blockIdx.y;
-    const int c0 = blockIdx.x * 512 + lane * 8;
+    const int cg0 = blockIdx.x * 128;
+    const int c0 = cg0 + c16 * 8;
     const bool active = c0 < C;
     const int nvalid = active ? (C - c0 < 8 ? C - c0 : 8) : 0;
     const half_t* xb = x + (int64_t)b * T * ld + c0;
+    const int t_first = wave * 4 + rp;  // this lane's rows: t_first, t_first + 16, ...
     float s[8], isc[8], ish[8];
     const bool pre = in_scale != nullptr;
 #pragma unroll
@@ -38,8 +43,17 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
         const float v = (float)h;
         return pre ? fmaxf(v * isc[e] + ish[e], 0.0f) : v;
     };
+    auto reduce_store = [&]() {  // sum over the 4 row groups of the wave, then over waves
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = s[e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (rp == 0) red[wave][c16 * 8 + e] = v;
+        }
+    };
     if (active) {
-        for (int t = wave; t < T; t += 4) {
+        for (int t = t_first; t < T; t += 16) {
             const half_t* p = xb + (int64_t)t * ld;
             if (nvalid == 8) {
                 const half8v v = *reinterpret_cast<const half8v*>(p);
@@ -50,22 +64,23 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+    reduce_store();
     __syncthreads();
-    for (int c = tid; c < 512; c += 256) mu[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)T;
-    __syncthreads();
-    for (int c = tid; c < 512; c += 256)
-        if (blockIdx.x * 512 + c < C) mean[(int64_t)b * ld_out + blockIdx.x * 512 + c] = mu[c];
+    if (tid < 128) {
+        const float m = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)T;
+        mu[tid] = m;
+        if (cg0 + tid < C) mean[(int64_t)b * ld_out + cg0 + tid] = m;
+    }
     if (stdv == nullptr) return;
+    __syncthreads();
     float m8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        m8[e] = mu[lane * 8 + e];
+        m8[e] = mu[c16 * 8 + e];
         s[e] = 0.0f;
     }
     if (active) {
-        for (int t = wave; t < T; t += 4) {
+        for (int t = t_first; t < T; t += 16) {
             const half_t* p = xb + (int64_t)t * ld;
             if (nvalid == 8) {
                 const half8v v = *reinterpret_cast<const half8v*>(p);
@@ -82,17 +97,14 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
             }
         }
     }
+    __syncthreads();  // everyone has read mu / red before red is reused
+    reduce_store();
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
-    __syncthreads();
-    const float denom = unbiased ? (float)(T - 1) : (float)T;
-    for (int c = tid; c < 512; c += 256) {
-        if (blockIdx.x * 512 + c < C) {
-            float var = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / denom;
-            if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
-            stdv[(int64_t)b * ld_out + blockIdx.x * 512 + c] = sqrtf(var);
-        }
+    if (tid < 128 && cg0 + tid < C) {
+        const float denom = unbiased ? (float)(T - 1) : (float)T;
+        float var = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / denom;
+        if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
+        stdv[(int64_t)b * ld_out + cg0 + tid] = sqrtf(var);
     }
 }
 
@@ -102,7 +114,7 @@ int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* m
     MV_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
-    MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 512), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
+    MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
               ld_out, unbiased, clamp_eps, in_scale, in_shift);
     return check_launch("time_stats_kernel");
 }
@@ -278,9 +290,9 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
     const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
     const int ntiles = (a.T + 15) / 16;
 
-    auto logits = [&](int t0, float4v (&l)[4]) {
+    // h rows of one 16-frame tile in MFMA B-fragment layout (row t0 + fr, k = kk*32 + 8*fg .. +8)
+    auto load_h = [&](int t0, half8v (&hf)[KS]) {
         const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
-        half8v hf[KS];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const int k = kk * 32 + 8 * fg;
@@ -291,6 +303,8 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
                 for (int e = 0; e < 8; ++e) hf[kk][e] = (k + e < a.A) ? hb[(int64_t)t * a.A + k + e] : (half_t)0.0f;
             }
         }
+    };
+    auto logits = [&](const half8v (&hf)[KS], float4v (&l)[4]) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             l[mi] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
@@ -298,21 +312,44 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
             for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
         }
     };
+    auto load_x = [&](int t0, half4v (&xv)[4]) {
+        const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int c = c0 + mi * 16 + 4 * fg;
+            if (c + 3 < a.C) {
+                xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
+            }
+        }
+    };
 
-    // ---- pass 1: per-channel max over time ----
+    // ---- pass 1: per-channel max over time (next tile's h rows are fetched while this tile computes) ----
     float mx[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx[mi][r] = -3.0e38f;
-    for (int tt = wave; tt < ntiles; tt += 4) {
-        float4v l[4];
-        logits(tt * 16, l);
-        if (tt * 16 + fr < a.T) {
+    {
+        half8v hcur[KS], hnext[KS];
+        if (wave < ntiles) load_h(wave * 16, hcur);
+        for (int tt = wave; tt < ntiles; tt += 4) {
+            const bool more = tt + 4 < ntiles;
+            if (more) load_h((tt + 4) * 16, hnext);
+            float4v l[4];
+            logits(hcur, l);
+            if (tt * 16 + fr < a.T) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
+                    for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
+            }
+            if (more) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+            }
         }
     }
 #pragma unroll
@@ -334,35 +371,44 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx[mi][r] = cmax[mi * 16 + 4 * fg + r];
 
-    // ---- pass 2: weights and shifted moments ----
+    // ---- pass 2: weights and shifted moments (h and x of the next tile prefetched) ----
     float s0[4][4], s1[4][4], s2[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
-    for (int tt = wave; tt < ntiles; tt += 4) {
-        float4v l[4];
-        logits(tt * 16, l);
-        const int t = tt * 16 + fr;
-        if (t < a.T) {
+    {
+        half8v hcur[KS], hnext[KS];
+        half4v xcur[4], xnext[4];
+        if (wave < ntiles) {
+            load_h(wave * 16, hcur);
+            load_x(wave * 16, xcur);
+        }
+        for (int tt = wave; tt < ntiles; tt += 4) {
+            const bool more = tt + 4 < ntiles;
+            if (more) {
+                load_h((tt + 4) * 16, hnext);
+                load_x((tt + 4) * 16, xnext);
+            }
+            float4v l[4];
+            logits(hcur, l);
+            if (tt * 16 + fr < a.T) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int c = c0 + mi * 16 + 4 * fg;
-                half4v xv;
-                if (c + 3 < a.C) {
-                    xv = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
-                } else {
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xv[r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(l[mi][r] - mx[mi][r]);
+                        const float d = (float)xcur[mi][r] - g[mi][r];
+                        s0[mi][r] += e;
+                        s1[mi][r] += e * d;
+                        s2[mi][r] += e * d * d;
+                    }
+            }
+            if (more) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = expf(l[mi][r] - mx[mi][r]);
-                    const float d = (float)xv[r] - g[mi][r];
-                    s0[mi][r] += e;
-                    s1[mi][r] += e * d;
-                    s2[mi][r] += e * d * d;
-                }
+                for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) xcur[mi] = xnext[mi];
             }
         }
     }

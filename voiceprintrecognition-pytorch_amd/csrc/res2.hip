@@ -1,0 +1,239 @@
+// Fused Res2Net chain of an SE-Res2Block (mvector/models/ecapa_tdnn.py:39-51): the `scale-1` dependent dilated
+// convolutions  y_j = BN(ReLU(conv_j(x_j + y_{j-1})))  of ONE utterance run inside ONE workgroup.
+//
+// Why: each step is a tiny GEMM (T x width x 3*width); as separate launches they are latency bound (7 dependent
+// launches per block, every intermediate makes an HBM round trip).  Here the step input lives in LDS for the whole
+// chain ([T_pad x width] fp16, XOR-swizzled rows), the step output stays in the MFMA accumulators until every wave has
+// finished reading the input, is then added to the next channel group x_{j+1} and written back over the input buffer.
+// Only the weights stream in (global -> LDS direct, double buffered, 64-wide K stages); they are shared by all
+// workgroups and stay in L2.  HBM traffic is the algorithmic minimum: read x once, write y once.
+//
+// Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
+// torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
+#include "kernels.h"
+
+namespace mv {
+
+constexpr int R2_THREADS = 512;
+constexpr int R2_NH = 10;            // time tiles (16 frames) per wave half -> T <= 320
+constexpr int R2_MAX_STEPS = 15;
+constexpr int R2_WSTAGE_BYTES = 128 * 64 * 2;  // one K stage of weights: [<=128 rows][64] fp16
+
+struct Res2Args {
+    const half_t* x;   // [B, T, C]  tdnn1 output
+    half_t* y;         // [B, T, C]  res2net output
+    const half_t* w[R2_MAX_STEPS];      // packed [width][k][width_pad] per step
+    const float* bias[R2_MAX_STEPS];
+    const float* scale[R2_MAX_STEPS];
+    const float* shift[R2_MAX_STEPS];
+    int T, C, width, steps, k, dil, kpad;  // kpad = round_up(width, 64)
+};
+
+__device__ __forceinline__ void r2_glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef MV_EMU
+    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ void r2_wait_loads() {
+#ifndef MV_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// MI = output channel tiles per wave (width = 64 * MI)
+template <int MI>
+__global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
+    MV_DYN_SMEM(smem);
+    constexpr int WIDTH = 64 * MI;
+    constexpr int CPR = WIDTH / 8;       // 16-byte chunks per activation row
+    constexpr int ROWB = WIDTH * 2;      // bytes per activation row
+    char* wbuf = smem;                               // 2 x R2_WSTAGE_BYTES
+    char* abuf = smem + 2 * R2_WSTAGE_BYTES;         // [Tp][WIDTH] fp16, chunk index ^= row & (CPR-1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.x;
+    const int T = a.T;
+    const int Tp = (T + 15) & ~15;
+    const int64_t rowbase = (int64_t)b * T;
+    const half_t* xb = a.x + rowbase * a.C;
+    half_t* yb = a.y + rowbase * a.C;
+    auto a_off = [&](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CPR - 1))) << 4); };
+
+    // ---- slice 0 passes through; slice 1 becomes the first step's input ----
+    for (int i = tid; i < Tp * CPR; i += R2_THREADS) {
+        const int row = i / CPR, ch = i - row * CPR;
+        half8v v0, v1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v0[e] = v1[e] = (half_t)0.0f;
+        if (row < T) {
+            v0 = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.C + ch * 8);
+            v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.C + WIDTH + ch * 8);
+            *reinterpret_cast<half8v*>(yb + (int64_t)row * a.C + ch * 8) = v0;
+        }
+        *reinterpret_cast<half8v*>(abuf + a_off(row, ch)) = v1;
+    }
+
+    const int cw = wave & 3;   // channel tile group
+    const int th = wave >> 2;  // time half
+    const int ntile = Tp / 16;
+    const int nh0 = th * R2_NH;  // first time tile of this wave
+    const int kstages_per_tap = a.kpad / 64;
+    const int nstages = a.k * kstages_per_tap;
+    const int half_k = (a.k - 1) / 2;
+    // weight transfers: a stage is [WIDTH rows][64] = WIDTH/8 transfers of 1 KiB; wave w issues transfers w, w+8
+    const int lrow = lane >> 3;
+    const int kc = (lane & 7) ^ lrow;
+
+    for (int j = 1; j <= a.steps; ++j) {
+        const half_t* wj = a.w[j - 1];
+        auto issue_w = [&](int s, int buf) {
+            const int tap = s / kstages_per_tap;
+            const int c0 = (s - tap * kstages_per_tap) * 64;
+            for (int tr = wave; tr < WIDTH / 8; tr += 8) {
+                const int co = tr * 8 + lrow;
+                r2_glds16(wj + ((int64_t)co * a.k + tap) * a.kpad + c0 + kc * 8, wbuf + buf * R2_WSTAGE_BYTES + tr * 1024);
+            }
+        };
+        float4v acc[MI][R2_NH];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < R2_NH; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        issue_w(0, 0);
+        r2_wait_loads();
+        __syncthreads();  // weights of stage 0 landed; activation buffer of this step is complete
+        for (int s = 0; s < nstages; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nstages) issue_w(s + 1, buf ^ 1);
+            const int tap = s / kstages_per_tap;
+            const int c0 = (s - tap * kstages_per_tap) * 64;
+            const int shift = (tap - half_k) * a.dil;
+            const char* wt = wbuf + buf * R2_WSTAGE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (c0 + kk * 32 < WIDTH) {  // K padding beyond the width holds zeros in the packed weights: skip
+                    half8v af[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row = (cw * MI + mi) * 16 + fr;
+                        af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < R2_NH; ++ni) {
+                        if (nh0 + ni < ntile) {
+                            int t = (nh0 + ni) * 16 + fr;
+                            t = t < T ? t : T - 1;
+                            int tin = t + shift;
+                            tin = tin < 0 ? -tin : (tin >= T ? 2 * (T - 1) - tin : tin);  // reflect "same" padding
+                            const half8v bf = *reinterpret_cast<const half8v*>(abuf + a_off(tin, (c0 >> 3) + kk * 4 + fg));
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf, acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            r2_wait_loads();
+            __syncthreads();
+        }
+        // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer ----
+        const bool more = j < a.steps;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int co = (cw * MI + mi) * 16 + 4 * fg;
+            const float4v bias4 = *reinterpret_cast<const float4v*>(a.bias[j - 1] + co);
+            const float4v scale4 = *reinterpret_cast<const float4v*>(a.scale[j - 1] + co);
+            const float4v shift4 = *reinterpret_cast<const float4v*>(a.shift[j - 1] + co);
+#pragma unroll
+            for (int ni = 0; ni < R2_NH; ++ni) {
+                if (nh0 + ni < ntile) {
+                    const int t = (nh0 + ni) * 16 + fr;
+                    half4v hv, nv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r];
+                        v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                        hv[r] = (half_t)v;
+                        nv[r] = (half_t)0.0f;
+                    }
+                    if (t < T) {
+                        *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
+                        if (more) {
+                            const half4v xv = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float v = (float)hv[r] + (float)xv[r];
+                                v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                                nv[r] = (half_t)v;
+                            }
+                        }
+                    }
+                    if (more) *reinterpret_cast<half4v*>(abuf + a_off(t, co >> 3) + (co & 7) * 2) = nv;
+                }
+            }
+        }
+        // the next step's first barrier (after its stage-0 weight load) publishes these LDS writes
+    }
+}
+
+size_t res2_chain_lds_bytes(int T, int width) { return 2 * (size_t)R2_WSTAGE_BYTES + (size_t)round_up(T, 16) * width * 2; }
+
+bool res2_chain_supported(int T, int width, int steps, int k) {
+    return (width == 64 || width == 128) && T <= 16 * 2 * R2_NH && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1;
+}
+
+int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const float* const* bias, const float* const* scale,
+                      const float* const* shift, int B, int T, int C, int width, int steps, int k, int dil, hipStream_t stream) {
+    MV_REQUIRE(res2_chain_supported(T, width, steps, k), "res2_chain: unsupported geometry");
+    MV_REQUIRE(C == width * (steps + 1), "res2_chain: channels must be (steps + 1) * width");
+    MV_REQUIRE(dil * (k - 1) / 2 < T, "res2_chain: reflect padding needs pad < T");
+    Res2Args a;
+    a.x = x;
+    a.y = y;
+    for (int j = 0; j < steps; ++j) {
+        a.w[j] = w[j];
+        a.bias[j] = bias[j];
+        a.scale[j] = scale[j];
+        a.shift[j] = shift[j];
+    }
+    a.T = T;
+    a.C = C;
+    a.width = width;
+    a.steps = steps;
+    a.k = k;
+    a.dil = dil;
+    a.kpad = conv1d_cin_pad(width);
+    const size_t lds = res2_chain_lds_bytes(T, width);
+    if (width == 128) {
+        if (MV_SET_MAX_SMEM(res2_chain_kernel<2>, lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
+        MV_LAUNCH(res2_chain_kernel<2>, ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+    } else {
+        if (MV_SET_MAX_SMEM(res2_chain_kernel<1>, lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
+        MV_LAUNCH(res2_chain_kernel<1>, ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+    }
+    return check_launch("res2_chain_kernel");
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, const float* const* bias,
+                         const float* const* scale, const float* const* shift, int32_t B, int32_t T, int32_t C,
+                         int32_t groups, int32_t k, int32_t dilation, mv_stream_t stream) {
+    MV_REQUIRE(x != nullptr && y != nullptr && w_packed != nullptr && bias != nullptr && scale != nullptr && shift != nullptr,
+               "mv_res2net_chain_f16: null argument");
+    MV_REQUIRE(groups >= 2 && C % groups == 0 && B > 0 && T > 0, "mv_res2net_chain_f16: bad geometry");
+    const int width = C / groups;
+    if (!mv::res2_chain_supported(T, width, groups - 1, k))
+        return mv::fail(MV_ERR_UNSUPPORTED, "mv_res2net_chain_f16: fused chain needs width 64/128, T <= 320 and an odd kernel");
+    return mv::res2_chain_launch(reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
+                                 reinterpret_cast<const half_t* const*>(w_packed), bias, scale, shift, B, T, C, width, groups - 1, k,
+                                 dilation, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -87,6 +87,8 @@ _SIGNATURES = {
     'mv_conv1d_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
     'mv_conv1d_pack_weight': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_conv1d_forward': (c_i32, [ctypes.POINTER(MvConv1dDesc), c_vp]),
+    'mv_res2net_chain_f16': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                             ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'mv_linear_f32': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
 }
