@@ -257,35 +257,11 @@ struct AspArgs {
 
 template <int KS>
 __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
-    __shared__ float red[4][4][64];  // [wave][quantity][channel]
-    __shared__ float cmax[64];
+    __shared__ float red[4][4][32];  // [wave][quantity][channel of the current half]
+    __shared__ float cmax[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const int c0 = blockIdx.x * 64;
     const int fr = lane & 15, fg = lane >> 4;
-    // A fragments: W2 rows c0 + mi*16 + fr, k = kk*32 + 8*fg .. +8
-    half8v wf[4][KS];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int row = c0 + mi * 16 + fr;
-            if (row < a.C_pad) {
-                wf[mi][kk] = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * fg);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) wf[mi][kk][e] = (half_t)0.0f;
-            }
-        }
-    float bias[4][4], g[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = c0 + mi * 16 + 4 * fg + r;
-            bias[mi][r] = c < a.C ? a.b2[c] : 0.0f;
-            g[mi][r] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-        }
     const half_t* hb = a.h + (int64_t)b * a.T * a.A;
     const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
     const int ntiles = (a.T + 15) / 16;
@@ -304,146 +280,176 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
             }
         }
     };
-    auto logits = [&](const half8v (&hf)[KS], float4v (&l)[4]) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            l[mi] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
-        }
-    };
-    auto load_x = [&](int t0, half4v (&xv)[4]) {
-        const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int c = c0 + mi * 16 + 4 * fg;
-            if (c + 3 < a.C) {
-                xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
-            }
-        }
-    };
 
-    // ---- pass 1: per-channel max over time (next tile's h rows are fetched while this tile computes) ----
-    float mx[4][4];
+    // The 64 channels of the workgroup are processed as two halves of 32 (two MFMA row tiles) to keep the per-lane
+    // state small enough for 3 waves per SIMD; both halves touch the same 128-byte lines of x back to back.
+    for (int half = 0; half < 2; ++half) {
+        const int c0 = blockIdx.x * 64 + half * 32;
+        if (c0 >= a.C) break;
+        // A fragments: W2 rows c0 + mi*16 + fr, k = kk*32 + 8*fg .. +8
+        half8v wf[2][KS];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx[mi][r] = -3.0e38f;
-    {
-        half8v hcur[KS], hnext[KS];
-        if (wave < ntiles) load_h(wave * 16, hcur);
-        for (int tt = wave; tt < ntiles; tt += 4) {
-            const bool more = tt + 4 < ntiles;
-            if (more) load_h((tt + 4) * 16, hnext);
-            float4v l[4];
-            logits(hcur, l);
-            if (tt * 16 + fr < a.T) {
+            for (int kk = 0; kk < KS; ++kk) {
+                const int row = c0 + mi * 16 + fr;
+                if (row < a.C_pad) {
+                    wf[mi][kk] = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * fg);
+                } else {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
+                    for (int e = 0; e < 8; ++e) wf[mi][kk][e] = (half_t)0.0f;
+                }
             }
-            if (more) {
+        float bias[2][4], g[2][4];
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + mi * 16 + 4 * fg + r;
+                bias[mi][r] = c < a.C ? a.b2[c] : 0.0f;
+                g[mi][r] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
             }
-        }
-    }
+        auto logits = [&](const half8v (&hf)[KS], float4v (&l)[2]) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 2; ++mi) {
+                l[mi] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = mx[mi][r];
-            v = fmaxf(v, __shfl_xor(v, 1));
-            v = fmaxf(v, __shfl_xor(v, 2));
-            v = fmaxf(v, __shfl_xor(v, 4));
-            v = fmaxf(v, __shfl_xor(v, 8));
-            if (fr == 0) red[wave][0][mi * 16 + 4 * fg + r] = v;
-        }
-    __syncthreads();
-    if (tid < 64) cmax[tid] = fmaxf(fmaxf(red[0][0][tid], red[1][0][tid]), fmaxf(red[2][0][tid], red[3][0][tid]));
-    __syncthreads();
+                for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
+            }
+        };
+        auto load_x = [&](int t0, half4v (&xv)[2]) {
+            const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 2; ++mi) {
+                const int c = c0 + mi * 16 + 4 * fg;
+                if (c + 3 < a.C) {
+                    xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
+                } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx[mi][r] = cmax[mi * 16 + 4 * fg + r];
+                    for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
+                }
+            }
+        };
 
-    // ---- pass 2: weights and shifted moments (h and x of the next tile prefetched) ----
-    float s0[4][4], s1[4][4], s2[4][4];
+        // ---- pass 1: per-channel max over time (the next tile's h rows are fetched while this tile computes) ----
+        float mx[2][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
-    {
-        half8v hcur[KS], hnext[KS];
-        half4v xcur[4], xnext[4];
-        if (wave < ntiles) {
-            load_h(wave * 16, hcur);
-            load_x(wave * 16, xcur);
-        }
-        for (int tt = wave; tt < ntiles; tt += 4) {
-            const bool more = tt + 4 < ntiles;
-            if (more) {
-                load_h((tt + 4) * 16, hnext);
-                load_x((tt + 4) * 16, xnext);
-            }
-            float4v l[4];
-            logits(hcur, l);
-            if (tt * 16 + fr < a.T) {
+            for (int r = 0; r < 4; ++r) mx[mi][r] = -3.0e38f;
+        {
+            half8v hcur[KS], hnext[KS];
+            if (wave < ntiles) load_h(wave * 16, hcur);
+            for (int tt = wave; tt < ntiles; tt += 4) {
+                const bool more = tt + 4 < ntiles;
+                if (more) load_h((tt + 4) * 16, hnext);
+                float4v l[2];
+                logits(hcur, l);
+                if (tt * 16 + fr < a.T) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __expf(l[mi][r] - mx[mi][r]);
-                        const float d = (float)xcur[mi][r] - g[mi][r];
-                        s0[mi][r] += e;
-                        s1[mi][r] += e * d;
-                        s2[mi][r] += e * d * d;
-                    }
-            }
-            if (more) {
+                        for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
+                }
+                if (more) {
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xcur[mi] = xnext[mi];
+                    for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+                }
             }
         }
-    }
-    __syncthreads();  // red[.][0] readers are done
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v0 = s0[mi][r], v1 = s1[mi][r], v2 = s2[mi][r];
-#pragma unroll
-            for (int m = 1; m <= 8; m <<= 1) {
-                v0 += __shfl_xor(v0, m);
-                v1 += __shfl_xor(v1, m);
-                v2 += __shfl_xor(v2, m);
+            for (int r = 0; r < 4; ++r) {
+                float v = mx[mi][r];
+                v = fmaxf(v, __shfl_xor(v, 1));
+                v = fmaxf(v, __shfl_xor(v, 2));
+                v = fmaxf(v, __shfl_xor(v, 4));
+                v = fmaxf(v, __shfl_xor(v, 8));
+                if (fr == 0) red[wave][0][mi * 16 + 4 * fg + r] = v;
             }
-            if (fr == 0) {
-                const int ch = mi * 16 + 4 * fg + r;
-                red[wave][1][ch] = v0;
-                red[wave][2][ch] = v1;
-                red[wave][3][ch] = v2;
+        __syncthreads();
+        if (tid < 32) cmax[tid] = fmaxf(fmaxf(red[0][0][tid], red[1][0][tid]), fmaxf(red[2][0][tid], red[3][0][tid]));
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[mi][r] = cmax[mi * 16 + 4 * fg + r];
+
+        // ---- pass 2: weights and shifted moments (h and x of the next tile prefetched) ----
+        float s0[2][4], s1[2][4], s2[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
+        {
+            half8v hcur[KS], hnext[KS];
+            half4v xcur[2], xnext[2];
+            if (wave < ntiles) {
+                load_h(wave * 16, hcur);
+                load_x(wave * 16, xcur);
+            }
+            for (int tt = wave; tt < ntiles; tt += 4) {
+                const bool more = tt + 4 < ntiles;
+                if (more) {
+                    load_h((tt + 4) * 16, hnext);
+                    load_x((tt + 4) * 16, xnext);
+                }
+                float4v l[2];
+                logits(hcur, l);
+                if (tt * 16 + fr < a.T) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __expf(l[mi][r] - mx[mi][r]);
+                            const float d = (float)xcur[mi][r] - g[mi][r];
+                            s0[mi][r] += e;
+                            s1[mi][r] += e * d;
+                            s2[mi][r] += e * d * d;
+                        }
+                }
+                if (more) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) xcur[mi] = xnext[mi];
+                }
             }
         }
-    __syncthreads();
-    if (tid < 64) {
-        const int c = c0 + tid;
-        if (c < a.C) {
-            const float z0 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
-            const float z1 = red[0][2][tid] + red[1][2][tid] + red[2][2][tid] + red[3][2][tid];
-            const float z2 = red[0][3][tid] + red[1][3][tid] + red[2][3][tid] + red[3][3][tid];
-            const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-            const float m1 = z1 / z0;
-            const float var = z2 / z0 - m1 * m1;
-            a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
-            a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v0 = s0[mi][r], v1 = s1[mi][r], v2 = s2[mi][r];
+#pragma unroll
+                for (int m = 1; m <= 8; m <<= 1) {
+                    v0 += __shfl_xor(v0, m);
+                    v1 += __shfl_xor(v1, m);
+                    v2 += __shfl_xor(v2, m);
+                }
+                if (fr == 0) {
+                    const int ch = mi * 16 + 4 * fg + r;
+                    red[wave][1][ch] = v0;
+                    red[wave][2][ch] = v1;
+                    red[wave][3][ch] = v2;
+                }
+            }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = c0 + tid;
+            if (c < a.C) {
+                const float z0 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+                const float z1 = red[0][2][tid] + red[1][2][tid] + red[2][2][tid] + red[3][2][tid];
+                const float z2 = red[0][3][tid] + red[1][3][tid] + red[2][3][tid] + red[3][3][tid];
+                const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+                const float m1 = z1 / z0;
+                const float var = z2 / z0 - m1 * m1;
+                a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
+                a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+            }
         }
+        __syncthreads();  // red / cmax are reused by the second half
     }
 }
 

@@ -18,6 +18,7 @@ constexpr int R2_THREADS = 512;
 constexpr int R2_NH = 10;            // time tiles (16 frames) per wave half -> T <= 320
 constexpr int R2_MAX_STEPS = 15;
 constexpr int R2_WSTAGE_BYTES = 128 * 64 * 2;  // one K stage of weights: [<=128 rows][64] fp16
+constexpr int R2_RING = 4;                     // weight stages in flight (ring of LDS slots)
 
 struct Res2Args {
     const half_t* x;   // [B, T, C]  tdnn1 output
@@ -38,9 +39,21 @@ __device__ __forceinline__ void r2_glds16(const void* gsrc, char* lds_wave_base)
 #endif
 }
 
-__device__ __forceinline__ void r2_wait_loads() {
+// wait until at most N of this wave's vector-memory operations are outstanding (the N youngest may stay in flight)
+template <int N>
+__device__ __forceinline__ void r2_wait_vm() {
 #ifndef MV_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the weight transfers that
+// are still in flight for later stages
+__device__ __forceinline__ void r2_lds_barrier() {
+#ifdef MV_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
 
@@ -51,8 +64,9 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     constexpr int WIDTH = 64 * MI;
     constexpr int CPR = WIDTH / 8;       // 16-byte chunks per activation row
     constexpr int ROWB = WIDTH * 2;      // bytes per activation row
-    char* wbuf = smem;                               // 2 x R2_WSTAGE_BYTES
-    char* abuf = smem + 2 * R2_WSTAGE_BYTES;         // [Tp][WIDTH] fp16, chunk index ^= row & (CPR-1)
+    constexpr int TP = MI;               // weight transfers per stage per wave (WIDTH/8 transfers over 8 waves)
+    char* wbuf = smem;                               // R2_RING x R2_WSTAGE_BYTES
+    char* abuf = smem + R2_RING * R2_WSTAGE_BYTES;   // [Tp][WIDTH] fp16, chunk index ^= row & (CPR-1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.x;
@@ -103,12 +117,23 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < R2_NH; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        issue_w(0, 0);
-        r2_wait_loads();
-        __syncthreads();  // weights of stage 0 landed; activation buffer of this step is complete
+        // Weight stages run up to R2_RING-1 ahead of the MFMAs: wait (counted) for stage s, barrier, refill the slot that
+        // stage s-1 just released with stage s+3, compute stage s.  One barrier per stage; it also publishes the
+        // activation buffer written by the previous step's epilogue.
+        for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         for (int s = 0; s < nstages; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nstages) issue_w(s + 1, buf ^ 1);
+            const int last_issued = s + R2_RING - 2 < nstages - 1 ? s + R2_RING - 2 : nstages - 1;
+            const int younger = last_issued - s;  // stages issued after stage s
+            if (younger >= 2) {
+                r2_wait_vm<2 * TP>();
+            } else if (younger == 1) {
+                r2_wait_vm<TP>();
+            } else {
+                r2_wait_vm<0>();
+            }
+            r2_lds_barrier();
+            if (s + R2_RING - 1 < nstages) issue_w(s + R2_RING - 1, (s + R2_RING - 1) % R2_RING);
+            const int buf = s % R2_RING;
             const int tap = s / kstages_per_tap;
             const int c0 = (s - tap * kstages_per_tap) * 64;
             const int shift = (tap - half_k) * a.dil;
@@ -122,26 +147,40 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                         const int row = (cw * MI + mi) * 16 + fr;
                         af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                     }
+                    // all R2_NH tiles are computed unconditionally (rows beyond T are clamped to T-1 and never stored):
+                    // no per-tile branch, so the LDS reads of a K step are batched ahead of its MFMAs
+                    half8v bf[R2_NH];
 #pragma unroll
                     for (int ni = 0; ni < R2_NH; ++ni) {
-                        if (nh0 + ni < ntile) {
-                            int t = (nh0 + ni) * 16 + fr;
-                            t = t < T ? t : T - 1;
-                            int tin = t + shift;
-                            tin = tin < 0 ? -tin : (tin >= T ? 2 * (T - 1) - tin : tin);  // reflect "same" padding
-                            const half8v bf = *reinterpret_cast<const half8v*>(abuf + a_off(tin, (c0 >> 3) + kk * 4 + fg));
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf, acc[mi][ni], 0, 0, 0);
-                        }
+                        int t = (nh0 + ni) * 16 + fr;
+                        t = t < T ? t : T - 1;
+                        int tin = t + shift;
+                        tin = tin < 0 ? -tin : (tin >= T ? 2 * (T - 1) - tin : tin);  // reflect "same" padding
+                        bf[ni] = *reinterpret_cast<const half8v*>(abuf + a_off(tin, (c0 >> 3) + kk * 4 + fg));
                     }
+#pragma unroll
+                    for (int ni = 0; ni < R2_NH; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
                 }
             }
-            r2_wait_loads();
-            __syncthreads();
         }
+        r2_lds_barrier();  // every wave is done with the activation buffer and the weight ring
         // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer ----
         const bool more = j < a.steps;
+        // the next channel group x_{j+1}: every load is issued before the first use (rows clamped, stores predicated)
+        half4v xn[MI][R2_NH];
+        if (more) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < R2_NH; ++ni) {
+                    int t = (nh0 + ni) * 16 + fr;
+                    t = t < T ? t : T - 1;
+                    xn[mi][ni] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + (cw * MI + mi) * 16 + 4 * fg);
+                }
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int co = (cw * MI + mi) * 16 + 4 * fg;
@@ -150,37 +189,26 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             const float4v shift4 = *reinterpret_cast<const float4v*>(a.shift[j - 1] + co);
 #pragma unroll
             for (int ni = 0; ni < R2_NH; ++ni) {
-                if (nh0 + ni < ntile) {
-                    const int t = (nh0 + ni) * 16 + fr;
-                    half4v hv, nv;
+                const int t = (nh0 + ni) * 16 + fr;
+                half4v hv, nv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r];
-                        v = fminf(fmaxf(v, -65504.0f), 65504.0f);
-                        hv[r] = (half_t)v;
-                        nv[r] = (half_t)0.0f;
-                    }
-                    if (t < T) {
-                        *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
-                        if (more) {
-                            const half4v xv = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + co);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float v = (float)hv[r] + (float)xv[r];
-                                v = fminf(fmaxf(v, -65504.0f), 65504.0f);
-                                nv[r] = (half_t)v;
-                            }
-                        }
-                    }
-                    if (more) *reinterpret_cast<half4v*>(abuf + a_off(t, co >> 3) + (co & 7) * 2) = nv;
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r];
+                    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                    hv[r] = (half_t)v;
+                    float w = more ? (float)hv[r] + (float)xn[mi][ni][r] : 0.0f;
+                    w = fminf(fmaxf(w, -65504.0f), 65504.0f);
+                    nv[r] = t < T ? (half_t)w : (half_t)0.0f;
                 }
+                if (t < T) *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
+                if (more && t < Tp) *reinterpret_cast<half4v*>(abuf + a_off(t, co >> 3) + (co & 7) * 2) = nv;
             }
         }
-        // the next step's first barrier (after its stage-0 weight load) publishes these LDS writes
+        // the next step's first stage barrier publishes these LDS writes
     }
 }
 
-size_t res2_chain_lds_bytes(int T, int width) { return 2 * (size_t)R2_WSTAGE_BYTES + (size_t)round_up(T, 16) * width * 2; }
+size_t res2_chain_lds_bytes(int T, int width) { return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)round_up(T, 16) * width * 2; }
 
 bool res2_chain_supported(int T, int width, int steps, int k) {
     return (width == 64 || width == 128) && T <= 16 * 2 * R2_NH && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1;
