@@ -209,6 +209,7 @@ typedef struct MvConv1dDesc {
     void* sum_dst;        /* x_{j+1} + y_j of the next Res2Net step (ecapa_tdnn.py:47) produced by this step's epilogue */
     int64_t ld_add, ld_sum;
     int32_t B, T_in, T_out, cin, cout, k, dilation, stride, pad, pad_mode;
+    int32_t tile;         /* workgroup tile: 0 = choose (256x256 for wide layers that fill the chip, else 128x128), 128, 256 */
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
 

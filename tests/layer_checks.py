@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, seed=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, seed=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -72,6 +72,7 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     d.B, d.T_in, d.T_out, d.cin, d.cout, d.k = B, T, T_out, cin, cout, k
     d.dilation, d.stride, d.pad = dil, stride, pad
     d.pad_mode = _hip.MV_PAD_REFLECT if pad_mode == 'reflect' else _hip.MV_PAD_ZERO
+    d.tile = tile
     _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
@@ -121,6 +122,8 @@ CONV_CASES = [
     dict(k=1, dil=1, y_f32=True, pre_act=0, affine=False, cin=64, cout=20, T=9, B=5),  # fp32 out, ragged cout
     dict(k=3, dil=1, B=1, T=300, cin=8, cout=8, extra_ld=56),         # many n tiles, narrow slice of a wide row
     dict(k=3, dil=2, cin=16, cout=16, second_out=True, T=41),          # Res2Net step emitting the next step's input
+    dict(k=1, dil=1, cin=72, cout=256, T=300, B=1, tile=256),           # 256 x 256 workgroup tile (8 waves)
+    dict(k=3, dil=2, cin=64, cout=512, T=70, B=2, tile=256, row_bias=True, post_act=2),  # 256 tile, 2 co tiles, ragged rows
 ]
 
 

@@ -19,6 +19,7 @@ REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/rocprof.log
 for f in $(find $OUT/prof -name "*kernel_stats*.csv"); do head -30 $f; done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $OUT/prof_campp -o bench -- python $REPO/bench.py --model campp --steps 3 --warmup 2 --no-cpu-baseline > $OUT/rocprof_campp.log 2>&1
 cd $REPO
 echo "== bench campp"; timeout 600 python bench.py --model campp --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_campp.log 2>&1; tail -1 $OUT/bench_campp.log
 echo "== bench ecapa512"; timeout 600 python bench.py --model ecapa512 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_ecapa512.log 2>&1; tail -1 $OUT/bench_ecapa512.log

@@ -103,22 +103,24 @@ __device__ __forceinline__ int input_time(const ConvArgs& a, int t, int tap) {
 }
 
 // ---- shared MFMA stage and epilogue ---------------------------------------------------------------------------
-__device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int wc, int wn, int lane, float4v (&acc)[4][4]) {
+// Wave tile = MI x NI MFMA tiles of 16 x 16; wc / wn = position of the wave inside the workgroup tile.
+template <int MI, int NI>
+__device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int wc, int wn, int lane, float4v (&acc)[MI][NI]) {
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        half8v af[4], bf[4];
+        half8v af[MI], bf[NI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-            af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off(wc * 64 + mi * 16 + frow, kk * 4 + fchunk));
+        for (int mi = 0; mi < MI; ++mi)
+            af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off(wc * (MI * 16) + mi * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off(wn * 64 + ni * 16 + frow, kk * 4 + fchunk));
+        for (int ni = 0; ni < NI; ++ni)
+            bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off(wn * (NI * 16) + ni * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
 }
@@ -139,13 +141,14 @@ __device__ __forceinline__ float4v act4(float4v v, int act) {
     return v;
 }
 
+template <int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0, int wc, int wn, int lane,
-                                              float4v (&acc)[4][4]) {
+                                              float4v (&acc)[MI][NI]) {
     const int crow = 4 * (lane >> 4);
-    int nn[4], nb[4], nt[4];
+    int nn[NI], nb[NI], nt[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        nn[ni] = n0 + wn * 64 + ni * 16 + (lane & 15);
+    for (int ni = 0; ni < NI; ++ni) {
+        nn[ni] = n0 + wn * (NI * 16) + ni * 16 + (lane & 15);
         nb[ni] = 0;
         nt[ni] = 0;
         if (a.row_bias != nullptr || a.gate != nullptr) {
@@ -156,14 +159,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0
     const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     const float4v one4 = float4v{1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int co = co0 + wc * 64 + mi * 16 + crow;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int co = co0 + wc * (MI * 16) + mi * 16 + crow;
         if (co >= a.cout) continue;
         const float4v bias4 = a.bias != nullptr ? *reinterpret_cast<const float4v*>(a.bias + co) : zero4;
         const float4v scale4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.scale + co) : one4;
         const float4v shift4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.shift + co) : zero4;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const int n = nn[ni];
             if (n >= a.n_rows) continue;
             float4v v = acc[mi][ni] + bias4;
@@ -214,27 +217,35 @@ __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, in
 }
 
 // ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
-__global__ __launch_bounds__(CV_THREADS) void conv1d_glds_kernel(ConvArgs a) {
+// Workgroup tile = (WC*MI*16) output channels x (WN*NI*16) time steps, WC x WN waves.  Two instances are built:
+//   <2,2,4,4>  128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU)  -- narrow layers and small problems
+//   <2,4,8,4>  256 x 256, 8 waves, 128 KiB LDS (1 workgroup per CU)  -- wide layers: each wave owns 128 x 64, i.e. 12
+//              fragment reads per 32 MFMAs instead of 8 per 16, and half the global->LDS bytes per FLOP; the 128^2
+//              kernel is LDS-bandwidth bound (reads + DMA writes ~1200 LDS cycles vs 1024 MFMA cycles per K stage).
+template <int WC, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
+    constexpr int TC = WC * MI * 16, TN = WN * NI * 16, NW = WC * WN;
+    constexpr int NTW = TC / 8 / NW, NTX = TN / 8 / NW;  // 1 KiB transfers per wave per stage
+    constexpr int STAGE_BYTES = (TC + TN) * CV_BK * 2;
     MV_DYN_SMEM(smem);
     int n_tile, co_tile;
     if (!tile_of_block(a, n_tile, co_tile)) return;  // whole workgroup leaves before any barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = wave >> 1, wn = wave & 1;
-    const int n0 = n_tile * CV_TN;
-    const int co0 = co_tile * CV_TC;
+    const int wc = wave / WN, wn = wave % WN;
+    const int n0 = n_tile * TN;
+    const int co0 = co_tile * TC;
 
-    // Wave w issues 4 transfers of 8 rows x 128 B for each operand: transfer i covers rows (w*4+i)*8 .. +8.
-    // Lane l lands at LDS position (row = l>>3, slot = l&7) and therefore fetches source chunk slot ^ (row & 7).
+    // Wave w issues NTX (NTW) transfers of 8 rows x 128 B for the activation (weight) tile: transfer i covers rows
+    // (w*NT+i)*8 .. +8.  Lane l lands at LDS position (row = l>>3, slot = l&7) and fetches source chunk slot ^ (row & 7).
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ (lrow & 7);  // (row & 7) == lrow because transfers start at multiples of 8
-    RowMap rm[4];
-    const half_t* wsrc[4];
+    RowMap rm[NTX];
+    const half_t* wsrc[NTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + lrow;
-        const int n = n0 + row;
+    for (int i = 0; i < NTX; ++i) {
+        const int n = n0 + (wave * NTX + i) * 8 + lrow;
         if (n < a.n_rows) {
             rm[i].b = n / a.T_out;
             rm[i].t = n - rm[i].b * a.T_out;
@@ -242,7 +253,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_glds_kernel(ConvArgs a) {
             rm[i].b = -1;
             rm[i].t = 0;
         }
-        const int co = co0 + row;
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int co = co0 + (wave * NTW + i) * 8 + lrow;
         wsrc[i] = co < a.cout_pad ? a.w + (int64_t)co * a.k * a.cin_pad + kc * 8 : nullptr;
     }
     const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
@@ -251,31 +265,31 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_glds_kernel(ConvArgs a) {
     const int nstages = a.k * kstages_per_tap;
 
     auto issue = [&](int s, int buf) {
-        char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
-        char* xtile = wt + CV_TC * CV_BK * 2;
+        char* wt = smem + buf * STAGE_BYTES;
+        char* xtile = wt + TC * CV_BK * 2;
         const int tap = s / kstages_per_tap;
         const int c0 = (s - tap * kstages_per_tap) * CV_BK;
         const int c = c0 + kc * 8;
         const bool ch_ok = c < a.cin;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NTX; ++i) {
             const int tin = input_time(a, rm[i].t, tap);
             const half_t* src = zero;
             if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
-            glds16(src, xtile + (wave * 4 + i) * 1024);
+            glds16(src, xtile + (wave * NTX + i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NTW; ++i) {
             const half_t* src = wsrc[i] != nullptr ? wsrc[i] + (int64_t)tap * a.cin_pad + c0 : zero;
-            glds16(src, wt + (wave * 4 + i) * 1024);
+            glds16(src, wt + (wave * NTW + i) * 1024);
         }
     };
 
-    float4v acc[4][4];
+    float4v acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 
     issue(0, 0);
     wait_all_loads();
@@ -283,12 +297,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_glds_kernel(ConvArgs a) {
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
-        const char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
-        mma_stage(wt, wt + CV_TC * CV_BK * 2, wc, wn, lane, acc);
+        const char* wt = smem + buf * STAGE_BYTES;
+        mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
         wait_all_loads();
         __syncthreads();
     }
-    conv_epilogue(a, n0, co0, wc, wn, lane, acc);
+    conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
 }
 
 // ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
@@ -410,11 +424,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
         const int buf = s & 1;
         if (s + 1 < nstages) issue_loads(s + 1);
         const char* wt = smem + buf * ((CV_TC + CV_TN) * CV_BK * 2);
-        mma_stage(wt, wt + CV_TC * CV_BK * 2, wc, wn, lane, acc);
+        mma_stage<4, 4>(wt, wt + CV_TC * CV_BK * 2, wc, wn, lane, acc);
         if (s + 1 < nstages) store_lds(s + 1, buf ^ 1);
         __syncthreads();
     }
-    conv_epilogue(a, n0, co0, wc, wn, lane, acc);
+    conv_epilogue<4, 4>(a, n0, co0, wc, wn, lane, acc);
 }
 
 // fp32 [Cout][Cin][k] -> fp16 [Cout_pad][k][Cin_pad], zero padded
@@ -502,22 +516,31 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.gate_seg_len = d.gate_seg_len > 0 ? d.gate_seg_len : 1;
     a.gate_nseg = (int)ceil_div(d.T_out, a.gate_seg_len);
     a.n_rows = d.B * d.T_out;
-    a.n_tiles = (int)ceil_div(a.n_rows, CV_TN);
-    a.co_tiles = (int)ceil_div(d.cout, CV_TC);
+    const bool f16 = d.x_dtype == MV_DT_F16;
+    const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
+    // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
+    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256, "conv1d: tile must be 0 (auto), 128 or 256");
+    const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
+    if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
+    const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    const int tn = big ? 256 : CV_TN, tc = big ? 256 : CV_TC;
+    a.n_tiles = (int)ceil_div(a.n_rows, tn);
+    a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
     static bool smem_set = false;
     if (!smem_set) {
-        if (MV_SET_MAX_SMEM(conv1d_glds_kernel, CV_LDS_BYTES) != hipSuccess ||
+        if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), 2 * CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    const bool f16 = d.x_dtype == MV_DT_F16;
-    const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
-    if (f16 && !has_x2 && !in_aff) {
-        MV_LAUNCH(conv1d_glds_kernel, (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
+    if (big) {
+        MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), 2 * CV_LDS_BYTES, stream, a);
+    } else if (f16 && !has_x2 && !in_aff) {
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else if (f16 && has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_mfma_kernel<half_t, true, false>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else if (f16 && !has_x2 && in_aff) {

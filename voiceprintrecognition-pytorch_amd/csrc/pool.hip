@@ -233,15 +233,15 @@ int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attentive statistics pooling tail.  Workgroup = (utterance b, 64-channel tile); wave w walks the 16-row time
-// tiles w, w+4, ...  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :] + b2[c]  on MFMA 16x16x32 (A = W2 rows held in
-// registers for the whole kernel, B = h rows loaded straight into fragment layout), so each lane holds 4 consecutive
-// channels of one time step.  Pass 1 finds the per-channel max over T, pass 2 recomputes the logits (K is only the
-// attention width, 128) and accumulates  s0 = sum e, s1 = sum e*(x - g), s2 = sum e*(x - g)^2  with e = exp(l - max)
-// and g the global mean of the channel (keeps the second moment well conditioned; exact zero variance for
-// constant channels).   mean = g + s1/s0,  std = sqrt(clamp(s2/s0 - (s1/s0)^2, 1e-12)).
-// KS = K steps of 32 (attention width padded to a multiple of 64, at most 256).
-
+// Attentive statistics pooling tail.  Workgroup = (utterance b, 64-channel tile); wave w walks the 16-row time tiles
+// w, w+4, ...  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :] + b2[c]  on MFMA 16x16x32 (A = W2 rows staged once in LDS,
+// B = h rows loaded straight into fragment layout), so each lane holds 4 consecutive channels of one time step.
+// ONE pass with an online softmax: every lane keeps, per channel it holds, a running max m and the sums
+//   s0 = sum e,  s1 = sum e*(x - g),  s2 = sum e*(x - g)^2,   e = exp(logit - m)
+// rescaled when m grows (g = global channel mean: keeps the second moment well conditioned and makes a constant
+// channel's variance exactly zero).  Lanes, then waves, are merged at the end with the same rescaling rule.
+//   mean = g + s1/s0,  std = sqrt(clamp(s2/s0 - (s1/s0)^2, 1e-12))      (pooling.py:91-94,122-125)
+// The [B, 9C, T] attention input and the [B, C, T] logits of the reference never exist.
 struct AspArgs {
     const half_t* h;    // [B, T, A]
     const half_t* w2;   // packed [C_pad][1][A_pad]
@@ -255,18 +255,45 @@ struct AspArgs {
     float eps;
 };
 
+__device__ __forceinline__ void asp_merge(float& m, float& s0, float& s1, float& s2, float om, float o0, float o1, float o2) {
+    const float nm = fmaxf(m, om);
+    const float ra = __expf(m - nm), rb = __expf(om - nm);
+    s0 = s0 * ra + o0 * rb;
+    s1 = s1 * ra + o1 * rb;
+    s2 = s2 * ra + o2 * rb;
+    m = nm;
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
-    __shared__ float red[4][4][32];  // [wave][quantity][channel of the current half]
-    __shared__ float cmax[32];
+    __shared__ __attribute__((aligned(16))) half_t wlds[64 * KS * 32];  // W2 tile, fragment-major: [mi][kk][lane][8]
+    __shared__ float part[4][4][64];                                     // [wave][m, s0, s1, s2][channel]
+    __shared__ __attribute__((aligned(16))) float cpar[2][64];           // [bias | global mean][channel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
     const int fr = lane & 15, fg = lane >> 4;
     const half_t* hb = a.h + (int64_t)b * a.T * a.A;
     const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
     const int ntiles = (a.T + 15) / 16;
 
-    // h rows of one 16-frame tile in MFMA B-fragment layout (row t0 + fr, k = kk*32 + 8*fg .. +8)
+    // stage the 64 x A_pad weight tile in MFMA A-fragment order: slot (mi, kk, lane) = row c0+mi*16+(lane&15), k = kk*32+8*(lane>>4)
+    for (int i = tid; i < 4 * KS * 64; i += 256) {
+        const int l = i & 63, kk = (i >> 6) % KS, mi = i / (64 * KS);
+        const int row = c0 + mi * 16 + (l & 15);
+        half8v v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)0.0f;
+        if (row < a.C_pad) v = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * (l >> 4));
+        *reinterpret_cast<half8v*>(wlds + (size_t)i * 8) = v;
+    }
+    if (tid < 64) {
+        const int c = c0 + tid;
+        cpar[0][tid] = c < a.C ? a.b2[c] : 0.0f;
+        cpar[1][tid] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+    }
+    __syncthreads();
+
     auto load_h = [&](int t0, half8v (&hf)[KS]) {
         const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
 #pragma unroll
@@ -280,176 +307,105 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
             }
         }
     };
-
-    // The 64 channels of the workgroup are processed as two halves of 32 (two MFMA row tiles) to keep the per-lane
-    // state small enough for 3 waves per SIMD; both halves touch the same 128-byte lines of x back to back.
-    for (int half = 0; half < 2; ++half) {
-        const int c0 = blockIdx.x * 64 + half * 32;
-        if (c0 >= a.C) break;
-        // A fragments: W2 rows c0 + mi*16 + fr, k = kk*32 + 8*fg .. +8
-        half8v wf[2][KS];
+    auto load_x = [&](int t0, half4v (&xv)[4]) {
+        const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 4; ++mi) {
+            const int c = c0 + mi * 16 + 4 * fg;
+            if (c + 3 < a.C) {
+                xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int row = c0 + mi * 16 + fr;
-                if (row < a.C_pad) {
-                    wf[mi][kk] = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * fg);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) wf[mi][kk][e] = (half_t)0.0f;
-                }
-            }
-        float bias[2][4], g[2][4];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = c0 + mi * 16 + 4 * fg + r;
-                bias[mi][r] = c < a.C ? a.b2[c] : 0.0f;
-                g[mi][r] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-            }
-        auto logits = [&](const half8v (&hf)[KS], float4v (&l)[2]) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                l[mi] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
-            }
-        };
-        auto load_x = [&](int t0, half4v (&xv)[2]) {
-            const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int c = c0 + mi * 16 + 4 * fg;
-                if (c + 3 < a.C) {
-                    xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
-                }
-            }
-        };
-
-        // ---- pass 1: per-channel max over time (the next tile's h rows are fetched while this tile computes) ----
-        float mx[2][4];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx[mi][r] = -3.0e38f;
-        {
-            half8v hcur[KS], hnext[KS];
-            if (wave < ntiles) load_h(wave * 16, hcur);
-            for (int tt = wave; tt < ntiles; tt += 4) {
-                const bool more = tt + 4 < ntiles;
-                if (more) load_h((tt + 4) * 16, hnext);
-                float4v l[2];
-                logits(hcur, l);
-                if (tt * 16 + fr < a.T) {
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mx[mi][r] = fmaxf(mx[mi][r], l[mi][r]);
-                }
-                if (more) {
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
-                }
+                for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
             }
         }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = mx[mi][r];
-                v = fmaxf(v, __shfl_xor(v, 1));
-                v = fmaxf(v, __shfl_xor(v, 2));
-                v = fmaxf(v, __shfl_xor(v, 4));
-                v = fmaxf(v, __shfl_xor(v, 8));
-                if (fr == 0) red[wave][0][mi * 16 + 4 * fg + r] = v;
-            }
-        __syncthreads();
-        if (tid < 32) cmax[tid] = fmaxf(fmaxf(red[0][0][tid], red[1][0][tid]), fmaxf(red[2][0][tid], red[3][0][tid]));
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx[mi][r] = cmax[mi * 16 + 4 * fg + r];
+    };
 
-        // ---- pass 2: weights and shifted moments (h and x of the next tile prefetched) ----
-        float s0[2][4], s1[2][4], s2[2][4];
+    float m[4][4], s0[4][4], s1[4][4], s2[4][4];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
-        {
-            half8v hcur[KS], hnext[KS];
-            half4v xcur[2], xnext[2];
-            if (wave < ntiles) {
-                load_h(wave * 16, hcur);
-                load_x(wave * 16, xcur);
+        for (int r = 0; r < 4; ++r) {
+            m[mi][r] = -3.0e38f;
+            s0[mi][r] = s1[mi][r] = s2[mi][r] = 0.0f;
+        }
+    {
+        half8v hcur[KS], hnext[KS];
+        half4v xcur[4], xnext[4];
+        if (wave < ntiles) {
+            load_h(wave * 16, hcur);
+            load_x(wave * 16, xcur);
+        }
+        for (int tt = wave; tt < ntiles; tt += 4) {
+            const bool more = tt + 4 < ntiles;
+            if (more) {  // next tile's rows are in flight while this tile computes
+                load_h((tt + 4) * 16, hnext);
+                load_x((tt + 4) * 16, xnext);
             }
-            for (int tt = wave; tt < ntiles; tt += 4) {
-                const bool more = tt + 4 < ntiles;
-                if (more) {
-                    load_h((tt + 4) * 16, hnext);
-                    load_x((tt + 4) * 16, xnext);
+            const bool valid = tt * 16 + fr < a.T;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float4v l = *reinterpret_cast<const float4v*>(&cpar[0][mi * 16 + 4 * fg]);
+                const float4v g4 = *reinterpret_cast<const float4v*>(&cpar[1][mi * 16 + 4 * fg]);
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const half8v wf = *reinterpret_cast<const half8v*>(wlds + ((size_t)(mi * KS + kk) * 64 + lane) * 8);
+                    l = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hcur[kk], l, 0, 0, 0);
                 }
-                float4v l[2];
-                logits(hcur, l);
-                if (tt * 16 + fr < a.T) {
+                if (valid) {
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float e = __expf(l[mi][r] - mx[mi][r]);
-                            const float d = (float)xcur[mi][r] - g[mi][r];
-                            s0[mi][r] += e;
-                            s1[mi][r] += e * d;
-                            s2[mi][r] += e * d * d;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const float nm = fmaxf(m[mi][r], l[r]);
+                        const float rs = __expf(m[mi][r] - nm);
+                        const float e = __expf(l[r] - nm);
+                        const float d = (float)xcur[mi][r] - g4[r];
+                        s0[mi][r] = s0[mi][r] * rs + e;
+                        s1[mi][r] = s1[mi][r] * rs + e * d;
+                        s2[mi][r] = s2[mi][r] * rs + e * d * d;
+                        m[mi][r] = nm;
+                    }
                 }
-                if (more) {
+            }
+            if (more) {
 #pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
+                for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) xcur[mi] = xnext[mi];
-                }
+                for (int mi = 0; mi < 4; ++mi) xcur[mi] = xnext[mi];
             }
         }
+    }
+    // ---- merge the 16 time lanes that share channels, then the 4 waves ----
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v0 = s0[mi][r], v1 = s1[mi][r], v2 = s2[mi][r];
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int m = 1; m <= 8; m <<= 1) {
-                    v0 += __shfl_xor(v0, m);
-                    v1 += __shfl_xor(v1, m);
-                    v2 += __shfl_xor(v2, m);
-                }
-                if (fr == 0) {
-                    const int ch = mi * 16 + 4 * fg + r;
-                    red[wave][1][ch] = v0;
-                    red[wave][2][ch] = v1;
-                    red[wave][3][ch] = v2;
-                }
+            for (int sh = 1; sh <= 8; sh <<= 1) {
+                const float om = __shfl_xor(m[mi][r], sh), o0 = __shfl_xor(s0[mi][r], sh);
+                const float o1 = __shfl_xor(s1[mi][r], sh), o2 = __shfl_xor(s2[mi][r], sh);
+                asp_merge(m[mi][r], s0[mi][r], s1[mi][r], s2[mi][r], om, o0, o1, o2);
             }
-        __syncthreads();
-        if (tid < 32) {
-            const int c = c0 + tid;
-            if (c < a.C) {
-                const float z0 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
-                const float z1 = red[0][2][tid] + red[1][2][tid] + red[2][2][tid] + red[3][2][tid];
-                const float z2 = red[0][3][tid] + red[1][3][tid] + red[2][3][tid] + red[3][3][tid];
-                const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-                const float m1 = z1 / z0;
-                const float var = z2 / z0 - m1 * m1;
-                a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
-                a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+            if (fr == 0) {
+                const int ch = mi * 16 + 4 * fg + r;
+                part[wave][0][ch] = m[mi][r];
+                part[wave][1][ch] = s0[mi][r];
+                part[wave][2][ch] = s1[mi][r];
+                part[wave][3][ch] = s2[mi][r];
             }
         }
-        __syncthreads();  // red / cmax are reused by the second half
+    __syncthreads();
+    if (tid < 64) {
+        const int c = c0 + tid;
+        if (c < a.C) {
+            float mm = part[0][0][tid], z0 = part[0][1][tid], z1 = part[0][2][tid], z2 = part[0][3][tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) asp_merge(mm, z0, z1, z2, part[w][0][tid], part[w][1][tid], part[w][2][tid], part[w][3][tid]);
+            const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+            const float m1 = z1 / z0;
+            const float var = z2 / z0 - m1 * m1;
+            a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
+            a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
+        }
     }
 }
 
