@@ -25,7 +25,7 @@ def test_emu_conv1d_rejects_bad_arguments():
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2), (3, 2100, 20, 0)])
 def test_emu_linear(shape):
     B, K, O, act = shape
     lc.linear_case(emu_cdll(), 'cpu', B, K, O, act)
@@ -96,3 +96,9 @@ def test_emu_melspec_other_geometry():
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1)])
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
+
+
+def test_emu_fbank_odd_window_length():
+    args = dict(sample_frequency=11025, num_mel_bins=40)  # 275-sample window (odd), 110-sample shift
+    w = frontend.synth_waveforms(2, 3000, seed=21)
+    lc.fbank_case(emu_cdll(), 'cpu', w, None, args)

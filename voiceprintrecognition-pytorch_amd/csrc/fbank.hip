@@ -186,25 +186,26 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
         const int f = fvalid ? f_raw : T - 1;
         const float* fp = wrow + (int64_t)f * a.shift;
 
-        // ---- load the frame: lane holds samples 32*n1 + 2*l16 (+1) ----
+        // ---- load the frame: lane holds samples 32*n1 + 2*l16 (+1).  Branch-free: indices beyond the frame are
+        // clamped to a valid address and the value is zeroed by a select, so all 16 loads are in flight together ----
         float e0[16], e1[16];
         float s = 0.0f;
+        const int last_pair = (a.win - 2) & ~1;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
-            float v0 = 0.0f, v1 = 0.0f;
-            if (idx + 1 < a.win) {
-                if (a.vec2_ok) {
-                    float2v v = *reinterpret_cast<const float2v*>(fp + idx);
-                    v0 = v[0];
-                    v1 = v[1];
-                } else {
-                    v0 = fp[idx];
-                    v1 = fp[idx + 1];
-                }
-            } else if (idx < a.win) {
-                v0 = fp[idx];
+            const int idc = idx < last_pair ? idx : last_pair;
+            float v0, v1;
+            if (a.vec2_ok) {
+                const float2v v = *reinterpret_cast<const float2v*>(fp + idc);
+                v0 = v[0];
+                v1 = v[1];
+            } else {
+                v0 = fp[idx < a.win ? idx : a.win - 1];
+                v1 = fp[idx + 1 < a.win ? idx + 1 : a.win - 1];
             }
+            v0 = idx < a.win ? v0 : 0.0f;
+            v1 = idx + 1 < a.win ? v1 : 0.0f;
             e0[n1] = v0;
             e1[n1] = v1;
             s += v0 + v1;
@@ -284,11 +285,18 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
                 const int st = mstart[m];
                 const float* wr = melw + a.tab.round_off[i] * 16 + l16;
                 float acc = 0.0f;
-                const int width = a.tab.round_width[i];
-                for (int j = 0; j < width; ++j) {
-                    int kk = st + j;
-                    kk = kk > 255 ? 255 : kk;
-                    acc += wr[j * 16] * pslot[kk];
+                const int width = a.tab.round_width[i];  // multiple of 4 (zero-weight padding)
+                for (int j = 0; j < width; j += 4) {
+                    float wv[4], pv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int kk = st + j + u;
+                        kk = kk > 255 ? 255 : kk;
+                        wv[u] = wr[(j + u) * 16];
+                        pv[u] = pslot[kk];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc += wv[u] * pv[u];
                 }
                 float val = acc;
                 if (a.use_log) val = logf(fmaxf(acc, 1.1920928955078125e-07f));
@@ -323,12 +331,27 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
     // ---- second pass over the rows this workgroup wrote: subtract mean, apply the length mask ----
     int mask_len = T;
     if (a.lens_ratio != nullptr) mask_len = (int)rintf(a.lens_ratio[b] * (float)T);  // round half to even
-    const int total = T * nbins;
-    for (int e = tid; e < total; e += FB_THREADS) {
-        const int t = e / nbins;
-        const int m = e - t * nbins;
-        float v = orow[e] - mean[m];
-        orow[e] = (t < mask_len) ? v : 0.0f;
+    if ((nbins & 3) == 0) {
+        // each thread keeps one float4 column group and walks the rows: no index arithmetic in the loop
+        const int q = nbins >> 2;               // float4 groups per row
+        const int rows_per_pass = FB_THREADS / q;
+        const int r0 = tid / q, cg = tid - r0 * q;
+        if (r0 < rows_per_pass) {
+            const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
+            for (int t = r0; t < T; t += rows_per_pass) {
+                float4v* p = reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg;
+                const float4v v = *p - m4;
+                *p = t < mask_len ? v : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+    } else {
+        const int total = T * nbins;
+        for (int e = tid; e < total; e += FB_THREADS) {
+            const int t = e / nbins;
+            const int m = e - t * nbins;
+            float v = orow[e] - mean[m];
+            orow[e] = (t < mask_len) ? v : 0.0f;
+        }
     }
 }
 
@@ -453,6 +476,7 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         if (i < rounds) {
             int w = 0;
             for (int l = 0; l < 16; ++l) w = width[i * 16 + l] > w ? width[i * 16 + l] : w;
+            w = (w + 3) & ~3;  // the kernel walks the weights four at a time
             tab.round_width[i] = w;
             off += w;
         }
@@ -529,7 +553,7 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.use_power = h->cfg.use_power;
     a.use_log = h->cfg.use_log_fbank;
     a.cmn = h->cfg.subtract_time_mean;
-    a.vec2_ok = ((reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0) ? 1 : 0;
+    a.vec2_ok = ((reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0) ? 1 : 0;
     a.tab = h->tab;
     MV_LAUNCH(mv::fbank_kernel, (B, 1, 1), (mv::FB_THREADS, 1, 1), h->smem_bytes, static_cast<hipStream_t>(stream), a);
     return mv::check_launch("fbank_kernel");

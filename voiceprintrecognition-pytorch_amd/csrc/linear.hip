@@ -33,11 +33,12 @@ __device__ __forceinline__ float4v load4_guard(const float* row, int k, int K, b
 
 // y[b, o] = act( sum_k x[b,k] w[o,k] + bias[o] );  with `cosine` set the dot product is divided by the two
 // row norms |x_b| |w_o| (accumulated in the same K loop), i.e. sklearn's cosine_similarity.
-__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int64_t ldx, const float* w, int64_t ldw,
-                                                         const float* bias, int act, float* y, int64_t ldy, int B,
-                                                         int K, int O, int cosine) {
-    __shared__ float red[4][16][17];
-    __shared__ float nrm[2][4][16];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                                                             const float* bias, int act, float* y, int64_t ldy, int B,
+                                                             int K, int O, int cosine) {
+    __shared__ float red[NW][16][17];
+    __shared__ float nrm[2][NW][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int64_t
     const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     float4v acc = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     float sqx = 0.0f, sqw = 0.0f;
-    // wave `wave` takes K blocks of 16 with index == wave (mod 4)
-    for (int k0 = wave * 16; k0 < K; k0 += 64) {
+    // wave `wave` takes K blocks of 16 with index == wave (mod NW)
+    for (int k0 = wave * 16; k0 < K; k0 += 16 * NW) {
         const int k = k0 + 4 * g;
         const float4v xa = load4_guard(xrow, k, K, xvec);
         const float4v wb = load4_guard(wrow, k, K, wvec);
@@ -82,14 +83,20 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int64_t
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * g + r][i] = acc[r];
     __syncthreads();
-    {
+    if (tid < 256) {
         const int r = tid >> 4, c = tid & 15;
         const int b = b0 + r, o = o0 + c;
         if (b < B && o < O) {
-            float v = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c];
+            float v = 0.0f, sx = 0.0f, sw = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                v += red[q][r][c];
+                sx += nrm[0][q][r];
+                sw += nrm[1][q][c];
+            }
             if (cosine) {
-                const float nx = sqrtf(nrm[0][0][r] + nrm[0][1][r] + nrm[0][2][r] + nrm[0][3][r]);
-                const float nw = sqrtf(nrm[1][0][c] + nrm[1][1][c] + nrm[1][2][c] + nrm[1][3][c]);
+                const float nx = sqrtf(sx);
+                const float nw = sqrtf(sw);
                 v = v / (fmaxf(nx, 1.17549435e-38f) * fmaxf(nw, 1.17549435e-38f));
             }
             if (bias != nullptr) v += bias[o];
@@ -119,8 +126,14 @@ int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream) {
     MV_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "linear_f32: null tensor");
     MV_REQUIRE(B > 0 && K > 0 && O > 0 && ldx >= K && ldw >= K && ldy >= O, "linear_f32: bad geometry");
-    MV_LAUNCH(linear_f32_kernel, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (256, 1, 1), 0, stream, x, ldx, w,
-              ldw, bias, act, y, ldy, B, K, O, cosine);
+    MV_REQUIRE(ceil_div(B, 16) <= 65535, "linear_f32: too many rows");
+    if (K >= 2048) {  // long reductions: 16 waves split K so the dependent load chain per wave stays short
+        MV_LAUNCH(linear_f32_kernel<16>, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (1024, 1, 1), 0, stream, x, ldx,
+                  w, ldw, bias, act, y, ldy, B, K, O, cosine);
+    } else {
+        MV_LAUNCH(linear_f32_kernel<4>, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (256, 1, 1), 0, stream, x, ldx, w,
+                  ldw, bias, act, y, ldy, B, K, O, cosine);
+    }
     return check_launch("linear_f32_kernel");
 }
 

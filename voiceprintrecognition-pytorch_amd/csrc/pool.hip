@@ -121,31 +121,56 @@ int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* m
 
 // ------------------------------------------------------------------------------------------------
 // CAM context: ctx[b, s, c] = mean_t x[b, t, c] + mean_{t in segment s} x[b, t, c]  (last segment divides by its
-// true length, campplus.py:103 avg_pool1d(ceil_mode=True)).  Workgroup = (utterance, 64-channel group... 8 ch/lane).
+// true length, campplus.py:103 avg_pool1d(ceil_mode=True)).  One workgroup per (utterance, 128-channel group): lane
+// (c16 = tid & 15) owns 8 channels, the 16 row phases (tid >> 4) walk each segment's frames 16 at a time.
 __global__ __launch_bounds__(256) void seg_mean_kernel(const half_t* x, int64_t ld, int T, int C, int seg_len, int nseg,
                                                        float* ctx) {
-    // each thread owns one channel; threads of a wave read 64 consecutive channels (128 B) per time step
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[16][128];
+    __shared__ float tot[128];
+    const int tid = threadIdx.x;
+    const int c16 = tid & 15, ph = tid >> 4;
     const int b = blockIdx.y;
-    if (c >= C) return;
-    const half_t* xb = x + (int64_t)b * T * ld + c;
-    float total = 0.0f;
+    const int cg0 = blockIdx.x * 128;
+    const int c0 = cg0 + c16 * 8;
+    const bool active = c0 + 8 <= C;  // C is a multiple of 8 (checked by the launcher)
+    const half_t* xb = x + (int64_t)b * T * ld + c0;
+    if (tid < 128) tot[tid] = 0.0f;
     for (int s = 0; s < nseg; ++s) {
         const int t0 = s * seg_len;
         const int t1 = t0 + seg_len < T ? t0 + seg_len : T;
-        float acc = 0.0f;
-        for (int t = t0; t < t1; ++t) acc += (float)xb[(int64_t)t * ld];
-        total += acc;
-        ctx[((int64_t)b * nseg + s) * C + c] = acc / (float)(t1 - t0);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+        if (active) {
+            for (int t = t0 + ph; t < t1; t += 16) {
+                const half8v v = *reinterpret_cast<const half8v*>(xb + (int64_t)t * ld);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        }
+        __syncthreads();  // previous segment's readers of `red` are done
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[ph][c16 * 8 + e] = acc[e];
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) v += red[p][tid];
+            tot[tid] += v;
+            if (cg0 + tid < C) ctx[((int64_t)b * nseg + s) * C + cg0 + tid] = v / (float)(t1 - t0);
+        }
     }
-    const float gm = total / (float)T;
-    for (int s = 0; s < nseg; ++s) ctx[((int64_t)b * nseg + s) * C + c] += gm;
+    if (tid < 128 && cg0 + tid < C) {
+        const float gm = tot[tid] / (float)T;
+        for (int s = 0; s < nseg; ++s) ctx[((int64_t)b * nseg + s) * C + cg0 + tid] += gm;
+    }
 }
 
 int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream) {
     MV_REQUIRE(x != nullptr && ctx != nullptr && B > 0 && T > 0 && C > 0 && seg_len > 0, "seg_mean: bad argument");
+    MV_REQUIRE(C % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "seg_mean: rows must be 16-byte aligned");
     const int nseg = (int)ceil_div(T, seg_len);
-    MV_LAUNCH(seg_mean_kernel, ((unsigned)ceil_div(C, 256), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, seg_len, nseg,
+    MV_LAUNCH(seg_mean_kernel, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, seg_len, nseg,
               ctx);
     return check_launch("seg_mean_kernel");
 }
