@@ -1,0 +1,23 @@
+"""Micro-benchmark of the Fbank kernel alone (HIP events on the launch stream): python tools/bench_fbank.py [B]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd')]
+import torch
+from mvector import _hip
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+fb = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80))
+g = torch.Generator().manual_seed(1234)
+wav = (0.1 * torch.randn([B, 48000], generator=g)).clamp(-1, 1).cuda()
+for _ in range(5):
+    out = fb(wav)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 50
+e0.record()
+for _ in range(n):
+    out = fb(wav)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / n * 1e3
+print(json.dumps(dict(waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, us=round(us, 2),
+                      GBps=round(B * 287360 / us / 1e3, 1), frac_of_8TBps=round(B * 287360 / us / 1e3 / 8000, 4))))

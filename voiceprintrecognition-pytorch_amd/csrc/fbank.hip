@@ -18,6 +18,7 @@
 // second pass (subtract mean, apply the length mask) re-reads rows this CU has just written (L2 hits).
 #include "common.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace mv {
@@ -100,15 +101,14 @@ __device__ __forceinline__ void fft16(cplx (&x)[16]) {
 }
 
 constexpr int FB_NFFT = 512;
-constexpr int FB_WAVES = 8;               // waves per workgroup
-constexpr int FB_THREADS = FB_WAVES * 64;
+constexpr int FB_MAX_WAVES = 16;          // waves per workgroup: 8, 12 or 16 (template parameter WAVES)
 constexpr int FB_TSTRIDE = 17;            // padded row of the 16x16 transpose tile (complex elements)
 constexpr int FB_SLOT_CPLX = 16 * FB_TSTRIDE;  // 272 complex = 2176 B per frame slot (>= 256 complex)
 constexpr int FB_MAX_ROUNDS = 8;          // filters per lane: num_mel_bins <= 128
 
 struct FbankTables {
     const float* window;    // [512] window, zero beyond the frame length
-    const float* tw256;     // [256][2] cos, sin of 2 pi m / 256
+    const float* tw256;     // [16 k1][16 n2][2] cos, sin of 2 pi n2 k1 / 256 (lane-contiguous)
     const float* tw512;     // [256][2] cos, sin of 2 pi k / 512
     const float* melw;      // [sum_i width_i][16] filter weights, round-major
     const int* mel_start;   // [rounds*16] first FFT bin of each filter
@@ -132,14 +132,20 @@ struct FbankArgs {
     FbankTables tab;
 };
 
-__global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
+// ROUNDS = ceil(num_mel_bins / 16): filters per lane (compile-time so the per-lane state stays in registers)
+template <int ROUNDS, bool VEC2, int FB_WAVES>
+__global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
+    constexpr int FB_THREADS = FB_WAVES * 64;
     MV_DYN_SMEM(smem);
-    // carve: per-wave exchange tiles | tw512 | melw | mel_start | column sums
-    cplx* xbuf = reinterpret_cast<cplx*>(smem);                                 // [FB_WAVES*4][FB_SLOT_CPLX]
+    // carve (every offset but the last is a compile-time constant, so LDS accesses are base + immediate):
+    // per-wave exchange tiles | tw512 | window | stage twiddles | column sums + mean | mel_start | mel weights
+    cplx* xbuf = reinterpret_cast<cplx*>(smem);                                   // [FB_WAVES*4][FB_SLOT_CPLX]
     float* tw512 = reinterpret_cast<float*>(xbuf + FB_WAVES * 4 * FB_SLOT_CPLX);  // [512]
-    float* melw = tw512 + 512;                                                  // [melw_elems]
-    int* mstart = reinterpret_cast<int*>(melw + a.tab.melw_elems);              // [rounds*16]
-    float* colsum = reinterpret_cast<float*>(mstart + a.tab.rounds * 16);       // [FB_WAVES][128] then mean[128]
+    float* lwin = tw512 + 512;                                                    // [512] window taps
+    float* ltw = lwin + 512;                                                      // [16][16][2] stage twiddles
+    float* colsum = ltw + 512;                                                    // [FB_WAVES][128] then mean[128]
+    int* mstart = reinterpret_cast<int*>(colsum + (FB_WAVES + 1) * 128);          // [FB_MAX_ROUNDS*16]
+    float* melw = reinterpret_cast<float*>(mstart + FB_MAX_ROUNDS * 16);          // [melw_elems]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,24 +156,15 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
     const int T = a.T;
     const int nbins = a.nbins;
 
-    for (int i = tid; i < 512; i += FB_THREADS) tw512[i] = a.tab.tw512[i];
+    for (int i = tid; i < 512; i += FB_THREADS) {
+        tw512[i] = a.tab.tw512[i];
+        lwin[i] = a.tab.window[i];
+        ltw[i] = a.tab.tw256[i];
+    }
     for (int i = tid; i < a.tab.melw_elems; i += FB_THREADS) melw[i] = a.tab.melw[i];
     for (int i = tid; i < a.tab.rounds * 16; i += FB_THREADS) mstart[i] = a.tab.mel_start[i];
+    for (int i = tid; i < FB_WAVES * 128; i += FB_THREADS) colsum[i] = 0.0f;
 
-    // per-lane constants: window taps of this lane's samples and the stage-1 -> stage-2 twiddles
-    float w0[16], w1[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        w0[n1] = a.tab.window[32 * n1 + 2 * l16];
-        w1[n1] = a.tab.window[32 * n1 + 2 * l16 + 1];
-    }
-    float twc[16], tws[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        int m = (l16 * k1) & 255;
-        twc[k1] = a.tab.tw256[2 * m];
-        tws[k1] = a.tab.tw256[2 * m + 1];
-    }
     __syncthreads();
 
     cplx* slot = xbuf + (wave * 4 + fs) * FB_SLOT_CPLX;
@@ -175,9 +172,9 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
     const float* wrow = a.wav + (int64_t)b * a.wav_stride;
     float* orow = a.out + (int64_t)b * T * nbins;
 
-    float csum[FB_MAX_ROUNDS];
+    float csum[ROUNDS];
 #pragma unroll
-    for (int i = 0; i < FB_MAX_ROUNDS; ++i) csum[i] = 0.0f;
+    for (int i = 0; i < ROUNDS; ++i) csum[i] = 0.0f;
 
     const int nquads = (T + 3) >> 2;
     for (int q = wave; q < nquads; q += FB_WAVES) {
@@ -190,25 +187,38 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
         // clamped to a valid address and the value is zeroed by a select, so all 16 loads are in flight together ----
         float e0[16], e1[16];
         float s = 0.0f;
-        const int last_pair = (a.win - 2) & ~1;
+        const int n1_full = a.win >> 5;  // groups of 32 samples that lie entirely inside the frame (uniform)
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            const int idx = 32 * n1 + 2 * l16;
-            const int idc = idx < last_pair ? idx : last_pair;
-            float v0, v1;
-            if (a.vec2_ok) {
-                const float2v v = *reinterpret_cast<const float2v*>(fp + idc);
-                v0 = v[0];
-                v1 = v[1];
-            } else {
-                v0 = fp[idx < a.win ? idx : a.win - 1];
-                v1 = fp[idx + 1 < a.win ? idx + 1 : a.win - 1];
+            float v0 = 0.0f, v1 = 0.0f;
+            if (n1 < n1_full) {  // plain base + constant offset: nothing per-lane to keep alive across iterations
+                if (VEC2) {
+                    const float2v v = *reinterpret_cast<const float2v*>(fp + 32 * n1 + 2 * l16);
+                    v0 = v[0];
+                    v1 = v[1];
+                } else {
+                    v0 = fp[32 * n1 + 2 * l16];
+                    v1 = fp[32 * n1 + 2 * l16 + 1];
+                }
             }
-            v0 = idx < a.win ? v0 : 0.0f;
-            v1 = idx + 1 < a.win ? v1 : 0.0f;
             e0[n1] = v0;
             e1[n1] = v1;
-            s += v0 + v1;
+        }
+        {   // the one group that straddles the end of the frame (none when win is a multiple of 32): clamp + select
+            const int idx = 32 * n1_full + 2 * l16;
+            float p0 = 0.0f, p1 = 0.0f;
+            if (32 * n1_full < a.win) {
+                p0 = fp[idx < a.win ? idx : a.win - 1];
+                p1 = fp[idx + 1 < a.win ? idx + 1 : a.win - 1];
+                p0 = idx < a.win ? p0 : 0.0f;
+                p1 = idx + 1 < a.win ? p1 : 0.0f;
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                e0[n1] = n1 == n1_full ? p0 : e0[n1];
+                e1[n1] = n1 == n1_full ? p1 : e1[n1];
+                s += e0[n1] + e1[n1];
+            }
         }
         // ---- remove DC (frame mean over the `win` samples) ----
         if (a.remove_dc) {
@@ -240,13 +250,17 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
                 rprev = r;
                 const float y0 = e0[n1] - a.preemph * prev;
                 const float y1 = e1[n1] - a.preemph * e0[n1];
-                z[n1] = cmake(y0 * w0[n1], y1 * w1[n1]);
+                const float2v w2 = *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16);
+                z[n1] = cmake(y0 * w2[0], y1 * w2[1]);
             }
         }
         // ---- stage 1: radix-16 over n1, twiddle by W256^(n2*k1) ----
         fft16(z);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul_conjtw(z[k1], twc[k1], tws[k1]);
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const float2v tw = *reinterpret_cast<const float2v*>(ltw + 2 * (k1 * 16 + l16));
+            z[k1] = cmul_conjtw(z[k1], tw[0], tw[1]);
+        }
         // ---- transpose: write [k1][n2], read [k1 = lane][n2] ----
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) slot[k1 * FB_TSTRIDE + l16] = z[k1];
@@ -259,12 +273,13 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
         // ---- real-input post-processing: X[k] from Z[k] and Z[256-k] ----
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) slot[l16 + 16 * k2] = z[k2];
+        if (l16 == 0) slot[256] = z[0];  // Z[256] == Z[0]: the partner index 256 - k then needs no wrap-around
         MV_WAVE_FENCE();
         float pw[16];
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const int k = l16 + 16 * k2;
-            const cplx zp = slot[(256 - k) & 255];
+            const cplx zp = slot[256 - k];
             const float c = tw512[2 * k], sn = tw512[2 * k + 1];
             const float ar = z[k2].re + zp.re, ai = z[k2].im - zp.im;
             const float br = z[k2].re - zp.re, bi = z[k2].im + zp.im;
@@ -278,9 +293,10 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
         for (int k2 = 0; k2 < 16; ++k2) pslot[l16 + 16 * k2] = pw[k2];
         MV_WAVE_FENCE();
         // ---- sparse mel filters: lane l16 owns filters l16 + 16*i ----
+        float vals[ROUNDS];
 #pragma unroll
-        for (int i = 0; i < FB_MAX_ROUNDS; ++i) {
-            if (i < a.tab.rounds) {
+        for (int i = 0; i < ROUNDS; ++i) {
+            {
                 const int m = l16 + 16 * i;
                 const int st = mstart[m];
                 const float* wr = melw + a.tab.round_off[i] * 16 + l16;
@@ -300,10 +316,28 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
                 }
                 float val = acc;
                 if (a.use_log) val = logf(fmaxf(acc, 1.1920928955078125e-07f));
-                if (fvalid && m < nbins) {
-                    orow[(int64_t)f * nbins + m] = val;
-                    csum[i] += val;
-                }
+                vals[i] = val;
+                if (fvalid && m < nbins) csum[i] += val;
+            }
+        }
+        // ---- the quad's four rows are contiguous in the output: stage them in LDS, store 16 bytes per lane ----
+        MV_WAVE_FENCE();  // every lane of the wave is done reading the power spectra
+        {
+            float* stage = reinterpret_cast<float*>(xbuf + (wave * 4) * FB_SLOT_CPLX);  // [4][nbins]
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i) {
+                const int m = l16 + 16 * i;
+                if (m < nbins) stage[fs * nbins + m] = vals[i];
+            }
+            MV_WAVE_FENCE();
+            const int frames_here = (q * 4 + 4 <= T) ? 4 : T - q * 4;
+            const int nfloat = frames_here * nbins;
+            float* dst = orow + (int64_t)q * 4 * nbins;
+            if ((nbins & 3) == 0) {
+                for (int e = lane * 4; e < nfloat; e += 256)
+                    *reinterpret_cast<float4v*>(dst + e) = *reinterpret_cast<const float4v*>(stage + e);
+            } else {
+                for (int e = lane; e < nfloat; e += 64) dst[e] = stage[e];
             }
         }
         MV_WAVE_FENCE();
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankArgs a) {
 
     // ---- per-utterance time mean (featurizer.py:79): reduce over frame slots, then over waves ----
 #pragma unroll
-    for (int i = 0; i < FB_MAX_ROUNDS; ++i) {
+    for (int i = 0; i < ROUNDS; ++i) {
         float v = csum[i];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -369,6 +403,7 @@ struct MvFbank {
     int* d_mel_start = nullptr;
     mv::FbankTables tab;
     size_t smem_bytes = 0;
+    int waves = 16;  // workgroup size in waves (tuning knob: MV_FBANK_WAVES = 8 | 12 | 16)
 };
 
 namespace {
@@ -405,6 +440,36 @@ int upload(const std::vector<T>& v, T** dptr) {
 }
 
 }  // namespace
+
+template <int R, int W>
+hipError_t fbank_set_smem_w(size_t bytes) {
+    hipError_t e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, true, W>), bytes);
+    if (e != hipSuccess) return e;
+    return MV_SET_MAX_SMEM((mv::fbank_kernel<R, false, W>), bytes);
+}
+
+template <int R>
+hipError_t fbank_set_smem(size_t bytes, int waves) {
+    if (waves == 8) return fbank_set_smem_w<R, 8>(bytes);
+    if (waves == 12) return fbank_set_smem_w<R, 12>(bytes);
+    return fbank_set_smem_w<R, 16>(bytes);
+}
+
+template <int R, int W>
+void fbank_launch_w(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a) {
+    if (a.vec2_ok) {
+        MV_LAUNCH((mv::fbank_kernel<R, true, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+    } else {
+        MV_LAUNCH((mv::fbank_kernel<R, false, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+    }
+}
+
+template <int R>
+void fbank_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, int waves) {
+    if (waves == 8) return fbank_launch_w<R, 8>(B, smem, st, a);
+    if (waves == 12) return fbank_launch_w<R, 12>(B, smem, st, a);
+    return fbank_launch_w<R, 16>(B, smem, st, a);
+}
 
 extern "C" {
 
@@ -447,8 +512,9 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         window[i] = (float)pow(hann, 0.85);
     }
     for (int m = 0; m < 256; ++m) {
-        tw256[2 * m] = (float)cos(2.0 * pi * m / 256.0);
-        tw256[2 * m + 1] = (float)sin(2.0 * pi * m / 256.0);
+        const int k1 = m >> 4, n2 = m & 15;  // stage-1 -> stage-2 twiddle W256^(n2*k1), laid out [k1][n2]
+        tw256[2 * m] = (float)cos(2.0 * pi * ((n2 * k1) & 255) / 256.0);
+        tw256[2 * m + 1] = (float)sin(2.0 * pi * ((n2 * k1) & 255) / 256.0);
         tw512[2 * m] = (float)cos(2.0 * pi * m / 512.0);
         tw512[2 * m + 1] = (float)sin(2.0 * pi * m / 512.0);
     }
@@ -500,10 +566,25 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     tab.tw512 = h->d_tw512;
     tab.melw = h->d_melw;
     tab.mel_start = h->d_mel_start;
-    h->smem_bytes = (size_t)mv::FB_WAVES * 4 * mv::FB_SLOT_CPLX * sizeof(mv::cplx) + 512 * sizeof(float) +
-                    melw.size() * sizeof(float) + (size_t)rounds * 16 * sizeof(int) +
-                    (size_t)(mv::FB_WAVES + 1) * 128 * sizeof(float);
-    if (MV_SET_MAX_SMEM(mv::fbank_kernel, h->smem_bytes) != hipSuccess) {
+    if (const char* e = getenv("MV_FBANK_WAVES")) {
+        const int w = atoi(e);
+        if (w == 8 || w == 12 || w == 16) h->waves = w;
+    }
+    h->smem_bytes = (size_t)h->waves * 4 * mv::FB_SLOT_CPLX * sizeof(mv::cplx) + 3 * 512 * sizeof(float) +
+                    (size_t)(h->waves + 1) * 128 * sizeof(float) + (size_t)mv::FB_MAX_ROUNDS * 16 * sizeof(int) +
+                    melw.size() * sizeof(float);
+    hipError_t se = hipSuccess;
+    switch (rounds) {
+        case 1: se = fbank_set_smem<1>(h->smem_bytes, h->waves); break;
+        case 2: se = fbank_set_smem<2>(h->smem_bytes, h->waves); break;
+        case 3: se = fbank_set_smem<3>(h->smem_bytes, h->waves); break;
+        case 4: se = fbank_set_smem<4>(h->smem_bytes, h->waves); break;
+        case 5: se = fbank_set_smem<5>(h->smem_bytes, h->waves); break;
+        case 6: se = fbank_set_smem<6>(h->smem_bytes, h->waves); break;
+        case 7: se = fbank_set_smem<7>(h->smem_bytes, h->waves); break;
+        default: se = fbank_set_smem<8>(h->smem_bytes, h->waves); break;
+    }
+    if (se != hipSuccess) {
         mv_fbank_destroy(h);
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_kernel");
     }
@@ -555,7 +636,17 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.cmn = h->cfg.subtract_time_mean;
     a.vec2_ok = ((reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0) ? 1 : 0;
     a.tab = h->tab;
-    MV_LAUNCH(mv::fbank_kernel, (B, 1, 1), (mv::FB_THREADS, 1, 1), h->smem_bytes, static_cast<hipStream_t>(stream), a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (h->tab.rounds) {
+        case 1: fbank_launch<1>(B, h->smem_bytes, st, a, h->waves); break;
+        case 2: fbank_launch<2>(B, h->smem_bytes, st, a, h->waves); break;
+        case 3: fbank_launch<3>(B, h->smem_bytes, st, a, h->waves); break;
+        case 4: fbank_launch<4>(B, h->smem_bytes, st, a, h->waves); break;
+        case 5: fbank_launch<5>(B, h->smem_bytes, st, a, h->waves); break;
+        case 6: fbank_launch<6>(B, h->smem_bytes, st, a, h->waves); break;
+        case 7: fbank_launch<7>(B, h->smem_bytes, st, a, h->waves); break;
+        default: fbank_launch<8>(B, h->smem_bytes, st, a, h->waves); break;
+    }
     return mv::check_launch("fbank_kernel");
 }
 
