@@ -1,0 +1,43 @@
+"""Micro-benchmark of mv_conv1d_forward tile variants on the backbone's GEMM shapes (HIP events)."""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd')]
+import torch
+from mvector import _hip
+import layer_checks as lc
+lib = _hip.lib()
+B, T = 256, 298
+shapes = [('c2c 1024->1024 k1', 1024, 1024, 1, 1), ('mfa 3072->3072 k1', 3072, 3072, 1, 1), ('asp 3072->128 k1', 3072, 128, 1, 1),
+          ('res2 128->128 k3d3', 128, 128, 3, 3), ('c2c 512->512 k1', 512, 512, 1, 1), ('mfa 1536->1536', 1536, 1536, 1, 1)]
+for name, cin, cout, k, dil in shapes:
+    x = (torch.randn(B, T, cin, device='cuda') * 0.5).half()
+    w = torch.randn(cout, cin, k, device='cuda') * (2.0 / (cin * k)) ** 0.5
+    packed = lc.pack_weight(lib, w)
+    bias = torch.randn(cout, device='cuda') * 0.1
+    scale = torch.rand(cout, device='cuda') + 0.5
+    shift = torch.randn(cout, device='cuda') * 0.1
+    y = torch.empty(B, T, cout, dtype=torch.float16, device='cuda')
+    for tile in (128, 256, 257):
+        if tile == 256 and cout % 256:
+            continue
+        d = _hip.MvConv1dDesc()
+        d.x, d.x_dtype, d.ldx = x.data_ptr(), _hip.MV_DT_F16, cin
+        d.w_packed, d.bias, d.scale, d.shift = packed.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        d.pre_act, d.post_act = 1, 0
+        d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout
+        d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, cin, cout, k, dil, 1
+        d.pad, d.pad_mode, d.tile = dil * (k - 1) // 2, _hip.MV_PAD_REFLECT, tile
+        st = _hip.current_stream(x)
+        for _ in range(3):
+            _hip.check(lib.mv_conv1d_forward(ctypes.byref(d), st))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            lib.mv_conv1d_forward(ctypes.byref(d), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        tf = 2.0 * B * T * cin * cout * k / us / 1e6
+        print(json.dumps(dict(shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))), flush=True)

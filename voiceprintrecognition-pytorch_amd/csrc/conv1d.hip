@@ -28,6 +28,7 @@ constexpr int CV_TN = 128;  // time steps per tile
 constexpr int CV_BK = 64;   // K elements per stage
 constexpr int CV_THREADS = 256;
 constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
+constexpr int CV_LDS_BYTES_MID = 256 * (128 * 2 + 8);          // 256 x 128 tile, 32-wide stages: 2 x 24 KiB stages, 66 KiB staged epilogue
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -387,6 +388,107 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     }
 }
 
+// ---- variant with 32-wide K stages: 128 channels x 256 time steps per workgroup, 4 waves each owning 64 x 128 (acc 128
+// VGPRs), 24 KiB per stage -> two workgroups per CU that run out of phase.  Rationale (PMC, profiles/r01f_pmc): with ONE
+// 8-wave workgroup per CU all waves hit the same barrier, the MFMA pipe idles 2/3 of the time (WAIT_ANY 45 %, MFMA busy
+// 33 %); two independent 4-wave workgroups keep 12 fragment reads per 32 MFMAs but desynchronise the waits.
+// LDS rows are 64 B: chunk (0..3) ^= (row >> 1) & 3 is conflict-free for the 16-lane ds_read_b128 service groups.
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+
+__global__ __launch_bounds__(256) void conv1d_glds32_kernel(ConvArgs a) {
+    constexpr int TC = 128, TN = 256, MI = 4, NI = 8, BK = 32;
+    constexpr int NTW = TC / 16 / 4, NTX = TN / 16 / 4;  // 1 KiB transfers (16 rows x 64 B) per wave per stage
+    constexpr int STAGE_BYTES = (TC + TN) * BK * 2;
+    MV_DYN_SMEM(smem);
+    int n_tile, co_tile;
+    if (!tile_of_block(a, n_tile, co_tile)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;
+    const int n0 = n_tile * TN;
+    const int co0 = co_tile * TC;
+    const int lrow = lane >> 2;                       // row inside a 16-row transfer
+    const int kc = (lane & 3) ^ ((lrow >> 1) & 3);    // source chunk that lands in LDS slot (lane & 3)
+    RowMap rm[NTX];
+    const half_t* wsrc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTX; ++i) {
+        const int n = n0 + (wave * NTX + i) * 16 + lrow;
+        if (n < a.n_rows) {
+            rm[i].b = n / a.T_out;
+            rm[i].t = n - rm[i].b * a.T_out;
+        } else {
+            rm[i].b = -1;
+            rm[i].t = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int co = co0 + (wave * NTW + i) * 16 + lrow;
+        wsrc[i] = co < a.cout_pad ? a.w + (int64_t)co * a.k * a.cin_pad + kc * 8 : nullptr;
+    }
+    const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
+    const int kstages_per_tap = a.cin_pad / BK;
+    const int nstages = a.k * kstages_per_tap;
+
+    auto issue = [&](int s, int buf) {
+        char* wt = smem + buf * STAGE_BYTES;
+        char* xtile = wt + TC * BK * 2;
+        const int tap = s / kstages_per_tap;
+        const int c0 = (s - tap * kstages_per_tap) * BK;
+        const int c = c0 + kc * 8;
+        const bool ch_ok = c < a.cin;
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) {
+            const int tin = input_time(a, rm[i].t, tap);
+            const half_t* src = zero;
+            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
+            glds16(src, xtile + (wave * NTX + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const half_t* src = wsrc[i] != nullptr ? wsrc[i] + (int64_t)tap * a.cin_pad + c0 : zero;
+            glds16(src, wt + (wave * NTW + i) * 1024);
+        }
+    };
+
+    float4v acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    issue(0, 0);
+    wait_all_loads();
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstages) issue(s + 1, buf ^ 1);
+        const char* wt = smem + buf * STAGE_BYTES;
+        const char* xtile = wt + TC * BK * 2;
+        half8v af[MI], bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off32(wc * 64 + mi * 16 + frow, fchunk));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off32(wn * 128 + ni * 16 + frow, fchunk));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        wait_all_loads();
+        __syncthreads();
+    }
+    if (a.y_f16 && a.sum_dst == nullptr) {
+        conv_epilogue_staged<MI, NI, TC, TN, 256>(a, smem, n0, co0, wc, wn, lane, tid, acc);
+    } else {
+        conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
+    }
+}
+
 // ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
 template <typename InT>
 struct RawChunk;
@@ -601,11 +703,14 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool f16 = d.x_dtype == MV_DT_F16;
     const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
     // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
-    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256, "conv1d: tile must be 0 (auto), 128 or 256");
+    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256 || d.tile == 257, "conv1d: tile must be 0 (auto), 128, 256 or 257");
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
-    const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
-    const int tn = big ? 256 : CV_TN, tc = big ? 256 : CV_TC;
+    const bool big = big_ok && d.tile != 128 && d.tile != 257 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    // 257 = 256 time steps x 128 channels with 32-wide K stages (two 4-wave workgroups per CU)
+    const bool mid = d.tile == 257;
+    if (mid) MV_REQUIRE(f16 && !has_x2 && !in_aff, "conv1d: tile 257 needs the plain fp16 path");
+    const int tn = (big || mid) ? 256 : CV_TN, tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
@@ -613,13 +718,16 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_glds32_kernel, CV_LDS_BYTES_MID) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    if (big) {
+    if (mid) {
+        MV_LAUNCH(conv1d_glds32_kernel, (grid, 1, 1), (256, 1, 1), CV_LDS_BYTES_MID, stream, a);
+    } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);

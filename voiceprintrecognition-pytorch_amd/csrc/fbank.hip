@@ -100,6 +100,21 @@ __device__ __forceinline__ void fft16(cplx (&x)[16]) {
     }
 }
 
+__device__ __forceinline__ void fb_glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef MV_EMU
+    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ void fb_wait_loads() {
+#ifndef MV_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 constexpr int FB_NFFT = 512;
 constexpr int FB_MAX_WAVES = 16;          // waves per workgroup: 8, 12 or 16 (template parameter WAVES)
 constexpr int FB_TSTRIDE = 17;            // padded row of the 16x16 transpose tile (complex elements)
@@ -129,11 +144,14 @@ struct FbankArgs {
     float inv_win;
     int remove_dc, use_power, use_log, cmn;
     int vec2_ok;
+    int load_mode;  // 0 scalar, 1 float2, 2 LDS-DMA prefetch
+    int64_t L;
     FbankTables tab;
 };
 
 // ROUNDS = ceil(num_mel_bins / 16): filters per lane (compile-time so the per-lane state stays in registers)
-template <int ROUNDS, bool VEC2, int FB_WAVES>
+// MODE: 0 scalar global loads, 1 float2 global loads, 2 = the quad's samples are prefetched by LDS-DMA one iteration ahead
+template <int ROUNDS, int MODE, int FB_WAVES>
 __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     constexpr int FB_THREADS = FB_WAVES * 64;
     MV_DYN_SMEM(smem);
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     float* colsum = ltw + 512;                                                    // [FB_WAVES][128] then mean[128]
     int* mstart = reinterpret_cast<int*>(colsum + (FB_WAVES + 1) * 128);          // [FB_MAX_ROUNDS*16]
     float* melw = reinterpret_cast<float*>(mstart + FB_MAX_ROUNDS * 16);          // [melw_elems]
+    float* sring = melw + a.tab.melw_elems;                                       // MODE 2: [FB_WAVES][2][1024] samples
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,11 +196,35 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     for (int i = 0; i < ROUNDS; ++i) csum[i] = 0.0f;
 
     const int nquads = (T + 3) >> 2;
+    // MODE 2: the 3*shift + win (<= 1024) samples of a quad of frames are contiguous; the wave copies them global -> LDS with
+    // four 1 KiB DMA transfers, one iteration ahead of their use (each sample is fetched once instead of 2.5 times).
+    float* swave = sring + wave * 2048;
+    auto prefetch_quad = [&](int q, int buf) {
+        const int64_t first = (int64_t)q * 4 * a.shift;
+        const int64_t last_ok = a.L - 4 - first;  // largest in-row start of a 4-float transfer, relative to `first`
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t off = i * 256 + lane * 4;
+            off = off < last_ok ? off : last_ok;  // clamped lanes land on samples no valid frame of this quad reads
+            fb_glds16(wrow + first + off, reinterpret_cast<char*>(swave + buf * 1024 + i * 256));
+        }
+    };
+    if (MODE == 2 && wave < nquads) prefetch_quad(wave, 0);
+    int ring = 0;
     for (int q = wave; q < nquads; q += FB_WAVES) {
         const int f_raw = q * 4 + fs;
         const bool fvalid = f_raw < T;
         const int f = fvalid ? f_raw : T - 1;
-        const float* fp = wrow + (int64_t)f * a.shift;
+        const float* fp;
+        if (MODE == 2) {
+            fb_wait_loads();   // this quad's transfers (issued one iteration ago) have landed
+            MV_WAVE_FENCE();
+            fp = swave + ring * 1024 + (f - q * 4) * a.shift;
+            if (q + FB_WAVES < nquads) prefetch_quad(q + FB_WAVES, ring ^ 1);
+            ring ^= 1;
+        } else {
+            fp = wrow + (int64_t)f * a.shift;
+        }
 
         // ---- load the frame: lane holds samples 32*n1 + 2*l16 (+1).  Branch-free: indices beyond the frame are
         // clamped to a valid address and the value is zeroed by a select, so all 16 loads are in flight together ----
@@ -192,7 +235,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         for (int n1 = 0; n1 < 16; ++n1) {
             float v0 = 0.0f, v1 = 0.0f;
             if (n1 < n1_full) {  // plain base + constant offset: nothing per-lane to keep alive across iterations
-                if (VEC2) {
+                if (MODE >= 1) {
                     const float2v v = *reinterpret_cast<const float2v*>(fp + 32 * n1 + 2 * l16);
                     v0 = v[0];
                     v1 = v[1];
@@ -403,7 +446,7 @@ struct MvFbank {
     int* d_mel_start = nullptr;
     mv::FbankTables tab;
     size_t smem_bytes = 0;
-    int waves = 16;  // workgroup size in waves (tuning knob: MV_FBANK_WAVES = 8 | 12 | 16)
+    int waves = 8;   // workgroup size in waves; 8 measured fastest (16 spills).  Tuning knob: MV_FBANK_WAVES = 8 | 12 | 16
 };
 
 namespace {
@@ -443,9 +486,11 @@ int upload(const std::vector<T>& v, T** dptr) {
 
 template <int R, int W>
 hipError_t fbank_set_smem_w(size_t bytes) {
-    hipError_t e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, true, W>), bytes);
+    hipError_t e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, 2, W>), bytes);
     if (e != hipSuccess) return e;
-    return MV_SET_MAX_SMEM((mv::fbank_kernel<R, false, W>), bytes);
+    e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, 1, W>), bytes);
+    if (e != hipSuccess) return e;
+    return MV_SET_MAX_SMEM((mv::fbank_kernel<R, 0, W>), bytes);
 }
 
 template <int R>
@@ -457,10 +502,12 @@ hipError_t fbank_set_smem(size_t bytes, int waves) {
 
 template <int R, int W>
 void fbank_launch_w(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a) {
-    if (a.vec2_ok) {
-        MV_LAUNCH((mv::fbank_kernel<R, true, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+    if (a.load_mode == 2) {
+        MV_LAUNCH((mv::fbank_kernel<R, 2, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+    } else if (a.load_mode == 1) {
+        MV_LAUNCH((mv::fbank_kernel<R, 1, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
     } else {
-        MV_LAUNCH((mv::fbank_kernel<R, false, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+        MV_LAUNCH((mv::fbank_kernel<R, 0, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
     }
 }
 
@@ -572,7 +619,7 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     }
     h->smem_bytes = (size_t)h->waves * 4 * mv::FB_SLOT_CPLX * sizeof(mv::cplx) + 3 * 512 * sizeof(float) +
                     (size_t)(h->waves + 1) * 128 * sizeof(float) + (size_t)mv::FB_MAX_ROUNDS * 16 * sizeof(int) +
-                    melw.size() * sizeof(float);
+                    melw.size() * sizeof(float) + (h->waves == 8 ? (size_t)h->waves * 2048 * sizeof(float) : 0);
     hipError_t se = hipSuccess;
     switch (rounds) {
         case 1: se = fbank_set_smem<1>(h->smem_bytes, h->waves); break;
@@ -635,6 +682,11 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.use_log = h->cfg.use_log_fbank;
     a.cmn = h->cfg.subtract_time_mean;
     a.vec2_ok = ((reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0) ? 1 : 0;
+    a.L = L;
+    // DMA prefetch needs 16-byte aligned 4-float transfers and a quad of frames that fits the 1024-sample ring slot
+    const bool dma_ok = (reinterpret_cast<uintptr_t>(wav) & 15) == 0 && (wav_stride & 3) == 0 && (h->shift & 3) == 0 &&
+                        (h->win & 1) == 0 && 3 * h->shift + h->win <= 1024 && L >= 4 && h->waves == 8;  // the sample ring is only carved for 8-wave workgroups
+    a.load_mode = dma_ok ? 2 : (a.vec2_ok ? 1 : 0);
     a.tab = h->tab;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (h->tab.rounds) {
