@@ -28,7 +28,6 @@ constexpr int CV_TN = 128;  // time steps per tile
 constexpr int CV_BK = 64;   // K elements per stage
 constexpr int CV_THREADS = 256;
 constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
-constexpr int CV_LDS_BYTES_MID = 256 * (128 * 2 + 8);          // 256 x 128 tile, 32-wide stages: 2 x 24 KiB stages, 66 KiB staged epilogue
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -388,24 +387,46 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     }
 }
 
-// ---- variant with 32-wide K stages: 128 channels x 256 time steps per workgroup, 4 waves each owning 64 x 128 (acc 128
-// VGPRs), 24 KiB per stage -> two workgroups per CU that run out of phase.  Rationale (PMC, profiles/r01f_pmc): with ONE
-// 8-wave workgroup per CU all waves hit the same barrier, the MFMA pipe idles 2/3 of the time (WAIT_ANY 45 %, MFMA busy
-// 33 %); two independent 4-wave workgroups keep 12 fragment reads per 32 MFMAs but desynchronise the waits.
+// ---- ring-buffered variant for wide layers: 256 x 256 tile, 8 waves (each 128 channels x 64 time steps), 32-wide K stages
+// in a 4-slot LDS ring with COUNTED waits, so three stages of global->LDS transfers stay in flight across the barriers.
+// Why: the double-buffered kernel above is latency bound -- measured 2.36 us per 64-wide stage against 0.85 us of MFMA
+// work, i.e. one stage of prefetch lead cannot cover the ~2.3 us issue-to-landed time of a stage under load
+// (profiles/r01f_pmc: WAIT_ANY 45 %, MFMA busy 33 %).  With three stages in flight the steady state is
+// max(compute, latency / 3) per stage.  (A 2-slot 32-wide variant measured 335 TF: shorter stages alone only make the
+// lead shorter; profiles/r01h_conv_tile_microbench.log.)
 // LDS rows are 64 B: chunk (0..3) ^= (row >> 1) & 3 is conflict-free for the 16-lane ds_read_b128 service groups.
 __device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
-__global__ __launch_bounds__(256) void conv1d_glds32_kernel(ConvArgs a) {
-    constexpr int TC = 128, TN = 256, MI = 4, NI = 8, BK = 32;
-    constexpr int NTW = TC / 16 / 4, NTX = TN / 16 / 4;  // 1 KiB transfers (16 rows x 64 B) per wave per stage
-    constexpr int STAGE_BYTES = (TC + TN) * BK * 2;
+template <int N>
+__device__ __forceinline__ void wait_loads_but() {  // wait until at most N vector-memory operations are outstanding
+#ifndef MV_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+// workgroup barrier that orders LDS traffic only (does not drain the transfers in flight for later stages)
+__device__ __forceinline__ void lds_barrier() {
+#ifdef MV_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+constexpr int CV_RING = 4;
+
+__global__ __launch_bounds__(512) void conv1d_glds_ring_kernel(ConvArgs a) {
+    constexpr int TC = 256, TN = 256, MI = 8, NI = 4, BK = 32, NW = 8;
+    constexpr int NTW = TC / 16 / NW, NTX = TN / 16 / NW;  // 1 KiB transfers (16 rows x 64 B) per wave per stage
+    constexpr int TP = NTW + NTX;
+    constexpr int STAGE_BYTES = (TC + TN) * BK * 2;        // 32 KiB
     MV_DYN_SMEM(smem);
     int n_tile, co_tile;
     if (!tile_of_block(a, n_tile, co_tile)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wc = wave >> 1, wn = wave & 1;
+    const int wc = wave >> 2, wn = wave & 3;
     const int n0 = n_tile * TN;
     const int co0 = co_tile * TC;
     const int lrow = lane >> 2;                       // row inside a 16-row transfer
@@ -433,8 +454,8 @@ __global__ __launch_bounds__(256) void conv1d_glds32_kernel(ConvArgs a) {
     const int kstages_per_tap = a.cin_pad / BK;
     const int nstages = a.k * kstages_per_tap;
 
-    auto issue = [&](int s, int buf) {
-        char* wt = smem + buf * STAGE_BYTES;
+    auto issue = [&](int s) {
+        char* wt = smem + (s % CV_RING) * STAGE_BYTES;
         char* xtile = wt + TC * BK * 2;
         const int tap = s / kstages_per_tap;
         const int c0 = (s - tap * kstages_per_tap) * BK;
@@ -461,29 +482,35 @@ __global__ __launch_bounds__(256) void conv1d_glds32_kernel(ConvArgs a) {
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int frow = lane & 15, fchunk = lane >> 4;
-    issue(0, 0);
-    wait_all_loads();
-    __syncthreads();
+    for (int s0 = 0; s0 < CV_RING - 1 && s0 < nstages; ++s0) issue(s0);
     for (int s = 0; s < nstages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstages) issue(s + 1, buf ^ 1);
-        const char* wt = smem + buf * STAGE_BYTES;
+        // stages s+1 .. min(s+2, last) were issued after stage s and may stay in flight
+        const int younger = (s + CV_RING - 2 < nstages - 1 ? s + CV_RING - 2 : nstages - 1) - s;
+        if (younger >= 2) {
+            wait_loads_but<2 * TP>();
+        } else if (younger == 1) {
+            wait_loads_but<TP>();
+        } else {
+            wait_loads_but<0>();
+        }
+        lds_barrier();  // stage s is visible to everyone; everyone is done with the slot of stage s-1 ...
+        if (s + CV_RING - 1 < nstages) issue(s + CV_RING - 1);  // ... which is refilled with stage s+3
+        const char* wt = smem + (s % CV_RING) * STAGE_BYTES;
         const char* xtile = wt + TC * BK * 2;
         half8v af[MI], bf[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off32(wc * 64 + mi * 16 + frow, fchunk));
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off32(wc * 128 + mi * 16 + frow, fchunk));
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off32(wn * 128 + ni * 16 + frow, fchunk));
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off32(wn * 64 + ni * 16 + frow, fchunk));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        wait_all_loads();
-        __syncthreads();
     }
+    __syncthreads();  // all waves are done with the ring before the epilogue reuses it
     if (a.y_f16 && a.sum_dst == nullptr) {
-        conv_epilogue_staged<MI, NI, TC, TN, 256>(a, smem, n0, co0, wc, wn, lane, tid, acc);
+        conv_epilogue_staged<MI, NI, TC, TN, 512>(a, smem, n0, co0, wc, wn, lane, tid, acc);
     } else {
         conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
     }
@@ -707,10 +734,10 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
     const bool big = big_ok && d.tile != 128 && d.tile != 257 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
-    // 257 = 256 time steps x 128 channels with 32-wide K stages (two 4-wave workgroups per CU)
-    const bool mid = d.tile == 257;
-    if (mid) MV_REQUIRE(f16 && !has_x2 && !in_aff, "conv1d: tile 257 needs the plain fp16 path");
-    const int tn = (big || mid) ? 256 : CV_TN, tc = big ? 256 : CV_TC;
+    // 257 = the 256 x 256 tile with the 4-slot ring of 32-wide stages (counted waits)
+    const bool ring = d.tile == 257;
+    if (ring) MV_REQUIRE(big_ok, "conv1d: tile 257 needs the plain fp16 path and cout % 256 == 0");
+    const int tn = (big || ring) ? 256 : CV_TN, tc = (big || ring) ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
@@ -718,15 +745,15 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_glds32_kernel, CV_LDS_BYTES_MID) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_glds_ring_kernel, CV_LDS_BYTES_BIG) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    if (mid) {
-        MV_LAUNCH(conv1d_glds32_kernel, (grid, 1, 1), (256, 1, 1), CV_LDS_BYTES_MID, stream, a);
+    if (ring) {
+        MV_LAUNCH(conv1d_glds_ring_kernel, (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
