@@ -124,9 +124,7 @@ CONV_CASES = [
     dict(k=3, dil=2, cin=16, cout=16, second_out=True, T=41),          # Res2Net step emitting the next step's input
     dict(k=1, dil=1, cin=72, cout=256, T=300, B=1, tile=256),           # 256 x 256 workgroup tile (8 waves)
     dict(k=3, dil=2, cin=64, cout=512, T=70, B=2, tile=256, row_bias=True, post_act=2),  # 256 tile, 2 co tiles, ragged rows
-    dict(k=1, dil=1, cin=104, cout=256, T=300, B=1, tile=257),          # 256 x 256 tile, 4-slot ring of 32-wide K stages
-    dict(k=3, dil=3, cin=32, cout=512, T=90, B=3, tile=257, gate_seg=25, pre_act=0, affine=False, pad_mode='zero'),
-    dict(k=1, dil=1, cin=320, cout=256, T=130, B=2, tile=257),          # ring longer than the stage count differences
+    dict(k=3, dil=3, cin=32, cout=512, T=90, B=3, tile=256, gate_seg=25, pre_act=0, affine=False, pad_mode='zero'),
 ]
 
 

@@ -5,26 +5,28 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprin
 import torch
 from mvector import _hip
 import layer_checks as lc
-lib = _hip.lib()
+lib = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else _hip.lib()
 B, T = 256, 298
 shapes = [('c2c 1024->1024 k1', 1024, 1024, 1, 1), ('mfa 3072->3072 k1', 3072, 3072, 1, 1), ('asp 3072->128 k1', 3072, 128, 1, 1),
           ('res2 128->128 k3d3', 128, 128, 3, 3), ('c2c 512->512 k1', 512, 512, 1, 1), ('mfa 1536->1536', 1536, 1536, 1, 1)]
 for name, cin, cout, k, dil in shapes:
-    x = (torch.randn(B, T, cin, device='cuda') * 0.5).half()
+    PADX = int(os.environ.get('MV_PADX', '0'))
+    xfull = (torch.randn(B, T, cin + PADX, device='cuda') * 0.5).half()
+    x = xfull
     w = torch.randn(cout, cin, k, device='cuda') * (2.0 / (cin * k)) ** 0.5
     packed = lc.pack_weight(lib, w)
     bias = torch.randn(cout, device='cuda') * 0.1
     scale = torch.rand(cout, device='cuda') + 0.5
     shift = torch.randn(cout, device='cuda') * 0.1
-    y = torch.empty(B, T, cout, dtype=torch.float16, device='cuda')
-    for tile in (128, 256, 257):
+    y = torch.empty(B, T, cout + PADX, dtype=torch.float16, device='cuda')
+    for tile in (128, 256):
         if tile == 256 and cout % 256:
             continue
         d = _hip.MvConv1dDesc()
-        d.x, d.x_dtype, d.ldx = x.data_ptr(), _hip.MV_DT_F16, cin
+        d.x, d.x_dtype, d.ldx = x.data_ptr(), _hip.MV_DT_F16, cin + PADX
         d.w_packed, d.bias, d.scale, d.shift = packed.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr()
         d.pre_act, d.post_act = 1, 0
-        d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout
+        d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout + PADX
         d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, cin, cout, k, dil, 1
         d.pad, d.pad_mode, d.tile = dil * (k - 1) // 2, _hip.MV_PAD_REFLECT, tile
         st = _hip.current_stream(x)

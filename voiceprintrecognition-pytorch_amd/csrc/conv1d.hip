@@ -374,9 +374,13 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
+#if !defined(MV_PROBE) || MV_PROBE != 1   // probe 1: no global->LDS traffic in the K loop (tools/probe only)
         if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
+#endif
         const char* wt = smem + buf * STAGE_BYTES;
+#if !defined(MV_PROBE) || MV_PROBE != 2   // probe 2: no LDS reads / MFMAs in the K loop
         mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+#endif
         wait_all_loads();
         __syncthreads();
     }
@@ -387,134 +391,11 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     }
 }
 
-// ---- ring-buffered variant for wide layers: 256 x 256 tile, 8 waves (each 128 channels x 64 time steps), 32-wide K stages
-// in a 4-slot LDS ring with COUNTED waits, so three stages of global->LDS transfers stay in flight across the barriers.
-// Why: the double-buffered kernel above is latency bound -- measured 2.36 us per 64-wide stage against 0.85 us of MFMA
-// work, i.e. one stage of prefetch lead cannot cover the ~2.3 us issue-to-landed time of a stage under load
-// (profiles/r01f_pmc: WAIT_ANY 45 %, MFMA busy 33 %).  With three stages in flight the steady state is
-// max(compute, latency / 3) per stage.  (A 2-slot 32-wide variant measured 335 TF: shorter stages alone only make the
-// lead shorter; profiles/r01h_conv_tile_microbench.log.)
-// LDS rows are 64 B: chunk (0..3) ^= (row >> 1) & 3 is conflict-free for the 16-lane ds_read_b128 service groups.
-__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
-
-template <int N>
-__device__ __forceinline__ void wait_loads_but() {  // wait until at most N vector-memory operations are outstanding
-#ifndef MV_EMU
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-
-// workgroup barrier that orders LDS traffic only (does not drain the transfers in flight for later stages)
-__device__ __forceinline__ void lds_barrier() {
-#ifdef MV_EMU
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
-constexpr int CV_RING = 4;
-
-__global__ __launch_bounds__(512) void conv1d_glds_ring_kernel(ConvArgs a) {
-    constexpr int TC = 256, TN = 256, MI = 8, NI = 4, BK = 32, NW = 8;
-    constexpr int NTW = TC / 16 / NW, NTX = TN / 16 / NW;  // 1 KiB transfers (16 rows x 64 B) per wave per stage
-    constexpr int TP = NTW + NTX;
-    constexpr int STAGE_BYTES = (TC + TN) * BK * 2;        // 32 KiB
-    MV_DYN_SMEM(smem);
-    int n_tile, co_tile;
-    if (!tile_of_block(a, n_tile, co_tile)) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wc = wave >> 2, wn = wave & 3;
-    const int n0 = n_tile * TN;
-    const int co0 = co_tile * TC;
-    const int lrow = lane >> 2;                       // row inside a 16-row transfer
-    const int kc = (lane & 3) ^ ((lrow >> 1) & 3);    // source chunk that lands in LDS slot (lane & 3)
-    RowMap rm[NTX];
-    const half_t* wsrc[NTW];
-#pragma unroll
-    for (int i = 0; i < NTX; ++i) {
-        const int n = n0 + (wave * NTX + i) * 16 + lrow;
-        if (n < a.n_rows) {
-            rm[i].b = n / a.T_out;
-            rm[i].t = n - rm[i].b * a.T_out;
-        } else {
-            rm[i].b = -1;
-            rm[i].t = 0;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int co = co0 + (wave * NTW + i) * 16 + lrow;
-        wsrc[i] = co < a.cout_pad ? a.w + (int64_t)co * a.k * a.cin_pad + kc * 8 : nullptr;
-    }
-    const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
-    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
-    const int kstages_per_tap = a.cin_pad / BK;
-    const int nstages = a.k * kstages_per_tap;
-
-    auto issue = [&](int s) {
-        char* wt = smem + (s % CV_RING) * STAGE_BYTES;
-        char* xtile = wt + TC * BK * 2;
-        const int tap = s / kstages_per_tap;
-        const int c0 = (s - tap * kstages_per_tap) * BK;
-        const int c = c0 + kc * 8;
-        const bool ch_ok = c < a.cin;
-#pragma unroll
-        for (int i = 0; i < NTX; ++i) {
-            const int tin = input_time(a, rm[i].t, tap);
-            const half_t* src = zero;
-            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
-            glds16(src, xtile + (wave * NTX + i) * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const half_t* src = wsrc[i] != nullptr ? wsrc[i] + (int64_t)tap * a.cin_pad + c0 : zero;
-            glds16(src, wt + (wave * NTW + i) * 1024);
-        }
-    };
-
-    float4v acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-
-    const int frow = lane & 15, fchunk = lane >> 4;
-    for (int s0 = 0; s0 < CV_RING - 1 && s0 < nstages; ++s0) issue(s0);
-    for (int s = 0; s < nstages; ++s) {
-        // stages s+1 .. min(s+2, last) were issued after stage s and may stay in flight
-        const int younger = (s + CV_RING - 2 < nstages - 1 ? s + CV_RING - 2 : nstages - 1) - s;
-        if (younger >= 2) {
-            wait_loads_but<2 * TP>();
-        } else if (younger == 1) {
-            wait_loads_but<TP>();
-        } else {
-            wait_loads_but<0>();
-        }
-        lds_barrier();  // stage s is visible to everyone; everyone is done with the slot of stage s-1 ...
-        if (s + CV_RING - 1 < nstages) issue(s + CV_RING - 1);  // ... which is refilled with stage s+3
-        const char* wt = smem + (s % CV_RING) * STAGE_BYTES;
-        const char* xtile = wt + TC * BK * 2;
-        half8v af[MI], bf[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off32(wc * 128 + mi * 16 + frow, fchunk));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off32(wn * 64 + ni * 16 + frow, fchunk));
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();  // all waves are done with the ring before the epilogue reuses it
-    if (a.y_f16 && a.sum_dst == nullptr) {
-        conv_epilogue_staged<MI, NI, TC, TN, 512>(a, smem, n0, co0, wc, wn, lane, tid, acc);
-    } else {
-        conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
-    }
-}
+// Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
+// r01h), a 256x256 tile with a 4-slot ring of 32-wide stages and counted vmcnt (500 / 775 TF, r01i -- no better than the
+// double buffer), padded leading dimensions (r01k, no effect).  Probes with the K loop reduced to its loads or to its
+// LDS reads + MFMAs (MV_PROBE, r01j) show the 256x256 kernel is bound by the global->LDS path: loads alone take 83 % of
+// the full time (~8.4 TB/s of L2->LDS traffic chip-wide), LDS reads + MFMAs alone reach 1530 TF.
 
 // ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
 template <typename InT>
@@ -730,14 +611,11 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool f16 = d.x_dtype == MV_DT_F16;
     const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
     // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
-    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256 || d.tile == 257, "conv1d: tile must be 0 (auto), 128, 256 or 257");
+    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256, "conv1d: tile must be 0 (auto), 128 or 256");
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
-    const bool big = big_ok && d.tile != 128 && d.tile != 257 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
-    // 257 = the 256 x 256 tile with the 4-slot ring of 32-wide stages (counted waits)
-    const bool ring = d.tile == 257;
-    if (ring) MV_REQUIRE(big_ok, "conv1d: tile 257 needs the plain fp16 path and cout % 256 == 0");
-    const int tn = (big || ring) ? 256 : CV_TN, tc = (big || ring) ? 256 : CV_TC;
+    const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    const int tn = big ? 256 : CV_TN, tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
@@ -745,16 +623,13 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_glds_ring_kernel, CV_LDS_BYTES_BIG) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    if (ring) {
-        MV_LAUNCH(conv1d_glds_ring_kernel, (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
-    } else if (big) {
+    if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);

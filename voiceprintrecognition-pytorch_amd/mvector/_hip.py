@@ -107,6 +107,16 @@ def bind(cdll):
     return cdll
 
 
+def bind_partial(cdll):
+    """Prototypes for whatever subset of the ABI a (probe) library exports; tools only."""
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(cdll, name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
+    return cdll
+
+
 def available():
     return os.path.exists(LIB_PATH)
 
