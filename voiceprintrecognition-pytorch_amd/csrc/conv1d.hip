@@ -65,6 +65,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // 256 zero bytes: source of every padded / out-of-range 16-byte chunk, so the loaders never branch
 __device__ __attribute__((aligned(256))) const unsigned char g_zero_page[256] = {0};
 
+// 256 ones: stands in for an absent BatchNorm scale in the persistent kernel's parameter slots
+__device__ __attribute__((aligned(256))) const float g_one_page[256] = {
+#define MV_ONE16 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f
+    MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16,
+    MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16, MV_ONE16
+#undef MV_ONE16
+};
+
 __device__ __forceinline__ half_t to_half_sat(float v) {
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);  // saturate instead of producing inf
     return (half_t)v;
@@ -274,13 +282,12 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
     }
 }
 
-__device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
+__device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n_tile, int& co_tile) {
     // XCD-aware super-tiles.  Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with a private L2.
     // XCD x owns the n-tiles x, x+8, ...; inside an XCD the blocks walk groups of <= 8 co-tiles: for each group, for each
     // owned n-tile, for each co-tile of the group.  The ~64 workgroups resident on an XCD therefore cover ~8 n-tiles x 8
     // co-tiles and stream K in near lockstep, so every activation slice and every weight slice fetched into that L2
     // is reused ~8 times before it is evicted.
-    const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int seq = bid >> 3;
     const int nx = (a.n_tiles + 7) >> 3;          // n-tiles per XCD (upper bound)
@@ -292,6 +299,10 @@ __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, in
     co_tile = base + idx - n_local * gw;
     n_tile = xcd + 8 * n_local;
     return n_tile < a.n_tiles;
+}
+
+__device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
+    return tile_of_index(a, blockIdx.x, n_tile, co_tile);
 }
 
 // ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
@@ -389,6 +400,190 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     } else {
         conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
     }
+}
+
+// ---- persistent 256 x 256 kernel: one workgroup per CU walks a list of tiles ------------------------------------
+// The 256^2 kernel above runs one workgroup per CU (128 KiB of LDS), so nothing overlaps a tile's prologue (first
+// stage in flight, nothing to compute) and epilogue (128 KiB of stores, all CUs at once, memory pipes idle during the
+// K loops): ~20 us per tile, a third of the time of a K = 1024 layer.  Here the workgroup stays resident and walks the
+// tiles  blockIdx.x + i * gridDim.x  of the same XCD-aware order:
+//   * the first K stage of the next tile is requested while the last stage of the current one computes;
+//   * the epilogue of tile i runs inside stage 0 of tile i+1 (after that stage's loads have been requested, before its
+//     MFMAs overwrite the accumulators), so its stores drain under the next tile's K loop;
+//   * bias / scale / shift of a tile arrive by LDS-DMA with its first stage (three rotating 3 KiB slots), so the
+//     epilogue issues no vector loads that would have to queue behind the stage loads;
+//   * the output goes through a wave-private 2 KiB staging block (16 time steps x 64 channels, XOR-swizzled) and
+//     leaves as 16-byte stores covering whole 128-byte row segments; no workgroup barrier in the epilogue.
+constexpr int CVP_STAGE_BYTES = 65536;
+constexpr int CVP_PARAM_OFF = 2 * CVP_STAGE_BYTES;
+constexpr int CVP_PARAM_SLOT = 3 * 1024;
+constexpr int CVP_STAGING_OFF = CVP_PARAM_OFF + 3 * CVP_PARAM_SLOT;
+constexpr int CVP_LDS_BYTES = CVP_STAGING_OFF + 8 * 2048;  // 156 672 B of the 160 KiB
+
+__device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* smem, int n0, int co0, int pslot, int wc, int wn,
+                                                    int wave, int lane, float4v (&acc)[8][4]) {
+    const char* par = smem + CVP_PARAM_OFF + pslot * CVP_PARAM_SLOT;
+    char* stg = smem + CVP_STAGING_OFF + wave * 2048;
+    const int r = lane & 15, q = lane >> 4;
+    half_t* y = reinterpret_cast<half_t*>(a.y);
+    const int rrow = lane >> 3, rch = lane & 7;
+    // host admits none / ReLU only: max(v, -inf) is the identity
+    const float lo_pre = a.pre_act == MV_ACT_RELU ? 0.0f : -INFINITY, lo_post = a.post_act == MV_ACT_RELU ? 0.0f : -INFINITY;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int col = wc * 128 + (h * 4 + m) * 16 + 4 * q;
+                float4v v = acc[h * 4 + m][ni] + *reinterpret_cast<const float4v*>(par + col * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
+                v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_post);
+                half4v hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = to_half_sat(v[e]);
+                const int pc = (m * 2 + (q >> 1)) ^ ((r >> 1) & 7);
+                *reinterpret_cast<half4v*>(stg + r * 128 + pc * 16 + (q & 1) * 8) = hv;
+            }
+            MV_WAVE_FENCE();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = rrow + 8 * j;
+                const half8v o = *reinterpret_cast<const half8v*>(stg + row * 128 + ((rch ^ ((row >> 1) & 7)) << 4));
+                const int n = n0 + wn * 64 + ni * 16 + row;
+                if (n < a.n_rows) *reinterpret_cast<half8v*>(y + (int64_t)n * a.ldy + co0 + wc * 128 + h * 64 + rch * 8) = o;
+            }
+            MV_WAVE_FENCE();
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a) {
+    constexpr int WN = 4, MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
+    MV_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wc = wave / WN, wn = wave % WN;
+    const int lrow = lane >> 3;
+    const int kc = (lane & 7) ^ (lrow & 7);
+    const int total = ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;  // virtual workgroup ids of tile_of_index
+    const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
+    const int kstages_per_tap = a.cin_pad / CV_BK;
+    const int nstages = a.k * kstages_per_tap;
+
+    // loader state: the tile whose stages are being requested
+    RowMap rm[NTX];
+    const half_t* wsrc[NTW];
+    int l_vb = blockIdx.x, l_n0 = 0, l_co0 = 0, l_ps = 0;
+
+    auto advance = [&](int vb) {  // first valid tile at or after vb (stride gridDim.x); sets the loader state
+        int n_tile = 0, co_tile = 0;
+        while (vb < total && !tile_of_index(a, vb, n_tile, co_tile)) vb += gridDim.x;
+        l_vb = vb;
+        if (vb >= total) return false;
+        l_n0 = n_tile * TN;
+        l_co0 = co_tile * TC;
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) {
+            const int n = l_n0 + (wave * NTX + i) * 8 + lrow;
+            if (n < a.n_rows) {
+                rm[i].b = n / a.T_out;
+                rm[i].t = n - rm[i].b * a.T_out;
+            } else {
+                rm[i].b = -1;
+                rm[i].t = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int co = l_co0 + (wave * NTW + i) * 8 + lrow;  // cout % 256 == 0: always inside the packed weights
+            wsrc[i] = a.w + (int64_t)co * a.k * a.cin_pad + kc * 8;
+        }
+        return true;
+    };
+
+    auto issue = [&](int s, int buf) {
+        char* wt = smem + buf * CVP_STAGE_BYTES;
+        char* xtile = wt + TC * CV_BK * 2;
+        const int tap = s / kstages_per_tap;
+        const int c0 = (s - tap * kstages_per_tap) * CV_BK;
+        const int c = c0 + kc * 8;
+        const bool ch_ok = c < a.cin;
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) {
+            const int tin = input_time(a, rm[i].t, tap);
+            const half_t* src = zero;
+            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
+            glds16(src, xtile + (wave * NTX + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) glds16(wsrc[i] + (int64_t)tap * a.cin_pad + c0, wt + (wave * NTW + i) * 1024);
+    };
+
+    // waves 0..2 fetch bias / scale / shift of the loader's tile (256 floats = 1 KiB each); absent arrays are replaced
+    // by constant pages, so the epilogue is branch-free
+    const float* pparam = a.bias != nullptr ? a.bias : reinterpret_cast<const float*>(g_zero_page);
+    bool pconst = a.bias == nullptr;
+    if (wave == 1) {
+        pparam = a.scale != nullptr ? a.scale : g_one_page;
+        pconst = a.scale == nullptr;
+    } else if (wave == 2) {
+        pparam = a.shift != nullptr ? a.shift : reinterpret_cast<const float*>(g_zero_page);
+        pconst = a.shift == nullptr;
+    }
+    auto issue_params = [&]() {
+        if (wave < 3) {
+            // constant pages: g_zero_page is 256 B (every lane reads its first 16 B), g_one_page a full 1 KiB
+            const float* src = pconst ? (wave == 1 ? pparam + lane * 4 : pparam) : pparam + l_co0 + lane * 4;
+            glds16(src, smem + CVP_PARAM_OFF + l_ps * CVP_PARAM_SLOT + wave * 1024);
+        }
+    };
+
+    if (!advance(l_vb)) return;  // whole workgroup leaves before any barrier
+    int buf = 0;
+    issue(0, 0);
+    issue_params();
+
+    float4v acc[MI][NI];
+    bool pending = false, more = true;
+    int e_n0 = 0, e_co0 = 0, e_ps = 0;
+    while (more) {
+        const int c_n0 = l_n0, c_co0 = l_co0, c_ps = l_ps;
+        for (int s = 0; s < nstages; ++s) {
+            wait_all_loads();
+            __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
+            if (s + 1 < nstages) {
+                issue(s + 1, buf ^ 1);
+            } else {
+                more = advance(l_vb + gridDim.x);
+                if (more) {
+                    l_ps = l_ps == 2 ? 0 : l_ps + 1;
+                    issue(0, buf ^ 1);
+                    issue_params();
+                }
+            }
+            if (s == 0) {
+                if (pending) persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            const char* wt = smem + buf * CVP_STAGE_BYTES;
+            mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+            buf ^= 1;
+        }
+        e_n0 = c_n0;
+        e_co0 = c_co0;
+        e_ps = c_ps;
+        pending = true;
+    }
+    persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
 }
 
 // Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
@@ -540,6 +735,28 @@ __global__ void pack_conv_weight_kernel(const float* w, int cout, int cin, int k
 int conv1d_cin_pad(int cin) { return (int)round_up(cin, CV_BK); }
 int conv1d_cout_pad(int cout) { return (int)round_up(cout, 32); }
 
+// Resident workgroups of the persistent kernel: one per CU (a multiple of 8 keeps  id mod 8 == XCD  across the walk).
+// MV_CONV_PERSIST_BLOCKS overrides it (tests walk several tiles per workgroup on small problems; 0 disables the kernel).
+static int persistent_blocks() {
+    static int n = -1;
+    if (n < 0) {
+        int v = 0;
+        if (const char* e = getenv("MV_CONV_PERSIST_BLOCKS")) {
+            v = atoi(e);
+        } else {
+#ifdef MV_EMU
+            v = 8;
+#else
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+#endif
+        }
+        n = v > 0 ? (int)round_up(v, 8) : 0;
+    }
+    return n;
+}
+
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w_packed != nullptr && d.y != nullptr, "conv1d: null tensor");
     MV_REQUIRE(d.B > 0 && d.T_in > 0 && d.T_out > 0 && d.cin > 0 && d.cout > 0 && d.k > 0, "conv1d: bad geometry");
@@ -615,6 +832,11 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
     const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    // persistent form of the 256^2 kernel: fp16 output through the wave-private staged epilogue
+    const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
+                         d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
+                         (d.pre_act == MV_ACT_NONE || d.pre_act == MV_ACT_RELU) &&
+                         (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) && persistent_blocks() > 0;
     const int tn = big ? 256 : CV_TN, tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
@@ -623,13 +845,18 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel, CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    if (big) {
+    if (persist) {
+        const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
+        const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
+        MV_LAUNCH(conv1d_glds_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+    } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
