@@ -5,9 +5,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd')]
 import torch
 from mvector import _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-fb = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80))
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 48000
+import ctypes
+cdll = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else None
+fb = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80), cdll=cdll)
 g = torch.Generator().manual_seed(1234)
-wav = (0.1 * torch.randn([B, 48000], generator=g)).clamp(-1, 1).cuda()
+wav = (0.1 * torch.randn([B, L], generator=g)).clamp(-1, 1).cuda()
 for _ in range(5):
     out = fb(wav)
 torch.cuda.synchronize()
@@ -19,5 +22,5 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
-print(json.dumps(dict(waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, us=round(us, 2),
-                      GBps=round(B * 287360 / us / 1e3, 1), frac_of_8TBps=round(B * 287360 / us / 1e3 / 8000, 4))))
+print(json.dumps(dict(lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, L=L, us=round(us, 2),
+                      GBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3, 1), frac_of_8TBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3 / 8000, 4))))

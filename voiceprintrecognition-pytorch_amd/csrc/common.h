@@ -54,6 +54,48 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 namespace mv {
 
+// DPP lane moves inside rows of 16 lanes (VALU, no LDS traffic).  CTRL is the hardware dpp_ctrl value:
+//   0x00..0xFF quad_perm, 0x110+n row_shr:n, 0x120+n row_ror:n, 0x140 row_mirror, 0x141 row_half_mirror.
+// Lanes without a source lane (row_shr) keep `old`.
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_ROR1 = 0x121, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+#ifdef MV_EMU
+template <int CTRL>
+inline float dpp_mov(float old, float src) {
+    const int lane = emu::flat_tid() & 63;
+    int from = lane;
+    bool has = true;
+    if (CTRL < 0x100) {
+        from = (lane & ~3) | ((CTRL >> (2 * (lane & 3))) & 3);
+    } else if (CTRL > 0x110 && CTRL < 0x120) {
+        has = (lane & 15) >= (CTRL - 0x110);
+        from = has ? lane - (CTRL - 0x110) : lane;
+    } else if (CTRL > 0x120 && CTRL < 0x130) {
+        from = (lane & ~15) | ((lane - (CTRL - 0x120)) & 15);
+    } else if (CTRL == 0x140) {
+        from = (lane & ~15) | (15 - (lane & 15));
+    } else if (CTRL == 0x141) {
+        from = (lane & ~7) | (7 - (lane & 7));
+    }
+    const float v = emu::shfl_from(src, from);
+    return has ? v : old;
+}
+#else
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                                 0xf, 0xf, false));
+}
+#endif
+
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);
+    v += dpp_mov<DPP_QUAD_XOR2>(0.0f, v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(0.0f, v);
+    v += dpp_mov<DPP_ROW_MIRROR>(0.0f, v);
+    return v;
+}
+
 // thread-local error string behind mv_last_error()
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

@@ -4,16 +4,21 @@
 // 119-132, torchaudio.compliance.kaldi.fbank) and the CMN / mask passes of AudioFeaturizer.forward
 // (featurizer.py:77-90).  Arithmetic follows oracle/frontend.py::kaldi_fbank.
 //
-// Mapping (wave64): one frame per 16 lanes, four frames per wave.  The 512-point real FFT of a
+// Mapping (wave64): one frame per 16 lanes (one DPP row), four frames per wave.  The 512-point real FFT of a
 // frame is a 256-point complex FFT of z[n] = x[2n] + i x[2n+1], computed as 16 x 16:
-//   stage 1  lane n2 holds z[16*n1 + n2], n1 = 0..15 (its samples are the float2 at 32*n1 + 2*n2,
-//            so a 16-lane group reads 128 contiguous bytes) and runs a radix-16 butterfly in registers;
-//   twiddle  W256^(n2*k1), per-lane constants kept in registers;
+//   load     lane n2 holds z[16*n1 + n2], n1 = 0..NG-1 (its samples are the float2 at 32*n1 + 2*n2, so a 16-lane
+//            group reads 128 contiguous bytes); groups beyond the window are compile-time zeros (NG = 13 for 25 ms);
+//   DC / pre-emphasis: the frame mean is a DPP row reduction, the previous sample comes from the neighbouring lane
+//            by a DPP row rotation -- no LDS traffic;
+//   stage 1  radix-16 butterfly in registers (zero inputs pruned), twiddle W256^(n2*k1) from an LDS table;
 //   transpose through a padded per-wave LDS tile (conflict-free both ways);
 //   stage 2  lane k1 runs the second radix-16 butterfly -> Z[k1 + 16*k2];
-//   real post-processing with the partner bin Z[256 - k] (LDS exchange), power spectrum to LDS;
-//   sparse triangular mel filters: lane n2 owns filters n2 + 16*i and walks only their non-zero
-//   bins (501 weights in total instead of a dense 257 x 80 product), log, store.
+//   real post-processing with the partner bin Z[256 - k] (LDS exchange), power spectrum back to the frame's slot;
+//   mel      on the matrix pipe, exact fp32: v_mfma_f32_4x4x1 runs 16 independent 4 x 4 outer products per issue
+//            = 16 blocks x (4 frames x 4 adjacent filters) x 1 FFT bin.  Every block walks only the bins its four
+//            triangles cover (the filterbank is banded: 80 filters need 28 + 44 steps instead of a 257 x 80 product),
+//            the weights come from an LDS table in operand order, the result lands as lane = filter, register =
+//            frame, so the log, the column sums for CMN and 256-byte row stores need no further shuffles.
 // One workgroup owns one utterance, so the per-utterance time mean is a workgroup reduction and the
 // second pass (subtract mean, apply the length mask) re-reads rows this CU has just written (L2 hits).
 #include "common.h"
@@ -23,31 +28,24 @@
 
 namespace mv {
 
-struct cplx {
-    float re, im;
-};
+// Complex values are float2 vectors {re, im}: sums, differences and twiddle products map onto the packed fp32 VALU ops
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, swaps and sign flips ride on their op_sel / neg modifiers).
+typedef float2v cplx;
 
-__device__ __forceinline__ cplx cmake(float r, float i) {
-    cplx c;
-    c.re = r;
-    c.im = i;
-    return c;
-}
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.re + b.re, a.im + b.im); }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmake(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cplx cmake(float r, float i) { return cplx{r, i}; }
+__device__ __forceinline__ cplx cswap(cplx a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cplx mul_mi(cplx a) { return cswap(a) * cplx{1.0f, -1.0f}; }  // a * (-i) = {im, -re}
 // a * (c - i s)
-__device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) {
-    return cmake(a.re * c + a.im * s, a.im * c - a.re * s);
-}
+__device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return a * cplx{c, c} + cswap(a) * cplx{s, -s}; }
 
 // multiply by W16^M = exp(-2 pi i M / 16), M compile-time
 template <int M>
 __device__ __forceinline__ cplx mul_w16(cplx a) {
     constexpr int m = M & 15;
     if constexpr (m == 0) return a;
-    if constexpr (m == 4) return cmake(a.im, -a.re);
-    if constexpr (m == 8) return cmake(-a.re, -a.im);
-    if constexpr (m == 12) return cmake(-a.im, a.re);
+    if constexpr (m == 4) return mul_mi(a);
+    if constexpr (m == 8) return -a;
+    if constexpr (m == 12) return -mul_mi(a);
     constexpr float C[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
                              -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f,
@@ -56,15 +54,17 @@ __device__ __forceinline__ cplx mul_w16(cplx a) {
                              1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
                              -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+    if constexpr (m == 2) return (a + mul_mi(a)) * cplx{C[2], C[2]};     // (1 - i) / sqrt 2
+    if constexpr (m == 6) return (mul_mi(a) - a) * cplx{C[2], C[2]};     // (-1 - i) / sqrt 2
     return cmul_conjtw(a, C[m], S[m]);
 }
 
 __device__ __forceinline__ void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
-    cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = csub(a1, a3);
-    a0 = cadd(t0, t2);
-    a2 = csub(t0, t2);
-    a1 = cmake(t1.re + t3.im, t1.im - t3.re);  // t1 - i t3
-    a3 = cmake(t1.re - t3.im, t1.im + t3.re);  // t1 + i t3
+    const cplx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = t1 + t3;  // t1 - i (a1 - a3)
+    a3 = t1 - t3;  // t1 + i (a1 - a3)
 }
 
 // forward 16-point DFT, natural order in and out:  X[k] = sum_n x[n] exp(-2 pi i n k / 16)
@@ -100,37 +100,23 @@ __device__ __forceinline__ void fft16(cplx (&x)[16]) {
     }
 }
 
-__device__ __forceinline__ void fb_glds16(const void* gsrc, char* lds_wave_base) {
-#ifdef MV_EMU
-    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
-#else
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#endif
-}
-
-__device__ __forceinline__ void fb_wait_loads() {
-#ifndef MV_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-
 constexpr int FB_NFFT = 512;
-constexpr int FB_MAX_WAVES = 16;          // waves per workgroup: 8, 12 or 16 (template parameter WAVES)
-constexpr int FB_TSTRIDE = 17;            // padded row of the 16x16 transpose tile (complex elements)
-constexpr int FB_SLOT_CPLX = 16 * FB_TSTRIDE;  // 272 complex = 2176 B per frame slot (>= 256 complex)
-constexpr int FB_MAX_ROUNDS = 8;          // filters per lane: num_mel_bins <= 128
+constexpr int FB_TSTRIDE = 17;        // padded row of the 16x16 transpose tile (complex elements)
+constexpr int FB_SLOT_FLOATS = 548;   // per-frame LDS slot: 16*17 complex = 544 floats, padded so the four frame rows of a
+                                      // wave start 36 banks apart (conflict-free 16-byte operand reads of the mel stage)
+constexpr int FB_MAX_PASSES = 2;      // 16 blocks x 4 filters per MFMA pass: num_mel_bins <= 128
 
 struct FbankTables {
     const float* window;    // [512] window, zero beyond the frame length
     const float* tw256;     // [16 k1][16 n2][2] cos, sin of 2 pi n2 k1 / 256 (lane-contiguous)
     const float* tw512;     // [256][2] cos, sin of 2 pi k / 512
-    const float* melw;      // [sum_i width_i][16] filter weights, round-major
-    const int* mel_start;   // [rounds*16] first FFT bin of each filter
-    int melw_elems;
-    int rounds;
-    int round_width[FB_MAX_ROUNDS];
-    int round_off[FB_MAX_ROUNDS];
+    const float* melb;      // [steps/4][64 lanes][4] mel weights in MFMA B-operand order, passes back to back
+    int melb_elems;
+    int passes;
+    int pass_steps[FB_MAX_PASSES];        // bins walked per pass (multiple of 4)
+    int pass_split[FB_MAX_PASSES];        // 1, 2 or 4 adjacent blocks share one filter group (each walks a part of its bins)
+    int pass_gbase[FB_MAX_PASSES];        // first filter group (4 filters) of the pass
+    int pass_start[FB_MAX_PASSES][16];    // first bin of each block (multiple of 4, start + steps <= 256)
 };
 
 struct FbankArgs {
@@ -143,33 +129,54 @@ struct FbankArgs {
     float preemph;
     float inv_win;
     int remove_dc, use_power, use_log, cmn;
-    int vec2_ok;
-    int load_mode;  // 0 scalar, 1 float2, 2 LDS-DMA prefetch
     int64_t L;
     FbankTables tab;
 };
 
-// ROUNDS = ceil(num_mel_bins / 16): filters per lane (compile-time so the per-lane state stays in registers)
-// MODE: 0 scalar global loads, 1 float2 global loads, 2 = the quad's samples are prefetched by LDS-DMA one iteration ahead
-template <int ROUNDS, int MODE, int FB_WAVES>
+#ifdef MV_EMU
+inline float fb_log2(float x) { return log2f(x); }
+#else
+__device__ __forceinline__ float fb_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32, normal inputs only
+#endif
+
+#ifdef MV_EMU
+inline float4v fb_mfma4(float a, float b, float4v c) {  // D[lane][r] += A[4*(lane/4) + r] * B[lane]
+    const int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 4);
+    emu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        float av;
+        memcpy(&av, emu::wave_slot(0, (lane & ~3) + r), 4);
+        c[r] = fmaf(av, b, c[r]);
+    }
+    emu::wave_sync();
+    return c;
+}
+#else
+__device__ __forceinline__ float4v fb_mfma4(float a, float b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+// NG = groups of 32 samples that cover the window (13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512);
+// VEC2: rows and frames start on 8-byte boundaries, samples are fetched as float2
+template <int NG, bool VEC2, int FB_WAVES>
 __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     constexpr int FB_THREADS = FB_WAVES * 64;
     MV_DYN_SMEM(smem);
-    // carve (every offset but the last is a compile-time constant, so LDS accesses are base + immediate):
-    // per-wave exchange tiles | tw512 | window | stage twiddles | column sums + mean | mel_start | mel weights
-    cplx* xbuf = reinterpret_cast<cplx*>(smem);                                   // [FB_WAVES*4][FB_SLOT_CPLX]
-    float* tw512 = reinterpret_cast<float*>(xbuf + FB_WAVES * 4 * FB_SLOT_CPLX);  // [512]
-    float* lwin = tw512 + 512;                                                    // [512] window taps
-    float* ltw = lwin + 512;                                                      // [16][16][2] stage twiddles
-    float* colsum = ltw + 512;                                                    // [FB_WAVES][128] then mean[128]
-    int* mstart = reinterpret_cast<int*>(colsum + (FB_WAVES + 1) * 128);          // [FB_MAX_ROUNDS*16]
-    float* melw = reinterpret_cast<float*>(mstart + FB_MAX_ROUNDS * 16);          // [melw_elems]
-    float* sring = melw + a.tab.melw_elems;                                       // MODE 2: [FB_WAVES][2][1024] samples
+    // carve (compile-time offsets): per-frame slots | tw512 | window | stage twiddles | mel weights; the column sums of
+    // the CMN epilogue reuse the slot area
+    float* xbuf = reinterpret_cast<float*>(smem);                   // [FB_WAVES*4][FB_SLOT_FLOATS]
+    float* tw512 = xbuf + FB_WAVES * 4 * FB_SLOT_FLOATS;            // [512]
+    float* lwin = tw512 + 512;                                      // [512] window taps
+    float* ltw = lwin + 512;                                        // [16][16][2] stage twiddles
+    float* melb = ltw + 512;                                        // [melb_elems]
+    float* colsum = xbuf;                                           // [FB_WAVES][128] then mean[128], after the frame loop
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2, filter lane in the mel stage
+    const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fs = lane >> 4;    // frame slot inside the wave
     const int b = blockIdx.x;
     const int T = a.T;
@@ -180,123 +187,114 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         lwin[i] = a.tab.window[i];
         ltw[i] = a.tab.tw256[i];
     }
-    for (int i = tid; i < a.tab.melw_elems; i += FB_THREADS) melw[i] = a.tab.melw[i];
-    for (int i = tid; i < a.tab.rounds * 16; i += FB_THREADS) mstart[i] = a.tab.mel_start[i];
-    for (int i = tid; i < FB_WAVES * 128; i += FB_THREADS) colsum[i] = 0.0f;
-
+    for (int i = tid * 4; i < a.tab.melb_elems; i += FB_THREADS * 4)
+        *reinterpret_cast<float4v*>(melb + i) = *reinterpret_cast<const float4v*>(a.tab.melb + i);
     __syncthreads();
 
-    cplx* slot = xbuf + (wave * 4 + fs) * FB_SLOT_CPLX;
-    float* pslot = reinterpret_cast<float*>(slot);
+    float* wslots = xbuf + wave * 4 * FB_SLOT_FLOATS;
+    float* pslot = wslots + fs * FB_SLOT_FLOATS;
+    cplx* slot = reinterpret_cast<cplx*>(pslot);
     const float* wrow = a.wav + (int64_t)b * a.wav_stride;
     float* orow = a.out + (int64_t)b * T * nbins;
 
-    float csum[ROUNDS];
+    // mel stage: this lane is (block = lane/4, j = lane%4): A operand = power of frame j, D = filter 4*(16*pass + block) + j
+    const float* arow = wslots + (lane & 3) * FB_SLOT_FLOATS;
+    int mstart[FB_MAX_PASSES];
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) csum[i] = 0.0f;
+    for (int p = 0; p < FB_MAX_PASSES; ++p) mstart[p] = a.tab.pass_start[p][lane >> 2];
+    float csum[FB_MAX_PASSES];
+#pragma unroll
+    for (int p = 0; p < FB_MAX_PASSES; ++p) csum[p] = 0.0f;
 
     const int nquads = (T + 3) >> 2;
-    // MODE 2: the 3*shift + win (<= 1024) samples of a quad of frames are contiguous; the wave copies them global -> LDS with
-    // four 1 KiB DMA transfers, one iteration ahead of their use (each sample is fetched once instead of 2.5 times).
-    float* swave = sring + wave * 2048;
-    auto prefetch_quad = [&](int q, int buf) {
-        const int64_t first = (int64_t)q * 4 * a.shift;
-        const int64_t last_ok = a.L - 4 - first;  // largest in-row start of a 4-float transfer, relative to `first`
+    // load: lane holds samples 32*n1 + 2*l16 (+1) and, for the pre-emphasis, the sample before them (one more 4-byte load
+    // that hits the lines just fetched; d[-1] := d[0]).  A group that reaches beyond the window has its indices clamped
+    // (the row may end with the frame) and the surplus values zeroed.
+    auto load_quad = [&](int q, cplx (&e)[NG], float (&eprev)[NG]) {
+        const int f_raw = q * 4 + fs;
+        const int f = f_raw < T ? f_raw : T - 1;  // surplus slots recompute the last frame; nothing of theirs is kept
+        const float* fp = wrow + (int64_t)f * a.shift;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t off = i * 256 + lane * 4;
-            off = off < last_ok ? off : last_ok;  // clamped lanes land on samples no valid frame of this quad reads
-            fb_glds16(wrow + first + off, reinterpret_cast<char*>(swave + buf * 1024 + i * 256));
+        for (int n1 = 0; n1 < NG; ++n1) {
+            const int idx = 32 * n1 + 2 * l16;
+            // NG == 13 is only launched for 384 < win <= 416: groups 0..11 are full at compile time
+            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            if (full) {
+                if (VEC2) {
+                    e[n1] = *reinterpret_cast<const float2v*>(fp + idx);
+                } else {
+                    e[n1] = cmake(fp[idx], fp[idx + 1]);
+                }
+                eprev[n1] = fp[n1 == 0 ? (idx > 0 ? idx - 1 : 0) : idx - 1];
+            } else {
+                const int i0 = idx < a.win ? idx : a.win - 1, i1 = idx + 1 < a.win ? idx + 1 : a.win - 1;
+                cplx v;
+                if (VEC2) {  // win is even: idx < win implies idx + 1 < win
+                    v = *reinterpret_cast<const float2v*>(fp + (idx < a.win ? idx : a.win - 2));
+                } else {
+                    v = cmake(fp[i0], fp[i1]);
+                }
+                e[n1] = v;  // surplus values are zeroed by mask_tail() when the group is consumed
+                eprev[n1] = fp[i0 > 0 ? i0 - 1 : 0];
+            }
         }
     };
-    if (MODE == 2 && wave < nquads) prefetch_quad(wave, 0);
-    int ring = 0;
-    for (int q = wave; q < nquads; q += FB_WAVES) {
-        const int f_raw = q * 4 + fs;
-        const bool fvalid = f_raw < T;
-        const int f = fvalid ? f_raw : T - 1;
-        const float* fp;
-        if (MODE == 2) {
-            fb_wait_loads();   // this quad's transfers (issued one iteration ago) have landed
-            MV_WAVE_FENCE();
-            fp = swave + ring * 1024 + (f - q * 4) * a.shift;
-            if (q + FB_WAVES < nquads) prefetch_quad(q + FB_WAVES, ring ^ 1);
-            ring ^= 1;
-        } else {
-            fp = wrow + (int64_t)f * a.shift;
-        }
 
-        // ---- load the frame: lane holds samples 32*n1 + 2*l16 (+1).  Branch-free: indices beyond the frame are
-        // clamped to a valid address and the value is zeroed by a select, so all 16 loads are in flight together ----
-        float e0[16], e1[16];
-        float s = 0.0f;
-        const int n1_full = a.win >> 5;  // groups of 32 samples that lie entirely inside the frame (uniform)
+    auto mask_tail = [&](cplx (&e)[NG]) {  // kept apart from the loads: a select right behind a prefetch would wait for it
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            float v0 = 0.0f, v1 = 0.0f;
-            if (n1 < n1_full) {  // plain base + constant offset: nothing per-lane to keep alive across iterations
-                if (MODE >= 1) {
-                    const float2v v = *reinterpret_cast<const float2v*>(fp + 32 * n1 + 2 * l16);
-                    v0 = v[0];
-                    v1 = v[1];
-                } else {
-                    v0 = fp[32 * n1 + 2 * l16];
-                    v1 = fp[32 * n1 + 2 * l16 + 1];
-                }
-            }
-            e0[n1] = v0;
-            e1[n1] = v1;
+        for (int n1 = 0; n1 < NG; ++n1) {
+            const int idx = 32 * n1 + 2 * l16;
+            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            if (!full) e[n1] = cmake(idx < a.win ? e[n1][0] : 0.0f, idx + 1 < a.win ? e[n1][1] : 0.0f);
         }
-        {   // the one group that straddles the end of the frame (none when win is a multiple of 32): clamp + select
-            const int idx = 32 * n1_full + 2 * l16;
-            float p0 = 0.0f, p1 = 0.0f;
-            if (32 * n1_full < a.win) {
-                p0 = fp[idx < a.win ? idx : a.win - 1];
-                p1 = fp[idx + 1 < a.win ? idx + 1 : a.win - 1];
-                p0 = idx < a.win ? p0 : 0.0f;
-                p1 = idx + 1 < a.win ? p1 : 0.0f;
-            }
+    };
+
+    // PREFETCH (workgroups of <= 12 waves, 170 VGPRs): the next quad's samples are requested before this quad is
+    // processed, so their latency hides under ~800 VALU instructions instead of stalling the top of every iteration
+    constexpr bool PREFETCH = FB_WAVES <= 12;
+    cplx enext[NG];
+    float epnext[NG];
+    if (PREFETCH && wave < nquads) load_quad(wave, enext, epnext);
+    for (int q = wave; q < nquads; q += FB_WAVES) {
+        cplx e[NG];
+        float eprev[NG];
+        if (PREFETCH) {
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                e0[n1] = n1 == n1_full ? p0 : e0[n1];
-                e1[n1] = n1 == n1_full ? p1 : e1[n1];
-                s += e0[n1] + e1[n1];
+            for (int n1 = 0; n1 < NG; ++n1) {
+                e[n1] = enext[n1];
+                eprev[n1] = epnext[n1];
             }
+            if (q + FB_WAVES < nquads) load_quad(q + FB_WAVES, enext, epnext);
+        } else {
+#if defined(MV_PROBE) && MV_PROBE == 3   // timing probe: samples from LDS instead of global memory
+#pragma unroll
+            for (int n1 = 0; n1 < NG; ++n1) {
+                e[n1] = *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16 + (q & 1));
+                eprev[n1] = lwin[32 * n1 + 2 * l16 + 3];
+            }
+#else
+            load_quad(q, e, eprev);
+#endif
         }
-        // ---- remove DC (frame mean over the `win` samples) ----
+        mask_tail(e);
+        // ---- DC removal (frame mean over the `win` samples), pre-emphasis y[j] = d[j] - c d[j-1] and window:
+        //      (x[j] - mu) - c (x[j-1] - mu) = x[j] - c x[j-1] - (1 - c) mu.  Taps beyond the window meet a zero weight ----
+        float dc = 0.0f;
         if (a.remove_dc) {
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 8);
-            const float mu = s * a.inv_win;
+            cplx s2 = cmake(0.0f, 0.0f);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int idx = 32 * n1 + 2 * l16;
-                e0[n1] = (idx < a.win) ? e0[n1] - mu : 0.0f;
-                e1[n1] = (idx + 1 < a.win) ? e1[n1] - mu : 0.0f;
-            }
+            for (int n1 = 0; n1 < NG; ++n1) s2 += e[n1];
+            dc = row16_sum(s2[0] + s2[1]) * a.inv_win * (1.0f - a.preemph);
         }
-        // ---- pre-emphasis y[j] = d[j] - c d[j-1], d[-1] := d[0]; then window ----
         cplx z[16];
-        {
-            const int src = (lane & 48) | ((l16 + 15) & 15);  // previous lane of the 16-lane group (rotating)
-            float rprev = 0.0f;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const float r = __shfl(e1[n1], src);
-                float prev;
-                if (l16 == 0)
-                    prev = (n1 == 0) ? e0[0] : rprev;
-                else
-                    prev = r;
-                rprev = r;
-                const float y0 = e0[n1] - a.preemph * prev;
-                const float y1 = e1[n1] - a.preemph * e0[n1];
-                const float2v w2 = *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16);
-                z[n1] = cmake(y0 * w2[0], y1 * w2[1]);
-            }
+        for (int n1 = 0; n1 < NG; ++n1) {
+            const cplx prev = cmake(eprev[n1], e[n1][0]);
+            const cplx y = e[n1] - prev * cplx{a.preemph, a.preemph} - cplx{dc, dc};
+            z[n1] = y * *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16);
         }
+#pragma unroll
+        for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
         // ---- stage 1: radix-16 over n1, twiddle by W256^(n2*k1) ----
         fft16(z);
 #pragma unroll
@@ -312,8 +310,10 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         for (int n2 = 0; n2 < 16; ++n2) z[n2] = slot[l16 * FB_TSTRIDE + n2];
         MV_WAVE_FENCE();
         // ---- stage 2: radix-16 over n2 -> Z[l16 + 16*k2] ----
+#if !defined(MV_PROBE) || MV_PROBE != 4   // timing probe 4: no second butterfly
         fft16(z);
-        // ---- real-input post-processing: X[k] from Z[k] and Z[256-k] ----
+#endif
+        // ---- real-input post-processing: X[k] from Z[k] and Z[256-k]; |X|^2 = (|2X|^2) / 4 ----
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) slot[l16 + 16 * k2] = z[k2];
         if (l16 == 0) slot[256] = z[0];  // Z[256] == Z[0]: the partner index 256 - k then needs no wrap-around
@@ -323,78 +323,94 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         for (int k2 = 0; k2 < 16; ++k2) {
             const int k = l16 + 16 * k2;
             const cplx zp = slot[256 - k];
-            const float c = tw512[2 * k], sn = tw512[2 * k + 1];
-            const float ar = z[k2].re + zp.re, ai = z[k2].im - zp.im;
-            const float br = z[k2].re - zp.re, bi = z[k2].im + zp.im;
-            const float xr = 0.5f * (ar + c * bi - sn * br);
-            const float xi = 0.5f * (ai - c * br - sn * bi);
-            const float p = xr * xr + xi * xi;
-            pw[k2] = a.use_power ? p : sqrtf(p);
+            const cplx cs = *reinterpret_cast<const float2v*>(tw512 + 2 * k);
+            const cplx za = z[k2] + zp * cplx{1.0f, -1.0f};  // Z[k] + conj(Z[256-k])
+            const cplx zb = z[k2] - zp * cplx{1.0f, -1.0f};  // Z[k] - conj(Z[256-k])
+            // 2 X[k] = za - i (c - i s) zb
+            const cplx x2 = za + cswap(zb) * cplx{cs[0], -cs[0]} - zb * cplx{cs[1], cs[1]};
+            const cplx sq = x2 * x2;
+            pw[k2] = 0.25f * (sq[0] + sq[1]);
+        }
+        if (!a.use_power) {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) pw[k2] = sqrtf(pw[k2]);
         }
         MV_WAVE_FENCE();
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) pslot[l16 + 16 * k2] = pw[k2];
         MV_WAVE_FENCE();
-        // ---- sparse mel filters: lane l16 owns filters l16 + 16*i ----
-        float vals[ROUNDS];
+        // ---- mel filters on the matrix pipe + log + row stores ----
+        const int frames_here = (q * 4 + 4 <= T) ? 4 : T - q * 4;
+        int moff = 0;
 #pragma unroll
-        for (int i = 0; i < ROUNDS; ++i) {
-            {
-                const int m = l16 + 16 * i;
-                const int st = mstart[m];
-                const float* wr = melw + a.tab.round_off[i] * 16 + l16;
-                float acc = 0.0f;
-                const int width = a.tab.round_width[i];  // multiple of 4 (zero-weight padding)
-                for (int j = 0; j < width; j += 4) {
-                    float wv[4], pv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int kk = st + j + u;
-                        kk = kk > 255 ? 255 : kk;
-                        wv[u] = wr[(j + u) * 16];
-                        pv[u] = pslot[kk];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc += wv[u] * pv[u];
+        for (int p = 0; p < FB_MAX_PASSES; ++p) {
+            if (p < a.tab.passes) {
+                float4v acc = float4v{0.0f, 0.0f, 0.0f, 0.0f}, acc2 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+                const int ngrp = a.tab.pass_steps[p] >> 2;
+                const float* ap = arow + mstart[p];
+                const float* bp = melb + moff * 64 + lane * 4;
+#if defined(MV_PROBE) && MV_PROBE == 1   // timing probe (tools/probe only): no mel loop
+                for (int g = 0; g < 0; ++g) {
+#else
+                for (int g = 0; g < ngrp; ++g) {
+#endif
+                    const float4v av = *reinterpret_cast<const float4v*>(ap + 4 * g);
+                    const float4v bv = *reinterpret_cast<const float4v*>(bp + g * 256);
+                    acc = fb_mfma4(av[0], bv[0], acc);
+                    acc2 = fb_mfma4(av[1], bv[1], acc2);
+                    acc = fb_mfma4(av[2], bv[2], acc);
+                    acc2 = fb_mfma4(av[3], bv[3], acc2);
                 }
-                float val = acc;
-                if (a.use_log) val = logf(fmaxf(acc, 1.1920928955078125e-07f));
-                vals[i] = val;
-                if (fvalid && m < nbins) csum[i] += val;
-            }
-        }
-        // ---- the quad's four rows are contiguous in the output: stage them in LDS, store 16 bytes per lane ----
-        MV_WAVE_FENCE();  // every lane of the wave is done reading the power spectra
-        {
-            float* stage = reinterpret_cast<float*>(xbuf + (wave * 4) * FB_SLOT_CPLX);  // [4][nbins]
+                acc += acc2;
+                moff += a.tab.pass_steps[p];
+                // blocks that share a filter group hold partial sums over disjoint bin ranges: add them up
+                const int split = a.tab.pass_split[p];
+                if (split >= 2) {
 #pragma unroll
-            for (int i = 0; i < ROUNDS; ++i) {
-                const int m = l16 + 16 * i;
-                if (m < nbins) stage[fs * nbins + m] = vals[i];
-            }
-            MV_WAVE_FENCE();
-            const int frames_here = (q * 4 + 4 <= T) ? 4 : T - q * 4;
-            const int nfloat = frames_here * nbins;
-            float* dst = orow + (int64_t)q * 4 * nbins;
-            if ((nbins & 3) == 0) {
-                for (int e = lane * 4; e < nfloat; e += 256)
-                    *reinterpret_cast<float4v*>(dst + e) = *reinterpret_cast<const float4v*>(stage + e);
-            } else {
-                for (int e = lane; e < nfloat; e += 64) dst[e] = stage[e];
+                    for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 4);
+                }
+                if (split == 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += __shfl_xor(acc[r], 8);
+                }
+                const int blk = lane >> 2;
+                const int m = 4 * (a.tab.pass_gbase[p] + blk / split) + (lane & 3);  // filter of this lane
+                if (m < nbins && (blk & (split - 1)) == 0) {
+                    float val[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)  // the clamp keeps the argument normal: one v_log_f32 (log2) and a scale
+                        val[r] = a.use_log ? fb_log2(fmaxf(acc[r], 1.1920928955078125e-07f)) * 0.69314718055994531f : acc[r];
+                    float* dst = orow + (int64_t)q * 4 * nbins + m;
+#if defined(MV_PROBE) && MV_PROBE == 2   // timing probe: (almost) no stores
+                    if (val[0] != 12345.0f) continue;
+#endif
+                    if (frames_here == 4) {
+                        csum[p] += (val[0] + val[1]) + (val[2] + val[3]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r * nbins] = val[r];
+                    } else {
+                        for (int r = 0; r < frames_here; ++r) {
+                            csum[p] += val[r];
+                            dst[r * nbins] = val[r];
+                        }
+                    }
+                }
             }
         }
-        MV_WAVE_FENCE();
+        MV_WAVE_FENCE();  // the power spectra have been consumed before the next quad's transposes overwrite them
     }
 
     if (!a.cmn && a.lens_ratio == nullptr) return;
 
-    // ---- per-utterance time mean (featurizer.py:79): reduce over frame slots, then over waves ----
+    // ---- per-utterance time mean (featurizer.py:79): lane = filter already, reduce over waves ----
+    __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        float v = csum[i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (fs == 0) colsum[wave * 128 + l16 + 16 * i] = v;
+    for (int p = 0; p < FB_MAX_PASSES; ++p) {
+        if (p < a.tab.passes) {
+            const int split = a.tab.pass_split[p], blk = lane >> 2;
+            const int m = 4 * (a.tab.pass_gbase[p] + blk / split) + (lane & 3);
+            if (m < 128 && (blk & (split - 1)) == 0) colsum[wave * 128 + m] = csum[p];  // every filter has exactly one owner lane
+        }
     }
     __syncthreads();
     float* mean = colsum + FB_WAVES * 128;
@@ -442,11 +458,10 @@ struct MvFbank {
     float* d_window = nullptr;
     float* d_tw256 = nullptr;
     float* d_tw512 = nullptr;
-    float* d_melw = nullptr;
-    int* d_mel_start = nullptr;
+    float* d_melb = nullptr;
     mv::FbankTables tab;
     size_t smem_bytes = 0;
-    int waves = 8;   // workgroup size in waves; 8 measured fastest (16 spills).  Tuning knob: MV_FBANK_WAVES = 8 | 12 | 16
+    int waves = 15;  // workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
 };
 
 namespace {
@@ -484,38 +499,39 @@ int upload(const std::vector<T>& v, T** dptr) {
 
 }  // namespace
 
-template <int R, int W>
-hipError_t fbank_set_smem_w(size_t bytes) {
-    hipError_t e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, 2, W>), bytes);
-    if (e != hipSuccess) return e;
-    e = MV_SET_MAX_SMEM((mv::fbank_kernel<R, 1, W>), bytes);
-    if (e != hipSuccess) return e;
-    return MV_SET_MAX_SMEM((mv::fbank_kernel<R, 0, W>), bytes);
+template <int NG, bool V>
+hipError_t fbank_set_smem_v(size_t bytes) {
+    hipError_t e = MV_SET_MAX_SMEM((mv::fbank_kernel<NG, V, 8>), bytes);
+    if (e == hipSuccess) e = MV_SET_MAX_SMEM((mv::fbank_kernel<NG, V, 12>), bytes);
+    if (e == hipSuccess) e = MV_SET_MAX_SMEM((mv::fbank_kernel<NG, V, 15>), bytes);
+    return e;
 }
 
-template <int R>
-hipError_t fbank_set_smem(size_t bytes, int waves) {
-    if (waves == 8) return fbank_set_smem_w<R, 8>(bytes);
-    if (waves == 12) return fbank_set_smem_w<R, 12>(bytes);
-    return fbank_set_smem_w<R, 16>(bytes);
+hipError_t fbank_set_smem(size_t bytes) {
+    hipError_t e = fbank_set_smem_v<13, true>(bytes);
+    if (e == hipSuccess) e = fbank_set_smem_v<13, false>(bytes);
+    if (e == hipSuccess) e = fbank_set_smem_v<16, true>(bytes);
+    if (e == hipSuccess) e = fbank_set_smem_v<16, false>(bytes);
+    return e;
 }
 
-template <int R, int W>
-void fbank_launch_w(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a) {
-    if (a.load_mode == 2) {
-        MV_LAUNCH((mv::fbank_kernel<R, 2, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
-    } else if (a.load_mode == 1) {
-        MV_LAUNCH((mv::fbank_kernel<R, 1, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+template <int NG, bool V>
+void fbank_launch_v(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, int waves) {
+    if (waves == 15) {
+        MV_LAUNCH((mv::fbank_kernel<NG, V, 15>), (B, 1, 1), (15 * 64, 1, 1), smem, st, a);
+    } else if (waves == 12) {
+        MV_LAUNCH((mv::fbank_kernel<NG, V, 12>), (B, 1, 1), (12 * 64, 1, 1), smem, st, a);
     } else {
-        MV_LAUNCH((mv::fbank_kernel<R, 0, W>), (B, 1, 1), (W * 64, 1, 1), smem, st, a);
+        MV_LAUNCH((mv::fbank_kernel<NG, V, 8>), (B, 1, 1), (8 * 64, 1, 1), smem, st, a);
     }
 }
 
-template <int R>
-void fbank_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, int waves) {
-    if (waves == 8) return fbank_launch_w<R, 8>(B, smem, st, a);
-    if (waves == 12) return fbank_launch_w<R, 12>(B, smem, st, a);
-    return fbank_launch_w<R, 16>(B, smem, st, a);
+void fbank_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, int waves, bool vec2) {
+    const bool ng13 = a.win > 12 * 32 && a.win <= 13 * 32;
+    if (ng13 && vec2) return fbank_launch_v<13, true>(B, smem, st, a, waves);
+    if (ng13) return fbank_launch_v<13, false>(B, smem, st, a, waves);
+    if (vec2) return fbank_launch_v<16, true>(B, smem, st, a, waves);
+    return fbank_launch_v<16, false>(B, smem, st, a, waves);
 }
 
 extern "C" {
@@ -539,7 +555,7 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     const int win = (int)(cfg->sample_frequency * cfg->frame_length_ms * 0.001f);
     const int shift = (int)(cfg->sample_frequency * cfg->frame_shift_ms * 0.001f);
     MV_REQUIRE(shift >= 1, "mv_fbank_create: frame shift must be at least one sample");
-    MV_REQUIRE(cfg->num_mel_bins >= 1 && cfg->num_mel_bins <= 16 * mv::FB_MAX_ROUNDS,
+    MV_REQUIRE(cfg->num_mel_bins >= 1 && cfg->num_mel_bins <= 64 * mv::FB_MAX_PASSES,
                "mv_fbank_create: num_mel_bins must be in [1, 128]");
     if (win <= mv::FB_NFFT / 2 || win > mv::FB_NFFT)
         return mv::fail(MV_ERR_UNSUPPORTED,
@@ -566,72 +582,109 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         tw512[2 * m + 1] = (float)sin(2.0 * pi * m / 512.0);
     }
     auto banks = kaldi_mel_banks(h->nbins, mv::FB_NFFT, cfg->sample_frequency, cfg->low_freq, cfg->high_freq);
-    const int rounds = (h->nbins + 15) / 16;
-    std::vector<int> start(rounds * 16, 0), width(rounds * 16, 0);
-    for (int m = 0; m < h->nbins; ++m) {
-        int lo = -1, hi = -1;
-        for (int k = 0; k < 256; ++k)
-            if (banks[m][k] > 0.0f) {
-                if (lo < 0) lo = k;
-                hi = k;
-            }
-        if (lo >= 0) {
-            start[m] = lo;
-            width[m] = hi - lo + 1;
-        }
-    }
+    // Mel stage tables.  One MFMA pass = 16 blocks x (4 frames x 4 adjacent filters); every block walks `steps` consecutive
+    // bins from its own start (a multiple of 4, so operands are 16-byte LDS reads; start + steps <= 256 keeps the walk inside
+    // the row).  A pass with <= 8 (<= 4) filter groups gives each group 2 (4) adjacent blocks that split its bin range: the
+    // wide high-frequency triangles then cost a quarter of the steps and the kernel adds the partial sums across lanes.
+    const int groups = (h->nbins + 3) / 4;
     mv::FbankTables& tab = h->tab;
-    tab.rounds = rounds;
-    int off = 0;
-    for (int i = 0; i < mv::FB_MAX_ROUNDS; ++i) {
-        tab.round_width[i] = 0;
-        tab.round_off[i] = off;
-        if (i < rounds) {
-            int w = 0;
-            for (int l = 0; l < 16; ++l) w = width[i * 16 + l] > w ? width[i * 16 + l] : w;
-            w = (w + 3) & ~3;  // the kernel walks the weights four at a time
-            tab.round_width[i] = w;
-            off += w;
+    tab.passes = 0;
+    std::vector<int> clo(groups, 0), cnum(groups, 0);  // first 4-bin chunk and number of chunks of each group
+    for (int g = 0; g < groups; ++g) {
+        int lo = 256, hi = -1;
+        for (int m = 4 * g; m < 4 * g + 4 && m < h->nbins; ++m)
+            for (int k = 0; k < 256; ++k)
+                if (banks[m][k] > 0.0f) {
+                    lo = k < lo ? k : lo;
+                    hi = k > hi ? k : hi;
+                }
+        if (hi >= 0) {
+            clo[g] = lo >> 2;
+            cnum[g] = (hi >> 2) - (lo >> 2) + 1;
         }
     }
-    std::vector<float> melw((size_t)(off > 0 ? off : 1) * 16, 0.0f);
-    for (int i = 0; i < rounds; ++i)
-        for (int l = 0; l < 16; ++l) {
-            const int m = i * 16 + l;
-            if (m >= h->nbins) continue;
-            for (int j = 0; j < width[m]; ++j) melw[(size_t)(tab.round_off[i] + j) * 16 + l] = banks[m][start[m] + j];
+    int total_steps = 0;
+    std::vector<int> seg_first[mv::FB_MAX_PASSES];  // first chunk of each block's segment
+    for (int p = 0, g0 = 0; p < mv::FB_MAX_PASSES; ++p) {
+        tab.pass_steps[p] = 0;
+        tab.pass_split[p] = 1;
+        tab.pass_gbase[p] = g0;
+        for (int blk = 0; blk < 16; ++blk) tab.pass_start[p][blk] = 0;
+        if (g0 >= groups) continue;
+        const int left = groups - g0;
+        // the last pass spreads its few groups over all 16 blocks; a full pass takes the next 16 groups
+        const int split = left <= 4 ? 4 : (left <= 8 ? 2 : 1);
+        const int ng = left < 16 / split ? left : 16 / split;
+        int seg_chunks = 1;
+        for (int g = g0; g < g0 + ng; ++g) {
+            const int per = (cnum[g] + split - 1) / split;
+            seg_chunks = per > seg_chunks ? per : seg_chunks;
         }
-    tab.melw_elems = (int)melw.size();
+        const int steps = 4 * seg_chunks;
+        tab.pass_steps[p] = steps;
+        tab.pass_split[p] = split;
+        seg_first[p].assign(16, -1);
+        for (int blk = 0; blk < ng * split; ++blk) {
+            const int g = g0 + blk / split, sidx = blk % split;
+            const int per = (cnum[g] + split - 1) / split;
+            const int first = clo[g] + sidx * per;                     // chunks [first, first + per) of the group
+            const int last = clo[g] + cnum[g];
+            if (first >= last) continue;                                // nothing left for this block: all-zero weights
+            seg_first[p][blk] = first;
+            int st = 4 * first;
+            if (st + steps > 256) st = 256 - steps;
+            tab.pass_start[p][blk] = st;
+        }
+        total_steps += steps;
+        g0 += ng;
+        tab.passes = p + 1;
+        if (p + 1 == mv::FB_MAX_PASSES && g0 < groups) {
+            delete h;
+            return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: num_mel_bins needs more than two MFMA passes");
+        }
+    }
+    std::vector<float> melb((size_t)total_steps * 64, 0.0f);  // [step / 4][lane][step % 4]
+    for (int p = 0, off = 0; p < tab.passes; off += tab.pass_steps[p], ++p) {
+        const int split = tab.pass_split[p];
+        for (int ln = 0; ln < 64; ++ln) {
+            const int blk = ln >> 2;
+            if (seg_first[p][blk] < 0) continue;
+            const int g = tab.pass_gbase[p] + blk / split;
+            const int m = 4 * g + (ln & 3);
+            if (m >= h->nbins) continue;
+            const int per = (cnum[g] + split - 1) / split;
+            const int k_lo = 4 * seg_first[p][blk], k_hi = 4 * (seg_first[p][blk] + per);  // bins owned by this block
+            for (int sidx = 0; sidx < tab.pass_steps[p]; ++sidx) {
+                const int k = tab.pass_start[p][blk] + sidx;
+                if (k >= k_lo && k < k_hi && k < 256)
+                    melb[((size_t)((off + sidx) >> 2) * 64 + ln) * 4 + (sidx & 3)] = banks[m][k];
+            }
+        }
+    }
+    tab.melb_elems = (int)melb.size();
     int rc;
     if ((rc = upload(window, &h->d_window)) || (rc = upload(tw256, &h->d_tw256)) || (rc = upload(tw512, &h->d_tw512)) ||
-        (rc = upload(melw, &h->d_melw)) || (rc = upload(start, &h->d_mel_start))) {
+        (rc = upload(melb, &h->d_melb))) {
         mv_fbank_destroy(h);
         return rc;
     }
     tab.window = h->d_window;
     tab.tw256 = h->d_tw256;
     tab.tw512 = h->d_tw512;
-    tab.melw = h->d_melw;
-    tab.mel_start = h->d_mel_start;
+    tab.melb = h->d_melb;
     if (const char* e = getenv("MV_FBANK_WAVES")) {
         const int w = atoi(e);
-        if (w == 8 || w == 12 || w == 16) h->waves = w;
+        if (w == 8 || w == 12 || w == 15) h->waves = w;
     }
-    h->smem_bytes = (size_t)h->waves * 4 * mv::FB_SLOT_CPLX * sizeof(mv::cplx) + 3 * 512 * sizeof(float) +
-                    (size_t)(h->waves + 1) * 128 * sizeof(float) + (size_t)mv::FB_MAX_ROUNDS * 16 * sizeof(int) +
-                    melw.size() * sizeof(float) + (h->waves == 8 ? (size_t)h->waves * 2048 * sizeof(float) : 0);
-    hipError_t se = hipSuccess;
-    switch (rounds) {
-        case 1: se = fbank_set_smem<1>(h->smem_bytes, h->waves); break;
-        case 2: se = fbank_set_smem<2>(h->smem_bytes, h->waves); break;
-        case 3: se = fbank_set_smem<3>(h->smem_bytes, h->waves); break;
-        case 4: se = fbank_set_smem<4>(h->smem_bytes, h->waves); break;
-        case 5: se = fbank_set_smem<5>(h->smem_bytes, h->waves); break;
-        case 6: se = fbank_set_smem<6>(h->smem_bytes, h->waves); break;
-        case 7: se = fbank_set_smem<7>(h->smem_bytes, h->waves); break;
-        default: se = fbank_set_smem<8>(h->smem_bytes, h->waves); break;
+    auto lds_need = [&](int waves) { return ((size_t)waves * 4 * mv::FB_SLOT_FLOATS + 3 * 512 + melb.size()) * sizeof(float); };
+    if (lds_need(h->waves) > 160 * 1024 && h->waves > 12) h->waves = 12;  // a long mel table leaves room for fewer frame slots
+    if (lds_need(h->waves) > 160 * 1024) h->waves = 8;
+    h->smem_bytes = lds_need(h->waves);
+    if (h->smem_bytes > 160 * 1024) {
+        mv_fbank_destroy(h);
+        return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: the mel table does not fit the LDS next to the frame slots");
     }
-    if (se != hipSuccess) {
+    if (fbank_set_smem(h->smem_bytes) != hipSuccess) {
         mv_fbank_destroy(h);
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_kernel");
     }
@@ -644,8 +697,7 @@ int mv_fbank_destroy(MvFbank* h) {
     hipFree(h->d_window);
     hipFree(h->d_tw256);
     hipFree(h->d_tw512);
-    hipFree(h->d_melw);
-    hipFree(h->d_mel_start);
+    hipFree(h->d_melb);
     delete h;
     return MV_OK;
 }
@@ -681,24 +733,10 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.use_power = h->cfg.use_power;
     a.use_log = h->cfg.use_log_fbank;
     a.cmn = h->cfg.subtract_time_mean;
-    a.vec2_ok = ((reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0) ? 1 : 0;
     a.L = L;
-    // DMA prefetch needs 16-byte aligned 4-float transfers and a quad of frames that fits the 1024-sample ring slot
-    const bool dma_ok = (reinterpret_cast<uintptr_t>(wav) & 15) == 0 && (wav_stride & 3) == 0 && (h->shift & 3) == 0 &&
-                        (h->win & 1) == 0 && 3 * h->shift + h->win <= 1024 && L >= 4 && h->waves == 8;  // the sample ring is only carved for 8-wave workgroups
-    a.load_mode = dma_ok ? 2 : (a.vec2_ok ? 1 : 0);
     a.tab = h->tab;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (h->tab.rounds) {
-        case 1: fbank_launch<1>(B, h->smem_bytes, st, a, h->waves); break;
-        case 2: fbank_launch<2>(B, h->smem_bytes, st, a, h->waves); break;
-        case 3: fbank_launch<3>(B, h->smem_bytes, st, a, h->waves); break;
-        case 4: fbank_launch<4>(B, h->smem_bytes, st, a, h->waves); break;
-        case 5: fbank_launch<5>(B, h->smem_bytes, st, a, h->waves); break;
-        case 6: fbank_launch<6>(B, h->smem_bytes, st, a, h->waves); break;
-        case 7: fbank_launch<7>(B, h->smem_bytes, st, a, h->waves); break;
-        default: fbank_launch<8>(B, h->smem_bytes, st, a, h->waves); break;
-    }
+    const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
+    fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
     return mv::check_launch("fbank_kernel");
 }
 
