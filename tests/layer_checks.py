@@ -125,6 +125,8 @@ CONV_CASES = [
     dict(k=1, dil=1, cin=72, cout=256, T=300, B=1, tile=256),           # 256 x 256 workgroup tile (8 waves)
     dict(k=3, dil=2, cin=64, cout=512, T=70, B=2, tile=256, row_bias=True, post_act=2),  # 256 tile, 2 co tiles, ragged rows
     dict(k=3, dil=3, cin=32, cout=512, T=90, B=3, tile=256, gate_seg=25, pre_act=0, affine=False, pad_mode='zero'),
+    dict(k=1, dil=1, cin=136, cout=128, T=170, B=3, tile=160, row_bias=True, post_act=2),  # 128 x 160 tile (ASP hidden layer shape)
+    dict(k=3, dil=2, cin=64, cout=200, T=100, B=2, tile=160),            # 160-row tile, taps, ragged channels
     dict(k=1, dil=1, cin=128, cout=768, T=300, B=4, tile=256),           # persistent kernel: 15 tiles, workgroups walk 3 of them
     dict(k=1, dil=1, cin=64, cout=512, T=150, B=7, tile=256),            # persistent, single K stage per tile (first == last stage)
     dict(k=3, dil=2, cin=72, cout=512, T=130, B=5, tile=256, pre_act=0, affine=False),  # persistent, taps, no BatchNorm affine

@@ -28,6 +28,7 @@ constexpr int CV_TN = 128;  // time steps per tile
 constexpr int CV_BK = 64;   // K elements per stage
 constexpr int CV_THREADS = 256;
 constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
+constexpr int CV_LDS_BYTES_WIDE = 2 * (CV_TC + 160) * CV_BK * 2;  // 128 x 160 tile: 72 KiB
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -76,6 +77,14 @@ __device__ __attribute__((aligned(256))) const float g_one_page[256] = {
 __device__ __forceinline__ half_t to_half_sat(float v) {
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);  // saturate instead of producing inf
     return (half_t)v;
+}
+
+__device__ __forceinline__ float clamp3(float v, float lo, float hi) {
+#ifdef MV_EMU
+    return fminf(fmaxf(v, lo), hi);
+#else
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+#endif
 }
 
 // One 16-byte global -> LDS transfer per lane: the wave writes 1 KiB at lds_wave_base + lane*16, the global
@@ -428,7 +437,7 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     half_t* y = reinterpret_cast<half_t*>(a.y);
     const int rrow = lane >> 3, rch = lane & 7;
     // host admits none / ReLU only: max(v, -inf) is the identity
-    const float lo_pre = a.pre_act == MV_ACT_RELU ? 0.0f : -INFINITY, lo_post = a.post_act == MV_ACT_RELU ? 0.0f : -INFINITY;
+    const float lo_pre = a.pre_act == MV_ACT_RELU ? 0.0f : -INFINITY, lo_post = a.post_act == MV_ACT_RELU ? 0.0f : -65504.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -440,11 +449,9 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
                 v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_post);
                 half4v hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = to_half_sat(v[e]);
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation and fp16 saturation in one v_med3
                 const int pc = (m * 2 + (q >> 1)) ^ ((r >> 1) & 7);
                 *reinterpret_cast<half4v*>(stg + r * 128 + pc * 16 + (q & 1) * 8) = hv;
             }
@@ -735,23 +742,27 @@ __global__ void pack_conv_weight_kernel(const float* w, int cout, int cin, int k
 int conv1d_cin_pad(int cin) { return (int)round_up(cin, CV_BK); }
 int conv1d_cout_pad(int cout) { return (int)round_up(cout, 32); }
 
+static int cu_count() {
+    static int n = -1;
+    if (n < 0) {
+#ifdef MV_EMU
+        n = 8;
+#else
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+#endif
+    }
+    return n;
+}
+
 // Resident workgroups of the persistent kernel: one per CU (a multiple of 8 keeps  id mod 8 == XCD  across the walk).
 // MV_CONV_PERSIST_BLOCKS overrides it (tests walk several tiles per workgroup on small problems; 0 disables the kernel).
 static int persistent_blocks() {
     static int n = -1;
     if (n < 0) {
-        int v = 0;
-        if (const char* e = getenv("MV_CONV_PERSIST_BLOCKS")) {
-            v = atoi(e);
-        } else {
-#ifdef MV_EMU
-            v = 8;
-#else
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
-#endif
-        }
+        const char* e = getenv("MV_CONV_PERSIST_BLOCKS");
+        const int v = e != nullptr ? atoi(e) : cu_count();
         n = v > 0 ? (int)round_up(v, 8) : 0;
     }
     return n;
@@ -828,7 +839,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool f16 = d.x_dtype == MV_DT_F16;
     const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
     // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
-    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 256, "conv1d: tile must be 0 (auto), 128 or 256");
+    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 160 || d.tile == 256, "conv1d: tile must be 0 (auto), 128, 160 or 256");
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
     const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
@@ -837,13 +848,29 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
                          (d.pre_act == MV_ACT_NONE || d.pre_act == MV_ACT_RELU) &&
                          (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) && persistent_blocks() > 0;
-    const int tn = big ? 256 : CV_TN, tc = big ? 256 : CV_TC;
+    // 128 x 160 tile of the direct path: two workgroups per CU = 2 * CUs slots; taken when it saves a whole round of
+    // workgroups (B*T = 76 288 rows x 128 channels: 477 tiles in one round instead of 596 tiles in two)
+    const bool direct = f16 && !has_x2 && !in_aff;
+    bool wide = false;
+    if (direct && !big) {
+        if (d.tile == 160) {
+            wide = true;
+        } else if (d.tile == 0) {
+            const int64_t slots = 2 * (int64_t)cu_count(), cot = ceil_div(d.cout, CV_TC);
+            const int64_t cost128 = ceil_div(ceil_div(a.n_rows, 128) * cot, slots) * 128;
+            const int64_t cost160 = ceil_div(ceil_div(a.n_rows, 160) * cot, slots) * 160;
+            wide = cost160 < cost128;
+        }
+    }
+    if (d.tile == 160) MV_REQUIRE(direct && !big, "conv1d: the 160-row tile belongs to the plain fp16 path");
+    const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
     static bool smem_set = false;
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
             MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel, CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
@@ -858,6 +885,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         MV_LAUNCH(conv1d_glds_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
+    } else if (wide) {
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else if (f16 && has_x2 && !in_aff) {

@@ -24,7 +24,7 @@ int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, con
                             int64_t ldo, int B, int T, int C, hipStream_t stream);
 int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_t ldd, int64_t n_rows, int C, hipStream_t stream);
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream);
-bool res2_chain_supported(int T, int width, int steps, int k);
+bool res2_chain_supported(int T, int width, int steps, int k, int dil);
 int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const float* const* bias, const float* const* scale,
                       const float* const* shift, int B, int T, int C, int width, int steps, int k, int dil, hipStream_t stream);
 int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,

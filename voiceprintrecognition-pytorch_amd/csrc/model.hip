@@ -420,7 +420,7 @@ struct EcapaModel : MvModelBase {
                                b.tdnn1.scale, b.tdnn1.shift, MV_ACT_NONE, nullptr, true, st)))
                 return rc;
             const int steps = cfg.res2net_scale - 1;
-            if (res2_chain_supported(T, b.width, steps, b.k)) {
+            if (res2_chain_supported(T, b.width, steps, b.k, b.dil)) {
                 // whole chain in one launch, one workgroup per utterance (res2.hip)
                 const half_t* wp[16];
                 const float *bp[16], *sp[16], *tp[16];

@@ -5,8 +5,11 @@
 // launches per block, every intermediate makes an HBM round trip).  Here the step input lives in LDS for the whole
 // chain ([T_pad x width] fp16, XOR-swizzled rows), the step output stays in the MFMA accumulators until every wave has
 // finished reading the input, is then added to the next channel group x_{j+1} and written back over the input buffer.
-// Only the weights stream in (global -> LDS direct, double buffered, 64-wide K stages); they are shared by all
+// Only the weights stream in (global -> LDS direct, 4-slot ring of 64-wide K stages); they are shared by all
 // workgroups and stay in L2.  HBM traffic is the algorithmic minimum: read x once, write y once.
+// The activation buffer carries the reflect padding physically (PAD halo rows on either side, rewritten by the epilogue
+// together with the rows they mirror), so a tap is a constant row shift: the row swizzle (row & 15) is then the same for
+// every time tile of a lane and the ten operand reads of a K step are one address + immediates.
 //
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
@@ -19,6 +22,8 @@ constexpr int R2_NH = 10;            // time tiles (16 frames) per wave half -> 
 constexpr int R2_MAX_STEPS = 15;
 constexpr int R2_WSTAGE_BYTES = 128 * 64 * 2;  // one K stage of weights: [<=128 rows][64] fp16
 constexpr int R2_RING = 4;                     // weight stages in flight (ring of LDS slots)
+constexpr int R2_MAXPAD = 8;                   // halo rows on either side of the activation buffer
+constexpr int R2_ROWS = 2 * R2_NH * 16 + 2 * R2_MAXPAD;  // rows of the activation buffer (all 20 time tiles + halo)
 
 struct Res2Args {
     const half_t* x;   // [B, T, C]  tdnn1 output
@@ -57,6 +62,14 @@ __device__ __forceinline__ void r2_lds_barrier() {
 #endif
 }
 
+__device__ __forceinline__ float r2_clamp_h(float v) {  // fp16 saturation
+#ifdef MV_EMU
+    return fminf(fmaxf(v, -65504.0f), 65504.0f);
+#else
+    return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+#endif
+}
+
 // MI = output channel tiles per wave (width = 64 * MI)
 template <int MI>
 __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
@@ -66,41 +79,44 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     constexpr int ROWB = WIDTH * 2;      // bytes per activation row
     constexpr int TP = MI;               // weight transfers per stage per wave (WIDTH/8 transfers over 8 waves)
     char* wbuf = smem;                               // R2_RING x R2_WSTAGE_BYTES
-    char* abuf = smem + R2_RING * R2_WSTAGE_BYTES;   // [Tp][WIDTH] fp16, chunk index ^= row & (CPR-1)
+    char* abuf = smem + R2_RING * R2_WSTAGE_BYTES;   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.x;
     const int T = a.T;
-    const int Tp = (T + 15) & ~15;
+    const int half_k = (a.k - 1) / 2;
+    const int PAD = half_k * a.dil;
     const int64_t rowbase = (int64_t)b * T;
     const half_t* xb = a.x + rowbase * a.C;
     half_t* yb = a.y + rowbase * a.C;
     auto a_off = [&](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CPR - 1))) << 4); };
 
-    // ---- slice 0 passes through; slice 1 becomes the first step's input ----
-    for (int i = tid; i < Tp * CPR; i += R2_THREADS) {
+    // ---- slice 0 passes through; slice 1 (with its reflected halo) becomes the first step's input; rows beyond stay zero ----
+    for (int i = tid; i < R2_ROWS * CPR; i += R2_THREADS) {
         const int row = i / CPR, ch = i - row * CPR;
-        half8v v0, v1;
+        const int t = row - PAD;
+        half8v v1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v0[e] = v1[e] = (half_t)0.0f;
-        if (row < T) {
-            v0 = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.C + ch * 8);
-            v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.C + WIDTH + ch * 8);
-            *reinterpret_cast<half8v*>(yb + (int64_t)row * a.C + ch * 8) = v0;
+        for (int e = 0; e < 8; ++e) v1[e] = (half_t)0.0f;
+        if (t >= -PAD && t < T + PAD) {
+            const int ts = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)ts * a.C + WIDTH + ch * 8);
+            if (t >= 0 && t < T)
+                *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + ch * 8) = *reinterpret_cast<const half8v*>(xb + (int64_t)t * a.C + ch * 8);
         }
         *reinterpret_cast<half8v*>(abuf + a_off(row, ch)) = v1;
     }
 
     const int cw = wave & 3;   // channel tile group
     const int th = wave >> 2;  // time half
-    const int ntile = Tp / 16;
     const int nh0 = th * R2_NH;  // first time tile of this wave
     const int kstages_per_tap = a.kpad / 64;
     const int nstages = a.k * kstages_per_tap;
-    const int half_k = (a.k - 1) / 2;
     // weight transfers: a stage is [WIDTH rows][64] = WIDTH/8 transfers of 1 KiB; wave w issues transfers w, w+8
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ lrow;
+    // operand rows of this lane: time tile ni starts at row (nh0 + ni) * 16 + fr (+ tap shift + PAD)
+    const int lane_row0 = nh0 * 16 + fr;
 
     for (int j = 1; j <= a.steps; ++j) {
         const half_t* wj = a.w[j - 1];
@@ -112,6 +128,20 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 r2_glds16(wj + ((int64_t)co * a.k + tap) * a.kpad + c0 + kc * 8, wbuf + buf * R2_WSTAGE_BYTES + tr * 1024);
             }
         };
+        // the next channel group x_{j+1} is requested first (rows clamped, stores predicated): these loads are older than
+        // every weight transfer, so the counted waits of the K loop cover them, and their latency overlaps stage 0's
+        const bool more = j < a.steps;
+        half4v xn[MI][R2_NH];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < R2_NH; ++ni) {
+                int t = (nh0 + ni) * 16 + fr;
+                t = t < T ? t : T - 1;
+                const half4v zero4h = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                xn[mi][ni] = more ? *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + (cw * MI + mi) * 16 + 4 * fg) : zero4h;
+            }
+        for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         float4v acc[MI][R2_NH];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -120,7 +150,6 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         // Weight stages run up to R2_RING-1 ahead of the MFMAs: wait (counted) for stage s, barrier, refill the slot that
         // stage s-1 just released with stage s+3, compute stage s.  One barrier per stage; it also publishes the
         // activation buffer written by the previous step's epilogue.
-        for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         for (int s = 0; s < nstages; ++s) {
             const int last_issued = s + R2_RING - 2 < nstages - 1 ? s + R2_RING - 2 : nstages - 1;
             const int younger = last_issued - s;  // stages issued after stage s
@@ -136,7 +165,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             const int buf = s % R2_RING;
             const int tap = s / kstages_per_tap;
             const int c0 = (s - tap * kstages_per_tap) * 64;
-            const int shift = (tap - half_k) * a.dil;
+            const int row0 = lane_row0 + (tap - half_k) * a.dil + PAD;  // >= 0; row0 + 16 * ni is tile ni's operand row
+            const int sw = row0 & (CPR - 1);                            // the same for every tile: 16 rows per tile
             const char* wt = wbuf + buf * R2_WSTAGE_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -147,17 +177,12 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                         const int row = (cw * MI + mi) * 16 + fr;
                         af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                     }
-                    // all R2_NH tiles are computed unconditionally (rows beyond T are clamped to T-1 and never stored):
-                    // no per-tile branch, so the LDS reads of a K step are batched ahead of its MFMAs
+                    // all R2_NH tiles are computed (tiles beyond T read zero rows and are never stored): one address, the
+                    // tiles are immediates
+                    const char* bp = abuf + row0 * ROWB + ((((c0 >> 3) + kk * 4 + fg) ^ sw) << 4);
                     half8v bf[R2_NH];
 #pragma unroll
-                    for (int ni = 0; ni < R2_NH; ++ni) {
-                        int t = (nh0 + ni) * 16 + fr;
-                        t = t < T ? t : T - 1;
-                        int tin = t + shift;
-                        tin = tin < 0 ? -tin : (tin >= T ? 2 * (T - 1) - tin : tin);  // reflect "same" padding
-                        bf[ni] = *reinterpret_cast<const half8v*>(abuf + a_off(tin, (c0 >> 3) + kk * 4 + fg));
-                    }
+                    for (int ni = 0; ni < R2_NH; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(bp + ni * 16 * ROWB);
 #pragma unroll
                     for (int ni = 0; ni < R2_NH; ++ni)
 #pragma unroll
@@ -167,20 +192,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             }
         }
         r2_lds_barrier();  // every wave is done with the activation buffer and the weight ring
-        // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer ----
-        const bool more = j < a.steps;
-        // the next channel group x_{j+1}: every load is issued before the first use (rows clamped, stores predicated)
-        half4v xn[MI][R2_NH];
-        if (more) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < R2_NH; ++ni) {
-                    int t = (nh0 + ni) * 16 + fr;
-                    t = t < T ? t : T - 1;
-                    xn[mi][ni] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + (cw * MI + mi) * 16 + 4 * fg);
-                }
-        }
+        // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer,
+        //      rows 1..PAD and T-1-PAD..T-2 also into the halo rows that mirror them ----
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int co = (cw * MI + mi) * 16 + 4 * fg;
@@ -193,32 +206,40 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 half4v hv, nv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r];
-                    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                    const float v = r2_clamp_h(fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r]);
                     hv[r] = (half_t)v;
-                    float w = more ? (float)hv[r] + (float)xn[mi][ni][r] : 0.0f;
-                    w = fminf(fmaxf(w, -65504.0f), 65504.0f);
-                    nv[r] = t < T ? (half_t)w : (half_t)0.0f;
+                    nv[r] = (half_t)r2_clamp_h((float)hv[r] + (float)xn[mi][ni][r]);
                 }
-                if (t < T) *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
-                if (more && t < Tp) *reinterpret_cast<half4v*>(abuf + a_off(t, co >> 3) + (co & 7) * 2) = nv;
+                if (t < T) {
+                    *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
+                    if (more) {
+                        const int cb = (co & 7) * 2;
+                        *reinterpret_cast<half4v*>(abuf + a_off(t + PAD, co >> 3) + cb) = nv;
+                        if (t >= 1 && t <= PAD) *reinterpret_cast<half4v*>(abuf + a_off(PAD - t, co >> 3) + cb) = nv;
+                        if (t >= T - 1 - PAD && t <= T - 2)
+                            *reinterpret_cast<half4v*>(abuf + a_off(2 * (T - 1) - t + PAD, co >> 3) + cb) = nv;
+                    }
+                }
             }
         }
         // the next step's first stage barrier publishes these LDS writes
     }
 }
 
-size_t res2_chain_lds_bytes(int T, int width) { return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)round_up(T, 16) * width * 2; }
+size_t res2_chain_lds_bytes(int T, int width) {
+    (void)T;
+    return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)R2_ROWS * width * 2;
+}
 
-bool res2_chain_supported(int T, int width, int steps, int k) {
-    return (width == 64 || width == 128) && T <= 16 * 2 * R2_NH && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1;
+bool res2_chain_supported(int T, int width, int steps, int k, int dil) {
+    return (width == 64 || width == 128) && T <= 16 * 2 * R2_NH && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1 &&
+           dil * (k - 1) / 2 <= R2_MAXPAD && dil * (k - 1) / 2 < T;
 }
 
 int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const float* const* bias, const float* const* scale,
                       const float* const* shift, int B, int T, int C, int width, int steps, int k, int dil, hipStream_t stream) {
-    MV_REQUIRE(res2_chain_supported(T, width, steps, k), "res2_chain: unsupported geometry");
+    MV_REQUIRE(res2_chain_supported(T, width, steps, k, dil), "res2_chain: unsupported geometry");
     MV_REQUIRE(C == width * (steps + 1), "res2_chain: channels must be (steps + 1) * width");
-    MV_REQUIRE(dil * (k - 1) / 2 < T, "res2_chain: reflect padding needs pad < T");
     Res2Args a;
     a.x = x;
     a.y = y;
@@ -257,8 +278,9 @@ int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, co
                "mv_res2net_chain_f16: null argument");
     MV_REQUIRE(groups >= 2 && C % groups == 0 && B > 0 && T > 0, "mv_res2net_chain_f16: bad geometry");
     const int width = C / groups;
-    if (!mv::res2_chain_supported(T, width, groups - 1, k))
-        return mv::fail(MV_ERR_UNSUPPORTED, "mv_res2net_chain_f16: fused chain needs width 64/128, T <= 320 and an odd kernel");
+    if (!mv::res2_chain_supported(T, width, groups - 1, k, dilation))
+        return mv::fail(MV_ERR_UNSUPPORTED,
+                        "mv_res2net_chain_f16: fused chain needs width 64/128, T <= 320, an odd kernel and padding <= 8 (< T)");
     return mv::res2_chain_launch(reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
                                  reinterpret_cast<const half_t* const*>(w_packed), bias, scale, shift, B, T, C, width, groups - 1, k,
                                  dilation, static_cast<hipStream_t>(stream));
