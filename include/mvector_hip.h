@@ -230,6 +230,15 @@ int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
                       int32_t unbiased, float clamp_eps, mv_stream_t stream);
 
+/* Attentive-statistics pooling tail (mvector/models/pooling.py:117-125): attention logits = W2 . h (the bias of the
+ * projection is constant over time and cancels in the softmax over time), softmax over time, weighted mean / std.
+ *   h  fp16 [B, T, A] (tanh output, |h| <= 1),  w2_packed = mv_conv1d_pack_weight of  W2[C, A, 1] * log2(e),
+ *   x  fp16 [B, T, ldx],  gmean fp32 [B, gmean_ld] or NULL (centre of the second moment),  out fp32 [B, 2C] = mean | std.
+ * logit_bound_log2 = max_c sum_k |W2[c,k]| * log2(e) selects the form without max subtraction when it is in [0, 60];
+ * pass a negative value for the online-softmax form (any weights). */
+int mv_asp_pool_f16(const void* h, const void* w2_packed, const void* x, int64_t ldx, const float* gmean, int64_t gmean_ld,
+                    float* out, int32_t B, int32_t T, int32_t C, int32_t A, float logit_bound_log2, mv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,37 @@ def time_stats_case(cdll, device, B=3, T=29, C=520, ld=528, unbiased=0, eps=1e-1
     return e1, e2
 
 
+def asp_pool_case(cdll, device, B=3, T=45, C=192, A=128, ldx=None, online=False, centred=True, wscale=0.08, seed=0):
+    """softmax over time of W2 . h (+ b2, which cancels), weighted mean / std of x (pooling.py:117-125)."""
+    g = torch.Generator().manual_seed(seed)
+    ldx = ldx or C
+    h = torch.tanh(torch.randn(B, T, A, generator=g)).half()
+    w2 = (torch.rand(C, A, generator=g) * 2 - 1) * wscale
+    b2 = torch.randn(C, generator=g)
+    x = (torch.randn(B, T, ldx, generator=g) * 1.5 + 0.3).half()
+    if centred:
+        x[:, :, 5] = 0.75  # constant channel: its variance must come out as exactly the clamp (needs the centred moments)
+    log2e = 1.4426950408889634
+    packed = pack_weight(cdll, (w2 * log2e).reshape(C, A, 1).to(device))
+    hd, xd = h.to(device), x.to(device)
+    gmean = x.float()[..., :C].mean(1).to(device) if centred else None
+    out = torch.empty(B, 2 * C, device=device)
+    bound = -1.0 if online else float(w2.abs().sum(1).max()) * log2e * 1.001
+    _hip.check(cdll.mv_asp_pool_f16(hd.data_ptr(), packed.data_ptr(), xd.data_ptr(), ldx, gmean.data_ptr() if centred else None, C,
+                                    out.data_ptr(), B, T, C, A, bound, _stream(xd)), cdll)
+    # reference in fp64 from the fp16-rounded operands the kernel sees
+    w2h = (w2 * log2e).half().double() / log2e
+    logits = h.double() @ w2h.t() + b2.double()                # [B, T, C]
+    wgt = torch.softmax(logits, dim=1)
+    xf = x.double()[..., :C]
+    mean = (wgt * xf).sum(1)
+    std = torch.sqrt(((wgt * (xf - mean.unsqueeze(1)) ** 2).sum(1)).clamp(1e-12))
+    ref = torch.cat([mean, std], 1).float()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+    return err
+
+
 def fbank_case(cdll, device, wav, ratio, method_args):
     from oracle import frontend
     fb = _hip.Fbank(method_args, cdll=cdll)

@@ -93,6 +93,12 @@ def test_emu_melspec_other_geometry():
                                                       f_max=7000, n_mels=40))
 
 
+@pytest.mark.parametrize('cfg', [dict(), dict(online=True), dict(B=5, T=9, C=72, A=64, ldx=80, centred=False),
+                                 dict(B=2, T=33, C=64, A=128, online=True, wscale=1.0)])
+def test_emu_asp_pool(cfg):
+    lc.asp_pool_case(emu_cdll(), 'cpu', **cfg)
+
+
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1)])
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)

@@ -206,6 +206,13 @@ def test_gpu_ecapa_on_melspectrogram_end_to_end():
     assert cos_dist(emb[:3].cpu(), ref).max() < 1e-4
 
 
+@pytest.mark.parametrize('cfg', [dict(), dict(online=True), dict(B=5, T=9, C=72, A=64, ldx=80, centred=False),
+                                 dict(B=2, T=33, C=64, A=128, online=True, wscale=1.0), dict(B=9, T=298, C=3072, A=128),
+                                 dict(B=6, T=298, C=1536, A=128, online=True), dict(B=3, T=1, C=64, A=128)])
+def test_gpu_asp_pool(cfg):
+    lc.asp_pool_case(product_lib(), DEV, **cfg)
+
+
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
                                  dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
 def test_gpu_res2net_fused_chain(cfg):

@@ -27,7 +27,7 @@ int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd,
 bool res2_chain_supported(int T, int width, int steps, int k, int dil);
 int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const float* const* bias, const float* const* scale,
                       const float* const* shift, int B, int T, int C, int width, int steps, int k, int dil, hipStream_t stream);
-int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,
-                    const float* gmean, int64_t gmean_ld, float* out, int B, int T, int C, int A, hipStream_t stream);
+int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, int64_t ldx, const float* gmean,
+                    int64_t gmean_ld, float* out, int B, int T, int C, int A, float logit_bound_log2, hipStream_t stream);
 
 }  // namespace mv

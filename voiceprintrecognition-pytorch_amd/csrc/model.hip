@@ -188,10 +188,24 @@ int AspLayer::create(MvModelBase* m, const Weights& w, const std::string& prefix
     if (tmp == nullptr) return fail(MV_ERR_HIP, "asp create: upload failed");
     if ((rc = m->make_conv_from(tmp, &w, prefix + ".tdnn.conv.conv.bias", A, C, 1, &tdnn))) return rc;
     if ((rc = m->make_bn(w, prefix + ".tdnn.norm.norm", A, &bn_scale, &bn_shift))) return rc;
-    if ((rc = m->make_conv(w, prefix + ".conv.conv.weight", prefix + ".conv.conv.bias", C, A, 1, &conv))) return rc;
-    if (conv.bias == nullptr) {
-        std::vector<float> zeros(C, 0.0f);
-        conv.bias = m->upload(zeros);
+    // attention projection asp.conv (C x A): stored times log2(e) so that the pooling kernel's softmax weight is a bare
+    // 2^logit; its bias is constant over time and cancels in the softmax over time (pooling.py:117-119), so it is dropped.
+    // h = tanh(.) is bounded by 1, so sum_k |W2[c,k]| bounds every logit (-> NOMAX form of the kernel)
+    {
+        const float log2e = 1.4426950408889634f;
+        std::vector<float> w2;
+        if ((rc = w.host(prefix + ".conv.conv.weight", (int64_t)C * A, w2))) return rc;
+        double bound = 0.0;
+        for (int c = 0; c < C; ++c) {
+            double sabs = 0.0;
+            for (int k = 0; k < A; ++k) sabs += fabs((double)w2[(size_t)c * A + k]);
+            bound = sabs > bound ? sabs : bound;
+        }
+        for (float& v : w2) v *= log2e;
+        logit_bound_log2 = std::isfinite(bound) ? (float)(bound * log2e * 1.001) : -1.0f;  // margin for the fp16 rounding of W2
+        float* tmp2 = m->upload(w2);
+        if (tmp2 == nullptr) return fail(MV_ERR_HIP, "asp create: upload failed");
+        if ((rc = m->make_conv_from(tmp2, nullptr, "", C, A, 1, &conv))) return rc;
     }
     return MV_OK;
 }
@@ -218,7 +232,7 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     if ((rc = run_conv(tdnn, x, MV_DT_F16, ldx, nullptr, 0, h, MV_DT_F16, A, B, T, T, 1, 0, MV_PAD_REFLECT, MV_ACT_RELU,
                        bn_scale, bn_shift, MV_ACT_TANH, row_bias, /*use_bias=*/!global_ctx, stream)))
         return rc;
-    return asp_pool_launch(h, conv.w, conv.bias, x, ldx, gmean, 2 * C, pooled, B, T, C, A, stream);
+    return asp_pool_launch(h, conv.w, x, ldx, gmean, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
 }
 
 // fold y = BN_out( W . BN_in(p) + b ) into one affine map (either BN optional)

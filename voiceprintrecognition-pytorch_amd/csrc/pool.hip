@@ -258,66 +258,94 @@ int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attentive statistics pooling tail.  Workgroup = (utterance b, 64-channel tile); wave w walks the 16-row time tiles
-// w, w+4, ...  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :] + b2[c]  on MFMA 16x16x32 (A = W2 rows staged once in LDS,
-// B = h rows loaded straight into fragment layout), so each lane holds 4 consecutive channels of one time step.
-// ONE pass with an online softmax: every lane keeps, per channel it holds, a running max m and the sums
-//   s0 = sum e,  s1 = sum e*(x - g),  s2 = sum e*(x - g)^2,   e = exp(logit - m)
-// rescaled when m grows (g = global channel mean: keeps the second moment well conditioned and makes a constant
-// channel's variance exactly zero).  Lanes, then waves, are merged at the end with the same rescaling rule.
+// Attentive statistics pooling tail.  Workgroup = (64-channel tile, 4 utterances), one utterance per wave, 16-row time
+// tiles.  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :]  (+ b2[c], which is constant over t and cancels in the softmax
+// over time, so it is never added)  on MFMA 16x16x32 (A = W2 rows staged once in LDS,
+// B = h rows loaded straight into fragment layout).  The W2 rows are fed in the order
+//     MFMA tile mi, row i  <->  channel 16*(i>>2) + 4*mi + (i&3)
+// so the 16 logits a lane ends up with (4 tiles x 4 rows) are 16 CONSECUTIVE channels of one time step: its x values
+// are two 16-byte loads and a 16-lane group reads whole 128-byte lines.
+// W2 arrives pre-multiplied by log2(e) (AspLayer::create), so the softmax weight is one v_exp_f32.
+// ONE pass over x with the sums
+//   s0 = sum e,  s1 = sum e*(x - g),  s2 = sum e*(x - g)^2        (g = global channel mean: keeps the second moment
+//   well conditioned and makes a constant channel's variance exactly zero)
 //   mean = g + s1/s0,  std = sqrt(clamp(s2/s0 - (s1/s0)^2, 1e-12))      (pooling.py:91-94,122-125)
+// Two forms of e:
+//   NOMAX  e = 2^logit.  h = tanh(.) is bounded by 1, so |logit| <= sum_k |W2[c,k]|; when that bound (in log2
+//          units) is <= 60 for every channel -- checked once at create; real checkpoints sit near 10-15 -- nothing can
+//          overflow or vanish in fp32 and the softmax needs no max subtraction at all: 10 VALU operations per element;
+//   online running max m per lane and channel, e = 2^(logit - m), sums rescaled when m grows (any weights).
 // The [B, 9C, T] attention input and the [B, C, T] logits of the reference never exist.
 struct AspArgs {
     const half_t* h;    // [B, T, A]
-    const half_t* w2;   // packed [C_pad][1][A_pad]
-    const float* b2;    // [C]
+    const half_t* w2;   // packed [C_pad][1][A_pad], times log2(e)
     const half_t* x;    // [B, T, ldx]
     int64_t ldx;
     const float* gmean; // [B, gmean_ld] or null
     int64_t gmean_ld;
     float* out;         // [B, 2C]: mean | std
-    int T, C, C_pad, A, A_pad;
+    int B, T, C, C_pad, A, A_pad;
     float eps;
 };
 
+__device__ __forceinline__ float asp_exp2(float v) {
+#ifdef MV_EMU
+    return exp2f(v);
+#else
+    return __builtin_amdgcn_exp2f(v);  // v_exp_f32: arguments are <= 0 (online) or within +-60 (NOMAX)
+#endif
+}
+
 __device__ __forceinline__ void asp_merge(float& m, float& s0, float& s1, float& s2, float om, float o0, float o1, float o2) {
     const float nm = fmaxf(m, om);
-    const float ra = __expf(m - nm), rb = __expf(om - nm);
+    const float ra = asp_exp2(m - nm), rb = asp_exp2(om - nm);
     s0 = s0 * ra + o0 * rb;
     s1 = s1 * ra + o1 * rb;
     s2 = s2 * ra + o2 * rb;
     m = nm;
 }
 
-template <int KS>
+template <int KS, bool NOMAX>
 __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
+    // Workgroup = (64-channel tile, 4 utterances): the W2 tile is staged once and shared, then every WAVE pools one whole
+    // utterance on its own -- no barrier and no cross-wave merge after the prologue.
     __shared__ __attribute__((aligned(16))) half_t wlds[64 * KS * 32];  // W2 tile, fragment-major: [mi][kk][lane][8]
-    __shared__ float part[4][4][64];                                     // [wave][m, s0, s1, s2][channel]
-    __shared__ __attribute__((aligned(16))) float cpar[2][64];           // [bias | global mean][channel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y * 4 + wave;
     const int c0 = blockIdx.x * 64;
     const int fr = lane & 15, fg = lane >> 4;
-    const half_t* hb = a.h + (int64_t)b * a.T * a.A;
-    const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
     const int ntiles = (a.T + 15) / 16;
 
-    // stage the 64 x A_pad weight tile in MFMA A-fragment order: slot (mi, kk, lane) = row c0+mi*16+(lane&15), k = kk*32+8*(lane>>4)
+    // stage the 64 x A_pad weight tile in MFMA A-fragment order: slot (mi, kk, lane): A row i = lane & 15 is channel
+    // c0 + 16*(i>>2) + 4*mi + (i&3), k = kk*32 + 8*(lane>>4)
     for (int i = tid; i < 4 * KS * 64; i += 256) {
         const int l = i & 63, kk = (i >> 6) % KS, mi = i / (64 * KS);
-        const int row = c0 + mi * 16 + (l & 15);
+        const int ar = l & 15;
+        const int row = c0 + 16 * (ar >> 2) + 4 * mi + (ar & 3);
         half8v v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (half_t)0.0f;
         if (row < a.C_pad) v = *reinterpret_cast<const half8v*>(a.w2 + (int64_t)row * a.A_pad + kk * 32 + 8 * (l >> 4));
         *reinterpret_cast<half8v*>(wlds + (size_t)i * 8) = v;
     }
-    if (tid < 64) {
-        const int c = c0 + tid;
-        cpar[0][tid] = c < a.C ? a.b2[c] : 0.0f;
-        cpar[1][tid] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-    }
     __syncthreads();
+    if (b >= a.B) return;
+    const half_t* hb = a.h + (int64_t)b * a.T * a.A;
+    const half_t* xb = a.x + (int64_t)b * a.T * a.ldx;
+
+    // this lane's 16 channels: c0 + 16*fg + 4*mi + r
+    const int cl = c0 + 16 * fg;
+    // (the bias b2[c] is constant over time, so it cancels in the softmax over time: it is never added)
+    float4v g4[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cl + 4 * mi + r;
+            g4[mi][r] = (a.gmean != nullptr && c < a.C) ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
+        }
+    }
+    const bool xvec = c0 + 64 <= a.C && (a.ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 
     auto load_h = [&](int t0, half8v (&hf)[KS]) {
         const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
@@ -332,17 +360,15 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
             }
         }
     };
-    auto load_x = [&](int t0, half4v (&xv)[4]) {
+    auto load_x = [&](int t0, half8v (&xv)[2]) {
         const int t = t0 + fr < a.T ? t0 + fr : a.T - 1;
+        const half_t* p = xb + (int64_t)t * a.ldx + cl;
+        if (xvec) {
+            xv[0] = *reinterpret_cast<const half8v*>(p);
+            xv[1] = *reinterpret_cast<const half8v*>(p + 8);
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int c = c0 + mi * 16 + 4 * fg;
-            if (c + 3 < a.C) {
-                xv[mi] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.ldx + c);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xv[mi][r] = (c + r < a.C) ? xb[(int64_t)t * a.ldx + c + r] : (half_t)0.0f;
-            }
+            for (int e = 0; e < 16; ++e) xv[e >> 3][e & 7] = (cl + e < a.C) ? p[e] : (half_t)0.0f;
         }
     };
 
@@ -356,99 +382,122 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
         }
     {
         half8v hcur[KS], hnext[KS];
-        half4v xcur[4], xnext[4];
-        if (wave < ntiles) {
-            load_h(wave * 16, hcur);
-            load_x(wave * 16, xcur);
-        }
-        for (int tt = wave; tt < ntiles; tt += 4) {
-            const bool more = tt + 4 < ntiles;
+        half8v xcur[2], xnext[2];
+        load_h(0, hcur);
+        load_x(0, xcur);
+        for (int tt = 0; tt < ntiles; ++tt) {
+            const bool more = tt + 1 < ntiles;
             if (more) {  // next tile's rows are in flight while this tile computes
-                load_h((tt + 4) * 16, hnext);
-                load_x((tt + 4) * 16, xnext);
+#if !defined(MV_PROBE) || MV_PROBE != 2   // timing probes (tools/probe only): 1 = no x loads, 2 = no h loads, 3 = no element math
+                load_h((tt + 1) * 16, hnext);
+#endif
+#if !defined(MV_PROBE) || MV_PROBE != 1
+                load_x((tt + 1) * 16, xnext);
+#endif
             }
-            const bool valid = tt * 16 + fr < a.T;
+            // rows beyond T (last tile only) get a logit of -inf: e = 0, they add nothing
+            const float voff = tt * 16 + fr < a.T ? 0.0f : -INFINITY;
+            // the W2 fragments are re-read from LDS every tile (the opaque copy keeps the compiler from parking all
+            // 16 of them in 64 VGPRs, which would halve the number of resident waves)
+            const half_t* wl = wlds + lane * 8;
+#ifndef MV_EMU
+            asm volatile("" : "+v"(wl));
+#endif
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                float4v l = *reinterpret_cast<const float4v*>(&cpar[0][mi * 16 + 4 * fg]);
-                const float4v g4 = *reinterpret_cast<const float4v*>(&cpar[1][mi * 16 + 4 * fg]);
+                float4v l = float4v{voff, voff, voff, voff};
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const half8v wf = *reinterpret_cast<const half8v*>(wlds + ((size_t)(mi * KS + kk) * 64 + lane) * 8);
+                    const half8v wf = *reinterpret_cast<const half8v*>(wl + (size_t)(mi * KS + kk) * 512);
                     l = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hcur[kk], l, 0, 0, 0);
                 }
-                if (valid) {
+#if defined(MV_PROBE) && MV_PROBE == 3
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float nm = fmaxf(m[mi][r], l[r]);
-                        const float rs = __expf(m[mi][r] - nm);
-                        const float e = __expf(l[r] - nm);
-                        const float d = (float)xcur[mi][r] - g4[r];
+                for (int r = 0; r < 4; ++r) s0[mi][r] += l[r] + (float)xcur[r >> 1][r];
+#else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 4 * mi + r;
+                    const float d = (float)xcur[ci >> 3][ci & 7] - g4[mi][r];
+                    if (NOMAX) {
+                        const float e = asp_exp2(l[r]);
+                        const float ed = e * d;
+                        s0[mi][r] += e;
+                        s1[mi][r] += ed;
+                        s2[mi][r] = fmaf(ed, d, s2[mi][r]);
+                    } else {
+                        const float nm = fmaxf(m[mi][r], l[r]);  // finite from the first valid row on; -3e38 before
+                        const float rs = asp_exp2(m[mi][r] - nm);
+                        const float e = asp_exp2(l[r] - nm);
+                        const float ed = e * d;
                         s0[mi][r] = s0[mi][r] * rs + e;
-                        s1[mi][r] = s1[mi][r] * rs + e * d;
-                        s2[mi][r] = s2[mi][r] * rs + e * d * d;
+                        s1[mi][r] = s1[mi][r] * rs + ed;
+                        s2[mi][r] = s2[mi][r] * rs + ed * d;
                         m[mi][r] = nm;
                     }
                 }
+#endif
             }
             if (more) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) hcur[kk] = hnext[kk];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) xcur[mi] = xnext[mi];
+                xcur[0] = xnext[0];
+                xcur[1] = xnext[1];
             }
         }
     }
-    // ---- merge the 16 time lanes that share channels, then the 4 waves ----
+    // ---- merge the 16 time lanes that share channels; lane fr == 0 writes its 16 channels ----
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (NOMAX) {
+                s0[mi][r] = row16_sum(s0[mi][r]);
+                s1[mi][r] = row16_sum(s1[mi][r]);
+                s2[mi][r] = row16_sum(s2[mi][r]);
+            } else {
 #pragma unroll
-            for (int sh = 1; sh <= 8; sh <<= 1) {
-                const float om = __shfl_xor(m[mi][r], sh), o0 = __shfl_xor(s0[mi][r], sh);
-                const float o1 = __shfl_xor(s1[mi][r], sh), o2 = __shfl_xor(s2[mi][r], sh);
-                asp_merge(m[mi][r], s0[mi][r], s1[mi][r], s2[mi][r], om, o0, o1, o2);
+                for (int sh = 1; sh <= 8; sh <<= 1) {
+                    const float om = __shfl_xor(m[mi][r], sh), o0 = __shfl_xor(s0[mi][r], sh);
+                    const float o1 = __shfl_xor(s1[mi][r], sh), o2 = __shfl_xor(s2[mi][r], sh);
+                    asp_merge(m[mi][r], s0[mi][r], s1[mi][r], s2[mi][r], om, o0, o1, o2);
+                }
             }
-            if (fr == 0) {
-                const int ch = mi * 16 + 4 * fg + r;
-                part[wave][0][ch] = m[mi][r];
-                part[wave][1][ch] = s0[mi][r];
-                part[wave][2][ch] = s1[mi][r];
-                part[wave][3][ch] = s2[mi][r];
+            const int c = cl + 4 * mi + r;
+            if (fr == 0 && c < a.C) {
+                const float m1 = s1[mi][r] / s0[mi][r];
+                const float var = s2[mi][r] / s0[mi][r] - m1 * m1;
+                a.out[(int64_t)b * 2 * a.C + c] = g4[mi][r] + m1;
+                a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
             }
         }
-    __syncthreads();
-    if (tid < 64) {
-        const int c = c0 + tid;
-        if (c < a.C) {
-            float mm = part[0][0][tid], z0 = part[0][1][tid], z1 = part[0][2][tid], z2 = part[0][3][tid];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) asp_merge(mm, z0, z1, z2, part[w][0][tid], part[w][1][tid], part[w][2][tid], part[w][3][tid]);
-            const float gm = a.gmean != nullptr ? a.gmean[(int64_t)b * a.gmean_ld + c] : 0.0f;
-            const float m1 = z1 / z0;
-            const float var = z2 / z0 - m1 * m1;
-            a.out[(int64_t)b * 2 * a.C + c] = gm + m1;
-            a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrtf(fmaxf(var, a.eps));
-        }
+}
+
+template <int KS>
+static void asp_pool_dispatch(const AspArgs& a, unsigned gx, unsigned gy, bool nomax, hipStream_t stream) {
+    if (nomax) {
+        MV_LAUNCH((asp_pool_kernel<KS, true>), (gx, gy, 1), (256, 1, 1), 0, stream, a);
+    } else {
+        MV_LAUNCH((asp_pool_kernel<KS, false>), (gx, gy, 1), (256, 1, 1), 0, stream, a);
     }
 }
 
-int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, const half_t* x, int64_t ldx,
-                    const float* gmean, int64_t gmean_ld, float* out, int B, int T, int C, int A, hipStream_t stream) {
-    MV_REQUIRE(h != nullptr && w2_packed != nullptr && b2 != nullptr && x != nullptr && out != nullptr, "asp_pool: null tensor");
+// w2_packed carries the factor log2(e); logit_bound_log2 = max_c sum_k |W2[c,k]| * log2(e), < 0 = unknown
+int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, int64_t ldx, const float* gmean,
+                    int64_t gmean_ld, float* out, int B, int T, int C, int A, float logit_bound_log2, hipStream_t stream) {
+    MV_REQUIRE(h != nullptr && w2_packed != nullptr && x != nullptr && out != nullptr, "asp_pool: null tensor");
     MV_REQUIRE(B > 0 && T > 0 && C > 0 && A > 0, "asp_pool: bad geometry");
     MV_REQUIRE(A % 8 == 0 && A <= 256, "asp_pool: attention width must be a multiple of 8 and <= 256");
     MV_REQUIRE(ldx % 4 == 0 && C % 4 == 0, "asp_pool: channels must be a multiple of 4");
     AspArgs a;
     a.h = h;
     a.w2 = w2_packed;
-    a.b2 = b2;
     a.x = x;
     a.ldx = ldx;
     a.gmean = gmean;
     a.gmean_ld = gmean_ld;
     a.out = out;
+    a.B = B;
     a.T = T;
     a.C = C;
     a.A = A;
@@ -456,11 +505,12 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, c
     a.A_pad = (int)round_up(A, 64);
     a.eps = 1e-12f;
     const unsigned gx = (unsigned)ceil_div(C, 64);
+    const bool nomax = logit_bound_log2 >= 0.0f && logit_bound_log2 <= 60.0f;
     switch (a.A_pad / 32) {
-        case 2: MV_LAUNCH(asp_pool_kernel<2>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
-        case 4: MV_LAUNCH(asp_pool_kernel<4>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
-        case 6: MV_LAUNCH(asp_pool_kernel<6>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
-        default: MV_LAUNCH(asp_pool_kernel<8>, (gx, (unsigned)B, 1), (256, 1, 1), 0, stream, a); break;
+        case 2: asp_pool_dispatch<2>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
+        case 4: asp_pool_dispatch<4>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
+        case 6: asp_pool_dispatch<6>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
+        default: asp_pool_dispatch<8>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
     }
     return check_launch("asp_pool_kernel");
 }
@@ -468,6 +518,13 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const float* b2, c
 }  // namespace mv
 
 extern "C" {
+
+int mv_asp_pool_f16(const void* h, const void* w2_packed, const void* x, int64_t ldx, const float* gmean, int64_t gmean_ld,
+                    float* out, int32_t B, int32_t T, int32_t C, int32_t A, float logit_bound_log2, mv_stream_t stream) {
+    return mv::asp_pool_launch(reinterpret_cast<const half_t*>(h), reinterpret_cast<const half_t*>(w2_packed),
+                               reinterpret_cast<const half_t*>(x), ldx, gmean, gmean_ld, out, B, T, C, A, logit_bound_log2,
+                               static_cast<hipStream_t>(stream));
+}
 
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
                       int32_t unbiased, float clamp_eps, mv_stream_t stream) {
