@@ -9,8 +9,12 @@ The batch dimension shards across ranks with no other exchange (weak scaling: B 
 
 Output: ONE JSON line on rank 0 (metric = utterances/sec embedded, BASELINE.json) with
   * per-stage times from events recorded on the launch stream inside the timed region,
-  * ``roofline``: the Fbank kernel against the HBM roofline (algorithmic bytes 287 360 B/utt),
-    plus ``roofline_backbone`` (conv/GEMM kernels against the dense fp16 MFMA peak),
+  * ``roofline``: the dominant kernel class (the implicit-GEMM conv1d launches, ~60 % of the GPU time) against the dense
+    fp16 MFMA peak -- algorithmic FLOPs 2*B*T*cin*cout*k per launch over the launch durations measured with HIP events the
+    library records on the launch stream around every conv launch of every 4th timed step (mv_profile_enable);
+    ``roofline_fbank``: the Fbank kernel against the HBM roofline the same way (algorithmic bytes 287 360 B/utt,
+    BASELINE.md section 4); ``roofline_backbone``: the whole backbone stage (all kernels) against the MFMA peak;
+    ``traffic`` = HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), null without one,
   * ``cpu_baseline``: the oracle (torch CPU fp32 port of the reference path) timed on a bounded sample on this
     host's cores -- N=1 only, outside the timed region,
   * ``parity``: max (1 - cos) between GPU and oracle embeddings on the first utterances of the batch.
@@ -32,7 +36,6 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 SAMPLES = 48000              # 3 s @ 16 kHz
-FBANK_BYTES_PER_UTT = 192000 + 298 * 80 * 4  # read waveform + write features
 
 MODELS = {
     # name: (class, kwargs, feature method, method args, GFLOP/utt, BASELINE config label)
@@ -122,6 +125,14 @@ def main():
             events[4].record()
         return emb, scores
 
+    cdll = _hip.lib()
+    import ctypes
+
+    def prof_read(cls):
+        n, ms, work = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _hip.check(cdll.mv_profile_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work), 0), cdll)
+        return n.value, ms.value, work.value
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
@@ -131,12 +142,16 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
+            # HIP events around every conv1d / fbank launch of every 4th step of the timed region (two event records per
+            # launch are not free on the host: CAM++ issues 108 conv launches per step)
+            cdll.mv_profile_enable(1 if i % 4 == 0 else 0)
             emb, scores = step(evs[i])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
 
+    cdll.mv_profile_enable(0)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -148,8 +163,35 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fb_ms, bb_ms = stage_ms[0], stage_ms[1]
-        fb_gbs = B * FBANK_BYTES_PER_UTT / (fb_ms * 1e-3) / 1e9
         bb_tflops = B * gflop_per_utt / (bb_ms * 1e-3) / 1e3
+        # per-launch legs: algorithmic work / launch durations from the library's HIP events (launch stream, timed region)
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+                traffic = json.load(fh).get('kernels', {})
+        except OSError:
+            pass
+
+        def pmc_bytes(prefix):
+            for k, v in traffic.items():
+                if k.startswith(prefix):
+                    return v['hbm_bytes_per_launch']
+            return None
+
+        n_conv, ms_conv, flop_conv = prof_read(0)
+        n_fb, ms_fb, byte_fb = prof_read(1)
+        conv_tflops = flop_conv / (ms_conv * 1e-3) / 1e12 if ms_conv > 0 else 0.0
+        fb_gbs = byte_fb / (ms_fb * 1e-3) / 1e9 if ms_fb > 0 else 0.0
+        roof_conv = {'kernel': 'conv1d (implicit GEMM on MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel), all launches',
+                     'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(conv_tflops / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': pmc_bytes('mv::conv1d_glds_persistent_kernel'),
+                     'launches': n_conv, 'avg_launch_us': round(ms_conv / max(n_conv, 1) * 1e3, 2),
+                     'algorithmic_gflop_per_launch': round(flop_conv / max(n_conv, 1) / 1e9, 3),
+                     'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3)}
+        roof_fbank = {'kernel': 'fbank_kernel', 'bound': 'hbm', 'achieved': round(fb_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': round(fb_gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_bytes('mv::fbank_kernel'), 'launches': n_fb,
+                      'avg_launch_us': round(ms_fb / max(n_fb, 1) * 1e3, 2),
+                      'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1))}
         out = {
             'metric': 'utterances/sec embedded (3 s@16 kHz, Fbank-80, EcapaTdnn, bs=256)',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
@@ -159,10 +201,9 @@ def main():
                        'frames': 298, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
             'stage_ms': {'fbank_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
                          'all_gather': round(stage_ms[2], 4), 'cosine': round(stage_ms[3], 4)},
-            'roofline': {'kernel': 'fbank_kernel', 'bound': 'hbm', 'achieved': round(fb_gbs, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(fb_gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'algorithmic_bytes_per_launch': B * FBANK_BYTES_PER_UTT},
-            'roofline_backbone': {'kernel': 'conv1d_mfma_kernel + pooling (whole backbone stage)', 'bound': 'mfma',
+            'roofline': roof_conv,
+            'roofline_fbank': roof_fbank,
+            'roofline_backbone': {'kernel': 'whole backbone stage (conv1d + res2 chain + SE + ASP + fc)', 'bound': 'mfma',
                                   'achieved': round(bb_tflops, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': round(bb_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                                   'algorithmic_gflop_per_utt': gflop_per_utt},

@@ -230,6 +230,14 @@ int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
                       int32_t unbiased, float clamp_eps, mv_stream_t stream);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (used by bench.py for its roofline legs; off by
+ * default, not thread-safe).  work = algorithmic FLOPs (MV_PROF_CONV1D: 2*B*T_out*cin*cout*k per launch) or algorithmic
+ * bytes (MV_PROF_FBANK: B*(4*L + 4*T*num_mel_bins) per launch).  mv_profile_read waits for the recorded launches. */
+#define MV_PROF_CONV1D 0
+#define MV_PROF_FBANK 1
+int mv_profile_enable(int32_t on);
+int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, double* total_work, int32_t reset);
+
 /* Attentive-statistics pooling tail (mvector/models/pooling.py:117-125): attention logits = W2 . h (the bias of the
  * projection is constant over time and cancels in the softmax over time), softmax over time, weighted mean / std.
  *   h  fp16 [B, T, A] (tanh output, |h| <= 1),  w2_packed = mv_conv1d_pack_weight of  W2[C, A, 1] * log2(e),

@@ -106,6 +106,11 @@ inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 // returns MV_OK or records "what: hip error string"
 int check_launch(const char* what);
 
+// optional HIP-event timing of a launch (mv_profile_enable): token = prof_begin(MV_PROF_*, algorithmic work, stream)
+// before the launch, prof_end(token, stream) after it; both are no-ops while profiling is off
+int prof_begin(int kernel_class, double work, hipStream_t stream);
+void prof_end(int token, hipStream_t stream);
+
 }  // namespace mv
 
 #define MV_REQUIRE(cond, msg)                                              \

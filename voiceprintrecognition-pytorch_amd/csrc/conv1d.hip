@@ -879,6 +879,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         smem_set = true;
     }
+    const int prof = prof_begin(MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
@@ -898,6 +899,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     } else {
         return fail(MV_ERR_UNSUPPORTED, "conv1d: this combination of input dtype / second input / pre-activation is not built");
     }
+    prof_end(prof, stream);
     return check_launch("conv1d_mfma_kernel");
 }
 

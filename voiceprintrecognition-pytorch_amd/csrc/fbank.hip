@@ -736,7 +736,9 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.L = L;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
+    const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
     fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
+    mv::prof_end(prof, static_cast<hipStream_t>(stream));
     return mv::check_launch("fbank_kernel");
 }
 

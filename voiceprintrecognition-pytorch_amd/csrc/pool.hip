@@ -14,14 +14,15 @@ namespace mv {
 // ------------------------------------------------------------------------------------------------
 // mean / std over time.  Workgroup = (utterance, 128-channel group): lane (c16 = lane & 15) owns 8 channels, the four
 // 16-lane groups of a wave and the four waves take interleaved time steps (16 rows in flight per workgroup), so a
-// [B=256, C=1024] reduction runs 2048 workgroups.  Two passes (mean, then centred second moment) exactly like the
-// reference's (x - mean)^2 form.
+// [B=256, C=1024] reduction runs 2048 workgroups.  ONE pass over x: the moments are taken about the channel's first
+// time step k = x[b, 0, c] (s1 = sum (x - k), s2 = sum (x - k)^2), which conditions the variance like the reference's
+// (x - mean)^2 form -- |mean - k| is of the order of the spread -- and makes a constant channel's variance exactly zero:
+//   mean = k + s1 / T,   var = (s2 - s1^2 / T) / (T or T - 1)
 // Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
                                                          float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
                                                          const float* in_scale, const float* in_shift) {
-    __shared__ float red[4][128];
-    __shared__ float mu[128];
+    __shared__ float red[2][4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, rp = lane >> 4;
     const int b = blockIdx.y;
@@ -31,11 +32,11 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
     const int nvalid = active ? (C - c0 < 8 ? C - c0 : 8) : 0;
     const half_t* xb = x + (int64_t)b * T * ld + c0;
     const int t_first = wave * 4 + rp;  // this lane's rows: t_first, t_first + 16, ...
-    float s[8], isc[8], ish[8];
+    float s1[8], s2[8], k8[8], isc[8], ish[8];
     const bool pre = in_scale != nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        s[e] = 0.0f;
+        s1[e] = s2[e] = k8[e] = 0.0f;
         isc[e] = (pre && e < nvalid) ? in_scale[c0 + e] : 1.0f;
         ish[e] = (pre && e < nvalid) ? in_shift[c0 + e] : 0.0f;
     }
@@ -43,68 +44,60 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
         const float v = (float)h;
         return pre ? fmaxf(v * isc[e] + ish[e], 0.0f) : v;
     };
-    auto reduce_store = [&]() {  // sum over the 4 row groups of the wave, then over waves
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = s[e];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (rp == 0) red[wave][c16 * 8 + e] = v;
-        }
-    };
     if (active) {
-        for (int t = t_first; t < T; t += 16) {
-            const half_t* p = xb + (int64_t)t * ld;
-            if (nvalid == 8) {
-                const half8v v = *reinterpret_cast<const half8v*>(p);
+        if (nvalid == 8) {
+            const half8v v0 = *reinterpret_cast<const half8v*>(xb);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] += val(v[e], e);
-            } else {
-                for (int e = 0; e < nvalid; ++e) s[e] += val(p[e], e);
-            }
+            for (int e = 0; e < 8; ++e) k8[e] = val(v0[e], e);
+        } else {
+            for (int e = 0; e < nvalid; ++e) k8[e] = val(xb[e], e);
         }
-    }
-    reduce_store();
-    __syncthreads();
-    if (tid < 128) {
-        const float m = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)T;
-        mu[tid] = m;
-        if (cg0 + tid < C) mean[(int64_t)b * ld_out + cg0 + tid] = m;
-    }
-    if (stdv == nullptr) return;
-    __syncthreads();
-    float m8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        m8[e] = mu[c16 * 8 + e];
-        s[e] = 0.0f;
-    }
-    if (active) {
         for (int t = t_first; t < T; t += 16) {
             const half_t* p = xb + (int64_t)t * ld;
             if (nvalid == 8) {
                 const half8v v = *reinterpret_cast<const half8v*>(p);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = val(v[e], e) - m8[e];
-                    s[e] += d * d;
+                    const float d = val(v[e], e) - k8[e];
+                    s1[e] += d;
+                    s2[e] = fmaf(d, d, s2[e]);
                 }
             } else {
                 for (int e = 0; e < nvalid; ++e) {
-                    const float d = val(p[e], e) - m8[e];
-                    s[e] += d * d;
+                    const float d = val(p[e], e) - k8[e];
+                    s1[e] += d;
+                    s2[e] = fmaf(d, d, s2[e]);
                 }
             }
         }
     }
-    __syncthreads();  // everyone has read mu / red before red is reused
-    reduce_store();
+    // sum over the 4 row groups of the wave, then over waves
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a1 = s1[e], a2 = s2[e];
+        a1 += __shfl_xor(a1, 16);
+        a1 += __shfl_xor(a1, 32);
+        a2 += __shfl_xor(a2, 16);
+        a2 += __shfl_xor(a2, 32);
+        if (rp == 0) {
+            red[0][wave][c16 * 8 + e] = a1;
+            red[1][wave][c16 * 8 + e] = a2;
+        }
+    }
     __syncthreads();
     if (tid < 128 && cg0 + tid < C) {
-        const float denom = unbiased ? (float)(T - 1) : (float)T;
-        float var = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / denom;
-        if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
-        stdv[(int64_t)b * ld_out + cg0 + tid] = sqrtf(var);
+        // k of channel tid: recomputed by its owner thread (one 2-byte load)
+        float kc = (float)x[(int64_t)b * T * ld + cg0 + tid];
+        if (pre) kc = fmaxf(kc * in_scale[cg0 + tid] + in_shift[cg0 + tid], 0.0f);
+        const float z1 = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+        const float z2 = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+        mean[(int64_t)b * ld_out + cg0 + tid] = kc + z1 / (float)T;
+        if (stdv != nullptr) {
+            const float denom = unbiased ? (float)(T - 1) : (float)T;
+            float var = fmaxf(z2 - z1 * z1 / (float)T, 0.0f) / denom;
+            if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
+            stdv[(int64_t)b * ld_out + cg0 + tid] = sqrtf(var);
+        }
     }
 }
 

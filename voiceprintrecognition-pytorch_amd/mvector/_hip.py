@@ -90,6 +90,8 @@ _SIGNATURES = {
     'mv_res2net_chain_f16': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                              ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'mv_linear_f32': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'mv_profile_enable': (c_i32, [c_i32]),
+    'mv_profile_read': (c_i32, [c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32]),
     'mv_asp_pool_f16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
 }
