@@ -250,6 +250,7 @@ inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 

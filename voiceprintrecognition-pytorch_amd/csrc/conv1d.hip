@@ -21,6 +21,8 @@
 // of the activation tile; the weights are shared by everyone).
 #include "common.h"
 
+#include <type_traits>
+
 namespace mv {
 
 constexpr int CV_TC = 128;  // output channels per tile
@@ -142,6 +144,71 @@ __device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
 }
+
+#ifndef MV_EMU
+// ---- hand-scheduled K stage of the 256 x 256 tile (wave tile 128 x 64: 8 x 4 MFMA tiles, 2 K halves) ---------------
+// The compiler serialises "2 ds_read, s_waitcnt lgkmcnt(0), 8 MFMA" and so exposes an LDS round trip in front of every
+// group of MFMAs.  Here the stage is eight steps (K half, pair of channel tiles) in inline assembly: the two weight
+// fragments of step i+1 are requested BEFORE the counted wait and the 8 MFMAs of step i, so the round trip runs under
+// the matrix pipe.  Rules kept by construction: a fragment register is only re-targeted by a read that is issued after
+// the last MFMA that sources it; LDS returns in order, so lgkmcnt(2) = "everything but the two newest reads".
+// Fragment addresses: row * 128 + ((chunk ^ (row & 7)) << 4) with row = tile base + frow -- the swizzle term depends on
+// the lane and the K half only, the channel / time tile is an immediate multiple of 2048.
+#define MV_MFMA8(A0, A1)                                                                                       \
+    "v_mfma_f32_16x16x32_f16 %0, " A0 ", %10, %0\n\tv_mfma_f32_16x16x32_f16 %1, " A0 ", %11, %1\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %2, " A0 ", %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, " A0 ", %13, %3\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %4, " A1 ", %10, %4\n\tv_mfma_f32_16x16x32_f16 %5, " A1 ", %11, %5\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %6, " A1 ", %12, %6\n\tv_mfma_f32_16x16x32_f16 %7, " A1 ", %13, %7"
+
+template <int WAIT>
+__device__ __forceinline__ void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%14)\n\t" MV_MFMA8("%8", "%9")
+                 : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3])
+                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT));
+}
+
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(d0), "=&v"(d1) : "v"(addr), "n"(OFF0), "n"(OFF1));
+}
+
+__device__ __forceinline__ void lds_read4(half8v (&d)[4], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(addr));
+}
+
+// wt / xtile: LDS byte addresses of the stage's weight and activation tiles
+__device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int wc, int wn, int lane, float4v (&acc)[8][4]) {
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const unsigned arow = wt + (wc * 128 + frow) * 128, brow = xtile + (wn * 64 + frow) * 128;
+    const unsigned sw0 = (unsigned)((fchunk ^ (frow & 7)) << 4), sw1 = (unsigned)(((4 + fchunk) ^ (frow & 7)) << 4);
+    const unsigned a0 = arow + sw0, a1 = arow + sw1, b0 = brow + sw0, b1 = brow + sw1;
+    half8v af[2][2], bf[4];
+    // K half 0
+    lds_read4(bf, b0);
+    lds_read2<0, 2048>(af[0][0], af[0][1], a0);
+    lds_read2<4096, 6144>(af[1][0], af[1][1], a0);
+    mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf);
+    lds_read2<8192, 10240>(af[0][0], af[0][1], a0);
+    mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf);
+    lds_read2<12288, 14336>(af[1][0], af[1][1], a0);
+    mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf);
+    lds_read2<0, 2048>(af[0][0], af[0][1], a1);  // first pair of K half 1: its registers were last sourced by the step above
+    mfma8_step<2>(acc[6], acc[7], af[1][0], af[1][1], bf);
+    // K half 1: the activation fragments are single-buffered, so they are re-targeted only now
+    lds_read4(bf, b1);
+    lds_read2<4096, 6144>(af[1][0], af[1][1], a1);
+    mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf);
+    lds_read2<8192, 10240>(af[0][0], af[0][1], a1);
+    mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf);
+    lds_read2<12288, 14336>(af[1][0], af[1][1], a1);
+    mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf);
+    mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf);
+    // MFMA results are read by VALU code (epilogue) only after a barrier and a round of transfers; pad the hazard anyway
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+}
+#endif
 
 // lane holds channels co..co+3 (rows) of time step n (column); cout is a multiple of 4, so a lane's four channels are
 // all valid or all invalid and every per-channel parameter is one float4 load (uniform branches only).
@@ -468,12 +535,15 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     }
 }
 
+// SIMPLE = 1x1 convolution whose input channels fill whole K stages (cin % 64 == 0): the row pointers depend on the tile
+// only and there is no tap / partial-block logic in the K loop.
+template <bool SIMPLE>
 __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a) {
     constexpr int WN = 4, MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / WN, wn = wave % WN;
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ (lrow & 7);
@@ -487,6 +557,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     RowMap rm[NTX];
     const half_t* wsrc[NTW];
     int l_vb = blockIdx.x, l_n0 = 0, l_co0 = 0, l_ps = 0;
+    int l_tap = -1;  // tap the activation row pointers below belong to
 
     auto advance = [&](int vb) {  // first valid tile at or after vb (stride gridDim.x); sets the loader state
         int n_tile = 0, co_tile = 0;
@@ -495,6 +566,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         if (vb >= total) return false;
         l_n0 = n_tile * TN;
         l_co0 = co_tile * TC;
+        l_tap = -1;  // new rows: the row pointers are rebuilt by the next issue()
 #pragma unroll
         for (int i = 0; i < NTX; ++i) {
             const int n = l_n0 + (wave * NTX + i) * 8 + lrow;
@@ -514,22 +586,36 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         return true;
     };
 
+    // Row pointers of this lane's activation transfers for the loader's current tap (zero page for padded / missing
+    // rows): a stage then costs one select and one 64-bit add per transfer instead of the full index arithmetic.
+    const half_t* xrow[NTX];
+    bool xok[NTX];
+    const bool full_k = (a.cin % CV_BK) == 0;  // no partial channel block at the end of a tap
     auto issue = [&](int s, int buf) {
         char* wt = smem + buf * CVP_STAGE_BYTES;
         char* xtile = wt + TC * CV_BK * 2;
-        const int tap = s / kstages_per_tap;
+        const int tap = SIMPLE ? 0 : s / kstages_per_tap;
         const int c0 = (s - tap * kstages_per_tap) * CV_BK;
-        const int c = c0 + kc * 8;
-        const bool ch_ok = c < a.cin;
+        if (tap != l_tap) {  // uniform: once per tile for 1x1 convolutions
+            l_tap = tap;
 #pragma unroll
-        for (int i = 0; i < NTX; ++i) {
-            const int tin = input_time(a, rm[i].t, tap);
-            const half_t* src = zero;
-            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
-            glds16(src, xtile + (wave * NTX + i) * 1024);
+            for (int i = 0; i < NTX; ++i) {
+                const int tin = input_time(a, rm[i].t, tap);
+                xok[i] = rm[i].b >= 0 && tin >= 0;
+                xrow[i] = xok[i] ? xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + kc * 8 : zero;
+            }
         }
+        if (SIMPLE || full_k) {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) glds16(wsrc[i] + (int64_t)tap * a.cin_pad + c0, wt + (wave * NTW + i) * 1024);
+            for (int i = 0; i < NTX; ++i) glds16(xrow[i] + (xok[i] ? c0 : 0), xtile + (wave * NTX + i) * 1024);
+        } else {
+            const bool ch_ok = c0 + kc * 8 < a.cin;
+#pragma unroll
+            for (int i = 0; i < NTX; ++i) glds16((xok[i] && ch_ok) ? xrow[i] + c0 : zero, xtile + (wave * NTX + i) * 1024);
+        }
+        const int64_t woff = SIMPLE ? (int64_t)c0 : (int64_t)tap * a.cin_pad + c0;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) glds16(wsrc[i] + woff, wt + (wave * NTW + i) * 1024);
     };
 
     // waves 0..2 fetch bias / scale / shift of the loader's tile (256 floats = 1 KiB each); absent arrays are replaced
@@ -559,32 +645,47 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     float4v acc[MI][NI];
     bool pending = false, more = true;
     int e_n0 = 0, e_co0 = 0, e_ps = 0;
+#ifndef MV_EMU
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address
+#endif
+    // One K stage.  FIRST / LAST are compile-time for the peeled copies, so the steady-state body (neither) is: wait,
+    // barrier, request stage s+1, 64 MFMAs -- no tile bookkeeping, no branches.
+    auto stage = [&](int s, auto first, auto last) {
+        wait_all_loads();
+        __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
+        if (!decltype(last)::value) {
+            issue(s + 1, buf ^ 1);
+        } else {
+            more = advance(l_vb + gridDim.x);
+            if (more) {
+                l_ps = l_ps == 2 ? 0 : l_ps + 1;
+                issue(0, buf ^ 1);
+                issue_params();
+            }
+        }
+        if (decltype(first)::value) {
+            if (pending) persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#ifdef MV_EMU
+        const char* wt = smem + buf * CVP_STAGE_BYTES;
+        mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+#else
+        const unsigned wt = smem_base + buf * CVP_STAGE_BYTES;
+        mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+#endif
+        buf ^= 1;
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
     while (more) {
         const int c_n0 = l_n0, c_co0 = l_co0, c_ps = l_ps;
-        for (int s = 0; s < nstages; ++s) {
-            wait_all_loads();
-            __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
-            if (s + 1 < nstages) {
-                issue(s + 1, buf ^ 1);
-            } else {
-                more = advance(l_vb + gridDim.x);
-                if (more) {
-                    l_ps = l_ps == 2 ? 0 : l_ps + 1;
-                    issue(0, buf ^ 1);
-                    issue_params();
-                }
-            }
-            if (s == 0) {
-                if (pending) persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-            const char* wt = smem + buf * CVP_STAGE_BYTES;
-            mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
-            buf ^= 1;
-        }
+        stage(0, yes{}, no{});  // nstages >= 2 (the launcher keeps single-stage problems on the one-shot kernel)
+        for (int s = 1; s + 1 < nstages; ++s) stage(s, no{}, no{});
+        stage(nstages - 1, no{}, yes{});
         e_n0 = c_n0;
         e_co0 = c_co0;
         e_ps = c_ps;
@@ -847,7 +948,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
                          (d.pre_act == MV_ACT_NONE || d.pre_act == MV_ACT_RELU) &&
-                         (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) && persistent_blocks() > 0;
+                         (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) && persistent_blocks() > 0 &&
+                         (int64_t)d.k * conv1d_cin_pad(d.cin) >= 2 * CV_BK;  // at least two K stages per tile
     // 128 x 160 tile of the direct path: two workgroups per CU = 2 * CUs slots; taken when it saves a whole round of
     // workgroups (B*T = 76 288 rows x 128 channels: 477 tiles in one round instead of 596 tiles in two)
     const bool direct = f16 && !has_x2 && !in_aff;
@@ -872,7 +974,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel, CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel<true>, CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel<false>, CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
@@ -883,7 +986,11 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
-        MV_LAUNCH(conv1d_glds_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        if (d.k == 1 && d.cin % CV_BK == 0) {
+            MV_LAUNCH(conv1d_glds_persistent_kernel<true>, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        } else {
+            MV_LAUNCH(conv1d_glds_persistent_kernel<false>, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        }
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (wide) {
