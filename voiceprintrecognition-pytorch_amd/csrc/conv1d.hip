@@ -164,22 +164,31 @@ template <int WAIT>
 __device__ __forceinline__ void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%14)\n\t" MV_MFMA8("%8", "%9")
                  : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3])
-                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT));
+                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
+                 : "memory");
 }
 
 template <int OFF0, int OFF1>
 __device__ __forceinline__ void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(d0), "=&v"(d1) : "v"(addr), "n"(OFF0), "n"(OFF1));
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(d0), "=&v"(d1)
+                 : "v"(addr), "n"(OFF0), "n"(OFF1)
+                 : "memory");
 }
 
 __device__ __forceinline__ void lds_read4(half8v (&d)[4], unsigned addr) {
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
-                 : "v"(addr));
+                 : "v"(addr)
+                 : "memory");
 }
 
-// wt / xtile: LDS byte addresses of the stage's weight and activation tiles
-__device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int wc, int wn, int lane, float4v (&acc)[8][4]) {
+// wt / xtile: LDS byte addresses of the stage's weight and activation tiles.  between(i), i = 0..7, runs between the
+// fragment requests and the (counted wait +) MFMAs of step i: the caller issues one of the next stage's eight global->LDS transfers there,
+// so the ~80 cycles each transfer spends entering the texture path pass while the matrix pipe works off queued MFMAs
+// instead of in front of them (a K stage otherwise starts with ~640 cycles of transfer issue and an idle matrix pipe).
+template <class F>
+__device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int wc, int wn, int lane, float4v (&acc)[8][4], F&& between) {
     const int frow = lane & 15, fchunk = lane >> 4;
     const unsigned arow = wt + (wc * 128 + frow) * 128, brow = xtile + (wn * 64 + frow) * 128;
     const unsigned sw0 = (unsigned)((fchunk ^ (frow & 7)) << 4), sw1 = (unsigned)(((4 + fchunk) ^ (frow & 7)) << 4);
@@ -189,21 +198,29 @@ __device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int w
     lds_read4(bf, b0);
     lds_read2<0, 2048>(af[0][0], af[0][1], a0);
     lds_read2<4096, 6144>(af[1][0], af[1][1], a0);
+    between(0);
     mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf);
     lds_read2<8192, 10240>(af[0][0], af[0][1], a0);
+    between(1);
     mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf);
     lds_read2<12288, 14336>(af[1][0], af[1][1], a0);
+    between(2);
     mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf);
     lds_read2<0, 2048>(af[0][0], af[0][1], a1);  // first pair of K half 1: its registers were last sourced by the step above
+    between(3);
     mfma8_step<2>(acc[6], acc[7], af[1][0], af[1][1], bf);
     // K half 1: the activation fragments are single-buffered, so they are re-targeted only now
     lds_read4(bf, b1);
     lds_read2<4096, 6144>(af[1][0], af[1][1], a1);
+    between(4);
     mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf);
     lds_read2<8192, 10240>(af[0][0], af[0][1], a1);
+    between(5);
     mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf);
     lds_read2<12288, 14336>(af[1][0], af[1][1], a1);
+    between(6);
     mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf);
+    between(7);
     mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf);
     // MFMA results are read by VALU code (epilogue) only after a barrier and a round of transfers; pad the hazard anyway
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -537,11 +554,26 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
 
 // SIMPLE = 1x1 convolution whose input channels fill whole K stages (cin % 64 == 0): the row pointers depend on the tile
 // only and there is no tap / partial-block logic in the K loop.
+// timing probe 3 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at four points of every stage
+#if defined(MV_PROBE) && MV_PROBE == 3
+__device__ unsigned long long g_trace[8192];
+__device__ int g_trace_n;
+#define MV_TRACE(tag)                                                                              \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && tid == 0 && trace_i < 8190) g_trace[trace_i++] = (__builtin_readcyclecounter() << 2) | (tag); \
+    } while (0)
+#else
+#define MV_TRACE(tag) ((void)0)
+#endif
+
 template <bool SIMPLE>
 __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a) {
     constexpr int WN = 4, MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x;
+#if defined(MV_PROBE) && MV_PROBE == 3
+    int trace_i = 0;
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / WN, wn = wave % WN;
@@ -591,9 +623,12 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     const half_t* xrow[NTX];
     bool xok[NTX];
     const bool full_k = (a.cin % CV_BK) == 0;  // no partial channel block at the end of a tap
-    auto issue = [&](int s, int buf) {
-        char* wt = smem + buf * CVP_STAGE_BYTES;
-        char* xtile = wt + TC * CV_BK * 2;
+    // prepare(s, buf): source pointers of this lane's eight transfers of stage s (4 activation + 4 weight row groups);
+    // dma(i) issues transfer i.  Stage s+1 is prepared at the top of stage s and its transfers are issued one per MFMA step.
+    const half_t* dsrc[NTX + NTW];
+    int dbuf = 0;
+    auto prepare = [&](int s, int buf) {
+        dbuf = buf;
         const int tap = SIMPLE ? 0 : s / kstages_per_tap;
         const int c0 = (s - tap * kstages_per_tap) * CV_BK;
         if (tap != l_tap) {  // uniform: once per tile for 1x1 convolutions
@@ -607,15 +642,25 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         }
         if (SIMPLE || full_k) {
 #pragma unroll
-            for (int i = 0; i < NTX; ++i) glds16(xrow[i] + (xok[i] ? c0 : 0), xtile + (wave * NTX + i) * 1024);
+            for (int i = 0; i < NTX; ++i) dsrc[i] = xrow[i] + (xok[i] ? c0 : 0);
         } else {
             const bool ch_ok = c0 + kc * 8 < a.cin;
 #pragma unroll
-            for (int i = 0; i < NTX; ++i) glds16((xok[i] && ch_ok) ? xrow[i] + c0 : zero, xtile + (wave * NTX + i) * 1024);
+            for (int i = 0; i < NTX; ++i) dsrc[i] = (xok[i] && ch_ok) ? xrow[i] + c0 : zero;
         }
         const int64_t woff = SIMPLE ? (int64_t)c0 : (int64_t)tap * a.cin_pad + c0;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) glds16(wsrc[i] + woff, wt + (wave * NTW + i) * 1024);
+        for (int i = 0; i < NTW; ++i) dsrc[NTX + i] = wsrc[i] + woff;
+    };
+    auto dma = [&](int i) {  // i < NTX: activation rows, else weight rows
+        char* wt = smem + dbuf * CVP_STAGE_BYTES;
+        char* dst = i < NTX ? wt + TC * CV_BK * 2 + (wave * NTX + i) * 1024 : wt + (wave * NTW + (i - NTX)) * 1024;
+        glds16(dsrc[i], dst);
+    };
+    auto issue = [&](int s, int buf) {
+        prepare(s, buf);
+#pragma unroll
+        for (int i = 0; i < NTX + NTW; ++i) dma(i);
     };
 
     // waves 0..2 fetch bias / scale / shift of the loader's tile (256 floats = 1 KiB each); absent arrays are replaced
@@ -652,17 +697,25 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     // barrier, request stage s+1, 64 MFMAs -- no tile bookkeeping, no branches.
     auto stage = [&](int s, auto first, auto last) {
         wait_all_loads();
+        MV_TRACE(0);
         __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
+        MV_TRACE(1);
+        bool feed = true;  // a stage (of this tile or the first of the next one) is requested during this stage
         if (!decltype(last)::value) {
-            issue(s + 1, buf ^ 1);
+            prepare(s + 1, buf ^ 1);
         } else {
             more = advance(l_vb + gridDim.x);
+            feed = more;
             if (more) {
                 l_ps = l_ps == 2 ? 0 : l_ps + 1;
-                issue(0, buf ^ 1);
+                prepare(0, buf ^ 1);
                 issue_params();
             }
         }
+#if defined(MV_PROBE) && MV_PROBE == 1   // timing probe 1 (tools/probe only): no global->LDS traffic inside a tile
+        if (!decltype(last)::value) feed = false;
+#endif
+        MV_TRACE(2);
         if (decltype(first)::value) {
             if (pending) persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
 #pragma unroll
@@ -670,13 +723,23 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
-#ifdef MV_EMU
+#if defined(MV_PROBE) && MV_PROBE == 2   // timing probe 2: no LDS reads / MFMAs
+        if (feed)
+            for (int i = 0; i < NTX + NTW; ++i) dma(i);
+#elif defined(MV_EMU)
+        if (feed)
+            for (int i = 0; i < NTX + NTW; ++i) dma(i);
         const char* wt = smem + buf * CVP_STAGE_BYTES;
         mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
 #else
         const unsigned wt = smem_base + buf * CVP_STAGE_BYTES;
-        mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+        if (decltype(last)::value) {
+            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) { if (feed) dma(i); });
+        } else {
+            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) { dma(i); });
+        }
 #endif
+        MV_TRACE(3);
         buf ^= 1;
     };
     using yes = std::integral_constant<bool, true>;
@@ -692,7 +755,22 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         pending = true;
     }
     persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+#if defined(MV_PROBE) && MV_PROBE == 3
+    MV_TRACE(0);
+    if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
+#endif
 }
+
+#if defined(MV_PROBE) && MV_PROBE == 3
+extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
+    int n = 0;
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(int));
+    n = n < max_n ? n : max_n;
+    hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), (size_t)n * sizeof(unsigned long long));
+    return n;
+}
+#endif
 
 // Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
 // r01h), a 256x256 tile with a 4-slot ring of 32-wide stages and counted vmcnt (500 / 775 TF, r01i -- no better than the
