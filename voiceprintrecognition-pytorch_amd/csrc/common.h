@@ -87,6 +87,23 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 }
 #endif
 
+// v_permlane16_swap (gfx950): the odd 16-lane rows of x trade places with the even rows of y
+//   x: row1 <- y.row0, row3 <- y.row2      y: row0 <- x.row1, row2 <- x.row3      (checked on the device: tools/permlane_probe.hip)
+__device__ __forceinline__ void row_swap_odd_even(unsigned& x, unsigned& y) {
+#ifdef MV_EMU
+    const int lane = emu::flat_tid() & 63;
+    const bool odd = (lane >> 4) & 1;
+    const unsigned from_y = emu::shfl_from(y, lane - 16), from_x = emu::shfl_from(x, lane + 16);  // out-of-row sources are unused
+    const unsigned nx = odd ? from_y : x, ny = odd ? y : from_x;
+    x = nx;
+    y = ny;
+#else
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+#endif
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);

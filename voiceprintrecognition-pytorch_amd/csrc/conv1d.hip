@@ -505,55 +505,59 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
 //     MFMAs overwrite the accumulators), so its stores drain under the next tile's K loop;
 //   * bias / scale / shift of a tile arrive by LDS-DMA with its first stage (three rotating 3 KiB slots), so the
 //     epilogue issues no vector loads that would have to queue behind the stage loads;
-//   * the output goes through a wave-private 2 KiB staging block (16 time steps x 64 channels, XOR-swizzled) and
-//     leaves as 16-byte stores covering whole 128-byte row segments; no workgroup barrier in the epilogue.
+//   * the output leaves straight from the accumulators as 16-byte stores (v_permlane16_swap pairs up adjacent channel
+//     tiles so that a lane owns 8 consecutive channels); no LDS staging, no barrier in the epilogue.
 constexpr int CVP_STAGE_BYTES = 65536;
 constexpr int CVP_PARAM_OFF = 2 * CVP_STAGE_BYTES;
 constexpr int CVP_PARAM_SLOT = 3 * 1024;
-constexpr int CVP_STAGING_OFF = CVP_PARAM_OFF + 3 * CVP_PARAM_SLOT;
-constexpr int CVP_LDS_BYTES = CVP_STAGING_OFF + 8 * 2048;  // 156 672 B of the 160 KiB
+constexpr int CVP_LDS_BYTES = CVP_PARAM_OFF + 3 * CVP_PARAM_SLOT;  // 140 288 B of the 160 KiB
 
+// Epilogue of the persistent kernel, straight from the accumulators to 16-byte stores -- no LDS staging, no fences.
+// A lane holds channels 4q..4q+3 (q = lane >> 4) of one time step r (= lane & 15) for each of its 8 channel tiles.  For a
+// pair of adjacent tiles (A, B) two v_permlane16_swap per register pair hand every even 16-lane row the second half of
+// tile A's channels and every odd row the first half of tile B's, so each lane ends up with 8 CONSECUTIVE channels:
+//   rows q even: A: 4q .. 4q+7           rows q odd: B: 4(q-1) .. 4(q-1)+7
+// and one store instruction writes, per time step, the 64 contiguous bytes of channels A*16 .. A*16+31.
 __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* smem, int n0, int co0, int pslot, int wc, int wn,
                                                     int wave, int lane, float4v (&acc)[8][4]) {
+    (void)wave;
     const char* par = smem + CVP_PARAM_OFF + pslot * CVP_PARAM_SLOT;
-    char* stg = smem + CVP_STAGING_OFF + wave * 2048;
     const int r = lane & 15, q = lane >> 4;
     half_t* y = reinterpret_cast<half_t*>(a.y);
-    const int rrow = lane >> 3, rch = lane & 7;
     // host admits none / ReLU only: max(v, -inf) is the identity
     const float lo_pre = a.pre_act == MV_ACT_RELU ? 0.0f : -INFINITY, lo_post = a.post_act == MV_ACT_RELU ? 0.0f : -65504.0f;
+    auto finish = [&](const float4v& c, int mi) {  // bias, activation, BatchNorm affine, saturation -> 4 fp16 in 2 registers
+        const int col = wc * 128 + mi * 16 + 4 * q;
+        float4v v = c + *reinterpret_cast<const float4v*>(par + col * 4);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
+        v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
+        half4v hv;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation + fp16 saturation: one v_med3
+        return hv;
+    };
+    const int ch_lane = (q & 1) * 16 + 4 * (q & ~1);  // first channel of this lane inside the 32-channel pair
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int col = wc * 128 + (h * 4 + m) * 16 + 4 * q;
-                float4v v = acc[h * 4 + m][ni] + *reinterpret_cast<const float4v*>(par + col * 4);
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + r;
+        half_t* yrow = y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
-                v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
-                half4v hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation and fp16 saturation in one v_med3
-                const int pc = (m * 2 + (q >> 1)) ^ ((r >> 1) & 7);
-                *reinterpret_cast<half4v*>(stg + r * 128 + pc * 16 + (q & 1) * 8) = hv;
-            }
-            MV_WAVE_FENCE();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = rrow + 8 * j;
-                const half8v o = *reinterpret_cast<const half8v*>(stg + row * 128 + ((rch ^ ((row >> 1) & 7)) << 4));
-                const int n = n0 + wn * 64 + ni * 16 + row;
-                if (n < a.n_rows) *reinterpret_cast<half8v*>(y + (int64_t)n * a.ldy + co0 + wc * 128 + h * 64 + rch * 8) = o;
-            }
-            MV_WAVE_FENCE();
+        for (int p = 0; p < 4; ++p) {
+            const half4v ha = finish(acc[2 * p][ni], 2 * p), hb = finish(acc[2 * p + 1][ni], 2 * p + 1);
+            unsigned xa[2], xb[2];
+            __builtin_memcpy(xa, &ha, 8);
+            __builtin_memcpy(xb, &hb, 8);
+            row_swap_odd_even(xa[0], xb[0]);
+            row_swap_odd_even(xa[1], xb[1]);
+            const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
+            half8v ov;
+            __builtin_memcpy(&ov, o, 16);
+            if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
         }
     }
 }
 
-// SIMPLE = 1x1 convolution whose input channels fill whole K stages (cin % 64 == 0): the row pointers depend on the tile
-// only and there is no tap / partial-block logic in the K loop.
 // timing probe 3 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at four points of every stage
 #if defined(MV_PROBE) && MV_PROBE == 3
 __device__ unsigned long long g_trace[8192];
@@ -772,6 +776,14 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 }
 #endif
 
+// Measured dead ends of the persistent kernel (r01s..r01v logs under profiles/): touching the lines of stage s+3 with one
+// 4-byte load each to pull them into L2 early (slower: the touches sit in the same in-order vmcnt queue); a 4-wave layout
+// with 128 x 128 wave tiles and the accumulators in AccVGPRs (a third less LDS traffic, but one wave per SIMD: 7 % slower on
+// K = 3072, 24 % on K = 1024); a counted vmcnt wait that lets the epilogue's stores drain across the next stage (neutral);
+// starting the eight XCDs ~1 us apart to break up the 32 MiB store burst of the lockstep epilogues (slower).  The in-kernel
+// timeline (MV_PROBE=3, tools/trace_conv.py) shows per K stage ~400 cycles barrier skew, ~1650 cycles MFMA issue per wave
+// (two waves share a SIMD's matrix pipe: 2048 busy cycles) and 1000-2000 cycles until the next stage has landed.
+//
 // Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
 // r01h), a 256x256 tile with a 4-slot ring of 32-wide stages and counted vmcnt (500 / 775 TF, r01i -- no better than the
 // double buffer), padded leading dimensions (r01k, no effect).  Probes with the K loop reduced to its loads or to its
@@ -1022,7 +1034,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
     const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
-    // persistent form of the 256^2 kernel: fp16 output through the wave-private staged epilogue
+    // persistent form of the 256^2 kernel: fp16 output, plain bias / ReLU / affine epilogue
     const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
                          (d.pre_act == MV_ACT_NONE || d.pre_act == MV_ACT_RELU) &&
