@@ -75,6 +75,13 @@ int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_fram
 int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                      const float* lens_ratio, float* out, mv_stream_t stream);
 
+/* Variable-length batch: row b holds num_samples[b] <= L valid samples (device array, int64).  Every utterance is
+ * featurised on its own -- frame count, time mean -- and rows beyond its frame count are zero in the [B, T(L), F] output:
+ * the result of the reference's evaluation path, which featurises per utterance (mvector/data_utils/reader.py:100-106)
+ * and zero-pads the features (collate_fn.py:11-19). */
+int mv_fbank_forward_varlen(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
+                            const int64_t* num_samples, float* out, mv_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Front-end 2: MelSpectrogram (power STFT, centre/reflect padding, HTK mel filterbank, NO log) +
  * time-mean subtraction + mask.  Replaces torchaudio.transforms.MelSpectrogram(**method_args)

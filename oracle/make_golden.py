@@ -12,6 +12,7 @@ into the reference modules and stores
 * ``<case>.npz``            -- input features and the reference's output embedding (+ a few
                                intermediate activations for the small cases),
 * ``cosine.npz``            -- sklearn ``cosine_similarity`` on seeded embeddings,
+* ``metrics.npz``           -- the reference's ``compute_fnr_fpr`` / ``compute_eer`` / ``compute_dcf`` on seeded trial scores,
 * ``frontend.npz``          -- front-end outputs.  torchaudio cannot be imported here, so these
                                come from the oracle restatement itself cross-checked (at
                                generation time, asserted below) against
@@ -157,5 +158,25 @@ def main():
     print('done ->', GOLDEN)
 
 
+def save_metrics_golden():
+    """mvector/metric/metrics.py of the reference, loaded by path (it only needs numpy / torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_metrics', os.path.join(REF, 'mvector', 'metric', 'metrics.py'))
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    rng = np.random.default_rng(7)
+    out = {}
+    for name, n, p_tgt in (('small', 60, 0.3), ('large', 20000, 0.05)):
+        labels = (rng.random(n) < p_tgt).astype(np.int32)
+        scores = (rng.normal(0.15, 0.18, n) + labels * 0.4).astype(np.float32)
+        fnr, fpr, thr = rm.compute_fnr_fpr(scores, labels)
+        eer, eer_thr = rm.compute_eer(fnr, fpr, scores)
+        out.update({f'{name}_scores': scores, f'{name}_labels': labels, f'{name}_fnr': fnr, f'{name}_fpr': fpr,
+                    f'{name}_thresholds': thr, f'{name}_eer': np.float64(eer), f'{name}_eer_threshold': np.float64(eer_thr),
+                    f'{name}_min_dcf': np.float64(rm.compute_dcf(fnr, fpr))})
+    np.savez_compressed(os.path.join(GOLDEN, 'metrics.npz'), **out)
+
+
 if __name__ == '__main__':
     main()
+    save_metrics_golden()

@@ -9,6 +9,7 @@ import torch
 
 import layer_checks as lc
 from emu_lib import emu_cdll
+from mvector import _hip
 from helpers import GOLDEN
 from oracle import frontend
 
@@ -102,6 +103,23 @@ def test_emu_asp_pool(cfg):
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1)])
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
+
+
+def test_emu_fbank_variable_length_batch():
+    """mv_fbank_forward_varlen: own frame count and time mean per row, zero rows behind it (reader.py:100-106 + collate_fn.py)"""
+    wav = frontend.synth_waveforms(4, 2400, seed=17)
+    lens = torch.tensor([2400, 1999, 400, 120])
+    padded = wav.clone()
+    for i, n in enumerate(lens):
+        padded[i, n:] = -0.5
+    out = _hip.Fbank(FB, cdll=emu_cdll())(padded, None, lens)
+    assert out.shape == (4, 13, 80)
+    for i, n in enumerate(lens.tolist()):
+        if n < 400:
+            assert out[i].abs().sum() == 0
+            continue
+        ref = frontend.audio_featurizer(wav[i, :n].unsqueeze(0), None, 'Fbank', FB)[0]
+        assert (out[i, :ref.shape[0]] - ref).abs().max() < 2e-3 and out[i, ref.shape[0]:].abs().sum() == 0
 
 
 def test_emu_fbank_odd_window_length():

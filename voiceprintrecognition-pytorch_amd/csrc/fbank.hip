@@ -123,6 +123,7 @@ struct FbankArgs {
     const float* wav;
     int64_t wav_stride;
     const float* lens_ratio;
+    const int64_t* num_samples;  // optional [B]: true length of every row (<= L); rows are featurised independently
     float* out;
     int B, T;
     int win, shift, nbins;
@@ -179,7 +180,16 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     const int l16 = lane & 15;   // n2 in stage 1, k1 in stage 2
     const int fs = lane >> 4;    // frame slot inside the wave
     const int b = blockIdx.x;
-    const int T = a.T;
+    // Variable-length batch (num_samples given): utterance b has its own frame count Tb; its time mean runs over those
+    // frames only and rows Tb..T-1 of its output block are zero -- exactly what the reference's evaluation path produces
+    // by featurising every utterance alone and zero-padding the features (reader.py:102, collate_fn.py:11-19).
+    const int Tout = a.T;  // rows of the output block
+    int T = a.T;
+    if (a.num_samples != nullptr) {
+        const int64_t ns = a.num_samples[b];
+        const int64_t tb = ns < a.win ? 0 : 1 + (ns - a.win) / a.shift;
+        T = (int)(tb < a.T ? tb : a.T);
+    }
     const int nbins = a.nbins;
 
     for (int i = tid; i < 512; i += FB_THREADS) {
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     float* pslot = wslots + fs * FB_SLOT_FLOATS;
     cplx* slot = reinterpret_cast<cplx*>(pslot);
     const float* wrow = a.wav + (int64_t)b * a.wav_stride;
-    float* orow = a.out + (int64_t)b * T * nbins;
+    float* orow = a.out + (int64_t)b * Tout * nbins;
 
     // mel stage: this lane is (block = lane/4, j = lane%4): A operand = power of frame j, D = filter 4*(16*pass + block) + j
     const float* arow = wslots + (lane & 3) * FB_SLOT_FLOATS;
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         MV_WAVE_FENCE();  // the power spectra have been consumed before the next quad's transposes overwrite them
     }
 
-    if (!a.cmn && a.lens_ratio == nullptr) return;
+    if (!a.cmn && a.lens_ratio == nullptr && a.num_samples == nullptr) return;
 
     // ---- per-utterance time mean (featurizer.py:79): lane = filter already, reduce over waves ----
     __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < FB_WAVES; ++w) v += colsum[w * 128 + tid];
-        mean[tid] = a.cmn ? v / (float)T : 0.0f;
+        mean[tid] = (a.cmn && T > 0) ? v / (float)T : 0.0f;
     }
     __syncthreads();  // also orders this workgroup's global stores before the reads below
     // ---- second pass over the rows this workgroup wrote: subtract mean, apply the length mask ----
@@ -431,14 +441,14 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         const int r0 = tid / q, cg = tid - r0 * q;
         if (r0 < rows_per_pass) {
             const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
-            for (int t = r0; t < T; t += rows_per_pass) {
+            for (int t = r0; t < Tout; t += rows_per_pass) {  // rows T..Tout-1 of a shorter utterance become zeros
                 float4v* p = reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg;
                 const float4v v = *p - m4;
                 *p = t < mask_len ? v : float4v{0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
     } else {
-        const int total = T * nbins;
+        const int total = Tout * nbins;
         for (int e = tid; e < total; e += FB_THREADS) {
             const int t = e / nbins;
             const int m = e - t * nbins;
@@ -708,8 +718,22 @@ int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_fram
     return MV_OK;
 }
 
+static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
+                              const int64_t* num_samples, float* out, mv_stream_t stream);
+
 int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                      const float* lens_ratio, float* out, mv_stream_t stream) {
+    return fbank_forward_impl(h, wav, B, L, wav_stride, lens_ratio, nullptr, out, stream);
+}
+
+int mv_fbank_forward_varlen(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
+                            const int64_t* num_samples, float* out, mv_stream_t stream) {
+    MV_REQUIRE(num_samples != nullptr, "mv_fbank_forward_varlen: null length array");
+    return fbank_forward_impl(h, wav, B, L, wav_stride, nullptr, num_samples, out, stream);
+}
+
+static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
+                              const int64_t* num_samples, float* out, mv_stream_t stream) {
     MV_REQUIRE(h != nullptr, "mv_fbank_forward: null handle");
     MV_REQUIRE(B >= 0 && L >= 0 && wav_stride >= L, "mv_fbank_forward: bad batch geometry");
     int64_t T = 0;
@@ -721,6 +745,7 @@ int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, i
     a.wav = wav;
     a.wav_stride = wav_stride;
     a.lens_ratio = lens_ratio;
+    a.num_samples = num_samples;
     a.out = out;
     a.B = B;
     a.T = (int)T;

@@ -69,6 +69,7 @@ _SIGNATURES = {
     'mv_fbank_destroy': (c_i32, [c_vp]),
     'mv_fbank_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     'mv_fbank_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'mv_fbank_forward_varlen': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'mv_melspec_default_cfg': (None, [ctypes.POINTER(MvMelSpecCfg)]),
     'mv_melspec_create': (c_i32, [ctypes.POINTER(MvMelSpecCfg), ctypes.POINTER(c_vp)]),
     'mv_melspec_destroy': (c_i32, [c_vp]),
@@ -192,14 +193,22 @@ class Fbank:
         check(self._cdll.mv_fbank_num_frames(self._h, num_samples, ctypes.byref(t)), self._cdll)
         return t.value
 
-    def __call__(self, wav, lens_ratio=None):
+    def __call__(self, wav, lens_ratio=None, num_samples=None):
+        """wav [B, L] fp32 -> [B, T(L), F].  ``lens_ratio``: the reference's batched semantics (mean over all T frames,
+        then mask).  ``num_samples`` (int64 [B]): every row featurised on its own length, zero rows beyond it."""
         assert wav.dim() == 2 and wav.dtype == torch.float32
+        assert lens_ratio is None or num_samples is None
         if wav.stride(1) != 1:
             wav = wav.contiguous()
         B, L = wav.shape
         T = self.num_frames(L)
         out = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=wav.device)
         if B == 0 or T == 0:
+            return out
+        if num_samples is not None:
+            num_samples = num_samples.to(device=wav.device, dtype=torch.int64).contiguous()
+            check(self._cdll.mv_fbank_forward_varlen(self._h, wav.data_ptr(), B, L, wav.stride(0), num_samples.data_ptr(), out.data_ptr(),
+                                                     current_stream(wav)), self._cdll)
             return out
         if lens_ratio is not None:
             lens_ratio = lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()

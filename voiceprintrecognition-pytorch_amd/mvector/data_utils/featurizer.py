@@ -74,6 +74,23 @@ class AudioFeaturizer(nn.Module):
                 return self._handle(waveforms.device)(waveforms, input_lens_ratio)
         return _cpu_frontend.featurize(waveforms, input_lens_ratio, self._feature_method, self._method_args)
 
+    def forward_varlen(self, waveforms, num_samples):
+        """Zero-padded waveforms [B, L] + true lengths int64 [B] -> [B, T(L), feature_dim]: every row is featurised on its
+        own length (own frame count, own time mean) and rows beyond it are zero -- what the reference's evaluation path
+        gets from per-utterance featurisation + ``collate_fn`` padding, in one launch (Fbank only on the GPU)."""
+        if waveforms.dtype != torch.float32:
+            waveforms = waveforms.float()
+        if waveforms.is_cuda and self._feature_method == 'Fbank':
+            with torch.cuda.device(waveforms.device):
+                return self._handle(waveforms.device)(waveforms, None, num_samples)
+        T = self.forward(waveforms[:1]).size(1)
+        out = torch.zeros((waveforms.size(0), T, self.feature_dim), dtype=torch.float32, device=waveforms.device)
+        for i in range(waveforms.size(0)):
+            n = int(num_samples[i])
+            f = self.forward(waveforms[i, :n])
+            out[i, :f.size(1)] = f[0]
+        return out
+
     @property
     def feature_dim(self):
         if self._feature_method == 'MelSpectrogram':
