@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1w
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/r1w/pytest_gpu.log
-timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 | tee gpurun_out/r1w/bench.log | cut -c1-200
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1y
+(echo "8 steps (product)"; timeout 600 python tools/bench_conv.py 2>&1 | grep -E "c2c 1024|mfa 3072" | grep '"tile": 256'
+for N in 4 2 1; do echo "transfers spread over $N steps"; MV_PROBE_LIB=tools/probe/libconv1d_probe1$N.so timeout 600 python tools/bench_conv.py 2>&1 | grep -E "c2c 1024|mfa 3072" | grep '"tile": 256'; done) | tee gpurun_out/r1y/conv_dma_steps.log

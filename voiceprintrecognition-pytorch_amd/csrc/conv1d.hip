@@ -507,6 +507,9 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
 //     epilogue issues no vector loads that would have to queue behind the stage loads;
 //   * the output leaves straight from the accumulators as 16-byte stores (v_permlane16_swap pairs up adjacent channel
 //     tiles so that a lane owns 8 consecutive channels); no LDS staging, no barrier in the epilogue.
+#ifndef CVP_DMA_STEPS
+#define CVP_DMA_STEPS 4
+#endif
 constexpr int CVP_STAGE_BYTES = 65536;
 constexpr int CVP_PARAM_OFF = 2 * CVP_STAGE_BYTES;
 constexpr int CVP_PARAM_SLOT = 3 * 1024;
@@ -737,10 +740,20 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
 #else
         const unsigned wt = smem_base + buf * CVP_STAGE_BYTES;
+        // CVP_DMA_STEPS = over how many of the 8 MFMA steps the 8 transfers are spread (8: one per step; 4: two per step
+        // in the first half, so the youngest transfer has half a stage more to land)
         if (decltype(last)::value) {
-            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) { if (feed) dma(i); });
+            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) {
+                if (feed && i < CVP_DMA_STEPS)
+                    for (int u = 0; u < 8 / CVP_DMA_STEPS; ++u) dma(i * (8 / CVP_DMA_STEPS) + u);
+            });
         } else {
-            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) { dma(i); });
+            mma_stage_8x4(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc, [&](int i) {
+                if (i < CVP_DMA_STEPS) {
+#pragma unroll
+                    for (int u = 0; u < 8 / CVP_DMA_STEPS; ++u) dma(i * (8 / CVP_DMA_STEPS) + u);
+                }
+            });
         }
 #endif
         MV_TRACE(3);
