@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1y
-(echo "8 steps (product)"; timeout 600 python tools/bench_conv.py 2>&1 | grep -E "c2c 1024|mfa 3072" | grep '"tile": 256'
-for N in 4 2 1; do echo "transfers spread over $N steps"; MV_PROBE_LIB=tools/probe/libconv1d_probe1$N.so timeout 600 python tools/bench_conv.py 2>&1 | grep -E "c2c 1024|mfa 3072" | grep '"tile": 256'; done) | tee gpurun_out/r1y/conv_dma_steps.log
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1z
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+timeout 600 python tools/bench_conv.py 2>&1 | grep -E "asp|res2|c2c 512" | tee gpurun_out/r1z/conv.log
+for m in ecapa1024 campp; do timeout 600 python bench.py --model $m --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['workload'][:20], d['value'], d['ms_per_step'], d['parity']['max_one_minus_cos'], d['roofline']['achieved'])"; done

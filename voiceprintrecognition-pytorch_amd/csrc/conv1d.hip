@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     if (!tile_of_block(a, n_tile, co_tile)) return;  // whole workgroup leaves before any barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / WN, wn = wave % WN;
     const int n0 = n_tile * TN;
     const int co0 = co_tile * TC;
@@ -446,25 +446,32 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     const int kstages_per_tap = a.cin_pad / CV_BK;
     const int nstages = a.k * kstages_per_tap;
 
+    // Row pointers of this lane's activation transfers for the current tap (zero page for padded / missing rows), rebuilt
+    // when the tap changes: a stage then costs a select and a 64-bit add per transfer instead of the full index arithmetic.
+    const half_t* xrow[NTX];
+    bool xok[NTX];
+    int cur_tap = -1;
+    const bool full_k = (a.cin % CV_BK) == 0;  // no partial channel block at the end of a tap
     auto issue = [&](int s, int buf) {
         char* wt = smem + buf * STAGE_BYTES;
         char* xtile = wt + TC * CV_BK * 2;
         const int tap = s / kstages_per_tap;
         const int c0 = (s - tap * kstages_per_tap) * CV_BK;
-        const int c = c0 + kc * 8;
-        const bool ch_ok = c < a.cin;
+        if (tap != cur_tap) {  // uniform
+            cur_tap = tap;
 #pragma unroll
-        for (int i = 0; i < NTX; ++i) {
-            const int tin = input_time(a, rm[i].t, tap);
-            const half_t* src = zero;
-            if (rm[i].b >= 0 && tin >= 0 && ch_ok) src = xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + c;
-            glds16(src, xtile + (wave * NTX + i) * 1024);
+            for (int i = 0; i < NTX; ++i) {
+                const int tin = input_time(a, rm[i].t, tap);
+                xok[i] = rm[i].b >= 0 && tin >= 0;
+                xrow[i] = xok[i] ? xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + kc * 8 : zero;
+            }
         }
+        const bool ch_ok = full_k || c0 + kc * 8 < a.cin;
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const half_t* src = wsrc[i] != nullptr ? wsrc[i] + (int64_t)tap * a.cin_pad + c0 : zero;
-            glds16(src, wt + (wave * NTW + i) * 1024);
-        }
+        for (int i = 0; i < NTX; ++i) glds16((xok[i] && ch_ok) ? xrow[i] + c0 : zero, xtile + (wave * NTX + i) * 1024);
+        const int64_t woff = (int64_t)tap * a.cin_pad + c0;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) glds16(wsrc[i] != nullptr ? wsrc[i] + woff : zero, wt + (wave * NTW + i) * 1024);
     };
 
     float4v acc[MI][NI];
