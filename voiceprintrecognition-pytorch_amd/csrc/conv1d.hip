@@ -821,10 +821,16 @@ template <>
 struct RawChunk<float> {
     float4v lo, hi;
 };
-__device__ __forceinline__ void load_raw(RawChunk<half_t>& r, const half_t* p) { r.v = *reinterpret_cast<const half8v*>(p); }
+// (pointer selects between a tensor and the zero page lose the address space: state it, or the loads become FLAT loads)
+#ifdef MV_EMU
+#define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)
+#else
+#define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#endif
+__device__ __forceinline__ void load_raw(RawChunk<half_t>& r, const half_t* p) { r.v = *MV_GLOBAL_PTR(half8v, p); }
 __device__ __forceinline__ void load_raw(RawChunk<float>& r, const float* p) {
-    r.lo = *reinterpret_cast<const float4v*>(p);
-    r.hi = *reinterpret_cast<const float4v*>(p + 4);
+    r.lo = *MV_GLOBAL_PTR(float4v, p);
+    r.hi = *MV_GLOBAL_PTR(float4v, p + 4);
 }
 __device__ __forceinline__ float raw_get(const RawChunk<half_t>& r, int e) { return (float)r.v[e]; }
 __device__ __forceinline__ float raw_get(const RawChunk<float>& r, int e) { return e < 4 ? r.lo[e] : r.hi[e - 4]; }
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + lrow + 32 * i;
-            wr[i] = *reinterpret_cast<const half8v*>(co < a.cout_pad ? a.w + ((int64_t)co * a.k + tap) * a.cin_pad + c : zero_h);
+            wr[i] = *MV_GLOBAL_PTR(half8v, co < a.cout_pad ? a.w + ((int64_t)co * a.k + tap) * a.cin_pad + c : zero_h);
         }
     };
 
