@@ -216,9 +216,21 @@ typedef struct MvConv1dDesc {
     void* sum_dst;        /* x_{j+1} + y_j of the next Res2Net step (ecapa_tdnn.py:47) produced by this step's epilogue */
     int64_t ld_add, ld_sum;
     int32_t B, T_in, T_out, cin, cout, k, dilation, stride, pad, pad_mode;
-    int32_t tile;         /* workgroup tile: 0 = choose (256x256 for wide layers that fill the chip, else 128x128), 128, 256 */
+    int32_t tile;         /* workgroup tile: 0 = choose (256x256 for wide layers that fill the chip, else 128x128), 128, 160, 256 */
+    /* optional fused time statistics of y (SE squeeze ecapa_tdnn.py:79, ASP global mean / std pooling.py:104-109): fp32 partial
+     * buffers of mv_conv1d_stats_elems(B, T_out, cout) floats each; stat_sq may be NULL (mean only).  Only on the persistent
+     * 1x1 path: fp16 in/out, cout % 256 == 0, cin % 64 == 0, no row_bias / gate, T_out >= 64.  Finish with
+     * mv_conv1d_stats_finish. */
+    float* stat_sum;
+    float* stat_sq;
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
+/* floats in one partial-statistics buffer, and the reduction of the partial rows to per-utterance mean[b, c] (and
+ * std[b, c] = sqrt(max(E[(y - mean)^2], clamp_eps)) when stat_sq / std are given).  `shift` = the BatchNorm shift passed to the
+ * conv (the moments are taken about it), NULL if the conv had none. */
+int64_t mv_conv1d_stats_elems(int32_t B, int32_t T_out, int32_t cout);
+int mv_conv1d_stats_finish(const float* stat_sum, const float* stat_sq, const float* shift, int32_t B, int32_t T_out, int32_t cout,
+                           float* mean, float* std, int64_t ld_out, float clamp_eps, mv_stream_t stream);
 
 /* Fused Res2Net chain (mvector/models/ecapa_tdnn.py:39-51): x, y fp16 [B, T, C]; `groups` channel groups of width C/groups;
  * y[..., 0:w] = x[..., 0:w];  y_j = BN(ReLU(conv_j(x_j + y_{j-1}))) for j = 1..groups-1 with reflect "same" padding.

@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, seed=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, seed=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -73,6 +73,11 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     d.dilation, d.stride, d.pad = dil, stride, pad
     d.pad_mode = _hip.MV_PAD_REFLECT if pad_mode == 'reflect' else _hip.MV_PAD_ZERO
     d.tile = tile
+    if stats:  # fused per-utterance time statistics of y (mean; mean + std)
+        nstat = cdll.mv_conv1d_stats_elems(B, T_out, cout)
+        psum = torch.full((nstat,), float('nan'), device=device)
+        psq = torch.full((nstat,), float('nan'), device=device) if stats == 2 else None
+        d.stat_sum, d.stat_sq = psum.data_ptr(), (psq.data_ptr() if psq is not None else None)
     _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
@@ -101,6 +106,19 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     err = (got[..., :cout] - ref).abs().max().item()
     tol = 2e-4 if y_f32 else 4e-3 * max(1.0, ref.abs().max().item())
     assert err < tol, f'conv1d mismatch {err} (tol {tol})'
+    if stats:
+        mean = torch.empty(B, cout, device=device)
+        std = torch.empty(B, cout, device=device) if stats == 2 else None
+        _hip.check(cdll.mv_conv1d_stats_finish(psum.data_ptr(), psq.data_ptr() if psq is not None else None,
+                                               shiftd.data_ptr() if affine else None, B, T_out, cout, mean.data_ptr(),
+                                               std.data_ptr() if std is not None else None, cout, 1e-12, _stream(xd)), cdll)
+        rmean = ref.mean(1)
+        e1 = (mean.cpu() - rmean).abs().max().item()
+        assert e1 < 2e-3 * max(1.0, rmean.abs().max().item()), f'fused time mean {e1}'
+        if stats == 2:
+            rstd = torch.sqrt(((ref - rmean.unsqueeze(1)) ** 2).mean(1).clamp(1e-12))
+            e2 = (std.cpu() - rstd).abs().max().item()
+            assert e2 < 2e-3 * max(1.0, rstd.abs().max().item()), f'fused time std {e2}'
     if second_out:
         want = (y.cpu().float()[..., :cout] + addsrc.cpu().float()[..., :cout]).half().float()
         got2 = sumdst.cpu().float()
@@ -129,6 +147,9 @@ CONV_CASES = [
     dict(k=3, dil=2, cin=64, cout=200, T=100, B=2, tile=160),            # 160-row tile, taps, ragged channels
     dict(k=1, dil=1, cin=128, cout=768, T=300, B=4, tile=256),           # persistent kernel: 15 tiles, workgroups walk 3 of them
     dict(k=1, dil=1, cin=64, cout=512, T=150, B=7, tile=256),            # persistent, single K stage per tile (first == last stage)
+    dict(k=1, dil=1, cin=128, cout=256, T=90, B=5, tile=256, stats=1),   # fused time mean: utterance boundaries inside 64-row blocks
+    dict(k=1, dil=1, cin=192, cout=512, T=298, B=3, tile=256, stats=2),  # fused mean + std (ASP global statistics), ragged last tile
+    dict(k=1, dil=1, cin=128, cout=256, T=64, B=4, tile=256, stats=2, affine=False, extra_ld=0),  # boundaries on block edges, no BN
     dict(k=3, dil=2, cin=72, cout=512, T=130, B=5, tile=256, pre_act=0, affine=False),  # persistent, taps, no BatchNorm affine
 ]
 

@@ -53,6 +53,8 @@ struct ConvArgs {
     int B, T_in, T_out, cin, cin_pad, cout, cout_pad, k, dil, stride, pad, pad_mode;
     int pre_act, post_act, y_f16, gate_seg_len, gate_nseg;
     int n_rows, n_tiles, co_tiles;
+    float* stat_sum;  // optional partial time sums of the output (persistent kernel): [ceil(n_rows / 64)][2][cout]
+    float* stat_sq;   // optional partial sums of squares (about the BatchNorm shift), same layout
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -528,6 +530,14 @@ constexpr int CVP_LDS_BYTES = CVP_PARAM_OFF + 3 * CVP_PARAM_SLOT;  // 140 288 B 
 // tile A's channels and every odd row the first half of tile B's, so each lane ends up with 8 CONSECUTIVE channels:
 //   rows q even: A: 4q .. 4q+7           rows q odd: B: 4(q-1) .. 4(q-1)+7
 // and one store instruction writes, per time step, the 64 contiguous bytes of channels A*16 .. A*16+31.
+// STATS (0 none, 1 sums, 2 sums + sums of squares): the per-utterance time statistics of the output -- the SE squeeze
+// (ecapa_tdnn.py:79) and the ASP global mean / std (pooling.py:104-109) -- are taken from the accumulators instead of a
+// second pass over the stored tensor.  Moments are about the BatchNorm shift t[c] (u = y - t; for conv -> ReLU -> BN that
+// is relu(.) * scale: a dead channel gives exact zeros).  A wave's 64 time steps are reduced with DPP row sums and written
+// as one partial row per (64-row block, slot): slot 0 = steps of the utterance the block starts in, slot 1 = steps of the
+// next utterance when its first frame lies inside the block (T_out >= 64, so at most one boundary).  stats_finish_kernel
+// adds up the 5-6 partial rows of an utterance in a fixed order (no atomics: results are run-to-run identical).
+template <int STATS>
 __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* smem, int n0, int co0, int pslot, int wc, int wn,
                                                     int wave, int lane, float4v (&acc)[8][4]) {
     (void)wave;
@@ -536,36 +546,133 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     half_t* y = reinterpret_cast<half_t*>(a.y);
     // host admits none / ReLU only: max(v, -inf) is the identity
     const float lo_pre = a.pre_act == MV_ACT_RELU ? 0.0f : -INFINITY, lo_post = a.post_act == MV_ACT_RELU ? 0.0f : -65504.0f;
-    auto finish = [&](const float4v& c, int mi) {  // bias, activation, BatchNorm affine, saturation -> 4 fp16 in 2 registers
-        const int col = wc * 128 + mi * 16 + 4 * q;
-        float4v v = c + *reinterpret_cast<const float4v*>(par + col * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
-        v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
-        half4v hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation + fp16 saturation: one v_med3
-        return hv;
-    };
     const int ch_lane = (q & 1) * 16 + 4 * (q & ~1);  // first channel of this lane inside the 32-channel pair
+    // statistics: where the next utterance starts, relative to this wave's first time step
+    const int first = n0 + wn * 64;
+    const int split = STATS ? (first / a.T_out + 1) * a.T_out - first : 0;  // rows >= split belong to the next utterance
+    const bool straddles = STATS && split < 64;
+    float4v keep_sum[2], keep_sq[2];  // [slot]: this lane's share of the wave's partial row (channel tile r, channels 4q..4q+3)
+    keep_sum[0] = keep_sum[1] = keep_sq[0] = keep_sq[1] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + r;
-        half_t* yrow = y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane;
+    for (int p = 0; p < 4; ++p) {
+        float4v shift4[2];
+        float4v s_sum[2][2], s_sq[2][2];  // [slot][tile of the pair]
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const half4v ha = finish(acc[2 * p][ni], 2 * p), hb = finish(acc[2 * p + 1][ni], 2 * p + 1);
+        for (int u = 0; u < 2; ++u) {
+            shift4[u] = *reinterpret_cast<const float4v*>(par + 2048 + (wc * 128 + (2 * p + u) * 16 + 4 * q) * 4);
+            s_sum[0][u] = s_sum[1][u] = s_sq[0][u] = s_sq[1][u] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + r;
+            half4v hv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = wc * 128 + (2 * p + u) * 16 + 4 * q;
+                float4v v = acc[2 * p + u][ni] + *reinterpret_cast<const float4v*>(par + col * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
+                v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4);  // u = y - shift
+                if (STATS) {
+                    float4v w = v;
+                    if (a.post_act == MV_ACT_RELU) {  // the moments are those of the stored value
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = fmaxf(v[e] + shift4[u][e], 0.0f) - shift4[u][e];
+                    }
+                    if (straddles) {
+                        const bool late = ni * 16 + r >= split;
+                        const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+                        const float4v w0 = late ? zero4 : w, w1 = late ? w : zero4;
+                        s_sum[0][u] += w0;
+                        s_sum[1][u] += w1;
+                        if (STATS == 2) {
+                            s_sq[0][u] += w0 * w0;
+                            s_sq[1][u] += w1 * w1;
+                        }
+                    } else {
+                        s_sum[0][u] += w;
+                        if (STATS == 2) s_sq[0][u] += w * w;
+                    }
+                }
+                v += shift4[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[u][e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation + fp16 saturation: one v_med3
+            }
             unsigned xa[2], xb[2];
-            __builtin_memcpy(xa, &ha, 8);
-            __builtin_memcpy(xb, &hb, 8);
+            __builtin_memcpy(xa, &hv[0], 8);
+            __builtin_memcpy(xb, &hv[1], 8);
             row_swap_odd_even(xa[0], xb[0]);
             row_swap_odd_even(xa[1], xb[1]);
             const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
             half8v ov;
             __builtin_memcpy(&ov, o, 16);
-            if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+            if (n < a.n_rows) *reinterpret_cast<half8v*>(y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane + p * 32) = ov;
+        }
+        if (STATS) {
+            // DPP row sums over the 16 time steps of a tile row group: every lane of a row then holds the sums of its 4
+            // channels; lane r keeps those of channel tile r, so the wave's 128 channels leave in ONE 512-byte store per
+            // (slot, moment) at the end instead of one 4-lane store per tile (store issue is what the epilogue waits on)
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                if (slot == 1 && !straddles) break;  // uniform
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4v t = s_sum[slot][u], t2 = s_sq[slot][u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] = row16_sum(t[e]);
+                        if (STATS == 2) t2[e] = row16_sum(t2[e]);
+                    }
+                    const bool mine = r == 2 * p + u;
+                    keep_sum[slot] = mine ? t : keep_sum[slot];
+                    if (STATS == 2) keep_sq[slot] = mine ? t2 : keep_sq[slot];
+                }
+            }
         }
     }
+    if (STATS) {
+        const int64_t prow = ((int64_t)(first >> 6) * 2) * a.cout + co0 + wc * 128 + r * 16 + 4 * q;
+        if (r < 8) {
+            *reinterpret_cast<float4v*>(a.stat_sum + prow) = keep_sum[0];
+            if (STATS == 2) *reinterpret_cast<float4v*>(a.stat_sq + prow) = keep_sq[0];
+            if (straddles) {
+                *reinterpret_cast<float4v*>(a.stat_sum + prow + a.cout) = keep_sum[1];
+                if (STATS == 2) *reinterpret_cast<float4v*>(a.stat_sq + prow + a.cout) = keep_sq[1];
+            }
+        }
+    }
+}
+
+// per-utterance mean (and std) from the partial rows written by the STATS epilogue
+__global__ void stats_finish_kernel(const float* psum, const float* psq, const float* shift, int B, int T, int C, float* mean,
+                                    float* stdv, int64_t ld_out, float clamp_eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= C || b >= B) return;
+    const int64_t r0 = (int64_t)b * T, r1 = r0 + T - 1;
+    float s = 0.0f, q2 = 0.0f;
+    for (int64_t k = r0 >> 6; k <= (r1 >> 6); ++k) {
+        const int64_t owner = (k << 6) / T;             // utterance of the block's first time step
+        const int slot = owner == b ? 0 : 1;            // otherwise the block starts in utterance b - 1 and b begins inside it
+        s += psum[(k * 2 + slot) * C + c];
+        if (psq != nullptr) q2 += psq[(k * 2 + slot) * C + c];
+    }
+    const float t = shift != nullptr ? shift[c] : 0.0f;
+    const float m = s / (float)T;
+    mean[(int64_t)b * ld_out + c] = t + m;
+    if (stdv != nullptr) {
+        float var = fmaxf(q2 / (float)T - m * m, 0.0f);
+        if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
+        stdv[(int64_t)b * ld_out + c] = sqrtf(var);
+    }
+}
+
+int conv_stats_finish_launch(const float* psum, const float* psq, const float* shift, int B, int T, int C, float* mean, float* stdv,
+                             int64_t ld_out, float clamp_eps, hipStream_t stream) {
+    MV_REQUIRE(psum != nullptr && mean != nullptr && B > 0 && T >= 64 && C > 0, "conv_stats_finish: bad argument");
+    MV_LAUNCH(stats_finish_kernel, ((unsigned)ceil_div(C, 256), (unsigned)B, 1), (256, 1, 1), 0, stream, psum, psq, shift, B, T, C, mean,
+              stdv, ld_out, clamp_eps);
+    return check_launch("stats_finish_kernel");
 }
 
 // timing probe 3 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at four points of every stage
@@ -580,7 +687,7 @@ __device__ int g_trace_n;
 #define MV_TRACE(tag) ((void)0)
 #endif
 
-template <bool SIMPLE>
+template <bool SIMPLE, int STATS>
 __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a) {
     constexpr int WN = 4, MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
@@ -731,7 +838,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
 #endif
         MV_TRACE(2);
         if (decltype(first)::value) {
-            if (pending) persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+            if (pending) persistent_epilogue<STATS>(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -778,7 +885,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         e_ps = c_ps;
         pending = true;
     }
-    persistent_epilogue(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+    persistent_epilogue<STATS>(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
 #if defined(MV_PROBE) && MV_PROBE == 3
     MV_TRACE(0);
     if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
@@ -985,6 +1092,21 @@ static int persistent_blocks() {
     return n;
 }
 
+bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k) {
+    // Measured (r02a): the DPP row sums put ~6 us per tile into the epilogue, on the critical path of every CU at once --
+    // 3 x 32 us on the tdnn2 layers and ~150 us on mfa, as much as the separate time_stats passes they replace (3 x 30 +
+    // 100-150 us), so the model keeps the separate passes unless MV_FUSE_STATS=1 asks for the fused form.
+    static const bool enabled = [] {
+        const char* e = getenv("MV_FUSE_STATS");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    if (!enabled) return false;
+    // mirrors the launcher's choice of the persistent kernel for an aligned fp16 TDNN layer (bias, ReLU, BatchNorm affine)
+    const int64_t n_rows = (int64_t)B * T;
+    return k == 1 && cin % CV_BK == 0 && cin >= 2 * CV_BK && cout % 256 == 0 && T >= 64 && persistent_blocks() > 0 &&
+           ceil_div(n_rows, 256) * (cout / 256) >= 256;
+}
+
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w_packed != nullptr && d.y != nullptr, "conv1d: null tensor");
     MV_REQUIRE(d.B > 0 && d.T_in > 0 && d.T_out > 0 && d.cin > 0 && d.cout > 0 && d.k > 0, "conv1d: bad geometry");
@@ -1053,6 +1175,10 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.gate_seg_len = d.gate_seg_len > 0 ? d.gate_seg_len : 1;
     a.gate_nseg = (int)ceil_div(d.T_out, a.gate_seg_len);
     a.n_rows = d.B * d.T_out;
+    a.stat_sum = d.stat_sum;
+    a.stat_sq = d.stat_sq;
+    const int stats = d.stat_sum == nullptr ? 0 : (d.stat_sq == nullptr ? 1 : 2);
+    if (d.stat_sq != nullptr) MV_REQUIRE(d.stat_sum != nullptr, "conv1d: stat_sq needs stat_sum");
     const bool f16 = d.x_dtype == MV_DT_F16;
     const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
     // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
@@ -1081,6 +1207,10 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         }
     }
     if (d.tile == 160) MV_REQUIRE(direct && !big, "conv1d: the 160-row tile belongs to the plain fp16 path");
+    if (stats)
+        MV_REQUIRE(persist && d.k == 1 && d.cin % CV_BK == 0 && d.T_out >= 64,
+                   "conv1d: fused time statistics need the persistent 1x1 kernel (fp16 in/out, cout % 256 == 0, cin % 64 == 0, "
+                   "plain bias / ReLU / affine epilogue, T_out >= 64)");
     const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
@@ -1090,8 +1220,10 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel<true>, CVP_LDS_BYTES) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv1d_glds_persistent_kernel<false>, CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 0>), CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 1>), CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 2>), CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<false, 0>), CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
@@ -1102,10 +1234,15 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
-        if (d.k == 1 && d.cin % CV_BK == 0) {
-            MV_LAUNCH(conv1d_glds_persistent_kernel<true>, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        const bool simple = d.k == 1 && d.cin % CV_BK == 0;
+        if (stats == 2) {
+            MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        } else if (stats == 1) {
+            MV_LAUNCH((conv1d_glds_persistent_kernel<true, 1>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+        } else if (simple) {
+            MV_LAUNCH((conv1d_glds_persistent_kernel<true, 0>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
         } else {
-            MV_LAUNCH(conv1d_glds_persistent_kernel<false>, (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
+            MV_LAUNCH((conv1d_glds_persistent_kernel<false, 0>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
         }
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
@@ -1141,6 +1278,17 @@ int mv_conv1d_pack_weight(const float* w, int32_t cout, int32_t cin, int32_t k, 
     MV_LAUNCH(mv::pack_conv_weight_kernel, (grid, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), w, cout, cin, k,
               mv::conv1d_cout_pad(cout), mv::conv1d_cin_pad(cin), reinterpret_cast<half_t*>(packed_f16));
     return mv::check_launch("pack_conv_weight_kernel");
+}
+
+int64_t mv_conv1d_stats_elems(int32_t B, int32_t T_out, int32_t cout) {
+    return mv::ceil_div((int64_t)B * T_out, 256) * 4 * 2 * (int64_t)cout;  // [64-row blocks of whole 256-row tiles][2 slots][cout]
+}
+
+int mv_conv1d_stats_finish(const float* stat_sum, const float* stat_sq, const float* shift, int32_t B, int32_t T_out, int32_t cout,
+                           float* mean, float* std, int64_t ld_out, float clamp_eps, mv_stream_t stream) {
+    if (std != nullptr) MV_REQUIRE(stat_sq != nullptr, "mv_conv1d_stats_finish: std needs the sums of squares");
+    return mv::conv_stats_finish_launch(stat_sum, std != nullptr ? stat_sq : nullptr, shift, B, T_out, cout, mean, std, ld_out, clamp_eps,
+                                        static_cast<hipStream_t>(stream));
 }
 
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream) {

@@ -47,7 +47,8 @@ int fold_final_linear(MvModelBase* m, const Weights& w, const std::string& weigh
 int run_conv(const ConvLayer& L, const void* x, int x_dtype, int64_t ldx, const void* x2, int64_t ldx2, void* y, int y_dtype,
              int64_t ldy, int B, int T_in, int T_out, int dil, int pad, int pad_mode, int pre_act, const float* scale,
              const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream,
-             const half_t* add_src = nullptr, int64_t ld_add = 0, half_t* sum_dst = nullptr, int64_t ld_sum = 0);
+             const half_t* add_src = nullptr, int64_t ld_add = 0, half_t* sum_dst = nullptr, int64_t ld_sum = 0,
+             float* stat_sum = nullptr, float* stat_sq = nullptr);
 
 // bump allocator over the caller-provided workspace (256-byte aligned slices)
 struct Carver {
@@ -76,7 +77,9 @@ struct AspLayer {
     float logit_bound_log2 = -1.0f;  // max_c sum_k |W2[c,k]| * log2(e): bounds every attention logit
     int create(MvModelBase* m, const Weights& w, const std::string& prefix, int C, int A, bool global_ctx);
     size_t workspace_floats(int B) const;
-    int forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled, hipStream_t stream) const;
+    // have_gstats: fws already holds the global mean | std of x ([B, 2C]) from the producer's fused statistics
+    int forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled, hipStream_t stream,
+                bool have_gstats = false) const;
 };
 
 }  // namespace mv

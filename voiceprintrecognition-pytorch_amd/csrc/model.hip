@@ -129,9 +129,11 @@ int MvModelBase::make_bn(const Weights& w, const std::string& prefix, int C, flo
 int run_conv(const ConvLayer& L, const void* x, int x_dtype, int64_t ldx, const void* x2, int64_t ldx2, void* y, int y_dtype,
              int64_t ldy, int B, int T_in, int T_out, int dil, int pad, int pad_mode, int pre_act, const float* scale,
              const float* shift, int post_act, const float* row_bias, bool use_bias, hipStream_t stream,
-             const half_t* add_src, int64_t ld_add, half_t* sum_dst, int64_t ld_sum) {
+             const half_t* add_src, int64_t ld_add, half_t* sum_dst, int64_t ld_sum, float* stat_sum, float* stat_sq) {
     MvConv1dDesc d;
     memset(&d, 0, sizeof(d));
+    d.stat_sum = stat_sum;
+    d.stat_sq = stat_sq;
     d.add_src = add_src;
     d.sum_dst = sum_dst;
     d.ld_add = ld_add;
@@ -214,12 +216,14 @@ size_t AspLayer::workspace_floats(int B) const { return (size_t)B * (2 * C + A);
 
 // x: [B, T, ldx] fp16 -> pooled [B, 2C] fp32.  h: [B*T, A] fp16 scratch, fws: workspace_floats(B) fp32 scratch.
 int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled,
-                      hipStream_t stream) const {
+                      hipStream_t stream, bool have_gstats) const {
     int rc;
     float* gstats = fws;                     // [B, 2C]  mean | std
     float* ctxb = fws + (size_t)B * 2 * C;   // [B, A]
     const float* gmean = nullptr;
-    if ((rc = time_stats_launch(x, ldx, B, T, C, gstats, gstats + C, 2 * C, 0, 1e-12f, stream))) return rc;
+    if (!have_gstats) {  // else: already written by the producer's fused epilogue statistics
+        if ((rc = time_stats_launch(x, ldx, B, T, C, gstats, gstats + C, 2 * C, 0, 1e-12f, stream))) return rc;
+    }
     gmean = gstats;
     const float* row_bias = nullptr;
     if (global_ctx) {
@@ -361,7 +365,7 @@ struct EcapaModel : MvModelBase {
 
     struct Ws {
         half_t *x16, *a0, *cat, *t1, *r2, *t2, *sc, *mfa, *h, *rs[2];
-        float *se_mean, *se_hid, *gate, *asp_f, *pooled;
+        float *se_mean, *se_hid, *gate, *asp_f, *pooled, *stat_sum, *stat_sq;
         size_t bytes;
     };
 
@@ -369,6 +373,10 @@ struct EcapaModel : MvModelBase {
         const size_t N = (size_t)B * T;
         Carver c(base);
         Ws s;
+        // partial rows of the time statistics fused into the tdnn2 / mfa epilogues (widest layer: mfa)
+        const int cwide = cfg.channels[4] > cmax ? cfg.channels[4] : cmax;
+        s.stat_sum = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cwide));
+        s.stat_sq = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cfg.channels[4]));
         s.x16 = c.take<half_t>(N * round_up(cfg.input_size, 8));
         s.a0 = c.take<half_t>(N * cfg.channels[0]);
         s.cat = c.take<half_t>(N * ccat);
@@ -461,11 +469,18 @@ struct EcapaModel : MvModelBase {
                         return rc;
                 }
             }
+            // SE: squeeze -> FC/ReLU -> FC/sigmoid -> gate * y + residual, written into the aggregation slice.  The squeeze
+            // (mean over time, ecapa_tdnn.py:79) comes out of tdnn2's epilogue when that layer runs on the persistent kernel.
+            const bool fused_sq = conv1d_can_fuse_stats(B, T, C, C, 1);
             if ((rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
-                               b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st)))
+                               b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st, nullptr, 0, nullptr, 0,
+                               fused_sq ? s.stat_sum : nullptr, nullptr)))
                 return rc;
-            // SE: squeeze -> FC/ReLU -> FC/sigmoid -> gate * y + residual, written into the aggregation slice
-            if ((rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st))) return rc;
+            if (fused_sq) {
+                if ((rc = conv_stats_finish_launch(s.stat_sum, nullptr, b.tdnn2.shift, B, T, C, s.se_mean, nullptr, C, 0.0f, st))) return rc;
+            } else {
+                if ((rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st))) return rc;
+            }
             if ((rc = linear_f32_launch(s.se_mean, C, b.se_w1, C, b.se_b1, MV_ACT_RELU, s.se_hid, cfg.se_channels, B, C,
                                         cfg.se_channels, 0, st)))
                 return rc;
@@ -480,11 +495,18 @@ struct EcapaModel : MvModelBase {
         }
         // multi-layer feature aggregation reads the three block outputs in place
         const int Cm = cfg.channels[4];
+        // the ASP global mean / std (pooling.py:104-109) come out of the mfa epilogue on the persistent kernel
+        const bool fused_gs = asp.global_ctx && cfg.kernel_sizes[4] == 1 && conv1d_can_fuse_stats(B, T, ccat, Cm, 1);
         if ((rc = run_conv(mfa.conv, s.cat, MV_DT_F16, ccat, nullptr, 0, s.mfa, MV_DT_F16, Cm, B, T, T, cfg.dilations[4],
                            cfg.dilations[4] * (cfg.kernel_sizes[4] - 1) / 2, R, MV_ACT_RELU, mfa.scale, mfa.shift, MV_ACT_NONE,
-                           nullptr, true, st)))
+                           nullptr, true, st, nullptr, 0, nullptr, 0, fused_gs ? s.stat_sum : nullptr, fused_gs ? s.stat_sq : nullptr)))
             return rc;
-        if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st))) return rc;
+        if (fused_gs) {
+            float* gstats = s.asp_f;  // [B, 2 Cm]: mean | std, the layout AspLayer::forward expects
+            if ((rc = conv_stats_finish_launch(s.stat_sum, s.stat_sq, mfa.shift, B, T, Cm, gstats, gstats + Cm, 2 * Cm, 1e-12f, st)))
+                return rc;
+        }
+        if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st, fused_gs))) return rc;
         // asp_bn folded into fc
         return linear_f32_launch(s.pooled, 2 * Cm, fc_w, 2 * Cm, fc_b, MV_ACT_NONE, emb, cfg.embd_dim, B, 2 * Cm, cfg.embd_dim, 0,
                                  st);

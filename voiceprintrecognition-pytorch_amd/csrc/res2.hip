@@ -131,6 +131,9 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         // the next channel group x_{j+1} is requested first (rows clamped, stores predicated): these loads are older than
         // every weight transfer, so the counted waits of the K loop cover them, and their latency overlaps stage 0's
         const bool more = j < a.steps;
+        // (unconditional loads: a select between a load and zero compiles to one branch + full wait per load; the last
+        // step simply re-reads its own group and ignores the values)
+        const int next_group = more ? j + 1 : j;
         half4v xn[MI][R2_NH];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -138,8 +141,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             for (int ni = 0; ni < R2_NH; ++ni) {
                 int t = (nh0 + ni) * 16 + fr;
                 t = t < T ? t : T - 1;
-                const half4v zero4h = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-                xn[mi][ni] = more ? *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + (j + 1) * WIDTH + (cw * MI + mi) * 16 + 4 * fg) : zero4h;
+                xn[mi][ni] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + next_group * WIDTH + (cw * MI + mi) * 16 + 4 * fg);
             }
         for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         float4v acc[MI][R2_NH];
