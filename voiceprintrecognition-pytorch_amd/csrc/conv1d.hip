@@ -550,6 +550,39 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     // statistics: where the next utterance starts, relative to this wave's first time step
     const int first = n0 + wn * 64;
     const int split = STATS ? (first / a.T_out + 1) * a.T_out - first : 0;  // rows >= split belong to the next utterance
+    if constexpr (STATS == 0) {
+        // time step outermost: the two 64-byte halves of a 128-byte output line are written by consecutive stores
+        auto finish = [&](const float4v& c, int mi) {  // bias, activation, BatchNorm affine, saturation -> 4 fp16 in 2 registers
+            const int col = wc * 128 + mi * 16 + 4 * q;
+            float4v v = c + *reinterpret_cast<const float4v*>(par + col * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
+            v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
+            half4v hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation + fp16 saturation: one v_med3
+            return hv;
+        };
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + r;
+            half_t* yrow = y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const half4v ha = finish(acc[2 * p][ni], 2 * p), hb = finish(acc[2 * p + 1][ni], 2 * p + 1);
+                unsigned xa[2], xb[2];
+                __builtin_memcpy(xa, &ha, 8);
+                __builtin_memcpy(xb, &hb, 8);
+                row_swap_odd_even(xa[0], xb[0]);
+                row_swap_odd_even(xa[1], xb[1]);
+                const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
+                half8v ov;
+                __builtin_memcpy(&ov, o, 16);
+                if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+            }
+        }
+        return;
+    }
     const bool straddles = STATS && split < 64;
     float4v keep_sum[2], keep_sq[2];  // [slot]: this lane's share of the wave's partial row (channel tile r, channels 4q..4q+3)
     keep_sum[0] = keep_sum[1] = keep_sq[0] = keep_sq[1] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
