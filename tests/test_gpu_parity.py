@@ -3,14 +3,17 @@ vectors.  Tolerances: Fbank features max-abs 2e-3 (both fp32 evaluations sit ~3e
 the log floor) and mean-abs 2e-5; embeddings 1 - cos <= 1e-4 (north_star); cosine scores 2e-6."""
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 import layer_checks as lc
+from conftest import ROOT
 from helpers import GOLDEN, cos_dist, load_case
-from oracle import frontend, models as omodels
+from oracle import frontend, models as omodels, scoring
 
 pytestmark = pytest.mark.gpu
 FB = dict(sample_frequency=16000, num_mel_bins=80)
@@ -96,6 +99,60 @@ def test_gpu_fbank_full_batch_properties():
     assert torch.equal(fb(wav[perm]), out[perm])             # utterances are independent
     ref = frontend.audio_featurizer(wav[250:].cpu(), None, 'Fbank', FB)
     assert (out[250:].cpu() - ref).abs().max().item() < 2e-3
+
+
+def test_gpu_fbank_gain_invariance_full_batch():
+    """log-mel + time-mean subtraction: a gain on the waveform shifts every log energy by the same constant, which the CMN
+    removes -- except where the quieter copy falls onto the log floor (Q1: [-1, 1]-scaled input, a few low bins), which
+    also moves that bin's time mean.  So: most (utterance, bin) columns are invariant, and where they are not the kernel
+    moves exactly as the oracle does."""
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    wav = 0.1 * torch.randn(256, 48000, generator=torch.Generator().manual_seed(4))
+    a, b = fb(wav.to(DEV)).cpu(), fb((wav * 0.25).to(DEV)).cpu()
+    col = (a - b).abs().amax(1)                     # [256, 80] worst frame per (utterance, bin)
+    assert (col < 2e-3).float().mean().item() > 0.9
+    ra = frontend.audio_featurizer(wav[:8], None, 'Fbank', FB)
+    rb = frontend.audio_featurizer(wav[:8] * 0.25, None, 'Fbank', FB)
+    assert ((a[:8] - b[:8]) - (ra - rb)).abs().max().item() < 3e-3
+
+
+def test_gpu_cosine_properties_full_size():
+    """config 4 scoring shape: [2048, 192] x [2048, 192]"""
+    from mvector import _hip
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2048, 192, generator=g).to(DEV)
+    s = _hip.cosine(x, x)
+    assert (s.diagonal() - 1).abs().max().item() < 2e-6
+    assert (s - s.t()).abs().max().item() < 2e-6                       # symmetric
+    assert (_hip.cosine(3.0 * x, 0.5 * x) - s).abs().max().item() < 2e-6  # scale invariant
+    ref = scoring.cosine_similarity(x[:64].cpu().numpy(), x.cpu().numpy())
+    assert np.abs(s[:64].cpu().numpy() - ref).max() < 2e-6
+
+
+def test_gpu_fused_time_statistics_model_path():
+    """MV_FUSE_STATS=1: SE squeeze and ASP global statistics come out of the tdnn2 / mfa epilogues (needs a batch that fills
+    the persistent kernel).  The knob is read once per process, hence the subprocess."""
+    code = (
+        "import sys, torch\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "from helpers import load_case, cos_dist\n"
+        "from oracle import frontend, models as omodels\n"
+        "from mvector.data_utils.featurizer import AudioFeaturizer\n"
+        "from mvector.models import EcapaTdnn\n"
+        "man, sd, _, _, _ = load_case('ecapa_c1024')\n"
+        "m = EcapaTdnn(**man['kwargs']); m.load_state_dict(sd); m.eval().cuda()\n"
+        "FB = dict(sample_frequency=16000, num_mel_bins=80)\n"
+        "wav = frontend.synth_waveforms(256, 48000)\n"
+        "emb = m(AudioFeaturizer('Fbank', method_args=FB)(wav.cuda()))\n"
+        "ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[:2], None, 'Fbank', FB))\n"
+        "d = cos_dist(emb[:2].cpu(), ref).max().item()\n"
+        "assert d < 1e-4, d\n"
+        "print('fused-stats parity', d)\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd'))
+    env = dict(os.environ, MV_FUSE_STATS='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'tdnn', 'campp', 'campp_short'])
