@@ -257,6 +257,14 @@ int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C
 int mv_profile_enable(int32_t on);
 int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, double* total_work, int32_t reset);
 
+/* int16 PCM rows [B, L] -> float32 waveforms in [-1, 1) (sample / 32768) on the device, zero beyond num_samples[b] (device
+ * int64 array, NULL = L everywhere).  normalize != 0: per-row dB normalisation over the true length, gain =
+ * 10^((target_db - 10 log10(mean x^2)) / 20) -- AudioSegment.normalize as called at mvector/predict.py:210-211; rows whose gain
+ * would exceed max_gain_db (digital silence; the reference raises ValueError) are left unscaled and flagged in too_quiet[b]
+ * (device int32 array, may be NULL). */
+int mv_wave_prepare_i16(const int16_t* pcm, int64_t pcm_stride, const int64_t* num_samples, int32_t B, int64_t L, int32_t normalize,
+                        float target_db, float max_gain_db, float* wav, int64_t wav_stride, int32_t* too_quiet, mv_stream_t stream);
+
 /* Attentive-statistics pooling tail (mvector/models/pooling.py:117-125): attention logits = W2 . h (the bias of the
  * projection is constant over time and cancels in the softmax over time), softmax over time, weighted mean / std.
  *   h  fp16 [B, T, A] (tanh output, |h| <= 1),  w2_packed = mv_conv1d_pack_weight of  W2[C, A, 1] * log2(e),

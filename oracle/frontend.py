@@ -190,3 +190,29 @@ def synth_waveforms(batch, length, seed=1234, amplitude=0.1):
 
 def as_numpy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def wave_prepare(pcm, num_samples=None, target_db=None, max_gain_db=300.0):
+    """int16 PCM [B, L] -> float32 waveforms as the reference's host path builds them before featurisation
+    (mvector/predict.py:185-212): samples / 32768 (AudioSegment int16 decode), optional ``normalize(target_db)`` over the
+    true length with gain = 10^((target_db - rms_db) / 20), rms_db = 10 log10(mean x^2); zeros beyond the true length (the
+    zero padding of predict_batch, predict.py:249-255).  yeaudio is not installed here: its ``normalize`` is restated from
+    the call site and the package's documented behaviour -- parity unpinned against yeaudio itself.
+    Returns (wav float32 [B, L], too_quiet bool [B])."""
+    import numpy as np
+    pcm = np.asarray(pcm)
+    B, L = pcm.shape
+    out = np.zeros((B, L), dtype=np.float32)
+    quiet = np.zeros(B, dtype=bool)
+    for b in range(B):
+        n = L if num_samples is None else int(num_samples[b])
+        x = pcm[b, :n].astype(np.float32) / 32768.0
+        if target_db is not None:
+            ms = float(np.mean(x.astype(np.float64) ** 2)) if n else 0.0
+            gain = target_db - 10.0 * np.log10(ms) if ms > 0 else np.inf
+            if gain > max_gain_db:
+                quiet[b] = True
+            else:
+                x = x * np.float32(10.0 ** (gain / 20.0))
+        out[b, :n] = x
+    return out, quiet

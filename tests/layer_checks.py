@@ -224,6 +224,21 @@ def asp_pool_case(cdll, device, B=3, T=45, C=192, A=128, ldx=None, online=False,
     return err
 
 
+def wave_prepare_case(cdll, device, B=5, L=5000, normalize=True, seed=0):
+    from oracle import frontend
+    g = torch.Generator().manual_seed(seed)
+    pcm = (torch.randn(B, L, generator=g) * 3000).clamp(-32768, 32767).to(torch.int16)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    pcm[1] = 0  # digital silence: the reference's normalize raises, the kernel flags the row
+    wav, flags = _hip.wave_prepare(pcm.to(device), lens.to(device), -20.0 if normalize else None, cdll=cdll)
+    ref, quiet = frontend.wave_prepare(pcm.numpy(), lens.numpy(), -20.0 if normalize else None)
+    err = np.abs(wav.cpu().numpy() - ref).max()
+    assert err < 2e-6 * max(1.0, np.abs(ref).max()), err
+    assert flags.cpu().numpy().astype(bool).tolist() == quiet.tolist()
+    return err
+
+
 def fbank_case(cdll, device, wav, ratio, method_args):
     from oracle import frontend
     fb = _hip.Fbank(method_args, cdll=cdll)

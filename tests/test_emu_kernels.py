@@ -122,6 +122,11 @@ def test_emu_fbank_variable_length_batch():
         assert (out[i, :ref.shape[0]] - ref).abs().max() < 2e-3 and out[i, ref.shape[0]:].abs().sum() == 0
 
 
+@pytest.mark.parametrize('normalize', [True, False])
+def test_emu_wave_prepare_int16(normalize):
+    lc.wave_prepare_case(emu_cdll(), 'cpu', normalize=normalize)
+
+
 def test_emu_fbank_odd_window_length():
     args = dict(sample_frequency=11025, num_mel_bins=40)  # 275-sample window (odd), 110-sample shift
     w = frontend.synth_waveforms(2, 3000, seed=21)

@@ -117,6 +117,11 @@ def test_gpu_fbank_gain_invariance_full_batch():
     assert ((a[:8] - b[:8]) - (ra - rb)).abs().max().item() < 3e-3
 
 
+@pytest.mark.parametrize('cfg', [dict(), dict(normalize=False), dict(B=256, L=48000, seed=2)])
+def test_gpu_wave_prepare_int16(cfg):
+    lc.wave_prepare_case(product_lib(), DEV, **cfg)
+
+
 def test_gpu_cosine_properties_full_size():
     """config 4 scoring shape: [2048, 192] x [2048, 192]"""
     from mvector import _hip
@@ -219,6 +224,10 @@ def test_gpu_predictor_matches_cpu_predictor(tmp_path):
                model_conf=dict(model='TDNN', model_args=dict(embd_dim=192)))
     gpu = MVectorPredictor(cfg, model_path=str(model_dir), use_gpu=True)
     e_gpu = gpu.predict_batch(paths)
+    assert gpu._last_batch_path == 'pcm16'  # 16-bit mono WAVs at the target rate: int16 upload, scaled / normalised on the device
+    floats = [z['pcm16'][i][: 16000 - 1500 * i].astype(np.float32) / 32768.0 for i in range(4)]
+    e_host = gpu.predict_batch(floats)      # ndarray input: the general host path
+    assert gpu._last_batch_path == 'host' and cos_dist(e_host, e_gpu).max() < 1e-6
     one = gpu.predict(paths[1])
     c_gpu = gpu.contrast(paths[0], paths[2])
     cpu = MVectorPredictor(cfg, model_path=str(model_dir), use_gpu=False)

@@ -95,6 +95,7 @@ _SIGNATURES = {
     'mv_linear_f32': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'mv_profile_enable': (c_i32, [c_i32]),
     'mv_profile_read': (c_i32, [c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32]),
+    'mv_wave_prepare_i16': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp]),
     'mv_asp_pool_f16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
 }
@@ -344,6 +345,23 @@ class Model:
                 self._cdll.mv_model_destroy(self._h)
         except Exception:
             pass
+
+
+def wave_prepare(pcm, num_samples=None, target_db=None, max_gain_db=300.0, cdll=None):
+    """int16 [B, L] on the device -> (float32 [B, L], too_quiet int32 [B]); ``target_db`` None = no dB normalisation."""
+    cdll = cdll or lib()
+    assert pcm.dim() == 2 and pcm.dtype == torch.int16
+    if pcm.stride(1) != 1:
+        pcm = pcm.contiguous()
+    B, L = pcm.shape
+    wav = torch.empty((B, L), dtype=torch.float32, device=pcm.device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=pcm.device)
+    if num_samples is not None:
+        num_samples = num_samples.to(device=pcm.device, dtype=torch.int64).contiguous()
+    check(cdll.mv_wave_prepare_i16(pcm.data_ptr(), pcm.stride(0) if B else L, _ptr(num_samples), B, L, 0 if target_db is None else 1,
+                                   float(target_db or 0.0), float(max_gain_db), wav.data_ptr(), L, flags.data_ptr(), current_stream(pcm)),
+          cdll)
+    return wav, flags
 
 
 def cosine(a, b, cdll=None):

@@ -84,3 +84,16 @@ except ImportError:
             if dtype == 'int16':
                 data = (data * 32767.0).astype(np.int16)
             wavfile.write(filepath, self._sample_rate, data)
+
+
+def read_pcm16(file):
+    """(int16 mono samples, sample rate) of a 16-bit PCM mono WAV given by path / file object / bytes, else None.
+    The GPU predictor uploads such audio as int16 and scales / normalises it on the device (mv_wave_prepare_i16)."""
+    from scipy.io import wavfile as _wavfile
+    try:
+        sr, data = _wavfile.read(io.BytesIO(file) if isinstance(file, (bytes, bytearray)) else file)
+    except Exception:
+        return None
+    if data.dtype != np.int16 or data.ndim != 1:
+        return None
+    return data, int(sr)
