@@ -44,6 +44,8 @@ MODELS = {
                   'EcapaTdnn (c=1024) + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
     'ecapa512': ('EcapaTdnn', dict(), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 3.090,
                  'EcapaTdnn (c=512) + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
+    'ecapa512_mel': ('EcapaTdnn', dict(), 'MelSpectrogram', dict(), 2.559,
+                     'EcapaTdnn (c=512) + MelSpectrogram-128, bs=256, 3 s@16 kHz synthetic (BASELINE config 4, per-GPU share)'),
     'campp': ('CAMPPlus', dict(embd_dim=192), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 3.355,
               'CAM++ + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
 }

@@ -32,64 +32,101 @@ struct StftArgs {
     int power_is_two;
 };
 
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+
 __device__ __forceinline__ int reflect_index(int64_t i, int64_t L) {
     if (i < 0) i = -i;
     if (i >= L) i = 2 * (L - 1) - i;
     return (int)i;
 }
 
+// Real input: X[k] = sum_n xw[n] e^{-2 pi i k n / N} is folded about n = N/2,
+//   Re X[k] = xw[0] + sum_{0 < n < N/2} (xw[n] + xw[N-n]) cos(2 pi k n / N) + xw[N/2] cos(pi k)       (N even)
+//   Im X[k] =       - sum_{0 < n < N/2} (xw[n] - xw[N-n]) sin(2 pi k n / N)
+// which halves the MFMA work (K = N/2 + 1 instead of N).  One WAVE owns 16 frames x NJT bin tiles (7: the 201 bins of the
+// default n_fft = 400 are two groups), so a gathered A fragment feeds 2 * NJT MFMA chains and the four waves of a workgroup
+// stream the same cos / sin rows through the L1 (the first version re-read 819 KB of tables from L2 for every 16 frames).
+template <int NJT>
 __global__ __launch_bounds__(256) void stft_power_kernel(StftArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int64_t nframes = (int64_t)a.B * a.T;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (row0 >= nframes) return;  // no barriers in this kernel
     const int64_t row = row0 + fr < nframes ? row0 + fr : nframes - 1;  // clamp; masked at the store
     const int b = (int)(row / a.T);
     const int t = (int)(row - (int64_t)b * a.T);
     const float* x = a.wav + (int64_t)b * a.wav_stride;
     const int64_t start = (int64_t)t * a.hop - a.pad;
     const bool interior = start >= 0 && start + a.n_fft <= a.L;
+    const int N = a.n_fft, kfold = N / 2 + 1;
+    auto xw = [&](int n) {  // windowed sample n of this lane's frame
+        const int64_t idx = interior ? start + n : reflect_index(start + n, a.L);
+        return x[idx] * a.window[n];
+    };
 
-    for (int bin0 = blockIdx.y * 256 + wave * 64; bin0 < a.nbin; bin0 += gridDim.y * 256) {
-        float4v re[4], im[4];
+    for (int bin0 = blockIdx.y * NJT * 16; bin0 < a.nbin; bin0 += gridDim.y * NJT * 16) {
+        float4v re[NJT], im[NJT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) re[j] = im[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* crow[4];
-        const float* srow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int bin = bin0 + j * 16 + fr;
-            bin = bin < a.nbin_pad ? bin : a.nbin_pad - 1;
-            crow[j] = a.dcos + (int64_t)bin * a.kpad;
-            srow[j] = a.dsin + (int64_t)bin * a.kpad;
-        }
+        for (int j = 0; j < NJT; ++j) re[j] = im[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        // this lane's table row for tile j is (bin0 + j*16 + fr); rows past the padded table are clamped (masked at the store)
+        int brow = bin0 + fr;
         for (int k0 = 0; k0 < a.kpad; k0 += 16) {
             const int k = k0 + 4 * g;
-            float av[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = k + e;
-                float v = 0.0f;
-                if (n < a.n_fft) {
-                    const int64_t idx = interior ? start + n : reflect_index(start + n, a.L);
-                    v = x[idx] * a.window[n];
-                }
-                av[e] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4v c4 = *reinterpret_cast<const float4v*>(crow[j] + k);
-                const float4v s4 = *reinterpret_cast<const float4v*>(srow[j] + k);
+            float ae[4], ao[4];
+            if (interior && N >= 64) {
+                // four consecutive samples and their four mirror partners are two 16-byte loads each (samples, window)
+                // instead of sixteen scattered 4-byte loads: the gather, not the MFMA, bounded the first version.
+                // For k == 0 the mirror block is shifted by one (n = 0 has no partner; N - 0 lies outside the frame).
+                const int sh = k == 0 ? 1 : 0;
+                const float4v x1 = *reinterpret_cast<const float4u*>(x + start + k);
+                const float4v w1 = *reinterpret_cast<const float4u*>(a.window + k);
+                const float4v x2 = *reinterpret_cast<const float4u*>(x + start + N - k - 3 - sh);
+                const float4v w2 = *reinterpret_cast<const float4u*>(a.window + N - k - 3 - sh);
+                const float4v p1 = x1 * w1, p2 = x2 * w2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    re[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], c4[e], re[j], 0, 0, 0);
-                    im[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], s4[e], im[j], 0, 0, 0);
+                    const int n = k + e;
+                    // partner N - n sits at element 3 - e (+1 when the block is shifted) of the mirror block
+                    const float m = sh ? (e == 1 ? p2[3] : (e == 2 ? p2[2] : p2[1])) : p2[3 - e];
+                    const bool has = n > 0 && 2 * n != N && n < kfold;
+                    ae[e] = n < kfold ? p1[e] + (has ? m : 0.0f) : 0.0f;
+                    ao[e] = has ? p1[e] - m : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = k + e;
+                    float ve = 0.0f, vo = 0.0f;
+                    if (n < kfold) {
+                        const float x1 = xw(n);
+                        ve = x1;
+                        if (n > 0 && 2 * n != N) {
+                            const float x2 = xw(N - n);
+                            ve = x1 + x2;
+                            vo = x1 - x2;
+                        }
+                    }
+                    ae[e] = ve;
+                    ao[e] = vo;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJT; ++j) {
+                int bin = brow + j * 16;
+                bin = bin < a.nbin_pad ? bin : a.nbin_pad - 1;
+                const float4v c4 = *reinterpret_cast<const float4v*>(a.dcos + (int64_t)bin * a.kpad + k);
+                const float4v s4 = *reinterpret_cast<const float4v*>(a.dsin + (int64_t)bin * a.kpad + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    re[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], c4[e], re[j], 0, 0, 0);
+                    im[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[e], s4[e], im[j], 0, 0, 0);
                 }
             }
         }
         // lane holds frames row0 + 4g + r, bin = bin0 + j*16 + fr
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJT; ++j) {
             const int bin = bin0 + j * 16 + fr;
             if (bin >= a.nbin) continue;
 #pragma unroll
@@ -184,7 +221,7 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     const int n_fft = cfg->n_fft;
     h->nbin = n_fft / 2 + 1;
     h->nbin_pad = (int)mv::round_up(h->nbin, 16);
-    h->kpad = (int)mv::round_up(n_fft, 16);
+    h->kpad = (int)mv::round_up(n_fft / 2 + 1, 16);  // folded transform length, padded to the MFMA K block
     h->pad = cfg->center ? n_fft / 2 : 0;
     const double pi = 3.14159265358979323846;
     // periodic Hann of win_length, centred in n_fft (torch.stft pads the window on both sides)
@@ -193,7 +230,7 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     for (int i = 0; i < cfg->win_length; ++i) window[left + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / cfg->win_length));
     std::vector<float> dcos((size_t)h->nbin_pad * h->kpad, 0.0f), dsin((size_t)h->nbin_pad * h->kpad, 0.0f);
     for (int k = 0; k < h->nbin; ++k)
-        for (int n = 0; n < n_fft; ++n) {
+        for (int n = 0; n <= n_fft / 2; ++n) {
             const int64_t m = ((int64_t)k * n) % n_fft;  // exact argument reduction
             const double ang = 2.0 * pi * (double)m / n_fft;
             dcos[(size_t)k * h->kpad + n] = (float)cos(ang);
@@ -288,8 +325,10 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
     a.nbin_pad = h->nbin_pad;
     a.power_is_two = h->cfg.power == 2.0f;
     const int64_t nframes = (int64_t)B * T;
-    const unsigned gy = (unsigned)mv::ceil_div(h->nbin, 256);
-    MV_LAUNCH(mv::stft_power_kernel, ((unsigned)mv::ceil_div(nframes, 16), gy, 1), (256, 1, 1), 0, st, a);
+    const unsigned gx = (unsigned)mv::ceil_div(nframes, 64);  // 4 waves x 16 frames
+    // 7 bin tiles per wave (56 accumulator registers for re + im: four waves per SIMD); the default n_fft = 400 has 13 tiles
+    const unsigned gy = (unsigned)mv::ceil_div(h->nbin, 7 * 16);
+    MV_LAUNCH(mv::stft_power_kernel<7>, (gx, gy, 1), (256, 1, 1), 0, st, a);
     int rc = mv::check_launch("stft_power_kernel");
     if (rc != MV_OK) return rc;
     rc = mv::linear_f32_launch(a.P, h->nbin_pad, h->d_fbT, h->nbin_pad, nullptr, MV_ACT_NONE, out, h->cfg.n_mels, (int)nframes,
