@@ -127,6 +127,37 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     return err
 
 
+def conv1d_window_case(cdll, device, B=3, T=300, F_=80, k=5, cout=512, tile=0, seed=0):
+    """The first ECAPA conv as the model runs it: reflect-padded channel-last features [B, T + k - 1, F], 1x1 conv with
+    cin = k*F and row stride F (overlapping rows), T_out = T.  Reference: plain k-tap conv with reflect padding."""
+    g = torch.Generator().manual_seed(seed)
+    pad = (k - 1) // 2
+    x = torch.randn(B, T, F_, generator=g)
+    w = torch.randn(cout, F_, k, generator=g) * (2.0 / (F_ * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    xp = F.pad(x.transpose(1, 2), (pad, pad), mode='reflect').transpose(1, 2).contiguous().half().to(device)
+    wr = w.permute(0, 2, 1).reshape(cout, k * F_, 1).contiguous().to(device)     # [co][tap*F + ci]
+    packed = pack_weight(cdll, wr)
+    biasd = bias.to(device)
+    y = torch.full((B, T, cout + 8), 7.0, dtype=torch.float16, device=device)
+    d = _hip.MvConv1dDesc()
+    d.x, d.x_dtype, d.ldx = xp.data_ptr(), _hip.MV_DT_F16, F_
+    d.w_packed, d.bias = packed.data_ptr(), biasd.data_ptr()
+    d.pre_act, d.post_act = 1, 0
+    d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout + 8
+    d.B, d.T_in, d.T_out, d.cin, d.cout, d.k = B, T + 2 * pad, T, k * F_, cout, 1
+    d.dilation, d.stride, d.pad, d.pad_mode, d.tile = 1, 1, 0, _hip.MV_PAD_ZERO, tile
+    _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xp)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    ref = torch.relu(F.conv1d(xp.cpu().float().transpose(1, 2), w.half().float(), bias)).transpose(1, 2)
+    got = y.cpu().float()
+    assert torch.all(got[..., cout:] == 7.0)
+    err = (got[..., :cout] - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), f'window conv mismatch {err}'
+    return err
+
+
 CONV_CASES = [
     dict(),                                                           # reflect k3 d2
     dict(k=5, dil=1, cin=80, cout=64, x_f32=True, T=50),              # first layer: fp32 features in

@@ -16,6 +16,11 @@ from oracle import frontend
 FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
+@pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=1, T=150, cout=256, tile=256)])
+def test_conv1d_window_emu(cfg):
+    lc.conv1d_window_case(emu_cdll(), 'cpu', **cfg)
+
+
 @pytest.mark.parametrize('idx', range(len(lc.CONV_CASES)))
 def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])

@@ -32,6 +32,11 @@ def test_gpu_library_is_the_hip_build():
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
+@pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=3, T=300, cout=512), dict(B=5, T=298, cout=1024, F_=128, tile=256)])
+def test_conv1d_window(cfg):
+    lc.conv1d_window_case(product_lib(), DEV, **cfg)
+
+
 @pytest.mark.parametrize('idx', range(len(lc.CONV_CASES)))
 def test_gpu_conv1d(idx):
     lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])

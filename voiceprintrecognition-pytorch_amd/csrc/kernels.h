@@ -26,6 +26,7 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
 int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream);
 int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
                             int64_t ldo, int B, int T, int C, hipStream_t stream);
+int cast_reflect_pad_launch(const float* src, half_t* dst, int B, int T, int C, int pad, hipStream_t stream);
 int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_t ldd, int64_t n_rows, int C, hipStream_t stream);
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream);
 bool res2_chain_supported(int T, int width, int steps, int k, int dil);

@@ -299,6 +299,8 @@ struct EcapaModel : MvModelBase {
         ConvLayer shortcut;
     };
     TdnnBlk block0, mfa;
+    ConvLayer block0w;         // block 0 as a 1x1 conv over the contiguous k*F window of the reflect-padded features
+    bool block0_window = false;
     std::vector<SeRes2> blocks;
     AspLayer asp;
     float* fc_w = nullptr;
@@ -318,6 +320,22 @@ struct EcapaModel : MvModelBase {
         int rc;
         MV_REQUIRE(c.res2net_scale >= 2 && c.res2net_scale <= 16, "ecapa: res2net_scale out of range");
         if ((rc = make_tdnn(w, "blocks.0", c.channels[0], c.input_size, c.kernel_sizes[0], &block0))) return rc;
+        // Channel-last features with F % 8 == 0 and a dilation-1 first conv: the k taps of output step t are the k*F
+        // CONTIGUOUS values starting at row t of the reflect-padded features, so block 0 is a 1x1 conv with cin = k*F and
+        // row stride F (rows overlap).  K = 5*80 = 400 -> 7 stages of 64 instead of 5 taps x 128 (80 padded) = 10.
+        block0_window = c.dilations[0] == 1 && c.input_size % 8 == 0 && c.kernel_sizes[0] > 1 && (c.kernel_sizes[0] % 2) == 1;
+        if (const char* e = std::getenv("MV_BLOCK0_WINDOW")) block0_window = block0_window && std::atoi(e) != 0;  // A/B switch
+        if (block0_window) {
+            const int F = c.input_size, k0 = c.kernel_sizes[0], C0 = c.channels[0];
+            std::vector<float> w0, wr((size_t)C0 * k0 * F);
+            if ((rc = w.host("blocks.0.conv.conv.weight", (int64_t)C0 * F * k0, w0))) return rc;
+            for (int co = 0; co < C0; ++co)
+                for (int ci = 0; ci < F; ++ci)
+                    for (int j = 0; j < k0; ++j) wr[((size_t)co * k0 + j) * F + ci] = w0[((size_t)co * F + ci) * k0 + j];
+            float* tmp = upload(wr);
+            if (tmp == nullptr) return fail(MV_ERR_HIP, "ecapa create: upload failed");
+            if ((rc = make_conv_from(tmp, &w, "blocks.0.conv.conv.bias", C0, k0 * F, 1, &block0w))) return rc;
+        }
         nblocks = 3;
         blocks.resize(nblocks);
         ccat = 0;
@@ -377,7 +395,7 @@ struct EcapaModel : MvModelBase {
         const int cwide = cfg.channels[4] > cmax ? cfg.channels[4] : cmax;
         s.stat_sum = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cwide));
         s.stat_sq = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cfg.channels[4]));
-        s.x16 = c.take<half_t>(N * round_up(cfg.input_size, 8));
+        s.x16 = c.take<half_t>((size_t)B * (T + cfg.kernel_sizes[0]) * round_up(cfg.input_size, 8));  // incl. the reflect halo rows
         s.a0 = c.take<half_t>(N * cfg.channels[0]);
         s.cat = c.take<half_t>(N * ccat);
         s.rs[0] = c.take<half_t>(N * (cmax / cfg.res2net_scale));
@@ -418,11 +436,18 @@ struct EcapaModel : MvModelBase {
         const int R = MV_PAD_REFLECT;
         // features to fp16 once (12 MB), then blocks.0 on the direct-to-LDS path
         const int64_t ldf = round_up(cfg.input_size, 8);
-        if ((rc = cast_rows_f32_f16_launch(feats, cfg.input_size, s.x16, ldf, (int64_t)B * T, cfg.input_size, st))) return rc;
-        if ((rc = run_conv(block0.conv, s.x16, MV_DT_F16, ldf, nullptr, 0, s.a0, MV_DT_F16, cfg.channels[0], B, T, T,
-                           cfg.dilations[0], cfg.dilations[0] * (cfg.kernel_sizes[0] - 1) / 2, R, MV_ACT_RELU, block0.scale,
-                           block0.shift, MV_ACT_NONE, nullptr, true, st)))
-            return rc;
+        const int pad0 = cfg.dilations[0] * (cfg.kernel_sizes[0] - 1) / 2;
+        if (block0_window) {
+            if ((rc = cast_reflect_pad_launch(feats, s.x16, B, T, cfg.input_size, pad0, st))) return rc;
+            if ((rc = run_conv(block0w, s.x16, MV_DT_F16, cfg.input_size, nullptr, 0, s.a0, MV_DT_F16, cfg.channels[0], B, T + 2 * pad0, T,
+                               1, 0, MV_PAD_ZERO, MV_ACT_RELU, block0.scale, block0.shift, MV_ACT_NONE, nullptr, true, st)))
+                return rc;
+        } else {
+            if ((rc = cast_rows_f32_f16_launch(feats, cfg.input_size, s.x16, ldf, (int64_t)B * T, cfg.input_size, st))) return rc;
+            if ((rc = run_conv(block0.conv, s.x16, MV_DT_F16, ldf, nullptr, 0, s.a0, MV_DT_F16, cfg.channels[0], B, T, T,
+                               cfg.dilations[0], pad0, R, MV_ACT_RELU, block0.scale, block0.shift, MV_ACT_NONE, nullptr, true, st)))
+                return rc;
+        }
         const half_t* xin = s.a0;
         int64_t ldin = cfg.channels[0];
         int cat_off = 0;

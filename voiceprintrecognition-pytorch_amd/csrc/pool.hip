@@ -242,6 +242,36 @@ int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_
     return check_launch("cast_rows_f32_f16_kernel");
 }
 
+// dst[b, t', :] = (fp16) src[b, reflect(t' - pad), :] for t' in [0, T + 2 pad): the features with the first conv's reflect
+// padding materialised (12 MB), so that the k taps of an output step are ONE contiguous run of k*C values (see
+// EcapaModel::forward, block 0)
+__global__ __launch_bounds__(256) void cast_reflect_pad_kernel(const float* src, half_t* dst, int B, int T, int C, int pad) {
+    const int Tp = T + 2 * pad, C8 = C >> 3;                 // C % 8 == 0: one lane = 8 channels (2 x 16 B in, 16 B out)
+    const int total = B * Tp * C8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c8 = i % C8, r = i / C8;
+        const int b = r / Tp;
+        int t = r - b * Tp - pad;
+        t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+        const float4v* s4 = reinterpret_cast<const float4v*>(src + ((int64_t)b * T + t) * C) + 2 * c8;
+        const float4v lo = s4[0], hi = s4[1];
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        half8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+        *reinterpret_cast<half8v*>(dst + (int64_t)i * 8) = o;
+    }
+}
+
+int cast_reflect_pad_launch(const float* src, half_t* dst, int B, int T, int C, int pad, hipStream_t stream) {
+    MV_REQUIRE(src != nullptr && dst != nullptr && pad >= 0 && pad < T && C % 8 == 0, "cast_reflect_pad: bad argument");
+    const int64_t total = (int64_t)B * (T + 2 * pad) * (C / 8);
+    MV_REQUIRE(total < (int64_t)1 << 31, "cast_reflect_pad: batch too large");
+    const int grid = (int)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    MV_LAUNCH(cast_reflect_pad_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, dst, B, T, C, pad);
+    return check_launch("cast_reflect_pad_kernel");
+}
+
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream) {
     MV_REQUIRE(C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_slice: channels must be a multiple of 8");
     const int64_t total = n_rows * (C / 8);
