@@ -53,6 +53,7 @@ struct ConvArgs {
     int B, T_in, T_out, cin, cin_pad, cout, cout_pad, k, dil, stride, pad, pad_mode;
     int pre_act, post_act, y_f16, gate_seg_len, gate_nseg;
     int n_rows, n_tiles, co_tiles;
+    int store_nt;  // persistent kernel: output stores carry the streaming policy bits (see conv_store_policy)
     float* stat_sum;  // optional partial time sums of the output (persistent kernel): [ceil(n_rows / 64)][2][cout]
     float* stat_sq;   // optional partial sums of squares (about the BatchNorm shift), same layout
 };
@@ -88,6 +89,18 @@ __device__ __forceinline__ float clamp3(float v, float lo, float hi) {
     return fminf(fmaxf(v, lo), hi);
 #else
     return __builtin_amdgcn_fmed3f(v, lo, hi);
+#endif
+}
+
+// max(v, lo) as exactly one v_max_f32: fmaxf / v_med3 against +inf are lowered to a canonicalising v_max v, v, v plus the
+// max itself, which doubled the activation cost of the 128-value epilogues
+__device__ __forceinline__ float max_raw(float v, float lo) {
+#ifdef MV_EMU
+    return fmaxf(v, lo);
+#else
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+    return r;
 #endif
 }
 
@@ -551,34 +564,63 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     const int first = n0 + wn * 64;
     const int split = STATS ? (first / a.T_out + 1) * a.T_out - first : 0;  // rows >= split belong to the next utterance
     if constexpr (STATS == 0) {
-        // time step outermost: the two 64-byte halves of a 128-byte output line are written by consecutive stores
-        auto finish = [&](const float4v& c, int mi) {  // bias, activation, BatchNorm affine, saturation -> 4 fp16 in 2 registers
-            const int col = wc * 128 + mi * 16 + 4 * q;
-            float4v v = c + *reinterpret_cast<const float4v*>(par + col * 4);
+        // Two halves of 4 channel tiles: their scale / shift stay in registers across the four 16-step column blocks (the
+        // per-block broadcast reads of the parameters used to cost more LDS cycles than the whole K stage), the bias is
+        // already in the accumulators (see the init in stage 0), and the two 64-byte halves of a 128-byte output line are
+        // still written by consecutive stores.
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
-            v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4) + *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
-            half4v hv;
+        for (int h = 0; h < 2; ++h) {
+            float4v sc[4], sh[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (half_t)clamp3(v[e], lo_post, 65504.0f);  // post-activation + fp16 saturation: one v_med3
-            return hv;
-        };
+            for (int u = 0; u < 4; ++u) {
+                const int col = wc * 128 + (4 * h + u) * 16 + 4 * q;
+                sc[u] = *reinterpret_cast<const float4v*>(par + 1024 + col * 4);
+                sh[u] = *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
+            }
+            auto finish = [&](const float4v& c, int u) {
+                // pre-activation as one v_max each, BatchNorm affine as two v_pk_fma_f32, post-activation + fp16 saturation
+                // as one v_med3 each
+                float2v v0 = {max_raw(c[0], lo_pre), max_raw(c[1], lo_pre)};
+                float2v v1 = {max_raw(c[2], lo_pre), max_raw(c[3], lo_pre)};
+                v0 = v0 * float2v{sc[u][0], sc[u][1]} + float2v{sh[u][0], sh[u][1]};
+                v1 = v1 * float2v{sc[u][2], sc[u][3]} + float2v{sh[u][2], sh[u][3]};
+                half4v hv;
+                hv[0] = (half_t)clamp3(v0[0], lo_post, 65504.0f);
+                hv[1] = (half_t)clamp3(v0[1], lo_post, 65504.0f);
+                hv[2] = (half_t)clamp3(v1[0], lo_post, 65504.0f);
+                hv[3] = (half_t)clamp3(v1[1], lo_post, 65504.0f);
+                return hv;
+            };
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + r;
-            half_t* yrow = y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane;
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + r;
+                half_t* yrow = y + (int64_t)n * a.ldy + co0 + wc * 128 + ch_lane;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const half4v ha = finish(acc[2 * p][ni], 2 * p), hb = finish(acc[2 * p + 1][ni], 2 * p + 1);
-                unsigned xa[2], xb[2];
-                __builtin_memcpy(xa, &ha, 8);
-                __builtin_memcpy(xb, &hb, 8);
-                row_swap_odd_even(xa[0], xb[0]);
-                row_swap_odd_even(xa[1], xb[1]);
-                const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
-                half8v ov;
-                __builtin_memcpy(&ov, o, 16);
-                if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int p = 2 * h + pp;
+                    const half4v ha = finish(acc[2 * p][ni], 2 * pp), hb = finish(acc[2 * p + 1][ni], 2 * pp + 1);
+                    unsigned xa[2], xb[2];
+                    __builtin_memcpy(xa, &ha, 8);
+                    __builtin_memcpy(xb, &hb, 8);
+                    row_swap_odd_even(xa[0], xb[0]);
+                    row_swap_odd_even(xa[1], xb[1]);
+                    const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
+                    half8v ov;
+                    __builtin_memcpy(&ov, o, 16);
+#if defined(MV_PROBE) && MV_PROBE == 4   // timing probe 4 (tools/probe only): the epilogue computes but never stores
+                    if (n < a.n_rows && a.ldy < 0) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+#elif defined(MV_EMU)
+                    if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+#else
+                    if (a.store_nt) {  // uniform
+                        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                        const uint4v ou = {o[0], o[1], o[2], o[3]};
+                        if (n < a.n_rows) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(yrow + p * 32), "v"(ou) : "memory");
+                    } else {
+                        if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+                    }
+#endif
+                }
             }
         }
         return;
@@ -602,7 +644,7 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int col = wc * 128 + (2 * p + u) * 16 + 4 * q;
-                float4v v = acc[2 * p + u][ni] + *reinterpret_cast<const float4v*>(par + col * 4);
+                float4v v = acc[2 * p + u][ni];  // bias included (accumulator init)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
                 v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4);  // u = y - shift
@@ -850,21 +892,23 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     // One K stage.  FIRST / LAST are compile-time for the peeled copies, so the steady-state body (neither) is: wait,
     // barrier, request stage s+1, 64 MFMAs -- no tile bookkeeping, no branches.
     auto stage = [&](int s, auto first, auto last) {
-        wait_all_loads();
-        MV_TRACE(0);
-        __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
-        MV_TRACE(1);
         bool feed = true;  // a stage (of this tile or the first of the next one) is requested during this stage
+        // bookkeeping of the stage to request (for the last stage: the next tile's row / weight pointers, two integer
+        // divisions per row) runs while this stage's transfers are still landing
         if (!decltype(last)::value) {
             prepare(s + 1, buf ^ 1);
         } else {
             more = advance(l_vb + gridDim.x);
             feed = more;
-            if (more) {
-                l_ps = l_ps == 2 ? 0 : l_ps + 1;
-                prepare(0, buf ^ 1);
-                issue_params();
-            }
+            if (more) prepare(0, buf ^ 1);
+        }
+        wait_all_loads();
+        MV_TRACE(0);
+        __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
+        MV_TRACE(1);
+        if (decltype(last)::value && more) {
+            l_ps = l_ps == 2 ? 0 : l_ps + 1;
+            issue_params();
         }
 #if defined(MV_PROBE) && MV_PROBE == 1   // timing probe 1 (tools/probe only): no global->LDS traffic inside a tile
         if (!decltype(last)::value) feed = false;
@@ -872,10 +916,14 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         MV_TRACE(2);
         if (decltype(first)::value) {
             if (pending) persistent_epilogue<STATS>(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+            // accumulators start from the bias of their 4 channels (parameter slot of the tile being computed)
+            const char* par = smem + CVP_PARAM_OFF + l_ps * CVP_PARAM_SLOT;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                const float4v b4 = *reinterpret_cast<const float4v*>(par + (wc * 128 + mi * 16 + 4 * (lane >> 4)) * 4);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
+            }
         }
 #if defined(MV_PROBE) && MV_PROBE == 2   // timing probe 2: no LDS reads / MFMAs
         if (feed)
@@ -940,7 +988,11 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 // 4-byte load each to pull them into L2 early (slower: the touches sit in the same in-order vmcnt queue); a 4-wave layout
 // with 128 x 128 wave tiles and the accumulators in AccVGPRs (a third less LDS traffic, but one wave per SIMD: 7 % slower on
 // K = 3072, 24 % on K = 1024); a counted vmcnt wait that lets the epilogue's stores drain across the next stage (neutral);
-// starting the eight XCDs ~1 us apart to break up the 32 MiB store burst of the lockstep epilogues (slower).  The in-kernel
+// starting the eight XCDs ~1 us apart to break up the 32 MiB store burst of the lockstep epilogues (slower); requesting
+// stage 1 of a tile ahead of the previous tile's epilogue stores + waiting with vmcnt(16) (neutral, r02d); streaming store
+// policy bits (faster per layer, slower end to end, see conv_store_policy).  Also neutral, but kept because they remove
+// work: the next tile's bookkeeping ahead of the wait, epilogue parameters in registers, bias in the accumulator init,
+// single-instruction max (r02d: the tile boundary is bounded by the store drain, not by the epilogue's instruction count).  The in-kernel
 // timeline (MV_PROBE=3, tools/trace_conv.py) shows per K stage ~400 cycles barrier skew, ~1650 cycles MFMA issue per wave
 // (two waves share a SIMD's matrix pipe: 2048 busy cycles) and 1000-2000 cycles until the next stage has landed.
 //
@@ -1099,6 +1151,20 @@ __global__ void pack_conv_weight_kernel(const float* w, int cout, int cin, int k
 int conv1d_cin_pad(int cin) { return (int)round_up(cin, CV_BK); }
 int conv1d_cout_pad(int cout) { return (int)round_up(cout, 32); }
 
+// Streaming ("sc1 nt") output stores for the persistent kernel -- measured, OFF by default.  All workgroups reach their
+// epilogues together, so a layer's output leaves as bursts of 32 MiB (in isolation the stores cost 27 us of a 187 us K = 1024
+// layer, 83 us of the 1270 us K = 3072 layer: probe 4).  With the streaming bits a K = 1024 layer alone runs 187 -> 173 us
+// (K = 3072: 1280 -> 1310 us), but the layers that consume the output then miss in L2 / MALL: end to end 68.2 k -> 65.7 k
+// utterances/s (r02d, same box).  MV_CONV_STORE_NT = 0 / 1 / 2: never (default) / K <= 1536 / always.
+static int conv_store_policy(int64_t k_total) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = std::getenv("MV_CONV_STORE_NT");
+        mode = e != nullptr ? std::atoi(e) : 0;
+    }
+    return mode == 2 || (mode == 1 && k_total <= 1536) ? 1 : 0;
+}
+
 static int cu_count() {
     static int n = -1;
     if (n < 0) {
@@ -1247,6 +1313,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
     a.n_tiles = (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
+    a.store_nt = conv_store_policy((int64_t)d.k * a.cin_pad);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
     static bool smem_set = false;
     if (!smem_set) {
