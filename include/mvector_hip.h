@@ -157,6 +157,22 @@ typedef struct MvTdnnCfg {
 } MvTdnnCfg;
 int mv_tdnn_create(const MvTdnnCfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
 
+/* ERes2Net.forward / ERes2NetV2.forward (mvector/models/eres2net.py:266-287 / 441-456): 2-D Res2Net blocks with AFF
+ * fusion, temporal statistics pooling (pooling.py:130-148), seg_1 (+ optional ReLU -> seg_bn_1 -> seg_2). */
+typedef struct MvEres2Cfg {
+    int32_t version;       /* 1 = ERes2Net, 2 = ERes2NetV2 */
+    int32_t input_size;    /* F (80); must be a multiple of 8 */
+    int32_t embd_dim;      /* 192 */
+    int32_t num_blocks[4]; /* {3,4,6,3} */
+    int32_t m_channels;    /* 32 */
+    int32_t mul_channel;   /* ERes2Net only: 1 */
+    int32_t expansion;     /* 2 */
+    int32_t base_width;    /* ERes2Net 32, ERes2NetV2 26 */
+    int32_t scale;         /* 2 */
+    int32_t two_emb_layer; /* 0 */
+} MvEres2Cfg;
+int mv_eres2net_create(const MvEres2Cfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
+
 int mv_model_destroy(MvModel* m);
 int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
 int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes);
@@ -185,6 +201,46 @@ int mv_l2_normalize_f32(float* x, int32_t n, int32_t dim, mv_stream_t stream);
 #define MV_ACT_SIGMOID 3
 #define MV_DT_F32 0
 #define MV_DT_F16 1
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D convolution layer of the ERes2Net family (eres2net.py:23-30: conv1x1 / conv3x3, zero padding k/2, no conv
+ * bias) on channel-last fp32 maps [B, H = frequency, W = time, C], channels padded to multiples of 16 (fp32 operands on
+ * v_mfma_f32_16x16x4_f32: the family is too deep for fp16 operands at the 1e-4 cosine bar, see csrc/conv2d.hip):
+ *   y = epi( sum_taps W . in + bias ),  in = x | x + x2 (eres2net.py:92) | cat(x, x2) (AFF, eres2net.py:49)
+ *   epi 0: clamp(v [+ res], lo, hi)   -- BatchNorm folded into W / bias, ReLU(0..20) eres2net.py:12-15, residual :103-105
+ *   epi 1: SiLU (AFF local_att, eres2net.py:41)
+ *   epi 2: res * (1 + tanh v) + res2 * (1 - tanh v)   (AFF output, eres2net.py:50-52)
+ * ------------------------------------------------------------------------------------------------ */
+#define MV_EPI_CLAMP 0
+#define MV_EPI_SILU 1
+#define MV_EPI_AFF 2
+/* pack [Cout][Cin][k][k] fp32 (nn.Conv2d layout) times an optional per-output-channel scale -> fp32 [cout16][k*k][cin16] */
+int64_t mv_conv2d_packed_elems(int32_t cout, int32_t cin, int32_t ks);
+int mv_conv2d_pack_weight(const float* w, const float* out_scale, int32_t cout, int32_t cin, int32_t ks, float* packed,
+                          mv_stream_t stream);
+typedef struct MvConv2dDesc {
+    const float* x;      /* [B, H, W, ldx] */
+    const float* x2;     /* optional second input */
+    int32_t x2_mode;     /* 0 none, 1 added, 2 concatenated behind the first cin1 channels */
+    int32_t cin1;
+    int64_t ldx, ldx2;
+    const float* w;      /* packed [cout16][ks*ks][cin16] */
+    const float* bias;   /* [cout16] */
+    const float* res;    /* epi 0: optional residual; epi 2: first AFF operand; [B, Ho, Wo, ldres] */
+    const float* res2;   /* epi 2: second AFF operand */
+    int64_t ldres, ldres2;
+    float* y;            /* [B, Ho, Wo, ldy], Ho = (H + 2*(ks/2) - ks)/stride + 1 */
+    int64_t ldy;
+    int32_t B, H, W, cin16, cout16, ks, stride, epi;
+    float lo, hi;
+} MvConv2dDesc;
+int mv_conv2d_forward(const MvConv2dDesc* d, mv_stream_t stream);
+/* first ERes2Net conv: features fp32 [B, T, F] -> fp32 [B, F, T, C] = relu(conv3x3(1 -> C) + bias), w fp32 [C][9] */
+int mv_conv2d_first(const float* feats, float* out, const float* w, const float* bias, int32_t B, int32_t T, int32_t F,
+                    int32_t C, mv_stream_t stream);
+/* temporal statistics pooling of fp32 [B, H, W, ld] (C real channels) -> fp32 [B, 2*C*H]: mean | sqrt(unbiased var + 1e-8),
+ * index c*H + h as the reference flattens [B, C, H] */
+int mv_tstp_f32(const float* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream);
 
 /* pack [Cout][Cin][k] fp32 (nn.Conv1d layout) -> fp16 [Cout_pad][k][Cin_pad]; returns element count */
 int64_t mv_conv1d_packed_elems(int32_t cout, int32_t cin, int32_t k);

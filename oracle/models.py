@@ -209,4 +209,86 @@ def campplus(sd, x, prefix='', blocks=((12, 1), (24, 2), (16, 2)), return_layers
     return emb
 
 
-FORWARDS = {'EcapaTdnn': ecapa_tdnn, 'TDNN': tdnn, 'CAMPPlus': campplus}
+# --------------------------------------------------------------------------- ERes2Net / ERes2NetV2
+
+def _relu20(x):
+    """eres2net.py:12-15: the family's "ReLU" is Hardtanh(0, 20)."""
+    return x.clamp(0.0, 20.0)
+
+
+def _aff(p, x, y):
+    """eres2net.py:32-52 (AFF): attention from cat(x, y) through conv1x1 -> BN -> SiLU -> conv1x1 -> BN."""
+    a = p.sub('local_att')
+    h = F.conv2d(torch.cat((x, y), dim=1), a['0.weight'], a['0.bias'])
+    h = F.silu(_bn(a.sub('1'), h))
+    h = _bn(a.sub('4'), F.conv2d(h, a['3.weight'], a['3.bias']))
+    att = 1.0 + torch.tanh(h)
+    return x * att + y * (2.0 - att)
+
+
+def _eres_block(p, x, stride):
+    """eres2net.py:55-108 / 111-170 (and the V2 twins :290-335 / :338-380): 1x1 (strided) -> scale x [3x3 on
+    sp (+ spx[i] | AFF(sp, spx[i]))] -> 1x1, shortcut conv+BN when the shape changes, ReLU20 everywhere."""
+    out = _relu20(_bn(p.sub('bn1'), F.conv2d(x, p['conv1.weight'], stride=stride)))
+    width = p['convs.0.weight'].shape[0]
+    groups = torch.split(out, width, 1)
+    outs, sp = [], None
+    for i, g in enumerate(groups):
+        if i == 0:
+            sp = g
+        elif p.has(f'fuse_models.{i - 1}.local_att.0.weight'):
+            sp = _aff(p.sub(f'fuse_models.{i - 1}'), sp, g)
+        else:
+            sp = sp + g
+        sp = _relu20(_bn(p.sub(f'bns.{i}'), F.conv2d(sp, p[f'convs.{i}.weight'], padding=1)))
+        outs.append(sp)
+    out = _bn(p.sub('bn3'), F.conv2d(torch.cat(outs, 1), p['conv3.weight']))
+    if p.has('shortcut.0.weight'):
+        x = _bn(p.sub('shortcut.1'), F.conv2d(x, p['shortcut.0.weight'], stride=stride))
+    return _relu20(out + x)
+
+
+def _tstp(x):
+    """pooling.py:130-148 (TemporalStatsPool): mean and sqrt(unbiased var + 1e-8) over the last axis, flattened [B, C*F]."""
+    return torch.cat((x.mean(-1).flatten(1), torch.sqrt(x.var(-1) + 1e-8).flatten(1)), 1)
+
+
+def _eres_layers(p, x):
+    """conv1/bn1/relu stem (plain ReLU, eres2net.py:270) and the four stages; block counts read from the keys."""
+    out = torch.relu(_bn(p.sub('bn1'), F.conv2d(x.permute(0, 2, 1).unsqueeze(1), p['conv1.weight'], padding=1)))
+    outs = []
+    for l in range(1, 5):
+        j = 0
+        while p.has(f'layer{l}.{j}.conv1.weight'):
+            out = _eres_block(p.sub(f'layer{l}.{j}'), out, 2 if (j == 0 and l > 1) else 1)
+            j += 1
+        outs.append(out)
+    return outs
+
+
+def _eres_head(p, stats):
+    emb = F.linear(stats, p['seg_1.weight'], p['seg_1.bias'])
+    if p.has('seg_2.weight'):  # two_emb_layer (eres2net.py:283-288)
+        emb = F.linear(_bn(p.sub('seg_bn_1'), torch.relu(emb)), p['seg_2.weight'], p['seg_2.bias'])
+    return emb
+
+
+def eres2net(sd, x, prefix=''):
+    """ERes2Net.forward, eres2net.py:266-289: bottom-up fusion of all four stage outputs."""
+    p = _P(sd, prefix)
+    o1, o2, o3, o4 = _eres_layers(p, x)
+    f12 = _aff(p.sub('fuse_mode12'), o2, F.conv2d(o1, p['layer1_downsample.weight'], stride=2, padding=1))
+    f123 = _aff(p.sub('fuse_mode123'), o3, F.conv2d(f12, p['layer2_downsample.weight'], stride=2, padding=1))
+    f1234 = _aff(p.sub('fuse_mode1234'), o4, F.conv2d(f123, p['layer3_downsample.weight'], stride=2, padding=1))
+    return _eres_head(p, _tstp(f1234))
+
+
+def eres2netv2(sd, x, prefix=''):
+    """ERes2NetV2.forward, eres2net.py:441-456: only stages 3 and 4 are fused."""
+    p = _P(sd, prefix)
+    _, _, o3, o4 = _eres_layers(p, x)
+    f34 = _aff(p.sub('fuse34'), o4, F.conv2d(o3, p['layer3_ds.weight'], stride=2, padding=1))
+    return _eres_head(p, _tstp(f34))
+
+
+FORWARDS = {'EcapaTdnn': ecapa_tdnn, 'TDNN': tdnn, 'CAMPPlus': campplus, 'ERes2Net': eres2net, 'ERes2NetV2': eres2netv2}

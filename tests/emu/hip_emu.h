@@ -279,6 +279,28 @@ inline emu_float4 emu_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_float4
     emu::wave_sync();
     return c;
 }
+// mfma_f32_16x16x16f16 : A[i=lane&15][k=4*(lane>>4)+e], B[k=4*(lane>>4)+e][j=lane&15], D as 16x16 above
+typedef _Float16 emu_half4 __attribute__((ext_vector_type(4)));
+inline emu_float4 emu_mfma_f32_16x16x16f16(emu_half4 a, emu_half4 b, emu_float4 c) {
+    int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 8);
+    memcpy(emu::wave_slot(1, lane), &b, 8);
+    emu::wave_sync();
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            emu_half4 av, bv;
+            memcpy(&av, emu::wave_slot(0, row + 16 * (k / 4)), 8);
+            memcpy(&bv, emu::wave_slot(1, col + 16 * (k / 4)), 8);
+            acc += (float)av[k % 4] * (float)bv[k % 4];
+        }
+        c[r] = acc;
+    }
+    emu::wave_sync();
+    return c;
+}
 inline emu_float16 emu_mfma_f32_32x32x16_f16(emu_half8 a, emu_half8 b, emu_float16 c) {
     int lane = emu::flat_tid() & 63;
     memcpy(emu::wave_slot(0, lane), &a, 16);
@@ -320,6 +342,7 @@ inline emu_float4 emu_mfma_f32_16x16x4f32(float a, float b, emu_float4 c) {
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_f16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) emu_mfma_f32_16x16x16f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
 

@@ -158,6 +158,128 @@ def conv1d_window_case(cdll, device, B=3, T=300, F_=80, k=5, cout=512, tile=0, s
     return err
 
 
+def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, x2_mode=0, epi=0, with_res=False,
+                lo=0.0, hi=20.0, seed=0):
+    """mv_conv2d_forward against F.conv2d in fp32 (ERes2Net layer: conv -> folded BN -> epilogue)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    r16 = lambda n: -(-n // 16) * 16
+    cin_a = cin if x2_mode != 2 else cin // 2          # concat: two operands of cin/2 channels each
+    lda = r16(cin_a) + 8
+    xa = rn(B, H, W, lda)
+    xb = rn(B, H, W, lda) if x2_mode else None
+    w = rn(cout, cin, ks, ks) * (2.0 / (cin * ks * ks)) ** 0.5
+    bn_scale = torch.rand(cout, generator=g) + 0.5
+    bias = rn(cout) * 0.3
+    p = ks // 2
+    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // stride + 1
+    c16 = r16(cout)
+    ldy = c16 + 4
+    res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
+    res2 = rn(B, Ho, Wo, c16) if epi == 2 else None
+    dev = lambda t: None if t is None else t.to(device).contiguous()
+    xad, xbd, resd, res2d = dev(xa), dev(xb), dev(res), dev(res2)
+    wd, sd = dev(w), dev(bn_scale)
+    if x2_mode == 2:
+        # packed K axis = [r16(cin_a) channels of x | r16(cin_a) channels of x2]
+        wfull = torch.zeros(cout, 2 * r16(cin_a), ks, ks)
+        wfull[:, :cin_a] = w[:, :cin_a]
+        wfull[:, r16(cin_a):r16(cin_a) + cin_a] = w[:, cin_a:]
+        wd = dev(wfull)
+        cin_k = 2 * r16(cin_a)
+    else:
+        cin_k = cin
+    n = cdll.mv_conv2d_packed_elems(cout, cin_k, ks)
+    packed = torch.zeros(n, dtype=torch.float32, device=device)
+    _hip.check(cdll.mv_conv2d_pack_weight(wd.data_ptr(), sd.data_ptr(), cout, cin_k, ks, packed.data_ptr(), _stream(wd)), cdll)
+    biasd = torch.zeros(c16, device=device)
+    biasd[:cout] = dev(bias)
+    y = torch.full((B, Ho, Wo, ldy), 7.0, dtype=torch.float32, device=device)
+    d = _hip.MvConv2dDesc()
+    d.x, d.ldx = xad.data_ptr(), lda
+    d.x2, d.ldx2, d.x2_mode, d.cin1 = (xbd.data_ptr() if x2_mode else None), lda, x2_mode, r16(cin_a)
+    d.w, d.bias = packed.data_ptr(), biasd.data_ptr()
+    d.res, d.ldres = (resd.data_ptr() if res is not None else None), c16
+    d.res2, d.ldres2 = (res2d.data_ptr() if res2 is not None else None), c16
+    d.y, d.ldy = y.data_ptr(), ldy
+    d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
+    d.lo, d.hi = lo, hi
+    _hip.check(cdll.mv_conv2d_forward(ctypes.byref(d), _stream(xad)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+
+    xin = xa.float()[..., :cin_a]
+    if x2_mode == 1:
+        xin = xin + xb.float()[..., :cin_a]
+    elif x2_mode == 2:
+        xin = torch.cat([xin, xb.float()[..., :cin_a]], dim=-1)
+    weff = w * bn_scale.view(-1, 1, 1, 1)
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias, stride=stride, padding=p).permute(0, 2, 3, 1)
+    if epi == 0:
+        if with_res:
+            ref = ref + res.float()[..., :cout]
+        ref = ref.clamp(lo, hi)
+    elif epi == 1:
+        ref = F.silu(ref)
+    else:
+        t = torch.tanh(ref)
+        ref = res.float()[..., :cout] * (1 + t) + res2.float()[..., :cout] * (1 - t)
+    got = y.cpu().float()
+    assert torch.all(got[..., c16:] == 7.0), 'kernel wrote outside its channel slice'
+    if c16 > cout and epi != 2:
+        assert torch.all(got[..., cout:c16] == (0.0 if epi != 0 else min(max(0.0, lo), hi))), 'padded channels must stay zero'
+    err = (got[..., :cout] - ref).abs().max().item()
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert err < tol, f'conv2d mismatch {err} (tol {tol})'
+    return err
+
+
+CONV2D_CASES = [
+    dict(),                                                                  # 3x3 16 -> 16
+    dict(cin=13, cout=13, x2_mode=1),                                        # ERes2NetV2 width 13 (padded), sp + spx[i]
+    dict(cin=32, cout=32, ks=1, stride=2, H=8, W=41),                        # strided 1x1 (conv1 / shortcut of a stage's first block)
+    dict(cin=64, cout=128, ks=3, stride=2, H=9, W=150, hi=65504.0, lo=-65504.0),  # layer1_downsample: no BN / activation
+    dict(cin=32, cout=64, ks=1, with_res=True, W=300, H=3),                  # conv3 + bn3 + residual + ReLU20, 3 time tiles
+    dict(cin=128, cout=16, ks=1, x2_mode=2, epi=1),                          # AFF local_att[0:3]: cat -> 1x1 -> BN -> SiLU
+    dict(cin=16, cout=64, ks=1, epi=2),                                      # AFF local_att[3:5] + fusion
+    dict(cin=104, cout=104, ks=3, H=5, W=40, B=1),                           # width 104: two K chunks, 7 channel blocks -> NB 1
+    dict(cin=256, cout=512, ks=3, stride=2, H=6, W=20, B=1, hi=65504.0, lo=-65504.0),  # layer3_downsample
+]
+
+
+def tstp_case(cdll, device, B=3, H=5, W=38, C=72, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ld = C + 8
+    x = torch.randn(B, H, W, ld, generator=g) * 2 + 1
+    x[0, 0, :, 3] = 1.5   # constant channel: std = sqrt(1e-8)
+    xd = x.to(device)
+    out = torch.full((B, 2 * C * H), float('nan'), device=device)
+    _hip.check(cdll.mv_tstp_f32(xd.data_ptr(), ld, B, H, W, C, out.data_ptr(), _stream(xd)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    xr = x.float()[..., :C].permute(0, 3, 1, 2)            # [B, C, H, W] as the reference holds it
+    ref = torch.cat([xr.mean(-1).flatten(1), torch.sqrt(xr.var(-1) + 1e-8).flatten(1)], 1)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), f'tstp mismatch {err}'
+    return err
+
+
+def conv2d_first_case(cdll, device, B=2, T=50, F_=16, C=32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, T, F_, generator=g)
+    w = torch.randn(C, 9, generator=g) * 0.3
+    bias = torch.randn(C, generator=g) * 0.1
+    fd, wd, bd = feats.to(device), w.to(device), bias.to(device)
+    out = torch.empty(B, F_, T, C, dtype=torch.float32, device=device)
+    _hip.check(cdll.mv_conv2d_first(fd.data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, T, F_, C, _stream(fd)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(feats.permute(0, 2, 1).unsqueeze(1), w.view(C, 1, 3, 3), bias, padding=1)).permute(0, 2, 3, 1)
+    err = (out.cpu().float() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), f'conv2d_first mismatch {err}'
+    return err
+
+
 CONV_CASES = [
     dict(),                                                           # reflect k3 d2
     dict(k=5, dil=1, cin=80, cout=64, x_f32=True, T=50),              # first layer: fp32 features in
@@ -283,10 +405,12 @@ def fbank_case(cdll, device, wav, ratio, method_args):
     return d.max().item()
 
 
-def model_case(cdll, device, case, tol=1e-4):
+def model_case(cdll, device, case, tol=1e-4, max_batch=None):
     """Golden case through the native model handle (weights from the manifest, reference embedding from golden)."""
     from helpers import load_case, cos_dist
     man, sd, x, emb_ref, _ = load_case(case)
+    if max_batch is not None:
+        x, emb_ref = x[:max_batch], emb_ref[:max_batch]
     kw = man['kwargs']
     if man['model'] == 'EcapaTdnn':
         cfg = _hip.MvEcapaCfg()
@@ -300,6 +424,16 @@ def model_case(cdll, device, case, tol=1e-4):
         cfg = _hip.MvTdnnCfg()
         cfg.input_size, cfg.channels, cfg.embd_dim = kw['input_size'], kw.get('channels', 512), kw.get('embd_dim', 192)
         kind = 'tdnn'
+    elif man['model'] in ('ERes2Net', 'ERes2NetV2'):
+        v2 = man['model'] == 'ERes2NetV2'
+        cfg = _hip.MvEres2Cfg()
+        cfg.version, cfg.input_size, cfg.embd_dim = (2 if v2 else 1), kw['input_size'], kw.get('embd_dim', 192)
+        for i, n in enumerate(kw.get('num_blocks', [3, 4, 6, 3])):
+            cfg.num_blocks[i] = n
+        cfg.m_channels, cfg.mul_channel, cfg.expansion = kw.get('m_channels', 32), 1, 2
+        cfg.base_width, cfg.scale = kw.get('base_width', 26 if v2 else 32), kw.get('scale', 2)
+        cfg.two_emb_layer = int(kw.get('two_emb_layer', False))
+        kind = 'eres2net'
     else:
         cfg = _hip.MvCamppCfg()
         cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 512)

@@ -16,6 +16,18 @@ from oracle import frontend
 FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
+@pytest.mark.parametrize('idx', range(len(lc.CONV2D_CASES)))
+def test_conv2d_emu(idx):
+    if idx == 8 and os.environ.get('MV_SLOW_EMU') != '1':
+        pytest.skip('~40 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
+    lc.conv2d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV2D_CASES[idx])
+
+
+def test_tstp_and_first_conv_emu():
+    lc.tstp_case(emu_cdll(), 'cpu')
+    lc.conv2d_first_case(emu_cdll(), 'cpu')
+
+
 @pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=1, T=150, cout=256, tile=256)])
 def test_conv1d_window_emu(cfg):
     lc.conv1d_window_case(emu_cdll(), 'cpu', **cfg)
@@ -75,6 +87,12 @@ def test_emu_fbank_edge_cases():
     assert (fb23(w) - ref).abs().max() < 2e-3
     with pytest.raises(RuntimeError, match='512-point'):
         lc._hip.Fbank(dict(sample_frequency=8000, num_mel_bins=40), cdll=emu_cdll())
+
+
+@pytest.mark.parametrize('case', ['eres2net_tiny', 'eres2netv2_tiny'])
+def test_emu_eres2net_tiny_end_to_end(case):
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', case, tol=1e-8, max_batch=1)  # fp32 operands: far inside the 1e-4 bar
+    assert rel < 1e-4
 
 
 def test_emu_ecapa_tiny_end_to_end():

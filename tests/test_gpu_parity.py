@@ -32,6 +32,16 @@ def test_gpu_library_is_the_hip_build():
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
+@pytest.mark.parametrize('idx', range(len(lc.CONV2D_CASES)))
+def test_conv2d(idx):
+    lc.conv2d_case(product_lib(), DEV, seed=idx, **lc.CONV2D_CASES[idx])
+
+
+def test_tstp_and_first_conv():
+    lc.tstp_case(product_lib(), DEV)
+    lc.conv2d_first_case(product_lib(), DEV, B=3, T=298, F_=80, C=32)
+
+
 @pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=3, T=300, cout=512), dict(B=5, T=298, cout=1024, F_=128, tile=256)])
 def test_conv1d_window(cfg):
     lc.conv1d_window_case(product_lib(), DEV, **cfg)
@@ -171,7 +181,33 @@ def test_gpu_native_model_matches_reference_golden(case):
     assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'tdnn', 'campp_short'])
+@pytest.mark.parametrize('case', ['eres2net_tiny', 'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32'])
+def test_gpu_eres2net_matches_reference_golden(case):
+    """ERes2Net / ERes2NetV2: fp32 operands, so far inside the 1e-4 bar."""
+    cd, rel = lc.model_case(product_lib(), DEV, case)
+    assert cd < 1e-6 and rel < 2e-3, (cd, rel)
+
+
+def test_gpu_eres2net_full_batch_properties():
+    """ERes2NetV2 m32 at 64 x 3 s through the module API: native path taken, finite, batch-invariant, spot parity vs the oracle."""
+    import mvector.models as M
+    man, sd, x, emb_ref, _ = load_case('eres2netv2_m32')
+    m = M.ERes2NetV2(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(64, 298, 80, generator=g) * 2.0
+    feats = feats - feats.mean(1, keepdim=True)
+    emb = m(feats.to(DEV))
+    assert m.__dict__.get('_native_handles'), 'native handle was not created: forward did not take the HIP path'
+    assert emb.shape == (64, 192) and torch.isfinite(emb).all()
+    small = m(feats[40:42].to(DEV))
+    assert cos_dist(small.cpu(), emb[40:42].cpu()).max() < 1e-9
+    ref = omodels.eres2netv2(sd, feats[:1])
+    assert cos_dist(emb[:1].cpu(), ref).max() < 1e-6
+
+
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'tdnn', 'campp_short', 'eres2net_tiny'])
 def test_gpu_module_forward_uses_native_and_tracks_weights(case):
     import mvector.models as M
     man, sd, x, emb_ref, _ = load_case(case)

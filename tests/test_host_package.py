@@ -16,7 +16,8 @@ from oracle import frontend, models as omodels, scoring
 FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'campp', 'tdnn'])
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'campp', 'tdnn', 'eres2net_tiny',
+                                  'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32'])
 def test_state_dict_layout_equals_reference_manifest(case):
     import mvector.models as M
     with open(os.path.join(GOLDEN, f'manifest_{case}.json')) as f:
@@ -28,7 +29,7 @@ def test_state_dict_layout_equals_reference_manifest(case):
     assert m.embd_dim == man['kwargs'].get('embd_dim', 192)
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'campp_short', 'tdnn'])
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'campp_short', 'tdnn', 'eres2net_tiny', 'eres2netv2_tiny'])
 def test_cpu_module_forward_matches_reference_golden(case):
     import mvector.models as M
     man, sd, x, emb_ref, _ = load_case(case)

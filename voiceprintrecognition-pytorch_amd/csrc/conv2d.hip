@@ -1,0 +1,339 @@
+// 2-D convolutions of the ERes2Net family (mvector/models/eres2net.py): 1x1 and 3x3 kernels, stride 1 or 2, zero padding
+// k/2, no conv bias, BatchNorm directly behind every conv (folded into the packed weights + a per-channel bias), the
+// clamped ReLU (Hardtanh 0..20, eres2net.py:12-15), the Res2Net "sp + spx[i]" input sum (eres2net.py:92), the residual
+// add (eres2net.py:103-105) and the attentional feature fusion AFF (eres2net.py:32-52) as epilogue / loader modes.
+//
+// Precision: fp32 maps, fp32 weights, v_mfma_f32_16x16x4_f32.  Unlike the TDNN-style backbones this family does not
+// tolerate 11-bit operands: ~50 clamped layers amplify a relative perturbation of 1e-6 at the input to 2e-4 at the
+// embedding, and rounding either the weights or the activations to fp16 moves the embedding by 6-8 % (1 - cos 2e-3..5e-3
+// against the 1e-4 bar; measured with the oracle).  The fp32 matrix pipe runs at a quarter of the
+// fp16 rate, which these small-channel, memory-heavy layers can afford.
+//
+// Layout: feature maps are channel-last fp32 [B, H = frequency, W = time, C]; the channel counts of the model (13 ... 512)
+// are padded to multiples of 16 when the weights are packed (zero rows / columns), so padded channels carry exact zeros.
+//
+// One workgroup (4 waves) owns 128 consecutive time steps of one (utterance, output frequency) row and one tile of
+// NB*16 output channels.  K loop over chunks of <= 32 input channels: the k x (127*stride + k) input patch of the chunk
+// is staged in LDS once (zero padding, the input sum and the channel concatenation of AFF happen here) and every tap
+// reads it back as MFMA B operands; the weights are small (<= 4.7 MB for the largest layer, L2 resident) and are read
+// straight from global memory as A operands, each feeding the wave's two 16-step column blocks.
+// K slot (step k4, lane group q) of a 16-channel group carries channel 4q + k4, so a lane's four K steps are ONE 16-byte
+// read of consecutive channels on both sides (the sum over K does not care about the order).  D[channel 4q+r][step j]:
+// a lane stores 4 consecutive channels (16 bytes) of one time step.
+#include "kernels.h"
+
+namespace mv {
+
+constexpr int C2_PX = 128;      // time steps per workgroup
+constexpr int C2_CK = 32;       // input channels per K chunk
+constexpr int C2_RS = C2_CK + 4;  // LDS row stride in floats (144 B: 16-byte aligned, spreads the banks)
+
+struct Conv2dArgs {
+    const float* x;     // [B, H, W, ldx]
+    const float* x2;    // optional second input, same spatial shape
+    const float* w;     // packed [cout16][k*k][cin16], BatchNorm scale folded in
+    const float* bias;  // [cout16]
+    const float* res;   // epi 0: optional residual [B, Ho, Wo, ldres]; epi 2: first AFF operand
+    const float* res2;  // epi 2: second AFF operand
+    float* y;           // [B, Ho, Wo, ldy]
+    int64_t ldx, ldx2, ldres, ldres2, ldy;
+    int x2_mode;        // 0 none, 1 added to x, 2 concatenated behind the cin1 channels of x
+    int cin1, cin16, cout16;
+    int B, H, W, Ho, Wo, ks, stride;
+    int epi;            // 0: clamp(v [+ res], lo, hi); 1: SiLU; 2: AFF mix  res*(1+tanh v) + res2*(1-tanh v)
+    float lo, hi;
+};
+
+__device__ __forceinline__ float4v mfma4(float a, float b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
+    MV_DYN_SMEM(smem);
+    float* patch = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, q = lane >> 4;
+    const int wtiles = (a.Wo + C2_PX - 1) / C2_PX;
+    const int wt = blockIdx.x % wtiles, ct = blockIdx.x / wtiles;
+    const int ho = blockIdx.y, b = blockIdx.z;
+    const int wo0 = wt * C2_PX, co0 = ct * NB * 16;
+    const int ks = a.ks, s = a.stride, p = ks >> 1, taps = ks * ks;
+    const int ncols = ks == 1 ? C2_PX : (C2_PX - 1) * s + ks;
+
+    float4v acc[2][NB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int c0 = 0; c0 < a.cin16; c0 += C2_CK) {
+        const int ck = a.cin16 - c0 < C2_CK ? a.cin16 - c0 : C2_CK;  // multiple of 16
+        const int chunks = ck >> 2;                                  // 16-byte pieces per position
+        const int items = ks * ncols * chunks;
+        for (int it = tid; it < items; it += 256) {
+            const int ch = it % chunks;
+            const int rc = it / chunks;
+            const int col = rc % ncols, kh = rc / ncols;
+            const int hi = ho * s - p + kh;
+            const int wi = ks == 1 ? (wo0 + col) * s : wo0 * s - p + col;
+            float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
+                const int64_t pix = ((int64_t)b * a.H + hi) * a.W + wi;
+                const int cc = c0 + ch * 4;
+                if (a.x2_mode == 2 && cc >= a.cin1) {
+                    v = *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + (cc - a.cin1));
+                } else {
+                    v = *reinterpret_cast<const float4v*>(a.x + pix * a.ldx + cc);
+                    if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + cc);
+                }
+            }
+            *reinterpret_cast<float4v*>(patch + (kh * ncols + col) * C2_RS + ch * 4) = v;
+        }
+        __syncthreads();
+        const int kgroups = ck >> 4;
+        for (int tap = 0; tap < taps; ++tap) {
+            const int kh = tap / ks, kw = tap - kh * ks;
+            for (int g = 0; g < kgroups; ++g) {
+                float4v bf[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int px = wave * 32 + u * 16 + j16;
+                    const int col = ks == 1 ? px : px * s + kw;
+                    bf[u] = *reinterpret_cast<const float4v*>(patch + (kh * ncols + col) * C2_RS + g * 16 + q * 4);
+                }
+#pragma unroll
+                for (int m = 0; m < NB; ++m) {
+                    const int co = co0 + m * 16 + j16;
+                    const float4v af =
+                        *reinterpret_cast<const float4v*>(a.w + ((int64_t)co * taps + tap) * a.cin16 + c0 + g * 16 + q * 4);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[k4], bf[u][k4], acc[u][m]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int wo = wo0 + wave * 32 + u * 16 + j16;
+        if (wo >= a.Wo) continue;
+        const int64_t pix = ((int64_t)b * a.Ho + ho) * a.Wo + wo;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int co = co0 + m * 16 + q * 4;
+            const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[u][m][r] + bias[r];
+            if (a.epi == 0) {
+                if (a.res != nullptr) {
+                    const float4v rv = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
+            } else if (a.epi == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            } else {
+                const float4v xa = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
+                const float4v ya = *reinterpret_cast<const float4v*>(a.res2 + pix * a.ldres2 + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = tanhf(v[r]);  // x_att = 1 + t;  out = x * x_att + y * (2 - x_att)
+                    v[r] = xa[r] * (1.0f + t) + ya[r] * (1.0f - t);
+                }
+            }
+            *reinterpret_cast<float4v*>(a.y + pix * a.ldy + co) = float4v{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+static size_t conv2d_lds_bytes(int ks, int stride) {
+    const int ncols = ks == 1 ? C2_PX : (C2_PX - 1) * stride + ks;
+    return (size_t)ks * ncols * C2_RS * sizeof(float);
+}
+
+int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
+    MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2d: null pointer");
+    MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0, "conv2d: empty input");
+    MV_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv2d: kernel 1 or 3, stride 1 or 2");
+    MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2d: channels must be padded to 16");
+    MV_REQUIRE(d.ldx % 4 == 0 && d.ldy % 4 == 0, "conv2d: leading dimensions");
+    MV_REQUIRE(d.x2_mode >= 0 && d.x2_mode <= 2 && (d.x2_mode == 0 || (d.x2 != nullptr && d.ldx2 % 4 == 0)), "conv2d: second input");
+    if (d.x2_mode == 2) MV_REQUIRE(d.cin1 > 0 && d.cin1 % 4 == 0 && d.cin1 < d.cin16, "conv2d: concat split");
+    MV_REQUIRE(d.epi >= 0 && d.epi <= 2, "conv2d: epilogue mode");
+    if (d.epi == 2) MV_REQUIRE(d.res != nullptr && d.res2 != nullptr, "conv2d: AFF mix needs both operands");
+    Conv2dArgs a;
+    a.x = d.x; a.x2 = d.x2; a.w = d.w; a.bias = d.bias; a.res = d.res; a.res2 = d.res2; a.y = d.y;
+    a.ldx = d.ldx; a.ldx2 = d.ldx2; a.ldres = d.ldres; a.ldres2 = d.ldres2; a.ldy = d.ldy;
+    a.x2_mode = d.x2_mode; a.cin1 = d.x2_mode == 2 ? d.cin1 : d.cin16; a.cin16 = d.cin16; a.cout16 = d.cout16;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.ks = d.ks; a.stride = d.stride;
+    const int p = d.ks / 2;
+    a.Ho = (d.H + 2 * p - d.ks) / d.stride + 1;
+    a.Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
+    a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
+    const int nb = d.cout16 % 128 == 0 ? 8 : (d.cout16 % 64 == 0 ? 4 : (d.cout16 % 32 == 0 ? 2 : 1));
+    const int wtiles = (a.Wo + C2_PX - 1) / C2_PX;
+    const dim3 grid((unsigned)(wtiles * (d.cout16 / (nb * 16))), (unsigned)a.Ho, (unsigned)d.B);
+    MV_REQUIRE(a.Ho <= 65535 && d.B <= 65535, "conv2d: grid too large");
+    const size_t lds = conv2d_lds_bytes(d.ks, d.stride);
+    static bool smem_set = false;
+    if (!smem_set) {
+        const int big = (int)conv2d_lds_bytes(3, 2);
+        if (MV_SET_MAX_SMEM(conv2d_kernel<1>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<2>, big) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<8>, big) != hipSuccess)
+            return fail(MV_ERR_HIP, "conv2d: cannot reserve dynamic LDS");
+        smem_set = true;
+    }
+    switch (nb) {
+        case 8: MV_LAUNCH(conv2d_kernel<8>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
+        case 4: MV_LAUNCH(conv2d_kernel<4>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
+        case 2: MV_LAUNCH(conv2d_kernel<2>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
+        default: MV_LAUNCH(conv2d_kernel<1>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
+    }
+    return check_launch("conv2d_kernel");
+}
+
+// ---- first conv of ERes2Net (eres2net.py:196-201, 250): one input map = the fp32 features [B, T, F] read transposed,
+// 3x3, zero padding, BatchNorm folded, plain ReLU.  K = 9 -> VALU; a lane produces 8 output maps of one position.
+__global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, float* out, const float* w, const float* bias,
+                                                           int B, int T, int F, int C) {
+    MV_DYN_SMEM(smem);
+    float* sw = reinterpret_cast<float*>(smem);  // [C][9] weights, then [C] bias
+    for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < C; i += 256) sw[C * 9 + i] = bias[i];
+    __syncthreads();
+    const int groups = C >> 3;
+    const int64_t total = (int64_t)B * F * T * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % groups);
+        const int64_t pix = i / groups;  // (b*F + f)*T + t
+        const int t = (int)(pix % T);
+        const int f = (int)((pix / T) % F);
+        const int b = (int)(pix / ((int64_t)T * F));
+        float x[9];
+#pragma unroll
+        for (int df = 0; df < 3; ++df)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int ff = f + df - 1, tt = t + dt - 1;
+                x[df * 3 + dt] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? feats[((int64_t)b * T + tt) * F + ff] : 0.0f;
+            }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = cg * 8 + e;
+            float acc = sw[C * 9 + co];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc += sw[co * 9 + j] * x[j];
+            o[e] = fmaxf(acc, 0.0f);
+        }
+        *reinterpret_cast<float4v*>(out + pix * C + cg * 8) = float4v{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<float4v*>(out + pix * C + cg * 8 + 4) = float4v{o[4], o[5], o[6], o[7]};
+    }
+}
+
+int conv2d_first_launch(const float* feats, float* out, const float* w, const float* bias, int B, int T, int F, int C,
+                        hipStream_t stream) {
+    MV_REQUIRE(feats != nullptr && out != nullptr && w != nullptr && bias != nullptr, "conv2d_first: null pointer");
+    MV_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024, "conv2d_first: output maps must be a multiple of 8");
+    const int64_t total = (int64_t)B * F * T * (C / 8);
+    const int grid = (int)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
+    MV_LAUNCH(conv2d_first_kernel, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, out, w, bias, B, T, F, C);
+    return check_launch("conv2d_first_kernel");
+}
+
+// ---- temporal statistics pooling (mvector/models/pooling.py:130-148) over channel-last maps [B, H, W, C]:
+// stats[b, c*H + h] = mean over W, stats[b, C*H + c*H + h] = sqrt(unbiased var + 1e-8) -- the reference flattens [B, C, H].
+// One workgroup per (utterance, frequency row); moments about the first time step (see time_stats_kernel).
+__global__ __launch_bounds__(256) void tstp_kernel(const float* x, int64_t ld, int H, int W, int C, int Creal, float* stats) {
+    __shared__ float red[2][256];
+    const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + ((int64_t)b * H + h) * W * ld;
+    for (int c0 = 0; c0 < Creal; c0 += 64) {  // 64 channels x 4 time phases per pass
+        const int c = c0 + (tid & 63), ph = tid >> 6;
+        float s1 = 0.0f, s2 = 0.0f, k = 0.0f;
+        if (c < Creal) {
+            k = xr[c];
+            for (int w = ph; w < W; w += 4) {
+                const float d = xr[(int64_t)w * ld + c] - k;
+                s1 += d;
+                s2 = fmaf(d, d, s2);
+            }
+        }
+        red[0][tid] = s1;
+        red[1][tid] = s2;
+        __syncthreads();
+        if (tid < 64 && c < Creal) {
+            const float z1 = red[0][tid] + red[0][tid + 64] + red[0][tid + 128] + red[0][tid + 192];
+            const float z2 = red[1][tid] + red[1][tid + 64] + red[1][tid + 128] + red[1][tid + 192];
+            const float var = fmaxf(z2 - z1 * z1 / (float)W, 0.0f) / (float)(W - 1);
+            float* sb = stats + (int64_t)b * 2 * Creal * H;
+            sb[c * H + h] = k + z1 / (float)W;
+            sb[Creal * H + c * H + h] = sqrtf(var + 1e-8f);
+        }
+        __syncthreads();
+    }
+    (void)C;
+}
+
+int tstp_launch(const float* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && stats != nullptr && B > 0 && H > 0 && W > 1 && C > 0 && ld >= C, "tstp: bad argument");
+    MV_REQUIRE(H <= 65535 && B <= 65535, "tstp: grid too large");
+    MV_LAUNCH(tstp_kernel, ((unsigned)H, (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, H, W, (int)ld, C, stats);
+    return check_launch("tstp_kernel");
+}
+
+// [Cout][Cin][k][k] fp32 (* out_scale[co]) -> fp32 [cout16][k*k][cin16], zero padded
+__global__ void pack_conv2d_weight_kernel(const float* w, const float* out_scale, int cout, int cin, int taps, int cout16,
+                                          int cin16, float* packed) {
+    const int64_t total = (int64_t)cout16 * taps * cin16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin16);
+        const int tap = (int)((i / cin16) % taps);
+        const int co = (int)(i / ((int64_t)cin16 * taps));
+        float v = 0.0f;
+        if (co < cout && ci < cin) v = w[((int64_t)co * cin + ci) * taps + tap] * (out_scale != nullptr ? out_scale[co] : 1.0f);
+        packed[i] = v;
+    }
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int64_t mv_conv2d_packed_elems(int32_t cout, int32_t cin, int32_t ks) {
+    return (int64_t)mv::round_up(cout, 16) * ks * ks * mv::round_up(cin, 16);
+}
+
+int mv_conv2d_pack_weight(const float* w, const float* out_scale, int32_t cout, int32_t cin, int32_t ks, float* packed,
+                          mv_stream_t stream) {
+    MV_REQUIRE(w != nullptr && packed != nullptr && cout > 0 && cin > 0 && (ks == 1 || ks == 3), "mv_conv2d_pack_weight: bad argument");
+    const int64_t total = mv_conv2d_packed_elems(cout, cin, ks);
+    const int grid = (int)(mv::ceil_div(total, 256) < 4096 ? mv::ceil_div(total, 256) : 4096);
+    MV_LAUNCH(mv::pack_conv2d_weight_kernel, (grid, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), w, out_scale, cout, cin,
+              ks * ks, (int)mv::round_up(cout, 16), (int)mv::round_up(cin, 16), packed);
+    return mv::check_launch("pack_conv2d_weight_kernel");
+}
+
+int mv_conv2d_forward(const MvConv2dDesc* d, mv_stream_t stream) {
+    MV_REQUIRE(d != nullptr, "mv_conv2d_forward: null descriptor");
+    return mv::conv2d_launch(*d, static_cast<hipStream_t>(stream));
+}
+
+int mv_conv2d_first(const float* feats, float* out, const float* w, const float* bias, int32_t B, int32_t T, int32_t F, int32_t C,
+                    mv_stream_t stream) {
+    return mv::conv2d_first_launch(feats, out, w, bias, B, T, F, C, static_cast<hipStream_t>(stream));
+}
+
+int mv_tstp_f32(const float* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream) {
+    return mv::tstp_launch(x, ld, B, H, W, C, stats, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -12,6 +12,12 @@ int conv_stats_finish_launch(const float* psum, const float* psq, const float* s
                              int64_t ld_out, float clamp_eps, hipStream_t stream);
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream);
 
+typedef MvConv2dDesc Conv2dDesc;
+int conv2d_launch(const Conv2dDesc& d, hipStream_t stream);
+int conv2d_first_launch(const float* feats, float* out, const float* w, const float* bias, int B, int T, int F, int C,
+                        hipStream_t stream);
+int tstp_launch(const float* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);
+
 int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
                       int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream);
 

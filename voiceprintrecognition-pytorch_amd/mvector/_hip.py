@@ -47,6 +47,19 @@ class MvCamppCfg(ctypes.Structure):
                 ('init_channels', c_i32)]
 
 
+class MvEres2Cfg(ctypes.Structure):
+    _fields_ = [('version', c_i32), ('input_size', c_i32), ('embd_dim', c_i32), ('num_blocks', c_i32 * 4),
+                ('m_channels', c_i32), ('mul_channel', c_i32), ('expansion', c_i32), ('base_width', c_i32),
+                ('scale', c_i32), ('two_emb_layer', c_i32)]
+
+
+class MvConv2dDesc(ctypes.Structure):
+    _fields_ = [('x', c_vp), ('x2', c_vp), ('x2_mode', c_i32), ('cin1', c_i32), ('ldx', c_i64), ('ldx2', c_i64),
+                ('w', c_vp), ('bias', c_vp), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64),
+                ('y', c_vp), ('ldy', c_i64), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('cin16', c_i32),
+                ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32), ('lo', c_f32), ('hi', c_f32)]
+
+
 class MvTdnnCfg(ctypes.Structure):
     _fields_ = [('input_size', c_i32), ('channels', c_i32), ('embd_dim', c_i32)]
 
@@ -79,6 +92,12 @@ _SIGNATURES = {
     'mv_ecapa_create': (c_i32, [ctypes.POINTER(MvEcapaCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
     'mv_campp_create': (c_i32, [ctypes.POINTER(MvCamppCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
     'mv_tdnn_create': (c_i32, [ctypes.POINTER(MvTdnnCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
+    'mv_eres2net_create': (c_i32, [ctypes.POINTER(MvEres2Cfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
+    'mv_conv2d_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
+    'mv_conv2d_pack_weight': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'mv_conv2d_forward': (c_i32, [ctypes.POINTER(MvConv2dDesc), c_vp]),
+    'mv_conv2d_first': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'mv_tstp_f32': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_model_destroy': (c_i32, [c_vp]),
     'mv_model_embd_dim': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     'mv_model_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_sz)]),
@@ -310,7 +329,7 @@ class Model:
             refs[i].numel = t.numel()
         self._h = c_vp()
         create = {'ecapa': self._cdll.mv_ecapa_create, 'campp': self._cdll.mv_campp_create,
-                  'tdnn': self._cdll.mv_tdnn_create}[kind]
+                  'tdnn': self._cdll.mv_tdnn_create, 'eres2net': self._cdll.mv_eres2net_create}[kind]
         if tensors and tensors[0].is_cuda:
             torch.cuda.current_stream(tensors[0].device).synchronize()  # weights fully written before create() reads them
         check(create(ctypes.byref(cfg), refs, len(tensors), ctypes.byref(self._h)), self._cdll)

@@ -5,6 +5,7 @@ import importlib
 from mvector.utils.logger import logger
 from .campplus import CAMPPlus
 from .ecapa_tdnn import EcapaTdnn
+from .eres2net import ERes2Net, ERes2NetV2
 from .tdnn import TDNN
 
 __all__ = ['build_model']
