@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (the ERes2Net family computes on fp32 operands, csrc/conv2d.hip)
 SAMPLES = 48000              # 3 s @ 16 kHz
 
 MODELS = {
@@ -46,6 +47,10 @@ MODELS = {
                  'EcapaTdnn (c=512) + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
     'ecapa512_mel': ('EcapaTdnn', dict(), 'MelSpectrogram', dict(), 2.559,
                      'EcapaTdnn (c=512) + MelSpectrogram-128, bs=256, 3 s@16 kHz synthetic (BASELINE config 4, per-GPU share)'),
+    'eres2net': ('ERes2Net', dict(m_channels=32), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 10.083,
+                 'ERes2Net (m_channels=32, configs/eres2net.yml) + Fbank-80, 3 s@16 kHz synthetic'),
+    'eres2netv2': ('ERes2NetV2', dict(m_channels=32), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 6.242,
+                   'ERes2NetV2 (m_channels=32) + Fbank-80, 3 s@16 kHz synthetic'),
     'campp': ('CAMPPlus', dict(embd_dim=192), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 3.355,
               'CAM++ + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
 }
@@ -179,13 +184,17 @@ def main():
             hits = [v for k, v in traffic.items() if k.startswith(prefix)] if args.model == 'ecapa1024' else []
             return max(hits, key=lambda v: v['launches_sampled'])['hbm_bytes_per_launch'] if hits else None
 
-        n_conv, ms_conv, flop_conv = prof_read(0)
+        f32_family = cls.startswith('ERes2Net')
+        n_conv, ms_conv, flop_conv = prof_read(2 if f32_family else 0)
         n_fb, ms_fb, byte_fb = prof_read(1)
         conv_tflops = flop_conv / (ms_conv * 1e-3) / 1e12 if ms_conv > 0 else 0.0
         fb_gbs = byte_fb / (ms_fb * 1e-3) / 1e9 if ms_fb > 0 else 0.0
-        roof_conv = {'kernel': 'conv1d (implicit GEMM on MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel), all launches',
-                     'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(conv_tflops / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': pmc_bytes('mv::conv1d_glds_persistent_kernel'),
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if f32_family else MFMA_F16_PEAK_TFLOPS
+        roof_conv = {'kernel': 'conv2d_kernel (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32), all launches, padded channel counts'
+                     if f32_family else
+                     'conv1d (implicit GEMM on MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel), all launches',
+                     'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                     'frac': round(conv_tflops / mfma_peak, 4), 'traffic': pmc_bytes('mv::conv1d_glds_persistent_kernel'),
                      'launches': n_conv, 'avg_launch_us': round(ms_conv / max(n_conv, 1) * 1e3, 2),
                      'algorithmic_gflop_per_launch': round(flop_conv / max(n_conv, 1) / 1e9, 3),
                      'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3)}
@@ -194,10 +203,11 @@ def main():
                       'avg_launch_us': round(ms_fb / max(n_fb, 1) * 1e3, 2),
                       'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1))}
         out = {
-            'metric': 'utterances/sec embedded (3 s@16 kHz, Fbank-80, EcapaTdnn, bs=256)',
+            'metric': f'utterances/sec embedded (3 s@16 kHz, Fbank-80, {cls}, bs={B})' if f32_family else
+            'utterances/sec embedded (3 s@16 kHz, Fbank-80, EcapaTdnn, bs=256)',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if f32_family else 'f16', 'data': 'synthetic',
             'config': {'workload': label, 'batch_per_gpu': B, 'global_batch': world * B, 'samples_per_utt': SAMPLES,
                        'frames': 298, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
             'stage_ms': {'fbank_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
@@ -205,8 +215,8 @@ def main():
             'roofline': roof_conv,
             'roofline_fbank': roof_fbank,
             'roofline_backbone': {'kernel': 'whole backbone stage (conv1d + res2 chain + SE + ASP + fc)', 'bound': 'mfma',
-                                  'achieved': round(bb_tflops, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                  'frac': round(bb_tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                                  'achieved': round(bb_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                                  'frac': round(bb_tflops / mfma_peak, 4),
                                   'algorithmic_gflop_per_utt': gflop_per_utt},
         }
         if world == 1:

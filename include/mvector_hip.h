@@ -310,6 +310,7 @@ int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C
  * bytes (MV_PROF_FBANK: B*(4*L + 4*T*num_mel_bins) per launch).  mv_profile_read waits for the recorded launches. */
 #define MV_PROF_CONV1D 0
 #define MV_PROF_FBANK 1
+#define MV_PROF_CONV2D 2 /* work = 2*B*Ho*Wo*cin16*cout16*ks*ks FLOPs on the padded channel counts */
 int mv_profile_enable(int32_t on);
 int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, double* total_work, int32_t reset);
 

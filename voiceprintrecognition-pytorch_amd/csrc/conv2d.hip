@@ -191,12 +191,14 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
             return fail(MV_ERR_HIP, "conv2d: cannot reserve dynamic LDS");
         smem_set = true;
     }
+    const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)d.cin16 * d.cout16 * d.ks * d.ks, stream);
     switch (nb) {
         case 8: MV_LAUNCH(conv2d_kernel<8>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
         case 4: MV_LAUNCH(conv2d_kernel<4>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
         case 2: MV_LAUNCH(conv2d_kernel<2>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
         default: MV_LAUNCH(conv2d_kernel<1>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
     }
+    prof_end(prof, stream);
     return check_launch("conv2d_kernel");
 }
 
