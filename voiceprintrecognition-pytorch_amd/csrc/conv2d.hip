@@ -12,9 +12,10 @@
 // Layout: feature maps are channel-last fp32 [B, H = frequency, W = time, C]; the channel counts of the model (13 ... 512)
 // are padded to multiples of 16 when the weights are packed (zero rows / columns), so padded channels carry exact zeros.
 //
-// One workgroup (4 waves) owns 128 consecutive time steps of one (utterance, output frequency) row and one tile of
-// NB*16 output channels.  K loop over chunks of <= 32 input channels: the k x (127*stride + k) input patch of the chunk
-// is staged in LDS once (zero padding, the input sum and the channel concatenation of AFF happen here) and every tap
+// The output plane of an utterance is cut into segments of 16 consecutive time steps (row-major: the maps shrink to
+// 10 x 38 in the last stage, so whole-row tiles would idle most lanes); one workgroup (4 waves) owns 8 consecutive
+// segments and one tile of NB*16 output channels.  K loop over chunks of <= 32 input channels: the k x (15*stride + k)
+// input patch behind each segment is staged in LDS once (zero padding, the input sum and the channel concatenation of AFF happen here) and every tap
 // reads it back as MFMA B operands; the weights are small (<= 4.7 MB for the largest layer, L2 resident) and are read
 // straight from global memory as A operands, each feeding the wave's two 16-step column blocks.
 // K slot (step k4, lane group q) of a 16-channel group carries channel 4q + k4, so a lane's four K steps are ONE 16-byte
@@ -24,9 +25,8 @@
 
 namespace mv {
 
-constexpr int C2_PX = 128;      // time steps per workgroup
+constexpr int C2_SEGS = 8;      // 16-step segments per workgroup (two per wave)
 constexpr int C2_CK = 32;       // input channels per K chunk
-constexpr int C2_RS = C2_CK + 4;  // LDS row stride in floats (144 B: 16-byte aligned, spreads the banks)
 
 struct Conv2dArgs {
     const float* x;     // [B, H, W, ldx]
@@ -54,64 +54,94 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     float* patch = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, q = lane >> 4;
-    const int wtiles = (a.Wo + C2_PX - 1) / C2_PX;
-    const int wt = blockIdx.x % wtiles, ct = blockIdx.x / wtiles;
-    const int ho = blockIdx.y, b = blockIdx.z;
-    const int wo0 = wt * C2_PX, co0 = ct * NB * 16;
+    const int nsegw = (a.Wo + 15) >> 4, nseg = a.Ho * nsegw;  // 16-step segments of one utterance, row-major
+    const int stiles = (nseg + C2_SEGS - 1) / C2_SEGS;
+    const int st = blockIdx.x % stiles, ct = blockIdx.x / stiles;
+    const int b = blockIdx.y;
+    const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
     const int ks = a.ks, s = a.stride, p = ks >> 1, taps = ks * ks;
-    const int ncols = ks == 1 ? C2_PX : (C2_PX - 1) * s + ks;
+    const int ncols = ks == 1 ? 16 : 15 * s + ks;  // input columns behind one segment
+    const int rs = (a.cin16 < C2_CK ? a.cin16 : C2_CK) + 4;  // LDS row stride in floats: 16-byte aligned, spreads the banks
+    const int seg_floats = ks * ncols * rs;
 
     float4v acc[2][NB];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int m = 0; m < NB; ++m) acc[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    // this lane's weight rows (clamped inside the matrix for the uneven last channel tile: computed, never stored)
+    const float* wrow[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        const int cb = co0 + m * 16 < a.cout16 ? co0 + m * 16 : a.cout16 - 16;
+        wrow[m] = a.w + (int64_t)(cb + j16) * taps * a.cin16 + q * 4;
+    }
+    // this wave's two segments
+    int ho_u[2], wo_u[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sg = sg0 + wave * 2 + u;
+        ho_u[u] = sg < nseg ? sg / nsegw : -1;
+        wo_u[u] = sg < nseg ? (sg - ho_u[u] * nsegw) * 16 : 0;
+    }
 
     for (int c0 = 0; c0 < a.cin16; c0 += C2_CK) {
         const int ck = a.cin16 - c0 < C2_CK ? a.cin16 - c0 : C2_CK;  // multiple of 16
         const int chunks = ck >> 2;                                  // 16-byte pieces per position
-        const int items = ks * ncols * chunks;
+        const int per_seg = ks * ncols * chunks;
+        const int items = C2_SEGS * per_seg;
         for (int it = tid; it < items; it += 256) {
-            const int ch = it % chunks;
-            const int rc = it / chunks;
+            const int sl = it / per_seg;
+            const int r0 = it - sl * per_seg;
+            const int ch = r0 % chunks;
+            const int rc = r0 / chunks;
             const int col = rc % ncols, kh = rc / ncols;
-            const int hi = ho * s - p + kh;
-            const int wi = ks == 1 ? (wo0 + col) * s : wo0 * s - p + col;
+            const int sg = sg0 + sl;
             float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
-                const int64_t pix = ((int64_t)b * a.H + hi) * a.W + wi;
-                const int cc = c0 + ch * 4;
-                if (a.x2_mode == 2 && cc >= a.cin1) {
-                    v = *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + (cc - a.cin1));
-                } else {
-                    v = *reinterpret_cast<const float4v*>(a.x + pix * a.ldx + cc);
-                    if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + cc);
+            if (sg < nseg) {
+                const int ho = sg / nsegw, wo0 = (sg - ho * nsegw) * 16;
+                const int hi = ho * s - p + kh;
+                const int wi = ks == 1 ? (wo0 + col) * s : wo0 * s - p + col;
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
+                    const int64_t pix = ((int64_t)b * a.H + hi) * a.W + wi;
+                    const int cc = c0 + ch * 4;
+                    if (a.x2_mode == 2 && cc >= a.cin1) {
+                        v = *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + (cc - a.cin1));
+                    } else {
+                        v = *reinterpret_cast<const float4v*>(a.x + pix * a.ldx + cc);
+                        if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + cc);
+                    }
                 }
             }
-            *reinterpret_cast<float4v*>(patch + (kh * ncols + col) * C2_RS + ch * 4) = v;
+            *reinterpret_cast<float4v*>(patch + sl * seg_floats + (kh * ncols + col) * rs + ch * 4) = v;
         }
         __syncthreads();
-        const int kgroups = ck >> 4;
+        const int kgroups = ck >> 4;  // 1 or 2
+        const float* pw = patch + (wave * 2) * seg_floats;
         for (int tap = 0; tap < taps; ++tap) {
             const int kh = tap / ks, kw = tap - kh * ks;
-            for (int g = 0; g < kgroups; ++g) {
-                float4v bf[2];
+            const int col = ks == 1 ? j16 : j16 * s + kw;
+            // all operands of the tap first (up to 2*NB weight reads in flight instead of one at a time), then the MFMAs
+            float4v af[2][NB], bf[2][2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int px = wave * 32 + u * 16 + j16;
-                    const int col = ks == 1 ? px : px * s + kw;
-                    bf[u] = *reinterpret_cast<const float4v*>(patch + (kh * ncols + col) * C2_RS + g * 16 + q * 4);
-                }
+            for (int g = 0; g < 2; ++g) {
+                if (g >= kgroups) break;  // uniform
 #pragma unroll
-                for (int m = 0; m < NB; ++m) {
-                    const int co = co0 + m * 16 + j16;
-                    const float4v af =
-                        *reinterpret_cast<const float4v*>(a.w + ((int64_t)co * taps + tap) * a.cin16 + c0 + g * 16 + q * 4);
+                for (int m = 0; m < NB; ++m)
+                    af[g][m] = *reinterpret_cast<const float4v*>(wrow[m] + (int64_t)tap * a.cin16 + c0 + g * 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    bf[g][u] = *reinterpret_cast<const float4v*>(pw + u * seg_floats + (kh * ncols + col) * rs + g * 16 + q * 4);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g >= kgroups) break;
+#pragma unroll
+                for (int m = 0; m < NB; ++m)
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[k4], bf[u][k4], acc[u][m]);
-                }
+                        for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[g][m][k4], bf[g][u][k4], acc[u][m]);
             }
         }
         __syncthreads();
@@ -119,12 +149,13 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int wo = wo0 + wave * 32 + u * 16 + j16;
-        if (wo >= a.Wo) continue;
-        const int64_t pix = ((int64_t)b * a.Ho + ho) * a.Wo + wo;
+        const int wo = wo_u[u] + j16;
+        if (ho_u[u] < 0 || wo >= a.Wo) continue;
+        const int64_t pix = ((int64_t)b * a.Ho + ho_u[u]) * a.Wo + wo;
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
             const int co = co0 + m * 16 + q * 4;
+            if (co0 + m * 16 >= a.cout16) break;
             const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
             float v[4];
 #pragma unroll
@@ -154,9 +185,10 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     }
 }
 
-static size_t conv2d_lds_bytes(int ks, int stride) {
-    const int ncols = ks == 1 ? C2_PX : (C2_PX - 1) * stride + ks;
-    return (size_t)ks * ncols * C2_RS * sizeof(float);
+static size_t conv2d_lds_bytes(int ks, int stride, int cin16) {
+    const int ncols = ks == 1 ? 16 : 15 * stride + ks;
+    const int rs = (cin16 < C2_CK ? cin16 : C2_CK) + 4;
+    return (size_t)C2_SEGS * ks * ncols * rs * sizeof(float);
 }
 
 int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
@@ -178,25 +210,35 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     a.Ho = (d.H + 2 * p - d.ks) / d.stride + 1;
     a.Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
     a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
-    const int nb = d.cout16 % 128 == 0 ? 8 : (d.cout16 % 64 == 0 ? 4 : (d.cout16 % 32 == 0 ? 2 : 1));
-    const int wtiles = (a.Wo + C2_PX - 1) / C2_PX;
-    const dim3 grid((unsigned)(wtiles * (d.cout16 / (nb * 16))), (unsigned)a.Ho, (unsigned)d.B);
-    MV_REQUIRE(a.Ho <= 65535 && d.B <= 65535, "conv2d: grid too large");
-    const size_t lds = conv2d_lds_bytes(d.ks, d.stride);
+    // channel tiles: one when the layer has <= 8 blocks of 16 channels, else the most even split into tiles of <= 8 blocks
+    const int nblk = d.cout16 / 16;
+    const int ctiles = (nblk + 7) / 8;
+    const int nb = (nblk + ctiles - 1) / ctiles;
+    const int nsegw = (a.Wo + 15) / 16;
+    const int stiles = (a.Ho * nsegw + C2_SEGS - 1) / C2_SEGS;
+    const dim3 grid((unsigned)(stiles * ctiles), (unsigned)d.B, 1);
+    MV_REQUIRE(d.B <= 65535, "conv2d: batch too large for one launch");
+    const size_t lds = conv2d_lds_bytes(d.ks, d.stride, d.cin16);
     static bool smem_set = false;
     if (!smem_set) {
-        const int big = (int)conv2d_lds_bytes(3, 2);
+        const int big = (int)conv2d_lds_bytes(3, 2, C2_CK);
         if (MV_SET_MAX_SMEM(conv2d_kernel<1>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<2>, big) != hipSuccess ||
-            MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<8>, big) != hipSuccess)
+            MV_SET_MAX_SMEM(conv2d_kernel<3>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv2d_kernel<5>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<6>, big) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv2d_kernel<7>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<8>, big) != hipSuccess)
             return fail(MV_ERR_HIP, "conv2d: cannot reserve dynamic LDS");
         smem_set = true;
     }
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)d.cin16 * d.cout16 * d.ks * d.ks, stream);
     switch (nb) {
-        case 8: MV_LAUNCH(conv2d_kernel<8>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
-        case 4: MV_LAUNCH(conv2d_kernel<4>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
-        case 2: MV_LAUNCH(conv2d_kernel<2>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
-        default: MV_LAUNCH(conv2d_kernel<1>, (grid.x, grid.y, grid.z), (256, 1, 1), lds, stream, a); break;
+        case 8: MV_LAUNCH(conv2d_kernel<8>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 7: MV_LAUNCH(conv2d_kernel<7>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 6: MV_LAUNCH(conv2d_kernel<6>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 5: MV_LAUNCH(conv2d_kernel<5>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 4: MV_LAUNCH(conv2d_kernel<4>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 3: MV_LAUNCH(conv2d_kernel<3>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        case 2: MV_LAUNCH(conv2d_kernel<2>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
+        default: MV_LAUNCH(conv2d_kernel<1>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
     }
     prof_end(prof, stream);
     return check_launch("conv2d_kernel");
