@@ -48,6 +48,48 @@ __device__ __forceinline__ float4v mfma4(float a, float b, float4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bias + epilogue mode + 16-byte stores of a wave's two segments (D[channel 4q+r][step j])
+template <int NB>
+__device__ __forceinline__ void conv2d_epilogue(const Conv2dArgs& a, float4v (&acc)[2][NB], const int (&ho_u)[2], const int (&wo_u)[2],
+                                                int b, int co0, int j16, int q) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int wo = wo_u[u] + j16;
+        if (ho_u[u] < 0 || wo >= a.Wo) continue;
+        const int64_t pix = ((int64_t)b * a.Ho + ho_u[u]) * a.Wo + wo;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int co = co0 + m * 16 + q * 4;
+            if (co0 + m * 16 >= a.cout16) break;
+            const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[u][m][r] + bias[r];
+            if (a.epi == 0) {
+                if (a.res != nullptr) {
+                    const float4v rv = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
+            } else if (a.epi == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            } else {
+                const float4v xa = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
+                const float4v ya = *reinterpret_cast<const float4v*>(a.res2 + pix * a.ldres2 + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = tanhf(v[r]);  // x_att = 1 + t;  out = x * x_att + y * (2 - x_att)
+                    v[r] = xa[r] * (1.0f + t) + ya[r] * (1.0f - t);
+                }
+            }
+            *reinterpret_cast<float4v*>(a.y + pix * a.ldy + co) = float4v{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     MV_DYN_SMEM(smem);
@@ -85,24 +127,33 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
         wo_u[u] = sg < nseg ? (sg - ho_u[u] * nsegw) * 16 : 0;
     }
 
+    // staging role of this thread: lanes 32*slot .. 32*slot+31 fill the patch of segment sg0 + slot
+    const int st_slot = tid >> 5, st_lane = tid & 31;
+    const int st_sg = sg0 + st_slot;
+    const bool st_ok = st_sg < nseg;
+    const int st_ho = st_ok ? st_sg / nsegw : 0;
+    const int st_h0 = st_ho * s - p;                                                   // input row of kh = 0
+    const int st_w0 = ks == 1 ? (st_sg - st_ho * nsegw) * 16 * s : (st_sg - st_ho * nsegw) * 16 * s - p;  // input column of col = 0
+    const int ncols_magic = 65536 / ncols + 1;                                         // rc / ncols for rc < 99
+
     for (int c0 = 0; c0 < a.cin16; c0 += C2_CK) {
-        const int ck = a.cin16 - c0 < C2_CK ? a.cin16 - c0 : C2_CK;  // multiple of 16
-        const int chunks = ck >> 2;                                  // 16-byte pieces per position
-        const int per_seg = ks * ncols * chunks;
-        const int items = C2_SEGS * per_seg;
-        for (int it = tid; it < items; it += 256) {
-            const int sl = it / per_seg;
-            const int r0 = it - sl * per_seg;
-            const int ch = r0 % chunks;
-            const int rc = r0 / chunks;
-            const int col = rc % ncols, kh = rc / ncols;
-            const int sg = sg0 + sl;
-            float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (sg < nseg) {
-                const int ho = sg / nsegw, wo0 = (sg - ho * nsegw) * 16;
-                const int hi = ho * s - p + kh;
-                const int wi = ks == 1 ? (wo0 + col) * s : wo0 * s - p + col;
-                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
+        const int ck = a.cin16 - c0 < C2_CK ? a.cin16 - c0 : C2_CK;  // 16 or 32
+        // Staging: 32 lanes per segment (8 segments = 256 threads), so the segment's row / first column are per-thread
+        // constants and an item costs one shift, one multiply-shift (division by ncols) and the address math -- the
+        // generic flat index needed four integer divisions per 16-byte load and cost more VALU time than the MFMAs
+        const int lg = ck == 32 ? 3 : 2;                             // log2(16-byte pieces per position): ck is 16 or 32
+        const int per_seg = (ks * ncols) << lg;
+        {
+            float* pseg = patch + st_slot * seg_floats;
+            for (int r0 = st_lane; r0 < per_seg; r0 += 32) {
+                const int ch = r0 & ((1 << lg) - 1);
+                const int rc = r0 >> lg;                             // kh * ncols + col, < 99
+                const int kh = (rc * ncols_magic) >> 16;
+                const int col = rc - kh * ncols;
+                const int hi = st_h0 + kh;
+                const int wi = ks == 1 ? st_w0 + col * s : st_w0 + col;
+                float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (st_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
                     const int64_t pix = ((int64_t)b * a.H + hi) * a.W + wi;
                     const int cc = c0 + ch * 4;
                     if (a.x2_mode == 2 && cc >= a.cin1) {
@@ -112,8 +163,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
                         if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + cc);
                     }
                 }
+                *reinterpret_cast<float4v*>(pseg + rc * rs + ch * 4) = v;
             }
-            *reinterpret_cast<float4v*>(patch + sl * seg_floats + (kh * ncols + col) * rs + ch * 4) = v;
         }
         __syncthreads();
         const int kgroups = ck >> 4;  // 1 or 2
@@ -147,42 +198,97 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
         __syncthreads();
     }
 
+    conv2d_epilogue<NB>(a, acc, ho_u, wo_u, b, co0, j16, q);
+}
+
+// 1x1 convolutions (conv1 / conv3 / shortcut / AFF: half of the family's FLOPs and most of its bytes) have no tap reuse, so
+// nothing is gained by staging the input: every wave streams its two segments' B operands straight from global memory
+// (a time step's 16 channels = 64 contiguous bytes over the 4 lane groups) -- no LDS, no barriers, waves fully independent.
+template <int NB>
+__global__ __launch_bounds__(256) void conv2d_1x1_kernel(Conv2dArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, q = lane >> 4;
+    const int nsegw = (a.Wo + 15) >> 4, nseg = a.Ho * nsegw;
+    const int stiles = (nseg + C2_SEGS - 1) / C2_SEGS;
+    const int st = blockIdx.x % stiles, ct = blockIdx.x / stiles;
+    const int b = blockIdx.y;
+    const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
+    const int s = a.stride;
+
+    float4v acc[2][NB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* wrow[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        const int cb = co0 + m * 16 < a.cout16 ? co0 + m * 16 : a.cout16 - 16;
+        wrow[m] = a.w + (int64_t)(cb + j16) * a.cin16 + q * 4;
+    }
+    int ho_u[2], wo_u[2];
+    const float* xp[2];   // this lane's input position in x (and x2): null = outside the map
+    const float* x2p[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+        const int sg = sg0 + wave * 2 + u;
+        ho_u[u] = sg < nseg ? sg / nsegw : -1;
+        wo_u[u] = sg < nseg ? (sg - ho_u[u] * nsegw) * 16 : 0;
         const int wo = wo_u[u] + j16;
-        if (ho_u[u] < 0 || wo >= a.Wo) continue;
-        const int64_t pix = ((int64_t)b * a.Ho + ho_u[u]) * a.Wo + wo;
-#pragma unroll
-        for (int m = 0; m < NB; ++m) {
-            const int co = co0 + m * 16 + q * 4;
-            if (co0 + m * 16 >= a.cout16) break;
-            const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[u][m][r] + bias[r];
-            if (a.epi == 0) {
-                if (a.res != nullptr) {
-                    const float4v rv = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
-            } else if (a.epi == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+        const bool ok = ho_u[u] >= 0 && wo < a.Wo;
+        const int64_t pix = ok ? ((int64_t)b * a.H + ho_u[u] * s) * a.W + wo * s : 0;
+        xp[u] = ok ? a.x + pix * a.ldx + q * 4 : nullptr;
+        x2p[u] = ok && a.x2_mode != 0 ? a.x2 + pix * a.ldx2 + q * 4 : nullptr;
+    }
+    const int groups = a.cin16 >> 4;
+    const int g1 = a.x2_mode == 2 ? a.cin1 >> 4 : groups;  // groups taken from x; the rest from x2 (AFF concat)
+    auto load_b = [&](int g, int u) {
+        float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (xp[u] != nullptr) {
+            if (g < g1) {
+                v = *reinterpret_cast<const float4v*>(xp[u] + g * 16);
+                if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(x2p[u] + g * 16);
             } else {
-                const float4v xa = *reinterpret_cast<const float4v*>(a.res + pix * a.ldres + co);
-                const float4v ya = *reinterpret_cast<const float4v*>(a.res2 + pix * a.ldres2 + co);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = tanhf(v[r]);  // x_att = 1 + t;  out = x * x_att + y * (2 - x_att)
-                    v[r] = xa[r] * (1.0f + t) + ya[r] * (1.0f - t);
-                }
+                v = *reinterpret_cast<const float4v*>(x2p[u] + (g - g1) * 16);
             }
-            *reinterpret_cast<float4v*>(a.y + pix * a.ldy + co) = float4v{v[0], v[1], v[2], v[3]};
+        }
+        return v;
+    };
+    // B operands (HBM latency) are requested one iteration ahead; the A operands of a 16-channel group (L2) just in time,
+    // in program order BEFORE the next B request so that waiting for them does not wait for the prefetch (in-order vmcnt)
+    float4v bn[2][2];
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bn[gg][u] = gg < groups ? load_b(gg, u) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int g0 = 0; g0 < groups; g0 += 2) {
+        float4v bf[2][2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bf[gg][u] = bn[gg][u];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            if (g0 + gg >= groups) break;  // uniform
+            float4v af[NB];
+#pragma unroll
+            for (int m = 0; m < NB; ++m) af[m] = *reinterpret_cast<const float4v*>(wrow[m] + (g0 + gg) * 16);
+            if (gg == 0) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (g0 + 2 + g2 < groups) bn[g2][u] = load_b(g0 + 2 + g2, u);
+            }
+#pragma unroll
+            for (int m = 0; m < NB; ++m)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[m][k4], bf[gg][u][k4], acc[u][m]);
         }
     }
+    conv2d_epilogue<NB>(a, acc, ho_u, wo_u, b, co0, j16, q);
 }
 
 static size_t conv2d_lds_bytes(int ks, int stride, int cin16) {
@@ -230,6 +336,18 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
         smem_set = true;
     }
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)d.cin16 * d.cout16 * d.ks * d.ks, stream);
+    if (d.ks == 1) {
+        switch (nb) {
+            case 8: MV_LAUNCH(conv2d_1x1_kernel<8>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 7: MV_LAUNCH(conv2d_1x1_kernel<7>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 6: MV_LAUNCH(conv2d_1x1_kernel<6>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 5: MV_LAUNCH(conv2d_1x1_kernel<5>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 4: MV_LAUNCH(conv2d_1x1_kernel<4>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 3: MV_LAUNCH(conv2d_1x1_kernel<3>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            case 2: MV_LAUNCH(conv2d_1x1_kernel<2>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+            default: MV_LAUNCH(conv2d_1x1_kernel<1>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;
+        }
+    } else
     switch (nb) {
         case 8: MV_LAUNCH(conv2d_kernel<8>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
         case 7: MV_LAUNCH(conv2d_kernel<7>, (grid.x, grid.y, 1), (256, 1, 1), lds, stream, a); break;
