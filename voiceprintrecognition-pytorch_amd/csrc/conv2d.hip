@@ -14,7 +14,7 @@
 //
 // The output plane of an utterance is cut into segments of 16 consecutive time steps (row-major: the maps shrink to
 // 10 x 38 in the last stage, so whole-row tiles would idle most lanes); one workgroup (4 waves) owns 8 consecutive
-// segments and one tile of NB*16 output channels.  K loop over chunks of <= 32 input channels: the k x (15*stride + k)
+// segments and one tile of NB*16 output channels.  K loop over chunks of 16 input channels: the k x (15*stride + k)
 // input patch behind each segment is staged in LDS once (zero padding, the input sum and the channel concatenation of AFF happen here) and every tap
 // reads it back as MFMA B operands; the weights are small (<= 4.7 MB for the largest layer, L2 resident) and are read
 // straight from global memory as A operands, each feeding the wave's two 16-step column blocks.
@@ -26,7 +26,7 @@
 namespace mv {
 
 constexpr int C2_SEGS = 8;      // 16-step segments per workgroup (two per wave)
-constexpr int C2_CK = 32;       // input channels per K chunk
+
 
 struct Conv2dArgs {
     const float* x;     // [B, H, W, ldx]
@@ -41,6 +41,7 @@ struct Conv2dArgs {
     int cin1, cin16, cout16;
     int B, H, W, Ho, Wo, ks, stride;
     int epi;            // 0: clamp(v [+ res], lo, hi); 1: SiLU; 2: AFF mix  res*(1+tanh v) + res2*(1-tanh v)
+    int ck_max;         // 3x3 kernel: input channels per K chunk (16 or 32)
     float lo, hi;
 };
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
     const int ks = a.ks, s = a.stride, p = ks >> 1, taps = ks * ks;
     const int ncols = ks == 1 ? 16 : 15 * s + ks;  // input columns behind one segment
-    const int rs = (a.cin16 < C2_CK ? a.cin16 : C2_CK) + 4;  // LDS row stride in floats: 16-byte aligned, spreads the banks
+    const int rs = (a.cin16 < a.ck_max ? a.cin16 : a.ck_max) + 4;  // LDS row stride in floats: 16-byte aligned, spreads the banks
     const int seg_floats = ks * ncols * rs;
 
     float4v acc[2][NB];
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int st_w0 = ks == 1 ? (st_sg - st_ho * nsegw) * 16 * s : (st_sg - st_ho * nsegw) * 16 * s - p;  // input column of col = 0
     const int ncols_magic = 65536 / ncols + 1;                                         // rc / ncols for rc < 99
 
-    for (int c0 = 0; c0 < a.cin16; c0 += C2_CK) {
-        const int ck = a.cin16 - c0 < C2_CK ? a.cin16 - c0 : C2_CK;  // 16 or 32
+    for (int c0 = 0; c0 < a.cin16; c0 += a.ck_max) {
+        const int ck = a.cin16 - c0 < a.ck_max ? a.cin16 - c0 : a.ck_max;  // 16 or 32
         // Staging: 32 lanes per segment (8 segments = 256 threads), so the segment's row / first column are per-thread
         // constants and an item costs one shift, one multiply-shift (division by ncols) and the address math -- the
         // generic flat index needed four integer divisions per 16-byte load and cost more VALU time than the MFMAs
@@ -291,9 +292,25 @@ __global__ __launch_bounds__(256) void conv2d_1x1_kernel(Conv2dArgs a) {
     conv2d_epilogue<NB>(a, acc, ho_u, wo_u, b, co0, j16, q);
 }
 
+// channels per K chunk of the 3x3 kernel: 16.  The patch of a 32-channel chunk (62 KiB at stride 1, 114 KiB at stride 2)
+// leaves 2 / 1 workgroups per CU; with 16 it is 4 / 2, and the extra barriers cost less than the lost overlap: ERes2NetV2-m32
+// 5.76 k -> 6.19 k utt/s, ERes2Net-m32 4.64 k -> 5.12 k (r02e, same box).  MV_CONV2D_CK = 16 / 32 overrides for measurements.
+static int conv2d_ck_max(int ks, int stride) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = std::getenv("MV_CONV2D_CK");
+        forced = e != nullptr ? std::atoi(e) : 0;
+    }
+    if (forced == 16 || forced == 32) return forced;
+    (void)ks;
+    (void)stride;
+    return 16;
+}
+
 static size_t conv2d_lds_bytes(int ks, int stride, int cin16) {
     const int ncols = ks == 1 ? 16 : 15 * stride + ks;
-    const int rs = (cin16 < C2_CK ? cin16 : C2_CK) + 4;
+    const int ckm = conv2d_ck_max(ks, stride);
+    const int rs = (cin16 < ckm ? cin16 : ckm) + 4;
     return (size_t)C2_SEGS * ks * ncols * rs * sizeof(float);
 }
 
@@ -316,6 +333,7 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     a.Ho = (d.H + 2 * p - d.ks) / d.stride + 1;
     a.Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
     a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
+    a.ck_max = conv2d_ck_max(d.ks, d.stride);
     // channel tiles: one when the layer has <= 8 blocks of 16 channels, else the most even split into tiles of <= 8 blocks
     const int nblk = d.cout16 / 16;
     const int ctiles = (nblk + 7) / 8;
@@ -327,7 +345,7 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const size_t lds = conv2d_lds_bytes(d.ks, d.stride, d.cin16);
     static bool smem_set = false;
     if (!smem_set) {
-        const int big = (int)conv2d_lds_bytes(3, 2, C2_CK);
+        const int big = 8 * 3 * 33 * 36 * 4;  // 3x3, stride 2, 32-channel chunks
         if (MV_SET_MAX_SMEM(conv2d_kernel<1>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<2>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<3>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<5>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<6>, big) != hipSuccess ||
