@@ -54,8 +54,32 @@ __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int
     const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     float4v acc = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     float sqx = 0.0f, sqw = 0.0f;
-    // wave `wave` takes K blocks of 16 with index == wave (mod NW)
-    for (int k0 = wave * 16; k0 < K; k0 += 16 * NW) {
+    // wave `wave` takes K blocks of 16 with index == wave (mod NW).  Main loop: four unguarded blocks per trip, their eight
+    // 16-byte loads in flight together (the chain of dependent load -> MFMA trips is what these small layers wait for);
+    // the guarded loop takes the remainder (and everything when the rows are not 16-byte aligned).
+    const int kfull = (xvec && wvec) ? (K & ~15) : 0;
+    int k0 = wave * 16;
+    for (; k0 + 3 * 16 * NW < kfull; k0 += 4 * 16 * NW) {
+        float4v xa[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xa[u] = *reinterpret_cast<const float4v*>(xrow + k0 + u * 16 * NW + 4 * g);
+            wb[u] = *reinterpret_cast<const float4v*>(wrow + k0 + u * 16 * NW + 4 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][e], wb[u][e], acc, 0, 0, 0);
+            if (cosine) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sqx += xa[u][e] * xa[u][e];
+                    sqw += wb[u][e] * wb[u][e];
+                }
+            }
+        }
+    }
+    for (; k0 < K; k0 += 16 * NW) {
         const int k = k0 + 4 * g;
         const float4v xa = load4_guard(xrow, k, K, xvec);
         const float4v wb = load4_guard(wrow, k, K, wvec);
