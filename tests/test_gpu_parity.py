@@ -188,6 +188,34 @@ def test_gpu_eres2net_matches_reference_golden(case):
     assert cd < 1e-6 and rel < 2e-3, (cd, rel)
 
 
+def test_gpu_eres2netv2_variable_length_bucketed():
+    """BASELINE config 4 shape: ERes2NetV2 on 1-10 s utterances with length bucketing (<= 8 buckets, padded inside a bucket,
+    predict_batch semantics); the shortest and the longest bucket are checked in full against the oracle."""
+    import mvector.models as M
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    from mvector.parallel import embed_bucketed, length_buckets
+    man, sd, _, _, _ = load_case('eres2netv2_m32')
+    m = M.ERes2NetV2(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+    g = torch.Generator().manual_seed(77)
+    lens = [int(v) for v in torch.randint(16000, 160001, (24,), generator=g)]
+    lens[0], lens[1] = 16000, 160000
+    wav = frontend.synth_waveforms(len(lens), max(lens), seed=5)
+    emb = embed_bucketed(fz, m, [wav[i, :n] for i, n in enumerate(lens)], max_buckets=8, device=torch.device(DEV)).cpu()
+    assert emb.shape == (24, 192) and torch.isfinite(emb).all() and m.__dict__.get('_native_handles')
+    buckets = length_buckets(lens, 8)
+    for idx in (buckets[0], buckets[-1]):
+        longest = max(lens[i] for i in idx)
+        padded = torch.zeros(len(idx), longest)
+        for r, i in enumerate(idx):
+            padded[r, :lens[i]] = wav[i, :lens[i]]
+        ratio = torch.tensor([lens[i] / longest for i in idx])
+        ref = omodels.eres2netv2(sd, frontend.audio_featurizer(padded, ratio, 'Fbank', FB))
+        assert cos_dist(emb[idx], ref).max() < 1e-4, cos_dist(emb[idx], ref).max()  # front-end fp32 rounding x the depth of the net
+
+
 def test_gpu_eres2net_full_batch_properties():
     """ERes2NetV2 m32 at 64 x 3 s through the module API: native path taken, finite, batch-invariant, spot parity vs the oracle."""
     import mvector.models as M

@@ -7,6 +7,7 @@ only collective it ever issues is DDP's gradient all-reduce in training (trainer
 """
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 
 
 def shard_rows(n_rows, rank=None, world=None):
@@ -45,3 +46,66 @@ def embed_and_score(featurizer, model, wav_local, lens_ratio=None):
     emb = model(featurizer(wav_local, lens_ratio))
     emb_all = all_gather_embeddings(emb)
     return emb, emb_all, cosine_block(emb, emb_all)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Variable-length batches (BASELINE config 4: 1-10 s utterances "with bucketing").  The reference pads a batch to its longest
+# utterance and its CMN then runs over the padded frames (predict.py:244-255, featurizer.py:79: quirk Q2), so an
+# utterance's embedding depends on what it is batched with; bucketing by length bounds both the wasted frames and that
+# dependence.  Inside a bucket the semantics are exactly predict_batch's.
+
+def length_buckets(num_samples, max_buckets=8):
+    """Group utterance indices into <= max_buckets buckets of similar length: equal-width length ranges between the shortest
+    and the longest utterance (padding waste <= 1/max_buckets of that range), empty ranges dropped, input order kept inside
+    a bucket.  Returns a list of index lists, shortest bucket first."""
+    n = [int(v) for v in num_samples]
+    if not n:
+        return []
+    lo, hi = min(n), max(n)
+    k = max(1, int(max_buckets))
+    width = (hi - lo) // k + 1
+    buckets = [[] for _ in range(k)]
+    for i, v in enumerate(n):
+        buckets[(v - lo) // width].append(i)
+    return [b for b in buckets if b]
+
+
+@torch.no_grad()
+def embed_bucketed(featurizer, model, waveforms, max_buckets=8, device=None):
+    """Embeddings [N, D] (input order, on every rank) of N variable-length waveforms (1-D float tensors).
+
+    Utterances are bucketed by length (``length_buckets``); every bucket is sharded over the ranks like a fixed-length
+    batch (``shard_rows``), zero-padded to the bucket's longest utterance, featurised with the length ratios and embedded;
+    the shards travel through one all-gather per bucket (padded to equal row counts, RCCL on GPUs)."""
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    if device is None:
+        device = next(model.parameters()).device
+    lens = [int(w.numel()) for w in waveforms]
+    out = None
+    for idx in length_buckets(lens, max_buckets):
+        longest = max(lens[i] for i in idx)
+        lo, hi = shard_rows(len(idx), rank, world)
+        mine = idx[lo:hi]
+        per = -(-len(idx) // world)  # rows every rank contributes to the all-gather (padded)
+        emb_local = None
+        if mine:
+            wav = torch.stack([F.pad(waveforms[i].to(device=device, dtype=torch.float32), (0, longest - lens[i])) for i in mine])
+            ratio = torch.tensor([lens[i] / longest for i in mine], dtype=torch.float32, device=device)
+            emb_local = model(featurizer(wav, ratio))
+        if out is None:
+            dim = emb_local.shape[1] if emb_local is not None else model.embd_dim
+            out = torch.zeros((len(waveforms), dim), dtype=torch.float32, device=device)
+        if not distributed:
+            out[torch.tensor(idx, device=device)] = emb_local
+            continue
+        block = torch.zeros((per, out.shape[1]), dtype=torch.float32, device=device)
+        if emb_local is not None:
+            block[:emb_local.shape[0]] = emb_local
+        gathered = all_gather_embeddings(block)
+        for r in range(world):
+            rlo, rhi = shard_rows(len(idx), r, world)
+            if rhi > rlo:
+                out[torch.tensor(idx[rlo:rhi], device=device)] = gathered[r * per:r * per + (rhi - rlo)]
+    return out
