@@ -13,8 +13,10 @@ import numpy as np
 import torch
 
 
-def make_state_dict(shapes, seed=0):
-    """shapes: {key: tuple}.  Returns {key: torch fp32 tensor (int64 for num_batches_tracked)}."""
+def make_state_dict(shapes, seed=0, bn_gain=1.0):
+    """shapes: {key: tuple}.  Returns {key: torch fp32 tensor (int64 for num_batches_tracked)}.
+    bn_gain scales every BatchNorm weight: deep residual stacks with unit-gain random weights are chaotic (the reference's own
+    fp32 forward then differs from fp64 by >10 %), a gain < 1 makes such a case well conditioned."""
     out = {}
     keys = set(shapes)
     for name in sorted(shapes):
@@ -30,7 +32,7 @@ def make_state_dict(shapes, seed=0):
         elif leaf == 'running_var':
             v = rng.uniform(0.5, 1.5, shape)
         elif is_bn and leaf == 'weight':
-            v = rng.uniform(0.8, 1.2, shape)
+            v = rng.uniform(0.8, 1.2, shape) * bn_gain
         elif leaf == 'bias':
             v = rng.normal(0.0, 0.1, shape)
         elif len(shape) >= 2:

@@ -13,7 +13,7 @@ def load_case(case):
     from oracle import weights
     with open(os.path.join(GOLDEN, f'manifest_{case}.json')) as f:
         man = json.load(f)
-    sd = weights.make_state_dict(man['shapes'], man['seed'])
+    sd = weights.make_state_dict(man['shapes'], man['seed'], man.get('bn_gain', 1.0))
     z = np.load(os.path.join(GOLDEN, f'{case}.npz'))
     return man, sd, torch.from_numpy(z['x']), torch.from_numpy(z['emb']), z
 
