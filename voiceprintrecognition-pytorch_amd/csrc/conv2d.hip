@@ -26,6 +26,7 @@
 namespace mv {
 
 constexpr int C2_SEGS = 8;      // 16-step segments per workgroup (two per wave)
+constexpr int C2_RS = 16 + 4;   // LDS row stride in floats of the 3x3 kernel's patch (16 channels + 16 bytes: spreads the banks)
 
 
 struct Conv2dArgs {
@@ -41,7 +42,6 @@ struct Conv2dArgs {
     int cin1, cin16, cout16;
     int B, H, W, Ho, Wo, ks, stride;
     int epi;            // 0: clamp(v [+ res], lo, hi); 1: SiLU; 2: AFF mix  res*(1+tanh v) + res2*(1-tanh v)
-    int ck_max;         // 3x3 kernel: input channels per K chunk (16 or 32)
     float lo, hi;
 };
 
@@ -102,10 +102,11 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int st = blockIdx.x % stiles, ct = blockIdx.x / stiles;
     const int b = blockIdx.y;
     const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
-    const int ks = a.ks, s = a.stride, p = ks >> 1, taps = ks * ks;
-    const int ncols = ks == 1 ? 16 : 15 * s + ks;  // input columns behind one segment
-    const int rs = (a.cin16 < a.ck_max ? a.cin16 : a.ck_max) + 4;  // LDS row stride in floats: 16-byte aligned, spreads the banks
-    const int seg_floats = ks * ncols * rs;
+    constexpr int taps = 9;
+    const int s = a.stride;
+    const int ncols = 15 * s + 3;              // input columns behind one segment
+    const int seg_floats = 3 * ncols * C2_RS;
+    const int per_seg = 3 * ncols * 4;          // 16-byte pieces of one segment's patch
 
     float4v acc[2][NB];
 #pragma unroll
@@ -133,26 +134,26 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int st_sg = sg0 + st_slot;
     const bool st_ok = st_sg < nseg;
     const int st_ho = st_ok ? st_sg / nsegw : 0;
-    const int st_h0 = st_ho * s - p;                                                   // input row of kh = 0
-    const int st_w0 = ks == 1 ? (st_sg - st_ho * nsegw) * 16 * s : (st_sg - st_ho * nsegw) * 16 * s - p;  // input column of col = 0
-    const int ncols_magic = 65536 / ncols + 1;                                         // rc / ncols for rc < 99
+    const int st_h0 = st_ho * s - 1;                              // input row of kh = 0
+    const int st_w0 = (st_sg - st_ho * nsegw) * 16 * s - 1;       // input column of col = 0
+    const int ncols_magic = 65536 / ncols + 1;                    // rc / ncols for rc < 99
 
-    for (int c0 = 0; c0 < a.cin16; c0 += a.ck_max) {
-        const int ck = a.cin16 - c0 < a.ck_max ? a.cin16 - c0 : a.ck_max;  // 16 or 32
-        // Staging: 32 lanes per segment (8 segments = 256 threads), so the segment's row / first column are per-thread
-        // constants and an item costs one shift, one multiply-shift (division by ncols) and the address math -- the
-        // generic flat index needed four integer divisions per 16-byte load and cost more VALU time than the MFMAs
-        const int lg = ck == 32 ? 3 : 2;                             // log2(16-byte pieces per position): ck is 16 or 32
-        const int per_seg = (ks * ncols) << lg;
+    // 16 input channels per K chunk (see conv2d_lds_bytes): every tap is then one MFMA group of 4 K steps.  The A operands of tap
+    // t+1 are requested before the MFMAs of tap t (those of tap 0 before the patch is staged), so the L2 latency of the
+    // weight reads is paid once per chunk instead of once per tap.
+    for (int c0 = 0; c0 < a.cin16; c0 += 16) {
+        float4v an[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) an[m] = *reinterpret_cast<const float4v*>(wrow[m] + c0);
         {
             float* pseg = patch + st_slot * seg_floats;
             for (int r0 = st_lane; r0 < per_seg; r0 += 32) {
-                const int ch = r0 & ((1 << lg) - 1);
-                const int rc = r0 >> lg;                             // kh * ncols + col, < 99
+                const int ch = r0 & 3;
+                const int rc = r0 >> 2;                              // kh * ncols + col, < 99
                 const int kh = (rc * ncols_magic) >> 16;
                 const int col = rc - kh * ncols;
                 const int hi = st_h0 + kh;
-                const int wi = ks == 1 ? st_w0 + col * s : st_w0 + col;
+                const int wi = st_w0 + col;
                 float4v v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (st_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
                     const int64_t pix = ((int64_t)b * a.H + hi) * a.W + wi;
@@ -164,37 +165,36 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
                         if (a.x2_mode == 1) v += *reinterpret_cast<const float4v*>(a.x2 + pix * a.ldx2 + cc);
                     }
                 }
-                *reinterpret_cast<float4v*>(pseg + rc * rs + ch * 4) = v;
+                *reinterpret_cast<float4v*>(pseg + rc * C2_RS + ch * 4) = v;
             }
         }
         __syncthreads();
-        const int kgroups = ck >> 4;  // 1 or 2
-        const float* pw = patch + (wave * 2) * seg_floats;
-        for (int tap = 0; tap < taps; ++tap) {
-            const int kh = tap / ks, kw = tap - kh * ks;
-            const int col = ks == 1 ? j16 : j16 * s + kw;
-            // all operands of the tap first (up to 2*NB weight reads in flight instead of one at a time), then the MFMAs
-            float4v af[2][NB], bf[2][2];
+        const float* pw = patch + (wave * 2) * seg_floats + q * 4;
+        auto tap_step = [&](int tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            float4v af[NB], bf[2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                if (g >= kgroups) break;  // uniform
+            for (int m = 0; m < NB; ++m) af[m] = an[m];
+            if (tap + 1 < 9) {
 #pragma unroll
-                for (int m = 0; m < NB; ++m)
-                    af[g][m] = *reinterpret_cast<const float4v*>(wrow[m] + (int64_t)tap * a.cin16 + c0 + g * 16);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    bf[g][u] = *reinterpret_cast<const float4v*>(pw + u * seg_floats + (kh * ncols + col) * rs + g * 16 + q * 4);
+                for (int m = 0; m < NB; ++m) an[m] = *reinterpret_cast<const float4v*>(wrow[m] + (int64_t)(tap + 1) * a.cin16 + c0);
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                if (g >= kgroups) break;
+            for (int u = 0; u < 2; ++u)
+                bf[u] = *reinterpret_cast<const float4v*>(pw + u * seg_floats + (kh * ncols + j16 * s + kw) * C2_RS);
 #pragma unroll
-                for (int m = 0; m < NB; ++m)
+            for (int m = 0; m < NB; ++m)
 #pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4)
+                for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[g][m][k4], bf[g][u][k4], acc[u][m]);
-            }
+                    for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[m][k4], bf[u][k4], acc[u][m]);
+        };
+        if constexpr (NB <= 2) {  // narrow tiles: all nine taps unrolled (the compiler then requests every tap's weights up front)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) tap_step(tap);
+        } else {                  // wide tiles: a rolled loop keeps exactly one tap of weights in flight (registers)
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) tap_step(tap);
         }
         __syncthreads();
     }
@@ -255,64 +255,48 @@ __global__ __launch_bounds__(256) void conv2d_1x1_kernel(Conv2dArgs a) {
         }
         return v;
     };
-    // B operands (HBM latency) are requested one iteration ahead; the A operands of a 16-channel group (L2) just in time,
-    // in program order BEFORE the next B request so that waiting for them does not wait for the prefetch (in-order vmcnt)
-    float4v bn[2][2];
+    // One 16-channel group per trip of a rolled loop (an unrolled one lets the compiler hoist every group's operands:
+    // 244 VGPRs at NB = 8).  Operands run ahead of the MFMAs: B (HBM latency) two groups, A (L2) one group; A is requested
+    // before B so that waiting for it never waits for the younger B request (in-order vmcnt).
+    float4v an[NB], bq[2][2];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) an[m] = *reinterpret_cast<const float4v*>(wrow[m]);
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) bn[gg][u] = gg < groups ? load_b(gg, u) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int g0 = 0; g0 < groups; g0 += 2) {
-        float4v bf[2][2];
+        for (int u = 0; u < 2; ++u) bq[gg][u] = gg < groups ? load_b(gg, u) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int g = 0; g < groups; ++g) {
+        float4v af[NB], bf[2];
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg)
+        for (int m = 0; m < NB; ++m) af[m] = an[m];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) bf[gg][u] = bn[gg][u];
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            if (g0 + gg >= groups) break;  // uniform
-            float4v af[NB];
-#pragma unroll
-            for (int m = 0; m < NB; ++m) af[m] = *reinterpret_cast<const float4v*>(wrow[m] + (g0 + gg) * 16);
-            if (gg == 0) {
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        if (g0 + 2 + g2 < groups) bn[g2][u] = load_b(g0 + 2 + g2, u);
-            }
-#pragma unroll
-            for (int m = 0; m < NB; ++m)
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[m][k4], bf[gg][u][k4], acc[u][m]);
+        for (int u = 0; u < 2; ++u) {
+            bf[u] = bq[0][u];
+            bq[0][u] = bq[1][u];
         }
+        if (g + 1 < groups) {
+#pragma unroll
+            for (int m = 0; m < NB; ++m) an[m] = *reinterpret_cast<const float4v*>(wrow[m] + (g + 1) * 16);
+        }
+        if (g + 2 < groups) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bq[1][u] = load_b(g + 2, u);
+        }
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[u][m] = mfma4(af[m][k4], bf[u][k4], acc[u][m]);
     }
     conv2d_epilogue<NB>(a, acc, ho_u, wo_u, b, co0, j16, q);
 }
 
-// channels per K chunk of the 3x3 kernel: 16.  The patch of a 32-channel chunk (62 KiB at stride 1, 114 KiB at stride 2)
-// leaves 2 / 1 workgroups per CU; with 16 it is 4 / 2, and the extra barriers cost less than the lost overlap: ERes2NetV2-m32
-// 5.76 k -> 6.19 k utt/s, ERes2Net-m32 4.64 k -> 5.12 k (r02e, same box).  MV_CONV2D_CK = 16 / 32 overrides for measurements.
-static int conv2d_ck_max(int ks, int stride) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = std::getenv("MV_CONV2D_CK");
-        forced = e != nullptr ? std::atoi(e) : 0;
-    }
-    if (forced == 16 || forced == 32) return forced;
-    (void)ks;
-    (void)stride;
-    return 16;
-}
-
-static size_t conv2d_lds_bytes(int ks, int stride, int cin16) {
-    const int ncols = ks == 1 ? 16 : 15 * stride + ks;
-    const int ckm = conv2d_ck_max(ks, stride);
-    const int rs = (cin16 < ckm ? cin16 : ckm) + 4;
-    return (size_t)C2_SEGS * ks * ncols * rs * sizeof(float);
-}
+// K chunk of the 3x3 kernel = 16 channels.  The patch of a 32-channel chunk (62 KiB at stride 1, 114 KiB at stride 2) leaves
+// 2 / 1 workgroups per CU; with 16 it is 4 / 2, and the extra barriers cost less than the lost overlap: ERes2NetV2-m32
+// 5.76 k -> 6.19 k utt/s, ERes2Net-m32 4.64 k -> 5.12 k (r02e, same box).
+static size_t conv2d_lds_bytes(int stride) { return (size_t)C2_SEGS * 3 * (15 * stride + 3) * C2_RS * sizeof(float); }
 
 int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2d: null pointer");
@@ -333,7 +317,6 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     a.Ho = (d.H + 2 * p - d.ks) / d.stride + 1;
     a.Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
     a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
-    a.ck_max = conv2d_ck_max(d.ks, d.stride);
     // channel tiles: one when the layer has <= 8 blocks of 16 channels, else the most even split into tiles of <= 8 blocks
     const int nblk = d.cout16 / 16;
     const int ctiles = (nblk + 7) / 8;
@@ -342,10 +325,10 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const int stiles = (a.Ho * nsegw + C2_SEGS - 1) / C2_SEGS;
     const dim3 grid((unsigned)(stiles * ctiles), (unsigned)d.B, 1);
     MV_REQUIRE(d.B <= 65535, "conv2d: batch too large for one launch");
-    const size_t lds = conv2d_lds_bytes(d.ks, d.stride, d.cin16);
+    const size_t lds = conv2d_lds_bytes(d.stride);
     static bool smem_set = false;
     if (!smem_set) {
-        const int big = 8 * 3 * 33 * 36 * 4;  // 3x3, stride 2, 32-channel chunks
+        const int big = (int)conv2d_lds_bytes(2);
         if (MV_SET_MAX_SMEM(conv2d_kernel<1>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<2>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<3>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<5>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<6>, big) != hipSuccess ||
