@@ -319,7 +319,16 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
     // channel tiles: one when the layer has <= 8 blocks of 16 channels, else the most even split into tiles of <= 8 blocks
     const int nblk = d.cout16 / 16;
-    const int ctiles = (nblk + 7) / 8;
+    // 1x1 kernel: at most 4 blocks of 16 channels per workgroup -- 124 VGPRs = 4 waves per SIMD instead of 2 at 8 blocks, which
+    // hides more of the operand latency than reading the B operands once more from L2 costs (ERes2NetV2-m32 6.56 k -> 6.86 k
+    // utt/s; 2 blocks: 6.62 k).  MV_CONV2D_NB1X1 overrides for measurements.
+    static int nb_cap_1x1 = -1;
+    if (nb_cap_1x1 < 0) {
+        const char* e = std::getenv("MV_CONV2D_NB1X1");
+        nb_cap_1x1 = e != nullptr && std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 4;
+    }
+    const int cap = d.ks == 1 ? nb_cap_1x1 : 8;
+    const int ctiles = (nblk + cap - 1) / cap;
     const int nb = (nblk + ctiles - 1) / ctiles;
     const int nsegw = (a.Wo + 15) / 16;
     const int stiles = (a.Ho * nsegw + C2_SEGS - 1) / C2_SEGS;
