@@ -327,7 +327,12 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
         const char* e = std::getenv("MV_CONV2D_NB1X1");
         nb_cap_1x1 = e != nullptr && std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 4;
     }
-    const int cap = d.ks == 1 ? nb_cap_1x1 : 8;
+    static int nb_cap_3x3 = -1;
+    if (nb_cap_3x3 < 0) {
+        const char* e = std::getenv("MV_CONV2D_NB3X3");
+        nb_cap_3x3 = e != nullptr && std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 8;
+    }
+    const int cap = d.ks == 1 ? nb_cap_1x1 : nb_cap_3x3;
     const int ctiles = (nblk + cap - 1) / cap;
     const int nb = (nblk + ctiles - 1) / ctiles;
     const int nsegw = (a.Wo + 15) / 16;
