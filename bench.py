@@ -77,7 +77,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='utterances per GPU')
     ap.add_argument('--model', default='ecapa1024', choices=sorted(MODELS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=32, help='utterances timed on the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=256, help='utterances timed on the CPU oracle (~10-20 s of CPU work)')
     ap.add_argument('--cpu-threads', type=int, default=32, help='torch CPU threads for the oracle baseline')
     args = ap.parse_args()
 
