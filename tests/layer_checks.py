@@ -244,6 +244,8 @@ CONV2D_CASES = [
     dict(cin=16, cout=64, ks=1, epi=2),                                      # AFF local_att[3:5] + fusion
     dict(cin=104, cout=104, ks=3, H=5, W=40, B=1),                           # width 104: two K chunks, 7 channel blocks -> NB 1
     dict(cin=256, cout=512, ks=3, stride=2, H=6, W=20, B=1, hi=65504.0, lo=-65504.0),  # layer3_downsample
+    dict(cin=48, cout=144, ks=3, H=3, W=20, B=1),                            # 9 channel blocks: two uneven tiles of 5 (one clamped block)
+    dict(cin=48, cout=208, ks=1, H=2, W=37, B=2, with_res=True),             # 1x1: 13 blocks -> 4 tiles of 4 (3 clamped blocks)
 ]
 
 
