@@ -11,6 +11,13 @@
 // together with the rows they mirror), so a tap is a constant row shift: the row swizzle (row & 15) is then the same for
 // every time tile of a lane and the ten operand reads of a K step are one address + immediates.
 //
+// Measured dead ends (r02j, tools/bench_res2.py, old and new kernel in one box: 156-160 us both): requesting the next
+// step's first weight stages ahead of the epilogue and the x_{j+1} / parameter loads in the middle of the K loop, with
+// run-time counted vmcnt waits so that the y stores and those loads drain under the K loop; one early wait instead of the
+// compiler's s_waitcnt vmcnt(0) in front of every conditional store block; keeping the row addresses from being hoisted
+// (256 VGPRs + 4 spills -> 208, no spills); tile-level uniform branches in the epilogue.  All neutral together: the chain is
+// not bound by its store / load latencies or by the epilogue's instruction count (next: an in-kernel timeline as for conv1d).
+//
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
 #include "kernels.h"
