@@ -52,6 +52,23 @@ def test_build_model_and_config_objects():
         build_model(80, dict_to_object(dict(model_conf=dict(model='NoSuchModel'))))
 
 
+def test_build_model_eres2net_family_and_constructor_contract():
+    """configs/eres2net.yml style construction (model name + model_args), the reference's attribute surface, CPU forward."""
+    from mvector.models import build_model
+    from mvector.utils.utils import dict_to_object
+    for name, extra in (('ERes2Net', {}), ('ERes2NetV2', dict(two_emb_layer=True))):
+        cfg = dict_to_object(dict(model_conf=dict(model=name, model_args=dict(embd_dim=48, m_channels=16, num_blocks=[1, 1, 1, 1], **extra))))
+        m = build_model(16, cfg).eval()
+        assert type(m).__name__ == name and m.embd_dim == 48 and m.stats_dim == 2 * 16 * 8
+        with torch.no_grad():
+            e = m(torch.randn(2, 40, 16))
+        assert e.shape == (2, 48) and torch.isfinite(e).all()
+        ok, why = m._native_supported()
+        assert ok, why
+    import mvector.models as M
+    assert M.ERes2Net(input_size=16, m_channels=24, num_blocks=[1, 1, 1, 1])._native_supported()[0] is False  # torch path only
+
+
 def test_cpu_featurizer_matches_oracle_and_contract():
     from mvector.data_utils.featurizer import AudioFeaturizer
     fz = AudioFeaturizer('Fbank', method_args=FB)
