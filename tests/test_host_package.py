@@ -69,6 +69,24 @@ def test_build_model_eres2net_family_and_constructor_contract():
     assert M.ERes2Net(input_size=16, m_channels=24, num_blocks=[1, 1, 1, 1])._native_supported()[0] is False  # torch path only
 
 
+def test_accuracy_helpers_match_the_reference_scan():
+    """cal_accuracy_threshold: the reference scans thresholds 0.00 .. 0.99 and keeps the first best (mvector/utils/utils.py:59-71)."""
+    from mvector.utils.utils import cal_accuracy, cal_accuracy_threshold, cosin_metric
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, 2, 500)
+    scores = (rng.normal(0.2, 0.2, 500) + 0.35 * labels).astype(np.float32)
+    best_acc, best_thr = 0, 0
+    for i in range(100):
+        acc = np.mean(((scores >= i * 0.01) == labels).astype(int))
+        if acc > best_acc:
+            best_acc, best_thr = acc, i * 0.01
+    acc, thr = cal_accuracy_threshold(scores, labels)
+    assert abs(acc - best_acc) < 1e-12 and abs(thr - best_thr) < 1e-12
+    assert abs(cal_accuracy(scores, labels, thr) - best_acc) < 1e-12
+    a, b = rng.normal(size=8), rng.normal(size=8)
+    assert abs(cosin_metric(a, b) - np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b))) < 1e-12
+
+
 def test_cpu_featurizer_matches_oracle_and_contract():
     from mvector.data_utils.featurizer import AudioFeaturizer
     fz = AudioFeaturizer('Fbank', method_args=FB)

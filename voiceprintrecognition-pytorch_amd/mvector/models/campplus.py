@@ -1,196 +1,122 @@
-"""CAM++ with the reference's constructor and state_dict layout (mvector/models/campplus.py:295-357):
-``head`` (FCM 2-D residual front-end) + ``xvector`` (strided TDNN, three CAM dense-TDNN blocks with transit
-layers, statistics pooling, dense embedding layer).  Eval-mode CUDA forwards run the native MI355X pipeline
-(csrc/campplus.hip); the torch graph below serves CPU tensors and training."""
+"""CAM++ with the reference's constructor and state_dict layout (mvector/models/campplus.py:295-357).
+
+Only the parameter TREE is the reference's (so its ``model.pth`` loads unchanged):
+
+    head.{conv1,bn1, layer{1,2}.{0,1}.{conv1,bn1,conv2,bn2[,shortcut.{0,1}]}, conv2,bn2}
+    xvector.tdnn.{linear, nonlinear.batchnorm}
+    xvector.block{1,2,3}.tdnnd{n}.{nonlinear1.batchnorm, linear1, nonlinear2.batchnorm, cam_layer.{linear_local,linear1,linear2}}
+    xvector.transit{1,2,3}.{nonlinear.batchnorm, linear}      xvector.out_nonlinear.batchnorm
+    xvector.dense.{linear, nonlinear.batchnorm}
+
+It is built from a nested description by ``_node`` (plain containers, no per-layer classes); the torch forward below walks
+that tree functionally and serves CPU tensors / training-mode calls.  Eval-mode CUDA forwards run the native MI355X
+pipeline (csrc/campplus.hip), which needs none of this code -- only the state_dict.
+"""
 import math
-from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F
-import torch.utils.checkpoint as cp
 from torch import nn
 
 from mvector.models._native import NativeBackbone
 
+_DENSE_BLOCKS = ((12, 1), (24, 2), (16, 2))  # (layers, dilation) of block1..3; kernel 3 everywhere (campplus.py:315-317)
+_SEG_LEN = 100                                # frames per context segment (campplus.py:101)
 
-def get_nonlinear(config_str, channels):
-    """'batchnorm-relu' style spec -> nn.Sequential whose child names are the spec tokens."""
-    seq = nn.Sequential()
-    for name in config_str.split('-'):
-        if name == 'relu':
-            seq.add_module('relu', nn.ReLU(inplace=True))
-        elif name == 'prelu':
-            seq.add_module('prelu', nn.PReLU(channels))
-        elif name == 'batchnorm':
-            seq.add_module('batchnorm', nn.BatchNorm1d(channels))
-        elif name == 'batchnorm_':
-            seq.add_module('batchnorm', nn.BatchNorm1d(channels, affine=False))
+
+class _Node(nn.Module):
+    """Container with named children; carries no behaviour (the forward lives in the functions below)."""
+
+    def __init__(self, children):
+        super().__init__()
+        for name, child in children:
+            self.add_module(name, child)
+
+
+def _node(*children):
+    return _Node(children)
+
+
+def _norm_act(spec, channels):
+    """'batchnorm-relu' style description -> container whose child names are the description's tokens
+    ('batchnorm_' = BatchNorm without affine parameters, still called 'batchnorm')."""
+    parts = []
+    for token in spec.split('-'):
+        if token == 'batchnorm':
+            parts.append(('batchnorm', nn.BatchNorm1d(channels)))
+        elif token == 'batchnorm_':
+            parts.append(('batchnorm', nn.BatchNorm1d(channels, affine=False)))
+        elif token == 'relu':
+            parts.append(('relu', nn.ReLU(inplace=True)))
+        elif token == 'prelu':
+            parts.append(('prelu', nn.PReLU(channels)))
         else:
-            raise ValueError('Unexpected module ({}).'.format(name))
+            raise ValueError('Unexpected module ({}).'.format(token))
+    seq = nn.Sequential()
+    for name, module in parts:
+        seq.add_module(name, module)
     return seq
 
 
-def statistics_pooling(x, dim=-1, keepdim=False, unbiased=True, eps=1e-2):
-    stats = torch.cat([x.mean(dim=dim), x.std(dim=dim, unbiased=unbiased)], dim=-1)
-    return stats.unsqueeze(dim=dim) if keepdim else stats
+def _conv1d(cin, cout, k=1, stride=1, dilation=1, bias=False):
+    return nn.Conv1d(cin, cout, k, stride=stride, padding=(k - 1) // 2 * dilation, dilation=dilation, bias=bias)
 
 
-class StatsPool(nn.Module):
-    def forward(self, x):
-        return statistics_pooling(x)
+def _res_block(cin, cout, stride):
+    kids = [('conv1', nn.Conv2d(cin, cout, 3, stride=(stride, 1), padding=1, bias=False)), ('bn1', nn.BatchNorm2d(cout)),
+            ('conv2', nn.Conv2d(cout, cout, 3, stride=1, padding=1, bias=False)), ('bn2', nn.BatchNorm2d(cout))]
+    short = nn.Sequential()
+    if stride != 1 or cin != cout:
+        short = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=(stride, 1), bias=False), nn.BatchNorm2d(cout))
+    return _node(*kids, ('shortcut', short))
 
 
-class TDNNLayer(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=False,
-                 config_str='batchnorm-relu'):
-        super().__init__()
-        if padding < 0:
-            assert kernel_size % 2 == 1, f'Expect equal paddings, but got even kernel size ({kernel_size})'
-            padding = (kernel_size - 1) // 2 * dilation
-        self.linear = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
-                                dilation=dilation, bias=bias)
-        self.nonlinear = get_nonlinear(config_str, out_channels)
-
-    def forward(self, x):
-        return self.nonlinear(self.linear(x))
+def _head(maps, feat_dim):
+    """FCM front-end (campplus.py:257-292): frequency axis F -> ceil(F/8) with `maps` feature maps."""
+    stage = lambda: nn.Sequential(_res_block(maps, maps, 2), _res_block(maps, maps, 1))
+    h = _node(('conv1', nn.Conv2d(1, maps, 3, stride=1, padding=1, bias=False)), ('bn1', nn.BatchNorm2d(maps)),
+              ('layer1', stage()), ('layer2', stage()),
+              ('conv2', nn.Conv2d(maps, maps, 3, stride=(2, 1), padding=1, bias=False)), ('bn2', nn.BatchNorm2d(maps)))
+    h.out_channels = maps * math.ceil(feat_dim / 8)
+    return h
 
 
-class CAMLayer(nn.Module):
-    """Local conv masked by a context gate computed from global + 100-frame segment means."""
-
-    def __init__(self, bn_channels, out_channels, kernel_size, stride, padding, dilation, bias, reduction=2):
-        super().__init__()
-        self.linear_local = nn.Conv1d(bn_channels, out_channels, kernel_size, stride=stride, padding=padding,
-                                      dilation=dilation, bias=bias)
-        self.linear1 = nn.Conv1d(bn_channels, bn_channels // reduction, 1)
-        self.relu = nn.ReLU(inplace=True)
-        self.linear2 = nn.Conv1d(bn_channels // reduction, out_channels, 1)
-        self.sigmoid = nn.Sigmoid()
-
-    def seg_pooling(self, x, seg_len=100, stype='avg'):
-        pool = {'avg': F.avg_pool1d, 'max': F.max_pool1d}.get(stype)
-        if pool is None:
-            raise ValueError('Wrong segment pooling type.')
-        seg = pool(x, kernel_size=seg_len, stride=seg_len, ceil_mode=True)
-        seg = seg.unsqueeze(-1).expand(*seg.shape, seg_len).reshape(*seg.shape[:-1], -1)
-        return seg[..., :x.shape[-1]]
-
-    def forward(self, x):
-        context = x.mean(-1, keepdim=True) + self.seg_pooling(x)
-        gate = self.sigmoid(self.linear2(self.relu(self.linear1(context))))
-        return self.linear_local(x) * gate
+def _dense_layer(cin, growth, bottleneck, dilation, spec):
+    cam = _node(('linear_local', _conv1d(bottleneck, growth, 3, dilation=dilation)),
+                ('linear1', nn.Conv1d(bottleneck, bottleneck // 2, 1)), ('linear2', nn.Conv1d(bottleneck // 2, growth, 1)))
+    return _node(('nonlinear1', _norm_act(spec, cin)), ('linear1', nn.Conv1d(cin, bottleneck, 1, bias=False)),
+                 ('nonlinear2', _norm_act(spec, bottleneck)), ('cam_layer', cam))
 
 
-class CAMDenseTDNNLayer(nn.Module):
-    def __init__(self, in_channels, out_channels, bn_channels, kernel_size, stride=1, dilation=1, bias=False,
-                 config_str='batchnorm-relu', memory_efficient=False):
-        super().__init__()
-        assert kernel_size % 2 == 1, f'Expect equal paddings, but got even kernel size ({kernel_size})'
-        self.memory_efficient = memory_efficient
-        self.nonlinear1 = get_nonlinear(config_str, in_channels)
-        self.linear1 = nn.Conv1d(in_channels, bn_channels, 1, bias=False)
-        self.nonlinear2 = get_nonlinear(config_str, bn_channels)
-        self.cam_layer = CAMLayer(bn_channels, out_channels, kernel_size, stride=stride,
-                                  padding=(kernel_size - 1) // 2 * dilation, dilation=dilation, bias=bias)
+# ---- functional forward over the tree ------------------------------------------------------------------------------
 
-    def bn_function(self, x):
-        return self.linear1(self.nonlinear1(x))
-
-    def forward(self, x):
-        if self.training and self.memory_efficient:
-            x = cp.checkpoint(self.bn_function, x, use_reentrant=False)
-        else:
-            x = self.bn_function(x)
-        return self.cam_layer(self.nonlinear2(x))
+def _res_forward(blk, x):
+    y = blk.bn2(blk.conv2(F.relu(blk.bn1(blk.conv1(x)))))
+    return F.relu(y + blk.shortcut(x))
 
 
-class CAMDenseTDNNBlock(nn.ModuleList):
-    def __init__(self, num_layers, in_channels, out_channels, bn_channels, kernel_size, stride=1, dilation=1,
-                 bias=False, config_str='batchnorm-relu', memory_efficient=False):
-        super().__init__()
-        for i in range(num_layers):
-            self.add_module('tdnnd%d' % (i + 1),
-                            CAMDenseTDNNLayer(in_channels=in_channels + i * out_channels, out_channels=out_channels,
-                                              bn_channels=bn_channels, kernel_size=kernel_size, stride=stride,
-                                              dilation=dilation, bias=bias, config_str=config_str,
-                                              memory_efficient=memory_efficient))
-
-    def forward(self, x):
-        for layer in self:
-            x = torch.cat([x, layer(x)], dim=1)
-        return x
+def _head_forward(h, feats):
+    y = F.relu(h.bn1(h.conv1(feats.unsqueeze(1))))
+    for stage in (h.layer1, h.layer2):
+        for blk in stage:
+            y = _res_forward(blk, y)
+    y = F.relu(h.bn2(h.conv2(y)))
+    return y.flatten(1, 2)  # [B, maps * F/8, T]
 
 
-class TransitLayer(nn.Module):
-    def __init__(self, in_channels, out_channels, bias=True, config_str='batchnorm-relu'):
-        super().__init__()
-        self.nonlinear = get_nonlinear(config_str, in_channels)
-        self.linear = nn.Conv1d(in_channels, out_channels, 1, bias=bias)
-
-    def forward(self, x):
-        return self.linear(self.nonlinear(x))
+def _segment_means(x, seg_len=_SEG_LEN):
+    """Mean of every seg_len-frame segment (the last one over its true length), repeated back to T frames."""
+    T = x.shape[-1]
+    seg = F.avg_pool1d(x, kernel_size=seg_len, stride=seg_len, ceil_mode=True)
+    return seg.repeat_interleave(seg_len, dim=-1)[..., :T]
 
 
-class DenseLayer(nn.Module):
-    def __init__(self, in_channels, out_channels, bias=False, config_str='batchnorm-relu'):
-        super().__init__()
-        self.linear = nn.Conv1d(in_channels, out_channels, 1, bias=bias)
-        self.nonlinear = get_nonlinear(config_str, out_channels)
-
-    def forward(self, x):
-        if len(x.shape) == 2:
-            x = self.linear(x.unsqueeze(dim=-1)).squeeze(dim=-1)
-        else:
-            x = self.linear(x)
-        return self.nonlinear(x)
-
-
-class BasicResBlock(nn.Module):
-    expansion = 1
-
-    def __init__(self, in_planes, planes, stride=1):
-        super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, stride=(stride, 1), padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.shortcut = nn.Sequential()
-        if stride != 1 or in_planes != self.expansion * planes:
-            self.shortcut = nn.Sequential(
-                nn.Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=(stride, 1), bias=False),
-                nn.BatchNorm2d(self.expansion * planes))
-
-    def forward(self, x):
-        out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
-        return F.relu(out + self.shortcut(x))
-
-
-class FCM(nn.Module):
-    """2-D convolutional front-end: frequency axis 80 -> 10 with 32 maps, flattened to 320 channels."""
-
-    def __init__(self, block=BasicResBlock, num_blocks=[2, 2], m_channels=32, feat_dim=80):
-        super().__init__()
-        self.in_planes = m_channels
-        self.conv1 = nn.Conv2d(1, m_channels, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(m_channels)
-        self.layer1 = self._make_layer(block, m_channels, num_blocks[0], stride=2)
-        self.layer2 = self._make_layer(block, m_channels, num_blocks[0], stride=2)
-        self.conv2 = nn.Conv2d(m_channels, m_channels, kernel_size=3, stride=(2, 1), padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(m_channels)
-        self.out_channels = m_channels * (math.ceil(feat_dim / 8))
-
-    def _make_layer(self, block, planes, num_blocks, stride):
-        layers = []
-        for s in [stride] + [1] * (num_blocks - 1):
-            layers.append(block(self.in_planes, planes, s))
-            self.in_planes = planes * block.expansion
-        return nn.Sequential(*layers)
-
-    def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x.unsqueeze(1))))
-        out = self.layer2(self.layer1(out))
-        out = F.relu(self.bn2(self.conv2(out)))
-        return out.reshape(out.shape[0], out.shape[1] * out.shape[2], out.shape[3])
+def _dense_layer_forward(layer, x):
+    h = layer.nonlinear2(layer.linear1(layer.nonlinear1(x)))
+    cam = layer.cam_layer
+    context = h.mean(-1, keepdim=True) + _segment_means(h)
+    gate = torch.sigmoid(cam.linear2(F.relu(cam.linear1(context))))
+    return cam.linear_local(h) * gate
 
 
 class CAMPPlus(NativeBackbone, nn.Module):
@@ -199,27 +125,26 @@ class CAMPPlus(NativeBackbone, nn.Module):
     def __init__(self, input_size, embd_dim=512, growth_rate=32, bn_size=4, init_channels=128,
                  config_str='batchnorm-relu', memory_efficient=True):
         super().__init__()
-        self.head = FCM(feat_dim=input_size)
-        channels = self.head.out_channels
         self.embd_dim = embd_dim
         self._cfg = dict(input_size=input_size, growth_rate=growth_rate, bn_size=bn_size, init_channels=init_channels,
                          config_str=config_str)
-        self.xvector = nn.Sequential(OrderedDict([
-            ('tdnn', TDNNLayer(channels, init_channels, 5, stride=2, dilation=1, padding=-1, config_str=config_str))]))
-        channels = init_channels
-        for i, (num_layers, kernel_size, dilation) in enumerate(zip((12, 24, 16), (3, 3, 3), (1, 2, 2))):
-            self.xvector.add_module('block%d' % (i + 1),
-                                    CAMDenseTDNNBlock(num_layers=num_layers, in_channels=channels,
-                                                      out_channels=growth_rate, bn_channels=bn_size * growth_rate,
-                                                      kernel_size=kernel_size, dilation=dilation,
-                                                      config_str=config_str, memory_efficient=memory_efficient))
-            channels = channels + num_layers * growth_rate
-            self.xvector.add_module('transit%d' % (i + 1),
-                                    TransitLayer(channels, channels // 2, bias=False, config_str=config_str))
-            channels //= 2
-        self.xvector.add_module('out_nonlinear', get_nonlinear(config_str, channels))
-        self.xvector.add_module('stats', StatsPool())
-        self.xvector.add_module('dense', DenseLayer(channels * 2, embd_dim, config_str='batchnorm_'))
+        self.memory_efficient = memory_efficient  # activation checkpointing of the reference's training path: not used here
+        self.head = _head(32, input_size)
+        bottleneck = bn_size * growth_rate
+        kids = [('tdnn', _node(('linear', _conv1d(self.head.out_channels, init_channels, 5, stride=2)),
+                               ('nonlinear', _norm_act(config_str, init_channels))))]
+        width = init_channels
+        for b, (layers, dilation) in enumerate(_DENSE_BLOCKS, start=1):
+            kids.append((f'block{b}', _node(*[(f'tdnnd{i + 1}', _dense_layer(width + i * growth_rate, growth_rate, bottleneck,
+                                                                             dilation, config_str)) for i in range(layers)])))
+            width += layers * growth_rate
+            kids.append((f'transit{b}', _node(('nonlinear', _norm_act(config_str, width)),
+                                              ('linear', nn.Conv1d(width, width // 2, 1, bias=False)))))
+            width //= 2
+        kids.append(('out_nonlinear', _norm_act(config_str, width)))
+        kids.append(('dense', _node(('linear', nn.Conv1d(2 * width, embd_dim, 1, bias=False)),
+                                    ('nonlinear', _norm_act('batchnorm_', embd_dim)))))
+        self.xvector = _node(*kids)
         for m in self.modules():
             if isinstance(m, (nn.Conv1d, nn.Linear)):
                 nn.init.kaiming_normal_(m.weight.data)
@@ -227,9 +152,10 @@ class CAMPPlus(NativeBackbone, nn.Module):
                     nn.init.zeros_(m.bias)
 
     def _native_supported(self):
-        if self._cfg['config_str'] != 'batchnorm-relu':
-            return False, f"config_str={self._cfg['config_str']!r}"
-        if self._cfg['growth_rate'] != 32 or self._cfg['bn_size'] != 4 or self._cfg['init_channels'] % 64 != 0:
+        c = self._cfg
+        if c['config_str'] != 'batchnorm-relu':
+            return False, f"config_str={c['config_str']!r}"
+        if c['growth_rate'] != 32 or c['bn_size'] != 4 or c['init_channels'] % 64 != 0:
             return False, 'growth_rate/bn_size/init_channels other than 32/4/multiple of 64'
         return True, ''
 
@@ -244,4 +170,14 @@ class CAMPPlus(NativeBackbone, nn.Module):
         """x: (B, T, F) -> (B, embd_dim)."""
         if self._use_native(x):
             return self._native_forward(x)
-        return self.xvector(self.head(x.permute(0, 2, 1)))
+        xv = self.xvector
+        y = _head_forward(self.head, x.transpose(1, 2))
+        y = xv.tdnn.nonlinear(xv.tdnn.linear(y))
+        for b in range(1, len(_DENSE_BLOCKS) + 1):
+            for layer in getattr(xv, f'block{b}').children():
+                y = torch.cat((y, _dense_layer_forward(layer, y)), dim=1)
+            transit = getattr(xv, f'transit{b}')
+            y = transit.linear(transit.nonlinear(y))
+        y = xv.out_nonlinear(y)
+        stats = torch.cat((y.mean(-1), y.std(-1, unbiased=True)), dim=-1)   # StatsPool (campplus.py:27-38)
+        return xv.dense.nonlinear(xv.dense.linear(stats.unsqueeze(-1)).squeeze(-1))

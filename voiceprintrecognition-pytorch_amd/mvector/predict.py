@@ -6,8 +6,6 @@ does (predict.py:244-255), moved to the GPU once, featurised there by the fused 
 kernel.  With ``use_gpu=False`` everything runs through the torch CPU graphs, as in the reference.
 """
 import os
-import pickle
-import shutil
 from io import BufferedReader
 
 import numpy as np
@@ -59,76 +57,29 @@ class MVectorPredictor:
         logger.info(f"成功加载模型参数：{model_path}")
         self.predictor.eval()
 
-        self.audio_feature = None        # enrolled embeddings [N, D]
-        self.audio_feature_mean = None   # per-user mean embeddings [U, D]
-        self.users_name = []
-        self.users_audio_path = []
-        self.users_name_mean = []
         self.audio_db_path = audio_db_path
-        if self.audio_db_path is not None:
-            self.audio_indexes_path = os.path.join(audio_db_path, "audio_indexes.bin")
-            self.__load_audio_db(self.audio_db_path)
-        self._speaker_diarize = None
+        self._gallery = None
+        if audio_db_path is not None:
+            self._open_gallery(audio_db_path)
 
-    # ------------------------------------------------------------------ audio-db bookkeeping (host side)
-    def __load_audio_indexes(self):
-        if not os.path.exists(self.audio_indexes_path):
-            return
-        with open(self.audio_indexes_path, "rb") as f:
-            indexes = pickle.load(f)
-        for name, feature, path in zip(indexes["users_name"], indexes["faces_feature"], indexes["users_image_path"]):
-            if not os.path.exists(path):
-                continue
-            self.users_name.append(name)
-            self.users_audio_path.append(path)
-            self.audio_feature = feature if self.audio_feature is None else np.vstack((self.audio_feature, feature))
-
-    def __write_index(self):
-        with open(self.audio_indexes_path, "wb") as f:
-            pickle.dump({"users_name": self.users_name, "faces_feature": self.audio_feature,
-                         "users_image_path": self.users_audio_path}, f)
-
-    def __append_features(self, features):
-        self.audio_feature = features if self.audio_feature is None else np.vstack((self.audio_feature, features))
-
-    def __load_audio_db(self, audio_db_path):
-        self.__load_audio_indexes()
-        os.makedirs(audio_db_path, exist_ok=True)
-        audios_path = []
-        for name in os.listdir(audio_db_path):
-            audio_dir = os.path.join(audio_db_path, name)
-            if not os.path.isdir(audio_dir):
-                continue
-            for file in os.listdir(audio_dir):
-                audios_path.append(os.path.join(audio_dir, file).replace('\\', '/'))
-        if len(audios_path) == 0:
-            return
-        logger.info('正在加载声纹库数据...')
-        batch_size = self.configs.dataset_conf.eval_conf.batch_size
-        pending = []
-        for audio_path in audios_path:
-            if audio_path in self.users_audio_path:
-                continue
-            audio_segment = self._load_audio(audio_path)
-            self.users_name.append(os.path.basename(os.path.dirname(audio_path)))
-            self.users_audio_path.append(audio_path)
-            pending.append(audio_segment.samples)
-            if len(pending) == batch_size:
-                self.__append_features(self.predict_batch(pending))
-                pending = []
-        if len(pending) != 0:
-            self.__append_features(self.predict_batch(pending))
-        assert len(self.audio_feature) == len(self.users_name) == len(self.users_audio_path), '加载的数量对不上！'
-        self.__write_index()
-        for name in set(self.users_name):
-            rows = [i for i, v in enumerate(self.users_name) if v == name]
-            feature = self.audio_feature[rows].mean(axis=0)
-            self.audio_feature_mean = feature if self.audio_feature_mean is None else \
-                np.vstack((self.audio_feature_mean, feature))
-            self.users_name_mean.append(name)
-        if len(self.audio_feature_mean.shape) == 1:
-            self.audio_feature_mean = self.audio_feature_mean[np.newaxis, :]
-        logger.info(f'声纹库数据加载完成，一共有{len(self.audio_feature_mean)}个用户，分别是：{self.users_name_mean}')
+    # ------------------------------------------------------------------ enrolment gallery (host side)
+    def _open_gallery(self, audio_db_path):
+        """Load ``audio_indexes.bin`` and embed (in eval-batch-sized batches) every audio file the index does not list yet."""
+        from mvector.infer_utils.gallery import SpeakerGallery
+        self._gallery = SpeakerGallery(audio_db_path)
+        todo = self._gallery.unindexed_audio()
+        if todo:
+            logger.info('正在加载声纹库数据...')
+            step = self.configs.dataset_conf.eval_conf.batch_size
+            for lo in range(0, len(todo), step):
+                chunk = todo[lo:lo + step]
+                rows = self.predict_batch([self._load_audio(p).samples for p in chunk])
+                for path, row in zip(chunk, rows):
+                    self._gallery.add(os.path.basename(os.path.dirname(path)), path, row)
+            self._gallery.save()
+        users, _ = self._gallery.user_means()
+        if users:
+            logger.info(f'声纹库数据加载完成，一共有{len(users)}个用户，分别是：{users}')
 
     # ------------------------------------------------------------------ scoring
     @staticmethod
@@ -141,27 +92,18 @@ class MVectorPredictor:
         gallery = np.asarray(gallery, dtype=np.float32)
         if self.device.type == 'cuda':
             from mvector import _hip
-            q = torch.from_numpy(queries).to(self.device)
-            g = torch.from_numpy(gallery).to(self.device)
-            return _hip.cosine(q, g).cpu().numpy()
-        qn = queries / np.linalg.norm(queries, axis=1, keepdims=True)
-        gn = gallery / np.linalg.norm(gallery, axis=1, keepdims=True)
-        return qn @ gn.T
+            return _hip.cosine(torch.from_numpy(queries).to(self.device), torch.from_numpy(gallery).to(self.device)).cpu().numpy()
+        return self.normalize_features(queries) @ self.normalize_features(gallery).T
 
-    def __retrieval(self, np_feature):
-        if isinstance(np_feature, list):
-            np_feature = np.array(np_feature)
-        labels = []
-        np_feature = self.normalize_features(np_feature.astype(np.float32))
-        similarities = self._cosine(np_feature, self.audio_feature_mean)
-        for sim in similarities:
-            idx = np.argmax(sim)
-            sim = sim[idx]
-            if sim >= self.threshold:
-                labels.append([self.users_name_mean[idx], round(float(sim), 5)])
-            else:
-                labels.append([None, None])
-        return labels
+    def _best_matches(self, embeddings):
+        """[name, score] of the best enrolled user per query row, or [None, None] below the threshold."""
+        users, means = self._gallery.user_means()
+        scores = self._cosine(np.atleast_2d(np.asarray(embeddings, dtype=np.float32)), means)
+        out = []
+        for row in scores:
+            best = int(np.argmax(row))
+            out.append([users[best], round(float(row[best]), 5)] if row[best] >= self.threshold else [None, None])
+        return out
 
     # ------------------------------------------------------------------ audio in
     def _load_audio(self, audio_data, sample_rate=16000):
@@ -269,49 +211,25 @@ class MVectorPredictor:
     def register(self, audio_data, user_name: str, sample_rate=16000):
         """声纹注册"""
         audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
-        feature = self.predict(audio_data=audio_segment)
-        self.__append_features(feature)
-        user_dir = os.path.join(self.audio_db_path, user_name)
-        index = len(os.listdir(user_dir)) if os.path.exists(user_dir) else 0
-        audio_path = os.path.join(user_dir, f'{index}.wav')
-        os.makedirs(user_dir, exist_ok=True)
+        embedding = self.predict(audio_data=audio_segment)
+        audio_path = self._gallery.next_audio_path(user_name)
         audio_segment.to_wav_file(audio_path)
-        self.users_audio_path.append(audio_path.replace('\\', '/'))
-        self.users_name.append(user_name)
-        self.__write_index()
-        if user_name in self.users_name_mean:
-            index = self.users_name_mean.index(user_name)
-            rows = [i for i, v in enumerate(self.users_name) if v == user_name]
-            self.audio_feature_mean[index] = self.audio_feature[rows].mean(axis=0)
-        else:
-            self.users_name_mean.append(user_name)
-            self.audio_feature_mean = feature[np.newaxis, :] if self.audio_feature_mean is None else \
-                np.vstack((self.audio_feature_mean, feature))
+        self._gallery.add(user_name, audio_path, embedding)
+        self._gallery.save()
         return True, "注册成功"
 
     def recognition(self, audio_data, threshold=None, sample_rate=16000):
         """声纹识别 -> [user name or None, score or None]"""
         if threshold:
             self.threshold = threshold
-        feature = self.predict(audio_data, sample_rate=sample_rate)
-        return self.__retrieval(np_feature=np.array([feature]))[0]
+        return self._best_matches(self.predict(audio_data, sample_rate=sample_rate))[0]
 
     def get_users(self):
-        return self.users_name
+        """One entry per enrolled audio, as the reference returns its ``users_name`` list."""
+        return list(self._gallery.names)
 
     def remove_user(self, user_name):
-        if user_name in self.users_name and user_name in self.users_name_mean:
-            for index in sorted((i for i, v in enumerate(self.users_name) if v == user_name), reverse=True):
-                del self.users_name[index]
-                del self.users_audio_path[index]
-                self.audio_feature = np.delete(self.audio_feature, index, axis=0)
-            self.__write_index()
-            shutil.rmtree(os.path.join(self.audio_db_path, user_name))
-            index = self.users_name_mean.index(user_name)
-            del self.users_name_mean[index]
-            self.audio_feature_mean = np.delete(self.audio_feature_mean, index, axis=0)
-            return True
-        return False
+        return self._gallery.remove(user_name)
 
     def speaker_diarization(self, audio_data, sample_rate=16000, speaker_num=None, search_audio_db=False):
         """说话人日志: VAD segmentation and spectral clustering are host post-processing of the reference

@@ -50,21 +50,24 @@ def dict_to_object(dict_obj):
     return Dict({k: dict_to_object(v) for k, v in dict_obj.items()})
 
 
-def cal_accuracy_threshold(y_score, y_true):
-    y_score, y_true = np.asarray(y_score), np.asarray(y_true)
-    best_accuracy, best_threshold = 0, 0
-    for i in range(100):
-        threshold = i * 0.01
-        acc = np.mean(((y_score >= threshold) == y_true).astype(int))
-        if acc > best_accuracy:
-            best_accuracy, best_threshold = acc, threshold
-    return best_accuracy, best_threshold
-
-
 def cal_accuracy(y_score, y_true, threshold=0.5):
-    y_score, y_true = np.asarray(y_score), np.asarray(y_true)
-    return np.mean(((y_score >= threshold) == y_true).astype(int))
+    """Fraction of trials on the right side of ``threshold`` (labels 0 / 1)."""
+    decided = np.asarray(y_score) >= threshold
+    return float(np.mean(decided == np.asarray(y_true).astype(bool)))
+
+
+def cal_accuracy_threshold(y_score, y_true):
+    """Best accuracy over the thresholds 0.00, 0.01, ... 0.99 and the (first) threshold reaching it, as the reference's
+    scan does; all thresholds at once."""
+    scores, labels = np.asarray(y_score), np.asarray(y_true).astype(bool)
+    grid = np.arange(100) * 0.01
+    acc = ((scores[None, :] >= grid[:, None]) == labels[None, :]).mean(axis=1)
+    best = int(np.argmax(acc))  # argmax returns the first maximum, like the strict '>' of the scan
+    if acc[best] <= 0:
+        return 0, 0
+    return acc[best], grid[best]
 
 
 def cosin_metric(x1, x2):
-    return np.dot(x1, x2) / (np.linalg.norm(x1) * np.linalg.norm(x2))
+    a, b = np.asarray(x1), np.asarray(x2)
+    return float(a @ b) / float(np.linalg.norm(a) * np.linalg.norm(b))
