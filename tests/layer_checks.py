@@ -246,6 +246,8 @@ CONV2D_CASES = [
     dict(cin=256, cout=512, ks=3, stride=2, H=6, W=20, B=1, hi=65504.0, lo=-65504.0),  # layer3_downsample
     dict(cin=48, cout=144, ks=3, H=3, W=20, B=1),                            # 9 channel blocks: two uneven tiles of 5 (one clamped block)
     dict(cin=48, cout=208, ks=1, H=2, W=37, B=2, with_res=True),             # 1x1: 13 blocks -> 4 tiles of 4 (3 clamped blocks)
+    dict(cin=32, cout=48, ks=1, stride=2, H=5, W=37, B=2),                   # strided 1x1 on odd sizes: 5 x 37 -> 3 x 19
+    dict(cin=16, cout=32, ks=3, stride=2, H=5, W=33, B=1, x2_mode=1),        # strided 3x3 on odd sizes with the input sum
 ]
 
 

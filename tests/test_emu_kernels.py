@@ -95,6 +95,29 @@ def test_emu_eres2net_tiny_end_to_end(case):
     assert rel < 1e-4
 
 
+def test_emu_eres2net_rejects_bad_arguments():
+    from helpers import load_case
+    man, sd, x, _, _ = load_case('eres2netv2_tiny')
+    cfg = lc._hip.MvEres2Cfg()
+    cfg.version, cfg.input_size, cfg.embd_dim = 2, 16, 64
+    for i, n in enumerate([1, 1, 2, 1]):
+        cfg.num_blocks[i] = n
+    cfg.m_channels, cfg.mul_channel, cfg.expansion, cfg.base_width, cfg.scale, cfg.two_emb_layer = 16, 1, 2, 26, 2, 1
+    m = lc._hip.Model('eres2net', cfg, sd, cdll=emu_cdll())
+    with pytest.raises(RuntimeError, match='at least 9 frames'):
+        m.forward(x[:, :8].contiguous())
+    cfg.m_channels = 24  # not a multiple of 16
+    with pytest.raises(RuntimeError, match='multiple of 16'):
+        lc._hip.Model('eres2net', cfg, sd, cdll=emu_cdll())
+    cfg.m_channels, cfg.expansion = 16, 4
+    with pytest.raises(RuntimeError, match='expansion 2'):
+        lc._hip.Model('eres2net', cfg, sd, cdll=emu_cdll())
+    cfg.expansion = 2
+    sd_missing = {k: v for k, v in sd.items() if k != 'fuse34.local_att.3.weight'}
+    with pytest.raises(RuntimeError, match='fuse34.local_att.3.weight'):
+        lc._hip.Model('eres2net', cfg, sd_missing, cdll=emu_cdll())
+
+
 def test_emu_ecapa_tiny_end_to_end():
     cd, rel = lc.model_case(emu_cdll(), 'cpu', 'ecapa_tiny')
     assert rel < 5e-3
