@@ -25,10 +25,17 @@ Pin status
   modules from /root/reference (loguru stubbed), loads weights produced by
   ``weights.py`` and stores their outputs in ``tests/golden/*.npz``;
   ``tests/test_oracle_models.py`` checks this restatement against them.
-* front-end (Fbank / MelSpectrogram): the reference has no tests and its
-  arithmetic lives in torchaudio, which cannot be run here, so there is no
-  reference-produced vector to pin to: **parity unpinned against torchaudio
-  itself**.  The restatement is instead cross-checked against two independent
+* ``AudioFeaturizer.forward`` / ``KaldiFbank.forward`` (the wrapper: per-utterance
+  loop, transposes, time-mean subtraction, torch.round mask, feature_dim): PINNED.
+  ``make_golden.py::save_featurizer_golden`` imports the reference's own
+  ``mvector/data_utils/featurizer.py`` under a stub ``torchaudio`` whose two
+  functions are the restatements below and stores its outputs on the Q1/Q2/Q3
+  fixtures in ``tests/golden/featurizer_ref.npz``; the oracle wrapper agrees bit
+  for bit, the product (CPU and HIP) within the front-end tolerance.
+* the arithmetic INSIDE ``kaldi.fbank`` / ``MelSpectrogram``: the reference has no
+  tests and that arithmetic lives in torchaudio, which cannot be run here, so
+  there is no torchaudio-produced vector to pin to: **parity unpinned against
+  torchaudio itself**.  The restatement is instead cross-checked against two independent
   implementations that ARE available: ``transformers.audio_utils.spectrogram``
   (the numpy code HuggingFace ships as the replacement for ``ta_kaldi.fbank``)
   and, for MelSpectrogram, ``torch.stft`` (the very op torchaudio calls) plus

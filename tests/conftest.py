@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """Without a device (the build container) the GPU parity tests are skipped instead of failing at their first launch."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no ROCm device: -m gpu tests run on the MI355X box')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

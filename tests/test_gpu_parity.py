@@ -88,6 +88,41 @@ def test_gpu_fbank_golden_fixed_and_ragged():
         assert np.all(outv[i, ml:] == 0) and np.any(outv[i, ml - 1] != 0)
 
 
+def test_gpu_featurizer_matches_reference_wrapper_golden():
+    """AudioFeaturizer.forward on the HIP path against tests/golden/featurizer_ref.npz = the REFERENCE's own featurizer.py wrapper
+    (KaldiFbank loop, transposes, CMN, torch.round mask) run by oracle/make_golden.py under a stub torchaudio (a3 pin)."""
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    z = np.load(os.path.join(GOLDEN, 'featurizer_ref.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(z['lens']):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    ratio, half = torch.from_numpy(z['ratio']).to(DEV), torch.from_numpy(z['half']).to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+
+    def close(got, want):
+        d = np.abs(got - want)
+        assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+        # masked frames are exactly zero, frame by frame, on both sides (Q3: the edge sits where torch.round puts it)
+        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
+    out = fz(wav[:2].to(DEV))
+    assert out.is_cuda and out.dtype == torch.float32
+    close(out.cpu().numpy(), z['fbank'])
+    close(fz(wav_var.to(DEV), ratio).cpu().numpy(), z['fbank_var'])
+    close(fz(wav_var.to(DEV), half).cpu().numpy()[:, :24], z['fbank_half'])
+    close(fz(wav[1, :16000].to(DEV)).cpu().numpy(), z['fbank_1d'])  # 1-D input is unsqueezed (featurizer.py:63-64)
+    mz = AudioFeaturizer('MelSpectrogram', method_args={})
+    scale = float(np.abs(z['mel']).max())
+    for got, want in ((mz(wav[:2].to(DEV)), z['mel']), (mz(wav_var.to(DEV), ratio)[2:], z['mel_var']),
+                      (mz(wav_var[:1].to(DEV), half[:1]), z['mel_half'])):
+        got = got.cpu().numpy()
+        assert np.abs(got - want).max() < 2e-4 * scale
+        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
+    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    got = AudioFeaturizer('MelSpectrogram', method_args=readme)(wav[:1].to(DEV)).cpu().numpy()
+    assert np.abs(got - z['mel_readme']).max() < 2e-4 * float(np.abs(z['mel_readme']).max())
+
+
 def test_gpu_fbank_ragged_strides_and_edges():
     wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)
     wav[2, 9000:] = 0

@@ -279,3 +279,48 @@ def test_sharded_path_world_size_2_gloo(tmp_path):
         assert (lo, hi) == ((0, 3), (3, 6))[r]
         assert np.abs(z['emb_all'] - full).max() < 1e-3          # every rank holds the whole embedding matrix
         assert np.abs(z['scores'] - sim[lo:hi]).max() < 1e-5     # and the score block of its own rows
+
+
+def test_native_handle_cache_is_not_part_of_module_state(tmp_path):
+    """A backbone that has built its native handle must still deep-copy, pickle and torch.save: the handle cache
+    holds ctypes objects; copies build their own handle on first use.  In-place parameter edits invalidate the cache key."""
+    import copy
+    import ctypes
+    import pickle
+    from mvector.models import EcapaTdnn
+    man, sd, _, _, _ = load_case('ecapa_tiny')
+    m = EcapaTdnn(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval()
+
+    class Handle:  # what _hip.Model holds: raw pointers and a CDLL
+        def __init__(self):
+            self.h, self.lib = ctypes.c_void_p(1234), ctypes.CDLL(None)
+    v0 = m._params_version()
+    m.__dict__['_native_handles'] = {0: (Handle(), v0)}
+    c = copy.deepcopy(m)
+    assert '_native_handles' not in c.__dict__ and '_native_handles' in m.__dict__
+    assert all(torch.equal(a, b) for a, b in zip(c.state_dict().values(), m.state_dict().values()))
+    assert c.blocks[0].conv.conv.weight.data_ptr() != m.blocks[0].conv.conv.weight.data_ptr()
+    r = pickle.loads(pickle.dumps(m))
+    assert '_native_handles' not in r.__dict__ and torch.equal(r.fc.conv.weight, m.fc.conv.weight)
+    torch.save(torch.nn.Sequential(m), str(tmp_path / 'whole_model.pt'))
+    # an in-place edit under no_grad (EMA swap, weight surgery) changes the version key the handle was built under
+    with torch.no_grad():
+        m.fc.conv.weight.mul_(1.0)
+    assert m._params_version() != v0
+    # gradient analysis with respect to the input needs the torch graph; plain inference (grad mode on, default
+    # requires_grad parameters -- what the reference's predictor does) must stay on the native path
+    x = torch.zeros(1, 20, man['kwargs']['input_size'])
+
+    class FakeCuda(torch.Tensor):
+        is_cuda = True
+    assert m._use_native(x) is False                       # CPU tensor
+    fx = x.as_subclass(FakeCuda)
+    assert m._use_native(fx) is True
+    fxg = x.clone().requires_grad_(True).as_subclass(FakeCuda)
+    assert m._use_native(fxg) is False
+    with torch.no_grad():
+        assert m._use_native(fxg) is True
+    m.train()
+    assert m._use_native(fx) is False and '_native_handles' in m.__dict__ and not m.__dict__['_native_handles']

@@ -150,7 +150,16 @@ int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream) {
     MV_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "linear_f32: null tensor");
     MV_REQUIRE(B > 0 && K > 0 && O > 0 && ldx >= K && ldw >= K && ldy >= O, "linear_f32: bad geometry");
-    MV_REQUIRE(ceil_div(B, 16) <= 65535, "linear_f32: too many rows");
+    // grid.y holds at most 65535 row tiles: longer inputs (evaluation score matrices with > 1 M trial rows) go in row chunks
+    constexpr int kMaxRows = 65535 * 16;
+    if (B > kMaxRows) {
+        for (int b0 = 0; b0 < B; b0 += kMaxRows) {
+            const int rows = B - b0 < kMaxRows ? B - b0 : kMaxRows;
+            const int rc = linear_f32_launch(x + (int64_t)b0 * ldx, ldx, w, ldw, bias, act, y + (int64_t)b0 * ldy, ldy, rows, K, O, cosine, stream);
+            if (rc != MV_OK) return rc;
+        }
+        return MV_OK;
+    }
     if (K >= 2048) {  // long reductions: 16 waves split K so the dependent load chain per wave stays short
         MV_LAUNCH(linear_f32_kernel<16>, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (1024, 1, 1), 0, stream, x, ldx,
                   w, ldw, bias, act, y, ldy, B, K, O, cosine);

@@ -4,7 +4,7 @@ The parameter tree (``conv1, bn1, layer{1..4}.{j}.{conv1,bn1,convs.i,bns.i,fuse_
 shortcut.{0,1}}``, ``layer{1,2,3}_downsample`` / ``layer3_ds``, ``fuse_mode{12,123,1234}`` / ``fuse34``, ``seg_1``,
 ``seg_bn_1``, ``seg_2``) is the reference's, so its ``model.pth`` loads unchanged.  Eval-mode CUDA forwards run on the
 native handle (csrc/eres2net.hip: every conv + BatchNorm + activation / residual / fusion is one conv2d_kernel launch on
-channel-last fp16 maps); the torch forward below serves CPU tensors and training-mode calls.
+channel-last fp32 maps); the torch forward below serves CPU tensors and training-mode calls.
 """
 import math
 
