@@ -9,15 +9,21 @@ The batch dimension shards across ranks with no other exchange (weak scaling: B 
 
 Output: ONE JSON line on rank 0 (metric = utterances/sec embedded, BASELINE.json) with
   * per-stage times from events recorded on the launch stream inside the timed region,
-  * ``roofline``: the dominant kernel class (the implicit-GEMM conv1d launches, ~60 % of the GPU time) against the dense
-    fp16 MFMA peak -- algorithmic FLOPs 2*B*T*cin*cout*k per launch over the launch durations measured with HIP events the
-    library records on the launch stream around every conv launch of every 4th timed step (mv_profile_enable);
-    ``roofline_fbank``: the Fbank kernel against the HBM roofline the same way (algorithmic bytes 287 360 B/utt,
-    BASELINE.md section 4); ``roofline_backbone``: the whole backbone stage (all kernels) against the MFMA peak;
+  * ``roofline``: the dominant kernel class (the implicit-GEMM conv launches) against the dense MFMA peak of its operand
+    type -- algorithmic FLOPs per launch over the launch durations measured with HIP events the library records on the
+    launch stream around every conv launch of every 4th timed step (mv_profile_enable);
+    ``roofline_fbank``: the front-end kernel against the HBM roofline the same way (algorithmic bytes 287 360 B/utt for
+    Fbank-80, SURVEY.md 8(d)); ``roofline_backbone``: the whole backbone stage (all kernels) against the MFMA peak;
     ``traffic`` = HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json), null without one,
-  * ``cpu_baseline``: the oracle (torch CPU fp32 port of the reference path) timed on a bounded sample on this
-    host's cores -- N=1 only, outside the timed region,
-  * ``parity``: max (1 - cos) between GPU and oracle embeddings on the first utterances of the batch.
+  * ``cpu_baseline`` (N=1): the oracle (torch CPU fp32 port of the reference path) timed on the whole batch on this host's
+    cores with autograd off ("best case"), and ``cpu_baseline_as_shipped``: a smaller sample with the autograd graph
+    recorded, as the reference's predictor runs (mvector/predict.py:228,262 never enter no_grad),
+  * ``parity``: max (1 - cos) between the GPU embeddings and the oracle embeddings over EVERY row of the batch,
+  * ``h2d_inclusive`` (N=1): the same step with the waveform batch uploaded from pinned host memory inside the timed
+    region (fp32, and int16 PCM converted on the device as ``predict_batch`` does),
+  * ``other_configs`` (N=1, default model only): the other single-GPU shares of BASELINE.json's configs -- CAM++ (config 3),
+    EcapaTdnn-512 + MelSpectrogram (config 4, per-GPU share) and the ~55 M ERes2NetV2 on a 1-10 s length-bucketed batch
+    (config 5, per-GPU share) -- each with its own label, throughput and parity.
 """
 import argparse
 import json
@@ -37,26 +43,28 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (the ERes2Net family computes on fp32 operands, csrc/conv2d.hip)
 SAMPLES = 48000              # 3 s @ 16 kHz
+FB80 = dict(sample_frequency=16000, num_mel_bins=80)
 
 MODELS = {
-    # name: (class, kwargs, feature method, method args, GFLOP/utt, BASELINE config label)
-    'ecapa1024': ('EcapaTdnn', dict(channels=[1024, 1024, 1024, 1024, 3072]), 'Fbank',
-                  dict(sample_frequency=16000, num_mel_bins=80), 11.175,
-                  'EcapaTdnn (c=1024) + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
-    'ecapa512': ('EcapaTdnn', dict(), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 3.090,
-                 'EcapaTdnn (c=512) + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
+    # name: (class, kwargs, feature method, method args, algorithmic GFLOP/utt at 3 s, label, BN gain)
+    'ecapa1024': ('EcapaTdnn', dict(channels=[1024, 1024, 1024, 1024, 3072]), 'Fbank', FB80, 11.175,
+                  'EcapaTdnn (c=1024) + Fbank-80, bs=256, 3 s@16 kHz synthetic', 1.0),
+    'ecapa512': ('EcapaTdnn', dict(), 'Fbank', FB80, 3.090, 'EcapaTdnn (c=512) + Fbank-80, bs=256, 3 s@16 kHz synthetic', 1.0),
     'ecapa512_mel': ('EcapaTdnn', dict(), 'MelSpectrogram', dict(), 2.559,
-                     'EcapaTdnn (c=512) + MelSpectrogram-128, bs=256, 3 s@16 kHz synthetic (BASELINE config 4, per-GPU share)'),
-    'eres2net': ('ERes2Net', dict(m_channels=32), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 10.083,
-                 'ERes2Net (m_channels=32, configs/eres2net.yml) + Fbank-80, 3 s@16 kHz synthetic'),
-    'eres2netv2': ('ERes2NetV2', dict(m_channels=32), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 6.242,
-                   'ERes2NetV2 (m_channels=32) + Fbank-80, 3 s@16 kHz synthetic'),
-    'campp': ('CAMPPlus', dict(embd_dim=192), 'Fbank', dict(sample_frequency=16000, num_mel_bins=80), 3.355,
-              'CAM++ + Fbank-80, bs=256, 3 s@16 kHz synthetic'),
+                     'EcapaTdnn (c=512) + MelSpectrogram-128, bs=256, 3 s@16 kHz synthetic (BASELINE config 4, per-GPU share)', 1.0),
+    'eres2net': ('ERes2Net', dict(m_channels=32), 'Fbank', FB80, 10.083,
+                 'ERes2Net (m_channels=32, configs/eres2net.yml) + Fbank-80, 3 s@16 kHz synthetic', 1.0),
+    'eres2netv2': ('ERes2NetV2', dict(m_channels=32), 'Fbank', FB80, 6.242,
+                   'ERes2NetV2 (m_channels=32) + Fbank-80, 3 s@16 kHz synthetic', 1.0),
+    # the README's "56 M" ERes2NetV2 has no shipped config: nearest constructor arguments, 54.9 M parameters (SURVEY.md 8(d)
+    # config 5); BatchNorm gain 0.7 keeps the seeded model well conditioned
+    'eres2netv2_w96s4': ('ERes2NetV2', dict(m_channels=96, base_width=26, scale=4), 'Fbank', FB80, None,
+                         'ERes2NetV2 (m_channels=96, base_width=26, scale=4: 54.9 M) + Fbank-80, 3 s@16 kHz synthetic', 0.7),
+    'campp': ('CAMPPlus', dict(embd_dim=192), 'Fbank', FB80, 3.355, 'CAM++ + Fbank-80, bs=256, 3 s@16 kHz synthetic', 1.0),
 }
 
 
-def randomise_bn(model, seed=1):
+def randomise_bn(model, seed=1, gain=1.0):
     """randomised BatchNorm statistics/affines (default BN is the identity)."""
     g = torch.Generator().manual_seed(seed)
     for m in model.modules():
@@ -65,8 +73,119 @@ def randomise_bn(model, seed=1):
             m.running_mean.copy_(torch.randn(n, generator=g) * 0.1)
             m.running_var.copy_(torch.rand(n, generator=g) + 0.5)
             if m.affine:
-                m.weight.data.copy_(torch.rand(n, generator=g) * 0.4 + 0.8)
+                m.weight.data.copy_((torch.rand(n, generator=g) * 0.4 + 0.8) * gain)
                 m.bias.data.copy_(torch.randn(n, generator=g) * 0.1)
+
+
+def build(name, dev):
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    import mvector.models as models
+    cls, kwargs, method, margs, gflop, label, gain = MODELS[name]
+    torch.manual_seed(0)
+    featurizer = AudioFeaturizer(method, method_args=margs)
+    model = getattr(models, cls)(input_size=featurizer.feature_dim, **kwargs)
+    randomise_bn(model, gain=gain)
+    model.eval()
+    state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+    return featurizer, model, state_cpu
+
+
+def metric_name(name, B):
+    cls, _, method, margs, _, _, _ = MODELS[name]
+    feat = 'Fbank-80' if method == 'Fbank' else f'MelSpectrogram-{margs.get("n_mels", 128)}'
+    return f'utterances/sec embedded (3 s@16 kHz, {feat}, {cls}, bs={B})'
+
+
+def frontend_bytes_per_utt(name, T):
+    _, _, method, margs, _, _, _ = MODELS[name]
+    F = margs.get('num_mel_bins', 23) if method == 'Fbank' else margs.get('n_mels', 128)
+    return SAMPLES * 4 + T * F * 4
+
+
+def oracle_embeddings(name, state_cpu, wav_cpu, chunk=32):
+    """oracle forward over the rows of wav_cpu in chunks of 32 (mvector/predict.py:261) -> (embeddings, seconds)"""
+    from oracle import frontend as ofe, models as om
+    cls, _, method, margs, _, _, _ = MODELS[name]
+    outs = []
+    t0 = time.perf_counter()
+    for i in range(0, wav_cpu.shape[0], chunk):
+        outs.append(om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(wav_cpu[i:i + chunk], None, method, margs)))
+    return torch.cat(outs), time.perf_counter() - t0
+
+
+def one_minus_cos(a, b):
+    return (1 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)).max().item()
+
+
+def short_run(name, dev, B, steps, warmup, parity_rows):
+    """throughput + parity of one of the other configurations (N=1, after the headline's timed region)"""
+    from mvector import _hip
+    featurizer, model, state_cpu = build(name, dev)
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn([B, SAMPLES], generator=g)).clamp(-1, 1).to(dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            emb = model(featurizer(wav))
+            _hip.cosine(emb, emb)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fb_ms = 0.0
+        for _ in range(steps):
+            e[0].record()
+            feats = featurizer(wav)
+            e[1].record()
+            emb = model(feats)
+            _hip.cosine(emb, emb)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fb_ms = e[0].elapsed_time(e[1])
+        ref, _ = oracle_embeddings(name, state_cpu, wav[:parity_rows].cpu())
+    T = feats.shape[1]
+    fb_gbs = B * frontend_bytes_per_utt(name, T) / (fb_ms * 1e-3) / 1e9
+    out = {'metric': metric_name(name, B), 'workload': MODELS[name][5], 'value': round(B * steps / dt, 1), 'unit': 'utterances/s',
+           'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'dtype': 'f32' if MODELS[name][0].startswith('ERes2Net') else 'f16',
+           'frontend_us': round(fb_ms * 1e3, 1), 'frontend_hbm_frac': round(fb_gbs / HBM_PEAK_GBS, 4),
+           'parity': {'max_one_minus_cos': one_minus_cos(emb[:parity_rows].cpu(), ref), 'utterances': parity_rows, 'tolerance': 1e-4}}
+    if MODELS[name][4]:
+        out['backbone_plus_frontend_tflops'] = round(B * MODELS[name][4] * steps / dt / 1e3, 1)
+    return out
+
+
+def bucketed_run(name, dev, n_utt, passes, parity_rows):
+    """BASELINE config 5 (per-GPU share): variable-length 1-10 s utterances, <= 8 length buckets (mvector.parallel.embed_bucketed)"""
+    from mvector import parallel
+    from oracle import frontend as ofe, models as om
+    featurizer, model, state_cpu = build(name, dev)
+    cls, _, method, margs, _, label, _ = MODELS[name]
+    g = torch.Generator().manual_seed(4321)
+    lens = torch.randint(16000, 160001, (n_utt,), generator=g).tolist()
+    waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1).to(dev) for n in lens]
+    emb = parallel.embed_bucketed(featurizer, model, waves, max_buckets=8, device=dev)  # warm-up: builds handle + workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        emb = parallel.embed_bucketed(featurizer, model, waves, max_buckets=8, device=dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # parity: the shortest bucket's first rows, with predict_batch semantics inside the bucket (padding to the bucket maximum)
+    idx = parallel.length_buckets(lens, 8)[0]
+    longest = max(lens[i] for i in idx)
+    rows = idx[:parity_rows]
+    padded = torch.zeros(len(idx), longest)
+    for r, i in enumerate(idx):
+        padded[r, :lens[i]] = waves[i].cpu()
+    ratio = torch.tensor([lens[i] / longest for i in idx], dtype=torch.float32)
+    with torch.no_grad():
+        ref = om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(padded[:len(rows)], ratio[:len(rows)], method, margs))
+    secs = sum(lens) / 16000.0
+    return {'metric': f'utterances/sec embedded (1-10 s@16 kHz length-bucketed, Fbank-80, {cls} 54.9 M, {n_utt} utterances)',
+            'workload': label.replace('3 s@16 kHz synthetic', f'{n_utt} utterances of 1-10 s (seeded uniform), 8 length buckets'),
+            'value': round(n_utt * passes / dt, 1), 'unit': 'utterances/s', 'audio_seconds_per_s': round(secs * passes / dt, 1),
+            'ms_per_pass': round(dt / passes * 1e3, 1), 'passes': passes, 'dtype': 'f32',
+            'parity': {'max_one_minus_cos': one_minus_cos(emb[torch.tensor(rows)].cpu(), ref), 'utterances': len(rows),
+                       'tolerance': 1e-4, 'rows': 'first rows of the shortest bucket'}}
 
 
 def main():
@@ -77,8 +196,9 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='utterances per GPU')
     ap.add_argument('--model', default='ecapa1024', choices=sorted(MODELS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the CAM++ / MelSpectrogram / bucketed ERes2NetV2 legs')
     ap.add_argument('--cpu-sample', type=int, default=256, help='utterances timed on the CPU oracle (~10-20 s of CPU work)')
-    ap.add_argument('--cpu-threads', type=int, default=32, help='torch CPU threads for the oracle baseline')
+    ap.add_argument('--cpu-threads', type=int, default=32, help='cap on the torch CPU threads of the oracle baseline')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -93,28 +213,20 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     from mvector import _hip
-    from mvector.data_utils.featurizer import AudioFeaturizer
-    import mvector.models as models
     _hip.lib()  # fail loudly if the HIP library is missing
 
-    cls, kwargs, method, margs, gflop_per_utt, label = MODELS[args.model]
-    torch.manual_seed(0)
-    featurizer = AudioFeaturizer(method, method_args=margs)
-    model = getattr(models, cls)(input_size=featurizer.feature_dim, **kwargs)
-    randomise_bn(model)
-    model.eval()
-    state_cpu = {k: v.clone() for k, v in model.state_dict().items()}
-    model.to(dev)
+    cls, kwargs, method, margs, gflop_per_utt, label, _ = MODELS[args.model]
+    featurizer, model, state_cpu = build(args.model, dev)
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn([B, SAMPLES], generator=g)).clamp(-1, 1).to(dev)
     gathered = torch.empty((world * B, model.embd_dim), dtype=torch.float32, device=dev)
 
-    def step(events=None):
+    def step(events=None, src=None):
         if events is not None:
             events[0].record()
-        feats = featurizer(wav)
+        feats = featurizer(wav if src is None else src)
         if events is not None:
             events[1].record()
         emb = model(feats)
@@ -130,14 +242,14 @@ def main():
         scores = _hip.cosine(emb, allemb)
         if events is not None:
             events[4].record()
-        return emb, scores
+        return emb, scores, feats.shape[1]
 
     cdll = _hip.lib()
     import ctypes
 
-    def prof_read(cls):
+    def prof_read(kcls):
         n, ms, work = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-        _hip.check(cdll.mv_profile_read(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work), 0), cdll)
+        _hip.check(cdll.mv_profile_read(kcls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work), 0), cdll)
         return n.value, ms.value, work.value
 
     with torch.no_grad():
@@ -149,10 +261,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            # HIP events around every conv1d / fbank launch of every 4th step of the timed region (two event records per
+            # HIP events around every conv / front-end launch of every 4th step of the timed region (two event records per
             # launch are not free on the host: CAM++ issues 108 conv launches per step)
             cdll.mv_profile_enable(1 if i % 4 == 0 else 0)
-            emb, scores = step(evs[i])
+            emb, scores, T = step(evs[i])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -170,8 +282,6 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fb_ms, bb_ms = stage_ms[0], stage_ms[1]
-        bb_tflops = B * gflop_per_utt / (bb_ms * 1e-3) / 1e3
-        # per-launch legs: algorithmic work / launch durations from the library's HIP events (launch stream, timed region)
         traffic = {}
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
@@ -190,58 +300,108 @@ def main():
         conv_tflops = flop_conv / (ms_conv * 1e-3) / 1e12 if ms_conv > 0 else 0.0
         fb_gbs = byte_fb / (ms_fb * 1e-3) / 1e9 if ms_fb > 0 else 0.0
         mfma_peak = MFMA_F32_PEAK_TFLOPS if f32_family else MFMA_F16_PEAK_TFLOPS
-        roof_conv = {'kernel': 'conv2d_kernel (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32), all launches, padded channel counts'
-                     if f32_family else
-                     'conv1d (implicit GEMM on MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel), all launches',
-                     'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+        conv_kernel = ('conv2d_kernel / conv2d_1x1_kernel (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32), all launches, '
+                       'algorithmic (unpadded) channel counts') if f32_family else \
+            'conv1d (implicit GEMM on fp16 MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel + conv1d_mfma_kernel), all launches'
+        roof_conv = {'kernel': conv_kernel, 'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
                      'frac': round(conv_tflops / mfma_peak, 4), 'traffic': pmc_bytes('mv::conv1d_glds_persistent_kernel'),
                      'launches': n_conv, 'avg_launch_us': round(ms_conv / max(n_conv, 1) * 1e3, 2),
                      'algorithmic_gflop_per_launch': round(flop_conv / max(n_conv, 1) / 1e9, 3),
                      'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3)}
-        roof_fbank = {'kernel': 'fbank_kernel', 'bound': 'hbm', 'achieved': round(fb_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                      'frac': round(fb_gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_bytes('mv::fbank_kernel'), 'launches': n_fb,
-                      'avg_launch_us': round(ms_fb / max(n_fb, 1) * 1e3, 2),
-                      'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1))}
+        fe_kernel = 'fbank_tile_kernel (Fbank-80 + CMN + mask, one launch)' if method == 'Fbank' else \
+            'melspec front-end (STFT power + HTK mel + CMN + mask)'
+        if n_fb > 0:
+            roof_fe = {'kernel': fe_kernel, 'bound': 'hbm', 'achieved': round(fb_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': round(fb_gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_bytes('mv::fbank_tile_kernel') or pmc_bytes('mv::fbank_kernel'),
+                       'launches': n_fb, 'avg_launch_us': round(ms_fb / max(n_fb, 1) * 1e3, 2),
+                       'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1))}
+        else:  # front-ends without a per-launch profile class: the stage time between events on the launch stream
+            fe_bytes = B * frontend_bytes_per_utt(args.model, T)
+            roof_fe = {'kernel': fe_kernel + ', stage time', 'bound': 'hbm', 'achieved': round(fe_bytes / (fb_ms * 1e-3) / 1e9, 1),
+                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(fe_bytes / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       'traffic': None, 'launches': None, 'avg_launch_us': round(fb_ms * 1e3, 2), 'algorithmic_bytes_per_launch': fe_bytes}
         out = {
-            'metric': f'utterances/sec embedded (3 s@16 kHz, Fbank-80, {cls}, bs={B})' if f32_family else
+            'metric': metric_name(args.model, B) if args.model != 'ecapa1024' else
             'utterances/sec embedded (3 s@16 kHz, Fbank-80, EcapaTdnn, bs=256)',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if f32_family else 'f16', 'data': 'synthetic',
             'config': {'workload': label, 'batch_per_gpu': B, 'global_batch': world * B, 'samples_per_utt': SAMPLES,
-                       'frames': 298, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
-            'stage_ms': {'fbank_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
+                       'frames': T, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
+            'stage_ms': {'frontend_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
                          'all_gather': round(stage_ms[2], 4), 'cosine': round(stage_ms[3], 4)},
             'roofline': roof_conv,
-            'roofline_fbank': roof_fbank,
-            'roofline_backbone': {'kernel': 'whole backbone stage (conv1d + res2 chain + SE + ASP + fc)', 'bound': 'mfma',
-                                  'achieved': round(bb_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
-                                  'frac': round(bb_tflops / mfma_peak, 4),
-                                  'algorithmic_gflop_per_utt': gflop_per_utt},
+            'roofline_fbank': roof_fe,
         }
+        if gflop_per_utt:
+            bb_tflops = B * gflop_per_utt / (bb_ms * 1e-3) / 1e3
+            bb_kernels = {'EcapaTdnn': 'conv1d + res2 chain + SE + ASP + fc', 'CAMPPlus': 'FCM conv2d + conv1d + CAM context + stats pool + dense',
+                          'TDNN': 'conv1d + ASP + linear'}.get(cls, 'conv2d + AFF + TSTP + seg_1')
+            out['roofline_backbone'] = {'kernel': f'whole {cls} backbone stage ({bb_kernels})', 'bound': 'mfma',
+                                        'achieved': round(bb_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                                        'frac': round(bb_tflops / mfma_peak, 4), 'algorithmic_gflop_per_utt': gflop_per_utt}
         if world == 1:
             # ---- parity gate + CPU baseline (oracle = test infrastructure; outside the timed region) ----
-            from oracle import frontend as ofe, models as om
-            n_par = min(4, B)
-            wav_cpu = wav[:n_par].cpu()
+            host_cores = os.cpu_count()
+            threads = min(host_cores, args.cpu_threads)
+            torch.set_num_threads(threads)
+            wav_cpu = wav.cpu()
+            n_par = B if not args.no_cpu_baseline else min(4, B)
             with torch.no_grad():
-                ref = om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(wav_cpu, None, method, margs))
-            cosd = (1 - torch.nn.functional.cosine_similarity(emb[:n_par].cpu().double(), ref.double(), dim=1)).max().item()
-            out['parity'] = {'max_one_minus_cos': cosd, 'utterances': n_par, 'tolerance': 1e-4}
+                oracle_embeddings(args.model, state_cpu, wav_cpu[:2])  # warm-up
+                n_cpu = max(1, min(args.cpu_sample, B)) if not args.no_cpu_baseline else n_par
+                ref, cpu_s = oracle_embeddings(args.model, state_cpu, wav_cpu[:max(n_cpu, n_par)])
+            out['parity'] = {'max_one_minus_cos': one_minus_cos(emb[:ref.shape[0]].cpu(), ref), 'utterances': int(ref.shape[0]),
+                             'tolerance': 1e-4}
             if not args.no_cpu_baseline:
-                # all host cores oversubscribe badly on the 256-thread GPU host (0.3 utt/s): cap the pool, report the count
-                torch.set_num_threads(min(os.cpu_count(), args.cpu_threads))
-                n_cpu = max(1, min(args.cpu_sample, B))
-                sample = wav[:n_cpu].cpu()
-                with torch.no_grad():
-                    om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(sample[:2], None, method, margs))  # warm-up
-                    tc = time.perf_counter()
-                    for i in range(0, n_cpu, 32):  # chunks of 32 as mvector/predict.py:261
-                        om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(sample[i:i + 32], None, method, margs))
-                    cpu_s = time.perf_counter() - tc
-                out['cpu_baseline'] = {'value': round(n_cpu / cpu_s, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
-                                       'kind': 'port', 'sample': f'{n_cpu} of the {B} synthetic utterances (same waveforms, same '
-                                       f'weights), oracle Fbank loop + oracle {cls} forward, torch CPU fp32, {cpu_s:.1f} s'}
+                note = (f'{host_cores} host threads visible; the pool is capped at {threads} (with all {host_cores} the oracle '
+                        f'oversubscribes to 0.3 utt/s on this host)')
+                out['cpu_baseline'] = {'value': round(ref.shape[0] / cpu_s, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
+                                       'host_cores': host_cores, 'kind': 'port', 'autograd': 'off (best case)', 'threads_note': note,
+                                       'sample': f'{ref.shape[0]} of the {B} synthetic utterances (same waveforms, same weights), '
+                                       f'oracle front-end loop + oracle {cls} forward in chunks of 32, torch CPU fp32, {cpu_s:.1f} s'}
+                # as shipped: the reference's predictor leaves autograd on, so every forward also records its graph
+                n_sh = min(64, B)
+                state_grad = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state_cpu.items()}
+                _, sh_s = oracle_embeddings(args.model, state_grad, wav_cpu[:n_sh])
+                out['cpu_baseline_as_shipped'] = {'value': round(n_sh / sh_s, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
+                                                  'host_cores': host_cores, 'kind': 'port', 'autograd': 'on, as mvector/predict.py:228,262',
+                                                  'sample': f'{n_sh} utterances, {sh_s:.1f} s'}
+                del state_grad
+            # ---- the same step with the upload inside the timed region ----
+            host_f32 = wav_cpu.pin_memory()
+            host_i16 = (wav_cpu * 32768.0).round().clamp(-32768, 32767).to(torch.int16).pin_memory()
+            k = max(4, args.steps // 2)
+            with torch.no_grad():
+                res = {}
+                for tag in ('fp32', 'int16'):
+                    for it in range(k + 2):
+                        if it == 2:
+                            torch.cuda.synchronize()
+                            th = time.perf_counter()
+                        if tag == 'fp32':
+                            src = host_f32.to(dev, non_blocking=True)
+                        else:
+                            src, _ = _hip.wave_prepare(host_i16.to(dev, non_blocking=True))
+                        e2, _, _ = step(None, src)
+                        e2.cpu()  # D2H of the embeddings, as predict_batch returns numpy
+                    torch.cuda.synchronize()
+                    res[tag] = B * k / (time.perf_counter() - th)
+            out['h2d_inclusive'] = {'value_fp32_upload': round(res['fp32'], 1), 'value_int16_upload': round(res['int16'], 1),
+                                    'unit': 'utterances/s', 'steps': k,
+                                    'note': 'waveforms uploaded from pinned host memory and embeddings copied back inside the timed '
+                                    'region; int16 = 16-bit PCM converted on the device (predict_batch path); never the headline value'}
+            if args.model == 'ecapa1024' and not args.no_other_configs:
+                others = {}
+                for key, fn in (('config3_campp', lambda: short_run('campp', dev, B, 10, 3, 8)),
+                                ('config4_share_ecapa512_mel', lambda: short_run('ecapa512_mel', dev, B, 10, 3, 8)),
+                                ('config5_share_eres2netv2_bucketed', lambda: bucketed_run('eres2netv2_w96s4', dev, 64, 2, 2))):
+                    try:
+                        others[key] = fn()
+                    except Exception as ex:  # a failing side leg must not take the headline line with it
+                        others[key] = {'error': f'{type(ex).__name__}: {ex}'}
+                    torch.cuda.empty_cache()
+                out['other_configs'] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

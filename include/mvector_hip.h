@@ -233,6 +233,7 @@ typedef struct MvConv2dDesc {
     int64_t ldy;
     int32_t B, H, W, cin16, cout16, ks, stride, epi;
     float lo, hi;
+    int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
 } MvConv2dDesc;
 int mv_conv2d_forward(const MvConv2dDesc* d, mv_stream_t stream);
 /* first ERes2Net conv: features fp32 [B, T, F] -> fp32 [B, F, T, C] = relu(conv3x3(1 -> C) + bias), w fp32 [C][9] */
@@ -310,7 +311,7 @@ int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C
  * bytes (MV_PROF_FBANK: B*(4*L + 4*T*num_mel_bins) per launch).  mv_profile_read waits for the recorded launches. */
 #define MV_PROF_CONV1D 0
 #define MV_PROF_FBANK 1
-#define MV_PROF_CONV2D 2 /* work = 2*B*Ho*Wo*cin16*cout16*ks*ks FLOPs on the padded channel counts */
+#define MV_PROF_CONV2D 2 /* work = 2*B*Ho*Wo*cin*cout*ks*ks FLOPs on the layer's own (unpadded) channel counts */
 int mv_profile_enable(int32_t on);
 int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, double* total_work, int32_t reset);
 

@@ -177,3 +177,15 @@ def test_emu_fbank_odd_window_length():
     args = dict(sample_frequency=11025, num_mel_bins=40)  # 275-sample window (odd), 110-sample shift
     w = frontend.synth_waveforms(2, 3000, seed=21)
     lc.fbank_case(emu_cdll(), 'cpu', w, None, args)
+
+
+def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypatch):
+    """80 bins run fbank_tile_kernel: feature block in LDS up to 298 frames (3 s), second pass over global memory beyond
+    that (311 frames here); MV_FBANK_IMPL=generic keeps fbank_kernel for the same geometry.  All three against the oracle."""
+    wav = frontend.synth_waveforms(2, 400 + 160 * 310, seed=23)
+    ratio = torch.tensor([0.83, 1.0])
+    lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)              # tile kernel, no LDS block (T = 311)
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:, :48000], ratio, FB)   # tile kernel, LDS block at its largest (T = 298)
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :48160], None, FB)   # one frame more: back to the global second pass
+    monkeypatch.setenv('MV_FBANK_IMPL', 'generic')
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-2 GPU session: DPP probe, parity tests, Fbank A/B (tile kernel vs generic kernel), bench (headline + other configs),
+# rocprof kernel stats, PMC passes.  usage (repo root on the GPU box): bash tools/gpu_round2.sh <tag> [skip-pmc]
+TAG=${1:-r03a}
+REPO=$(cd $(dirname $0)/.. && pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+cd $REPO
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8 > $OUT/rocminfo.txt 2>&1; nproc >> $OUT/rocminfo.txt
+[ -x tools/probe/dpp_probe ] && tools/probe/dpp_probe > $OUT/dpp_probe.log 2>&1; cat $OUT/dpp_probe.log
+echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -rA -p no:cacheprovider -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+grep -E "passed|failed|Error|FAILED" $OUT/pytest_gpu.log | tail -15
+echo "== fbank A/B"
+for impl in tile generic; do MV_FBANK_IMPL=$impl timeout 300 python tools/bench_fbank.py >> $OUT/fbank_ab.log 2>&1; done
+for impl in tile generic; do MV_FBANK_IMPL=$impl timeout 300 python tools/bench_fbank.py >> $OUT/fbank_ab.log 2>&1; done
+MV_FBANK_IMPL=tile timeout 300 python tools/bench_fbank.py 256 160000 >> $OUT/fbank_ab.log 2>&1
+MV_FBANK_IMPL=generic timeout 300 python tools/bench_fbank.py 256 160000 >> $OUT/fbank_ab.log 2>&1
+cat $OUT/fbank_ab.log
+echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
+echo "== bench"; timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
+tail -2 $OUT/bench.log | cut -c1-3000
+echo "== rocprof"
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/rocprof.log
+for f in $(find $OUT/prof -name "*kernel_stats*.csv"); do head -25 $f; done
+cd $REPO
+if [ -z "$2" ]; then echo "== pmc"; bash tools/gpu_pmc.sh $TAG/pmc; fi

@@ -17,6 +17,16 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG']
 
 
+def _file_flags(path):
+    """extra hipcc flags a source asks for in a line `// hipcc-flags: ...` (e.g. fbank.hip keeps the SLP vectoriser from
+    re-packing scalar fp32 code into v_pk_* ops that need register shuffles)"""
+    with open(path) as f:
+        for line in f:
+            if line.startswith('// hipcc-flags:'):
+                return line.split(':', 1)[1].split()
+    return []
+
+
 def _digest(paths):
     h = hashlib.sha1(' '.join(FLAGS).encode())
     for p in paths:
@@ -39,7 +49,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == want:
             continue
-        cmd = [HIPCC] + FLAGS + ['-x', 'hip', '-c', s, '-o', o]
+        cmd = [HIPCC] + FLAGS + _file_flags(s) + ['-x', 'hip', '-c', s, '-o', o]
         procs.append((s, cmd, stamp, want, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     rebuilt = False
     for s, cmd, stamp, want, p in procs:

@@ -66,6 +66,9 @@ inline float dpp_mov(float old, float src) {
     bool has = true;
     if (CTRL < 0x100) {
         from = (lane & ~3) | ((CTRL >> (2 * (lane & 3))) & 3);
+    } else if (CTRL > 0x100 && CTRL < 0x110) {  // row_shl:n -- lane i reads lane i + n of its row
+        has = (lane & 15) + (CTRL - 0x100) <= 15;
+        from = has ? lane + (CTRL - 0x100) : lane;
     } else if (CTRL > 0x110 && CTRL < 0x120) {
         has = (lane & 15) >= (CTRL - 0x110);
         from = has ? lane - (CTRL - 0x110) : lane;
@@ -86,6 +89,26 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
                                                                  0xf, 0xf, false));
 }
 #endif
+
+// 8-byte LDS load that the load/store merger leaves alone (volatile, with the LDS address space stated: a volatile access
+// through a generic pointer would become a flat load)
+__device__ __forceinline__ float2v lds_load_unmerged(const float2v* p) {
+#ifdef MV_EMU
+    return *p;
+#else
+    return *(const volatile __attribute__((address_space(3))) float2v*)(p);
+#endif
+}
+
+// DPP move for patterns in which every lane has a source lane (mirror, rotate, quad_perm): no `old` operand to initialise
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_all(float src) {
+#ifdef MV_EMU
+    return dpp_mov<CTRL>(src, src);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+#endif
+}
 
 // v_permlane16_swap (gfx950): the odd 16-lane rows of x trade places with the even rows of y
 //   x: row1 <- y.row0, row3 <- y.row2      y: row0 <- x.row1, row2 <- x.row3      (checked on the device: tools/permlane_probe.hip)

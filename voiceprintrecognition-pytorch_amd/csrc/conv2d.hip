@@ -350,7 +350,8 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
             return fail(MV_ERR_HIP, "conv2d: cannot reserve dynamic LDS");
         smem_set = true;
     }
-    const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)d.cin16 * d.cout16 * d.ks * d.ks, stream);
+    const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
+                                                (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
     if (d.ks == 1) {
         switch (nb) {
             case 8: MV_LAUNCH(conv2d_1x1_kernel<8>, (grid.x, grid.y, 1), (256, 1, 1), 0, stream, a); break;

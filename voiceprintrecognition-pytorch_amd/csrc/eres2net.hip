@@ -23,6 +23,7 @@ struct C2Layer {
     float* w = nullptr;
     float* bias = nullptr;
     int cin16 = 0, cout16 = 0, ks = 1, stride = 1;
+    int cin = 0, cout = 0;  // the layer's own channel counts (algorithmic FLOP accounting)
 };
 
 struct AffLayer {  // AFF (eres2net.py:32-52) on `ch` channels (padded chp per operand)
@@ -89,6 +90,8 @@ struct Eres2Model : MvModelBase {
         MV_HIP_OK(hipMemcpy(L->w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         L->cin16 = cin16;
         L->cout16 = cout16;
+        L->cin = cin;
+        L->cout = cout;
         L->ks = ks;
         L->stride = stride;
         return MV_OK;
@@ -297,6 +300,7 @@ struct Eres2Model : MvModelBase {
         d.w = L.w; d.bias = L.bias; d.res = res; d.res2 = res2; d.ldres = ldres; d.ldres2 = ldres2;
         d.y = y; d.ldy = ldy; d.B = B; d.H = H; d.W = W; d.cin16 = L.cin16; d.cout16 = L.cout16; d.ks = L.ks; d.stride = L.stride;
         d.epi = epi; d.lo = lo; d.hi = hi;
+        d.cin_alg = L.cin; d.cout_alg = L.cout;
         return conv2d_launch(d, st);
     }
 

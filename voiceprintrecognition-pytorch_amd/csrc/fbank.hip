@@ -21,6 +21,11 @@
 //            frame, so the log, the column sums for CMN and 256-byte row stores need no further shuffles.
 // One workgroup owns one utterance, so the per-utterance time mean is a workgroup reduction and the
 // second pass (subtract mean, apply the length mask) re-reads rows this CU has just written (L2 hits).
+//
+// hipcc-flags: -fno-slp-vectorize -fno-signed-zeros
+//   (complex math is written on float2 vectors where packed ops pay; the SLP pass would additionally pair up scalar chains
+//    -- DC sums, pre-emphasis, the paired post-processing -- at the price of two v_mov per packed op; without signed zeros
+//    the zero-padded inputs of the first FFT stage fold away)
 #include "common.h"
 
 #include <cstdlib>
@@ -108,6 +113,7 @@ constexpr int FB_MAX_PASSES = 2;      // 16 blocks x 4 filters per MFMA pass: nu
 
 struct FbankTables {
     const float* window;    // [512] window, zero beyond the frame length
+    const float* window_half;  // [512] 0.5 * window (fbank_tile_kernel: Z comes out halved, so |2X|^2 / 4 needs no scaling)
     const float* tw256;     // [16 k1][16 n2][2] cos, sin of 2 pi n2 k1 / 256 (lane-contiguous)
     const float* tw512;     // [256][2] cos, sin of 2 pi k / 512
     const float* melb;      // [steps/4][64 lanes][4] mel weights in MFMA B-operand order, passes back to back
@@ -131,6 +137,7 @@ struct FbankArgs {
     float inv_win;
     int remove_dc, use_power, use_log, cmn;
     int64_t L;
+    int tile_in_lds;  // fbank_tile_kernel: the utterance's [T, nbins] block stays in LDS until the time mean is known
     FbankTables tab;
 };
 
@@ -458,6 +465,314 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fbank_tile_kernel: the same arithmetic with the issue slots and LDS cycles cut to what the algorithm needs.
+//
+// Measured on the kernel above (profiles/r01m, r01n, r02h): VALU 39 % busy, LDS 30 %, waves 53 % parked, 1.62 x the
+// algorithmic HBM traffic (the CMN pass re-reads and rewrites the features).  Per wave iteration (4 frames) it issues
+// ~1280 VALU lane-ops and ~690 LDS cycles; one LDS cycle is shared by the CU's four SIMDs, so an LDS cycle costs as
+// much machine time as two VALU ops.  This kernel (same frame -> 16-lane mapping, 8 waves of <= 256 VGPRs):
+//   * every per-lane constant lives in registers for the whole utterance: window taps, stage twiddles, post-processing
+//     twiddles and the mel weights in MFMA operand order (no table reads in the loop);
+//   * real-FFT post-processing in PAIRS (k, 256 - k): both bins come from the same two values Z[k], Z[256-k]; a lane
+//     owns 8 pairs instead of 16 single bins.  The partner value sits in lane 16 - k1 of the same 16-lane row: two DPP
+//     moves (row_mirror, then row_shr:1 whose lane 0 keeps `old` = its own register, exactly what k1 = 0 needs) -- no
+//     LDS exchange.  The window is pre-scaled by 1/2, so |2X|^2 / 4 = |2 X_half|^2 needs no scaling;
+//   * one LDS transpose per frame, in a layout shared by the wave's four frames: row k1 = 64 elements [frame][n2] + one
+//     pad -> lane-linear conflict-free writes, conflict-free reads, one address register each way;
+//   * the [T, nbins] log-mel block of the utterance stays in LDS (95 KB for 3 s x 80 bins) until the time mean is
+//     known: features are written to HBM once (algorithmic traffic), not written, re-read and rewritten.  Longer
+//     utterances fall back to the second pass over global memory inside the same kernel.
+// Instantiated for the mel geometry of the reference configurations (80 bins, 16 kHz, 512-point FFT: passes of 7 and 11
+// four-bin groups); any other geometry runs fbank_kernel above.
+constexpr int FBT_WAVES = 8;
+constexpr int FBT_ROW = 65;                      // complex elements per transpose row: [4 frames][16] + 1 pad
+constexpr int FBT_SLOT_FLOATS = 16 * FBT_ROW * 2;  // 2080 floats = 8320 B per wave
+constexpr int FBT_WIN_FLOATS = 448;              // window taps kept in LDS (the taps the 13 / 14 sample groups of a <= 448-sample window touch)
+constexpr int FBT_PSTR = 292;                    // floats between the power rows of the wave's four frames (36 banks apart)
+
+// One ds_read_b64 per element: pairs of them would be merged into ds_read2_b64, which moves 128 B per LDS clock where
+// ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS table); a volatile access is left alone by the merger.
+__device__ __forceinline__ cplx lds_read_single(const cplx* p) { return lds_load_unmerged(p); }
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
+
+template <int NG, bool VEC2, int G0, int G1>
+__global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a) {
+    constexpr int THREADS = FBT_WAVES * 64;
+    MV_DYN_SMEM(smem);
+    float* xbuf = reinterpret_cast<float*>(smem);                  // [FBT_WAVES][FBT_SLOT_FLOATS]
+    float* lwin = xbuf + FBT_WAVES * FBT_SLOT_FLOATS;              // [FBT_WIN_FLOATS] 0.5 * window
+    float* tile = lwin + FBT_WIN_FLOATS;                           // [T][nbins] when a.tile_in_lds
+    float* colsum = xbuf;                                          // [FBT_WAVES][128] then mean[128], after the frame loop
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l16 = lane & 15;
+    const int fs = lane >> 4;
+    const int b = blockIdx.x;
+    const int Tout = a.T;
+    int T = a.T;
+    if (a.num_samples != nullptr) {
+        const int64_t ns = a.num_samples[b];
+        const int64_t tb = ns < a.win ? 0 : 1 + (ns - a.win) / a.shift;
+        T = (int)(tb < a.T ? tb : a.T);
+    }
+    const int nbins = a.nbins;
+
+    // ---- per-lane constants (registers) ----
+    for (int i = tid; i < FBT_WIN_FLOATS; i += THREADS) lwin[i] = a.tab.window_half[i];
+    const float* cwin = lwin + 2 * l16;  // 0.5 * window at samples 32 n1 + 2 l16 (+1): one 8-byte LDS read per group
+    float2v ctw1[16];       // W256^(l16 k1) as (cos, sin), k1 = 1..15
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) ctw1[k1] = *reinterpret_cast<const float2v*>(a.tab.tw256 + 2 * (k1 * 16 + l16));
+    float2v ctw2[8];        // (cos, sin) of pi k / 256 at k = l16 + 16 j
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ctw2[j] = *reinterpret_cast<const float2v*>(a.tab.tw512 + 2 * (l16 + 16 * j));
+    float4v mb0[G0], mb1[G1];  // mel weights of this lane's (block, filter): 4 bins per group
+#pragma unroll
+    for (int g = 0; g < G0; ++g) mb0[g] = *reinterpret_cast<const float4v*>(a.tab.melb + (size_t)g * 256 + lane * 4);
+#pragma unroll
+    for (int g = 0; g < G1; ++g) mb1[g] = *reinterpret_cast<const float4v*>(a.tab.melb + (size_t)(G0 + g) * 256 + lane * 4);
+
+    float* wslot = xbuf + wave * FBT_SLOT_FLOATS;
+    cplx* tw_write = reinterpret_cast<cplx*>(wslot) + lane;                       // element (k1, frame fs, n2 = l16) at + k1 * FBT_ROW
+    const cplx* tw_read = reinterpret_cast<const cplx*>(wslot) + l16 * FBT_ROW + 16 * fs;  // element (k1 = l16, fs, n2) at + n2
+    float* prow = wslot + fs * FBT_PSTR;                                          // power row of this lane's frame
+    float* p_own = prow + l16;                                                    // bin l16 + 16 j at + 16 j
+    float* p_par = prow + (16 - l16);                                             // bin 256 - k = (16 - l16) + 16 (15 - j) at + 16 (15 - j)
+    // lane 0 of a row: its j = 0 partner slot would be the Nyquist bin (zero mel weight); it stores bin 128 there instead
+    float* p_par0 = l16 == 0 ? prow + 128 - 240 : p_par;
+    const float* wrow = a.wav + (int64_t)b * a.wav_stride;
+    float* orow = a.out + (int64_t)b * Tout * nbins;
+
+    // mel stage: lane = (block = lane / 4, i = lane % 4): A operand = power of frame i, D = 4 frames x filter
+    const float* arow = wslot + (lane & 3) * FBT_PSTR;
+    const float* ap0 = arow + a.tab.pass_start[0][lane >> 2];
+    const float* ap1 = arow + a.tab.pass_start[1][lane >> 2];
+    const int blk = lane >> 2;
+    const int split1 = a.tab.pass_split[1];
+    const int m0 = 4 * (a.tab.pass_gbase[0] + blk) + (lane & 3);                // pass 0: one block per filter group
+    const int m1 = 4 * (a.tab.pass_gbase[1] + blk / split1) + (lane & 3);
+    const bool own0 = m0 < nbins, own1 = m1 < nbins && (blk & (split1 - 1)) == 0;
+    float csum0 = 0.0f, csum1 = 0.0f;
+    const bool use_tile = a.tile_in_lds != 0;
+
+    __syncthreads();  // window taps
+    const int nquads = (T + 3) >> 2;
+    for (int q = wave; q < nquads; q += FBT_WAVES) {
+        const int f_raw = q * 4 + fs;
+        const int f = f_raw < T ? f_raw : T - 1;  // surplus slots recompute the last frame; nothing of theirs is kept
+        const float* fp = wrow + (int64_t)f * a.shift;
+        cplx e[NG];
+        float eprev[NG];
+#pragma unroll
+        for (int n1 = 0; n1 < NG; ++n1) {
+            const int idx = 32 * n1 + 2 * l16;
+            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            if (full) {
+                if (VEC2) {
+                    e[n1] = *reinterpret_cast<const float2v*>(fp + idx);
+                } else {
+                    e[n1] = cmake(fp[idx], fp[idx + 1]);
+                }
+                eprev[n1] = fp[n1 == 0 ? (idx > 0 ? idx - 1 : 0) : idx - 1];
+            } else {
+                const int i0 = idx < a.win ? idx : a.win - 1, i1 = idx + 1 < a.win ? idx + 1 : a.win - 1;
+                cplx v;
+                if (VEC2) {
+                    v = *reinterpret_cast<const float2v*>(fp + (idx < a.win ? idx : a.win - 2));
+                } else {
+                    v = cmake(fp[i0], fp[i1]);
+                }
+                e[n1] = cmake(idx < a.win ? v[0] : 0.0f, idx + 1 < a.win ? v[1] : 0.0f);
+                eprev[n1] = fp[i0 > 0 ? i0 - 1 : 0];
+            }
+        }
+        // ---- DC removal, pre-emphasis, window (see fbank_kernel) ----
+        float dc = 0.0f;
+        if (a.remove_dc) {
+            float s0 = 0.0f, s1 = 0.0f;  // scalar: the 12-byte loads leave (x[j], x[j+1]) on odd register pairs
+#pragma unroll
+            for (int n1 = 0; n1 < NG; ++n1) {
+                s0 += e[n1][0];
+                s1 += e[n1][1];
+            }
+            dc = row16_sum(s0 + s1) * a.inv_win * (1.0f - a.preemph);
+        }
+        cplx z[16];
+        const float npre = -a.preemph;
+#pragma unroll
+        for (int n1 = 0; n1 < NG; ++n1) {  // scalar on purpose: pairing (x[j-1], x[j]) for a packed op would cost two moves
+            const float2v w2 = lds_load_unmerged(reinterpret_cast<const float2v*>(cwin + 32 * n1));
+            const float y0 = fmaf(npre, eprev[n1], e[n1][0]) - dc;
+            const float y1 = fmaf(npre, e[n1][0], e[n1][1]) - dc;
+            z[n1] = cmake(y0 * w2[0], y1 * w2[1]);
+        }
+#pragma unroll
+        for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
+        // ---- stage 1 + twiddle ----
+        fft16(z);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul_conjtw(z[k1], ctw1[k1][0], ctw1[k1][1]);
+        // ---- the one transpose ----
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) tw_write[k1 * FBT_ROW] = z[k1];
+        MV_WAVE_FENCE();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_read_single(tw_read + n2);
+        MV_WAVE_FENCE();
+        // ---- stage 2 -> z[k2] = Z[l16 + 16 k2] (halved) ----
+        fft16(z);
+        // ---- paired real-input post-processing ----
+        //   A = Z[k], B = Z[256-k], w = exp(-i pi k / 256):  za = A + conj B, zb = A - conj B, r = w zb,
+        //   2X[k] = za - i r,  2X[256-k] = conj(za) - i conj(r)
+        float pk[8], pp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const cplx own_alt = z[(16 - j) & 15];  // lane 0 (k1 = 0): partner Z[16 (16 - j)] is its own register; j = 0: Z[256] = Z[0]
+            const cplx src = z[15 - j];
+            cplx bp;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float t = dpp_mov_all<DPP_ROW_MIRROR>(src[c]);
+                bp[c] = dpp_mov<DPP_ROW_SHR1>(own_alt[c], t);
+            }
+            const cplx av = z[j];
+            const float zar = av[0] + bp[0], zai = av[1] - bp[1];
+            const float zbr = av[0] - bp[0], zbi = av[1] + bp[1];
+            const float c = ctw2[j][0], s = ctw2[j][1];      // w = c - i s
+            const float rr = zbr * c + zbi * s, ri = zbi * c - zbr * s;
+            const float u1 = zar + ri, u2 = zai - rr;        // 2X[k]
+            const float v1 = zar - ri, v2 = zai + rr;        // conj of 2X[256-k]
+            pk[j] = u1 * u1 + u2 * u2;
+            pp[j] = v1 * v1 + v2 * v2;
+        }
+        {   // bin 128 = conj(Z[128]) lives in lane 0's register 8; it takes the slot of lane 0's (unused) Nyquist output
+            const float p128 = z[8][0] * z[8][0] + z[8][1] * z[8][1];
+            pp[0] = l16 == 0 ? p128 : pp[0];
+        }
+        // (the transposed values were all read before the FFT: the power rows may overwrite them)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p_own[16 * j] = pk[j];
+        p_par0[16 * 15] = pp[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) p_par[16 * (15 - j)] = pp[j];
+        MV_WAVE_FENCE();
+        // ---- mel filters on the matrix pipe (weights in registers) ----
+        // four independent accumulator chains per pass (the matrix pipe never waits for its own result), each started
+        // from the constant zero operand
+        const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        float4v acc0[4], acc1[4];
+#pragma unroll
+        for (int g = 0; g < G0; ++g) {
+            const float4v av = *reinterpret_cast<const float4v*>(ap0 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc0[c] = fb_mfma4(av[c], mb0[g][c], g == 0 ? zero4 : acc0[c]);
+        }
+#pragma unroll
+        for (int g = 0; g < G1; ++g) {
+            const float4v av = *reinterpret_cast<const float4v*>(ap1 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc1[c] = fb_mfma4(av[c], mb1[g][c], g == 0 ? zero4 : acc1[c]);
+        }
+        const float4v a0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
+        float4v a1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
+        MV_WAVE_FENCE();  // the power rows are consumed: the next quad's transpose may overwrite them
+        // pass 1: `split1` adjacent blocks hold partial sums of one filter group over disjoint bin ranges; the first of
+        // them collects the others (lanes 4 / 8 / 12 further up in the same 16-lane row)
+        if (split1 >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[r] += dpp_mov<DPP_ROW_SHL4>(0.0f, a1[r]);
+        }
+        if (split1 == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[r] += dpp_mov<DPP_ROW_SHL8>(0.0f, a1[r]);
+        }
+        const int frames_here = (q * 4 + 4 <= T) ? 4 : T - q * 4;
+        float v0[4], v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v0[r] = fb_log2(fmaxf(a0[r], 1.1920928955078125e-07f)) * 0.69314718055994531f;
+            v1[r] = fb_log2(fmaxf(a1[r], 1.1920928955078125e-07f)) * 0.69314718055994531f;
+        }
+        if (frames_here < 4) {  // last quad of the utterance: surplus frames are neither summed nor kept
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                if (r >= frames_here) {
+                    v0[r] = 0.0f;
+                    v1[r] = 0.0f;
+                }
+            }
+        }
+        csum0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+        csum1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        const int row0 = q * 4 * nbins;
+        if (use_tile) {  // uniform: LDS block [t][m] (rows beyond T exist in the block whenever T is not a multiple of 4? no:
+                         // the block has T rows; surplus rows are skipped below)
+            float* d0 = tile + row0 + m0;
+            float* d1 = tile + row0 + m1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < frames_here) {
+                    if (own0) d0[r * nbins] = v0[r];
+                    if (own1) d1[r * nbins] = v1[r];
+                }
+            }
+        } else {
+            float* d0 = orow + row0 + m0;
+            float* d1 = orow + row0 + m1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < frames_here) {
+                    if (own0) d0[r * nbins] = v0[r];
+                    if (own1) d1[r * nbins] = v1[r];
+                }
+            }
+        }
+    }
+
+    const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;
+    if (!second_pass && !use_tile) return;
+
+    // ---- per-utterance time mean (featurizer.py:79) ----
+    __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
+    if (own0) colsum[wave * 128 + m0] = csum0;   // (lanes that own no filter summed values nobody reads)
+    if (own1) colsum[wave * 128 + m1] = csum1;
+    __syncthreads();
+    float* mean = colsum + FBT_WAVES * 128;
+    if (tid < 128) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < FBT_WAVES; ++w) v += colsum[w * 128 + tid];
+        mean[tid] = (a.cmn && T > 0 && tid < nbins) ? v / (float)T : 0.0f;
+    }
+    __syncthreads();  // also orders this workgroup's stores (LDS block / global rows) before the reads below
+    // ---- subtract the mean, apply the length mask, write the features (once, when the block sat in LDS) ----
+    int mask_len = T;
+    if (a.lens_ratio != nullptr) mask_len = (int)rintf(a.lens_ratio[b] * (float)T);  // round half to even
+    const int qn = nbins >> 2;              // float4 groups per row (nbins % 4 == 0 for this kernel)
+    const int rows_per_pass = THREADS / qn;
+    const int r0 = tid / qn, cg = tid - r0 * qn;
+    if (r0 < rows_per_pass) {
+        const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
+        const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if (use_tile) {
+            for (int t = r0; t < Tout; t += rows_per_pass) {  // rows T..Tout-1 of a shorter utterance become zeros
+                const float4v raw = t < T ? *(reinterpret_cast<const float4v*>(tile + t * nbins) + cg) : zero4;
+                *(reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg) = t < mask_len ? raw - m4 : zero4;
+            }
+        } else {
+            for (int t = r0; t < Tout; t += rows_per_pass) {
+                float4v* p = reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg;
+                const float4v raw = t < T ? *p : zero4;
+                *p = t < mask_len ? raw - m4 : zero4;
+            }
+        }
+    }
+}
+
 }  // namespace mv
 
 // ------------------------------------------------------------------------------------------ host side
@@ -466,12 +781,14 @@ struct MvFbank {
     MvFbankCfg cfg;
     int win, shift, nbins;
     float* d_window = nullptr;
+    float* d_window_half = nullptr;
     float* d_tw256 = nullptr;
     float* d_tw512 = nullptr;
     float* d_melb = nullptr;
     mv::FbankTables tab;
     size_t smem_bytes = 0;
-    int waves = 15;  // workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
+    int waves = 15;  // fbank_kernel: workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
+    bool tile_kernel = false;  // the mel geometry matches an instantiation of fbank_tile_kernel (MV_FBANK_IMPL=generic turns it off)
 };
 
 namespace {
@@ -544,6 +861,41 @@ void fbank_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, in
     return fbank_launch_v<16, false>(B, smem, st, a, waves);
 }
 
+// fbank_tile_kernel is instantiated for the mel geometry of the reference configurations: 80 bins at 16 kHz on a 512-point
+// FFT = a pass of 16 filter groups (7 four-bin steps) and a pass of 4 groups spread over all blocks (11 steps)
+constexpr int FBT_G0 = 7, FBT_G1 = 11;
+
+static bool fbank_tile_geometry_ok(const MvFbank* h) {
+    const mv::FbankTables& t = h->tab;
+    return t.passes == 2 && t.pass_steps[0] == 4 * FBT_G0 && t.pass_steps[1] == 4 * FBT_G1 && t.pass_split[0] == 1 &&
+           (h->nbins & 3) == 0 && h->nbins <= 128 && h->win <= mv::FBT_WIN_FLOATS && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
+}
+
+static size_t fbank_tile_lds_bytes(int T, int nbins, bool tile) {
+    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::FBT_WIN_FLOATS + (tile ? (size_t)T * nbins : 0)) * sizeof(float);
+}
+
+template <int NG, bool V>
+static hipError_t fbank_tile_set_smem() {
+    return MV_SET_MAX_SMEM((mv::fbank_tile_kernel<NG, V, FBT_G0, FBT_G1>), 160 * 1024);
+}
+
+static void fbank_tile_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, bool vec2) {
+    const bool ng13 = a.win > 12 * 32 && a.win <= 13 * 32;
+    const dim3 grid(B, 1, 1), block(mv::FBT_WAVES * 64, 1, 1);
+    if (ng13 && vec2) {
+        MV_LAUNCH((mv::fbank_tile_kernel<13, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+    } else if (ng13) {
+        MV_LAUNCH((mv::fbank_tile_kernel<13, false, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+    } else if (vec2) {
+        MV_LAUNCH((mv::fbank_tile_kernel<16, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+    } else {
+        MV_LAUNCH((mv::fbank_tile_kernel<16, false, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+    }
+    (void)grid;
+    (void)block;
+}
+
 extern "C" {
 
 void mv_fbank_default_cfg(MvFbankCfg* cfg) {
@@ -578,11 +930,12 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     h->nbins = cfg->num_mel_bins;
 
     const double pi = 3.14159265358979323846;
-    std::vector<float> window(512, 0.0f), tw256(512), tw512(512);
+    std::vector<float> window(512, 0.0f), window_half(512, 0.0f), tw256(512), tw512(512);
     for (int i = 0; i < win; ++i) {
         // povey: hann(win, periodic=False) ** 0.85
         const double hann = 0.5 - 0.5 * cos(2.0 * pi * i / (win - 1));
         window[i] = (float)pow(hann, 0.85);
+        window_half[i] = 0.5f * window[i];  // exact: the halved spectrum squares to |X|^2 without a final scale
     }
     for (int m = 0; m < 256; ++m) {
         const int k1 = m >> 4, n2 = m & 15;  // stage-1 -> stage-2 twiddle W256^(n2*k1), laid out [k1][n2]
@@ -673,12 +1026,14 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     }
     tab.melb_elems = (int)melb.size();
     int rc;
-    if ((rc = upload(window, &h->d_window)) || (rc = upload(tw256, &h->d_tw256)) || (rc = upload(tw512, &h->d_tw512)) ||
+    if ((rc = upload(window, &h->d_window)) || (rc = upload(window_half, &h->d_window_half)) || (rc = upload(tw256, &h->d_tw256)) ||
+        (rc = upload(tw512, &h->d_tw512)) ||
         (rc = upload(melb, &h->d_melb))) {
         mv_fbank_destroy(h);
         return rc;
     }
     tab.window = h->d_window;
+    tab.window_half = h->d_window_half;
     tab.tw256 = h->d_tw256;
     tab.tw512 = h->d_tw512;
     tab.melb = h->d_melb;
@@ -698,6 +1053,15 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         mv_fbank_destroy(h);
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_kernel");
     }
+    h->tile_kernel = fbank_tile_geometry_ok(h);
+    if (const char* e = getenv("MV_FBANK_IMPL")) {  // measurement knob: "generic" keeps fbank_kernel for every geometry
+        if (strcmp(e, "generic") == 0) h->tile_kernel = false;
+    }
+    if (h->tile_kernel && (fbank_tile_set_smem<13, true>() != hipSuccess || fbank_tile_set_smem<13, false>() != hipSuccess ||
+                           fbank_tile_set_smem<16, true>() != hipSuccess || fbank_tile_set_smem<16, false>() != hipSuccess)) {
+        mv_fbank_destroy(h);
+        return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_tile_kernel");
+    }
     *out = h;
     return MV_OK;
 }
@@ -705,6 +1069,7 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
 int mv_fbank_destroy(MvFbank* h) {
     if (h == nullptr) return MV_OK;
     hipFree(h->d_window);
+    hipFree(h->d_window_half);
     hipFree(h->d_tw256);
     hipFree(h->d_tw512);
     hipFree(h->d_melb);
@@ -759,12 +1124,19 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.use_log = h->cfg.use_log_fbank;
     a.cmn = h->cfg.subtract_time_mean;
     a.L = L;
+    a.tile_in_lds = 0;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
     const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
-    fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
+    if (h->tile_kernel) {
+        // the utterance's feature block stays in LDS when it fits next to the wave slots (T <= 298 frames at 80 bins: 3 s of audio)
+        a.tile_in_lds = fbank_tile_lds_bytes((int)T, h->nbins, true) <= 160 * 1024 ? 1 : 0;
+        fbank_tile_launch(B, fbank_tile_lds_bytes((int)T, h->nbins, a.tile_in_lds != 0), static_cast<hipStream_t>(stream), a, vec2);
+    } else {
+        fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
+    }
     mv::prof_end(prof, static_cast<hipStream_t>(stream));
-    return mv::check_launch("fbank_kernel");
+    return mv::check_launch(h->tile_kernel ? "fbank_tile_kernel" : "fbank_kernel");
 }
 
 }  // extern "C"

@@ -57,7 +57,8 @@ class MvConv2dDesc(ctypes.Structure):
     _fields_ = [('x', c_vp), ('x2', c_vp), ('x2_mode', c_i32), ('cin1', c_i32), ('ldx', c_i64), ('ldx2', c_i64),
                 ('w', c_vp), ('bias', c_vp), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64),
                 ('y', c_vp), ('ldy', c_i64), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('cin16', c_i32),
-                ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32), ('lo', c_f32), ('hi', c_f32)]
+                ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32), ('lo', c_f32), ('hi', c_f32),
+                ('cin_alg', c_i32), ('cout_alg', c_i32)]
 
 
 class MvTdnnCfg(ctypes.Structure):
