@@ -362,7 +362,8 @@ def main():
                                        f'oracle front-end loop + oracle {cls} forward in chunks of 32, torch CPU fp32, {cpu_s:.1f} s'}
                 # as shipped: the reference's predictor leaves autograd on, so every forward also records its graph
                 n_sh = min(64, B)
-                state_grad = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state_cpu.items()}
+                state_grad = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running_' not in k else v)
+                              for k, v in state_cpu.items()}  # parameters (not BatchNorm buffers) require grad, as in a loaded nn.Module
                 _, sh_s = oracle_embeddings(args.model, state_grad, wav_cpu[:n_sh])
                 out['cpu_baseline_as_shipped'] = {'value': round(n_sh / sh_s, 2), 'unit': 'utterances/s', 'cores': torch.get_num_threads(),
                                                   'host_cores': host_cores, 'kind': 'port', 'autograd': 'on, as mvector/predict.py:228,262',

@@ -69,6 +69,9 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out);
 int mv_fbank_destroy(MvFbank* h);
 /* T = 1 + (L - window) / shift, or 0 when L < window (snip_edges=True) */
 int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_frames);
+/* which kernel this handle launches: *tile_kernel = 1 for fbank_tile_kernel (mel geometry of the reference configurations:
+ * 80 bins / 16 kHz / 512-point FFT), 0 for the generic fbank_kernel; pass_steps[2] = FFT bins each mel MFMA pass walks */
+int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps);
 /* wav: [B, L] fp32 rows ``wav_stride`` elements apart.  lens_ratio: [B] fp32 or NULL
  * (featurizer.py:80-90: frames t >= round_half_even(ratio * T) are zeroed).  out: [B, T, num_mel_bins]
  * fp32, contiguous. */
@@ -104,6 +107,9 @@ typedef struct MvMelSpec MvMelSpec;
 
 void mv_melspec_default_cfg(MvMelSpecCfg* cfg);
 int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out);
+/* *tile_kernel = 1 when the handle launches melspec_tile_kernel (n_fft = 400 as a real FFT fused with mel + CMN + mask in one
+ * launch), 0 for the dense-DFT kernels (any other geometry) */
+int mv_melspec_info(const MvMelSpec* h, int32_t* tile_kernel);
 int mv_melspec_destroy(MvMelSpec* h);
 int mv_melspec_num_frames(const MvMelSpec* h, int64_t num_samples, int64_t* num_frames);
 size_t mv_melspec_workspace_bytes(const MvMelSpec* h, int32_t B, int64_t L);

@@ -129,6 +129,20 @@ def test_emu_campp_short_end_to_end():
     assert rel < 1e-2
 
 
+def test_emu_melspec_fft_kernel_and_dft_kernel(monkeypatch):
+    """default geometry (n_fft 400, 128 mels) = melspec_tile_kernel: edge frames with reflect padding, a masked row, feature
+    rows beyond the LDS block (T = 241 > 212 rows) and fewer; MV_MELSPEC_IMPL=dft keeps the dense-DFT kernels alive"""
+    assert _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
+    assert not _hip.MelSpec(dict(n_fft=512), cdll=emu_cdll()).info()['tile_kernel']
+    wav = frontend.synth_waveforms(2, 48000, seed=31)
+    lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([0.71, 1.0]), {})          # T = 241: 212 rows in LDS, 29 through global
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :5000 + 3], None, {})                # T = 26, odd length
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :9000], None, dict(hop_length=160))  # other hop
+    monkeypatch.setenv('MV_MELSPEC_IMPL', 'dft')
+    assert not _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :6000], None, {})
+
+
 def test_emu_melspec_default_and_masked():
     wav = frontend.synth_waveforms(2, 2000, seed=12)
     lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([1.0, 0.45]), {})
@@ -184,8 +198,11 @@ def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypat
     that (311 frames here); MV_FBANK_IMPL=generic keeps fbank_kernel for the same geometry.  All three against the oracle."""
     wav = frontend.synth_waveforms(2, 400 + 160 * 310, seed=23)
     ratio = torch.tensor([0.83, 1.0])
+    assert _hip.Fbank(FB, cdll=emu_cdll()).info() == {'tile_kernel': True, 'pass_steps': (28, 12)}
+    assert not _hip.Fbank(dict(sample_frequency=16000), cdll=emu_cdll()).info()['tile_kernel']  # 23 bins: generic kernel
     lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)              # tile kernel, no LDS block (T = 311)
     lc.fbank_case(emu_cdll(), 'cpu', wav[:, :48000], ratio, FB)   # tile kernel, LDS block at its largest (T = 298)
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :48160], None, FB)   # one frame more: back to the global second pass
     monkeypatch.setenv('MV_FBANK_IMPL', 'generic')
+    assert not _hip.Fbank(FB, cdll=emu_cdll()).info()['tile_kernel']
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB)

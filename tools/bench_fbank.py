@@ -22,5 +22,5 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
-print(json.dumps(dict(lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), impl=os.environ.get('MV_FBANK_IMPL', 'tile'), waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, L=L, us=round(us, 2),
+print(json.dumps(dict(info=fb.info(), lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), impl=os.environ.get('MV_FBANK_IMPL', 'tile'), waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, L=L, us=round(us, 2),
                       GBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3, 1), frac_of_8TBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3 / 8000, 4))))

@@ -26,90 +26,18 @@
 //   (complex math is written on float2 vectors where packed ops pay; the SLP pass would additionally pair up scalar chains
 //    -- DC sums, pre-emphasis, the paired post-processing -- at the price of two v_mov per packed op; without signed zeros
 //    the zero-padded inputs of the first FFT stage fold away)
-#include "common.h"
+#include "frontend_common.h"
 
 #include <cstdlib>
 #include <vector>
 
 namespace mv {
 
-// Complex values are float2 vectors {re, im}: sums, differences and twiddle products map onto the packed fp32 VALU ops
-// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, swaps and sign flips ride on their op_sel / neg modifiers).
-typedef float2v cplx;
-
-__device__ __forceinline__ cplx cmake(float r, float i) { return cplx{r, i}; }
-__device__ __forceinline__ cplx cswap(cplx a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ __forceinline__ cplx mul_mi(cplx a) { return cswap(a) * cplx{1.0f, -1.0f}; }  // a * (-i) = {im, -re}
-// a * (c - i s)
-__device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return a * cplx{c, c} + cswap(a) * cplx{s, -s}; }
-
-// multiply by W16^M = exp(-2 pi i M / 16), M compile-time
-template <int M>
-__device__ __forceinline__ cplx mul_w16(cplx a) {
-    constexpr int m = M & 15;
-    if constexpr (m == 0) return a;
-    if constexpr (m == 4) return mul_mi(a);
-    if constexpr (m == 8) return -a;
-    if constexpr (m == 12) return -mul_mi(a);
-    constexpr float C[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                             0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
-                             -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f,
-                             0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
-    constexpr float S[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
-                             1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                             0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
-                             -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-    if constexpr (m == 2) return (a + mul_mi(a)) * cplx{C[2], C[2]};     // (1 - i) / sqrt 2
-    if constexpr (m == 6) return (mul_mi(a) - a) * cplx{C[2], C[2]};     // (-1 - i) / sqrt 2
-    return cmul_conjtw(a, C[m], S[m]);
-}
-
-__device__ __forceinline__ void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
-    const cplx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
-    a0 = t0 + t2;
-    a2 = t0 - t2;
-    a1 = t1 + t3;  // t1 - i (a1 - a3)
-    a3 = t1 - t3;  // t1 + i (a1 - a3)
-}
-
-// forward 16-point DFT, natural order in and out:  X[k] = sum_n x[n] exp(-2 pi i n k / 16)
-__device__ __forceinline__ void fft16(cplx (&x)[16]) {
-    // n = 4*n1 + n2, k = k1 + 4*k2
-    cplx y[4][4];  // [n2][k1]
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) {
-        cplx a0 = x[n2], a1 = x[4 + n2], a2 = x[8 + n2], a3 = x[12 + n2];
-        dft4(a0, a1, a2, a3);
-        y[n2][0] = a0;
-        y[n2][1] = a1;
-        y[n2][2] = a2;
-        y[n2][3] = a3;
-    }
-    y[1][1] = mul_w16<1>(y[1][1]);
-    y[1][2] = mul_w16<2>(y[1][2]);
-    y[1][3] = mul_w16<3>(y[1][3]);
-    y[2][1] = mul_w16<2>(y[2][1]);
-    y[2][2] = mul_w16<4>(y[2][2]);
-    y[2][3] = mul_w16<6>(y[2][3]);
-    y[3][1] = mul_w16<3>(y[3][1]);
-    y[3][2] = mul_w16<6>(y[3][2]);
-    y[3][3] = mul_w16<9>(y[3][3]);
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-        cplx a0 = y[0][k1], a1 = y[1][k1], a2 = y[2][k1], a3 = y[3][k1];
-        dft4(a0, a1, a2, a3);
-        x[k1] = a0;
-        x[k1 + 4] = a1;
-        x[k1 + 8] = a2;
-        x[k1 + 12] = a3;
-    }
-}
-
 constexpr int FB_NFFT = 512;
 constexpr int FB_TSTRIDE = 17;        // padded row of the 16x16 transpose tile (complex elements)
 constexpr int FB_SLOT_FLOATS = 548;   // per-frame LDS slot: 16*17 complex = 544 floats, padded so the four frame rows of a
                                       // wave start 36 banks apart (conflict-free 16-byte operand reads of the mel stage)
-constexpr int FB_MAX_PASSES = 2;      // 16 blocks x 4 filters per MFMA pass: num_mel_bins <= 128
+constexpr int FB_MAX_PASSES = MEL_MAX_PASSES;  // 16 blocks x 4 filters per MFMA pass: num_mel_bins <= 128
 
 struct FbankTables {
     const float* window;    // [512] window, zero beyond the frame length
@@ -118,7 +46,7 @@ struct FbankTables {
     const float* tw512;     // [256][2] cos, sin of 2 pi k / 512
     const float* melb;      // [steps/4][64 lanes][4] mel weights in MFMA B-operand order, passes back to back
     int melb_elems;
-    int passes;
+    int passes;                           // (copied from the MelPlan of frontend_common.h)
     int pass_steps[FB_MAX_PASSES];        // bins walked per pass (multiple of 4)
     int pass_split[FB_MAX_PASSES];        // 1, 2 or 4 adjacent blocks share one filter group (each walks a part of its bins)
     int pass_gbase[FB_MAX_PASSES];        // first filter group (4 filters) of the pass
@@ -140,31 +68,6 @@ struct FbankArgs {
     int tile_in_lds;  // fbank_tile_kernel: the utterance's [T, nbins] block stays in LDS until the time mean is known
     FbankTables tab;
 };
-
-#ifdef MV_EMU
-inline float fb_log2(float x) { return log2f(x); }
-#else
-__device__ __forceinline__ float fb_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32, normal inputs only
-#endif
-
-#ifdef MV_EMU
-inline float4v fb_mfma4(float a, float b, float4v c) {  // D[lane][r] += A[4*(lane/4) + r] * B[lane]
-    const int lane = emu::flat_tid() & 63;
-    memcpy(emu::wave_slot(0, lane), &a, 4);
-    emu::wave_sync();
-    for (int r = 0; r < 4; ++r) {
-        float av;
-        memcpy(&av, emu::wave_slot(0, (lane & ~3) + r), 4);
-        c[r] = fmaf(av, b, c[r]);
-    }
-    emu::wave_sync();
-    return c;
-}
-#else
-__device__ __forceinline__ float4v fb_mfma4(float a, float b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
-#endif
 
 // NG = groups of 32 samples that cover the window (13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512);
 // VEC2: rows and frames start on 8-byte boundaries, samples are fetched as float2
@@ -483,19 +386,13 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
 //   * the [T, nbins] log-mel block of the utterance stays in LDS (95 KB for 3 s x 80 bins) until the time mean is
 //     known: features are written to HBM once (algorithmic traffic), not written, re-read and rewritten.  Longer
 //     utterances fall back to the second pass over global memory inside the same kernel.
-// Instantiated for the mel geometry of the reference configurations (80 bins, 16 kHz, 512-point FFT: passes of 7 and 11
+// Instantiated for the mel geometry of the reference configurations (80 bins, 16 kHz, 512-point FFT: passes of 7 and 3
 // four-bin groups); any other geometry runs fbank_kernel above.
 constexpr int FBT_WAVES = 8;
 constexpr int FBT_ROW = 65;                      // complex elements per transpose row: [4 frames][16] + 1 pad
 constexpr int FBT_SLOT_FLOATS = 16 * FBT_ROW * 2;  // 2080 floats = 8320 B per wave
 constexpr int FBT_WIN_FLOATS = 448;              // window taps kept in LDS (the taps the 13 / 14 sample groups of a <= 448-sample window touch)
 constexpr int FBT_PSTR = 292;                    // floats between the power rows of the wave's four frames (36 banks apart)
-
-// One ds_read_b64 per element: pairs of them would be merged into ds_read2_b64, which moves 128 B per LDS clock where
-// ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS table); a volatile access is left alone by the merger.
-__device__ __forceinline__ cplx lds_read_single(const cplx* p) { return lds_load_unmerged(p); }
-
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
 
 template <int NG, bool VEC2, int G0, int G1>
 __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a) {
@@ -650,7 +547,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             pp[j] = v1 * v1 + v2 * v2;
         }
         {   // bin 128 = conj(Z[128]) lives in lane 0's register 8; it takes the slot of lane 0's (unused) Nyquist output
-            const float p128 = z[8][0] * z[8][0] + z[8][1] * z[8][1];
+            const float p128 = 4.0f * (z[8][0] * z[8][0] + z[8][1] * z[8][1]);  // |X[128]|^2 = |Z[128]|^2, and z is Z / 2
             pp[0] = l16 == 0 ? p128 : pp[0];
         }
         // (the transposed values were all read before the FFT: the power rows may overwrite them)
@@ -862,8 +759,8 @@ void fbank_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, in
 }
 
 // fbank_tile_kernel is instantiated for the mel geometry of the reference configurations: 80 bins at 16 kHz on a 512-point
-// FFT = a pass of 16 filter groups (7 four-bin steps) and a pass of 4 groups spread over all blocks (11 steps)
-constexpr int FBT_G0 = 7, FBT_G1 = 11;
+// FFT = a pass of 16 filter groups (7 four-bin steps) and a pass of 4 groups, each split over 4 blocks (3 steps)
+constexpr int FBT_G0 = 7, FBT_G1 = 3;
 
 static bool fbank_tile_geometry_ok(const MvFbank* h) {
     const mv::FbankTables& t = h->tab;
@@ -945,84 +842,21 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         tw512[2 * m + 1] = (float)sin(2.0 * pi * m / 512.0);
     }
     auto banks = kaldi_mel_banks(h->nbins, mv::FB_NFFT, cfg->sample_frequency, cfg->low_freq, cfg->high_freq);
-    // Mel stage tables.  One MFMA pass = 16 blocks x (4 frames x 4 adjacent filters); every block walks `steps` consecutive
-    // bins from its own start (a multiple of 4, so operands are 16-byte LDS reads; start + steps <= 256 keeps the walk inside
-    // the row).  A pass with <= 8 (<= 4) filter groups gives each group 2 (4) adjacent blocks that split its bin range: the
-    // wide high-frequency triangles then cost a quarter of the steps and the kernel adds the partial sums across lanes.
-    const int groups = (h->nbins + 3) / 4;
+    // Mel stage tables (frontend_common.h::build_mel_plan): passes of 16 blocks x (4 frames x 4 adjacent filters), every block
+    // walking only the bins its triangles cover, inside the 256 bins of a power row
     mv::FbankTables& tab = h->tab;
-    tab.passes = 0;
-    std::vector<int> clo(groups, 0), cnum(groups, 0);  // first 4-bin chunk and number of chunks of each group
-    for (int g = 0; g < groups; ++g) {
-        int lo = 256, hi = -1;
-        for (int m = 4 * g; m < 4 * g + 4 && m < h->nbins; ++m)
-            for (int k = 0; k < 256; ++k)
-                if (banks[m][k] > 0.0f) {
-                    lo = k < lo ? k : lo;
-                    hi = k > hi ? k : hi;
-                }
-        if (hi >= 0) {
-            clo[g] = lo >> 2;
-            cnum[g] = (hi >> 2) - (lo >> 2) + 1;
-        }
+    mv::MelPlan plan;
+    std::vector<float> melb;
+    if (!mv::build_mel_plan(banks, 256, &plan, &melb)) {
+        delete h;
+        return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: num_mel_bins needs more than two MFMA passes");
     }
-    int total_steps = 0;
-    std::vector<int> seg_first[mv::FB_MAX_PASSES];  // first chunk of each block's segment
-    for (int p = 0, g0 = 0; p < mv::FB_MAX_PASSES; ++p) {
-        tab.pass_steps[p] = 0;
-        tab.pass_split[p] = 1;
-        tab.pass_gbase[p] = g0;
-        for (int blk = 0; blk < 16; ++blk) tab.pass_start[p][blk] = 0;
-        if (g0 >= groups) continue;
-        const int left = groups - g0;
-        // the last pass spreads its few groups over all 16 blocks; a full pass takes the next 16 groups
-        const int split = left <= 4 ? 4 : (left <= 8 ? 2 : 1);
-        const int ng = left < 16 / split ? left : 16 / split;
-        int seg_chunks = 1;
-        for (int g = g0; g < g0 + ng; ++g) {
-            const int per = (cnum[g] + split - 1) / split;
-            seg_chunks = per > seg_chunks ? per : seg_chunks;
-        }
-        const int steps = 4 * seg_chunks;
-        tab.pass_steps[p] = steps;
-        tab.pass_split[p] = split;
-        seg_first[p].assign(16, -1);
-        for (int blk = 0; blk < ng * split; ++blk) {
-            const int g = g0 + blk / split, sidx = blk % split;
-            const int per = (cnum[g] + split - 1) / split;
-            const int first = clo[g] + sidx * per;                     // chunks [first, first + per) of the group
-            const int last = clo[g] + cnum[g];
-            if (first >= last) continue;                                // nothing left for this block: all-zero weights
-            seg_first[p][blk] = first;
-            int st = 4 * first;
-            if (st + steps > 256) st = 256 - steps;
-            tab.pass_start[p][blk] = st;
-        }
-        total_steps += steps;
-        g0 += ng;
-        tab.passes = p + 1;
-        if (p + 1 == mv::FB_MAX_PASSES && g0 < groups) {
-            delete h;
-            return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: num_mel_bins needs more than two MFMA passes");
-        }
-    }
-    std::vector<float> melb((size_t)total_steps * 64, 0.0f);  // [step / 4][lane][step % 4]
-    for (int p = 0, off = 0; p < tab.passes; off += tab.pass_steps[p], ++p) {
-        const int split = tab.pass_split[p];
-        for (int ln = 0; ln < 64; ++ln) {
-            const int blk = ln >> 2;
-            if (seg_first[p][blk] < 0) continue;
-            const int g = tab.pass_gbase[p] + blk / split;
-            const int m = 4 * g + (ln & 3);
-            if (m >= h->nbins) continue;
-            const int per = (cnum[g] + split - 1) / split;
-            const int k_lo = 4 * seg_first[p][blk], k_hi = 4 * (seg_first[p][blk] + per);  // bins owned by this block
-            for (int sidx = 0; sidx < tab.pass_steps[p]; ++sidx) {
-                const int k = tab.pass_start[p][blk] + sidx;
-                if (k >= k_lo && k < k_hi && k < 256)
-                    melb[((size_t)((off + sidx) >> 2) * 64 + ln) * 4 + (sidx & 3)] = banks[m][k];
-            }
-        }
+    tab.passes = plan.passes;
+    for (int p = 0; p < mv::FB_MAX_PASSES; ++p) {
+        tab.pass_steps[p] = plan.pass_steps[p];
+        tab.pass_split[p] = plan.pass_split[p];
+        tab.pass_gbase[p] = plan.pass_gbase[p];
+        for (int blk = 0; blk < 16; ++blk) tab.pass_start[p][blk] = plan.pass_start[p][blk];
     }
     tab.melb_elems = (int)melb.size();
     int rc;
@@ -1080,6 +914,14 @@ int mv_fbank_destroy(MvFbank* h) {
 int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_frames) {
     MV_REQUIRE(h != nullptr && num_frames != nullptr, "mv_fbank_num_frames: null argument");
     *num_frames = num_samples < h->win ? 0 : 1 + (num_samples - h->win) / h->shift;
+    return MV_OK;
+}
+
+int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps) {
+    MV_REQUIRE(h != nullptr && tile_kernel != nullptr && pass_steps != nullptr, "mv_fbank_info: null argument");
+    *tile_kernel = h->tile_kernel ? 1 : 0;
+    pass_steps[0] = h->tab.pass_steps[0];
+    pass_steps[1] = h->tab.pass_steps[1];
     return MV_OK;
 }
 

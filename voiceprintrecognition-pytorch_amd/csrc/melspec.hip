@@ -14,8 +14,11 @@
 //   mel projection      exact-fp32 GEMM (linear.hip) against the transposed filterbank.
 //   cmn_mask_kernel     column means over ALL frames (padded ones included, featurizer.py:79), subtract, zero the frames
 //                       t >= round_half_even(ratio * T).
+// hipcc-flags: -fno-slp-vectorize -fno-signed-zeros
+//   (see fbank.hip: scalar chains stay scalar instead of being re-packed into v_pk_* ops behind register shuffles)
 #include <vector>
 
+#include "frontend_common.h"
 #include "kernels.h"
 
 namespace mv {
@@ -141,6 +144,311 @@ __global__ __launch_bounds__(256) void stft_power_kernel(StftArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// melspec_tile_kernel: n_fft = 400 (the torchaudio default every MelSpectrogram configuration of the reference runs
+// with) as a real FFT, fused with the HTK mel stage, the time-mean subtraction and the length mask in ONE launch.
+//
+// 400 = 16 x 25.  With n = 16 n1 + n2 and k = k1 + 25 k2:
+//     X[k1 + 25 k2] = sum_n2 W16^(n2 k2) . W400^(n2 k1) . Y[k1, n2],      Y[k1, n2] = sum_n1 W25^(n1 k1) x[16 n1 + n2]
+//   * a frame sits on 16 lanes, lane n2 holds the 25 REAL samples x[16 n1 + n2] (64 contiguous bytes per 16 lanes and n1);
+//   * Y: real-input 25-point DFT in registers as 5 x 5 (n1 = 5a + b, k1 = c + 5d): five real 5-point DFTs over a, twiddles
+//     W25^(bc) for c = 1, 2 only, then one real (c = 0) and two complex (c = 1, 2) 5-point DFTs over b; the inputs are real, so
+//     Y[25 - k1] = conj Y[k1] and k1 = 0..12 is all that is needed: c = 1, 2 with all five d give k1 = {1,6,11,16,21},
+//     {2,7,12,17,22}, i.e. Y[9], Y[4], Y[8], Y[3] by conjugation -- 188 lane-ops instead of 650 for the dense product;
+//   * twiddle by W400^(n2 k1) (per-lane constants), ONE LDS transpose in the layout of fbank_tile_kernel (row k1 = [frame][n2]
+//     + pad), then lane k1 < 13 runs the 16-point FFT over n2: its 16 outputs are the bins k1 + 25 k2, of which k2 >= 8 are
+//     the conjugates of the bins 400 - k -- every bin 0..200 comes out exactly once (lane 0: k2 = 0..8), no post-processing;
+//   * |X|^2 -> power rows in LDS -> banded HTK mel on v_mfma_f32_4x4x1 with the weights in registers (12 + 20 steps for 128
+//     mels) -> raw power features (no log, featurizer.py:76-79);
+//   * features of the first `tile_rows` frames wait in LDS for the time mean (featurizer.py:79) and are written once; the
+//     frames that do not fit (27 of 241 for 3 s x 128 mels) take the write / re-read / rewrite route through global memory.
+// Any other n_fft runs the dense-DFT kernels above.
+constexpr int MST_WAVES = 8;
+constexpr int MST_ROW = 65;                       // complex elements per transpose row: [4 frames][16 n2] + 1 pad
+constexpr int MST_SLOT_FLOATS = 13 * MST_ROW * 2 + 2;  // 1692 floats per wave (16-byte multiple: the mel operands are 16-byte reads)
+constexpr int MST_PSTR = 228;                     // floats between the power rows of the wave's four frames (36 banks apart)
+
+struct MelTileArgs {
+    const float* wav;
+    int64_t wav_stride;
+    int64_t L;
+    const float* lens_ratio;
+    float* out;               // [B, T, n_mels]
+    const float* window;      // [400]
+    const float* tw400;       // [13 k1][16 n2][2] cos, sin of 2 pi n2 k1 / 400
+    const float* melb;        // MFMA B-operand order (frontend_common.h)
+    int B, T, hop, pad, n_mels, cmn, tile_rows;
+    MelPlan plan;
+};
+
+// real 5-point DFT: X[d] = sum_a v[a] W5^(a d); returns X[0] (real) and X[1], X[2] (X[5-d] = conj X[d])
+__device__ __forceinline__ void rdft5(float v0, float v1, float v2, float v3, float v4, float& x0, cplx& x1, cplx& x2) {
+    constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
+    const float s1 = v1 + v4, e1 = v1 - v4, s2 = v2 + v3, e2 = v2 - v3;
+    x0 = v0 + (s1 + s2);
+    x1 = cmake(fmaf(C2, s2, fmaf(C1, s1, v0)), -fmaf(S2, e2, S1 * e1));     // cos(4 pi d/5), sin(4 pi d/5) at d = 1
+    x2 = cmake(fmaf(C1, s2, fmaf(C2, s1, v0)), -fmaf(-S1, e2, S2 * e1));    // d = 2: cos(8 pi/5) = C1, sin(8 pi/5) = -S1
+}
+
+// complex 5-point DFT, all five outputs
+__device__ __forceinline__ void cdft5(cplx z0, cplx z1, cplx z2, cplx z3, cplx z4, cplx (&x)[5]) {
+    constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;
+    constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;
+    const cplx s1 = z1 + z4, e1 = z1 - z4, s2 = z2 + z3, e2 = z2 - z3;
+    x[0] = z0 + (s1 + s2);
+    const cplx t1 = z0 + s1 * cplx{C1, C1} + s2 * cplx{C2, C2};
+    const cplx t2 = z0 + s1 * cplx{C2, C2} + s2 * cplx{C1, C1};
+    const cplx u1 = e1 * cplx{S1, S1} + e2 * cplx{S2, S2};
+    const cplx u2 = e1 * cplx{S2, S2} - e2 * cplx{S1, S1};
+    // X[d] = t_d - i u_d, X[5-d] = t_d + i u_d;  -i u = {u.im, -u.re}
+    const cplx m1 = mul_mi(u1), m2 = mul_mi(u2);
+    x[1] = t1 + m1;
+    x[4] = t1 - m1;
+    x[2] = t2 + m2;
+    x[3] = t2 - m2;
+}
+
+// z * W25^m (m compile-time)
+template <int M>
+__device__ __forceinline__ cplx mul_w25(cplx z) {
+    constexpr double PI2_25 = 6.283185307179586476925 / 25.0;
+    // constexpr cos/sin are not available in device code: table of the 8 angles the 5 x 5 split uses (m = b c, b = 1..4, c = 1, 2)
+    constexpr float C[9] = {1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899666f,
+                            0.0f, 0.06279051952931337f, 0.0f, -0.42577929156507272f};
+    constexpr float S[9] = {0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f,
+                            0.0f, 0.99802672842827156f, 0.0f, 0.90482705246601958f};
+    static_assert(M == 1 || M == 2 || M == 3 || M == 4 || M == 6 || M == 8, "angle not in the table");
+    (void)PI2_25;
+    return cmul_conjtw(z, C[M], S[M]);
+}
+
+template <int G0, int G1>
+__global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArgs a) {
+    constexpr int THREADS = MST_WAVES * 64;
+    MV_DYN_SMEM(smem);
+    float* xbuf = reinterpret_cast<float*>(smem);                  // [MST_WAVES][MST_SLOT_FLOATS]
+    float* tile = xbuf + MST_WAVES * MST_SLOT_FLOATS;              // [tile_rows][n_mels]
+    float* colsum = xbuf;                                          // [MST_WAVES][256] then mean[256], after the frame loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, fs = lane >> 4;
+    const int b = blockIdx.x;
+    const int T = a.T, nm = a.n_mels;
+    const float* x = a.wav + (int64_t)b * a.wav_stride;
+    float* orow = a.out + (int64_t)b * T * nm;
+
+    // ---- per-lane constants ----
+    float cwin[25];
+#pragma unroll
+    for (int n1 = 0; n1 < 25; ++n1) cwin[n1] = a.window[16 * n1 + l16];
+    float2v ctw[13];
+#pragma unroll
+    for (int k1 = 1; k1 < 13; ++k1) ctw[k1] = *reinterpret_cast<const float2v*>(a.tw400 + 2 * (k1 * 16 + l16));
+    float4v mb0[G0], mb1[G1 > 0 ? G1 : 1];
+#pragma unroll
+    for (int g = 0; g < G0; ++g) mb0[g] = *reinterpret_cast<const float4v*>(a.melb + (size_t)g * 256 + lane * 4);
+#pragma unroll
+    for (int g = 0; g < G1; ++g) mb1[g] = *reinterpret_cast<const float4v*>(a.melb + (size_t)(G0 + g) * 256 + lane * 4);
+
+    for (int i = tid; i < MST_WAVES * MST_SLOT_FLOATS; i += THREADS) xbuf[i] = 0.0f;  // pads of the power rows meet zero weights: keep them finite
+    __syncthreads();
+    float* wslot = xbuf + wave * MST_SLOT_FLOATS;
+    cplx* tw_write = reinterpret_cast<cplx*>(wslot) + lane;                              // (k1, frame fs, n2 = l16) at + k1 * MST_ROW
+    const int krow = l16 < 13 ? l16 : 12;                                                 // lanes 13..15 idle through stage 2
+    const cplx* tw_read = reinterpret_cast<const cplx*>(wslot) + krow * MST_ROW + 16 * fs; // (k1 = krow, fs, n2) at + n2
+    float* prow = wslot + fs * MST_PSTR;
+    float* p_lo = prow + krow;            // bin k1 + 25 k2, k2 = 0..7
+    float* p_hi = prow + 25 - krow;       // bin 400 - k = (25 - k1) + 25 (15 - k2), k2 = 8..15 (lane 0: k2 = 8 only -> bin 200)
+    const bool act = l16 < 13;
+    const float* arow = wslot + (lane & 3) * MST_PSTR;
+    const float* ap0 = arow + a.plan.pass_start[0][lane >> 2];
+    const float* ap1 = arow + a.plan.pass_start[1][lane >> 2];
+    const int blk = lane >> 2;
+    const int split0 = a.plan.pass_split[0], split1 = a.plan.pass_split[1];
+    const int m0 = 4 * (a.plan.pass_gbase[0] + blk / split0) + (lane & 3);
+    const int m1 = 4 * (a.plan.pass_gbase[1] + blk / split1) + (lane & 3);
+    const bool own0 = m0 < nm && (blk & (split0 - 1)) == 0;
+    const bool own1 = G1 > 0 && m1 < nm && (blk & (split1 - 1)) == 0;
+    float csum0 = 0.0f, csum1 = 0.0f;
+    const int tile_rows = a.tile_rows;  // multiple of 4
+
+    const int nquads = (T + 3) >> 2;
+    for (int q = wave; q < nquads; q += MST_WAVES) {
+        const int f_raw = q * 4 + fs;
+        const int f = f_raw < T ? f_raw : T - 1;
+        const int64_t start = (int64_t)f * a.hop - a.pad;
+        float v[25];
+        if (start >= 0 && start + 400 <= a.L) {
+            const float* fp = x + start + l16;
+#pragma unroll
+            for (int n1 = 0; n1 < 25; ++n1) v[n1] = fp[16 * n1] * cwin[n1];
+        } else {  // first / last frames: reflect padding of torch.stft(center=True), or zeros beyond the signal without it
+#pragma unroll
+            for (int n1 = 0; n1 < 25; ++n1) {
+                int64_t i = start + 16 * n1 + l16;
+                if (a.pad > 0) {
+                    if (i < 0) i = -i;
+                    if (i >= a.L) i = 2 * (a.L - 1) - i;
+                }
+                v[n1] = (i >= 0 && i < a.L) ? x[i] * cwin[n1] : 0.0f;
+            }
+        }
+        // ---- Y[k1], k1 = 0..12: 5 x 5 real DFT (n1 = 5a + b) ----
+        float a0[5];
+        cplx a1[5], a2[5];
+#pragma unroll
+        for (int bb = 0; bb < 5; ++bb) rdft5(v[bb], v[5 + bb], v[10 + bb], v[15 + bb], v[20 + bb], a0[bb], a1[bb], a2[bb]);
+        a1[1] = mul_w25<1>(a1[1]); a1[2] = mul_w25<2>(a1[2]); a1[3] = mul_w25<3>(a1[3]); a1[4] = mul_w25<4>(a1[4]);
+        a2[1] = mul_w25<2>(a2[1]); a2[2] = mul_w25<4>(a2[2]); a2[3] = mul_w25<6>(a2[3]); a2[4] = mul_w25<8>(a2[4]);
+        cplx y[13];
+        {
+            float y0;
+            cplx y5, y10;
+            rdft5(a0[0], a0[1], a0[2], a0[3], a0[4], y0, y5, y10);   // c = 0: k1 = 0, 5, 10
+            y[0] = cmake(y0, 0.0f);
+            y[5] = y5;
+            y[10] = y10;
+            cplx o[5];
+            cdft5(a1[0], a1[1], a1[2], a1[3], a1[4], o);             // c = 1: k1 = 1, 6, 11, 16, 21
+            y[1] = o[0]; y[6] = o[1]; y[11] = o[2];
+            y[9] = o[3] * cplx{1.0f, -1.0f};                          // Y[9] = conj Y[16]
+            y[4] = o[4] * cplx{1.0f, -1.0f};                          // Y[4] = conj Y[21]
+            cdft5(a2[0], a2[1], a2[2], a2[3], a2[4], o);             // c = 2: k1 = 2, 7, 12, 17, 22
+            y[2] = o[0]; y[7] = o[1]; y[12] = o[2];
+            y[8] = o[3] * cplx{1.0f, -1.0f};                          // Y[8] = conj Y[17]
+            y[3] = o[4] * cplx{1.0f, -1.0f};                          // Y[3] = conj Y[22]
+        }
+#pragma unroll
+        for (int k1 = 1; k1 < 13; ++k1) y[k1] = cmul_conjtw(y[k1], ctw[k1][0], ctw[k1][1]);
+        // ---- transpose: lane n2 -> lane k1 ----
+#pragma unroll
+        for (int k1 = 0; k1 < 13; ++k1) tw_write[k1 * MST_ROW] = y[k1];
+        MV_WAVE_FENCE();
+        cplx z[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_read_single(tw_read + n2);
+        MV_WAVE_FENCE();
+        fft16(z);  // z[k2] = X[k1 + 25 k2]
+        float pw[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) pw[k2] = z[k2][0] * z[k2][0] + z[k2][1] * z[k2][1];
+        if (act) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) p_lo[25 * k2] = pw[k2];
+            p_hi[25 * 7] = pw[8];
+            if (l16 != 0) {  // lane 0: k2 = 9..15 repeat its bins 175..25
+#pragma unroll
+                for (int k2 = 9; k2 < 16; ++k2) p_hi[25 * (15 - k2)] = pw[k2];
+            }
+        }
+        MV_WAVE_FENCE();
+        // ---- banded mel on the matrix pipe ----
+        const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        float4v acc0[4], acc1[4];
+#pragma unroll
+        for (int g = 0; g < G0; ++g) {
+            const float4v av = *reinterpret_cast<const float4v*>(ap0 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc0[c] = fb_mfma4(av[c], mb0[g][c], g == 0 ? zero4 : acc0[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc1[c] = zero4;
+#pragma unroll
+        for (int g = 0; g < G1; ++g) {
+            const float4v av = *reinterpret_cast<const float4v*>(ap1 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc1[c] = fb_mfma4(av[c], mb1[g][c], g == 0 ? zero4 : acc1[c]);
+        }
+        float4v r0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
+        float4v r1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
+        MV_WAVE_FENCE();  // the power rows are consumed: the next quad's transpose may overwrite them
+        if (split0 >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r0[r] += dpp_mov<DPP_ROW_SHL4>(0.0f, r0[r]);
+        }
+        if (split0 == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r0[r] += dpp_mov<DPP_ROW_SHL8>(0.0f, r0[r]);
+        }
+        if (split1 >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r1[r] += dpp_mov<DPP_ROW_SHL4>(0.0f, r1[r]);
+        }
+        if (split1 == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r1[r] += dpp_mov<DPP_ROW_SHL8>(0.0f, r1[r]);
+        }
+        const int frames_here = (q * 4 + 4 <= T) ? 4 : T - q * 4;
+        if (frames_here < 4) {
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                if (r >= frames_here) {
+                    r0[r] = 0.0f;
+                    r1[r] = 0.0f;
+                }
+            }
+        }
+        csum0 += (r0[0] + r0[1]) + (r0[2] + r0[3]);
+        csum1 += (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        const int row0 = q * 4 * nm;
+        if (q * 4 < tile_rows) {  // uniform: tile_rows is a multiple of 4
+            float* d0 = tile + row0 + m0;
+            float* d1 = tile + row0 + m1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < frames_here) {
+                    if (own0) d0[r * nm] = r0[r];
+                    if (own1) d1[r * nm] = r1[r];
+                }
+            }
+        } else {
+            float* d0 = orow + row0 + m0;
+            float* d1 = orow + row0 + m1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < frames_here) {
+                    if (own0) d0[r * nm] = r0[r];
+                    if (own1) d1[r * nm] = r1[r];
+                }
+            }
+        }
+    }
+
+    // ---- per-utterance time mean over ALL frames (featurizer.py:79), mask, single write of the rows held in LDS ----
+    __syncthreads();
+    if (own0) colsum[wave * 256 + m0] = csum0;
+    if (own1) colsum[wave * 256 + m1] = csum1;
+    __syncthreads();
+    float* mean = colsum + MST_WAVES * 256;
+    if (tid < 256) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MST_WAVES; ++w) s += colsum[w * 256 + tid];
+        mean[tid] = (a.cmn && tid < nm) ? s / (float)T : 0.0f;
+    }
+    __syncthreads();
+    int mask_len = T;
+    if (a.lens_ratio != nullptr) mask_len = (int)rintf(a.lens_ratio[b] * (float)T);
+    const int qn = nm >> 2;  // n_mels % 4 == 0 for this kernel
+    const int rows_per_pass = THREADS / qn;
+    const int r0 = tid / qn, cg = tid - r0 * qn;
+    if (r0 < rows_per_pass) {
+        const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
+        const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        int t = r0;
+        for (; t < T && t < tile_rows; t += rows_per_pass) {  // rows held in LDS: written to HBM once
+            const float4v raw = *(reinterpret_cast<const float4v*>(tile + t * nm) + cg);
+            *(reinterpret_cast<float4v*>(orow + (int64_t)t * nm) + cg) = t < mask_len ? raw - m4 : zero4;
+        }
+        for (; t < T; t += rows_per_pass) {                   // rows that went through global memory
+            float4v* gp = reinterpret_cast<float4v*>(orow + (int64_t)t * nm) + cg;
+            const float4v raw = *gp;
+            *gp = t < mask_len ? raw - m4 : zero4;
+        }
+    }
+}
+
 // out[b, t, c] -= mean_t out[b, :, c]; frames t >= mask_len zeroed.  One workgroup per utterance.
 __global__ __launch_bounds__(256) void cmn_mask_kernel(float* out, int T, int C, const float* lens_ratio, int cmn) {
     __shared__ float part[4][256];
@@ -181,7 +489,16 @@ struct MvMelSpec {
     float* d_cos = nullptr;
     float* d_sin = nullptr;
     float* d_fbT = nullptr;  // [n_mels][nbin_pad]
+    // melspec_tile_kernel (n_fft = 400 and a mel plan that matches an instantiation)
+    bool tile_kernel = false;
+    float* d_tw400 = nullptr;
+    float* d_melb = nullptr;
+    mv::MelPlan plan;
 };
+
+// instantiated mel geometry: 128 HTK filters over 0 .. 8 kHz on the 201 bins of n_fft = 400 = two passes of 16 filter groups
+// walking 12 and 20 bins
+constexpr int MST_G0 = 3, MST_G1 = 5;
 
 namespace {
 
@@ -264,7 +581,41 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
         mv_melspec_destroy(h);
         return rc;
     }
+    // ---- FFT path (melspec_tile_kernel) when the geometry matches ----
+    if (n_fft == 400 && cfg->power == 2.0f && (cfg->n_mels & 3) == 0 && cfg->n_mels <= 128) {
+        std::vector<std::vector<float>> banks(cfg->n_mels, std::vector<float>(h->nbin, 0.0f));
+        for (int j = 0; j < cfg->n_mels; ++j)
+            for (int k = 0; k < h->nbin; ++k) banks[j][k] = fbT[(size_t)j * h->nbin_pad + k];
+        std::vector<float> melb;
+        const bool ok = mv::build_mel_plan(banks, 208, &h->plan, &melb);  // rows of 201 bins, readable up to 208 (MST_PSTR = 228)
+        if (ok && h->plan.pass_steps[0] == 4 * MST_G0 && h->plan.pass_steps[1] == 4 * MST_G1) {
+            std::vector<float> tw(13 * 16 * 2);
+            for (int k1 = 0; k1 < 13; ++k1)
+                for (int n2 = 0; n2 < 16; ++n2) {
+                    tw[2 * (k1 * 16 + n2)] = (float)cos(2.0 * pi * (n2 * k1) / 400.0);
+                    tw[2 * (k1 * 16 + n2) + 1] = (float)sin(2.0 * pi * (n2 * k1) / 400.0);
+                }
+            if ((rc = upload_vec(tw, &h->d_tw400)) || (rc = upload_vec(melb, &h->d_melb))) {
+                mv_melspec_destroy(h);
+                return rc;
+            }
+            h->tile_kernel = true;
+            if (const char* e = getenv("MV_MELSPEC_IMPL")) {  // measurement knob: "dft" keeps the dense-DFT kernels
+                if (strcmp(e, "dft") == 0) h->tile_kernel = false;
+            }
+            if (h->tile_kernel && MV_SET_MAX_SMEM((mv::melspec_tile_kernel<MST_G0, MST_G1>), 160 * 1024) != hipSuccess) {
+                mv_melspec_destroy(h);
+                return mv::fail(MV_ERR_HIP, "mv_melspec_create: cannot reserve dynamic LDS for melspec_tile_kernel");
+            }
+        }
+    }
     *out = h;
+    return MV_OK;
+}
+
+int mv_melspec_info(const MvMelSpec* h, int32_t* tile_kernel) {
+    MV_REQUIRE(h != nullptr && tile_kernel != nullptr, "mv_melspec_info: null argument");
+    *tile_kernel = h->tile_kernel ? 1 : 0;
     return MV_OK;
 }
 
@@ -274,6 +625,8 @@ int mv_melspec_destroy(MvMelSpec* h) {
     hipFree(h->d_cos);
     hipFree(h->d_sin);
     hipFree(h->d_fbT);
+    hipFree(h->d_tw400);
+    hipFree(h->d_melb);
     delete h;
     return MV_OK;
 }
@@ -304,6 +657,23 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
     if (B == 0 || T == 0) return MV_OK;
     MV_REQUIRE(wav != nullptr && out != nullptr && workspace != nullptr, "mv_melspec_forward: null buffer");
     if (h->cfg.center) MV_REQUIRE(L > h->pad, "mv_melspec_forward: reflect padding needs more than n_fft/2 samples (torch.stft raises too)");
+    if (h->tile_kernel && (int64_t)T * h->cfg.n_mels < ((int64_t)1 << 31)) {
+        mv::MelTileArgs t;
+        t.wav = wav; t.wav_stride = wav_stride; t.L = L; t.lens_ratio = lens_ratio; t.out = out;
+        t.window = h->d_window; t.tw400 = h->d_tw400; t.melb = h->d_melb;
+        t.B = B; t.T = (int)T; t.hop = h->cfg.hop_length; t.pad = h->pad; t.n_mels = h->cfg.n_mels; t.cmn = h->cfg.subtract_time_mean;
+        t.plan = h->plan;
+        // feature rows that fit next to the wave slots stay in LDS until the time mean is known; the rest go through global memory
+        const size_t slots = (size_t)mv::MST_WAVES * mv::MST_SLOT_FLOATS * sizeof(float);
+        int64_t rows = (int64_t)((160 * 1024 - slots) / ((size_t)h->cfg.n_mels * sizeof(float))) & ~(int64_t)3;
+        const int64_t need = (T + 3) & ~(int64_t)3;
+        t.tile_rows = (int)(rows < need ? rows : need);
+        const size_t smem = slots + (size_t)t.tile_rows * h->cfg.n_mels * sizeof(float);
+        const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->cfg.n_mels), static_cast<hipStream_t>(stream));
+        MV_LAUNCH((mv::melspec_tile_kernel<MST_G0, MST_G1>), ((unsigned)B, 1, 1), (mv::MST_WAVES * 64, 1, 1), smem, static_cast<hipStream_t>(stream), t);
+        mv::prof_end(prof, static_cast<hipStream_t>(stream));
+        return mv::check_launch("melspec_tile_kernel");
+    }
     MV_REQUIRE(workspace_bytes >= mv_melspec_workspace_bytes(h, B, L), "mv_melspec_forward: workspace too small");
     MV_REQUIRE((int64_t)B * T < ((int64_t)1 << 31), "mv_melspec_forward: too many frames");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -81,11 +81,13 @@ _SIGNATURES = {
     'mv_fbank_default_cfg': (None, [ctypes.POINTER(MvFbankCfg)]),
     'mv_fbank_create': (c_i32, [ctypes.POINTER(MvFbankCfg), ctypes.POINTER(c_vp)]),
     'mv_fbank_destroy': (c_i32, [c_vp]),
+    'mv_fbank_info': (c_i32, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     'mv_fbank_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     'mv_fbank_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'mv_fbank_forward_varlen': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'mv_melspec_default_cfg': (None, [ctypes.POINTER(MvMelSpecCfg)]),
     'mv_melspec_create': (c_i32, [ctypes.POINTER(MvMelSpecCfg), ctypes.POINTER(c_vp)]),
+    'mv_melspec_info': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     'mv_melspec_destroy': (c_i32, [c_vp]),
     'mv_melspec_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     'mv_melspec_workspace_bytes': (c_sz, [c_vp, c_i32, c_i64]),
@@ -216,6 +218,12 @@ class Fbank:
         check(self._cdll.mv_fbank_num_frames(self._h, num_samples, ctypes.byref(t)), self._cdll)
         return t.value
 
+    def info(self):
+        """{'tile_kernel': bool, 'pass_steps': (s0, s1)} -- which kernel the handle launches (mv_fbank_info)"""
+        tk, steps = c_i32(), (c_i32 * 2)()
+        check(self._cdll.mv_fbank_info(self._h, ctypes.byref(tk), steps), self._cdll)
+        return {'tile_kernel': bool(tk.value), 'pass_steps': (steps[0], steps[1])}
+
     def __call__(self, wav, lens_ratio=None, num_samples=None):
         """wav [B, L] fp32 -> [B, T(L), F].  ``lens_ratio``: the reference's batched semantics (mean over all T frames,
         then mask).  ``num_samples`` (int64 [B]): every row featurised on its own length, zero rows beyond it."""
@@ -280,6 +288,12 @@ class MelSpec:
         self.n_mels = cfg.n_mels
         self._h = c_vp()
         check(self._cdll.mv_melspec_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
+
+    def info(self):
+        """{'tile_kernel': bool}: True when the FFT kernel (n_fft = 400) runs, False for the dense-DFT kernels"""
+        tk = c_i32()
+        check(self._cdll.mv_melspec_info(self._h, ctypes.byref(tk)), self._cdll)
+        return {'tile_kernel': bool(tk.value)}
 
     def num_frames(self, num_samples):
         t = c_i64()
