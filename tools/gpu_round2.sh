@@ -20,6 +20,7 @@ cat $OUT/fbank_ab.log
 echo "== melspec A/B"
 for impl in fft dft fft dft; do MV_MELSPEC_IMPL=$impl timeout 300 python tools/bench_melspec.py >> $OUT/melspec_ab.log 2>&1; done
 grep impl $OUT/melspec_ab.log
+echo "== res2"; timeout 300 python tools/bench_res2.py > $OUT/res2.log 2>&1; grep res2 $OUT/res2.log
 echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
 echo "== bench"; timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
 tail -2 $OUT/bench.log | cut -c1-3000

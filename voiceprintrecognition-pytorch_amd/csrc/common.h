@@ -90,6 +90,32 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 }
 #endif
 
+// Pointers with their address space stated: two branches that store the same values once to LDS and once to global memory
+// are otherwise tail-merged into ONE flat store behind a selected base pointer.
+#ifdef MV_EMU
+#define MV_AS_LDS(T, p) (p)
+#define MV_AS_GLOBAL(T, p) (p)
+#else
+#define MV_AS_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define MV_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#endif
+
+// value the optimiser must treat as freshly computed here: keeps per-tile addresses from being hoisted out of a loop nest
+// into dozens of long-lived registers
+#ifdef MV_EMU
+#define MV_OPAQUE(x) ((void)0)
+#else
+#define MV_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
+// instruction-order hint for the machine scheduler: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read,
+// 0x200 DS write, 0x020 VMEM read) form one group, groups are emitted in the order the hints are written
+#ifdef MV_EMU
+#define MV_SCHED_GROUP(mask, n) ((void)0)
+#else
+#define MV_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#endif
+
 // 8-byte LDS load that the load/store merger leaves alone (volatile, with the LDS address space stated: a volatile access
 // through a generic pointer would become a flat load)
 __device__ __forceinline__ float2v lds_load_unmerged(const float2v* p) {

@@ -65,7 +65,8 @@ struct FbankArgs {
     float inv_win;
     int remove_dc, use_power, use_log, cmn;
     int64_t L;
-    int tile_in_lds;  // fbank_tile_kernel: the utterance's [T, nbins] block stays in LDS until the time mean is known
+    int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
+                      // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
     FbankTables tab;
 };
 
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     MV_DYN_SMEM(smem);
     float* xbuf = reinterpret_cast<float*>(smem);                  // [FBT_WAVES][FBT_SLOT_FLOATS]
     float* lwin = xbuf + FBT_WAVES * FBT_SLOT_FLOATS;              // [FBT_WIN_FLOATS] 0.5 * window
-    float* tile = lwin + FBT_WIN_FLOATS;                           // [T][nbins] when a.tile_in_lds
+    float* ltw1 = lwin + FBT_WIN_FLOATS;                           // [16 k1][16 n2][2] stage twiddles
+    float* tile = ltw1 + 512;                                      // [tile_rows][nbins]
     float* colsum = xbuf;                                          // [FBT_WAVES][128] then mean[128], after the frame loop
 
     const int tid = threadIdx.x;
@@ -421,9 +423,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     // ---- per-lane constants (registers) ----
     for (int i = tid; i < FBT_WIN_FLOATS; i += THREADS) lwin[i] = a.tab.window_half[i];
     const float* cwin = lwin + 2 * l16;  // 0.5 * window at samples 32 n1 + 2 l16 (+1): one 8-byte LDS read per group
-    float2v ctw1[16];       // W256^(l16 k1) as (cos, sin), k1 = 1..15
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) ctw1[k1] = *reinterpret_cast<const float2v*>(a.tab.tw256 + 2 * (k1 * 16 + l16));
+    for (int i = tid; i < 512; i += THREADS) ltw1[i] = a.tab.tw256[i];
+    const float* ctw1 = ltw1 + 2 * l16;  // W256^(l16 k1) as (cos, sin) at + 32 k1: one 8-byte LDS read per twiddle
     float2v ctw2[8];        // (cos, sin) of pi k / 256 at k = l16 + 16 j
 #pragma unroll
     for (int j = 0; j < 8; ++j) ctw2[j] = *reinterpret_cast<const float2v*>(a.tab.tw512 + 2 * (l16 + 16 * j));
@@ -454,16 +455,15 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int m1 = 4 * (a.tab.pass_gbase[1] + blk / split1) + (lane & 3);
     const bool own0 = m0 < nbins, own1 = m1 < nbins && (blk & (split1 - 1)) == 0;
     float csum0 = 0.0f, csum1 = 0.0f;
-    const bool use_tile = a.tile_in_lds != 0;
+    const int tile_rows = a.tile_rows;
 
     __syncthreads();  // window taps
     const int nquads = (T + 3) >> 2;
-    for (int q = wave; q < nquads; q += FBT_WAVES) {
+    // samples of one quad: lane holds x[32 n1 + 2 l16] (+1) and, for the pre-emphasis, the sample before them
+    auto load_quad = [&](int q, cplx (&e)[NG], float (&eprev)[NG]) {
         const int f_raw = q * 4 + fs;
         const int f = f_raw < T ? f_raw : T - 1;  // surplus slots recompute the last frame; nothing of theirs is kept
         const float* fp = wrow + (int64_t)f * a.shift;
-        cplx e[NG];
-        float eprev[NG];
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
@@ -483,9 +483,22 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
                 } else {
                     v = cmake(fp[i0], fp[i1]);
                 }
-                e[n1] = cmake(idx < a.win ? v[0] : 0.0f, idx + 1 < a.win ? v[1] : 0.0f);
+                e[n1] = v;  // taps beyond the window are zeroed when the group is consumed (a select right behind the load would wait for it)
                 eprev[n1] = fp[i0 > 0 ? i0 - 1 : 0];
             }
+        }
+    };
+    // The next quad's samples are requested as soon as this quad's have been consumed (window stage): their HBM latency runs
+    // under the two FFTs, the post-processing and the mel stage instead of stalling the top of every iteration (two waves
+    // per SIMD cannot hide it: PMC r03b, waves 61 % parked with the VALU 30 % busy).
+    // (two register sets used alternately -- the loop below is unrolled by two -- so the prefetched values are consumed where
+    // the loads put them instead of being copied into loop-carried registers)
+    auto process_quad = [&](int q, cplx (&e)[NG], float (&eprev)[NG], cplx (&e_next)[NG], float (&eprev_next)[NG]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n1 = 0; n1 < NG; ++n1) {
+            const int idx = 32 * n1 + 2 * l16;
+            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            if (!full) e[n1] = cmake(idx < a.win ? e[n1][0] : 0.0f, idx + 1 < a.win ? e[n1][1] : 0.0f);
         }
         // ---- DC removal, pre-emphasis, window (see fbank_kernel) ----
         float dc = 0.0f;
@@ -509,10 +522,14 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         }
 #pragma unroll
         for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
+        if (q + FBT_WAVES < nquads) load_quad(q + FBT_WAVES, e_next, eprev_next);
         // ---- stage 1 + twiddle ----
         fft16(z);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul_conjtw(z[k1], ctw1[k1][0], ctw1[k1][1]);
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const float2v tw = lds_load_unmerged(reinterpret_cast<const float2v*>(ctw1 + 32 * k1));
+            z[k1] = cmul_conjtw(z[k1], tw[0], tw[1]);
+        }
         // ---- the one transpose ----
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) tw_write[k1 * FBT_ROW] = z[k1];
@@ -606,10 +623,9 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         csum0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
         csum1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
         const int row0 = q * 4 * nbins;
-        if (use_tile) {  // uniform: LDS block [t][m] (rows beyond T exist in the block whenever T is not a multiple of 4? no:
-                         // the block has T rows; surplus rows are skipped below)
-            float* d0 = tile + row0 + m0;
-            float* d1 = tile + row0 + m1;
+        if (q * 4 < tile_rows) {  // uniform (tile_rows is a multiple of 4): LDS block [t][m]
+            auto d0 = MV_AS_LDS(float, tile + row0 + m0);
+            auto d1 = MV_AS_LDS(float, tile + row0 + m1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < frames_here) {
@@ -618,8 +634,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
                 }
             }
         } else {
-            float* d0 = orow + row0 + m0;
-            float* d1 = orow + row0 + m1;
+            auto d0 = MV_AS_GLOBAL(float, orow + row0 + m0);
+            auto d1 = MV_AS_GLOBAL(float, orow + row0 + m1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < frames_here) {
@@ -628,10 +644,17 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
                 }
             }
         }
+    };
+    cplx ea[NG], eb[NG];
+    float pa[NG], pb[NG];
+    if (wave < nquads) load_quad(wave, ea, pa);
+    for (int q = wave; q < nquads; q += 2 * FBT_WAVES) {
+        process_quad(q, ea, pa, eb, pb);
+        if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, eb, pb, ea, pa);
     }
 
     const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;
-    if (!second_pass && !use_tile) return;
+    if (!second_pass && tile_rows == 0) return;
 
     // ---- per-utterance time mean (featurizer.py:79) ----
     __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
@@ -655,13 +678,13 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     if (r0 < rows_per_pass) {
         const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
         const float4v zero4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        if (use_tile) {
-            for (int t = r0; t < Tout; t += rows_per_pass) {  // rows T..Tout-1 of a shorter utterance become zeros
-                const float4v raw = t < T ? *(reinterpret_cast<const float4v*>(tile + t * nbins) + cg) : zero4;
-                *(reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg) = t < mask_len ? raw - m4 : zero4;
-            }
-        } else {
-            for (int t = r0; t < Tout; t += rows_per_pass) {
+        int t = r0;
+        for (; t < Tout && t < tile_rows; t += rows_per_pass) {  // rows held in LDS: written to HBM once
+            const float4v raw = t < T ? *(reinterpret_cast<const float4v*>(tile + t * nbins) + cg) : zero4;
+            *(reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg) = t < mask_len ? raw - m4 : zero4;
+        }
+        if (second_pass) {
+            for (; t < Tout; t += rows_per_pass) {  // rows that went through global memory (rows T..Tout-1 of a shorter utterance become zeros)
                 float4v* p = reinterpret_cast<float4v*>(orow + (int64_t)t * nbins) + cg;
                 const float4v raw = t < T ? *p : zero4;
                 *p = t < mask_len ? raw - m4 : zero4;
@@ -768,8 +791,8 @@ static bool fbank_tile_geometry_ok(const MvFbank* h) {
            (h->nbins & 3) == 0 && h->nbins <= 128 && h->win <= mv::FBT_WIN_FLOATS && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
 }
 
-static size_t fbank_tile_lds_bytes(int T, int nbins, bool tile) {
-    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::FBT_WIN_FLOATS + (tile ? (size_t)T * nbins : 0)) * sizeof(float);
+static size_t fbank_tile_fixed_lds_bytes() {
+    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::FBT_WIN_FLOATS + 512) * sizeof(float);
 }
 
 template <int NG, bool V>
@@ -966,14 +989,18 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.use_log = h->cfg.use_log_fbank;
     a.cmn = h->cfg.subtract_time_mean;
     a.L = L;
-    a.tile_in_lds = 0;
+    a.tile_rows = 0;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
     const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
     if (h->tile_kernel) {
-        // the utterance's feature block stays in LDS when it fits next to the wave slots (T <= 298 frames at 80 bins: 3 s of audio)
-        a.tile_in_lds = fbank_tile_lds_bytes((int)T, h->nbins, true) <= 160 * 1024 ? 1 : 0;
-        fbank_tile_launch(B, fbank_tile_lds_bytes((int)T, h->nbins, a.tile_in_lds != 0), static_cast<hipStream_t>(stream), a, vec2);
+        // feature rows that fit next to the wave slots stay in LDS until the time mean is known (288 of the 298 frames of a
+        // 3 s utterance at 80 bins); the rest go through global memory
+        const size_t fixed = fbank_tile_fixed_lds_bytes();
+        const int64_t fit = (int64_t)((160 * 1024 - fixed) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
+        const int64_t need = (T + 3) & ~(int64_t)3;
+        a.tile_rows = (int)(fit < need ? fit : need);
+        fbank_tile_launch(B, fixed + (size_t)a.tile_rows * h->nbins * sizeof(float), static_cast<hipStream_t>(stream), a, vec2);
     } else {
         fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
     }

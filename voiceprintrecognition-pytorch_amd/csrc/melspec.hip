@@ -274,16 +274,17 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
     const int tile_rows = a.tile_rows;  // multiple of 4
 
     const int nquads = (T + 3) >> 2;
-    for (int q = wave; q < nquads; q += MST_WAVES) {
+    // samples of one quad (lane n2 of a frame: x[16 n1 + n2]); first / last frames: reflect padding of torch.stft(center=True),
+    // or zeros beyond the signal without it
+    auto load_quad = [&](int q, float (&raw)[25]) {
         const int f_raw = q * 4 + fs;
         const int f = f_raw < T ? f_raw : T - 1;
         const int64_t start = (int64_t)f * a.hop - a.pad;
-        float v[25];
         if (start >= 0 && start + 400 <= a.L) {
             const float* fp = x + start + l16;
 #pragma unroll
-            for (int n1 = 0; n1 < 25; ++n1) v[n1] = fp[16 * n1] * cwin[n1];
-        } else {  // first / last frames: reflect padding of torch.stft(center=True), or zeros beyond the signal without it
+            for (int n1 = 0; n1 < 25; ++n1) raw[n1] = fp[16 * n1];
+        } else {
 #pragma unroll
             for (int n1 = 0; n1 < 25; ++n1) {
                 int64_t i = start + 16 * n1 + l16;
@@ -291,9 +292,17 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
                     if (i < 0) i = -i;
                     if (i >= a.L) i = 2 * (a.L - 1) - i;
                 }
-                v[n1] = (i >= 0 && i < a.L) ? x[i] * cwin[n1] : 0.0f;
+                raw[n1] = (i >= 0 && i < a.L) ? x[i] : 0.0f;
             }
         }
+    };
+    // the next quad's samples are requested as soon as this quad's are windowed (two register sets, loop unrolled by two):
+    // their latency runs under the transform instead of stalling the top of every iteration
+    auto process_quad = [&](int q, float (&raw)[25], float (&raw_next)[25]) __attribute__((always_inline)) {
+        float v[25];
+#pragma unroll
+        for (int n1 = 0; n1 < 25; ++n1) v[n1] = raw[n1] * cwin[n1];
+        if (q + MST_WAVES < nquads) load_quad(q + MST_WAVES, raw_next);
         // ---- Y[k1], k1 = 0..12: 5 x 5 real DFT (n1 = 5a + b) ----
         float a0[5];
         cplx a1[5], a2[5];
@@ -393,8 +402,8 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
         csum1 += (r1[0] + r1[1]) + (r1[2] + r1[3]);
         const int row0 = q * 4 * nm;
         if (q * 4 < tile_rows) {  // uniform: tile_rows is a multiple of 4
-            float* d0 = tile + row0 + m0;
-            float* d1 = tile + row0 + m1;
+            auto d0 = MV_AS_LDS(float, tile + row0 + m0);
+            auto d1 = MV_AS_LDS(float, tile + row0 + m1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < frames_here) {
@@ -403,8 +412,8 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
                 }
             }
         } else {
-            float* d0 = orow + row0 + m0;
-            float* d1 = orow + row0 + m1;
+            auto d0 = MV_AS_GLOBAL(float, orow + row0 + m0);
+            auto d1 = MV_AS_GLOBAL(float, orow + row0 + m1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (r < frames_here) {
@@ -413,6 +422,12 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
                 }
             }
         }
+    };
+    float ra[25], rb[25];
+    if (wave < nquads) load_quad(wave, ra);
+    for (int q = wave; q < nquads; q += 2 * MST_WAVES) {
+        process_quad(q, ra, rb);
+        if (q + MST_WAVES < nquads) process_quad(q + MST_WAVES, rb, ra);
     }
 
     // ---- per-utterance time mean over ALL frames (featurizer.py:79), mask, single write of the rows held in LDS ----

@@ -24,6 +24,8 @@
 //
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace mv {
@@ -156,21 +158,15 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 r2_glds16(wj + ((int64_t)co * a.k + tap) * a.kpad + c0 + kc * 8, wbuf + buf * R2_WSTAGE_BYTES + tr * 1024);
             }
         };
-        // the next channel group x_{j+1} is requested first (rows clamped, stores predicated): these loads are older than
-        // every weight transfer, so the counted waits of the K loop cover them, and their latency overlaps stage 0's
+        // the next channel group x_{j+1} (rows clamped, stores predicated) is requested when the LAST K stage starts: its
+        // latency runs under that stage's MFMAs and the 40 registers are not held through the whole K loop (which now keeps
+        // two phases of operand fragments in flight).  (Unconditional loads: a select between a load and zero compiles to one
+        // branch + full wait per load; the last step simply re-reads its own group and ignores the values.)
         const bool more = j < a.steps;
-        // (unconditional loads: a select between a load and zero compiles to one branch + full wait per load; the last
-        // step simply re-reads its own group and ignores the values)
         const int next_group = more ? j + 1 : j;
-        half4v xn[MI][R2_NH];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < R2_NH; ++ni) {
-                int t = (nh0 + ni) * 16 + fr;
-                t = t < T ? t : T - 1;
-                xn[mi][ni] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + next_group * WIDTH + (cw * MI + mi) * 16 + 4 * fg);
-            }
+        half4v xn[MI][R2_NH];   // MI == 1: this wave's 4 channels per tile
+        half8v xp[R2_NH];       // MI == 2: 8 consecutive channels per lane (paired layout of the epilogue)
+        const int co8 = (cw * 2 + (fg & 1)) * 16 + 8 * (fg >> 1);
         for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         float4v acc[MI][R2_NH];
 #pragma unroll
@@ -180,7 +176,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         // Weight stages run up to R2_RING-1 ahead of the MFMAs: wait (counted) for stage s, barrier, refill the slot that
         // stage s-1 just released with stage s+3, compute stage s.  One barrier per stage; it also publishes the
         // activation buffer written by the previous step's epilogue.
-        for (int s = 0; s < nstages; ++s) {
+        auto do_stage = [&](int s, auto LAST) __attribute__((always_inline)) {
             const int last_issued = s + R2_RING - 2 < nstages - 1 ? s + R2_RING - 2 : nstages - 1;
             const int younger = last_issued - s;  // stages issued after stage s
             if (younger >= 2) {
@@ -194,40 +190,119 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             r2_lds_barrier();
             R2_TRACE(3);  // barrier passed
             if (s + R2_RING - 1 < nstages) issue_w(s + R2_RING - 1, (s + R2_RING - 1) % R2_RING);
+            if constexpr (decltype(LAST)::value) {
+#pragma unroll
+                for (int ni = 0; ni < R2_NH; ++ni) {
+                    int t = (nh0 + ni) * 16 + fr;
+                    t = t < T ? t : T - 1;
+                    MV_OPAQUE(t);
+                    if constexpr (MI == 2) {
+                        xp[ni] = *reinterpret_cast<const half8v*>(xb + (int64_t)t * a.C + next_group * WIDTH + co8);
+                    } else {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            xn[mi][ni] = *reinterpret_cast<const half4v*>(xb + (int64_t)t * a.C + next_group * WIDTH + (cw * MI + mi) * 16 + 4 * fg);
+                    }
+                }
+            }
             const int buf = s % R2_RING;
             const int tap = s / kstages_per_tap;
             const int c0 = (s - tap * kstages_per_tap) * 64;
             const int row0 = lane_row0 + (tap - half_k) * a.dil + PAD;  // >= 0; row0 + 16 * ni is tile ni's operand row
             const int sw = row0 & (CPR - 1);                            // the same for every tile: 16 rows per tile
             const char* wt = wbuf + buf * R2_WSTAGE_BYTES;
+            // The stage's 2 K halves x 2 groups of 5 time tiles are four phases; the operand reads of phase p + 1 are issued
+            // before the MFMAs of phase p, so an LDS round trip never sits in front of the matrix pipe (the compiler's own
+            // order "reads, wait, MFMAs" per half costs 2.45 k cycles per stage for 1.3 k cycles of matrix work: in-kernel
+            // timeline r02j).  WIDTH is a multiple of 64, so both K halves hold real weights.
+            static_assert(R2_NH % 2 == 0, "time tiles are processed in two groups");
+            constexpr int NG = R2_NH / 2;
+            half8v af[2][MI];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (c0 + kk * 32 < WIDTH) {  // K padding beyond the width holds zeros in the packed weights: skip
-                    half8v af[MI];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int row = (cw * MI + mi) * 16 + fr;
-                        af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
-                    }
-                    // all R2_NH tiles are computed (tiles beyond T read zero rows and are never stored): one address, the
-                    // tiles are immediates
-                    const char* bp = abuf + row0 * ROWB + ((((c0 >> 3) + kk * 4 + fg) ^ sw) << 4);
-                    half8v bf[R2_NH];
-#pragma unroll
-                    for (int ni = 0; ni < R2_NH; ++ni) bf[ni] = *reinterpret_cast<const half8v*>(bp + ni * 16 * ROWB);
-#pragma unroll
-                    for (int ni = 0; ni < R2_NH; ++ni)
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = (cw * MI + mi) * 16 + fr;
+                    af[kk][mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                 }
-            }
-        }
+            const int bchunk = (c0 >> 3) + fg;
+            const char* bp0 = abuf + row0 * ROWB + ((bchunk ^ sw) << 4);
+            const char* bp1 = abuf + row0 * ROWB + (((bchunk + 4) ^ sw) << 4);
+            half8v bq[4][NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bq[0][g] = *reinterpret_cast<const half8v*>(bp0 + g * 16 * ROWB);
+            auto phase = [&](auto PH) __attribute__((always_inline)) {
+                constexpr int ph = decltype(PH)::value;
+                if constexpr (ph < 3) {
+                    const char* bp = ((ph + 1) >> 1) ? bp1 : bp0;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) bq[ph + 1][g] = *reinterpret_cast<const half8v*>(bp + (((ph + 1) & 1) * NG + g) * 16 * ROWB);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi][(ph & 1) * NG + g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ph >> 1][mi], bq[ph][g], acc[mi][(ph & 1) * NG + g], 0, 0, 0);
+                // keep the order written above: NG reads of the next phase, then this phase's MFMAs
+                if constexpr (ph < 3) MV_SCHED_GROUP(0x100, NG);
+                MV_SCHED_GROUP(0x008, NG * MI);
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+        };
+        for (int s = 0; s + 1 < nstages; ++s) do_stage(s, std::false_type{});
+        do_stage(nstages - 1, std::true_type{});  // peeled: the x_{j+1} registers exist from here on only
         R2_TRACE(4);  // last stage's MFMAs issued
         r2_lds_barrier();  // every wave is done with the activation buffer and the weight ring
         R2_TRACE(5);
         // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer,
         //      rows 1..PAD and T-1-PAD..T-2 also into the halo rows that mirror them ----
+        if constexpr (MI == 2) {
+            // The two channel tiles of the wave are paired through v_permlane16_swap: afterwards a lane holds 8 consecutive
+            // channels (even lane rows: tile 0, odd rows: tile 1), so y_j leaves in 16-byte stores (64 contiguous bytes per time
+            // step and wave instead of two rounds of 32), x_{j+1} arrives in 16-byte loads and the next input is one 16-byte LDS
+            // write per tile -- half the store / load / ds_write instructions of the 8-byte form (the epilogue was as long as the
+            // K loop: in-kernel timeline r02j, store-issue bound).
+            float4v bias4[2], scale4[2], shift4[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int co = (cw * 2 + mi) * 16 + 4 * fg;
+                bias4[mi] = *reinterpret_cast<const float4v*>(a.bias[j - 1] + co);
+                scale4[mi] = *reinterpret_cast<const float4v*>(a.scale[j - 1] + co);
+                shift4[mi] = *reinterpret_cast<const float4v*>(a.shift[j - 1] + co);
+            }
+#pragma unroll
+            for (int ni = 0; ni < R2_NH; ++ni) {
+                int t = (nh0 + ni) * 16 + fr;
+                MV_OPAQUE(t);
+                unsigned w[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    half4v hv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = (half_t)r2_clamp_h(fmaxf(acc[mi][ni][r] + bias4[mi][r], 0.0f) * scale4[mi][r] + shift4[mi][r]);
+                    __builtin_memcpy(w[mi], &hv, 8);
+                }
+                row_swap_odd_even(w[0][0], w[1][0]);
+                row_swap_odd_even(w[0][1], w[1][1]);
+                const unsigned o[4] = {w[0][0], w[0][1], w[1][0], w[1][1]};
+                half8v ov;
+                __builtin_memcpy(&ov, o, 16);
+                const half8v hi8 = {(half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f,
+                                    (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f};
+                const half8v nv = __builtin_elementwise_max(__builtin_elementwise_min(ov + xp[ni], hi8), -hi8);
+                if (t < T) {
+                    *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
+                    if (more) {
+                        *reinterpret_cast<half8v*>(abuf + a_off(t + PAD, co8 >> 3)) = nv;
+                        if (t >= 1 && t <= PAD) *reinterpret_cast<half8v*>(abuf + a_off(PAD - t, co8 >> 3)) = nv;
+                        if (t >= T - 1 - PAD && t <= T - 2) *reinterpret_cast<half8v*>(abuf + a_off(2 * (T - 1) - t + PAD, co8 >> 3)) = nv;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int co = (cw * MI + mi) * 16 + 4 * fg;
@@ -259,6 +334,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     }
                 }
             }
+        }
         }
         // the next step's first stage barrier publishes these LDS writes
         R2_TRACE(6);  // epilogue issued
