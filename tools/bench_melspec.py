@@ -7,7 +7,9 @@ import torch
 from mvector import _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 48000
-ms = _hip.MelSpec({})
+import ctypes
+cdll = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else None
+ms = _hip.MelSpec({}, cdll=cdll)
 g = torch.Generator().manual_seed(1234)
 wav = (0.1 * torch.randn([B, L], generator=g)).clamp(-1, 1).cuda()
 for _ in range(5):
@@ -22,5 +24,5 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
 nbytes = B * (L * 4 + out.shape[1] * out.shape[2] * 4)
-print(json.dumps(dict(impl=os.environ.get('MV_MELSPEC_IMPL', 'fft'), tile_kernel=ms.info()['tile_kernel'], B=B, L=L, frames=out.shape[1], us=round(us, 2),
+print(json.dumps(dict(lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), impl=os.environ.get('MV_MELSPEC_IMPL', 'fft'), tile_kernel=ms.info()['tile_kernel'], B=B, L=L, frames=out.shape[1], us=round(us, 2),
                       GBps=round(nbytes / us / 1e3, 1), frac_of_8TBps=round(nbytes / us / 1e3 / 8000, 4))))

@@ -17,6 +17,8 @@ for impl in tile generic; do MV_FBANK_IMPL=$impl timeout 300 python tools/bench_
 MV_FBANK_IMPL=tile timeout 300 python tools/bench_fbank.py 256 160000 >> $OUT/fbank_ab.log 2>&1
 MV_FBANK_IMPL=generic timeout 300 python tools/bench_fbank.py 256 160000 >> $OUT/fbank_ab.log 2>&1
 cat $OUT/fbank_ab.log
+echo "== packed-complex arm"
+for i in 1 2; do MV_PROBE_LIB=$REPO/tools/probe/libmvector_pk.so timeout 300 python tools/bench_fbank.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/fbank_ab.log; MV_PROBE_LIB=$REPO/tools/probe/libmvector_pk.so timeout 300 python tools/bench_melspec.py 2>&1 | grep impl | tee -a $OUT/melspec_ab.log; done
 echo "== melspec A/B"
 for impl in fft dft fft dft; do MV_MELSPEC_IMPL=$impl timeout 300 python tools/bench_melspec.py >> $OUT/melspec_ab.log 2>&1; done
 grep impl $OUT/melspec_ab.log

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
             const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
             if (full) {
                 if (VEC2) {
-                    e[n1] = *reinterpret_cast<const float2v*>(fp + idx);
+                    e[n1] = cload(fp + idx);
                 } else {
                     e[n1] = cmake(fp[idx], fp[idx + 1]);
                 }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
                 const int i0 = idx < a.win ? idx : a.win - 1, i1 = idx + 1 < a.win ? idx + 1 : a.win - 1;
                 cplx v;
                 if (VEC2) {  // win is even: idx < win implies idx + 1 < win
-                    v = *reinterpret_cast<const float2v*>(fp + (idx < a.win ? idx : a.win - 2));
+                    v = cload(fp + (idx < a.win ? idx : a.win - 2));
                 } else {
                     v = cmake(fp[i0], fp[i1]);
                 }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
 #if defined(MV_PROBE) && MV_PROBE == 3   // timing probe: samples from LDS instead of global memory
 #pragma unroll
             for (int n1 = 0; n1 < NG; ++n1) {
-                e[n1] = *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16 + (q & 1));
+                e[n1] = cload(lwin + 32 * n1 + 2 * l16 + (q & 1));
                 eprev[n1] = lwin[32 * n1 + 2 * l16 + 3];
             }
 #else
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
             const cplx prev = cmake(eprev[n1], e[n1][0]);
-            const cplx y = e[n1] - prev * cplx{a.preemph, a.preemph} - cplx{dc, dc};
-            z[n1] = y * *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16);
+            const cplx y = e[n1] - cscale(prev, a.preemph) - cmake(dc, dc);
+            const float2v w2 = *reinterpret_cast<const float2v*>(lwin + 32 * n1 + 2 * l16);
+            z[n1] = cmul_elem(y, w2[0], w2[1]);
         }
 #pragma unroll
         for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
@@ -244,13 +245,12 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         for (int k2 = 0; k2 < 16; ++k2) {
             const int k = l16 + 16 * k2;
             const cplx zp = slot[256 - k];
-            const cplx cs = *reinterpret_cast<const float2v*>(tw512 + 2 * k);
-            const cplx za = z[k2] + zp * cplx{1.0f, -1.0f};  // Z[k] + conj(Z[256-k])
-            const cplx zb = z[k2] - zp * cplx{1.0f, -1.0f};  // Z[k] - conj(Z[256-k])
+            const float2v cs = *reinterpret_cast<const float2v*>(tw512 + 2 * k);
+            const cplx za = z[k2] + cconj(zp);  // Z[k] + conj(Z[256-k])
+            const cplx zb = z[k2] - cconj(zp);  // Z[k] - conj(Z[256-k])
             // 2 X[k] = za - i (c - i s) zb
-            const cplx x2 = za + cswap(zb) * cplx{cs[0], -cs[0]} - zb * cplx{cs[1], cs[1]};
-            const cplx sq = x2 * x2;
-            pw[k2] = 0.25f * (sq[0] + sq[1]);
+            const cplx x2 = za + cmul_elem(cswap(zb), cs[0], -cs[0]) - cscale(zb, cs[1]);
+            pw[k2] = 0.25f * (x2[0] * x2[0] + x2[1] * x2[1]);
         }
         if (!a.use_power) {
 #pragma unroll
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
             if (full) {
                 if (VEC2) {
-                    e[n1] = *reinterpret_cast<const float2v*>(fp + idx);
+                    e[n1] = cload(fp + idx);
                 } else {
                     e[n1] = cmake(fp[idx], fp[idx + 1]);
                 }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
                 const int i0 = idx < a.win ? idx : a.win - 1, i1 = idx + 1 < a.win ? idx + 1 : a.win - 1;
                 cplx v;
                 if (VEC2) {
-                    v = *reinterpret_cast<const float2v*>(fp + (idx < a.win ? idx : a.win - 2));
+                    v = cload(fp + (idx < a.win ? idx : a.win - 2));
                 } else {
                     v = cmake(fp[i0], fp[i1]);
                 }

@@ -7,15 +7,46 @@
 
 namespace mv {
 
-// Complex values are float2 vectors {re, im}: sums, differences and twiddle products map onto the packed fp32 VALU ops
-// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, swaps and sign flips ride on their op_sel / neg modifiers).
+// Complex values {re, im}.  Two spellings of the same arithmetic:
+//   * default: a plain struct -- every operation is scalar fp32 VALU work (v_add / v_mul / v_fma at full rate);
+//   * -DMV_CPLX_PACKED: float2 vectors -- sums, differences and twiddle products become packed fp32 ops (v_pk_add_f32 /
+//     v_pk_mul_f32 / v_pk_fma_f32).  Half the instructions, but PMC on gfx950 (profiles/r03c: 4.05 cycles per VALU instruction
+//     on average in fbank_tile_kernel, a third of them packed) shows the packed forms issuing several times slower than two
+//     scalar ops; kept only as the A/B arm of tools/bench_fbank.py.
+#ifdef MV_CPLX_PACKED
 typedef float2v cplx;
-
 __device__ __forceinline__ cplx cmake(float r, float i) { return cplx{r, i}; }
 __device__ __forceinline__ cplx cswap(cplx a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cplx cscale(cplx a, float s) { return a * cplx{s, s}; }
+__device__ __forceinline__ cplx cconj(cplx a) { return a * cplx{1.0f, -1.0f}; }
 __device__ __forceinline__ cplx mul_mi(cplx a) { return cswap(a) * cplx{1.0f, -1.0f}; }  // a * (-i) = {im, -re}
 // a * (c - i s)
 __device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return a * cplx{c, c} + cswap(a) * cplx{s, -s}; }
+#else
+struct alignas(8) cplx {
+    float re, im;
+    __device__ __forceinline__ float& operator[](int i) { return i == 0 ? re : im; }
+    __device__ __forceinline__ float operator[](int i) const { return i == 0 ? re : im; }
+};
+__device__ __forceinline__ cplx cmake(float r, float i) { return cplx{r, i}; }
+__device__ __forceinline__ cplx operator+(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a) { return cplx{-a.re, -a.im}; }
+__device__ __forceinline__ cplx& operator+=(cplx& a, cplx b) { a = a + b; return a; }
+__device__ __forceinline__ cplx cswap(cplx a) { return cplx{a.im, a.re}; }
+__device__ __forceinline__ cplx cscale(cplx a, float s) { return cplx{a.re * s, a.im * s}; }
+__device__ __forceinline__ cplx cconj(cplx a) { return cplx{a.re, -a.im}; }
+__device__ __forceinline__ cplx mul_mi(cplx a) { return cplx{a.im, -a.re}; }  // a * (-i)
+// a * (c - i s) = (re c + im s) + i (im c - re s)
+__device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return cplx{fmaf(a.im, s, a.re * c), fmaf(-a.re, s, a.im * c)}; }
+#endif
+
+// 8-byte load of two consecutive floats as a complex value; elementwise product (window taps on {x[2n], x[2n+1]})
+__device__ __forceinline__ cplx cload(const float* p) {
+    const float2v v = *reinterpret_cast<const float2v*>(p);
+    return cmake(v[0], v[1]);
+}
+__device__ __forceinline__ cplx cmul_elem(cplx a, float w0, float w1) { return cmake(a[0] * w0, a[1] * w1); }
 
 // multiply by W16^M = exp(-2 pi i M / 16), M compile-time
 template <int M>
@@ -33,8 +64,8 @@ __device__ __forceinline__ cplx mul_w16(cplx a) {
                              1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
                              -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
-    if constexpr (m == 2) return (a + mul_mi(a)) * cplx{C[2], C[2]};     // (1 - i) / sqrt 2
-    if constexpr (m == 6) return (mul_mi(a) - a) * cplx{C[2], C[2]};     // (-1 - i) / sqrt 2
+    if constexpr (m == 2) return cscale(a + mul_mi(a), C[2]);     // (1 - i) / sqrt 2
+    if constexpr (m == 6) return cscale(mul_mi(a) - a, C[2]);     // (-1 - i) / sqrt 2
     return cmul_conjtw(a, C[m], S[m]);
 }
 
@@ -106,7 +137,10 @@ __device__ __forceinline__ float4v fb_mfma4(float a, float b, float4v c) {
 
 // One ds_read_b64 per element: pairs of them would be merged into ds_read2_b64, which moves 128 B per LDS clock where
 // ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS table); a volatile access is left alone by the merger.
-__device__ __forceinline__ cplx lds_read_single(const cplx* p) { return lds_load_unmerged(p); }
+__device__ __forceinline__ cplx lds_read_single(const cplx* p) {
+    const float2v v = lds_load_unmerged(reinterpret_cast<const float2v*>(p));
+    return cmake(v[0], v[1]);
+}
 
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
 

@@ -197,10 +197,10 @@ __device__ __forceinline__ void cdft5(cplx z0, cplx z1, cplx z2, cplx z3, cplx z
     constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;
     const cplx s1 = z1 + z4, e1 = z1 - z4, s2 = z2 + z3, e2 = z2 - z3;
     x[0] = z0 + (s1 + s2);
-    const cplx t1 = z0 + s1 * cplx{C1, C1} + s2 * cplx{C2, C2};
-    const cplx t2 = z0 + s1 * cplx{C2, C2} + s2 * cplx{C1, C1};
-    const cplx u1 = e1 * cplx{S1, S1} + e2 * cplx{S2, S2};
-    const cplx u2 = e1 * cplx{S2, S2} - e2 * cplx{S1, S1};
+    const cplx t1 = z0 + cscale(s1, C1) + cscale(s2, C2);
+    const cplx t2 = z0 + cscale(s1, C2) + cscale(s2, C1);
+    const cplx u1 = cscale(e1, S1) + cscale(e2, S2);
+    const cplx u2 = cscale(e1, S2) - cscale(e2, S1);
     // X[d] = t_d - i u_d, X[5-d] = t_d + i u_d;  -i u = {u.im, -u.re}
     const cplx m1 = mul_mi(u1), m2 = mul_mi(u2);
     x[1] = t1 + m1;
@@ -321,12 +321,12 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
             cplx o[5];
             cdft5(a1[0], a1[1], a1[2], a1[3], a1[4], o);             // c = 1: k1 = 1, 6, 11, 16, 21
             y[1] = o[0]; y[6] = o[1]; y[11] = o[2];
-            y[9] = o[3] * cplx{1.0f, -1.0f};                          // Y[9] = conj Y[16]
-            y[4] = o[4] * cplx{1.0f, -1.0f};                          // Y[4] = conj Y[21]
+            y[9] = cconj(o[3]);                          // Y[9] = conj Y[16]
+            y[4] = cconj(o[4]);                          // Y[4] = conj Y[21]
             cdft5(a2[0], a2[1], a2[2], a2[3], a2[4], o);             // c = 2: k1 = 2, 7, 12, 17, 22
             y[2] = o[0]; y[7] = o[1]; y[12] = o[2];
-            y[8] = o[3] * cplx{1.0f, -1.0f};                          // Y[8] = conj Y[17]
-            y[3] = o[4] * cplx{1.0f, -1.0f};                          // Y[3] = conj Y[22]
+            y[8] = cconj(o[3]);                          // Y[8] = conj Y[17]
+            y[3] = cconj(o[4]);                          // Y[3] = conj Y[22]
         }
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) y[k1] = cmul_conjtw(y[k1], ctw[k1][0], ctw[k1][1]);
