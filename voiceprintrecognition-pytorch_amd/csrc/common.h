@@ -108,6 +108,14 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 #define MV_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
+// a value that is the same in every lane of the wave (wave index, loop counters derived from it), moved to a scalar
+// register so that branches on it are scalar branches instead of exec-masked regions
+#ifdef MV_EMU
+#define MV_UNIFORM(x) (x)
+#else
+#define MV_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 // instruction-order hint for the machine scheduler: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read,
 // 0x200 DS write, 0x020 VMEM read) form one group, groups are emitted in the order the hints are written
 #ifdef MV_EMU

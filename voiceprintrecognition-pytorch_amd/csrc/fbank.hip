@@ -459,8 +459,13 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 
     __syncthreads();  // window taps
     const int nquads = (T + 3) >> 2;
-    // samples of one quad: lane holds x[32 n1 + 2 l16] (+1) and, for the pre-emphasis, the sample before them
-    auto load_quad = [&](int q, cplx (&e)[NG], float (&eprev)[NG]) {
+    // samples of one quad: lane holds {x[j-1], x[j], x[j+1]} at j = 32 n1 + 2 l16 -- the sample pair and, for the
+    // pre-emphasis, the sample before it -- as ONE 12-byte load per group whose three result registers are consumed as
+    // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
+    // 12-byte load and then copy the components out right behind it: a full-latency wait directly after the prefetch was
+    // issued, which is why prefetching showed no gain in r03c.)
+    typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+    auto load_quad = [&](int q, float3u (&r)[NG]) {
         const int f_raw = q * 4 + fs;
         const int f = f_raw < T ? f_raw : T - 1;  // surplus slots recompute the last frame; nothing of theirs is kept
         const float* fp = wrow + (int64_t)f * a.shift;
@@ -468,61 +473,54 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         for (int n1 = 0; n1 < NG; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
             const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
-            if (full) {
-                if (VEC2) {
-                    e[n1] = cload(fp + idx);
-                } else {
-                    e[n1] = cmake(fp[idx], fp[idx + 1]);
-                }
-                eprev[n1] = fp[n1 == 0 ? (idx > 0 ? idx - 1 : 0) : idx - 1];
+            // first group: x[-1] := x[0] (replicate); groups that reach beyond the window: clamped (the row may end with the
+            // frame), their surplus taps are zeroed when the group is consumed
+            int j = idx;
+            if (!full) j = idx < a.win ? idx : a.win - 2;
+            if (n1 == 0) {
+                const int jp = j > 0 ? j - 1 : 0;
+                r[n1] = float3u{fp[jp], fp[j], fp[j + 1]};
             } else {
-                const int i0 = idx < a.win ? idx : a.win - 1, i1 = idx + 1 < a.win ? idx + 1 : a.win - 1;
-                cplx v;
-                if (VEC2) {
-                    v = cload(fp + (idx < a.win ? idx : a.win - 2));
-                } else {
-                    v = cmake(fp[i0], fp[i1]);
-                }
-                e[n1] = v;  // taps beyond the window are zeroed when the group is consumed (a select right behind the load would wait for it)
-                eprev[n1] = fp[i0 > 0 ? i0 - 1 : 0];
+                r[n1] = *reinterpret_cast<const float3u*>(fp + j - 1);
             }
         }
     };
     // The next quad's samples are requested as soon as this quad's have been consumed (window stage): their HBM latency runs
     // under the two FFTs, the post-processing and the mel stage instead of stalling the top of every iteration (two waves
-    // per SIMD cannot hide it: PMC r03b, waves 61 % parked with the VALU 30 % busy).
-    // (two register sets used alternately -- the loop below is unrolled by two -- so the prefetched values are consumed where
-    // the loads put them instead of being copied into loop-carried registers)
-    auto process_quad = [&](int q, cplx (&e)[NG], float (&eprev)[NG], cplx (&e_next)[NG], float (&eprev_next)[NG]) __attribute__((always_inline)) {
+    // per SIMD cannot hide it: PMC r03b, waves 61 % parked with the VALU 30 % busy).  Two register sets used alternately --
+    // the loop below is unrolled by two -- so the prefetched values are consumed where the loads put them.
+    auto process_quad = [&](int q, float3u (&r)[NG], float3u (&r_next)[NG]) __attribute__((always_inline)) {
+        float x0[NG], x1[NG];
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
             const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
-            if (!full) e[n1] = cmake(idx < a.win ? e[n1][0] : 0.0f, idx + 1 < a.win ? e[n1][1] : 0.0f);
+            x0[n1] = full || idx < a.win ? r[n1][1] : 0.0f;
+            x1[n1] = full || idx + 1 < a.win ? r[n1][2] : 0.0f;
         }
         // ---- DC removal, pre-emphasis, window (see fbank_kernel) ----
         float dc = 0.0f;
         if (a.remove_dc) {
-            float s0 = 0.0f, s1 = 0.0f;  // scalar: the 12-byte loads leave (x[j], x[j+1]) on odd register pairs
+            float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
             for (int n1 = 0; n1 < NG; ++n1) {
-                s0 += e[n1][0];
-                s1 += e[n1][1];
+                s0 += x0[n1];
+                s1 += x1[n1];
             }
             dc = row16_sum(s0 + s1) * a.inv_win * (1.0f - a.preemph);
         }
         cplx z[16];
         const float npre = -a.preemph;
 #pragma unroll
-        for (int n1 = 0; n1 < NG; ++n1) {  // scalar on purpose: pairing (x[j-1], x[j]) for a packed op would cost two moves
+        for (int n1 = 0; n1 < NG; ++n1) {
             const float2v w2 = lds_load_unmerged(reinterpret_cast<const float2v*>(cwin + 32 * n1));
-            const float y0 = fmaf(npre, eprev[n1], e[n1][0]) - dc;
-            const float y1 = fmaf(npre, e[n1][0], e[n1][1]) - dc;
+            const float y0 = fmaf(npre, r[n1][0], x0[n1]) - dc;   // taps beyond the window meet a zero weight
+            const float y1 = fmaf(npre, x0[n1], x1[n1]) - dc;
             z[n1] = cmake(y0 * w2[0], y1 * w2[1]);
         }
 #pragma unroll
         for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
-        if (q + FBT_WAVES < nquads) load_quad(q + FBT_WAVES, e_next, eprev_next);
+        if (q + FBT_WAVES < nquads) load_quad(q + FBT_WAVES, r_next);
         // ---- stage 1 + twiddle ----
         fft16(z);
 #pragma unroll
@@ -645,12 +643,11 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             }
         }
     };
-    cplx ea[NG], eb[NG];
-    float pa[NG], pb[NG];
-    if (wave < nquads) load_quad(wave, ea, pa);
+    float3u ra[NG], rb[NG];
+    if (wave < nquads) load_quad(wave, ra);
     for (int q = wave; q < nquads; q += 2 * FBT_WAVES) {
-        process_quad(q, ea, pa, eb, pb);
-        if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, eb, pb, ea, pa);
+        process_quad(q, ra, rb);
+        if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, rb, ra);
     }
 
     const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;

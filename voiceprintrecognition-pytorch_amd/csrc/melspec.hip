@@ -280,7 +280,12 @@ __global__ __launch_bounds__(MST_WAVES * 64) void melspec_tile_kernel(MelTileArg
         const int f_raw = q * 4 + fs;
         const int f = f_raw < T ? f_raw : T - 1;
         const int64_t start = (int64_t)f * a.hop - a.pad;
-        if (start >= 0 && start + 400 <= a.L) {
+        // one decision for the wave's four frames (consecutive frames: first and last decide), on a scalar: a per-lane
+        // branch would emit both paths behind exec masks and make the edge path wait for every interior load it overwrites
+        const int qs = MV_UNIFORM(q);
+        const int f_last = qs * 4 + 3 < T ? qs * 4 + 3 : T - 1;
+        const bool interior = (int64_t)qs * 4 * a.hop - a.pad >= 0 && (int64_t)f_last * a.hop - a.pad + 400 <= a.L;
+        if (interior) {
             const float* fp = x + start + l16;
 #pragma unroll
             for (int n1 = 0; n1 < 25; ++n1) raw[n1] = fp[16 * n1];
