@@ -13,8 +13,11 @@ def load_case(case):
     from oracle import weights
     with open(os.path.join(GOLDEN, f'manifest_{case}.json')) as f:
         man = json.load(f)
-    sd = weights.make_state_dict(man['shapes'], man['seed'], man.get('bn_gain', 1.0))
+    sd = weights.make_state_dict(man['shapes'], man['seed'], man.get('bn_gain', 1.0), stress=man.get('stress', False))
     z = np.load(os.path.join(GOLDEN, f'{case}.npz'))
+    for k in z.files:  # calibrated BatchNorm statistics of the stress cases travel in the fixture
+        if k.startswith('bn:'):
+            sd[k[3:].replace('/', '.')] = torch.from_numpy(z[k])
     return man, sd, torch.from_numpy(z['x']), torch.from_numpy(z['emb']), z
 
 

@@ -216,6 +216,17 @@ def test_gpu_native_model_matches_reference_golden(case):
     assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
 
 
+@pytest.mark.parametrize('case', ['ecapa_stress', 'campp_stress'])
+def test_gpu_fp16_backbones_stress_golden(case):
+    """fp16 stress: conv output channels scaled over 10^-1.5 .. 10^0.5, BatchNorm gains up to 3, running
+    statistics calibrated by the reference in training mode (running_var from 0 -- dead ReLU channels -- to ~80, median
+    ~0.1).  The embeddings come from the reference modules (fp32 vs fp64 of the reference itself: 1e-10); the fp16 path has
+    to stay inside the same 1e-4 bar, and the margin is printed."""
+    cd, rel = lc.model_case(product_lib(), DEV, case)
+    print(f'{case}: 1 - cos = {cd:.3e} (bar 1e-4, margin x{1e-4 / max(cd, 1e-30):.0f}), max rel err {rel:.3e}')
+    assert cd < 1e-4, (cd, rel)
+
+
 @pytest.mark.parametrize('case', ['eres2net_tiny', 'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32', 'eres2netv2_w96s4'])
 def test_gpu_eres2net_matches_reference_golden(case):
     """ERes2Net / ERes2NetV2: fp32 operands, so far inside the 1e-4 bar."""
@@ -340,6 +351,100 @@ def test_gpu_predictor_matches_cpu_predictor(tmp_path):
     assert cos_dist(e_gpu, e_cpu).max() < 1e-4
     assert cos_dist(one, cpu.predict(paths[1])).max() < 1e-4
     assert abs(c_gpu - cpu.contrast(paths[0], paths[2])) < 1e-3
+
+
+def _predictor_fixture(tmp_path, ragged=True):
+    import scipy.io.wavfile as wavfile
+    man, sd, _, _, _ = load_case('tdnn')
+    model_dir = tmp_path / 'model'
+    model_dir.mkdir()
+    torch.save({'0.' + k: v for k, v in sd.items()}, str(model_dir / 'model.pth'))
+    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    paths, pcms = [], []
+    for i, pcm in enumerate(z['pcm16']):
+        p = str(tmp_path / f'u{i}.wav')
+        cut = pcm[: 16000 - (1500 * i if ragged else 0)]
+        wavfile.write(p, 16000, cut)
+        paths.append(p)
+        pcms.append(cut)
+    cfg = dict(dataset_conf=dict(dataset=dict(min_duration=0.3, sample_rate=16000, use_dB_normalization=True, target_dB=-20),
+                                 eval_conf=dict(batch_size=2)),
+               preprocess_conf=dict(feature_method='Fbank', method_args=dict(sample_frequency=16000, num_mel_bins=80)),
+               model_conf=dict(model='TDNN', model_args=dict(embd_dim=192)))
+    return cfg, str(model_dir), paths, pcms, sd
+
+
+def _oracle_predict_batch(sd, pcms, target_db=-20.0):
+    """the reference's predict_batch semantics restated with oracle pieces: int16 -> float, dB normalisation over the true
+    length, zero padding to the batch maximum, length ratios, Fbank + CMN over the padded frames + mask, TDNN forward
+    (predict.py:185-212, 231-265)"""
+    n = torch.tensor([len(p) for p in pcms])
+    longest = int(n.max())
+    staged = torch.zeros(len(pcms), longest, dtype=torch.int16)
+    for i, p in enumerate(pcms):
+        staged[i, :len(p)] = torch.from_numpy(np.ascontiguousarray(p))
+    wav, _ = frontend.wave_prepare(staged, n, target_db)
+    ratio = n.float() / longest
+    return omodels.tdnn(sd, frontend.audio_featurizer(wav, ratio, 'Fbank', FB)).numpy()
+
+
+def test_gpu_predictor_matches_oracle(tmp_path):
+    """MVectorPredictor(use_gpu=True) against the ORACLE directly (not against the package's CPU predictor): predict_batch on a
+    ragged batch (int16 upload path and host path), predict, contrast."""
+    from mvector.predict import MVectorPredictor
+    cfg, model_dir, paths, pcms, sd = _predictor_fixture(tmp_path)
+    gpu = MVectorPredictor(cfg, model_path=model_dir, use_gpu=True)
+    want = _oracle_predict_batch(sd, pcms)
+    got = gpu.predict_batch(paths)
+    assert gpu._last_batch_path == 'pcm16' and got.shape == (4, 192)
+    assert cos_dist(got, want).max() < 1e-4, cos_dist(got, want).max()
+    floats = [p.astype(np.float32) / 32768.0 for p in pcms]
+    assert cos_dist(gpu.predict_batch(floats), want).max() < 1e-4 and gpu._last_batch_path == 'host'
+    single = _oracle_predict_batch(sd, [pcms[1]])[0]
+    assert cos_dist(gpu.predict(paths[1]), single).max() < 1e-4
+    a, b = _oracle_predict_batch(sd, [pcms[0]])[0], _oracle_predict_batch(sd, [pcms[2]])[0]
+    assert abs(gpu.contrast(paths[0], paths[2]) - scoring.contrast(a, b)) < 1e-3
+
+
+def test_gpu_register_recognition_remove_user_device_gallery(tmp_path):
+    """f4: enrolment matrix resident on the GPU (per-user sums, updated in place), recognition through mv_cosine_f32 without
+    re-uploading it; register -> recognition -> remove_user against the oracle's retrieval (predict.py:169-183, 281-363)."""
+    from mvector.predict import MVectorPredictor
+    cfg, model_dir, paths, pcms, sd = _predictor_fixture(tmp_path, ragged=False)
+    db = tmp_path / 'audio_db'
+    p = MVectorPredictor(cfg, threshold=0.3, audio_db_path=str(db), model_path=model_dir, use_gpu=True)
+    dg = p._device_gallery
+    assert dg is not None and dg.matrix().is_cuda and dg.matrix().shape == (0, 192)
+    emb = [_oracle_predict_batch(sd, [pcm])[0] for pcm in pcms]
+    assert p.register(paths[0], 'alice') == (True, '注册成功') and p.register(paths[2], 'bob')[0] and p.register(paths[1], 'alice')[0]
+    assert dg.users == ['alice', 'bob'] and dg.uploads == 0   # embeddings went from the backbone into the matrix on the device
+    means = np.stack([(emb[0] + emb[1]) / 2, emb[2]])
+    for q in (1, 3):
+        want = scoring.retrieval(emb[q][None], means, ['alice', 'bob'], 0.3)[0]
+        got = p.recognition(paths[q])
+        assert got[0] == want[0] and abs(got[1] - want[1]) < 2e-3, (got, want)
+    assert dg.uploads == 0                                     # recognition re-uploaded nothing
+    sums = dg.matrix().cpu().numpy()
+    assert cos_dist(sums, means).max() < 1e-4                  # sums and means point the same way
+    assert p.remove_user('alice') and dg.users == ['bob'] and p.get_users() == ['bob']
+    got = p.recognition(paths[0])
+    want = scoring.retrieval(emb[0][None], means[1:], ['bob'], 0.3)[0]
+    assert got[0] == want[0] and (got[1] is None or abs(got[1] - want[1]) < 2e-3)
+    # a fresh predictor rebuilds the resident matrix from audio_indexes.bin with ONE upload
+    p2 = MVectorPredictor(cfg, threshold=0.3, audio_db_path=str(db), model_path=model_dir, use_gpu=True)
+    assert p2._device_gallery.users == ['bob'] and p2._device_gallery.uploads == 1
+    assert p2.recognition(paths[2])[0] == 'bob'
+
+
+def test_gpu_cosine_more_than_a_million_rows():
+    """evaluation score matrices beyond 65535 row tiles: rows go in chunks inside mv_cosine_f32"""
+    from mvector import _hip
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(65535 * 16 + 40, 8, generator=g).to(DEV)
+    b = torch.randn(3, 8, generator=g).to(DEV)
+    s = _hip.cosine(a, b)
+    ref = torch.nn.functional.normalize(a, dim=1) @ torch.nn.functional.normalize(b, dim=1).t()
+    assert s.shape == (65535 * 16 + 40, 3) and (s - ref).abs().max().item() < 2e-6
 
 
 def test_gpu_melspec_golden_and_variants():

@@ -324,3 +324,24 @@ def test_native_handle_cache_is_not_part_of_module_state(tmp_path):
         assert m._use_native(fxg) is True
     m.train()
     assert m._use_native(fx) is False and '_native_handles' in m.__dict__ and not m.__dict__['_native_handles']
+
+
+def test_device_gallery_sums_grow_and_remove_on_cpu_tensors():
+    """DeviceGallery bookkeeping (the GPU-resident enrolment matrix of the HIP predictor), exercised on CPU tensors: per-user
+    sums point the same way as the reference's per-user means, growth keeps rows, removal keeps the order of the others."""
+    from mvector.infer_utils.gallery import DeviceGallery
+    rng = np.random.default_rng(0)
+    dg = DeviceGallery(torch.device('cpu'), 6, capacity=2)
+    rows = {f'u{i}': [rng.normal(size=6).astype(np.float32) for _ in range(1 + i % 3)] for i in range(7)}
+    for name, rs in rows.items():
+        for r in rs:
+            dg.add(name, torch.from_numpy(r))
+    assert dg.users == list(rows) and dg.matrix().shape == (7, 6) and dg.sums.shape[0] >= 7
+    for i, name in enumerate(rows):
+        mean = np.mean(rows[name], axis=0)
+        assert abs(scoring.contrast(dg.matrix()[i].numpy(), mean) - 1.0) < 1e-6
+    assert dg.remove('u2') and not dg.remove('u2')
+    assert dg.users == ['u0', 'u1', 'u3', 'u4', 'u5', 'u6']
+    assert np.allclose(dg.matrix()[2].numpy(), np.sum(rows['u3'], axis=0), atol=1e-6)
+    dg.add('u2', rows['u2'][0])  # numpy row: one upload, new last row
+    assert dg.users[-1] == 'u2' and dg.uploads == 0  # same device: nothing to move

@@ -7,6 +7,11 @@ On disk it is the reference's layout, so galleries are interchangeable (mvector/
 
 In memory: one row per enrolled audio plus running per-user sums, from which the matrix of per-user mean embeddings that
 recognition scores against is rebuilt lazily (the reference re-stacks numpy arrays on every change).
+
+``DeviceGallery`` is the GPU-resident mirror the HIP predictor scores against: one fp32 row of per-user embedding SUMS per
+user in a device matrix that grows geometrically; enrolling an audio adds one row in place (``index_add_``), so the
+matrix is never re-uploaded.  Cosine similarity ignores the scale of a row, so scoring against the sums equals scoring
+against the reference's per-user means (predict.py:142-151, 165-183).
 """
 import os
 import pickle
@@ -93,3 +98,68 @@ class SpeakerGallery:
 
     def __len__(self):
         return len(self.names)
+
+
+class DeviceGallery:
+    """Per-user embedding sums resident on the device (see the module docstring); mirrors a SpeakerGallery."""
+
+    def __init__(self, device, dim, capacity=64):
+        import torch
+        self.device = device
+        self.users = []                       # row index -> user name (first-enrolment order)
+        self._row_of = {}
+        self.sums = torch.zeros((capacity, dim), dtype=torch.float32, device=device)
+        self.uploads = 0                      # host -> device row transfers (tests: recognition must not add any)
+
+    @classmethod
+    def from_gallery(cls, gallery, device, dim):
+        dg = cls(device, dim, capacity=max(64, 2 * len(set(gallery.names))))
+        import torch
+        if len(gallery):
+            rows = torch.from_numpy(np.stack(gallery.rows)).to(device)  # one upload of the whole index
+            dg.uploads += 1
+            for name in gallery.names:
+                dg._row(name)
+            idx = torch.tensor([dg._row_of[n] for n in gallery.names], dtype=torch.int64, device=device)
+            dg.sums.index_add_(0, idx, rows)
+        return dg
+
+    def _row(self, name):
+        import torch
+        r = self._row_of.get(name)
+        if r is None:
+            r = len(self.users)
+            if r == self.sums.shape[0]:   # grow geometrically, on the device
+                bigger = torch.zeros((2 * r, self.sums.shape[1]), dtype=torch.float32, device=self.device)
+                bigger[:r] = self.sums
+                self.sums = bigger
+            self.users.append(name)
+            self._row_of[name] = r
+        return r
+
+    def add(self, name, embedding):
+        """embedding: 1-D device tensor (stays on the device) or array (one row upload)"""
+        import torch
+        if not torch.is_tensor(embedding):
+            embedding = torch.as_tensor(np.asarray(embedding, dtype=np.float32))
+        if embedding.device != self.sums.device:
+            embedding = embedding.to(self.device)
+            self.uploads += 1
+        r = self._row(name)  # first: a new user may replace self.sums by a bigger matrix
+        self.sums[r] += embedding.reshape(-1).float()
+
+    def remove(self, name):
+        """drop a user: the rows behind it move up (device-side copy), order of the others is kept"""
+        r = self._row_of.pop(name, None)
+        if r is None:
+            return False
+        n = len(self.users)
+        if r < n - 1:
+            self.sums[r:n - 1] = self.sums[r + 1:n].clone()
+        self.sums[n - 1].zero_()
+        del self.users[r]
+        self._row_of = {u: i for i, u in enumerate(self.users)}
+        return True
+
+    def matrix(self):
+        return self.sums[:len(self.users)]

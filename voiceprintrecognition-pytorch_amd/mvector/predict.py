@@ -80,6 +80,11 @@ class MVectorPredictor:
         users, _ = self._gallery.user_means()
         if users:
             logger.info(f'声纹库数据加载完成，一共有{len(users)}个用户，分别是：{users}')
+        self._device_gallery = None
+        if self.device.type == 'cuda':
+            # GPU-resident enrolment matrix (per-user sums): recognition scores against it without re-uploading anything
+            from mvector.infer_utils.gallery import DeviceGallery
+            self._device_gallery = DeviceGallery.from_gallery(self._gallery, self.device, self.predictor[0].embd_dim)
 
     # ------------------------------------------------------------------ scoring
     @staticmethod
@@ -96,9 +101,16 @@ class MVectorPredictor:
         return self.normalize_features(queries) @ self.normalize_features(gallery).T
 
     def _best_matches(self, embeddings):
-        """[name, score] of the best enrolled user per query row, or [None, None] below the threshold."""
-        users, means = self._gallery.user_means()
-        scores = self._cosine(np.atleast_2d(np.asarray(embeddings, dtype=np.float32)), means)
+        """[name, score] of the best enrolled user per query row, or [None, None] below the threshold.  ``embeddings``: array
+        or (GPU predictor) a device tensor, which is scored against the device-resident gallery through mv_cosine_f32."""
+        if getattr(self, '_device_gallery', None) is not None:
+            from mvector import _hip
+            users = self._device_gallery.users
+            q = embeddings if torch.is_tensor(embeddings) else torch.as_tensor(np.atleast_2d(np.asarray(embeddings, dtype=np.float32)))
+            scores = _hip.cosine(q.to(self.device).reshape(-1, q.shape[-1]), self._device_gallery.matrix()).cpu().numpy()
+        else:
+            users, means = self._gallery.user_means()
+            scores = self._cosine(np.atleast_2d(np.asarray(embeddings, dtype=np.float32)), means)
         out = []
         for row in scores:
             best = int(np.argmax(row))
@@ -129,12 +141,15 @@ class MVectorPredictor:
 
     # ------------------------------------------------------------------ embedding extraction (the hot path)
     @torch.no_grad()
-    def predict(self, audio_data, sample_rate=16000):
-        """预测一个音频的特征 -> np.ndarray [embd_dim]"""
+    def _embed(self, audio_data, sample_rate=16000):
+        """one utterance -> embedding tensor [1, embd_dim] on the predictor's device"""
         input_data = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
         wav = torch.tensor(input_data.samples, dtype=torch.float32).unsqueeze(0).to(self.device)
-        audio_feature = self._audio_featurizer(wav)
-        return self.predictor(audio_feature).data.cpu().numpy()[0]
+        return self.predictor(self._audio_featurizer(wav)).data
+
+    def predict(self, audio_data, sample_rate=16000):
+        """预测一个音频的特征 -> np.ndarray [embd_dim]"""
+        return self._embed(audio_data, sample_rate).cpu().numpy()[0]
 
     def _pcm16_batch(self, audios_data):
         """Raw int16 mono PCM at the configured rate for EVERY item (paths / bytes of 16-bit mono WAVs), else None.
@@ -211,25 +226,30 @@ class MVectorPredictor:
     def register(self, audio_data, user_name: str, sample_rate=16000):
         """声纹注册"""
         audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
-        embedding = self.predict(audio_data=audio_segment)
+        emb = self._embed(audio_segment)
         audio_path = self._gallery.next_audio_path(user_name)
         audio_segment.to_wav_file(audio_path)
-        self._gallery.add(user_name, audio_path, embedding)
+        self._gallery.add(user_name, audio_path, emb.cpu().numpy()[0])
         self._gallery.save()
+        if getattr(self, '_device_gallery', None) is not None:
+            self._device_gallery.add(user_name, emb[0])  # the embedding never leaves the device for the resident matrix
         return True, "注册成功"
 
     def recognition(self, audio_data, threshold=None, sample_rate=16000):
         """声纹识别 -> [user name or None, score or None]"""
         if threshold:
             self.threshold = threshold
-        return self._best_matches(self.predict(audio_data, sample_rate=sample_rate))[0]
+        return self._best_matches(self._embed(audio_data, sample_rate=sample_rate))[0]
 
     def get_users(self):
         """One entry per enrolled audio, as the reference returns its ``users_name`` list."""
         return list(self._gallery.names)
 
     def remove_user(self, user_name):
-        return self._gallery.remove(user_name)
+        ok = self._gallery.remove(user_name)
+        if ok and getattr(self, '_device_gallery', None) is not None:
+            self._device_gallery.remove(user_name)
+        return ok
 
     def speaker_diarization(self, audio_data, sample_rate=16000, speaker_num=None, search_audio_db=False):
         """说话人日志: VAD segmentation and spectral clustering are host post-processing of the reference
