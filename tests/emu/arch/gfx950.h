@@ -1,0 +1,119 @@
+// Host C++ spellings of csrc/arch/gfx950.h for the SIMT emulator (tests/emu/hip_emu.h, force-included before this file).
+// TEST INFRASTRUCTURE ONLY: the emulator build puts tests/emu in front of csrc on the include path, so the kernels'
+// #include <arch/gfx950.h> finds this file; the product build never sees it.  Same names, same semantics, lane-exact.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#define MV_LAUNCH(kernel, grid, block, shmem, stream, ...) emu::launch(dim3 grid, dim3 block, (shmem), [=]() { kernel(__VA_ARGS__); })
+#define MV_DYN_SMEM(name) char* name = MV_EMU_DYN_SMEM()
+#define MV_SET_MAX_SMEM(kernel, bytes) hipSuccess
+#define MV_WAVE_FENCE() emu::wave_sync()
+#define MV_AS_LDS(T, p) (p)
+#define MV_AS_GLOBAL(T, p) (p)
+#define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)
+#define MV_OPAQUE(x) ((void)0)
+#define MV_UNIFORM(x) (x)
+#define MV_SCHED_GROUP(mask, n) ((void)0)
+
+// hipEvent shim for the optional launch profiling (capi.cpp): events are no-ops, elapsed time is zero
+typedef void* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
+
+namespace mv {
+
+template <int CTRL>
+inline float dpp_mov(float old, float src) {
+    const int lane = emu::flat_tid() & 63;
+    int from = lane;
+    bool has = true;
+    if (CTRL < 0x100) {
+        from = (lane & ~3) | ((CTRL >> (2 * (lane & 3))) & 3);
+    } else if (CTRL > 0x100 && CTRL < 0x110) {  // row_shl:n -- lane i reads lane i + n of its row
+        has = (lane & 15) + (CTRL - 0x100) <= 15;
+        from = has ? lane + (CTRL - 0x100) : lane;
+    } else if (CTRL > 0x110 && CTRL < 0x120) {  // row_shr:n -- lane i reads lane i - n
+        has = (lane & 15) >= (CTRL - 0x110);
+        from = has ? lane - (CTRL - 0x110) : lane;
+    } else if (CTRL > 0x120 && CTRL < 0x130) {  // row_ror:n
+        from = (lane & ~15) | ((lane - (CTRL - 0x120)) & 15);
+    } else if (CTRL == 0x140) {
+        from = (lane & ~15) | (15 - (lane & 15));
+    } else if (CTRL == 0x141) {
+        from = (lane & ~7) | (7 - (lane & 7));
+    }
+    const float v = emu::shfl_from(src, from);
+    return has ? v : old;
+}
+template <int CTRL>
+inline float dpp_mov_all(float src) { return dpp_mov<CTRL>(src, src); }
+inline void row_swap_odd_even(unsigned& x, unsigned& y) {
+    const int lane = emu::flat_tid() & 63;
+    const bool odd = (lane >> 4) & 1;
+    const unsigned from_y = emu::shfl_from(y, lane - 16), from_x = emu::shfl_from(x, lane + 16);  // out-of-row sources are unused
+    const unsigned nx = odd ? from_y : x, ny = odd ? y : from_x;
+    x = nx;
+    y = ny;
+}
+
+inline float fmed3(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+inline float max_raw(float v, float lo) { return fmaxf(v, lo); }
+inline float exp2_fast(float v) { return exp2f(v); }
+inline float log2_fast(float v) { return log2f(v); }
+inline float4v mfma_4x4x1(float a, float b, float4v c) {  // D[lane][r] += A[4 * (lane / 4) + r] * B[lane]
+    const int lane = emu::flat_tid() & 63;
+    memcpy(emu::wave_slot(0, lane), &a, 4);
+    emu::wave_sync();
+    for (int r = 0; r < 4; ++r) {
+        float av;
+        memcpy(&av, emu::wave_slot(0, (lane & ~3) + r), 4);
+        c[r] = fmaf(av, b, c[r]);
+    }
+    emu::wave_sync();
+    return c;
+}
+
+inline float2v lds_load_unmerged(const float2v* p) { return *p; }
+// "LDS byte address": offset from the start of the emulated block's dynamic LDS
+inline unsigned lds_addr(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - MV_EMU_DYN_SMEM()); }
+inline const char* lds_ptr(unsigned addr) { return MV_EMU_DYN_SMEM() + addr; }
+typedef const half_t* lds_half_ptr;
+inline lds_half_ptr lds_opaque_half_ptr(const half_t* p) { return p; }
+inline half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *reinterpret_cast<const half8v*>(p + elem_off); }
+inline void glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16); }
+template <int N>
+inline void wait_vm() {}
+inline void lds_barrier() { __syncthreads(); }
+
+template <int WAIT>
+inline void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
+    for (int i = 0; i < 4; ++i) c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
+    for (int i = 0; i < 4; ++i) c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
+}
+template <int OFF0, int OFF1>
+inline void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
+    d0 = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF0));
+    d1 = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF1));
+}
+inline void lds_read4(half8v (&d)[4], unsigned addr) {
+    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 2048 * i));
+}
+inline void mfma_hazard_pad() {}
+inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }
+
+inline int device_cu_count() { return 8; }
+
+}  // namespace mv

@@ -15,7 +15,7 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 def build(verbose=False):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
-    deps = srcs + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip_emu.h'),
+    deps = srcs + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip_emu.h'), os.path.join(HERE, 'arch', 'gfx950.h'),
                                                                    os.path.join(ROOT, 'include', 'mvector_hip.h')]
     h = hashlib.sha1()
     for d in deps:
@@ -28,7 +28,8 @@ def build(verbose=False):
     procs = []
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s) + '.o')
-        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-DMV_EMU', '-include',
+        # tests/emu in front of csrc on the include path: <arch/gfx950.h> resolves to the emulator's host spellings
+        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-I', HERE, '-I', CSRC, '-include',
                os.path.join(HERE, 'hip_emu.h'), '-Wno-unused-value', '-c', s, '-o', o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)

@@ -14,7 +14,7 @@ OUT_DIR = os.path.join(HERE, 'mvector', 'lib')
 OBJ_DIR = os.path.join(HERE, 'build')
 LIB = os.path.join(OUT_DIR, 'libmvector_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG', '-I', CSRC]  # <arch/gfx950.h> = csrc/arch
 
 
 def _file_flags(path):
@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
-    headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'mvector_hip.h')]
+    headers = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + sorted(glob.glob(os.path.join(CSRC, 'arch', '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'mvector_hip.h')]
     hdr_digest = _digest(headers)
     procs, objs = [], []
     for s in srcs:

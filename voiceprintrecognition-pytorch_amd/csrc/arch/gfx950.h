@@ -1,0 +1,159 @@
+// gfx950 (MI355X / CDNA4) spellings of everything in csrc/ that is not plain HIP C++: launch macros, DPP / permlane lane
+// moves, LDS-DMA, counted waits, inline-assembly MFMA steps, address-space qualified accesses.  The kernels include this
+// file as <arch/gfx950.h>; the test-suite's SIMT emulator (tests/emu) puts a header of the same name with host C++
+// spellings of the same functions in front of it on the include path, so no kernel source carries an #ifdef.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#define MV_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3 grid, dim3 block, (shmem), (stream), __VA_ARGS__)
+#define MV_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// dynamic LDS above 64 KiB has to be requested per kernel
+#define MV_SET_MAX_SMEM(kernel, bytes) \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+// LDS traffic between lanes of ONE wave: DS ops of a wave execute in program order, so only the compiler has to be kept
+// from reordering across this point.
+#define MV_WAVE_FENCE()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+// Pointers with their address space stated: two branches that store the same values once to LDS and once to global memory
+// are otherwise tail-merged into ONE flat store behind a selected base pointer; pointer selects between a tensor and the zero
+// page lose the address space too (flat loads).
+#define MV_AS_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define MV_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+// value the optimiser must treat as freshly computed here: keeps per-tile addresses from being hoisted out of a loop nest
+// into dozens of long-lived registers
+#define MV_OPAQUE(x) asm volatile("" : "+v"(x))
+// a value that is the same in every lane of the wave, moved to a scalar register so that branches on it are scalar branches
+#define MV_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// instruction-order hint for the machine scheduler: the next `n` instructions of class `mask` (0x008 MFMA, 0x100 DS read,
+// 0x200 DS write, 0x020 VMEM read) form one group, groups are emitted in the order the hints are written
+#define MV_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+
+namespace mv {
+
+// ---- lane moves ----------------------------------------------------------------------------------------------------------
+// DPP moves inside rows of 16 lanes (VALU, no LDS traffic).  CTRL is the hardware dpp_ctrl value: 0x00..0xFF quad_perm,
+// 0x100+n row_shl:n (lane i reads lane i+n), 0x110+n row_shr:n (lane i reads lane i-n), 0x120+n row_ror:n, 0x140 row_mirror,
+// 0x141 row_half_mirror.  Lanes without a source lane keep `old`.  (Checked on the device: tools/dpp_probe.hip.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                                 0xf, 0xf, false));
+}
+// for patterns in which every lane has a source lane (mirror, rotate, quad_perm): no `old` operand to initialise
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_all(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
+// v_permlane16_swap: the odd 16-lane rows of x trade places with the even rows of y
+//   x: row1 <- y.row0, row3 <- y.row2      y: row0 <- x.row1, row2 <- x.row3      (tools/permlane_probe.hip)
+__device__ __forceinline__ void row_swap_odd_even(unsigned& x, unsigned& y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// ---- arithmetic with a single-instruction spelling ---------------------------------------------------------------------------
+__device__ __forceinline__ float fmed3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+// max(v, lo) as exactly one v_max_f32: fmaxf / v_med3 against +inf are lowered to a canonicalising v_max v, v, v plus the
+// max itself, which doubled the activation cost of the 128-value epilogues
+__device__ __forceinline__ float max_raw(float v, float lo) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+    return r;
+}
+__device__ __forceinline__ float exp2_fast(float v) { return __builtin_amdgcn_exp2f(v); }  // v_exp_f32
+__device__ __forceinline__ float log2_fast(float v) { return __builtin_amdgcn_logf(v); }   // v_log_f32, normal inputs only
+// v_mfma_f32_4x4x1: 16 independent 4 x 4 outer products; D[lane][r] += A[4 * (lane / 4) + r] * B[lane]
+__device__ __forceinline__ float4v mfma_4x4x1(float a, float b, float4v c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// ---- LDS -------------------------------------------------------------------------------------------------------------------
+// 8-byte LDS load that the load/store merger leaves alone (volatile, with the LDS address space stated: a volatile access
+// through a generic pointer would become a flat load); pairs would be merged into ds_read2_b64, which moves 128 B per LDS
+// clock where ds_read_b64 moves 256
+__device__ __forceinline__ float2v lds_load_unmerged(const float2v* p) { return *(const volatile __attribute__((address_space(3))) float2v*)(p); }
+// byte address inside the workgroup's LDS allocation (what ds_* instructions take)
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+// opaque LDS pointer to fp16 fragments: keeps the compiler from parking all fragments in registers, stays LDS-qualified (an
+// opaque GENERIC pointer would turn the reads into flat loads)
+typedef const __attribute__((address_space(3))) half_t* lds_half_ptr;
+__device__ __forceinline__ lds_half_ptr lds_opaque_half_ptr(const half_t* p) {
+    lds_half_ptr q = (lds_half_ptr)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *(const __attribute__((address_space(3))) half8v*)(p + elem_off); }
+// One 16-byte global -> LDS transfer per lane: the wave writes 1 KiB at lds_wave_base + lane * 16, the global address is per
+// lane (swizzles are applied to the SOURCE address).  No VGPR staging.
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base,
+                                     16, 0, 0);
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (the N youngest may stay in flight)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain transfers still in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- hand-scheduled pieces of the 256 x 256 GEMM stage (conv1d.hip) ---------------------------------------------------------------
+#define MV_MFMA8(A0, A1)                                                                                       \
+    "v_mfma_f32_16x16x32_f16 %0, " A0 ", %10, %0\n\tv_mfma_f32_16x16x32_f16 %1, " A0 ", %11, %1\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %2, " A0 ", %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, " A0 ", %13, %3\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %4, " A1 ", %10, %4\n\tv_mfma_f32_16x16x32_f16 %5, " A1 ", %11, %5\n\t"          \
+    "v_mfma_f32_16x16x32_f16 %6, " A1 ", %12, %6\n\tv_mfma_f32_16x16x32_f16 %7, " A1 ", %13, %7"
+// wait until at most WAIT LDS reads are outstanding, then 8 MFMAs: (a0 | a1) x b[0..3] into c0[0..3] | c1[0..3]
+template <int WAIT>
+__device__ __forceinline__ void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%14)\n\t" MV_MFMA8("%8", "%9")
+                 : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3])
+                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
+                 : "memory");
+}
+#undef MV_MFMA8
+// two / four 16-byte fragment reads from LDS byte address `addr` (+ immediate offsets), no wait
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(d0), "=&v"(d1) : "v"(addr), "n"(OFF0), "n"(OFF1) : "memory");
+}
+__device__ __forceinline__ void lds_read4(half8v (&d)[4], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(addr)
+                 : "memory");
+}
+// MFMA results are read by VALU code only after a barrier and a round of transfers; pad the hazard anyway
+__device__ __forceinline__ void mfma_hazard_pad() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+// 16-byte store with the streaming policy bits (write-through, no L2 allocation)
+__device__ __forceinline__ void store16_streaming(void* p, const unsigned (&o)[4]) {
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    const uint4v ou = {o[0], o[1], o[2], o[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(ou) : "memory");
+}
+
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+inline int device_cu_count() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+}
+
+}  // namespace mv

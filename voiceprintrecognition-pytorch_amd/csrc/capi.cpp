@@ -22,7 +22,6 @@ int check_launch(const char* what) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline legs) ----
 // Off by default: the launchers call prof_begin / prof_end, which do nothing until mv_profile_enable(1).
-#ifndef MV_EMU
 namespace {
 struct ProfRecord {
     int cls;
@@ -56,10 +55,6 @@ int prof_begin(int cls, double work, hipStream_t stream) {
 void prof_end(int token, hipStream_t stream) {
     if (token >= 0 && token < (int)g_prof.size()) hipEventRecord(g_prof[token].stop, stream);
 }
-#else
-int prof_begin(int, double, hipStream_t) { return -1; }
-void prof_end(int, hipStream_t) {}
-#endif
 
 }  // namespace mv
 
@@ -68,11 +63,7 @@ extern "C" {
 const char* mv_last_error(void) { return mv::g_last_error.c_str(); }
 
 int mv_profile_enable(int32_t on) {
-#ifndef MV_EMU
     mv::g_prof_on = on != 0;
-#else
-    (void)on;
-#endif
     return MV_OK;
 }
 
@@ -81,7 +72,6 @@ int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, doub
     *calls = 0;
     *total_ms = 0.0;
     *total_work = 0.0;
-#ifndef MV_EMU
     for (const auto& r : mv::g_prof) {
         if (r.cls != kernel_class) continue;
         MV_HIP_OK(hipEventSynchronize(r.stop));
@@ -98,10 +88,6 @@ int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, doub
         }
         mv::g_prof.clear();
     }
-#else
-    (void)kernel_class;
-    (void)reset;
-#endif
     return MV_OK;
 }
 

@@ -84,42 +84,10 @@ __device__ __forceinline__ half_t to_half_sat(float v) {
     return (half_t)v;
 }
 
-__device__ __forceinline__ float clamp3(float v, float lo, float hi) {
-#ifdef MV_EMU
-    return fminf(fmaxf(v, lo), hi);
-#else
-    return __builtin_amdgcn_fmed3f(v, lo, hi);
-#endif
-}
+__device__ __forceinline__ float clamp3(float v, float lo, float hi) { return fmed3(v, lo, hi); }
 
-// max(v, lo) as exactly one v_max_f32: fmaxf / v_med3 against +inf are lowered to a canonicalising v_max v, v, v plus the
-// max itself, which doubled the activation cost of the 128-value epilogues
-__device__ __forceinline__ float max_raw(float v, float lo) {
-#ifdef MV_EMU
-    return fmaxf(v, lo);
-#else
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
-    return r;
-#endif
-}
-
-// One 16-byte global -> LDS transfer per lane: the wave writes 1 KiB at lds_wave_base + lane*16, the global
-// address is per lane (swizzles are applied to the SOURCE address).  No VGPR staging.
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-#ifdef MV_EMU
-    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
-#else
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#endif
-}
-
-__device__ __forceinline__ void wait_all_loads() {
-#ifndef MV_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
+// (max_raw = max as exactly one v_max_f32, glds16 = one 16-byte global -> LDS transfer per lane, wait_vm<N>: arch/gfx950.h)
+__device__ __forceinline__ void wait_all_loads() { wait_vm<0>(); }
 
 struct RowMap {  // where the rows (time steps) of this lane live
     int b, t;    // b < 0: row beyond the tensor
@@ -160,43 +128,15 @@ __device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int
     }
 }
 
-#ifndef MV_EMU
 // ---- hand-scheduled K stage of the 256 x 256 tile (wave tile 128 x 64: 8 x 4 MFMA tiles, 2 K halves) ---------------
 // The compiler serialises "2 ds_read, s_waitcnt lgkmcnt(0), 8 MFMA" and so exposes an LDS round trip in front of every
-// group of MFMAs.  Here the stage is eight steps (K half, pair of channel tiles) in inline assembly: the two weight
+// group of MFMAs.  Here the stage is eight steps (K half, pair of channel tiles) built from the arch header's inline-assembly
+// pieces (mfma8_step = counted wait + 8 MFMAs, lds_read2 / lds_read4 = fragment requests without a wait): the two weight
 // fragments of step i+1 are requested BEFORE the counted wait and the 8 MFMAs of step i, so the round trip runs under
 // the matrix pipe.  Rules kept by construction: a fragment register is only re-targeted by a read that is issued after
 // the last MFMA that sources it; LDS returns in order, so lgkmcnt(2) = "everything but the two newest reads".
 // Fragment addresses: row * 128 + ((chunk ^ (row & 7)) << 4) with row = tile base + frow -- the swizzle term depends on
 // the lane and the K half only, the channel / time tile is an immediate multiple of 2048.
-#define MV_MFMA8(A0, A1)                                                                                       \
-    "v_mfma_f32_16x16x32_f16 %0, " A0 ", %10, %0\n\tv_mfma_f32_16x16x32_f16 %1, " A0 ", %11, %1\n\t"          \
-    "v_mfma_f32_16x16x32_f16 %2, " A0 ", %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, " A0 ", %13, %3\n\t"          \
-    "v_mfma_f32_16x16x32_f16 %4, " A1 ", %10, %4\n\tv_mfma_f32_16x16x32_f16 %5, " A1 ", %11, %5\n\t"          \
-    "v_mfma_f32_16x16x32_f16 %6, " A1 ", %12, %6\n\tv_mfma_f32_16x16x32_f16 %7, " A1 ", %13, %7"
-
-template <int WAIT>
-__device__ __forceinline__ void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%14)\n\t" MV_MFMA8("%8", "%9")
-                 : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3])
-                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
-                 : "memory");
-}
-
-template <int OFF0, int OFF1>
-__device__ __forceinline__ void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                 : "=&v"(d0), "=&v"(d1)
-                 : "v"(addr), "n"(OFF0), "n"(OFF1)
-                 : "memory");
-}
-
-__device__ __forceinline__ void lds_read4(half8v (&d)[4], unsigned addr) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
-                 : "v"(addr)
-                 : "memory");
-}
 
 // wt / xtile: LDS byte addresses of the stage's weight and activation tiles.  between(i), i = 0..7, runs between the
 // fragment requests and the (counted wait +) MFMAs of step i: the caller issues one of the next stage's eight global->LDS transfers there,
@@ -237,10 +177,8 @@ __device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int w
     mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf);
     between(7);
     mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf);
-    // MFMA results are read by VALU code (epilogue) only after a barrier and a round of transfers; pad the hazard anyway
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    mfma_hazard_pad();
 }
-#endif
 
 // lane holds channels co..co+3 (rows) of time step n (column); cout is a multiple of 4, so a lane's four channels are
 // all valid or all invalid and every per-channel parameter is one float4 load (uniform branches only).
@@ -609,13 +547,9 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
                     __builtin_memcpy(&ov, o, 16);
 #if defined(MV_PROBE) && MV_PROBE == 4   // timing probe 4 (tools/probe only): the epilogue computes but never stores
                     if (n < a.n_rows && a.ldy < 0) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
-#elif defined(MV_EMU)
-                    if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
 #else
                     if (a.store_nt) {  // uniform
-                        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-                        const uint4v ou = {o[0], o[1], o[2], o[3]};
-                        if (n < a.n_rows) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(yrow + p * 32), "v"(ou) : "memory");
+                        if (n < a.n_rows) store16_streaming(yrow + p * 32, o);
                     } else {
                         if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
                     }
@@ -886,9 +820,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     float4v acc[MI][NI];
     bool pending = false, more = true;
     int e_n0 = 0, e_co0 = 0, e_ps = 0;
-#ifndef MV_EMU
-    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address
-#endif
+    const unsigned smem_base = lds_addr(smem);  // LDS byte address
     // One K stage.  FIRST / LAST are compile-time for the peeled copies, so the steady-state body (neither) is: wait,
     // barrier, request stage s+1, 64 MFMAs -- no tile bookkeeping, no branches.
     auto stage = [&](int s, auto first, auto last) {
@@ -928,11 +860,6 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
 #if defined(MV_PROBE) && MV_PROBE == 2   // timing probe 2: no LDS reads / MFMAs
         if (feed)
             for (int i = 0; i < NTX + NTW; ++i) dma(i);
-#elif defined(MV_EMU)
-        if (feed)
-            for (int i = 0; i < NTX + NTW; ++i) dma(i);
-        const char* wt = smem + buf * CVP_STAGE_BYTES;
-        mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
 #else
         const unsigned wt = smem_base + buf * CVP_STAGE_BYTES;
         // CVP_DMA_STEPS = over how many of the 8 MFMA steps the 8 transfers are spread (8: one per step; 4: two per step
@@ -1013,12 +940,7 @@ template <>
 struct RawChunk<float> {
     float4v lo, hi;
 };
-// (pointer selects between a tensor and the zero page lose the address space: state it, or the loads become FLAT loads)
-#ifdef MV_EMU
-#define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)
-#else
-#define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
-#endif
+// (pointer selects between a tensor and the zero page lose the address space: MV_GLOBAL_PTR states it, or the loads become FLAT loads)
 __device__ __forceinline__ void load_raw(RawChunk<half_t>& r, const half_t* p) { r.v = *MV_GLOBAL_PTR(half8v, p); }
 __device__ __forceinline__ void load_raw(RawChunk<float>& r, const float* p) {
     r.lo = *MV_GLOBAL_PTR(float4v, p);
@@ -1167,15 +1089,7 @@ static int conv_store_policy(int64_t k_total) {
 
 static int cu_count() {
     static int n = -1;
-    if (n < 0) {
-#ifdef MV_EMU
-        n = 8;
-#else
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-#endif
-    }
+    if (n < 0) n = device_cu_count();
     return n;
 }
 

@@ -311,13 +311,7 @@ struct AspArgs {
     float eps;
 };
 
-__device__ __forceinline__ float asp_exp2(float v) {
-#ifdef MV_EMU
-    return exp2f(v);
-#else
-    return __builtin_amdgcn_exp2f(v);  // v_exp_f32: arguments are <= 0 (online) or within +-60 (NOMAX)
-#endif
-}
+__device__ __forceinline__ float asp_exp2(float v) { return exp2_fast(v); }  // v_exp_f32: arguments are <= 0 (online) or within +-60 (NOMAX)
 
 __device__ __forceinline__ void asp_merge(float& m, float& s0, float& s1, float& s2, float om, float o0, float o1, float o2) {
     const float nm = fmaxf(m, om);
@@ -422,24 +416,13 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
             const float voff = tt * 16 + fr < a.T ? 0.0f : -INFINITY;
             // the W2 fragments are re-read from LDS every tile (the opaque copy keeps the compiler from parking all
             // 16 of them in 64 VGPRs, which would halve the number of resident waves)
-#ifdef MV_EMU
-            const half_t* wl = wlds + lane * 8;
-#else
-            // (an LDS-qualified pointer: an opaque GENERIC pointer would turn the fragment reads into flat loads)
-            typedef const __attribute__((address_space(3))) half_t* lds_half_ptr;
-            lds_half_ptr wl = (lds_half_ptr)wlds + lane * 8;
-            asm volatile("" : "+v"(wl));
-#endif
+            const lds_half_ptr wl = lds_opaque_half_ptr(wlds + lane * 8);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 float4v l = float4v{voff, voff, voff, voff};
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-#ifdef MV_EMU
-                    const half8v wf = *reinterpret_cast<const half8v*>(wl + (size_t)(mi * KS + kk) * 512);
-#else
-                    const half8v wf = *(const __attribute__((address_space(3))) half8v*)(wl + (mi * KS + kk) * 512);
-#endif
+                    const half8v wf = lds_load_half8(wl, (mi * KS + kk) * 512);
                     l = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hcur[kk], l, 0, 0, 0);
                 }
 #if defined(MV_PROBE) && MV_PROBE == 3

@@ -48,40 +48,13 @@ struct Res2Args {
     int T, C, width, steps, k, dil, kpad;  // kpad = round_up(width, 64)
 };
 
-__device__ __forceinline__ void r2_glds16(const void* gsrc, char* lds_wave_base) {
-#ifdef MV_EMU
-    memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16);
-#else
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#endif
-}
-
-// wait until at most N of this wave's vector-memory operations are outstanding (the N youngest may stay in flight)
+// (LDS-DMA transfers, counted waits, the LDS-only barrier and the fp16 saturation are the arch header's glds16 / wait_vm /
+// lds_barrier / fmed3)
+__device__ __forceinline__ void r2_glds16(const void* gsrc, char* lds_wave_base) { glds16(gsrc, lds_wave_base); }
 template <int N>
-__device__ __forceinline__ void r2_wait_vm() {
-#ifndef MV_EMU
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the weight transfers that
-// are still in flight for later stages
-__device__ __forceinline__ void r2_lds_barrier() {
-#ifdef MV_EMU
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
-__device__ __forceinline__ float r2_clamp_h(float v) {  // fp16 saturation
-#ifdef MV_EMU
-    return fminf(fmaxf(v, -65504.0f), 65504.0f);
-#else
-    return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-#endif
-}
+__device__ __forceinline__ void r2_wait_vm() { wait_vm<N>(); }
+__device__ __forceinline__ void r2_lds_barrier() { lds_barrier(); }
+__device__ __forceinline__ float r2_clamp_h(float v) { return fmed3(v, -65504.0f, 65504.0f); }  // fp16 saturation
 
 // timing probe 1 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at tagged points (tools/trace_res2.py)
 #if defined(MV_PROBE) && MV_PROBE == 1
