@@ -1,0 +1,313 @@
+// One CAMDenseTDNNLayer of CAM++ (mvector/models/campplus.py:71-150) as ONE launch, one workgroup per utterance:
+//
+//     h    = ReLU(BN2(W1 . ReLU(BN1(x))))                1x1 conv over the cin channels written so far (bottleneck 128)
+//     ctx  = mean_T(h) + segmean_100(h)                   (last segment divided by its true length: avg_pool1d ceil_mode)
+//     m    = sigmoid(Wb . ReLU(Wa . ctx + ba) + bb)       per 100-frame segment, 128 -> 64 -> 32, fp32
+//     y    = conv_k3,dil(h) * m                           zero padding; written as 32 new channels behind the cin inputs
+//
+// Why: as separate launches (1x1 conv with the transform on load, segment means, two tiny FCs, k=3 conv with the gate in its
+// epilogue) a layer is five kernels and ~76 us for ~12 us of memory traffic (profiles/r02k: 52 layers = 3.9 ms of the 5.8 ms
+// CAM++ step); the bottleneck h makes an HBM round trip and the context needs a grid-wide boundary.  The context couples all
+// frames of ONE utterance and nothing else, so an utterance per workgroup keeps h (T2 x 128 fp16 = 38 KB for 3 s) in LDS from
+// the 1x1 GEMM to the k=3 conv, evaluates the context FCs in place and touches HBM for exactly: the utterance's input
+// channels (once), the weights (L2-resident, shared by all workgroups) and the 32 output channels.
+//
+// GEMM conventions as in res2.hip: weights are the MFMA A operand (rows = output channels), activations the B operand
+// (columns = time steps), so a lane ends up with 4 consecutive output channels of one time step.  8 waves: wave (cw = w & 3,
+// th = w >> 2) owns output-channel tiles {2 cw, 2 cw + 1} x time tiles {5 th .. 5 th + 4} of the 1x1 GEMM; W1 streams through
+// a 3-slot LDS ring by LDS-DMA, x is loaded to registers one 64-channel stage ahead, passed through BN1 + ReLU in fp32 and
+// written to a double-buffered LDS tile (the loads bypass L1: the buffer is re-read by the next layer's launch with 32 more
+// channels, and every element is used exactly once here).
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace mv {
+
+constexpr int CD_THREADS = 512;
+constexpr int CD_TT = 10;                           // time tiles of 16 frames: T2 <= 160 (3.2 s of audio after the stride-2 TDNN)
+constexpr int CD_ROWS = CD_TT * 16;
+constexpr int CD_BN = 128;                          // bottleneck channels (bn_size * growth_rate)
+constexpr int CD_G = 32;                            // growth rate
+constexpr int CD_PAD = 2;                           // largest dilation of the k=3 conv
+constexpr int CD_XS_BYTES = CD_ROWS * 128;          // one x stage: [160 rows][64 fp16]
+constexpr int CD_WS_BYTES = CD_BN * 128;            // one W1 stage: [128 rows][64 fp16]
+constexpr int CD_RING = 3;
+constexpr int CD_H_BYTES = (CD_ROWS + 2 * CD_PAD) * CD_BN * 2;  // h with zero halo rows on both sides
+constexpr int CD_MAX_SEG = 2;                       // segments of 100 frames within 160 frames
+
+struct CamDenseArgs {
+    half_t* x;            // [B, T2, ldx]: channels [0, cin) are read, [cin, cin + 32) are written
+    int64_t ldx;
+    const half_t* w1;     // packed [128][1][cin_pad64]
+    const float *bn1_s, *bn1_t;   // [cin]
+    const float *bn2_s, *bn2_t;   // [128]
+    const half_t* wl;     // packed [32][3][128]
+    const float *wa, *ba, *wb, *bb;  // [64][128], [64], [32][64], [32]
+    int T2, cin, cin_pad, dil, seg_len;
+};
+
+__global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArgs a) {
+    MV_DYN_SMEM(smem);
+    char* xs = smem;                                           // 2 x CD_XS_BYTES (later: reduction scratch)
+    char* ws = xs + 2 * CD_XS_BYTES;                           // CD_RING x CD_WS_BYTES
+    char* hbuf = ws + CD_RING * CD_WS_BYTES;                   // CD_H_BYTES, row r = t + CD_PAD
+    float* fsm = reinterpret_cast<float*>(hbuf + CD_H_BYTES);  // ctx [2][128] | g1 [2][64] | gate [2][32]
+    float* ctx = fsm;
+    float* g1 = ctx + CD_MAX_SEG * CD_BN;
+    float* gate = g1 + CD_MAX_SEG * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.x;
+    const int T2 = a.T2;
+    half_t* xb = a.x + (int64_t)b * T2 * a.ldx;
+    const int nst = a.cin_pad / 64;
+
+    // zero the bottleneck buffer: halo rows and the rows behind T2 must read as zero padding
+    for (int i = tid; i < CD_H_BYTES / 16; i += CD_THREADS) reinterpret_cast<float4v*>(hbuf)[i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
+    const int cw = wave & 3, th = wave >> 2;
+    const int lrow = lane >> 3, kc = (lane & 7) ^ lrow;
+    auto issue_w = [&](int s) {  // W1 stage s: 128 rows x 128 bytes = 16 transfers of 1 KiB, two per wave
+        char* dst = ws + (s % CD_RING) * CD_WS_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tr = wave * 2 + u;
+            const int co = tr * 8 + lrow;
+            glds16(a.w1 + (int64_t)co * a.cin_pad + s * 64 + kc * 8, dst + tr * 1024);
+        }
+    };
+    // x staging: thread = (chunk of 8 channels, row), three rows per thread and stage
+    const int xchunk = tid & 7, xrow0 = tid >> 3;
+    half8v xr[3];
+    auto load_x = [&](int s) {
+        const int c = s * 64 + xchunk * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int row = xrow0 + 64 * p;
+            half8v v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)0.0f;
+            if (row < T2 && c < a.cin) v = __builtin_nontemporal_load(reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c));
+            xr[p] = v;
+        }
+    };
+    auto store_x = [&](int s) {  // BN1 + ReLU in fp32, then into the stage tile (rows >= T2 and channels >= cin stay zero)
+        const int c = s * 64 + xchunk * 8;
+        const bool live = c < a.cin;
+        float4v s0 = float4v{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0, t0 = s0, t1 = s0;
+        if (live) {
+            s0 = *reinterpret_cast<const float4v*>(a.bn1_s + c);
+            s1 = *reinterpret_cast<const float4v*>(a.bn1_s + c + 4);
+            t0 = *reinterpret_cast<const float4v*>(a.bn1_t + c);
+            t1 = *reinterpret_cast<const float4v*>(a.bn1_t + c + 4);
+        }
+        char* dst = xs + (s & 1) * CD_XS_BYTES;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int row = xrow0 + 64 * p;
+            if (row < CD_ROWS) {
+                half8v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)fmaxf((float)xr[p][e] * s0[e] + t0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)xr[p][4 + e] * s1[e] + t1[e], 0.0f);
+                }
+                if (!(row < T2 && live)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)0.0f;
+                }
+                *reinterpret_cast<half8v*>(dst + row * 128 + ((xchunk ^ (row & 7)) << 4)) = o;
+            }
+        }
+    };
+
+    issue_w(0);
+    if (nst > 1) issue_w(1);
+    load_x(0);
+    store_x(0);
+    float4v acc[2][5];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < nst; ++s) {
+        // W1 stage s landed (at most the one younger stage may still be in flight), x stage s written by every thread
+        if (s + 1 < nst) {
+            wait_vm<2>();
+        } else {
+            wait_vm<0>();
+        }
+        lds_barrier();
+        if (s + 2 < nst) issue_w(s + 2);
+        if (s + 1 < nst) load_x(s + 1);
+        const char* wt = ws + (s % CD_RING) * CD_WS_BYTES;
+        const char* xt = xs + (s & 1) * CD_XS_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8v af[2], bf[5];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = (cw * 2 + mi) * 16 + fr;
+                af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni) {
+                const int row = (th * 5 + ni) * 16 + fr;
+                bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (s + 1 < nst) store_x(s + 1);  // the other x tile: its readers passed this stage's barrier
+    }
+    // epilogue A: BN2 + ReLU -> hbuf (fp16, swizzled 16-byte chunks: chunk ^= row & 15), frames >= T2 stay zero
+    auto h_off = [&](int row, int chunk) { return row * (CD_BN * 2) + ((chunk ^ (row & 15)) << 4); };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int co = (cw * 2 + mi) * 16 + 4 * fg;
+        const float4v sc = *reinterpret_cast<const float4v*>(a.bn2_s + co);
+        const float4v sh = *reinterpret_cast<const float4v*>(a.bn2_t + co);
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) {
+            const int t = (th * 5 + ni) * 16 + fr;
+            half4v hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+            if (t < T2) *reinterpret_cast<half4v*>(hbuf + h_off(t + CD_PAD, co >> 3) + (co & 7) * 2) = hv;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: context gate per 100-frame segment ----
+    const int nseg = (T2 + a.seg_len - 1) / a.seg_len;  // <= CD_MAX_SEG (checked by the launcher)
+    {
+        // partial sums: thread = (8-channel chunk, 32 row phases); scratch [32][2][128] floats in the (now idle) x tiles
+        float* part = reinterpret_cast<float*>(xs);
+        const int cg = tid & 15, rp = tid >> 4;
+        float sum[CD_MAX_SEG][8];
+#pragma unroll
+        for (int sg = 0; sg < CD_MAX_SEG; ++sg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[sg][e] = 0.0f;
+        for (int t = rp; t < T2; t += 32) {
+            const half8v v = *reinterpret_cast<const half8v*>(hbuf + h_off(t + CD_PAD, cg));
+            if (t < a.seg_len) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[0][e] += (float)v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[1][e] += (float)v[e];
+            }
+        }
+#pragma unroll
+        for (int sg = 0; sg < CD_MAX_SEG; ++sg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[(rp * CD_MAX_SEG + sg) * CD_BN + cg * 8 + e] = sum[sg][e];
+        __syncthreads();
+        if (tid < CD_MAX_SEG * CD_BN) {
+            const int sg = tid / CD_BN, c = tid - sg * CD_BN;
+            float v = 0.0f, other = 0.0f;
+            for (int p = 0; p < 32; ++p) {
+                v += part[(p * CD_MAX_SEG + sg) * CD_BN + c];
+                other += part[(p * CD_MAX_SEG + (1 - sg)) * CD_BN + c];
+            }
+            const int t0 = sg * a.seg_len;
+            const int len = (t0 + a.seg_len < T2 ? t0 + a.seg_len : T2) - t0;
+            ctx[sg * CD_BN + c] = len > 0 ? (v + other) / (float)T2 + v / (float)len : 0.0f;
+        }
+        __syncthreads();
+        if (tid < CD_MAX_SEG * 64) {  // g1 = ReLU(Wa ctx + ba)
+            const int sg = tid >> 6, j = tid & 63;
+            float v = a.ba[j];
+            const float* wr = a.wa + j * CD_BN;
+            const float* cx = ctx + sg * CD_BN;
+            for (int c = 0; c < CD_BN; c += 4) {
+                const float4v w4 = *reinterpret_cast<const float4v*>(wr + c);
+                v = fmaf(w4[0], cx[c], v);
+                v = fmaf(w4[1], cx[c + 1], v);
+                v = fmaf(w4[2], cx[c + 2], v);
+                v = fmaf(w4[3], cx[c + 3], v);
+            }
+            g1[sg * 64 + j] = fmaxf(v, 0.0f);
+        }
+        __syncthreads();
+        if (tid < CD_MAX_SEG * CD_G) {  // gate = sigmoid(Wb g1 + bb)
+            const int sg = tid >> 5, co = tid & 31;
+            float v = a.bb[co];
+            const float* wr = a.wb + co * 64;
+            for (int j = 0; j < 64; ++j) v = fmaf(wr[j], g1[sg * 64 + j], v);
+            gate[sg * CD_G + co] = 1.0f / (1.0f + expf(-v));
+        }
+        __syncthreads();
+    }
+
+    // ---- phase C: y = conv_k3(h) * gate -> channels [cin, cin + 32) of x ----
+    {
+        const int ct = wave & 1, tg = wave >> 1;  // channel tile, time tiles tg, tg + 4, tg + 8
+        float4v yc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        const half_t* wrow = a.wl + (int64_t)(ct * 16 + fr) * 3 * CD_BN + 8 * fg;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const half8v af = *reinterpret_cast<const half8v*>(wrow + tap * CD_BN + kk * 32);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int tile = tg + 4 * j;
+                    if (tile < CD_TT) {  // uniform per wave
+                        const int row = tile * 16 + fr + (tap - 1) * a.dil + CD_PAD;
+                        const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
+                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int co = ct * 16 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tile = tg + 4 * j;
+            const int t = tile * 16 + fr;
+            if (tile < CD_TT && t < T2) {
+                const float* gt = gate + (t / a.seg_len) * CD_G + co;
+                half4v hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(yc[j][r] * gt[r], -65504.0f, 65504.0f);
+                *reinterpret_cast<half4v*>(xb + (int64_t)t * a.ldx + a.cin + co) = hv;
+            }
+        }
+    }
+}
+
+constexpr size_t CD_LDS_BYTES = 2 * CD_XS_BYTES + CD_RING * CD_WS_BYTES + CD_H_BYTES + (CD_MAX_SEG * (CD_BN + 64 + CD_G)) * sizeof(float);
+
+bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len) {
+    return bottleneck == CD_BN && growth == CD_G && T2 >= 1 && T2 <= CD_ROWS && cin % 32 == 0 && cin >= 32 && dil >= 1 && dil <= CD_PAD &&
+           seg_len > 0 && (T2 + seg_len - 1) / seg_len <= CD_MAX_SEG;
+}
+
+int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
+                           const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
+                           const float* bb, int dil, int seg_len, hipStream_t stream) {
+    MV_REQUIRE(cam_dense_layer_supported(T2, cin, CD_BN, CD_G, dil, seg_len), "cam_dense_layer: unsupported geometry");
+    MV_REQUIRE(ldx >= cin + CD_G && (ldx % 8) == 0, "cam_dense_layer: the row must hold the inputs and 32 new channels (16-byte aligned chunks)");
+    static bool smem_set = false;
+    if (!smem_set) {
+        if (MV_SET_MAX_SMEM(cam_dense_layer_kernel, CD_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_layer: cannot reserve LDS");
+        smem_set = true;
+    }
+    CamDenseArgs a;
+    a.x = x; a.ldx = ldx; a.w1 = w1; a.bn1_s = bn1_s; a.bn1_t = bn1_t; a.bn2_s = bn2_s; a.bn2_t = bn2_t; a.wl = wl;
+    a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb;
+    a.T2 = T2; a.cin = cin; a.cin_pad = conv1d_cin_pad(cin); a.dil = dil; a.seg_len = seg_len;
+    MV_LAUNCH(cam_dense_layer_kernel, ((unsigned)B, 1, 1), (CD_THREADS, 1, 1), CD_LDS_BYTES, stream, a);
+    return check_launch("cam_dense_layer_kernel");
+}
+
+}  // namespace mv

@@ -10,6 +10,7 @@
 //                 ctx = mean_T(h) + segmean_100(h)             (campplus.py:94-111) -> [B, nseg, 128]
 //                 m   = sigmoid(W_b . ReLU(W_a . ctx + b_a) + b_b)   evaluated once per segment, not per frame
 //                 y   = conv_k3(h) * m                          gate multiplied in the conv epilogue
+//             (one launch per layer for utterances of up to 160 strided frames: camdense.hip; five launches beyond)
 //             transit: 1x1 conv with BN/ReLU on load; out_nonlinear + StatsPool (unbiased std) fused into one reduction;
 //             dense + BN(affine=False) folded into one fp32 linear layer.
 #include <array>
@@ -281,11 +282,20 @@ struct CamppModel : MvModelBase {
             if ((rc = conv1d_launch(d, st))) return rc;
         }
         const int G = cfg.growth_rate;
+        const char* fused_env = getenv("MV_CAMPP_FUSED");  // measurement knob: MV_CAMPP_FUSED=0 keeps the five launches per layer
+        const bool fused_dense = !(fused_env != nullptr && fused_env[0] == '0');
         for (int bi = 0; bi < 3; ++bi) {
             const Block& Bk = blocks[bi];
             half_t* X = s.xb[bi];
             const int64_t ld = Bk.c_out;
             for (const DenseLayer& L : Bk.layers) {
+                // utterances of up to 160 strided frames (3.2 s): the whole layer is one launch with the bottleneck kept in LDS
+                if (fused_dense && cam_dense_layer_supported(T2, L.cin, bn_ch, G, Bk.dil, 100)) {
+                    if ((rc = cam_dense_layer_launch(X, ld, B, T2, L.cin, L.lin1.w, L.bn1_s, L.bn1_t, L.bn2_s, L.bn2_t, L.local.w, L.wa, L.ba,
+                                                     L.wb, L.bb, Bk.dil, 100, st)))
+                        return rc;
+                    continue;
+                }
                 MvConv1dDesc d;
                 memset(&d, 0, sizeof(d));
                 d.x = X;

@@ -29,6 +29,11 @@ int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const floa
 int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F2, int sf2, int mode2, const half_t* w,
                        const float* bias, half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, int Fout,
                        hipStream_t stream);
+// one CAMDenseTDNNLayer (campplus.py:114-150) as one launch, one workgroup per utterance (camdense.hip); T2 <= 160 frames
+bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len);
+int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
+                           const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
+                           const float* bb, int dil, int seg_len, hipStream_t stream);
 int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream);
 int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
                             int64_t ldo, int B, int T, int C, hipStream_t stream);
