@@ -34,6 +34,8 @@ constexpr int CD_XS_BYTES = CD_ROWS * 128;          // one x stage: [160 rows][6
 constexpr int CD_WS_BYTES = CD_BN * 128;            // one W1 stage: [128 rows][64 fp16]
 constexpr int CD_RING = 3;
 constexpr int CD_H_BYTES = (CD_ROWS + 2 * CD_PAD) * CD_BN * 2;  // h with zero halo rows on both sides
+constexpr int CD_XPF = 4;                           // x stages in flight in registers (global latency >> one stage of 20 MFMAs per wave)
+static_assert(CD_XPF == 4, "the stage loop is unrolled by four and its counted waits assume this depth");
 constexpr int CD_MAX_SEG = 2;                       // segments of 100 frames within 160 frames
 
 struct CamDenseArgs {
@@ -52,10 +54,12 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     char* xs = smem;                                           // 2 x CD_XS_BYTES (later: reduction scratch)
     char* ws = xs + 2 * CD_XS_BYTES;                           // CD_RING x CD_WS_BYTES
     char* hbuf = ws + CD_RING * CD_WS_BYTES;                   // CD_H_BYTES, row r = t + CD_PAD
-    float* fsm = reinterpret_cast<float*>(hbuf + CD_H_BYTES);  // ctx [2][128] | g1 [2][64] | gate [2][32]
+    float* fsm = reinterpret_cast<float*>(hbuf + CD_H_BYTES);  // ctx [2][128] | g1 [2][64] | gate [2][32] | BN1 scale, shift [cin_pad] each
     float* ctx = fsm;
     float* g1 = ctx + CD_MAX_SEG * CD_BN;
     float* gate = g1 + CD_MAX_SEG * 64;
+    float* lbn_s = gate + CD_MAX_SEG * CD_G;
+    float* lbn_t = lbn_s + a.cin_pad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -66,6 +70,13 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 
     // zero the bottleneck buffer: halo rows and the rows behind T2 must read as zero padding
     for (int i = tid; i < CD_H_BYTES / 16; i += CD_THREADS) reinterpret_cast<float4v*>(hbuf)[i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    // BN1 parameters into LDS: read per stage next to x values that were requested four stages earlier -- a global load there
+    // would wait behind every younger x prefetch (vector-memory results return in order)
+    for (int i = tid; i < a.cin_pad; i += CD_THREADS) {
+        lbn_s[i] = i < a.cin ? a.bn1_s[i] : 0.0f;
+        lbn_t[i] = i < a.cin ? a.bn1_t[i] : 0.0f;
+    }
+    __syncthreads();
 
     // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
     const int cw = wave & 3, th = wave >> 2;
@@ -81,29 +92,24 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     };
     // x staging: thread = (chunk of 8 channels, row), three rows per thread and stage
     const int xchunk = tid & 7, xrow0 = tid >> 3;
-    half8v xr[3];
-    auto load_x = [&](int s) {
-        const int c = s * 64 + xchunk * 8;
+    half8v xr[CD_XPF][3];
+    // (every wave issues exactly three loads per stage -- rows / channels beyond the data are clamped here and zeroed in
+    // store_x -- so the counted waits of the stage loop can rely on the number of operations in flight)
+    auto load_x = [&](int s, half8v (&r)[3]) {
+        int c = s * 64 + xchunk * 8;
+        c = c < a.cin ? c : 0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const int row = xrow0 + 64 * p;
-            half8v v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)0.0f;
-            if (row < T2 && c < a.cin) v = __builtin_nontemporal_load(reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c));
-            xr[p] = v;
+            int row = xrow0 + 64 * p;
+            row = row < T2 ? row : T2 - 1;
+            r[p] = __builtin_nontemporal_load(reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c));
         }
     };
-    auto store_x = [&](int s) {  // BN1 + ReLU in fp32, then into the stage tile (rows >= T2 and channels >= cin stay zero)
+    auto store_x = [&](int s, const half8v (&r)[3]) {  // BN1 + ReLU in fp32, then into the stage tile (rows >= T2 and channels >= cin stay zero)
         const int c = s * 64 + xchunk * 8;
         const bool live = c < a.cin;
-        float4v s0 = float4v{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0, t0 = s0, t1 = s0;
-        if (live) {
-            s0 = *reinterpret_cast<const float4v*>(a.bn1_s + c);
-            s1 = *reinterpret_cast<const float4v*>(a.bn1_s + c + 4);
-            t0 = *reinterpret_cast<const float4v*>(a.bn1_t + c);
-            t1 = *reinterpret_cast<const float4v*>(a.bn1_t + c + 4);
-        }
+        const float4v s0 = *reinterpret_cast<const float4v*>(lbn_s + c), s1 = *reinterpret_cast<const float4v*>(lbn_s + c + 4);
+        const float4v t0 = *reinterpret_cast<const float4v*>(lbn_t + c), t1 = *reinterpret_cast<const float4v*>(lbn_t + c + 4);
         char* dst = xs + (s & 1) * CD_XS_BYTES;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
                 half8v o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (half_t)fmaxf((float)xr[p][e] * s0[e] + t0[e], 0.0f);
-                    o[4 + e] = (half_t)fmaxf((float)xr[p][4 + e] * s1[e] + t1[e], 0.0f);
+                    o[e] = (half_t)fmaxf((float)r[p][e] * s0[e] + t0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)r[p][4 + e] * s1[e] + t1[e], 0.0f);
                 }
                 if (!(row < T2 && live)) {
 #pragma unroll
@@ -126,23 +132,37 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 
     issue_w(0);
     if (nst > 1) issue_w(1);
-    load_x(0);
-    store_x(0);
+    // x: CD_XPF stages in flight in registers (register set = stage % CD_XPF; the stage loop is unrolled by CD_XPF so the sets
+    // are named at compile time)
+#pragma unroll
+    for (int u = 0; u < CD_XPF; ++u)
+        if (u < nst) load_x(u, xr[u]);
+    store_x(0, xr[0]);
     float4v acc[2][5];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < nst; ++s) {
-        // W1 stage s landed (at most the one younger stage may still be in flight), x stage s written by every thread
-        if (s + 1 < nst) {
-            wait_vm<2>();
-        } else {
-            wait_vm<0>();
+    auto stage = [&](int s, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;  // s % CD_XPF
+        // W1 stage s has landed and x stage s has been written by every thread:
+        // issued after W1 stage s (which went out in stage s - 2): the x loads of stages s - 2 + CD_XPF and s - 1 + CD_XPF
+        // (3 each) and W1 stage s + 1 (2 transfers), as far as those stages exist.  Stages 0 and 1: the prologue's wait for
+        // x stage 0 already covered both W1 stages.
+        if (s >= 2) {
+            if (s + CD_XPF - 1 < nst) {
+                wait_vm<8>();
+            } else if (s + CD_XPF - 2 < nst) {
+                wait_vm<5>();
+            } else if (s + 1 < nst) {
+                wait_vm<2>();
+            } else {
+                wait_vm<0>();
+            }
         }
         lds_barrier();
         if (s + 2 < nst) issue_w(s + 2);
-        if (s + 1 < nst) load_x(s + 1);
+        if (s + CD_XPF < nst) load_x(s + CD_XPF, xr[u]);  // set u was consumed when stage s was written (end of stage s - 1)
         const char* wt = ws + (s % CD_RING) * CD_WS_BYTES;
         const char* xt = xs + (s & 1) * CD_XS_BYTES;
 #pragma unroll
@@ -163,7 +183,13 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (s + 1 < nst) store_x(s + 1);  // the other x tile: its readers passed this stage's barrier
+        if (s + 1 < nst) store_x(s + 1, xr[(u + 1) % CD_XPF]);  // the other x tile: its readers passed this stage's barrier
+    };
+    for (int s0 = 0; s0 < nst; s0 += CD_XPF) {
+        stage(s0, std::integral_constant<int, 0>{});
+        if (s0 + 1 < nst) stage(s0 + 1, std::integral_constant<int, 1>{});
+        if (s0 + 2 < nst) stage(s0 + 2, std::integral_constant<int, 2>{});
+        if (s0 + 3 < nst) stage(s0 + 3, std::integral_constant<int, 3>{});
     }
     // epilogue A: BN2 + ReLU -> hbuf (fp16, swizzled 16-byte chunks: chunk ^= row & 15), frames >= T2 stay zero
     auto h_off = [&](int row, int chunk) { return row * (CD_BN * 2) + ((chunk ^ (row & 15)) << 4); };
@@ -285,10 +311,12 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     }
 }
 
-constexpr size_t CD_LDS_BYTES = 2 * CD_XS_BYTES + CD_RING * CD_WS_BYTES + CD_H_BYTES + (CD_MAX_SEG * (CD_BN + 64 + CD_G)) * sizeof(float);
+constexpr int CD_MAX_CIN = 2048;  // BN1 parameters of the layer live in LDS
+constexpr size_t CD_LDS_BYTES = 2 * CD_XS_BYTES + CD_RING * CD_WS_BYTES + CD_H_BYTES + (CD_MAX_SEG * (CD_BN + 64 + CD_G) + 2 * CD_MAX_CIN) * sizeof(float);
 
 bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len) {
-    return bottleneck == CD_BN && growth == CD_G && T2 >= 1 && T2 <= CD_ROWS && cin % 32 == 0 && cin >= 32 && dil >= 1 && dil <= CD_PAD &&
+    return bottleneck == CD_BN && growth == CD_G && T2 >= 1 && T2 <= CD_ROWS && cin % 32 == 0 && cin >= 32 && cin <= CD_MAX_CIN - 64 && dil >= 1 &&
+           dil <= CD_PAD &&
            seg_len > 0 && (T2 + seg_len - 1) / seg_len <= CD_MAX_SEG;
 }
 
