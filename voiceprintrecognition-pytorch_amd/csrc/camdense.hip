@@ -16,8 +16,8 @@
 // (columns = time steps), so a lane ends up with 4 consecutive output channels of one time step.  8 waves: wave (cw = w & 3,
 // th = w >> 2) owns output-channel tiles {2 cw, 2 cw + 1} x time tiles {5 th .. 5 th + 4} of the 1x1 GEMM; W1 streams through
 // a 3-slot LDS ring by LDS-DMA, x is loaded to registers one 64-channel stage ahead, passed through BN1 + ReLU in fp32 and
-// written to a double-buffered LDS tile (the loads bypass L1: the buffer is re-read by the next layer's launch with 32 more
-// channels, and every element is used exactly once here).
+// written to a double-buffered LDS tile.  (Default cache policy on these loads: the block's buffer -- 78 MB for 256 utterances --
+// is re-read by every later layer and lives in the 256 MB Infinity Cache; non-temporal loads measured 1.5-2.6 TB/s, r03i.)
 #include <type_traits>
 
 #include "kernels.h"
@@ -78,8 +78,32 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     }
     __syncthreads();
 
-    // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
+    // ---- parameters of the later phases are requested NOW: they are the oldest vector-memory operations of the wave, so they
+    // are long complete when phases A-epilogue / B / C consume them and never sit in front of a counted wait.  (Requested where
+    // they are used, each of them costs a full L2 / HBM round trip in a kernel that has ~20 us of work per launch.)
     const int cw = wave & 3, th = wave >> 2;
+    float4v e_bn2s[2], e_bn2t[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        e_bn2s[mi] = *reinterpret_cast<const float4v*>(a.bn2_s + (cw * 2 + mi) * 16 + 4 * fg);
+        e_bn2t[mi] = *reinterpret_cast<const float4v*>(a.bn2_t + (cw * 2 + mi) * 16 + 4 * fg);
+    }
+    // context FCs, cooperative: FC1 row j = tid >> 3, channels 16 * (tid & 7) .. + 15; FC2 row co = tid >> 4, inputs 4 * (tid & 15) .. + 3
+    float4v e_wa[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e_wa[u] = *reinterpret_cast<const float4v*>(a.wa + (tid >> 3) * CD_BN + (tid & 7) * 16 + 4 * u);
+    const float4v e_wb = *reinterpret_cast<const float4v*>(a.wb + (tid >> 4) * 64 + (tid & 15) * 4);
+    const float e_ba = a.ba[tid >> 3], e_bb = a.bb[tid >> 4];
+    half8v e_wl[3][4];  // k=3 conv weights of this wave's channel tile: A fragments of the 12 K steps
+    {
+        const half_t* wrow = a.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CD_BN + 8 * fg;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) e_wl[tap][kk] = *reinterpret_cast<const half8v*>(wrow + tap * CD_BN + kk * 32);
+    }
+
+    // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
     const int lrow = lane >> 3, kc = (lane & 7) ^ lrow;
     auto issue_w = [&](int s) {  // W1 stage s: 128 rows x 128 bytes = 16 transfers of 1 KiB, two per wave
         char* dst = ws + (s % CD_RING) * CD_WS_BYTES;
@@ -102,7 +126,7 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
         for (int p = 0; p < 3; ++p) {
             int row = xrow0 + 64 * p;
             row = row < T2 ? row : T2 - 1;
-            r[p] = __builtin_nontemporal_load(reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c));
+            r[p] = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c);
         }
     };
     auto store_x = [&](int s, const half8v (&r)[3]) {  // BN1 + ReLU in fp32, then into the stage tile (rows >= T2 and channels >= cin stay zero)
@@ -196,8 +220,7 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int co = (cw * 2 + mi) * 16 + 4 * fg;
-        const float4v sc = *reinterpret_cast<const float4v*>(a.bn2_s + co);
-        const float4v sh = *reinterpret_cast<const float4v*>(a.bn2_t + co);
+        const float4v sc = e_bn2s[mi], sh = e_bn2t[mi];
 #pragma unroll
         for (int ni = 0; ni < 5; ++ni) {
             const int t = (th * 5 + ni) * 16 + fr;
@@ -247,27 +270,39 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
             ctx[sg * CD_BN + c] = len > 0 ? (v + other) / (float)T2 + v / (float)len : 0.0f;
         }
         __syncthreads();
-        if (tid < CD_MAX_SEG * 64) {  // g1 = ReLU(Wa ctx + ba)
-            const int sg = tid >> 6, j = tid & 63;
-            float v = a.ba[j];
-            const float* wr = a.wa + j * CD_BN;
-            const float* cx = ctx + sg * CD_BN;
-            for (int c = 0; c < CD_BN; c += 4) {
-                const float4v w4 = *reinterpret_cast<const float4v*>(wr + c);
-                v = fmaf(w4[0], cx[c], v);
-                v = fmaf(w4[1], cx[c + 1], v);
-                v = fmaf(w4[2], cx[c + 2], v);
-                v = fmaf(w4[3], cx[c + 3], v);
+        {   // g1 = ReLU(Wa ctx + ba): 8 threads per output row, both segments, partial dot products summed over 8 lanes (DPP)
+            const int j = tid >> 3, part8 = tid & 7;
+#pragma unroll
+            for (int sg = 0; sg < CD_MAX_SEG; ++sg) {
+                const float* cx = ctx + sg * CD_BN + part8 * 16;
+                float v = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4v c4 = *reinterpret_cast<const float4v*>(cx + 4 * u);
+                    v = fmaf(e_wa[u][0], c4[0], v);
+                    v = fmaf(e_wa[u][1], c4[1], v);
+                    v = fmaf(e_wa[u][2], c4[2], v);
+                    v = fmaf(e_wa[u][3], c4[3], v);
+                }
+                v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);
+                v += dpp_mov<DPP_QUAD_XOR2>(0.0f, v);
+                v += dpp_mov<DPP_ROW_HALF_MIRROR>(0.0f, v);  // lanes l and 7 - l of each 8: the two quads hold equal sums after the quad steps
+                if (part8 == 0) g1[sg * 64 + j] = fmaxf(v + e_ba, 0.0f);
             }
-            g1[sg * 64 + j] = fmaxf(v, 0.0f);
         }
         __syncthreads();
-        if (tid < CD_MAX_SEG * CD_G) {  // gate = sigmoid(Wb g1 + bb)
-            const int sg = tid >> 5, co = tid & 31;
-            float v = a.bb[co];
-            const float* wr = a.wb + co * 64;
-            for (int j = 0; j < 64; ++j) v = fmaf(wr[j], g1[sg * 64 + j], v);
-            gate[sg * CD_G + co] = 1.0f / (1.0f + expf(-v));
+        {   // gate = sigmoid(Wb g1 + bb): 16 threads per output row (one DPP row), both segments
+            const int co = tid >> 4, part16 = tid & 15;
+#pragma unroll
+            for (int sg = 0; sg < CD_MAX_SEG; ++sg) {
+                const float4v g4 = *reinterpret_cast<const float4v*>(g1 + sg * 64 + part16 * 4);
+                float v = e_wb[0] * g4[0];
+                v = fmaf(e_wb[1], g4[1], v);
+                v = fmaf(e_wb[2], g4[2], v);
+                v = fmaf(e_wb[3], g4[3], v);
+                v = row16_sum(v);
+                if (part16 == 0) gate[sg * CD_G + co] = 1.0f / (1.0f + expf(-(v + e_bb)));
+            }
         }
         __syncthreads();
     }
@@ -278,12 +313,11 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
         float4v yc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        const half_t* wrow = a.wl + (int64_t)(ct * 16 + fr) * 3 * CD_BN + 8 * fg;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const half8v af = *reinterpret_cast<const half8v*>(wrow + tap * CD_BN + kk * 32);
+                const half8v af = e_wl[tap][kk];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int tile = tg + 4 * j;
