@@ -52,7 +52,7 @@ def test_collate_pads_and_keeps_order():
     assert wav.tolist() == [[1, 1, 1, 1, 1], [2, 2, 2, 0, 0]] and ns.tolist() == [5, 3] and labels.tolist() == [2, 0]
 
 
-def _make_eval_set(tmp_path, n_spk=3, per_spk=3, seed=5):
+def _make_eval_set(tmp_path, n_spk=3, per_spk=3, seed=5, num_workers=0):
     """wav files of different lengths + enrol / trial lists + a TDNN checkpoint; returns everything the oracle needs too."""
     import scipy.io.wavfile as wavfile
     man, sd, _, _, _ = load_case('tdnn')
@@ -74,7 +74,7 @@ def _make_eval_set(tmp_path, n_spk=3, per_spk=3, seed=5):
         with open(str(tmp_path / f'{k}.txt'), 'w') as f:
             f.writelines(v)
     cfg = dict(dataset_conf=dict(dataset=dict(min_duration=0.3, sample_rate=16000, use_dB_normalization=True, target_dB=-20),
-                                 eval_conf=dict(batch_size=4, max_duration=20), dataLoader=dict(num_workers=0),
+                                 eval_conf=dict(batch_size=4, max_duration=20), dataLoader=dict(num_workers=num_workers),
                                  enroll_list=str(tmp_path / 'enroll.txt'), trials_list=str(tmp_path / 'trials.txt')),
                preprocess_conf=dict(feature_method='Fbank', method_args=FB),
                model_conf=dict(model='TDNN', model_args=dict(embd_dim=192)))
@@ -103,7 +103,7 @@ def _oracle_eval(cfg, sd):
 
 def test_trainer_evaluate_cpu_matches_oracle(tmp_path):
     from mvector.trainer import MVectorTrainer
-    cfg, model_dir, sd = _make_eval_set(tmp_path)
+    cfg, model_dir, sd = _make_eval_set(tmp_path, num_workers=2)
     eer, dcf, thr = MVectorTrainer(cfg, use_gpu=False).evaluate(resume_model=model_dir)
     o_eer, o_dcf, o_thr, _ = _oracle_eval(cfg, sd)
     assert abs(eer - o_eer) < 1e-6 and abs(dcf - o_dcf) < 1e-6 and abs(thr - o_thr) < 1e-4
@@ -151,7 +151,7 @@ def test_gpu_fbank_varlen_matches_per_utterance_oracle():
 @pytest.mark.gpu
 def test_gpu_trainer_evaluate_matches_oracle(tmp_path):
     from mvector.trainer import MVectorTrainer
-    cfg, model_dir, sd = _make_eval_set(tmp_path, n_spk=4, per_spk=4, seed=9)
+    cfg, model_dir, sd = _make_eval_set(tmp_path, n_spk=4, per_spk=4, seed=9, num_workers=2)  # decode in forked workers, embed on the GPU
     eer, dcf, thr = MVectorTrainer(cfg, use_gpu=True).evaluate(resume_model=model_dir)
     o_eer, o_dcf, o_thr, _ = _oracle_eval(cfg, sd)
     # fp16 activations move individual scores by ~1e-4; the rank-based metrics move only if two trials swap order

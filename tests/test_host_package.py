@@ -50,6 +50,11 @@ def test_build_model_and_config_objects():
     assert cfg.model_conf.model_args.channels[-1] == 192
     with pytest.raises(AttributeError):
         build_model(80, dict_to_object(dict(model_conf=dict(model='NoSuchModel'))))
+    import mvector.models as M
+    for name in ('Res2Net', 'ResNetSE', 'SpeakerIdentification'):  # exported like the reference, outside the accelerated path
+        assert hasattr(M, name)
+        with pytest.raises(NotImplementedError, match='outside the MI355X embedding path'):
+            build_model(80, dict_to_object(dict(model_conf=dict(model=name))))
 
 
 def test_build_model_eres2net_family_and_constructor_contract():

@@ -67,9 +67,10 @@ class MVectorTrainer(object):
         ds_conf = self.configs.dataset_conf
         args = dict(ds_conf.get('dataset', {}))
         args['max_duration'] = ds_conf.eval_conf.max_duration
+        # DataLoader workers as configured (dataLoader.num_workers), also for the GPU path: there the workers only decode and
+        # dB-normalise audio (waveform items; featurisation happens on the GPU in the main process), so forked workers never
+        # touch the HIP runtime
         loader_args = dict(ds_conf.get('dataLoader', {}))
-        if self.use_gpu:
-            loader_args['num_workers'] = 0  # decoding only; featurisation happens on the GPU in the main process
         lists = [ds_conf.enroll_list, ds_conf.trials_list]
         use_wave = self._waveform_batches and not any(self._has_npy(p) for p in lists)
         out = []
