@@ -26,9 +26,13 @@ echo "== res2"; timeout 300 python tools/bench_res2.py > $OUT/res2.log 2>&1; gre
 echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
 echo "== bench"; timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
 tail -2 $OUT/bench.log | cut -c1-3000
+echo "== bench campp / ecapa512 / mel"
+for m in campp ecapa512 ecapa512_mel eres2netv2; do timeout 600 python bench.py --model $m --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$m.log 2>&1; grep "^{" $OUT/bench_$m.log | cut -c1-400; done
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/rocprof.log
 for f in $(find $OUT/prof -name "*kernel_stats*.csv"); do head -25 $f; done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_campp -o bench -- python $REPO/bench.py --model campp --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_campp.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mel -o bench -- python $REPO/bench.py --model ecapa512_mel --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof_mel.log 2>&1
 cd $REPO
 if [ -z "$2" ]; then echo "== pmc"; bash tools/gpu_pmc.sh $TAG/pmc; fi
