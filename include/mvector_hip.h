@@ -338,6 +338,17 @@ int mv_wave_prepare_i16(const int16_t* pcm, int64_t pcm_stride, const int64_t* n
 int mv_asp_pool_f16(const void* h, const void* w2_packed, const void* x, int64_t ldx, const float* gmean, int64_t gmean_ld,
                     float* out, int32_t B, int32_t T, int32_t C, int32_t A, float logit_bound_log2, mv_stream_t stream);
 
+/* One 3x3 Conv2d of the CAM++ front-end (FCM, mvector/models/campplus.py:221-292: BasicResBlock.conv1 / conv2 (+ shortcut) and
+ * FCM.conv2) on channel-last fp16 maps with 32 feature maps, eval BatchNorm already folded into w / bias, ReLU at the end:
+ *   x  fp16 [B, Fin, T, 32];  stride sf (1 | 2) on the frequency axis, zero padding 1;  y fp16, element (b, fo, t, co) at
+ *   y + b * y_sB + fo * y_sF + t * y_sT + co (strides in elements);  Fout = (Fin - 1) / sf + 1;
+ *   w  fp16 [9 or 10][32 co][32 ci], tap = 3 * df + dt;  bias fp32 [32];
+ *   mode2 = 0: none;  1: tenth tap = the block's strided 1x1 shortcut conv (+BN) on x2 [B, F2, T, 32] at row fo * sf2;
+ *   2: identity residual, x2 added before the ReLU.  Layer-level entry point of the parity tests. */
+int mv_fcm_conv3x3_f16(const void* x, int32_t Fin, int32_t sf, const void* x2, int32_t F2, int32_t sf2, int32_t mode2, const void* w,
+                       const float* bias, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, int32_t Fout,
+                       mv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

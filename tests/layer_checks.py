@@ -381,6 +381,53 @@ def asp_pool_case(cdll, device, B=3, T=45, C=192, A=128, ldx=None, online=False,
     return err
 
 
+FCM_CASES = [
+    dict(B=2, Fin=12, T=45, sf=1, mode2=0),                # one time tile, NI = 1, plain conv
+    dict(B=2, Fin=12, T=45, sf=2, mode2=0),                # strided in frequency (BasicResBlock.conv1 / FCM.conv2)
+    dict(B=1, Fin=9, T=70, sf=2, mode2=0, strided_out=True),  # odd Fin, NI = 2, the [B, T, F8, 32] output layout of FCM.conv2
+    dict(B=2, Fin=6, T=100, sf=1, mode2=1, sf2=2),         # conv2 + strided 1x1 shortcut tap on the block input
+    dict(B=2, Fin=6, T=33, sf=1, mode2=2),                 # conv2 + identity residual
+    dict(B=1, Fin=5, T=330, sf=1, mode2=2),                # two time tiles (T > 320), NI = 3
+    dict(B=1, Fin=3, T=16, sf=1, mode2=0),                 # fewer rows than the ring
+]
+
+
+def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, seed=0):
+    """3x3 conv2d over (frequency, time) with 32 maps + folded BN bias + (1x1 shortcut | identity) + ReLU (campplus.py:221-292)."""
+    g = torch.Generator().manual_seed(seed)
+    Fout = (Fin - 1) // sf + 1
+    x = torch.randn(B, Fin, T, 32, generator=g).half()
+    ntaps = 10 if mode2 == 1 else 9
+    w = (torch.randn(ntaps, 32, 32, generator=g) * 0.08).half()
+    bias = torch.randn(32, generator=g) * 0.1
+    F2 = (Fout - 1) * sf2 + 1 + (1 if sf2 == 2 else 0)
+    x2 = torch.randn(B, F2, T, 32, generator=g).half() if mode2 else None
+    if strided_out:      # y[b, t, fo, co]
+        y = torch.full((B, T, Fout, 32), float('nan')).half().to(device)
+        sB, sF, sT = T * Fout * 32, 32, Fout * 32
+    else:                # y[b, fo, t, co]
+        y = torch.full((B, Fout, T, 32), float('nan')).half().to(device)
+        sB, sF, sT = Fout * T * 32, T * 32, 32
+    xd, wd, bd = x.to(device), w.to(device), bias.to(device)
+    x2d = x2.to(device) if mode2 else None
+    _hip.check(cdll.mv_fcm_conv3x3_f16(xd.data_ptr(), Fin, sf, x2d.data_ptr() if mode2 else None, F2 if mode2 else 0, sf2, mode2,
+                                       wd.data_ptr(), bd.data_ptr(), y.data_ptr(), sB, sF, sT, B, T, Fout, _stream(xd)), cdll)
+    # reference in fp64 from the fp16 operands
+    xin = x.double().permute(0, 3, 1, 2)                                        # [B, 32, F, T]
+    w33 = w[:9].double().reshape(3, 3, 32, 32).permute(2, 3, 0, 1).contiguous()  # [co, ci, df, dt]
+    ref = torch.nn.functional.conv2d(xin, w33, bias.double(), stride=(sf, 1), padding=1)
+    if mode2 == 1:
+        ref = ref + torch.nn.functional.conv2d(x2.double().permute(0, 3, 1, 2), w[9].double().reshape(32, 32, 1, 1), None, stride=(sf2, 1))[:, :, :Fout]
+    elif mode2 == 2:
+        ref = ref + x2.double().permute(0, 3, 1, 2)[:, :, ::sf2][:, :, :Fout]
+    ref = ref.clamp(min=0).permute(0, 3, 2, 1) if strided_out else ref.clamp(min=0).permute(0, 2, 3, 1)
+    out = y.cpu().double()
+    assert torch.isfinite(out).all(), 'unwritten outputs'
+    err = (out - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err   # the fp16 rounding of the stored result
+    return err
+
+
 def wave_prepare_case(cdll, device, B=5, L=5000, normalize=True, seed=0):
     from oracle import frontend
     g = torch.Generator().manual_seed(seed)

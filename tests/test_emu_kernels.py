@@ -118,6 +118,14 @@ def test_emu_eres2net_rejects_bad_arguments():
         lc._hip.Model('eres2net', cfg, sd_missing, cdll=emu_cdll())
 
 
+@pytest.mark.parametrize('idx', range(len(lc.FCM_CASES)))
+@pytest.mark.parametrize('impl', ['band', 'row'])
+def test_emu_fcm_conv3x3(idx, impl, monkeypatch):
+    """the band kernel (LDS ring of input rows, default) and the one-row-per-workgroup kernel (MV_FCM_IMPL=row)"""
+    monkeypatch.setenv('MV_FCM_IMPL', impl)
+    lc.fcm_conv_case(emu_cdll(), 'cpu', seed=idx, **lc.FCM_CASES[idx])
+
+
 def test_emu_ecapa_tiny_end_to_end():
     cd, rel = lc.model_case(emu_cdll(), 'cpu', 'ecapa_tiny')
     assert rel < 5e-3

@@ -493,6 +493,22 @@ def test_gpu_asp_pool(cfg):
     lc.asp_pool_case(product_lib(), DEV, **cfg)
 
 
+FCM_GPU_CASES = lc.FCM_CASES + [
+    dict(B=9, Fin=80, T=298, sf=2, mode2=0),            # the shipped geometry: FCM layer1.block0.conv1, NI = 5
+    dict(B=7, Fin=40, T=298, sf=1, mode2=1, sf2=2),     # layer1.block0.conv2 + shortcut
+    dict(B=7, Fin=40, T=298, sf=1, mode2=2),            # layer1.block1.conv2 + identity
+    dict(B=300, Fin=20, T=298, sf=2, mode2=0, strided_out=True),  # more workgroups than CUs, FCM.conv2 layout
+    dict(B=2, Fin=20, T=1000, sf=1, mode2=2),           # 10 s: four time tiles
+]
+
+
+@pytest.mark.parametrize('idx', range(len(FCM_GPU_CASES)))
+@pytest.mark.parametrize('impl', ['band', 'row'])
+def test_gpu_fcm_conv3x3(idx, impl, monkeypatch):
+    monkeypatch.setenv('MV_FCM_IMPL', impl)
+    lc.fcm_conv_case(product_lib(), DEV, seed=idx, **FCM_GPU_CASES[idx])
+
+
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
                                  dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
 def test_gpu_res2net_fused_chain(cfg):

@@ -14,6 +14,9 @@ namespace mv {
 constexpr int FCM_TT = 128;  // frames per tile
 constexpr int FCM_C = 32;    // feature maps
 
+// 256 zero bytes: source of every padded 16-byte chunk of the band kernel's row transfers
+__device__ __attribute__((aligned(256))) const unsigned char g_fcm_zero_page[256] = {0};
+
 // ---- first conv: one input map (the fp32 features [B, T, F], read transposed), K = 9 -> plain VALU -----------------
 __global__ __launch_bounds__(256) void fcm_conv1_kernel(const float* feats, half_t* out, const float* w, const float* bias,
                                                         int B, int T, int F) {
@@ -177,6 +180,191 @@ __global__ __launch_bounds__(256) void fcm_conv3x3_kernel(FcmConvArgs a) {
     }
 }
 
+
+// ---- band kernel: one workgroup walks a band of output frequency rows with the input rows in an LDS ring --------------
+// The row kernel above stages three input rows per (utterance, output row) workgroup and computes with nothing in flight: every
+// input row is fetched three times (from L2 at best) and each 128-frame tile pays a full memory round trip (measured 2.3-2.5
+// TB/s on tensors that are read and written exactly once).  Here a workgroup owns (utterance, time tile of 64*NI frames, band
+// of output rows) and walks the band downwards:
+//   * input rows enter a ring of RING row slots by LDS-DMA (global_load_lds, 16 B per lane, no registers), each row ONCE, 2-4
+//     rows ahead of the row being computed; the residual input (shortcut 1x1 tap / identity add of BasicResBlock) rides a
+//     second ring of 2 slots; one counted s_waitcnt + one barrier per output row;
+//   * the nine (ten) [32 x 32] tap matrices stay in registers as MFMA A fragments with their ROWS PERMUTED
+//     (A row i of tile mi <-> output map 8*(i>>2) + 4*mi + (i&3)), so a lane ends up with 8 consecutive maps of one
+//     position: one 16-byte store, a 16-lane group writes a whole 1 KiB run;
+//   * the identity residual is a tenth tap with the (permuted) identity matrix: exact in fp16 x fp32-accumulate.
+// LDS: RING slots of (64*NI + 2) positions x 64 B rounded up to whole 1 KiB transfers (+ 2 residual slots + one dump KiB that
+// swallows the transfers of waves whose share of a row is one short, so every wave issues the same number per row and the
+// waits can be counted).  NI = 5: 7 x 21 KiB + 1 = 148 KiB (no residual), 5 x 21 + 2 x 20 + 1 = 146 KiB.
+template <int NI, int SF, bool HAS2>
+struct FcmBand {
+    static constexpr int RING = HAS2 ? 5 : 7;
+    static constexpr int POS = 64 * NI;                 // output positions per time tile (4 waves x NI x 16)
+    static constexpr int NTR = 4 * NI + 1;              // 1 KiB transfers per input row slot ((POS + 2) * 64 B rounded up)
+    static constexpr int TPW = NI + 1;                  // transfers per wave and row
+    static constexpr int SLOT_BYTES = NTR * 1024;
+    static constexpr int RES_BYTES = POS * 64;
+    static constexpr int DUMP_OFF = RING * SLOT_BYTES + (HAS2 ? 2 * RES_BYTES : 0);
+    static constexpr int LDS_BYTES = DUMP_OFF + 1024;
+    static constexpr int AHEAD = (RING - 3 - SF) * TPW;  // transfers that may stay in flight when a row starts
+};
+
+template <int NI, int SF, bool HAS2>
+__global__ __launch_bounds__(256) void fcm_band_kernel(FcmConvArgs a, int n_ttiles, int n_bands, int band_rows) {
+    typedef FcmBand<NI, SF, HAS2> G;
+    MV_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = MV_UNIFORM(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    int wg = blockIdx.x;
+    const int band = wg % n_bands;
+    wg /= n_bands;
+    const int tt = wg % n_ttiles;
+    const int b = wg / n_ttiles;
+    const int t0 = tt * G::POS;
+    const int f0 = band * band_rows;
+    const int f1 = f0 + band_rows < a.Fout ? f0 + band_rows : a.Fout;
+    const int nsteps = f1 - f0;
+    if (nsteps <= 0) return;
+    const int g0 = f0 * SF - 1;                 // first input row of the band (may be -1: zero padding)
+    const int rel_last = (nsteps - 1) * SF + 2;  // last input row the band needs (relative to g0)
+
+    // ---- weights: A fragments with permuted rows, bias of this lane's 8 maps ----
+    const int ntaps = a.mode2 == 1 ? 10 : 9;
+    half8v wf[10][2];
+#pragma unroll
+    for (int tap = 0; tap < 10; ++tap)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);
+            if (tap < ntaps) {
+                wf[tap][mi] = *reinterpret_cast<const half8v*>(a.w + ((tap * FCM_C + co) * FCM_C + 8 * fg));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[tap][mi][e] = (half_t)((HAS2 && a.mode2 == 2 && 8 * fg + e == co) ? 1.0f : 0.0f);
+            }
+        }
+    float bias[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mi][r] = a.bias[8 * fg + 4 * mi + r];
+
+    // ---- this lane's share of a row transfer: element offset inside an input row (-1 = zero padding in time) ----
+    const half_t* zero = reinterpret_cast<const half_t*>(g_fcm_zero_page);
+    int xoff[G::TPW];
+    bool xlive[G::TPW];
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) {
+        const int j = wave + 4 * i;
+        const int q = j * 64 + lane;         // 16-byte chunk inside the slot
+        const int pi = q >> 2;               // slot position: frame t0 + pi - 1
+        const int c = (q & 3) ^ ((pi >> 1) & 3);
+        const int t = t0 + pi - 1;
+        xlive[i] = j < G::NTR;
+        xoff[i] = (xlive[i] && pi < G::POS + 2 && t >= 0 && t < a.T) ? t * FCM_C + c * 8 : -1;
+    }
+    int roff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane;
+        const int pi = q >> 2;
+        const int c = (q & 3) ^ ((pi >> 1) & 3);
+        const int t = t0 + pi;
+        roff[i] = t < a.T ? t * FCM_C + c * 8 : -1;
+    }
+    char* const dump = smem + G::DUMP_OFF;
+
+    int islot = 0;  // ring slot of the next row to be requested
+    int irel = 0;   // its index relative to g0
+    auto issue_row = [&]() {
+        const int fin = g0 + irel;
+        const bool rok = fin >= 0 && fin < a.Fin && irel <= rel_last;  // uniform
+        const half_t* base = a.x + ((int64_t)b * a.Fin + (rok ? fin : 0)) * a.T * FCM_C;
+        char* slot = smem + islot * G::SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < G::TPW; ++i) {
+            const half_t* src = (rok && xoff[i] >= 0) ? base + xoff[i] : zero;
+            glds16(src, xlive[i] ? slot + (wave + 4 * i) * 1024 : dump);
+        }
+        ++irel;
+        islot = islot + 1 == G::RING ? 0 : islot + 1;
+    };
+    auto issue_res = [&](int k) {
+        const bool rok = k < nsteps;
+        const int f2 = (f0 + (rok ? k : 0)) * a.sf2;
+        const half_t* base = a.x2 + ((int64_t)b * a.F2 + f2) * a.T * FCM_C;
+        char* slot = smem + G::RING * G::SLOT_BYTES + (k & 1) * G::RES_BYTES;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const half_t* src = (rok && roff[i] >= 0) ? base + roff[i] : zero;
+            glds16(src, slot + (wave + 4 * i) * 1024);
+        }
+    };
+
+    if (HAS2) issue_res(0);
+#pragma unroll 1
+    for (int r = 0; r < G::RING - SF; ++r) issue_row();
+
+    int cslot = 0;  // ring slot of the first input row of the current output row
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+        wait_vm<G::AHEAD>();   // everything but the youngest AHEAD transfers of this wave has landed ...
+        lds_barrier();         // ... in every wave; all waves are done with the slots the next requests overwrite
+        if (HAS2) issue_res(k + 1);
+#pragma unroll
+        for (int s = 0; s < SF; ++s) issue_row();
+
+        float4v acc[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{bias[mi][0], bias[mi][1], bias[mi][2], bias[mi][3]};
+        const int pbase = wave * (16 * NI) + fr;
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+            int sl = cslot + df;
+            sl = sl >= G::RING ? sl - G::RING : sl;
+            const char* row = smem + sl * G::SLOT_BYTES;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const half8v bf = *reinterpret_cast<const half8v*>(row + fcm_lds_off(pbase + ni * 16 + dt, fg));
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[df * 3 + dt][mi], bf, acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        if (HAS2) {
+            const char* row = smem + G::RING * G::SLOT_BYTES + (k & 1) * G::RES_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const half8v bf = *reinterpret_cast<const half8v*>(row + fcm_lds_off(pbase + ni * 16, fg));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[9][mi], bf, acc[mi][ni], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: ReLU, 8 consecutive maps of one position per lane ----
+        const int fo = f0 + k;
+        half_t* yrow = a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF + 8 * fg;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + pbase + ni * 16;
+            half8v o;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * mi + r] = (half_t)fmed3(acc[mi][ni][r], 0.0f, 65504.0f);
+            if (t < a.T) *MV_AS_GLOBAL(half8v, yrow + (int64_t)t * a.y_sT) = o;
+        }
+        cslot += SF;
+        cslot = cslot >= G::RING ? cslot - G::RING : cslot;
+    }
+}
+
 int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F,
                      hipStream_t stream) {
     const int64_t total = (int64_t)B * F * T * 4;
@@ -185,11 +373,48 @@ int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const floa
     return check_launch("fcm_conv1_kernel");
 }
 
+template <int NI, int SF, bool HAS2>
+static int fcm_band_launch_one(const FcmConvArgs& a, int n_ttiles, hipStream_t stream) {
+    typedef FcmBand<NI, SF, HAS2> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (MV_SET_MAX_SMEM((fcm_band_kernel<NI, SF, HAS2>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm band kernel: LDS size rejected");
+        attr_set = true;
+    }
+    // one workgroup per CU is resident (LDS): split the output rows into bands only while (utterance, time tile) pairs alone do
+    // not fill the chip; every band re-reads its two halo rows
+    const int64_t pairs = (int64_t)a.B * n_ttiles;
+    const int cus = device_cu_count();
+    int n_bands = (int)ceil_div((int64_t)cus, pairs);
+    const int max_bands = a.Fout / 4 > 0 ? a.Fout / 4 : 1;
+    n_bands = n_bands < 1 ? 1 : (n_bands > max_bands ? max_bands : n_bands);
+    const int band_rows = (int)ceil_div(a.Fout, n_bands);
+    n_bands = (int)ceil_div(a.Fout, band_rows);
+    MV_REQUIRE(pairs * n_bands < ((int64_t)1 << 31), "fcm_conv3x3: grid too large");
+    MV_LAUNCH((fcm_band_kernel<NI, SF, HAS2>), ((unsigned)(pairs * n_bands), 1, 1), (256, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands,
+              band_rows);
+    return check_launch("fcm_band_kernel");
+}
+
+template <int NI>
+static int fcm_band_launch_ni(const FcmConvArgs& a, int n_ttiles, hipStream_t stream) {
+    if (a.mode2 != 0) return fcm_band_launch_one<NI, 1, true>(a, n_ttiles, stream);
+    if (a.sf == 2) return fcm_band_launch_one<NI, 2, false>(a, n_ttiles, stream);
+    return fcm_band_launch_one<NI, 1, false>(a, n_ttiles, stream);
+}
+
+// MV_FCM_IMPL=row keeps the one-row-per-workgroup kernel (A/B runs); read per call, not cached
+static bool fcm_band_enabled() {
+    const char* e = getenv("MV_FCM_IMPL");
+    return e == nullptr || strcmp(e, "row") != 0;
+}
+
 int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F2, int sf2, int mode2, const half_t* w,
                        const float* bias, half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, int Fout,
                        hipStream_t stream) {
     MV_REQUIRE(x != nullptr && w != nullptr && bias != nullptr && y != nullptr, "fcm_conv3x3: null tensor");
     MV_REQUIRE(mode2 == 0 || x2 != nullptr, "fcm_conv3x3: residual input missing");
+    MV_REQUIRE(B > 0 && T > 0 && Fin > 0 && Fout > 0, "fcm_conv3x3: bad geometry");
     MV_REQUIRE((int64_t)B * Fout < ((int64_t)1 << 31), "fcm_conv3x3: grid too large");
     FcmConvArgs a;
     a.x = x;
@@ -208,8 +433,37 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
     a.F2 = F2;
     a.sf2 = sf2;
     a.mode2 = mode2;
+    // band kernel: 16-byte stores need 8-map alignment of the output rows; the residual conv is never strided (BasicResBlock)
+    const bool band_ok = (sf == 1 || sf == 2) && (mode2 == 0 || sf == 1) && y_sB % 8 == 0 && y_sF % 8 == 0 && y_sT % 8 == 0 &&
+                         (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (int64_t)T * FCM_C * (int64_t)(Fin > F2 ? Fin : F2) < ((int64_t)1 << 31);
+    if (band_ok && fcm_band_enabled()) {
+        // time tiles of 64 * NI frames, NI <= 5: as few tiles as possible, then the smallest NI that covers T
+        const int n16 = (int)ceil_div(T, 16);
+        const int n_ttiles = (int)ceil_div(n16, 20);
+        const int ni = (int)ceil_div(n16, 4 * n_ttiles);
+        switch (ni) {
+            case 1: return fcm_band_launch_ni<1>(a, n_ttiles, stream);
+            case 2: return fcm_band_launch_ni<2>(a, n_ttiles, stream);
+            case 3: return fcm_band_launch_ni<3>(a, n_ttiles, stream);
+            case 4: return fcm_band_launch_ni<4>(a, n_ttiles, stream);
+            default: return fcm_band_launch_ni<5>(a, n_ttiles, stream);
+        }
+    }
     MV_LAUNCH(fcm_conv3x3_kernel, ((unsigned)(B * Fout), 1, 1), (256, 1, 1), 0, stream, a);
     return check_launch("fcm_conv3x3_kernel");
 }
 
 }  // namespace mv
+
+extern "C" {
+int mv_fcm_conv3x3_f16(const void* x, int32_t Fin, int32_t sf, const void* x2, int32_t F2, int32_t sf2, int32_t mode2, const void* w,
+                       const float* bias, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, int32_t Fout,
+                       mv_stream_t stream) {
+    MV_REQUIRE(Fin > 0 && (sf == 1 || sf == 2) && Fout == (Fin - 1) / sf + 1, "fcm_conv3x3: Fout must be (Fin - 1) / sf + 1");
+    MV_REQUIRE(mode2 >= 0 && mode2 <= 2, "fcm_conv3x3: mode2 must be 0, 1 or 2");
+    MV_REQUIRE(mode2 == 0 || (sf2 >= 1 && F2 > (Fout - 1) * sf2), "fcm_conv3x3: residual rows out of range");
+    return mv::fcm_conv3x3_launch(reinterpret_cast<const half_t*>(x), Fin, sf, reinterpret_cast<const half_t*>(x2), F2, sf2, mode2,
+                                  reinterpret_cast<const half_t*>(w), bias, reinterpret_cast<half_t*>(y), y_sB, y_sF, y_sT, B, T, Fout,
+                                  static_cast<hipStream_t>(stream));
+}
+}

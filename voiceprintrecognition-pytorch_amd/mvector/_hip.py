@@ -119,6 +119,7 @@ _SIGNATURES = {
     'mv_profile_read': (c_i32, [c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32]),
     'mv_wave_prepare_i16': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp]),
     'mv_asp_pool_f16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    'mv_fcm_conv3x3_f16': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
 }
 
