@@ -19,6 +19,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define MV_DYN_SMEM(name) char* name = MV_EMU_DYN_SMEM()
 #define MV_SET_MAX_SMEM(kernel, bytes) hipSuccess
 #define MV_WAVE_FENCE() emu::wave_sync()
+#define MV_EMU_WAVE_SYNC() emu::wave_sync()
 #define MV_AS_LDS(T, p) ((T*)(p))
 #define MV_AS_GLOBAL(T, p) ((T*)(p))
 #define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)
@@ -72,6 +73,8 @@ inline void row_swap_odd_even(unsigned& x, unsigned& y) {
 inline float fmed3(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 inline float max_raw(float v, float lo) { return fmaxf(v, lo); }
 inline float exp2_fast(float v) { return exp2f(v); }
+inline float rcp_fast(float v) { return 1.0f / v; }
+inline float sqrt_fast(float v) { return sqrtf(v); }
 inline float log2_fast(float v) { return log2f(v); }
 inline float4v mfma_4x4x1(float a, float b, float4v c) {  // D[lane][r] += A[4 * (lane / 4) + r] * B[lane]
     const int lane = emu::flat_tid() & 63;
@@ -97,6 +100,20 @@ inline void glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base
 template <int N>
 inline void wait_vm() {}
 inline void lds_barrier() { __syncthreads(); }
+inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
+    memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc, 16);
+}
+inline void lds_read1(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr)); }
+template <int N>
+inline void lds_wait(half8v&, half8v&) {}
+template <int N>
+inline void lds_wait(half8v&) {}
+template <int N>
+inline void lds_wait(half8v&, half8v&, half8v&) {}
+template <int N>
+inline void lds_wait(half8v&, half8v&, half8v&, half8v&) {}
+template <int OFF>
+inline void lds_read1_off(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF)); }
 
 template <int WAIT>
 inline void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {

@@ -163,7 +163,10 @@ def test_emu_melspec_other_geometry():
 
 
 @pytest.mark.parametrize('cfg', [dict(), dict(online=True), dict(B=5, T=9, C=72, A=64, ldx=80, centred=False),
-                                 dict(B=2, T=33, C=64, A=128, online=True, wscale=1.0)])
+                                 dict(B=2, T=33, C=64, A=128, online=True, wscale=1.0),
+                                 # the ring kernel (C a multiple of 256, bounded logits): 3 / 7 / 1 / 2 tiles, A = 128 and 64, no centre
+                                 dict(B=2, T=45, C=256), dict(B=2, T=100, C=512, A=64), dict(B=1, T=16, C=256), dict(B=1, T=1, C=256),
+                                 dict(B=2, T=17, C=256, centred=False), dict(B=1, T=130, C=256, ldx=264)])
 def test_emu_asp_pool(cfg):
     lc.asp_pool_case(emu_cdll(), 'cpu', **cfg)
 

@@ -488,7 +488,9 @@ def test_gpu_ecapa_on_melspectrogram_end_to_end():
 
 @pytest.mark.parametrize('cfg', [dict(), dict(online=True), dict(B=5, T=9, C=72, A=64, ldx=80, centred=False),
                                  dict(B=2, T=33, C=64, A=128, online=True, wscale=1.0), dict(B=9, T=298, C=3072, A=128),
-                                 dict(B=6, T=298, C=1536, A=128, online=True), dict(B=3, T=1, C=64, A=128)])
+                                 dict(B=6, T=298, C=1536, A=128, online=True), dict(B=3, T=1, C=64, A=128),
+                                 dict(B=2, T=45, C=256), dict(B=2, T=100, C=512, A=64), dict(B=1, T=16, C=256), dict(B=1, T=1, C=256),
+                                 dict(B=2, T=17, C=256, centred=False), dict(B=3, T=1000, C=1024, ldx=1032), dict(B=300, T=50, C=256)])
 def test_gpu_asp_pool(cfg):
     lc.asp_pool_case(product_lib(), DEV, **cfg)
 

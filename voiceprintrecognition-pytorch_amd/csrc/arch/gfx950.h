@@ -34,6 +34,8 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // Pointers with their address space stated: two branches that store the same values once to LDS and once to global memory
 // are otherwise tail-merged into ONE flat store behind a selected base pointer; pointer selects between a tensor and the zero
 // page lose the address space too (flat loads).
+// wave-level rendezvous that only the SIMT emulator needs (its lanes are fibres; on the device the lanes of a wave run in lockstep)
+#define MV_EMU_WAVE_SYNC() do { } while (0)
 #define MV_AS_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define MV_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
@@ -79,6 +81,8 @@ __device__ __forceinline__ float max_raw(float v, float lo) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
     return r;
 }
+__device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }    // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float sqrt_fast(float v) { return __builtin_amdgcn_sqrtf(v); }  // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float exp2_fast(float v) { return __builtin_amdgcn_exp2f(v); }  // v_exp_f32
 __device__ __forceinline__ float log2_fast(float v) { return __builtin_amdgcn_logf(v); }   // v_log_f32, normal inputs only
 // v_mfma_f32_4x4x1: 16 independent 4 x 4 outer products; D[lane][r] += A[4 * (lane / 4) + r] * B[lane]
@@ -111,6 +115,14 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The same transfer as inline assembly, invisible to the compiler's wait-count insertion.  With the builtin the compiler knows that
+// LDS is written behind its back: it puts s_waitcnt vmcnt(0) in front of every LDS load that may alias a transfer in flight and in
+// front of the first use of any global load that shares the counter with one (mixed event types are assumed to complete out of
+// order) -- which drains exactly the transfers a ring is meant to keep in flight.  The caller owns the ordering: the data is in LDS
+// once a later s_waitcnt vmcnt (the caller's, or the compiler's for a younger tracked load) has retired the transfer.
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base_addr) : "memory", "m0");
+}
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain transfers still in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -140,6 +152,28 @@ __device__ __forceinline__ void lds_read4(half8v (&d)[4], unsigned addr) {
                  : "v"(addr)
                  : "memory");
 }
+// one 16-byte fragment read the compiler cannot see through (it would put s_waitcnt vmcnt(0) in front of a plain LDS load that may
+// alias an LDS-DMA transfer still in flight -- also the ones that are meant to stay in flight); pair with lds_wait before use
+__device__ __forceinline__ void lds_read1(half8v& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(d) : "v"(addr) : "memory"); }
+// wait until at most N LDS operations of this wave are outstanding; a and b are the registers the reads above deliver
+template <int N>
+__device__ __forceinline__ void lds_wait(half8v& a, half8v& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(half8v& a, half8v& b, half8v& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(half8v& a, half8v& b, half8v& c, half8v& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(half8v& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read1_off(half8v& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory"); }
 // MFMA results are read by VALU code only after a barrier and a round of transfers; pad the hazard anyway
 __device__ __forceinline__ void mfma_hazard_pad() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // 16-byte store with the streaming policy bits (write-through, no L2 allocation)

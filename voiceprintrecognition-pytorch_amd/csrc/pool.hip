@@ -487,6 +487,250 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
         }
 }
 
+// ---- ring form (round 2): the shipped shapes (whole 64-channel tiles, 16-byte aligned rows, A = 64 or 128, bounded logits).
+// Workgroup = (ONE utterance, four ADJACENT 64-channel tiles), one tile per wave, no barrier:
+//   * the four waves walk the same rows at the same pace, so the workgroup reads 512 contiguous bytes of every x row (the register
+//     form has four utterances per workgroup: isolated 128-byte segments 6 KiB apart);
+//   * BOTH streams of a wave -- its x rows (16 x 128 B per tile) and the h rows (16 x 2A B) -- travel global -> LDS directly into
+//     PRIVATE rings (x: four tiles, three ahead; h: three tiles, two ahead): no load registers, up to 14 KiB in flight per wave, one
+//     counted s_waitcnt per tile.  The transfers are issued from inline assembly (glds16_untracked): with the builtin -- or with h
+//     in ordinary registers -- the compiler adds its own waits, which either drain the rings (vmcnt(0) in front of every LDS load
+//     that may alias a transfer) or force half of the just-requested h rows to land (it counts only the loads it knows about):
+//     measured 185-195 us for every such variant against 211-225 us for the register form;
+//   * the W2 tile of the wave (64 x A fp16) lives in REGISTERS as MFMA A fragments for the whole utterance;
+//   * the element math runs on float2 (v_pk_add/mul/fma_f32): 2 cvt + 2 exp + 5 packed operations per channel pair.
+// LDS tiles: x 16 rows x 128 B, 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7); h 16 rows x 2A B, chunk c of row r
+// at position c ^ (r & (2A/16 - 1)): the 16 lanes of a fragment group read 16 different bank groups.
+constexpr int ASP_XRING = 6, ASP_HRING = 6;
+
+template <int KS>
+__global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
+    constexpr int HROW = KS * 64;          // bytes per h row (A_pad fp16)
+    constexpr int HTILE = 16 * HROW;       // 2 or 4 KiB
+    constexpr int HTR = HTILE / 1024;      // transfers per h tile
+    constexpr int HCH = HROW / 16;         // 16-byte chunks per h row (8 or 16)
+    MV_DYN_SMEM(smem);  // the workgroup's h ring (ASP_HRING tiles), then four private x rings (ASP_XRING tiles each)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = MV_UNIFORM(tid >> 6);
+    const int b = blockIdx.y;
+    const int c0 = (blockIdx.x * 4 + wave) * 64;  // (C is a multiple of 256 here: every wave has a tile and reaches every barrier)
+    const int fr = lane & 15, fg = lane >> 4;
+#if defined(MV_PROBE) && MV_PROBE == 25   // probe: prologue + epilogue only
+    const int ntiles = a.T < 0 ? 1 : 0;
+#else
+    const int ntiles = (a.T + 15) / 16;
+#endif
+    const half_t* hb = a.h + (int64_t)b * a.T * a.A;
+    const half_t* xb = a.x + (int64_t)b * a.T * a.ldx + c0;
+    const int cl = c0 + 16 * fg;
+
+    half8v wf[4][KS];   // W2 tile of this wave (loaded below, behind the first ring requests)
+    float2v g2[4][2];   // global channel means of this lane's 16 channels
+    const unsigned hring = MV_UNIFORM(lds_addr(smem));
+    const unsigned xring = hring + (unsigned)(ASP_HRING * HTILE + wave * (ASP_XRING * 2048));
+    // x transfers: lane l of transfer j (0 / 1) lands at (row 8j + (l >> 3), chunk position l & 7).  Every transfer has its own
+    // running source pointer (one 64-bit add per tile instead of a clamp, a 64-bit multiply and two adds); tiles that reach beyond
+    // T (the last one, and the ones the ring requests past the end) re-read row T - 1 through the slow path: the counts stay exact.
+    const half_t* xsrc[2];
+    int xrow[2], xch[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        xrow[j] = 8 * j + (lane >> 3);
+        xch[j] = ((lane & 7) ^ ((xrow[j] >> 1) & 7)) * 8;
+        xsrc[j] = xb + (int64_t)xrow[j] * a.ldx + xch[j];
+    }
+    const int64_t xstep = 16 * a.ldx;
+    auto issue_x = [&](int tile, int slot) {
+#if defined(MV_PROBE) && MV_PROBE == 27   // probe: every address through the clamp + multiply path
+        const bool whole = false;
+#else
+        const bool whole = tile * 16 + 16 <= a.T;  // uniform
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const half_t* src = xsrc[j];
+            if (!whole) {
+                const int t = tile * 16 + xrow[j];
+                src = xb + (int64_t)(t < a.T ? t : a.T - 1) * a.ldx + xch[j];
+            }
+            glds16_untracked(src, xring + (unsigned)(slot * 2048 + j * 1024));
+            xsrc[j] += xstep;
+        }
+    };
+    // h transfers: the tile is shared by the four waves; wave w moves transfer j = w % HTR (A = 64: two transfers, moved twice --
+    // identical bytes to the same place -- so that every wave issues exactly one per tile and the waits can be counted):
+    // lane l lands at (row (64 / HCH) * j + l / HCH, chunk position l % HCH)
+    const int hj = wave % HTR;
+    const int hrow = (64 / HCH) * hj + lane / HCH;
+    const int hch = ((lane % HCH) ^ (hrow & (HCH - 1))) * 8;
+    const half_t* hsrc = hb + (int64_t)hrow * a.A + hch;
+    const int hstep = 16 * a.A;
+    auto issue_h = [&](int tile, int slot) {
+#if defined(MV_PROBE) && MV_PROBE == 27
+        const bool whole = false;
+#else
+        const bool whole = tile * 16 + 16 <= a.T;
+#endif
+        const half_t* src = hsrc;
+        if (!whole) {
+            const int t = tile * 16 + hrow;
+            src = hb + (int64_t)(t < a.T ? t : a.T - 1) * a.A + hch;
+        }
+        glds16_untracked(src, hring + (unsigned)(slot * HTILE + hj * 1024));
+        hsrc += hstep;
+    };
+    // this lane's reads: x row fr, chunks 2 fg, 2 fg + 1; h row fr, chunks 4 kk + fg
+    const int sw = (fr >> 1) & 7;
+    const unsigned xoff0 = (unsigned)(fr * 128 + (((2 * fg) ^ sw) << 4)), xoff1 = (unsigned)(fr * 128 + (((2 * fg + 1) ^ sw) << 4));
+    unsigned hoff[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) hoff[kk] = (unsigned)(fr * HROW + (((4 * kk + fg) ^ (fr & (HCH - 1))) << 4));
+
+    float2v s0[4][2], s1[4][2], s2[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) s0[mi][q] = s1[mi][q] = s2[mi][q] = float2v{0.0f, 0.0f};
+
+    // Software pipeline: step tt requests h(tt+5) and x(tt+6), fetches tile tt+1 from the rings into registers and runs ITS MFMAs,
+    // then does the element math of tile tt on the logits the previous step left behind -- the matrix pipe and the LDS round trip of a
+    // tile work under the VALU block of the tile before it.  Request order = steps -6 .. -1 of the same rule: x0 | h0 x1 | h1 x2 | ...
+    // | h4 x5, then step tt: h(tt+5) x(tt+6).  Younger than this wave's part of h(tt+1) (requested in step tt-4, with x(tt+2) behind
+    // it) when step tt waits: 2 + 4 steps x 3 = 14 transfers; x(tt+1) is older still.  After the wait a barrier: every wave's part of
+    // h(tt+1) has landed, and every wave is done reading h(tt) -- whose slot h(tt+6) overwrites one step later.
+    auto fetch = [&](int tile, int hslot, int xslot, float4v (&l)[4], half8v& xv0, half8v& xv1) {
+        MV_EMU_WAVE_SYNC();  // (emulator only: lanes read what other lanes of the wave transferred)
+        const unsigned xt = xring + (unsigned)(xslot * 2048);
+        const unsigned ht = hring + (unsigned)(hslot * HTILE);
+        half8v hf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) lds_read1(hf[kk], ht + hoff[kk]);
+        lds_read1(xv0, xt + xoff0);
+        lds_read1(xv1, xt + xoff1);
+        MV_EMU_WAVE_SYNC();  // (... and the slots are overwritten by later transfers)
+        const float voff = tile * 16 + fr < a.T ? 0.0f : -INFINITY;
+        if constexpr (KS == 4) lds_wait<2>(hf[0], hf[1], hf[2], hf[3]); else lds_wait<2>(hf[0], hf[1]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            l[mi] = float4v{voff, voff, voff, voff};
+#if !defined(MV_PROBE) || MV_PROBE != 24   // timing probes (tools/probe only): 21 = no x transfers, 22 = no h transfers, 23 = no element math, 24 = no MFMA
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
+#else
+            for (int kk = 0; kk < KS; ++kk) l[mi][kk & 3] += (float)hf[kk][0] * (float)wf[mi][kk][0];
+#endif
+        }
+        lds_wait<0>(xv0, xv1);
+    };
+    auto pool = [&](const float4v (&l)[4], const half8v& xv0, const half8v& xv1) {
+#if defined(MV_PROBE) && MV_PROBE == 23
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            s0[mi][0] += float2v{l[mi][0], l[mi][1]};
+            s0[mi][1] += float2v{l[mi][2] + (float)xv0[mi], l[mi][3] + (float)xv1[mi]};
+        }
+#else
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ci = 4 * mi + 2 * q;
+                const half8v& xv = ci < 8 ? xv0 : xv1;
+                const float2v xf = float2v{(float)xv[ci & 7], (float)xv[(ci & 7) + 1]};
+                const float2v d = xf - g2[mi][q];
+                const float2v e = float2v{asp_exp2(l[mi][2 * q]), asp_exp2(l[mi][2 * q + 1])};
+                const float2v ed = e * d;
+                s0[mi][q] += e;
+                s1[mi][q] += ed;
+                s2[mi][q] = __builtin_elementwise_fma(ed, d, s2[mi][q]);
+            }
+        }
+#endif
+    };
+    issue_x(0, 0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        issue_h(i, i);
+        issue_x(i + 1, i + 1);
+    }
+    // W2 tile as A fragments: tile mi, row i = fr  <->  channel c0 + 16 * (i >> 2) + 4 * mi + (i & 3), k = kk * 32 + 8 * fg
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            wf[mi][kk] = *MV_GLOBAL_PTR(half8v, a.w2 + (int64_t)(c0 + 16 * (fr >> 2) + 4 * mi + (fr & 3)) * a.A_pad + kk * 32 + 8 * fg);
+    {
+        float4v g4[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            g4[mi] = a.gmean != nullptr ? *MV_GLOBAL_PTR(float4v, a.gmean + (int64_t)b * a.gmean_ld + cl + 4 * mi) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            g2[mi][0] = float2v{g4[mi][0], g4[mi][1]};
+            g2[mi][1] = float2v{g4[mi][2], g4[mi][3]};
+        }
+    }
+    // (The ring requests above are already in flight: the latency of these loads and of the first tiles overlap.)
+    // The loads above are the only ones the compiler tracks.  Touch every register they deliver: the compiler then waits for them HERE
+    // (s_waitcnt vmcnt(0) in front of the first touch) instead of re-checking them inside the loop on every iteration, where its
+    // vmcnt(0) would drain the rings.
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) MV_OPAQUE(wf[mi][kk]);
+        MV_OPAQUE(g2[mi][0]);
+        MV_OPAQUE(g2[mi][1]);
+    }
+
+    float4v la[4], lb[4];
+    half8v xa0, xa1, xb0, xb1;
+    wait_vm<14>();
+    lds_barrier();
+    fetch(0, 0, 0, la, xa0, xa1);
+    int hs = 5, xs = 0;  // ring slots of h(tt+5) and x(tt+6)
+    auto step = [&](int tt, float4v (&lcur)[4], half8v& xc0, half8v& xc1, float4v (&lnext)[4], half8v& xn0, half8v& xn1) {
+#if !defined(MV_PROBE) || (MV_PROBE != 22 && MV_PROBE != 28)   // 28 = neither stream
+        issue_h(tt + 5, hs);
+#endif
+#if !defined(MV_PROBE) || (MV_PROBE != 21 && MV_PROBE != 28)
+        issue_x(tt + 6, xs);
+#endif
+        wait_vm<14>();
+        lds_barrier();
+        hs = hs == ASP_HRING - 1 ? 0 : hs + 1;   // now the slot of h(tt)  ... and of h(tt+6) next step
+        xs = xs == ASP_XRING - 1 ? 0 : xs + 1;   // the slot of x(tt+1)   ... and of x(tt+7) next step
+        int h1 = hs + 1;                         // slot of h(tt+1)
+        h1 = h1 == ASP_HRING ? 0 : h1;
+        fetch(tt + 1, h1, xs, lnext, xn0, xn1);
+        pool(lcur, xc0, xc1);
+    };
+    int tt = 0;
+#pragma unroll 1
+    for (; tt + 1 < ntiles; tt += 2) {  // the two register sets trade roles: no copies
+        step(tt, la, xa0, xa1, lb, xb0, xb1);
+        step(tt + 1, lb, xb0, xb1, la, xa0, xa1);
+    }
+    if (tt < ntiles) pool(la, xa0, xa1);   // odd tile count: the last tile's logits are in the first set
+    wait_vm<0>();  // the rings belong to the workgroup's LDS allocation: nothing may still be landing when the wave ends
+    // 48 sums over the 16 time lanes of a row, then mean / std by lane fr == 0 (v_rcp / v_sqrt: 1 ulp, far inside the 2e-5 bar)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z0 = row16_sum(s0[mi][r >> 1][r & 1]);
+            const float z1 = row16_sum(s1[mi][r >> 1][r & 1]);
+            const float z2 = row16_sum(s2[mi][r >> 1][r & 1]);
+            if (fr == 0) {
+                const int c = cl + 4 * mi + r;
+                const float inv = rcp_fast(z0);
+                const float m1 = z1 * inv;
+                const float var = z2 * inv - m1 * m1;
+                a.out[(int64_t)b * 2 * a.C + c] = g2[mi][r >> 1][r & 1] + m1;
+                a.out[(int64_t)b * 2 * a.C + a.C + c] = sqrt_fast(fmaxf(var, a.eps));
+            }
+        }
+}
+
 template <int KS>
 static void asp_pool_dispatch(const AspArgs& a, unsigned gx, unsigned gy, bool nomax, hipStream_t stream) {
     if (nomax) {
@@ -520,6 +764,20 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, i
     a.eps = 1e-12f;
     const unsigned gx = (unsigned)ceil_div(C, 64);
     const bool nomax = logit_bound_log2 >= 0.0f && logit_bound_log2 <= 60.0f;
+    // ring form: whole tiles, aligned rows, no partial h fragments; MV_ASP_IMPL=regs keeps the register form (A/B runs)
+    const char* impl = getenv("MV_ASP_IMPL");
+    const bool ring_ok = nomax && C % 256 == 0 && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && A == a.A_pad &&
+                         (gmean == nullptr || (gmean_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gmean) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(h) & 15) == 0 && !(impl != nullptr && strcmp(impl, "regs") == 0);
+    if (ring_ok && (a.A_pad == 64 || a.A_pad == 128)) {
+        const unsigned gxw = (unsigned)ceil_div(C, 256);
+        if (a.A_pad == 64) {
+            MV_LAUNCH((asp_pool_ring_kernel<2>), (gxw, (unsigned)B, 1), (256, 1, 1), 4 * ASP_XRING * 2048 + ASP_HRING * 2048, stream, a);
+        } else {
+            MV_LAUNCH((asp_pool_ring_kernel<4>), (gxw, (unsigned)B, 1), (256, 1, 1), 4 * ASP_XRING * 2048 + ASP_HRING * 4096, stream, a);
+        }
+        return check_launch("asp_pool_ring_kernel");
+    }
     switch (a.A_pad / 32) {
         case 2: asp_pool_dispatch<2>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
         case 4: asp_pool_dispatch<4>(a, gx, (unsigned)ceil_div(B, 4), nomax, stream); break;
