@@ -915,7 +915,9 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 // 4-byte load each to pull them into L2 early (slower: the touches sit in the same in-order vmcnt queue; repeated in round 2
 // with 4-byte LDS-DMA touches into a scratch row, all transfers untracked and COUNTED stage waits that leave the touches in
 // flight: still 7-12 % slower at every distance 1..4, profiles/r04h_* -- the global -> LDS path is bound by request
-// throughput, not by the latency of the single stage in flight, and the touches double its requests); a 4-wave layout
+// throughput, not by the latency of the single stage in flight, and the touches double its requests); a late start, by a hashed
+// fraction of a tile time, for the workgroups that walk one tile fewer than the longest walk, so that the 32 MiB output bursts of
+// the lockstep tile boundaries spread out (neutral to 3 % slower, profiles/r04j_*); a 4-wave layout
 // with 128 x 128 wave tiles and the accumulators in AccVGPRs (a third less LDS traffic, but one wave per SIMD: 7 % slower on
 // K = 3072, 24 % on K = 1024); a counted vmcnt wait that lets the epilogue's stores drain across the next stage (neutral);
 // starting the eight XCDs ~1 us apart to break up the 32 MiB store burst of the lockstep epilogues (slower); requesting
