@@ -19,7 +19,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define MV_DYN_SMEM(name) char* name = MV_EMU_DYN_SMEM()
 #define MV_SET_MAX_SMEM(kernel, bytes) hipSuccess
 #define MV_WAVE_FENCE() emu::wave_sync()
-#define MV_EMU_WAVE_SYNC() emu::wave_sync()
+#define MV_LOCKSTEP_POINT() emu::wave_sync()
 #define MV_AS_LDS(T, p) ((T*)(p))
 #define MV_AS_GLOBAL(T, p) ((T*)(p))
 #define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)

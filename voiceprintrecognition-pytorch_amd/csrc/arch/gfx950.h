@@ -34,8 +34,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // Pointers with their address space stated: two branches that store the same values once to LDS and once to global memory
 // are otherwise tail-merged into ONE flat store behind a selected base pointer; pointer selects between a tensor and the zero
 // page lose the address space too (flat loads).
-// wave-level rendezvous that only the SIMT emulator needs (its lanes are fibres; on the device the lanes of a wave run in lockstep)
-#define MV_EMU_WAVE_SYNC() do { } while (0)
+// point at which lanes of one wave hand data to each other through LDS without a barrier: the lanes of a wave run in lockstep, so
+// there is nothing to do (the test-suite's SIMT emulator runs lanes as fibres and makes them meet here)
+#define MV_LOCKSTEP_POINT() do { } while (0)
 #define MV_AS_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define MV_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))

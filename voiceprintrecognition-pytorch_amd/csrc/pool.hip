@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     // it) when step tt waits: 2 + 4 steps x 3 = 14 transfers; x(tt+1) is older still.  After the wait a barrier: every wave's part of
     // h(tt+1) has landed, and every wave is done reading h(tt) -- whose slot h(tt+6) overwrites one step later.
     auto fetch = [&](int tile, int hslot, int xslot, float4v (&l)[4], half8v& xv0, half8v& xv1) {
-        MV_EMU_WAVE_SYNC();  // (emulator only: lanes read what other lanes of the wave transferred)
+        MV_LOCKSTEP_POINT();  // (lanes read what other lanes of the wave transferred)
         const unsigned xt = xring + (unsigned)(xslot * 2048);
         const unsigned ht = hring + (unsigned)(hslot * HTILE);
         half8v hf[KS];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
         for (int kk = 0; kk < KS; ++kk) lds_read1(hf[kk], ht + hoff[kk]);
         lds_read1(xv0, xt + xoff0);
         lds_read1(xv1, xt + xoff1);
-        MV_EMU_WAVE_SYNC();  // (... and the slots are overwritten by later transfers)
+        MV_LOCKSTEP_POINT();  // (... and the slots are overwritten by later transfers)
         const float voff = tile * 16 + fr < a.T ? 0.0f : -INFINITY;
         if constexpr (KS == 4) lds_wait<2>(hf[0], hf[1], hf[2], hf[3]); else lds_wait<2>(hf[0], hf[1]);
 #pragma unroll
