@@ -14,10 +14,19 @@
 //
 // GEMM conventions as in res2.hip: weights are the MFMA A operand (rows = output channels), activations the B operand
 // (columns = time steps), so a lane ends up with 4 consecutive output channels of one time step.  8 waves: wave (cw = w & 3,
-// th = w >> 2) owns output-channel tiles {2 cw, 2 cw + 1} x time tiles {5 th .. 5 th + 4} of the 1x1 GEMM; W1 streams through
-// a 3-slot LDS ring by LDS-DMA, x is loaded to registers one 64-channel stage ahead, passed through BN1 + ReLU in fp32 and
-// written to a double-buffered LDS tile.  (Default cache policy on these loads: the block's buffer -- 78 MB for 256 utterances --
-// is re-read by every later layer and lives in the 256 MB Infinity Cache; non-temporal loads measured 1.5-2.6 TB/s, r03i.)
+// th = w >> 2) owns output-channel tiles {2 cw, 2 cw + 1} x time tiles {5 th .. 5 th + 4} of the 1x1 GEMM.  Both operand streams
+// are LDS-DMA rings (global_load_lds, issued from inline assembly -- glds16_untracked): W1 in 3 slots, the raw x stage
+// ([160 rows][64 channels] fp16) in 4 slots; a landed x stage is passed through BN1 + ReLU IN PLACE (LDS -> fp32 -> LDS) one
+// stage before the MFMAs read it, so two x stages and two weight stages are in flight under every stage's MFMAs with one counted
+// s_waitcnt and one barrier per stage.  (Round 2, first form: x went through registers, "four stages in flight" -- but the compiler,
+// seeing register loads next to builtin LDS-DMA on the same counter, put s_waitcnt vmcnt(0) in front of their first use and of the
+// fragment reads, draining everything in every stage.  Measured after the change, r04l: the same 25 us per layer on average, 16 us
+// for the 2-stage layers, 36 us for the 16-stage ones = ~14 us of fixed cost -- launch, parameter and first-stage latency, the
+// serial context phase, store drain -- plus ~1.35 us per stage, which is what the in-place transform (~120 VALU per wave) and 20
+// MFMAs cost two waves per SIMD.  The stream is no longer the limit; chaining the layers of a block in one launch is what
+// would remove the fixed part.)  Default cache policy on these loads: the block's buffer --
+// 78 MB for 256 utterances -- is re-read by every later layer and lives in the 256 MB Infinity Cache; non-temporal loads measured
+// 1.5-2.6 TB/s, r03i.
 #include <type_traits>
 
 #include "kernels.h"
@@ -30,13 +39,18 @@ constexpr int CD_ROWS = CD_TT * 16;
 constexpr int CD_BN = 128;                          // bottleneck channels (bn_size * growth_rate)
 constexpr int CD_G = 32;                            // growth rate
 constexpr int CD_PAD = 2;                           // largest dilation of the k=3 conv
-constexpr int CD_XS_BYTES = CD_ROWS * 128;          // one x stage: [160 rows][64 fp16]
-constexpr int CD_WS_BYTES = CD_BN * 128;            // one W1 stage: [128 rows][64 fp16]
-constexpr int CD_RING = 3;
-constexpr int CD_H_BYTES = (CD_ROWS + 2 * CD_PAD) * CD_BN * 2;  // h with zero halo rows on both sides
-constexpr int CD_XPF = 4;                           // x stages in flight in registers (global latency >> one stage of 20 MFMAs per wave)
-static_assert(CD_XPF == 4, "the stage loop is unrolled by four and its counted waits assume this depth");
+constexpr int CD_XS_BYTES = CD_ROWS * 128;          // one x stage: [160 rows][64 fp16] = 20 transfers of 1 KiB
+constexpr int CD_WS_BYTES = CD_BN * 128;            // one W1 stage: [128 rows][64 fp16] = 16 transfers
+constexpr int CD_RING = 3;                          // W1 stages: s (read), s + 1, s + 2
+constexpr int CD_XRING = 4;                         // x stages: s (read), s + 1 (BN1 + ReLU in place), s + 2, s + 3 (in flight)
+constexpr int CD_H_BYTES = (CD_ROWS + 2 * CD_PAD) * CD_BN * 2;  // h with zero halo rows on both sides; reuses the x ring after phase A
+constexpr int CD_PART_BYTES = 32 * 2 * CD_BN * 4;   // phase B partial sums, behind h in the x ring
+static_assert(CD_H_BYTES + CD_PART_BYTES <= CD_XRING * CD_XS_BYTES, "h and the phase B scratch live in the idle x ring");
 constexpr int CD_MAX_SEG = 2;                       // segments of 100 frames within 160 frames
+constexpr int CD_MAX_CIN = 2048;                    // BN1 parameters of the layer live in LDS
+
+// 256 zero bytes: source of the padding transfers
+__device__ __attribute__((aligned(256))) const unsigned char g_cd_zero_page[256] = {0};
 
 struct CamDenseArgs {
     half_t* x;            // [B, T2, ldx]: channels [0, cin) are read, [cin, cin + 32) are written
@@ -51,10 +65,10 @@ struct CamDenseArgs {
 
 __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArgs a) {
     MV_DYN_SMEM(smem);
-    char* xs = smem;                                           // 2 x CD_XS_BYTES (later: reduction scratch)
-    char* ws = xs + 2 * CD_XS_BYTES;                           // CD_RING x CD_WS_BYTES
-    char* hbuf = ws + CD_RING * CD_WS_BYTES;                   // CD_H_BYTES, row r = t + CD_PAD
-    float* fsm = reinterpret_cast<float*>(hbuf + CD_H_BYTES);  // ctx [2][128] | g1 [2][64] | gate [2][32] | BN1 scale, shift [cin_pad] each
+    char* xs = smem;                                           // CD_XRING x CD_XS_BYTES; after phase A: h, then the phase B scratch
+    char* ws = xs + CD_XRING * CD_XS_BYTES;                    // CD_RING x CD_WS_BYTES
+    char* hbuf = xs;                                           // CD_H_BYTES, row r = t + CD_PAD
+    float* fsm = reinterpret_cast<float*>(ws + CD_RING * CD_WS_BYTES);  // ctx [2][128] | g1 [2][64] | gate [2][32] | BN1 scale, shift [cin_pad] each
     float* ctx = fsm;
     float* g1 = ctx + CD_MAX_SEG * CD_BN;
     float* gate = g1 + CD_MAX_SEG * 64;
@@ -68,10 +82,7 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     half_t* xb = a.x + (int64_t)b * T2 * a.ldx;
     const int nst = a.cin_pad / 64;
 
-    // zero the bottleneck buffer: halo rows and the rows behind T2 must read as zero padding
-    for (int i = tid; i < CD_H_BYTES / 16; i += CD_THREADS) reinterpret_cast<float4v*>(hbuf)[i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-    // BN1 parameters into LDS: read per stage next to x values that were requested four stages earlier -- a global load there
-    // would wait behind every younger x prefetch (vector-memory results return in order)
+    // BN1 parameters into LDS: the in-place transform of every stage reads them next to transfers in flight
     for (int i = tid; i < a.cin_pad; i += CD_THREADS) {
         lbn_s[i] = i < a.cin ? a.bn1_s[i] : 0.0f;
         lbn_t[i] = i < a.cin ? a.bn1_t[i] : 0.0f;
@@ -92,8 +103,8 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     float4v e_wa[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) e_wa[u] = *reinterpret_cast<const float4v*>(a.wa + (tid >> 3) * CD_BN + (tid & 7) * 16 + 4 * u);
-    const float4v e_wb = *reinterpret_cast<const float4v*>(a.wb + (tid >> 4) * 64 + (tid & 15) * 4);
-    const float e_ba = a.ba[tid >> 3], e_bb = a.bb[tid >> 4];
+    float4v e_wb = *reinterpret_cast<const float4v*>(a.wb + (tid >> 4) * 64 + (tid & 15) * 4);
+    float e_ba = a.ba[tid >> 3], e_bb = a.bb[tid >> 4];
     half8v e_wl[3][4];  // k=3 conv weights of this wave's channel tile: A fragments of the 12 K steps
     {
         const half_t* wrow = a.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CD_BN + 8 * fg;
@@ -105,90 +116,103 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 
     // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
     const int lrow = lane >> 3, kc = (lane & 7) ^ lrow;
-    auto issue_w = [&](int s) {  // W1 stage s: 128 rows x 128 bytes = 16 transfers of 1 KiB, two per wave
-        char* dst = ws + (s % CD_RING) * CD_WS_BYTES;
+    const unsigned xs_addr = lds_addr(xs), ws_addr = lds_addr(ws);
+    const unsigned dump_addr = lds_addr(reinterpret_cast<char*>(gate + CD_MAX_SEG * CD_G + 2 * CD_MAX_CIN));  // 1 KiB behind the BN1 tables: where the padding transfers land
+    const half_t* zero = reinterpret_cast<const half_t*>(g_cd_zero_page);
+    const int wave_u = MV_UNIFORM(wave);
+    // Every wave issues exactly 3 x transfers and 2 W1 transfers per stage -- stages beyond the last one and the x transfers 20..23
+    // read a constant page into the dump KiB -- so the waits below can be counted.
+    auto issue_x = [&](int s) {  // x stage s: 160 rows x 128 bytes; transfer tr covers rows 8 tr .. 8 tr + 7 (rows >= T2 re-read row T2 - 1)
+        const bool real = s < nst;
+        const unsigned dst = xs_addr + (unsigned)((s & (CD_XRING - 1)) * CD_XS_BYTES);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tr = wave_u + 8 * u;
+            int row = tr * 8 + lrow;
+            row = row < T2 ? row : T2 - 1;
+            const bool live = real && tr < CD_ROWS / 8;  // uniform
+            glds16_untracked(live ? xb + (int64_t)row * a.ldx + s * 64 + kc * 8 : zero, live ? dst + (unsigned)(tr * 1024) : dump_addr);
+        }
+    };
+    auto issue_w = [&](int s) {  // W1 stage s: 128 rows x 128 bytes = 16 transfers, two per wave
+        const bool real = s < nst;
+        const unsigned dst = ws_addr + (unsigned)((s % CD_RING) * CD_WS_BYTES);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int tr = wave * 2 + u;
+            const int tr = wave_u * 2 + u;
             const int co = tr * 8 + lrow;
-            glds16(a.w1 + (int64_t)co * a.cin_pad + s * 64 + kc * 8, dst + tr * 1024);
+            glds16_untracked(real ? a.w1 + (int64_t)co * a.cin_pad + s * 64 + kc * 8 : zero, real ? dst + (unsigned)(tr * 1024) : dump_addr);
         }
     };
-    // x staging: thread = (chunk of 8 channels, row), three rows per thread and stage
+    // BN1 + ReLU in fp32, in place: thread = (16-byte chunk, row), three rows per thread and stage; rows >= T2 and channels >= cin
+    // become zero (whatever the transfer brought: clamped rows, the not yet written output channels of this very layer)
     const int xchunk = tid & 7, xrow0 = tid >> 3;
-    half8v xr[CD_XPF][3];
-    // (every wave issues exactly three loads per stage -- rows / channels beyond the data are clamped here and zeroed in
-    // store_x -- so the counted waits of the stage loop can rely on the number of operations in flight)
-    auto load_x = [&](int s, half8v (&r)[3]) {
-        int c = s * 64 + xchunk * 8;
-        c = c < a.cin ? c : 0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            int row = xrow0 + 64 * p;
-            row = row < T2 ? row : T2 - 1;
-            r[p] = *reinterpret_cast<const half8v*>(xb + (int64_t)row * a.ldx + c);
-        }
-    };
-    auto store_x = [&](int s, const half8v (&r)[3]) {  // BN1 + ReLU in fp32, then into the stage tile (rows >= T2 and channels >= cin stay zero)
+    auto transform = [&](int s) {
         const int c = s * 64 + xchunk * 8;
         const bool live = c < a.cin;
         const float4v s0 = *reinterpret_cast<const float4v*>(lbn_s + c), s1 = *reinterpret_cast<const float4v*>(lbn_s + c + 4);
         const float4v t0 = *reinterpret_cast<const float4v*>(lbn_t + c), t1 = *reinterpret_cast<const float4v*>(lbn_t + c + 4);
-        char* dst = xs + (s & 1) * CD_XS_BYTES;
+        char* tile = xs + (s & (CD_XRING - 1)) * CD_XS_BYTES;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int row = xrow0 + 64 * p;
             if (row < CD_ROWS) {
+                half8v* cell = reinterpret_cast<half8v*>(tile + row * 128 + ((xchunk ^ (row & 7)) << 4));
+                const half8v r = *cell;
                 half8v o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (half_t)fmaxf((float)r[p][e] * s0[e] + t0[e], 0.0f);
-                    o[4 + e] = (half_t)fmaxf((float)r[p][4 + e] * s1[e] + t1[e], 0.0f);
+                    o[e] = (half_t)fmaxf((float)r[e] * s0[e] + t0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)r[4 + e] * s1[e] + t1[e], 0.0f);
                 }
                 if (!(row < T2 && live)) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)0.0f;
                 }
-                *reinterpret_cast<half8v*>(dst + row * 128 + ((xchunk ^ (row & 7)) << 4)) = o;
+                *cell = o;
             }
         }
     };
 
+    // request order = stages -3, -2, -1 of the rule "stage s requests x(s+3), then W1(s+2)": x0 | x1 W0 | x2 W1
+    issue_x(0);
+    issue_x(1);
     issue_w(0);
-    if (nst > 1) issue_w(1);
-    // x: CD_XPF stages in flight in registers (register set = stage % CD_XPF; the stage loop is unrolled by CD_XPF so the sets
-    // are named at compile time)
+    issue_x(2);
+    issue_w(1);
+    // The parameter loads above are the only vector loads the compiler tracks: touch what they deliver, so that its wait for them
+    // sits here and not inside the stage loop (where a conservative vmcnt(0) would drain the rings)
 #pragma unroll
-    for (int u = 0; u < CD_XPF; ++u)
-        if (u < nst) load_x(u, xr[u]);
-    store_x(0, xr[0]);
+    for (int mi = 0; mi < 2; ++mi) {
+        MV_OPAQUE(e_bn2s[mi]);
+        MV_OPAQUE(e_bn2t[mi]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) MV_OPAQUE(e_wa[u]);
+    MV_OPAQUE(e_wb);
+    MV_OPAQUE(e_ba);
+    MV_OPAQUE(e_bb);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) MV_OPAQUE(e_wl[tap][kk]);
+    wait_vm<10>();  // x0 has landed (younger: x1 W0 x2 W1 = 3 + 2 + 3 + 2)
+    lds_barrier();
+    transform(0);
     float4v acc[2][5];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-    auto stage = [&](int s, auto U) __attribute__((always_inline)) {
-        constexpr int u = decltype(U)::value;  // s % CD_XPF
-        // W1 stage s has landed and x stage s has been written by every thread:
-        // issued after W1 stage s (which went out in stage s - 2): the x loads of stages s - 2 + CD_XPF and s - 1 + CD_XPF
-        // (3 each) and W1 stage s + 1 (2 transfers), as far as those stages exist.  Stages 0 and 1: the prologue's wait for
-        // x stage 0 already covered both W1 stages.
-        if (s >= 2) {
-            if (s + CD_XPF - 1 < nst) {
-                wait_vm<8>();
-            } else if (s + CD_XPF - 2 < nst) {
-                wait_vm<5>();
-            } else if (s + 1 < nst) {
-                wait_vm<2>();
-            } else {
-                wait_vm<0>();
-            }
-        }
-        lds_barrier();
-        if (s + 2 < nst) issue_w(s + 2);
-        if (s + CD_XPF < nst) load_x(s + CD_XPF, xr[u]);  // set u was consumed when stage s was written (end of stage s - 1)
+#pragma unroll 1
+    for (int s = 0; s < nst; ++s) {
+        // W1(s) and x(s+1) have landed: requested in stage s - 2, younger are x(s+2) and W1(s+1) = 3 + 2 transfers
+        wait_vm<5>();
+        lds_barrier();  // ... in every wave; x(s) is transformed; every wave is done with x(s-1) and W1(s-1), whose slots are requested now
+        issue_x(s + 3);
+        issue_w(s + 2);
         const char* wt = ws + (s % CD_RING) * CD_WS_BYTES;
-        const char* xt = xs + (s & 1) * CD_XS_BYTES;
+        const char* xt = xs + (s & (CD_XRING - 1)) * CD_XS_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8v af[2], bf[5];
@@ -207,13 +231,16 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (s + 1 < nst) store_x(s + 1, xr[(u + 1) % CD_XPF]);  // the other x tile: its readers passed this stage's barrier
-    };
-    for (int s0 = 0; s0 < nst; s0 += CD_XPF) {
-        stage(s0, std::integral_constant<int, 0>{});
-        if (s0 + 1 < nst) stage(s0 + 1, std::integral_constant<int, 1>{});
-        if (s0 + 2 < nst) stage(s0 + 2, std::integral_constant<int, 2>{});
-        if (s0 + 3 < nst) stage(s0 + 3, std::integral_constant<int, 3>{});
+        if (s + 1 < nst) transform(s + 1);  // uniform
+    }
+    wait_vm<0>();   // only padding transfers are left: nothing may still be landing when the ring is reused
+    lds_barrier();  // every wave is done with the x ring: it becomes h (rows [CD_PAD, CD_PAD + T2)) and the phase B scratch
+    // halo rows and the rows behind T2 of h read as zero padding
+    {
+        constexpr int ROWB = CD_BN * 2;
+        const int tail0 = (T2 + CD_PAD) * ROWB, total = CD_H_BYTES;
+        for (int i = tid * 16; i < CD_PAD * ROWB; i += CD_THREADS * 16) *reinterpret_cast<float4v*>(hbuf + i) = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = tail0 + tid * 16; i < total; i += CD_THREADS * 16) *reinterpret_cast<float4v*>(hbuf + i) = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     }
     // epilogue A: BN2 + ReLU -> hbuf (fp16, swizzled 16-byte chunks: chunk ^= row & 15), frames >= T2 stay zero
     auto h_off = [&](int row, int chunk) { return row * (CD_BN * 2) + ((chunk ^ (row & 15)) << 4); };
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     const int nseg = (T2 + a.seg_len - 1) / a.seg_len;  // <= CD_MAX_SEG (checked by the launcher)
     {
         // partial sums: thread = (8-channel chunk, 32 row phases); scratch [32][2][128] floats in the (now idle) x tiles
-        float* part = reinterpret_cast<float*>(xs);
+        float* part = reinterpret_cast<float*>(xs + CD_H_BYTES);
         const int cg = tid & 15, rp = tid >> 4;
         float sum[CD_MAX_SEG][8];
 #pragma unroll
@@ -345,8 +372,7 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
     }
 }
 
-constexpr int CD_MAX_CIN = 2048;  // BN1 parameters of the layer live in LDS
-constexpr size_t CD_LDS_BYTES = 2 * CD_XS_BYTES + CD_RING * CD_WS_BYTES + CD_H_BYTES + (CD_MAX_SEG * (CD_BN + 64 + CD_G) + 2 * CD_MAX_CIN) * sizeof(float);
+constexpr size_t CD_LDS_BYTES = CD_XRING * CD_XS_BYTES + CD_RING * CD_WS_BYTES + (CD_MAX_SEG * (CD_BN + 64 + CD_G) + 2 * CD_MAX_CIN) * sizeof(float) + 1024;
 
 bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len) {
     return bottleneck == CD_BN && growth == CD_G && T2 >= 1 && T2 <= CD_ROWS && cin % 32 == 0 && cin >= 32 && cin <= CD_MAX_CIN - 64 && dil >= 1 &&
