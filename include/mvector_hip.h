@@ -286,12 +286,22 @@ typedef struct MvConv1dDesc {
      * mv_conv1d_stats_finish. */
     float* stat_sum;
     float* stat_sq;
+    /* optional fused time statistics of the INPUT x (the ASP global mean / std, pooling.py:104-109, taken from the x tiles the hidden
+     * 1x1 conv of the attention streams through LDS anyway): fp32 partial buffers of mv_conv1d_in_stats_elems(B, T_in, cin) floats
+     * each (sums and sums of squares per (utterance, 160-frame tile, channel)).  Only on the direct fp16 path with the 128 x 160 tile:
+     * k = 1, stride 1, no padding, T_out == T_in, cout <= 128, no x2 / in_scale.  Finish with mv_conv1d_in_stats_finish. */
+    float* in_stat_sum;
+    float* in_stat_sq;
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
 /* floats in one partial-statistics buffer, and the reduction of the partial rows to per-utterance mean[b, c] (and
  * std[b, c] = sqrt(max(E[(y - mean)^2], clamp_eps)) when stat_sq / std are given).  `shift` = the BatchNorm shift passed to the
  * conv (the moments are taken about it), NULL if the conv had none. */
 int64_t mv_conv1d_stats_elems(int32_t B, int32_t T_out, int32_t cout);
+/* per-utterance mean[b, c] and std[b, c] = sqrt(max(E[x^2] - mean^2, clamp_eps)) of the conv INPUT from the in_stat_* partials */
+int64_t mv_conv1d_in_stats_elems(int32_t B, int32_t T_in, int32_t cin);
+int mv_conv1d_in_stats_finish(const float* in_stat_sum, const float* in_stat_sq, int32_t B, int32_t T_in, int32_t cin, float* mean,
+                              float* std, int64_t ld_out, float clamp_eps, mv_stream_t stream);
 int mv_conv1d_stats_finish(const float* stat_sum, const float* stat_sq, const float* shift, int32_t B, int32_t T_out, int32_t cout,
                            float* mean, float* std, int64_t ld_out, float clamp_eps, mv_stream_t stream);
 

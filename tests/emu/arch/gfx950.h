@@ -55,6 +55,9 @@ inline float dpp_mov(float old, float src) {
         from = (lane & ~15) | (15 - (lane & 15));
     } else if (CTRL == 0x141) {
         from = (lane & ~7) | (7 - (lane & 7));
+    } else if (CTRL == 0x142) {  // row_bcast:15 -- rows 1..3 read lane 15 of the row in front of them
+        has = lane >= 16;
+        from = has ? ((lane >> 4) - 1) * 16 + 15 : lane;
     }
     const float v = emu::shfl_from(src, from);
     return has ? v : old;

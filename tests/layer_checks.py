@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, seed=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -78,9 +78,25 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
         psum = torch.full((nstat,), float('nan'), device=device)
         psq = torch.full((nstat,), float('nan'), device=device) if stats == 2 else None
         d.stat_sum, d.stat_sq = psum.data_ptr(), (psq.data_ptr() if psq is not None else None)
+    if in_stats:  # fused per-utterance time statistics of the INPUT x (ASP global mean / std)
+        nin = cdll.mv_conv1d_in_stats_elems(B, T, cin)
+        isum = torch.full((nin,), float('nan'), device=device)
+        isq = torch.full((nin,), float('nan'), device=device)
+        d.in_stat_sum, d.in_stat_sq = isum.data_ptr(), isq.data_ptr()
     _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
+    if in_stats:
+        imean = torch.empty(B, 2 * cin, device=device)
+        _hip.check(cdll.mv_conv1d_in_stats_finish(isum.data_ptr(), isq.data_ptr(), B, T, cin, imean.data_ptr(),
+                                                  imean.data_ptr() + 4 * cin, 2 * cin, 1e-12, _stream(xd)), cdll)
+        xs = xd.cpu().double()[..., :cin]
+        rm = xs.mean(1)
+        rs = torch.sqrt(((xs - rm.unsqueeze(1)) ** 2).mean(1).clamp(1e-12))
+        got_ms = imean.cpu().double()
+        e1 = (got_ms[:, :cin] - rm).abs().max().item()
+        e2 = (got_ms[:, cin:] - rs).abs().max().item()
+        assert e1 < 2e-6 * max(1.0, rm.abs().max().item()) and e2 < 2e-5 * max(1.0, rs.abs().max().item()), f'input statistics {e1} {e2}'
 
     # ---- torch fp32 reference on the values the kernel actually consumes ----
     xin = xd.cpu().float()[..., :cin]
@@ -308,6 +324,11 @@ CONV_CASES = [
     dict(k=1, dil=1, cin=192, cout=512, T=298, B=3, tile=256, stats=2),  # fused mean + std (ASP global statistics), ragged last tile
     dict(k=1, dil=1, cin=128, cout=256, T=64, B=4, tile=256, stats=2, affine=False, extra_ld=0),  # boundaries on block edges, no BN
     dict(k=3, dil=2, cin=72, cout=512, T=130, B=5, tile=256, pre_act=0, affine=False),  # persistent, taps, no BatchNorm affine
+    # fused INPUT statistics (the ASP hidden layer): per-utterance tiles of 160 frames, fp32 pre-activation out
+    dict(k=1, dil=1, cin=192, cout=128, T=45, B=3, in_stats=True, y_f32=True, pre_act=0, affine=False),   # one partial tile per utterance
+    dict(k=1, dil=1, cin=320, cout=128, T=298, B=3, in_stats=True, y_f32=True, pre_act=0, affine=False),  # two tiles, ragged second one
+    dict(k=1, dil=1, cin=72, cout=64, T=160, B=2, in_stats=True, extra_ld=0),                            # exact tile, partial K stage, fp16 out with epilogue
+    dict(k=1, dil=1, cin=128, cout=128, T=1, B=5, in_stats=True, y_f32=True, pre_act=0, affine=False),    # single frame: std = sqrt(eps)
 ]
 
 

@@ -22,9 +22,11 @@
 
 namespace mv {
 
-constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_ROR1 = 0x121, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_ROR1 = 0x121, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141,
+              DPP_ROW_BCAST15 = 0x142;  // lanes of rows 1..3 read lane 15 of the row in front of them (row 0 keeps `old`)
 
 // sum over the 16 lanes of a DPP row, result in every lane
+// (the form with old = 0 folds into one v_add_f32_dpp per step; the builtin without an `old` operand stays a v_mov_b32_dpp + v_add)
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);
     v += dpp_mov<DPP_QUAD_XOR2>(0.0f, v);

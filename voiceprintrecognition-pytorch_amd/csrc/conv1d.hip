@@ -56,6 +56,11 @@ struct ConvArgs {
     int store_nt;  // persistent kernel: output stores carry the streaming policy bits (see conv_store_policy)
     float* stat_sum;  // optional partial time sums of the output (persistent kernel): [ceil(n_rows / 64)][2][cout]
     float* stat_sq;   // optional partial sums of squares (about the BatchNorm shift), same layout
+    // one-shot 128 x 160 kernel: tiles never straddle utterances (tile = (utterance, 160-frame block)), and the workgroups of channel
+    // tile 0 leave the time sums / sums of squares of their x tiles in in_sum / in_sq: [B * tiles_per_utt][cin]
+    int per_utt, tiles_per_utt;
+    float* in_sum;
+    float* in_sq;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -196,8 +201,9 @@ __device__ __forceinline__ float4v act4(float4v v, int act) {
     return v;
 }
 
+// n_end: first row behind the tile's valid rows (the tensor's row count, or the end of the tile's utterance)
 template <int MI, int NI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0, int wc, int wn, int lane,
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int n_end, int co0, int wc, int wn, int lane,
                                               float4v (&acc)[MI][NI]) {
     const int crow = 4 * (lane >> 4);
     int nn[NI], nb[NI], nt[NI];
@@ -223,7 +229,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = nn[ni];
-            if (n >= a.n_rows) continue;
+            if (n >= n_end) continue;
             float4v v = acc[mi][ni] + bias4;
             if (a.row_bias != nullptr) v += *reinterpret_cast<const float4v*>(a.row_bias + (int64_t)nb[ni] * a.cout + co);
             v = act4(v, a.pre_act);
@@ -256,7 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int co0
 // contiguous row segments (TC*2 bytes).  The direct form stores 8 bytes per lane into 16 different rows per instruction,
 // which the PMC run showed as 1.7x write amplification at the memory side (WRITE_SIZE 790 MB for a 468 MB tensor).
 template <int MI, int NI, int TC, int TN, int NTHREADS>
-__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* smem, int n0, int co0, int wc, int wn, int lane,
+__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* smem, int n0, int n_end, int co0, int wc, int wn, int lane,
                                                      int tid, float4v (&acc)[MI][NI]) {
     constexpr int ROWB = TC * 2 + 8;
     const int crow = 4 * (lane >> 4);
@@ -267,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
         const int n = n0 + nl[ni];
         nb[ni] = 0;
         nt[ni] = 0;
-        if ((a.row_bias != nullptr || a.gate != nullptr) && n < a.n_rows) {
+        if ((a.row_bias != nullptr || a.gate != nullptr) && n < n_end) {
             nb[ni] = n / a.T_out;
             nt[ni] = n - nb[ni] * a.T_out;
         }
@@ -284,7 +290,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
         const float4v shift4 = (cok && a.scale != nullptr) ? *reinterpret_cast<const float4v*>(a.shift + co) : zero4;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const bool ok = cok && n0 + nl[ni] < a.n_rows;
+            const bool ok = cok && n0 + nl[ni] < n_end;
             float4v v = acc[mi][ni] + bias4;
             if (a.row_bias != nullptr && ok) v += *reinterpret_cast<const float4v*>(a.row_bias + (int64_t)nb[ni] * a.cout + co);
             v = act4(v, a.pre_act);
@@ -307,7 +313,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
         const int row = i / CPRW, ch = i - row * CPRW;
         const int n = n0 + row;
         const int co = co0 + ch * 8;
-        if (n >= a.n_rows || co >= a.cout) continue;
+        if (n >= n_end || co >= a.cout) continue;
         const char* src = smem + row * ROWB + ch * 16;
         half_t* dst = y + (int64_t)n * a.ldy + co;
         if (vec_ok && co + 8 <= a.cout) {
@@ -351,6 +357,57 @@ __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, in
     return tile_of_index(a, blockIdx.x, n_tile, co_tile);
 }
 
+// Time sums of one landed x stage ([TN rows][64 channels] in LDS; rows beyond the utterance came from the zero page and add nothing)
+// for the fused input statistics of a 1x1 layer: wave w takes the 16-byte chunks 2w and 2w + 1 (16 channels), its two 32-lane halves
+// one chunk each, lane g of a half the rows g, g + 32, ...; sums and sums of squares in fp32 (v_pk_add / v_pk_fma), reduced over the
+// 32 lanes (DPP row sums + one cross-row exchange) and written by one lane per half: 2 x 32 bytes per (tile, chunk).
+template <int TN>
+__device__ __forceinline__ void input_stats_stage(const ConvArgs& a, const char* xtile, int c0, int n_tile, int wave, int lane) {
+    const int chunk = 2 * wave + (lane >> 5), g = lane & 31;
+    float2v s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s1[q] = s2[q] = float2v{0.0f, 0.0f};
+#pragma unroll
+    for (int p = 0; p < TN / 32; ++p) {
+        const int row = g + 32 * p;
+        const half8v v = *reinterpret_cast<const half8v*>(xtile + lds_off(row, chunk));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2v f = float2v{(float)v[2 * q], (float)v[2 * q + 1]};
+            s1[q] += f;
+            s2[q] = __builtin_elementwise_fma(f, f, s2[q]);
+        }
+    }
+    // row sums in every lane of a 16-lane row, then the odd rows add the even row in front of them (row_bcast:15: lane 15 of the
+    // previous row): lanes 16..31 / 48..63 hold the sums of their 32-lane half -- all DPP, no LDS round trip
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // (MV_OPAQUE: keeps the vectoriser from pairing the sixteen reductions into v_pk_add_f32, which cannot carry a DPP operand --
+        // every step would become v_mov 0, v_mov_b32_dpp and half a packed add instead of one v_add_f32_dpp)
+        float t1 = s1[e >> 1][e & 1], t2 = s2[e >> 1][e & 1];
+        MV_OPAQUE(t1);
+        MV_OPAQUE(t2);
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        t1 += dpp_mov<DPP_ROW_BCAST15>(0.0f, t1);
+        t2 += dpp_mov<DPP_ROW_BCAST15>(0.0f, t2);
+        MV_OPAQUE(t1);
+        MV_OPAQUE(t2);
+        r1[e] = t1;
+        r2[e] = t2;
+    }
+    const int c = c0 + chunk * 8;
+    if (g == 16 && c < a.cin) {  // cin % 8 == 0: a chunk is inside or outside
+        float* ps = a.in_sum + (int64_t)n_tile * a.cin + c;
+        float* pq = a.in_sq + (int64_t)n_tile * a.cin + c;
+        *reinterpret_cast<float4v*>(ps) = float4v{r1[0], r1[1], r1[2], r1[3]};
+        *reinterpret_cast<float4v*>(ps + 4) = float4v{r1[4], r1[5], r1[6], r1[7]};
+        *reinterpret_cast<float4v*>(pq) = float4v{r2[0], r2[1], r2[2], r2[3]};
+        *reinterpret_cast<float4v*>(pq + 4) = float4v{r2[4], r2[5], r2[6], r2[7]};
+    }
+}
+
 // ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
 // Workgroup tile = (WC*MI*16) output channels x (WN*NI*16) time steps, WC x WN waves.  Two instances are built:
 //   <2,2,4,4>  128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU)  -- narrow layers and small problems
@@ -369,7 +426,14 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / WN, wn = wave % WN;
-    const int n0 = n_tile * TN;
+    // rows of the tile: n0 .. n0 + TN - 1 of the flat [B * T_out] row space, valid below n_end.  per_utt: tile = (utterance, block of
+    // TN frames), so no tile straddles two utterances (the fused input statistics are per utterance)
+    int n0 = n_tile * TN, n_end = a.n_rows;
+    if (a.per_utt) {
+        const int ub = n_tile / a.tiles_per_utt;
+        n0 = ub * a.T_out + (n_tile - ub * a.tiles_per_utt) * TN;
+        n_end = (ub + 1) * a.T_out;
+    }
     const int co0 = co_tile * TC;
 
     // Wave w issues NTX (NTW) transfers of 8 rows x 128 B for the activation (weight) tile: transfer i covers rows
@@ -381,7 +445,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NTX; ++i) {
         const int n = n0 + (wave * NTX + i) * 8 + lrow;
-        if (n < a.n_rows) {
+        if (n < n_end) {
             rm[i].b = n / a.T_out;
             rm[i].t = n - rm[i].b * a.T_out;
         } else {
@@ -445,13 +509,16 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
 #if !defined(MV_PROBE) || MV_PROBE != 2   // probe 2: no LDS reads / MFMAs in the K loop
         mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
 #endif
+        if constexpr (NW == 4 && TN % 32 == 0) {
+            if (a.in_sum != nullptr && co_tile == 0) input_stats_stage<TN>(a, wt + TC * CV_BK * 2, s * CV_BK, n_tile, wave, lane);  // uniform
+        }
         wait_all_loads();
         __syncthreads();
     }
     if (a.y_f16 && a.sum_dst == nullptr) {
-        conv_epilogue_staged<MI, NI, TC, TN, 64 * NW>(a, smem, n0, co0, wc, wn, lane, tid, acc);
+        conv_epilogue_staged<MI, NI, TC, TN, 64 * NW>(a, smem, n0, n_end, co0, wc, wn, lane, tid, acc);
     } else {
-        conv_epilogue<MI, NI>(a, n0, co0, wc, wn, lane, acc);
+        conv_epilogue<MI, NI>(a, n0, n_end, co0, wc, wn, lane, acc);
     }
 }
 
@@ -682,6 +749,37 @@ int conv_stats_finish_launch(const float* psum, const float* psq, const float* s
     MV_LAUNCH(stats_finish_kernel, ((unsigned)ceil_div(C, 256), (unsigned)B, 1), (256, 1, 1), 0, stream, psum, psq, shift, B, T, C, mean,
               stdv, ld_out, clamp_eps);
     return check_launch("stats_finish_kernel");
+}
+
+// per-utterance mean / std of a conv INPUT from the partial rows of input_stats_stage: [B * tiles_per_utt][C]
+__global__ void in_stats_finish_kernel(const float* psum, const float* psq, int B, int T, int C, int tiles_per_utt, float* mean, float* stdv,
+                                       int64_t ld_out, float clamp_eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= C || b >= B) return;
+    float s = 0.0f, q2 = 0.0f;
+    for (int k = 0; k < tiles_per_utt; ++k) {
+        s += psum[((int64_t)b * tiles_per_utt + k) * C + c];
+        q2 += psq[((int64_t)b * tiles_per_utt + k) * C + c];
+    }
+    const float m = s / (float)T;
+    mean[(int64_t)b * ld_out + c] = m;
+    if (stdv != nullptr) {
+        float var = fmaxf(q2 / (float)T - m * m, 0.0f);
+        if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
+        stdv[(int64_t)b * ld_out + c] = sqrtf(var);
+    }
+}
+
+constexpr int CV_IN_STATS_TN = 160;  // the tile of the kernel that takes them
+int64_t conv_in_stats_elems(int B, int T, int cin) { return (int64_t)B * ceil_div(T, CV_IN_STATS_TN) * cin; }
+
+int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
+                                float clamp_eps, hipStream_t stream) {
+    MV_REQUIRE(psum != nullptr && psq != nullptr && mean != nullptr && B > 0 && T > 0 && C > 0, "conv_in_stats_finish: bad argument");
+    MV_LAUNCH(in_stats_finish_kernel, ((unsigned)ceil_div(C, 256), (unsigned)B, 1), (256, 1, 1), 0, stream, psum, psq, B, T, C,
+              (int)ceil_div(T, CV_IN_STATS_TN), mean, stdv, ld_out, clamp_eps);
+    return check_launch("in_stats_finish_kernel");
 }
 
 // timing probe 3 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at four points of every stage
@@ -1058,7 +1156,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
         if (s + 1 < nstages) store_lds(s + 1, buf ^ 1);
         __syncthreads();
     }
-    conv_epilogue<4, 4>(a, n0, co0, wc, wn, lane, acc);
+    conv_epilogue<4, 4>(a, n0, a.n_rows, co0, wc, wn, lane, acc);
 }
 
 // fp32 [Cout][Cin][k] -> fp16 [Cout_pad][k][Cin_pad], zero padded
@@ -1195,6 +1293,12 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.n_rows = d.B * d.T_out;
     a.stat_sum = d.stat_sum;
     a.stat_sq = d.stat_sq;
+    a.per_utt = 0;
+    a.tiles_per_utt = 1;
+    a.in_sum = d.in_stat_sum;
+    a.in_sq = d.in_stat_sq;
+    const bool in_stats = d.in_stat_sum != nullptr;
+    MV_REQUIRE((d.in_stat_sum == nullptr) == (d.in_stat_sq == nullptr), "conv1d: in_stat_sum / in_stat_sq go together");
     const int stats = d.stat_sum == nullptr ? 0 : (d.stat_sq == nullptr ? 1 : 2);
     if (d.stat_sq != nullptr) MV_REQUIRE(d.stat_sum != nullptr, "conv1d: stat_sq needs stat_sum");
     const bool f16 = d.x_dtype == MV_DT_F16;
@@ -1203,7 +1307,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 160 || d.tile == 256, "conv1d: tile must be 0 (auto), 128, 160 or 256");
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
-    const bool big = big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    const bool big = !in_stats && big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
     // persistent form of the 256^2 kernel: fp16 output, plain bias / ReLU / affine epilogue
     const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
@@ -1215,7 +1319,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool direct = f16 && !has_x2 && !in_aff;
     bool wide = false;
     if (direct && !big) {
-        if (d.tile == 160) {
+        if (d.tile == 160 || in_stats) {
             wide = true;
         } else if (d.tile == 0) {
             const int64_t slots = 2 * (int64_t)cu_count(), cot = ceil_div(d.cout, CV_TC);
@@ -1229,8 +1333,15 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         MV_REQUIRE(persist && d.k == 1 && d.cin % CV_BK == 0 && d.T_out >= 64,
                    "conv1d: fused time statistics need the persistent 1x1 kernel (fp16 in/out, cout % 256 == 0, cin % 64 == 0, "
                    "plain bias / ReLU / affine epilogue, T_out >= 64)");
+    if (in_stats) {
+        MV_REQUIRE(direct && wide && d.k == 1 && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out && d.cout <= CV_TC && d.tile != 128 &&
+                       d.tile != 256 && (reinterpret_cast<uintptr_t>(d.in_stat_sum) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.in_stat_sq) & 15) == 0,
+                   "conv1d: fused input statistics need the direct fp16 1x1 path with the 160-row tile (stride 1, no padding, cout <= 128)");
+        a.per_utt = 1;
+        a.tiles_per_utt = (int)ceil_div(d.T_out, CV_IN_STATS_TN);
+    }
     const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
-    a.n_tiles = (int)ceil_div(a.n_rows, tn);
+    a.n_tiles = a.per_utt ? d.B * a.tiles_per_utt : (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     a.store_nt = conv_store_policy((int64_t)d.k * a.cin_pad);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
@@ -1308,6 +1419,13 @@ int mv_conv1d_stats_finish(const float* stat_sum, const float* stat_sq, const fl
     if (std != nullptr) MV_REQUIRE(stat_sq != nullptr, "mv_conv1d_stats_finish: std needs the sums of squares");
     return mv::conv_stats_finish_launch(stat_sum, std != nullptr ? stat_sq : nullptr, shift, B, T_out, cout, mean, std, ld_out, clamp_eps,
                                         static_cast<hipStream_t>(stream));
+}
+
+int64_t mv_conv1d_in_stats_elems(int32_t B, int32_t T_in, int32_t cin) { return mv::conv_in_stats_elems(B, T_in, cin); }
+
+int mv_conv1d_in_stats_finish(const float* in_stat_sum, const float* in_stat_sq, int32_t B, int32_t T_in, int32_t cin, float* mean,
+                              float* std, int64_t ld_out, float clamp_eps, mv_stream_t stream) {
+    return mv::conv_in_stats_finish_launch(in_stat_sum, in_stat_sq, B, T_in, cin, mean, std, ld_out, clamp_eps, static_cast<hipStream_t>(stream));
 }
 
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream) {

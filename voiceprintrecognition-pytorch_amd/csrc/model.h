@@ -76,7 +76,7 @@ struct AspLayer {
     ConvLayer conv;   // asp.conv (C x A), weights times log2(e); the bias cancels in the softmax over time
     float logit_bound_log2 = -1.0f;  // max_c sum_k |W2[c,k]| * log2(e): bounds every attention logit
     int create(MvModelBase* m, const Weights& w, const std::string& prefix, int C, int A, bool global_ctx);
-    size_t workspace_floats(int B) const;
+    size_t workspace_floats(int B, int T) const;
     // have_gstats: fws already holds the global mean | std of x ([B, 2C]) from the producer's fused statistics
     int forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled, hipStream_t stream,
                 bool have_gstats = false) const;

@@ -212,7 +212,17 @@ int AspLayer::create(MvModelBase* m, const Weights& w, const std::string& prefix
     return MV_OK;
 }
 
-size_t AspLayer::workspace_floats(int B) const { return (size_t)B * (2 * C + A); }
+// [B, 2C] global mean | std, [B, A] context bias; with the fused statistics also the hidden layer before its bias / activation
+// ([B*T, A] fp32) and the two partial buffers of the conv's input statistics
+size_t AspLayer::workspace_floats(int B, int T) const {
+    return (size_t)B * (2 * C + A) + (size_t)B * T * A + 2 * (size_t)conv_in_stats_elems(B, T, C);
+}
+
+// MV_ASP_FUSE_STATS=0 keeps the separate global-statistics pass in front of the hidden conv (A/B runs); read per call
+static bool asp_fuse_stats_enabled() {
+    const char* e = getenv("MV_ASP_FUSE_STATS");
+    return e == nullptr || atoi(e) != 0;
+}
 
 // x: [B, T, ldx] fp16 -> pooled [B, 2C] fp32.  h: [B*T, A] fp16 scratch, fws: workspace_floats(B) fp32 scratch.
 int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled,
@@ -221,6 +231,38 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     float* gstats = fws;                     // [B, 2C]  mean | std
     float* ctxb = fws + (size_t)B * 2 * C;   // [B, A]
     const float* gmean = nullptr;
+    if (global_ctx && !have_gstats && A <= 128 && ldx % 8 == 0 && asp_fuse_stats_enabled()) {
+        // x is streamed ONCE for the global statistics and the hidden layer: the 1x1 conv over x collects the time sums of its own x
+        // tiles and leaves the pre-activation z = Wx . x (fp32); the context columns [mean; std] enter as a per-utterance bias that
+        // is added afterwards, together with ReLU -> BatchNorm -> tanh (asp_hidden_act_kernel).  Saves the separate statistics
+        // pass over x (469 MB at the bench shape).
+        float* z = ctxb + (size_t)B * A;                       // [B*T, A]
+        float* psum = z + (size_t)B * T * A;
+        float* psq = psum + conv_in_stats_elems(B, T, C);
+        MvConv1dDesc d;
+        memset(&d, 0, sizeof(d));
+        d.x = x;
+        d.x_dtype = MV_DT_F16;
+        d.ldx = ldx;
+        d.w_packed = tdnn.w;
+        d.y = z;
+        d.y_dtype = MV_DT_F32;
+        d.ldy = A;
+        d.B = B;
+        d.T_in = d.T_out = T;
+        d.cin = C;
+        d.cout = A;
+        d.k = 1;
+        d.dilation = d.stride = 1;
+        d.pad_mode = MV_PAD_REFLECT;
+        d.in_stat_sum = psum;
+        d.in_stat_sq = psq;
+        if ((rc = conv1d_launch(d, stream))) return rc;
+        if ((rc = conv_in_stats_finish_launch(psum, psq, B, T, C, gstats, gstats + C, 2 * C, 1e-12f, stream))) return rc;
+        if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream))) return rc;
+        if ((rc = asp_hidden_act_launch(z, ctxb, bn_scale, bn_shift, h, B, T, A, stream))) return rc;
+        return asp_pool_launch(h, conv.w, x, ldx, gstats, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
+    }
     if (!have_gstats) {  // else: already written by the producer's fused epilogue statistics
         if ((rc = time_stats_launch(x, ldx, B, T, C, gstats, gstats + C, 2 * C, 0, 1e-12f, stream))) return rc;
     }
@@ -409,7 +451,7 @@ struct EcapaModel : MvModelBase {
         s.se_mean = c.take<float>((size_t)B * cmax);
         s.se_hid = c.take<float>((size_t)B * cfg.se_channels);
         s.gate = c.take<float>((size_t)B * cmax);
-        s.asp_f = c.take<float>(asp.workspace_floats(B));
+        s.asp_f = c.take<float>(asp.workspace_floats(B, T));
         s.pooled = c.take<float>((size_t)B * 2 * cfg.channels[4]);
         s.bytes = c.total();
         return s;
@@ -584,7 +626,7 @@ struct TdnnModel : MvModelBase {
         s.a = c.take<half_t>(N * cfg.channels);
         s.b = c.take<half_t>(N * cfg.channels);
         s.h = c.take<half_t>(N * 128);
-        s.asp_f = c.take<float>(asp.workspace_floats(B));
+        s.asp_f = c.take<float>(asp.workspace_floats(B, T));
         s.pooled = c.take<float>((size_t)B * 2 * cfg.channels);
         s.bytes = c.total();
         return s;

@@ -281,6 +281,37 @@ int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Deferred epilogue of the ASP hidden layer (pooling.py:80-84, 110-117): the context columns of asp.tdnn multiply [mean; std] of
+// the utterance -- a per-utterance bias -- so the 1x1 conv over x can run BEFORE the statistics are known (and collect them from
+// its own x tiles, MvConv1dDesc.in_stat_*); this pass then adds the bias and applies ReLU -> BatchNorm -> tanh:
+//   h[b, t, a] = tanh(relu(z[b, t, a] + row_bias[b, a]) * scale[a] + shift[a])      z fp32 [B*T, A], h fp16 [B*T, A], A % 4 == 0
+__global__ __launch_bounds__(256) void asp_hidden_act_kernel(const float* z, const float* row_bias, const float* scale, const float* shift,
+                                                             half_t* h, int64_t total4, int T, int A4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / A4;
+        const int a4 = (int)(i - row * A4);
+        const int b = (int)(row / T);
+        const float4v v = *reinterpret_cast<const float4v*>(z + i * 4);
+        const float4v rb = *reinterpret_cast<const float4v*>(row_bias + ((int64_t)b * A4 + a4) * 4);
+        const float4v sc = *reinterpret_cast<const float4v*>(scale + a4 * 4), sh = *reinterpret_cast<const float4v*>(shift + a4 * 4);
+        half4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)tanhf(fmaxf(v[e] + rb[e], 0.0f) * sc[e] + sh[e]);
+        *reinterpret_cast<half4v*>(h + i * 4) = o;
+    }
+}
+
+int asp_hidden_act_launch(const float* z, const float* row_bias, const float* scale, const float* shift, half_t* h, int B, int T, int A,
+                          hipStream_t stream) {
+    MV_REQUIRE(z != nullptr && row_bias != nullptr && scale != nullptr && shift != nullptr && h != nullptr, "asp_hidden_act: null tensor");
+    MV_REQUIRE(B > 0 && T > 0 && A > 0 && A % 4 == 0, "asp_hidden_act: bad geometry");
+    const int64_t total4 = (int64_t)B * T * (A / 4);
+    const int grid = (int)(ceil_div(total4, 256) < 4096 ? ceil_div(total4, 256) : 4096);
+    MV_LAUNCH(asp_hidden_act_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, z, row_bias, scale, shift, h, total4, T, A / 4);
+    return check_launch("asp_hidden_act_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Attentive statistics pooling tail.  Workgroup = (64-channel tile, 4 utterances), one utterance per wave, 16-row time
 // tiles.  Per tile:  logits[c, t] = W2[c, :] . h[b, t, :]  (+ b2[c], which is constant over t and cancels in the softmax
 // over time, so it is never added)  on MFMA 16x16x32 (A = W2 rows staged once in LDS,

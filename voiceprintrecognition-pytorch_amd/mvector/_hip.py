@@ -72,7 +72,7 @@ class MvConv1dDesc(ctypes.Structure):
                 ('y', c_vp), ('y_dtype', c_i32), ('ldy', c_i64), ('add_src', c_vp), ('sum_dst', c_vp), ('ld_add', c_i64),
                 ('ld_sum', c_i64), ('B', c_i32), ('T_in', c_i32), ('T_out', c_i32),
                 ('cin', c_i32), ('cout', c_i32), ('k', c_i32), ('dilation', c_i32), ('stride', c_i32), ('pad', c_i32),
-                ('pad_mode', c_i32), ('tile', c_i32), ('stat_sum', c_vp), ('stat_sq', c_vp)]
+                ('pad_mode', c_i32), ('tile', c_i32), ('stat_sum', c_vp), ('stat_sq', c_vp), ('in_stat_sum', c_vp), ('in_stat_sq', c_vp)]
 
 
 _SIGNATURES = {
@@ -111,6 +111,8 @@ _SIGNATURES = {
     'mv_conv1d_pack_weight': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_conv1d_forward': (c_i32, [ctypes.POINTER(MvConv1dDesc), c_vp]),
     'mv_conv1d_stats_elems': (c_i64, [c_i32, c_i32, c_i32]),
+    'mv_conv1d_in_stats_elems': (c_i64, [c_i32, c_i32, c_i32]),
+    'mv_conv1d_in_stats_finish': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp]),
     'mv_conv1d_stats_finish': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp]),
     'mv_res2net_chain_f16': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                              ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
