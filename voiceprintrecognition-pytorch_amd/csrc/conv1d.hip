@@ -113,6 +113,24 @@ __device__ __forceinline__ int input_time(const ConvArgs& a, int t, int tap) {
 // ---- shared MFMA stage and epilogue ---------------------------------------------------------------------------
 // Wave tile = MI x NI MFMA tiles of 16 x 16; wc / wn = position of the wave inside the workgroup tile.
 template <int MI, int NI>
+__device__ __forceinline__ void mma_half_stage(const char* wt, const char* xtile, int wc, int wn, int lane, int kk, float4v (&acc)[MI][NI]) {
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    half8v af[MI], bf[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const half8v*>(wt + lds_off(wc * (MI * 16) + mi * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const half8v*>(xtile + lds_off(wn * (NI * 16) + ni * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+}
+
+template <int MI, int NI>
 __device__ __forceinline__ void mma_stage(const char* wt, const char* xtile, int wc, int wn, int lane, float4v (&acc)[MI][NI]) {
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
@@ -361,12 +379,15 @@ __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, in
 // for the fused input statistics of a 1x1 layer: wave w takes the 16-byte chunks 2w and 2w + 1 (16 channels), its two 32-lane halves
 // one chunk each, lane g of a half the rows g, g + 32, ...; sums and sums of squares in fp32 (v_pk_add / v_pk_fma), reduced over the
 // 32 lanes (DPP row sums + one cross-row exchange) and written by one lane per half: 2 x 32 bytes per (tile, chunk).
-template <int TN>
-__device__ __forceinline__ void input_stats_stage(const ConvArgs& a, const char* xtile, int c0, int n_tile, int wave, int lane) {
-    const int chunk = 2 * wave + (lane >> 5), g = lane & 31;
+struct InStats {
     float2v s1[4], s2[4];
+};
+
+template <int TN>
+__device__ __forceinline__ void input_stats_accumulate(InStats& st, const char* xtile, int wave, int lane) {
+    const int chunk = 2 * wave + (lane >> 5), g = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s1[q] = s2[q] = float2v{0.0f, 0.0f};
+    for (int q = 0; q < 4; ++q) st.s1[q] = st.s2[q] = float2v{0.0f, 0.0f};
 #pragma unroll
     for (int p = 0; p < TN / 32; ++p) {
         const int row = g + 32 * p;
@@ -374,10 +395,14 @@ __device__ __forceinline__ void input_stats_stage(const ConvArgs& a, const char*
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float2v f = float2v{(float)v[2 * q], (float)v[2 * q + 1]};
-            s1[q] += f;
-            s2[q] = __builtin_elementwise_fma(f, f, s2[q]);
+            st.s1[q] += f;
+            st.s2[q] = __builtin_elementwise_fma(f, f, st.s2[q]);
         }
     }
+}
+
+__device__ __forceinline__ void input_stats_reduce_store(const ConvArgs& a, const InStats& st, int c0, int n_tile, int wave, int lane) {
+    const int chunk = 2 * wave + (lane >> 5), g = lane & 31;
     // row sums in every lane of a 16-lane row, then the odd rows add the even row in front of them (row_bcast:15: lane 15 of the
     // previous row): lanes 16..31 / 48..63 hold the sums of their 32-lane half -- all DPP, no LDS round trip
     float r1[8], r2[8];
@@ -385,7 +410,7 @@ __device__ __forceinline__ void input_stats_stage(const ConvArgs& a, const char*
     for (int e = 0; e < 8; ++e) {
         // (MV_OPAQUE: keeps the vectoriser from pairing the sixteen reductions into v_pk_add_f32, which cannot carry a DPP operand --
         // every step would become v_mov 0, v_mov_b32_dpp and half a packed add instead of one v_add_f32_dpp)
-        float t1 = s1[e >> 1][e & 1], t2 = s2[e >> 1][e & 1];
+        float t1 = st.s1[e >> 1][e & 1], t2 = st.s2[e >> 1][e & 1];
         MV_OPAQUE(t1);
         MV_OPAQUE(t2);
         t1 = row16_sum(t1);
@@ -414,7 +439,9 @@ __device__ __forceinline__ void input_stats_stage(const ConvArgs& a, const char*
 //   <2,4,8,4>  256 x 256, 8 waves, 128 KiB LDS (1 workgroup per CU)  -- wide layers: each wave owns 128 x 64, i.e. 12
 //              fragment reads per 32 MFMAs instead of 8 per 16, and half the global->LDS bytes per FLOP; the 128^2
 //              kernel is LDS-bandwidth bound (reads + DMA writes ~1200 LDS cycles vs 1024 MFMA cycles per K stage).
-template <int WC, int WN, int MI, int NI>
+// INSTATS: the fused input statistics as a compile-time variant, so that their VALU work sits in the K loop's basic block next to
+// the MFMAs (the scheduler interleaves them; behind a run-time branch they would run after the matrix pipe's 40 issues)
+template <int WC, int WN, int MI, int NI, bool INSTATS = false>
 __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     constexpr int TC = WC * MI * 16, TN = WN * NI * 16, NW = WC * WN;
     constexpr int NTW = TC / 8 / NW, NTX = TN / 8 / NW;  // 1 KiB transfers per wave per stage
@@ -500,21 +527,30 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     issue(0, 0);
     wait_all_loads();
     __syncthreads();
+    InStats st;  // (INSTATS) time sums of the stage before the current one, reduced and stored under the current stage's MFMAs
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
 #if !defined(MV_PROBE) || MV_PROBE != 1   // probe 1: no global->LDS traffic in the K loop (tools/probe only)
         if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
 #endif
         const char* wt = smem + buf * STAGE_BYTES;
+        if constexpr (INSTATS) {
+            // the statistics of the stage in two halves, each behind one K half's MFMAs: the matrix pipe works off its 20 issues while
+            // the vector unit runs the ~100 VALU operations written after them (a single channel tile here: cout <= 128)
+            static_assert(NW == 4 && TN % 32 == 0, "input statistics: 256 threads, whole groups of 32 rows");
+            mma_half_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, 0, acc);
+            if (s > 0) input_stats_reduce_store(a, st, (s - 1) * CV_BK, n_tile, wave, lane);  // the previous stage's sums (uniform)
+            mma_half_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, 1, acc);
+            input_stats_accumulate<TN>(st, wt + TC * CV_BK * 2, wave, lane);
+        } else {
 #if !defined(MV_PROBE) || MV_PROBE != 2   // probe 2: no LDS reads / MFMAs in the K loop
-        mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+            mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
 #endif
-        if constexpr (NW == 4 && TN % 32 == 0) {
-            if (a.in_sum != nullptr && co_tile == 0) input_stats_stage<TN>(a, wt + TC * CV_BK * 2, s * CV_BK, n_tile, wave, lane);  // uniform
         }
         wait_all_loads();
         __syncthreads();
     }
+    if constexpr (INSTATS) input_stats_reduce_store(a, st, (nstages - 1) * CV_BK, n_tile, wave, lane);
     if (a.y_f16 && a.sum_dst == nullptr) {
         conv_epilogue_staged<MI, NI, TC, TN, 64 * NW>(a, smem, n0, n_end, co0, wc, wn, lane, tid, acc);
     } else {
@@ -1349,6 +1385,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (!smem_set) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 0>), CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 1>), CVP_LDS_BYTES) != hipSuccess ||
@@ -1376,6 +1413,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         }
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
+    } else if (wide && in_stats) {
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5, true>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (wide) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {

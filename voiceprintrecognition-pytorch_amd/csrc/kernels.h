@@ -15,9 +15,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream);
 int64_t conv_in_stats_elems(int B, int T, int cin);
 int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
                                 float clamp_eps, hipStream_t stream);
-// h[b, t, :] = tanh(relu(z[b, t, :] + row_bias[b, :]) * scale + shift) as fp16: the deferred epilogue of the ASP hidden layer
-int asp_hidden_act_launch(const float* z, const float* row_bias, const float* scale, const float* shift, half_t* h, int B, int T, int A,
-                          hipStream_t stream);
+// zh[b, t, :] <- tanh(relu(zh[b, t, :] + row_bias[b, :]) * scale + shift), fp16 in place: the deferred epilogue of the ASP hidden layer
+int asp_hidden_act_launch(half_t* zh, const float* row_bias, const float* scale, const float* shift, int B, int T, int A, hipStream_t stream);
 
 typedef MvConv2dDesc Conv2dDesc;
 int conv2d_launch(const Conv2dDesc& d, hipStream_t stream);

@@ -212,10 +212,10 @@ int AspLayer::create(MvModelBase* m, const Weights& w, const std::string& prefix
     return MV_OK;
 }
 
-// [B, 2C] global mean | std, [B, A] context bias; with the fused statistics also the hidden layer before its bias / activation
-// ([B*T, A] fp32) and the two partial buffers of the conv's input statistics
+// [B, 2C] global mean | std, [B, A] context bias, the two partial buffers of the hidden conv's fused input statistics
 size_t AspLayer::workspace_floats(int B, int T) const {
-    return (size_t)B * (2 * C + A) + (size_t)B * T * A + 2 * (size_t)conv_in_stats_elems(B, T, C);
+    (void)T;
+    return (size_t)B * (2 * C + A) + 2 * (size_t)conv_in_stats_elems(B, T, C);
 }
 
 // MV_ASP_FUSE_STATS=0 keeps the separate global-statistics pass in front of the hidden conv (A/B runs); read per call
@@ -231,13 +231,12 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     float* gstats = fws;                     // [B, 2C]  mean | std
     float* ctxb = fws + (size_t)B * 2 * C;   // [B, A]
     const float* gmean = nullptr;
-    if (global_ctx && !have_gstats && A <= 128 && ldx % 8 == 0 && asp_fuse_stats_enabled()) {
+    if (global_ctx && !have_gstats && A <= 128 && A % 8 == 0 && ldx % 8 == 0 && asp_fuse_stats_enabled()) {
         // x is streamed ONCE for the global statistics and the hidden layer: the 1x1 conv over x collects the time sums of its own x
-        // tiles and leaves the pre-activation z = Wx . x (fp32); the context columns [mean; std] enter as a per-utterance bias that
-        // is added afterwards, together with ReLU -> BatchNorm -> tanh (asp_hidden_act_kernel).  Saves the separate statistics
-        // pass over x (469 MB at the bench shape).
-        float* z = ctxb + (size_t)B * A;                       // [B*T, A]
-        float* psum = z + (size_t)B * T * A;
+        // tiles and leaves the pre-activation z = Wx . x in h; the context columns [mean; std] enter as a per-utterance bias that
+        // is added afterwards, together with ReLU -> BatchNorm -> tanh (asp_hidden_act_kernel, in place).  Saves the separate
+        // statistics pass over x (469 MB at the bench shape).
+        float* psum = ctxb + (size_t)B * A;
         float* psq = psum + conv_in_stats_elems(B, T, C);
         MvConv1dDesc d;
         memset(&d, 0, sizeof(d));
@@ -245,8 +244,8 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
         d.x_dtype = MV_DT_F16;
         d.ldx = ldx;
         d.w_packed = tdnn.w;
-        d.y = z;
-        d.y_dtype = MV_DT_F32;
+        d.y = h;
+        d.y_dtype = MV_DT_F16;
         d.ldy = A;
         d.B = B;
         d.T_in = d.T_out = T;
@@ -260,7 +259,7 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
         if ((rc = conv1d_launch(d, stream))) return rc;
         if ((rc = conv_in_stats_finish_launch(psum, psq, B, T, C, gstats, gstats + C, 2 * C, 1e-12f, stream))) return rc;
         if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream))) return rc;
-        if ((rc = asp_hidden_act_launch(z, ctxb, bn_scale, bn_shift, h, B, T, A, stream))) return rc;
+        if ((rc = asp_hidden_act_launch(h, ctxb, bn_scale, bn_shift, B, T, A, stream))) return rc;
         return asp_pool_launch(h, conv.w, x, ldx, gstats, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
     }
     if (!have_gstats) {  // else: already written by the producer's fused epilogue statistics
