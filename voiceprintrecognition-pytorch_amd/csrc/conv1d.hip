@@ -1062,6 +1062,15 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 // timeline (MV_PROBE=3, tools/trace_conv.py) shows per K stage ~400 cycles barrier skew, ~1650 cycles MFMA issue per wave
 // (two waves share a SIMD's matrix pipe: 2048 busy cycles) and 1000-2000 cycles until the next stage has landed.
 //
+// Round 2, bytes in flight (profiles/r05a_gemm_load_depth_probe.log, r05b_conv_ring_vs_double.log): the K loop's transfers ALONE scale with
+// the bytes a CU has in flight -- 64 KiB: 82 us (K = 1024) / 1080 us (K = 3072), 96 KiB: 71 / 809 us, 128 KiB: 55 / 785 us (saturated at 22.9 /
+// 14.3 TB/s into LDS), while 32-wide stages (64-byte row segments) stay at 14 / 11 TB/s at any depth (the path counts requests: why the 4-slot
+// ring of round 1 gained nothing).  A kernel built on that -- weight halves of the stages one ahead in a ring of two 32 KiB slots, activation
+// halves two ahead in a ring of three (all 160 KiB of LDS, 96 KiB in flight, vmcnt(4) stage waits, epilogue parameters in six registers per
+// lane behind ds_bpermute) -- is correct and SLOWER: K = 1024 187 -> 200 us, K = 3072 1292 -> 1338 us, end to end 71.7 k -> 70.0 k utt/s
+// (tools/variants/conv1d_ring_persistent.hip.txt).  So the full kernel is not bound by the latency of its transfers either; what the transfers
+// and the MFMA stream share is the LDS itself: per stage and CU 64 KiB of LDS-DMA writes + 192 KiB of fragment reads for 2048 matrix-pipe cycles.
+//
 // Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
 // r01h), a 256x256 tile with a 4-slot ring of 32-wide stages and counted vmcnt (500 / 775 TF, r01i -- no better than the
 // double buffer), padded leading dimensions (r01k, no effect).  Probes with the K loop reduced to its loads or to its
