@@ -103,6 +103,7 @@ inline void glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base
 template <int N>
 inline void wait_vm() {}
 inline void lds_barrier() { __syncthreads(); }
+inline void barrier_only() { __syncthreads(); }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc, 16);
 }
@@ -130,6 +131,17 @@ inline void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
 }
 inline void lds_read4(half8v (&d)[4], unsigned addr) {
     for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 2048 * i));
+}
+template <int OFF, int STRIDE>
+inline void lds_read5(half8v (&d)[5], unsigned addr) {
+    for (int i = 0; i < 5; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF + i * STRIDE));
+}
+template <int WAIT>
+inline void mfma10_step(float4v* c0, float4v* c1, const half8v& a0, const half8v& a1, const half8v (&b)[5]) {
+    for (int i = 0; i < 5; ++i) {
+        c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
+        c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
+    }
 }
 inline void mfma_hazard_pad() {}
 inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }

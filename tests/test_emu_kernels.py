@@ -43,7 +43,7 @@ def test_emu_conv1d_rejects_bad_arguments():
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2), (3, 2100, 20, 0)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2), (3, 2100, 20, 0), (4, 4180, 18, 0)])
 def test_emu_linear(shape):
     B, K, O, act = shape
     lc.linear_case(emu_cdll(), 'cpu', B, K, O, act)
@@ -171,7 +171,7 @@ def test_emu_asp_pool(cfg):
     lc.asp_pool_case(emu_cdll(), 'cpu', **cfg)
 
 
-@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1)])
+@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1), dict(width=128, T=75, dil=3, B=2)])
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
 

@@ -52,7 +52,7 @@ def test_gpu_conv1d(idx):
     lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0)])
 def test_gpu_linear(shape):
     lc.linear_case(product_lib(), DEV, *shape)
 

@@ -127,6 +127,10 @@ __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain transfers still in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// bare workgroup barrier: no wait for this wave's outstanding LDS reads (they may stay in flight across it when nobody writes what they
+// read); everything else a barrier has to order is the caller's business
+__device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+
 // ---- hand-scheduled pieces of the 256 x 256 GEMM stage (conv1d.hip) ---------------------------------------------------------------
 #define MV_MFMA8(A0, A1)                                                                                       \
     "v_mfma_f32_16x16x32_f16 %0, " A0 ", %10, %0\n\tv_mfma_f32_16x16x32_f16 %1, " A0 ", %11, %1\n\t"          \
@@ -175,6 +179,30 @@ __device__ __forceinline__ void lds_wait(half8v& a) {
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read1_off(half8v& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory"); }
+// ---- hand-scheduled pieces of the Res2Net chain stage (res2.hip): 2 channel tiles x 5 time tiles per step ----------------------------
+// five 16-byte fragment reads at addr + OFF + i * STRIDE, no wait
+template <int OFF, int STRIDE>
+__device__ __forceinline__ void lds_read5(half8v (&d)[5], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\t"
+                 "ds_read_b128 %3, %5 offset:%9\n\tds_read_b128 %4, %5 offset:%10"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4])
+                 : "v"(addr), "n"(OFF), "n"(OFF + STRIDE), "n"(OFF + 2 * STRIDE), "n"(OFF + 3 * STRIDE), "n"(OFF + 4 * STRIDE)
+                 : "memory");
+}
+// wait until at most WAIT LDS reads are outstanding, then 10 MFMAs: (a0 | a1) x b[0..4] into c0[G..G+4] | c1[G..G+4]
+template <int WAIT>
+__device__ __forceinline__ void mfma10_step(float4v* c0, float4v* c1, const half8v& a0, const half8v& a1, const half8v (&b)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(%17)\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %10, %12, %0\n\tv_mfma_f32_16x16x32_f16 %5, %11, %12, %5\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %10, %13, %1\n\tv_mfma_f32_16x16x32_f16 %6, %11, %13, %6\n\t"
+                 "v_mfma_f32_16x16x32_f16 %2, %10, %14, %2\n\tv_mfma_f32_16x16x32_f16 %7, %11, %14, %7\n\t"
+                 "v_mfma_f32_16x16x32_f16 %3, %10, %15, %3\n\tv_mfma_f32_16x16x32_f16 %8, %11, %15, %8\n\t"
+                 "v_mfma_f32_16x16x32_f16 %4, %10, %16, %4\n\tv_mfma_f32_16x16x32_f16 %9, %11, %16, %9"
+                 : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c0[4]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+                   "+v"(c1[4])
+                 : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "n"(WAIT)
+                 : "memory");
+}
 // MFMA results are read by VALU code only after a barrier and a round of transfers; pad the hazard anyway
 __device__ __forceinline__ void mfma_hazard_pad() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // 16-byte store with the streaming policy bits (write-through, no L2 allocation)

@@ -33,7 +33,7 @@ __device__ __forceinline__ float4v load4_guard(const float* row, int k, int K, b
 
 // y[b, o] = act( sum_k x[b,k] w[o,k] + bias[o] );  with `cosine` set the dot product is divided by the two
 // row norms |x_b| |w_o| (accumulated in the same K loop), i.e. sklearn's cosine_similarity.
-template <int NW>
+template <int NW, int U = 4>
 __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int64_t ldx, const float* w, int64_t ldw,
                                                              const float* bias, int act, float* y, int64_t ldy, int B,
                                                              int K, int O, int cosine) {
@@ -54,20 +54,21 @@ __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int
     const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     float4v acc = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     float sqx = 0.0f, sqw = 0.0f;
-    // wave `wave` takes K blocks of 16 with index == wave (mod NW).  Main loop: four unguarded blocks per trip, their eight
-    // 16-byte loads in flight together (the chain of dependent load -> MFMA trips is what these small layers wait for);
-    // the guarded loop takes the remainder (and everything when the rows are not 16-byte aligned).
+    // wave `wave` takes K blocks of 16 with index == wave (mod NW).  Main loop: U unguarded blocks per trip, their 2 U
+    // 16-byte loads in flight together (the chain of dependent load -> MFMA trips is what these small layers wait for: U = 8 for the
+    // K = 6144 layers of the ASP head, three trips instead of six); the guarded loop takes the remainder (and everything when the rows
+    // are not 16-byte aligned).
     const int kfull = (xvec && wvec) ? (K & ~15) : 0;
     int k0 = wave * 16;
-    for (; k0 + 3 * 16 * NW < kfull; k0 += 4 * 16 * NW) {
-        float4v xa[4], wb[4];
+    for (; k0 + (U - 1) * 16 * NW < kfull; k0 += U * 16 * NW) {
+        float4v xa[U], wb[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             xa[u] = *reinterpret_cast<const float4v*>(xrow + k0 + u * 16 * NW + 4 * g);
             wb[u] = *reinterpret_cast<const float4v*>(wrow + k0 + u * 16 * NW + 4 * g);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][e], wb[u][e], acc, 0, 0, 0);
             if (cosine) {
@@ -160,7 +161,10 @@ int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, 
         }
         return MV_OK;
     }
-    if (K >= 2048) {  // long reductions: 16 waves split K so the dependent load chain per wave stays short
+    if (K >= 4096) {
+        MV_LAUNCH((linear_f32_kernel<16, 8>), ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (1024, 1, 1), 0, stream, x, ldx,
+                  w, ldw, bias, act, y, ldy, B, K, O, cosine);
+    } else if (K >= 2048) {  // long reductions: 16 waves split K so the dependent load chain per wave stays short
         MV_LAUNCH(linear_f32_kernel<16>, ((unsigned)ceil_div(O, 16), (unsigned)ceil_div(B, 16), 1), (1024, 1, 1), 0, stream, x, ldx,
                   w, ldw, bias, act, y, ldy, B, K, O, cosine);
     } else {

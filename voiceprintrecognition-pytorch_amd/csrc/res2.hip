@@ -22,6 +22,17 @@
 // each behind a compiler-inserted s_waitcnt vmcnt(0)).  The restructured variant (tools/variants/) removes exactly those waits
 // and still measures the same: its timeline is the next thing to take.
 //
+// Round 2 (r05c-r05h, tools/bench_res2.py old vs new in one box, profiles/r05_res2_chain_direct.log): width 128 runs the DIRECT form below
+// (121-125 -> 107-110 us): weight fragments from global memory into registers two stages ahead, no weight ring and no barrier inside the K
+// loop, hand-scheduled K stage, x_{j+1} by LDS-DMA in the ring's place.  Steps on the way: the hand-scheduled stage alone inside the ring form
+// 116 us; + the next stage's activation fragments in flight across the stage barrier: the same (the stage barrier itself, not the LDS latency
+// behind it, was the cost); direct weights one stage ahead + x_{j+1} in registers 113-116 (the L2 latency is longer than a stage); two stages
+// ahead + x_{j+1} as ONE burst of LDS-DMA at the start of the step 116-126 (80 transfers per CU in front of stage 0's MFMAs); the burst
+// spread over the stages, two transfers per wave and stage: 107-110.  What is left per step of ~27 k cycles (timeline r05g): four stages at
+// the matrix pipe's pace (~1.1-1.3 k), two late ones (2.5-4.5 k: the first fragment loads behind the previous epilogue's y stores -- one
+// in-order counter for loads and stores, and the chip-wide store burst of an epilogue takes thousands of cycles to retire), ~6 k epilogue,
+// ~2.7 k in the barrier in front of the step.
+//
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
 #include <type_traits>
@@ -30,6 +41,11 @@
 
 namespace mv {
 
+#ifndef MV_RES2_ASM
+#define MV_RES2_ASM 1  // 0: weight ring in LDS + compiler-scheduled K stage for every width (tools/probe A/B arm only)
+#endif
+constexpr bool R2_DIRECT = MV_RES2_ASM != 0;  // width 128, T <= 304: weights straight into registers, hand-scheduled K stage (below)
+constexpr int R2_XNEXT_BYTES = 77824;         // direct form: [<= 304 rows][128] fp16 of the next channel group, where the weight ring was
 constexpr int R2_THREADS = 512;
 constexpr int R2_NH = 10;            // time tiles (16 frames) per wave half -> T <= 320
 constexpr int R2_MAX_STEPS = 15;
@@ -69,16 +85,18 @@ __device__ int g_r2_trace_n;
 #endif
 
 // MI = output channel tiles per wave (width = 64 * MI)
-template <int MI>
+template <int MI, bool DIRECT = false>
 __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
+    static_assert(!DIRECT || MI == 2, "the direct form is written for width 128");
     MV_DYN_SMEM(smem);
     constexpr int WIDTH = 64 * MI;
     constexpr int CPR = WIDTH / 8;       // 16-byte chunks per activation row
     constexpr int ROWB = WIDTH * 2;      // bytes per activation row
     constexpr int TP = MI;               // weight transfers per stage per wave (WIDTH/8 transfers over 8 waves)
-    char* wbuf = smem;                               // R2_RING x R2_WSTAGE_BYTES
-    char* abuf = smem + R2_RING * R2_WSTAGE_BYTES;   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
+    char* wbuf = smem;                               // R2_RING x R2_WSTAGE_BYTES  (direct form: the next channel group instead)
+    char* abuf = smem + (DIRECT ? R2_XNEXT_BYTES : R2_RING * R2_WSTAGE_BYTES);   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = MV_UNIFORM(wave);
 #if defined(MV_PROBE) && MV_PROBE == 1
     int trace_i = 0;
 #endif
@@ -119,6 +137,45 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     // operand rows of this lane: time tile ni starts at row (nh0 + ni) * 16 + fr (+ tap shift + PAD)
     const int lane_row0 = nh0 * 16 + fr;
 
+    // ---- width 128, direct form (round 2) -------------------------------------------------------------------------------------------
+    // In-kernel timeline of the ring form (r05c): a K stage = 1650-1750 cycles from the stage barrier to the next wait + 700-800 in the
+    // barrier, for 1280 cycles of matrix work per SIMD (2 waves x 40 MFMAs); every step starts by waiting for its first weight stage,
+    // and the ten x_{j+1} register loads in front of the last stage cost 3.6 k cycles of issue.  Here:
+    //  * a wave's weight operands of a stage are just FOUR 16-byte fragments per lane (2 K halves x 2 channel tiles), so they skip LDS:
+    //    each lane loads them from global memory (L2 resident: 96 KiB per step, the two time halves of a channel group share the lines
+    //    through L1) TWO stages ahead into a rotation of three register sets -- one stage of lead does not cover the L2 latency (r05e);
+    //  * no weight ring, and -- the activation buffer being constant inside a step -- NO barrier inside the K loop: the waves of a SIMD
+    //    drift apart and keep its matrix pipe fed; the only barriers left are the two around the epilogue;
+    //  * activation fragments: two register groups of five time tiles, read by inline assembly one phase ahead of the MFMAs that use
+    //    them (counted lgkmcnt waits; the compiler's own schedule fell back to "one read, full wait, two MFMAs" in the second K half),
+    //    the first group of stage s + 1 under the last phases of stage s;
+    //  * the next channel group x_{j+1} arrives by LDS-DMA in the LDS the ring used to occupy (requested at the start of the step, read
+    //    by the epilogue; rows XOR-swizzled through the source addresses), not through 40 registers per lane.
+    half8v wf[3][2][2];  // [set][K half][channel tile]
+    auto load_wf = [&](const half_t* wj, int s, half8v (&dst)[2][2]) {
+        const int tap = s / kstages_per_tap;
+        const int c0 = (s - tap * kstages_per_tap) * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = (cw * 2 + mi) * 16 + fr;
+                dst[kk][mi] = *MV_GLOBAL_PTR(half8v, wj + ((int64_t)row * a.k + tap) * a.kpad + c0 + (kk * 4 + fg) * 8);
+            }
+    };
+    // weight fragments of the stage that runs `ahead` stages after stage s of step j (possibly in the next step; nothing after the last)
+    auto load_ahead = [&](int j, int s, half8v (&dst)[2][2]) {
+        if (s < nstages) {
+            load_wf(a.w[j - 1], s, dst);
+        } else if (j < a.steps) {
+            load_wf(a.w[j], s - nstages, dst);
+        }
+    };
+    if constexpr (DIRECT) {
+        load_ahead(1, 0, wf[0]);
+        load_ahead(1, 1, wf[1]);
+    }
+
     R2_TRACE(0);  // prologue done (slice copy + first input staged)
     for (int j = 1; j <= a.steps; ++j) {
         R2_TRACE(1);  // step start
@@ -140,7 +197,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         half4v xn[MI][R2_NH];   // MI == 1: this wave's 4 channels per tile
         half8v xp[R2_NH];       // MI == 2: 8 consecutive channels per lane (paired layout of the epilogue)
         const int co8 = (cw * 2 + (fg & 1)) * 16 + 8 * (fg >> 1);
-        for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
+        if constexpr (!DIRECT)
+            for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
         float4v acc[MI][R2_NH];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -225,8 +283,87 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             phase(std::integral_constant<int, 2>{});
             phase(std::integral_constant<int, 3>{});
         };
-        for (int s = 0; s + 1 < nstages; ++s) do_stage(s, std::false_type{});
-        do_stage(nstages - 1, std::true_type{});  // peeled: the x_{j+1} registers exist from here on only
+        if constexpr (DIRECT) {
+            constexpr int NG = R2_NH / 2;
+            static_assert(NG == 5, "mfma10_step takes five time tiles");
+            // x_{j+1} transfers per wave and stage: ceil(76 / 8) = 10 per wave spread over the step's stages (>= 6: k >= 3)
+            constexpr int XPS = 2;
+            half8v bA[5], bB[5];
+            auto b_addr = [&](int s, int khalf) {  // LDS byte address of time tile 0's fragment for K half `khalf` of stage s
+                const int tap = s / kstages_per_tap;
+                const int c0 = (s - tap * kstages_per_tap) * 64;
+                const int row0 = lane_row0 + (tap - half_k) * a.dil + PAD;  // >= 0; row0 + 16 * ni is tile ni's operand row
+                const int chunk = (c0 >> 3) + fg + 4 * khalf;
+                return lds_addr(abuf) + (unsigned)(row0 * ROWB + ((chunk ^ (row0 & (CPR - 1))) << 4));
+            };
+            auto stage = [&](int s, half8v (&cur)[2][2], half8v (&ahead)[2][2], auto LAST) __attribute__((always_inline)) {
+                load_ahead(j, s + 2, ahead);
+                R2_TRACE(3);
+                const unsigned bp1 = b_addr(s, 1);
+                mfma10_step<0>(&acc[0][0], &acc[1][0], cur[0][0], cur[0][1], bA);
+                lds_read5<0, 16 * ROWB>(bA, bp1);  // (these registers were last sourced by the step above)
+                {
+                    // Request x_{next_group}: 4 rows of 256 B per transfer, row r's 16-byte chunk c lands at chunk position c ^ (r & 15);
+                    // XPS transfers per wave and stage, so that the memory pipe takes them between the weight loads instead of as one
+                    // burst of 80 per CU that the waves would sit behind (r05f: 3-4 k cycles in front of the MFMAs of stage 0).
+                    // Untracked, and issued behind the stage's first MFMAs: the compiler counts the waits for the weight fragments from
+                    // the loads it knows, so a transfer in front of a fragment's first use would be waited for with it.
+                    const int nrow4 = (T + 3) >> 2;
+#pragma unroll
+                    for (int u = 0; u < XPS; ++u) {
+                        const int i = wave_u + 8 * (s * XPS + u);
+                        if (i < nrow4) {
+                            int row = 4 * i + (lane >> 4);
+                            row = row < T ? row : T - 1;
+                            const int chunk = (lane & 15) ^ (row & 15);
+                            glds16_untracked(xb + (int64_t)row * a.C + next_group * WIDTH + chunk * 8, lds_addr(wbuf) + i * 1024);
+                        }
+                    }
+                }
+                mfma10_step<5>(&acc[0][NG], &acc[1][NG], cur[0][0], cur[0][1], bB);
+                lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp1);
+                mfma10_step<5>(&acc[0][0], &acc[1][0], cur[1][0], cur[1][1], bA);
+                if constexpr (decltype(LAST)::value) {
+                    mfma10_step<0>(&acc[0][NG], &acc[1][NG], cur[1][0], cur[1][1], bB);
+                } else {
+                    const unsigned np0 = b_addr(s + 1, 0);
+                    lds_read5<0, 16 * ROWB>(bA, np0);
+                    mfma10_step<5>(&acc[0][NG], &acc[1][NG], cur[1][0], cur[1][1], bB);
+                    lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, np0);
+                }
+                R2_TRACE(2);
+            };
+            r2_lds_barrier();  // publishes the activation buffer written by the previous epilogue (or the prologue); x_{j+1} of the
+                               // previous step has been read by everyone
+            {
+                const unsigned bp0 = b_addr(0, 0);
+                lds_read5<0, 16 * ROWB>(bA, bp0);
+                lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp0);
+            }
+            // nstages is a multiple of 3 here (launcher), so the rotation of the three fragment sets is static
+            for (int s = 0; s + 3 < nstages; s += 3) {
+                stage(s, wf[0], wf[2], std::false_type{});
+                stage(s + 1, wf[1], wf[0], std::false_type{});
+                stage(s + 2, wf[2], wf[1], std::false_type{});
+            }
+            stage(nstages - 3, wf[0], wf[2], std::false_type{});
+            stage(nstages - 2, wf[1], wf[0], std::false_type{});
+            stage(nstages - 1, wf[2], wf[1], std::true_type{});
+            mfma_hazard_pad();  // the assembly MFMAs are invisible to the compiler's hazard padding
+            // x_{j+1} has landed for this wave once at most the fragment loads of the last stage (younger than every transfer; none after
+            // the last step) are outstanding; the barrier below then publishes every wave's rows
+            // (at most 10 transfers per wave, XPS = 2 per stage: the last ones leave in stage 4 at the latest, and nstages >= 6, so the
+            // four fragment loads of the last stage are younger.  Requesting the next step's stage-2 fragments here, ahead of the epilogue's
+            // y stores, moved the late stage from 2 to 3 and made stage 0 and the epilogue longer: 115 us instead of 108, r05h.)
+            if (more) {
+                r2_wait_vm<4>();
+            } else {
+                r2_wait_vm<0>();
+            }
+        } else {
+            for (int s = 0; s + 1 < nstages; ++s) do_stage(s, std::false_type{});
+            do_stage(nstages - 1, std::true_type{});  // peeled: the x_{j+1} registers exist from here on only
+        }
         R2_TRACE(4);  // last stage's MFMAs issued
         r2_lds_barrier();  // every wave is done with the activation buffer and the weight ring
         R2_TRACE(5);
@@ -265,7 +402,14 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 __builtin_memcpy(&ov, o, 16);
                 const half8v hi8 = {(half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f,
                                     (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f};
-                const half8v nv = __builtin_elementwise_max(__builtin_elementwise_min(ov + xp[ni], hi8), -hi8);
+                half8v xnext;
+                if constexpr (!DIRECT) {
+                    xnext = xp[ni];
+                } else {
+                    const int tc = t < T ? t : T - 1;
+                    xnext = *reinterpret_cast<const half8v*>(wbuf + tc * ROWB + (((co8 >> 3) ^ (tc & 15)) << 4));
+                }
+                const half8v nv = __builtin_elementwise_max(__builtin_elementwise_min(ov + xnext, hi8), -hi8);
                 if (t < T) {
                     *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
                     if (more) {
@@ -328,8 +472,12 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 }
 #endif
 
-size_t res2_chain_lds_bytes(int T, int width) {
-    (void)T;
+static bool res2_direct(int T, int width, int k) {  // (k * 2 K stages per step: the rotation of three fragment sets wants a multiple of 3)
+    return R2_DIRECT && width == 128 && k % 3 == 0 && ((T + 3) & ~3) * width * 2 <= R2_XNEXT_BYTES;
+}
+
+size_t res2_chain_lds_bytes(int T, int width, int k) {
+    if (res2_direct(T, width, k)) return (size_t)R2_XNEXT_BYTES + (size_t)R2_ROWS * width * 2;  // 163 840 B: all of the CU's LDS
     return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)R2_ROWS * width * 2;
 }
 
@@ -358,8 +506,11 @@ int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const 
     a.k = k;
     a.dil = dil;
     a.kpad = conv1d_cin_pad(width);
-    const size_t lds = res2_chain_lds_bytes(T, width);
-    if (width == 128) {
+    const size_t lds = res2_chain_lds_bytes(T, width, k);
+    if (res2_direct(T, width, k)) {
+        if (MV_SET_MAX_SMEM((res2_chain_kernel<2, true>), lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
+        MV_LAUNCH((res2_chain_kernel<2, true>), ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+    } else if (width == 128) {
         if (MV_SET_MAX_SMEM(res2_chain_kernel<2>, lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
         MV_LAUNCH(res2_chain_kernel<2>, ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
     } else {
