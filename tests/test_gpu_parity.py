@@ -515,3 +515,32 @@ def test_gpu_fcm_conv3x3(idx, impl, monkeypatch):
                                  dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
 def test_gpu_res2net_fused_chain(cfg):
     lc.res2_chain_case(product_lib(), DEV, **cfg)
+
+
+@pytest.mark.parametrize('case', ['campp_short', 'ecapa_tiny', 'tdnn'])
+def test_gpu_model_forward_is_hipgraph_capturable(case):
+    """a model forward is a fixed launch sequence on the caller's stream over the caller's workspace (no allocation, no
+    synchronisation) -- so it can be captured in a hipGraph and replayed on new inputs (CAM++ issues ~110 launches per forward: at
+    batch 1 the eager path is bound by the host's launch rate).  Capture after one warm-up (lazy one-time setup), replay on two inputs."""
+    from mvector import models as pmodels
+    man, sd, x, _, _ = load_case(case)
+    model = getattr(pmodels, man['model'])(**man['kwargs'])
+    model.load_state_dict(sd)
+    model.eval().to(DEV)
+    xs = [x.to(DEV), (x * 0.5 + 0.1).to(DEV)]
+    with torch.no_grad():
+        eager = [model(v).clone() for v in xs]
+        static_in = xs[0].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(static_in)  # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = model(static_in)
+        for v, ref in zip(xs, eager):
+            static_in.copy_(v)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_out, ref), (static_out - ref).abs().max().item()
