@@ -544,3 +544,23 @@ def test_gpu_model_forward_is_hipgraph_capturable(case):
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(static_out, ref), (static_out - ref).abs().max().item()
+
+
+@pytest.mark.parametrize('case,T', [('ecapa_c1024', 305), ('ecapa_c1024', 321), ('ecapa_c1024', 998), ('ecapa_c512', 998), ('ecapa_c512', 9),
+                                    ('campp', 998), ('campp', 23), ('tdnn', 998), ('tdnn', 30)])
+def test_gpu_backbones_long_and_short_utterances(case, T):
+    """Frame counts outside the golden fixtures (1-10 s is the range BASELINE configs[4] names): T = 305 / 321 leave the Res2Net
+    chain's direct form / fused form (its limits are 304 / 320 frames), 998 frames = 10 s takes the multi-tile paths of the ASP
+    pooling and the CAM dense layers, the short ones are close to the reflect-padding minimum.  Reference = the oracle on the CPU."""
+    from mvector import models as pmodels
+    man, sd, x, _, _ = load_case(case)
+    g = torch.Generator().manual_seed(T)
+    feats = torch.randn(2, T, x.shape[2], generator=g) * x.std() + x.mean()
+    ref = omodels.FORWARDS[man['model']](sd, feats)
+    model = getattr(pmodels, man['model'])(**man['kwargs'])
+    model.load_state_dict(sd)
+    model.eval().to(DEV)
+    with torch.no_grad():
+        emb = model(feats.to(DEV)).cpu()
+    d = cos_dist(emb, ref).max().item()
+    assert d < 1e-4, d
