@@ -564,3 +564,41 @@ def test_gpu_backbones_long_and_short_utterances(case, T):
         emb = model(feats.to(DEV)).cpu()
     d = cos_dist(emb, ref).max().item()
     assert d < 1e-4, d
+
+
+def test_gpu_rccl_one_rank_group_runs_the_exchange_step():
+    """The multi-GPU exchange is one all_gather_into_tensor on the nccl (= RCCL) backend.  The GPU boxes of
+    this build have one device, so this runs the very call in a one-rank group: it proves that the RCCL stack of the image loads,
+    that the process-group bootstrap on 127.0.0.1 works and that the sharded step (embed -> all-gather -> cosine block) runs on
+    device buffers.  The N > 1 layout itself is covered by the world_size-2 gloo tests."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')\n"
+        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1)\n"
+        "from helpers import load_case, cos_dist\n"
+        "from oracle import frontend, models as omodels, scoring\n"
+        "from mvector import parallel\n"
+        "from mvector.data_utils.featurizer import AudioFeaturizer\n"
+        "from mvector.models import EcapaTdnn\n"
+        "man, sd, _, _, _ = load_case('ecapa_tiny')\n"
+        "m = EcapaTdnn(**man['kwargs']); m.load_state_dict(sd); m.eval().cuda()\n"
+        "FB = dict(sample_frequency=16000, num_mel_bins=80)\n"
+        "wav = frontend.synth_waveforms(6, 8000, seed=21)\n"
+        "lo, hi = parallel.shard_rows(6)\n"
+        "assert (lo, hi) == (0, 6)\n"
+        "with torch.no_grad():\n"
+        "    emb = m(AudioFeaturizer('Fbank', method_args=FB)(wav.cuda()))\n"
+        "    allemb = parallel.all_gather_embeddings(emb, always=True)\n"
+        "    scores = parallel.cosine_block(emb, allemb)\n"
+        "torch.cuda.synchronize()\n"
+        "assert allemb.data_ptr() != emb.data_ptr() and torch.equal(allemb, emb)\n"
+        "ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav, None, 'Fbank', FB))\n"
+        "assert cos_dist(allemb.cpu(), ref).max().item() < 1e-4\n"
+        "sim = scoring.cosine_similarity(ref.numpy(), ref.numpy())\n"
+        "assert abs(scores.cpu().numpy() - sim).max() < 1e-3\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl one-rank exchange ok')\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -19,9 +19,10 @@ def shard_rows(n_rows, rank=None, world=None):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_embeddings(emb_local, out=None):
-    """[B_local, D] per rank (equal B_local) -> [world * B_local, D] on every rank, rank-major order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def all_gather_embeddings(emb_local, out=None, always=False):
+    """[B_local, D] per rank (equal B_local) -> [world * B_local, D] on every rank, rank-major order.
+    ``always``: issue the collective even in a one-rank group (a 1-GPU box can then exercise the RCCL call itself)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always):
         return emb_local
     world = dist.get_world_size()
     if out is None:
