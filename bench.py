@@ -302,9 +302,9 @@ def main():
         mfma_peak = MFMA_F32_PEAK_TFLOPS if f32_family else MFMA_F16_PEAK_TFLOPS
         conv_kernel = ('conv2d_kernel / conv2d_1x1_kernel (fp32 implicit GEMM on v_mfma_f32_16x16x4_f32), all launches, '
                        'algorithmic (unpadded) channel counts') if f32_family else \
-            'conv1d (implicit GEMM on fp16 MFMA: conv1d_glds_persistent_kernel + conv1d_glds_kernel + conv1d_mfma_kernel), all launches'
+            'conv1d (implicit GEMM on fp16 MFMA: conv1d_ring_persistent_kernel + conv1d_glds_persistent_kernel + conv1d_glds_kernel + conv1d_mfma_kernel), all launches'
         roof_conv = {'kernel': conv_kernel, 'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
-                     'frac': round(conv_tflops / mfma_peak, 4), 'traffic': pmc_bytes('mv::conv1d_glds_persistent_kernel'),
+                     'frac': round(conv_tflops / mfma_peak, 4), 'traffic': pmc_bytes('mv::conv1d_ring_persistent_kernel') or pmc_bytes('mv::conv1d_glds_persistent_kernel'),
                      'launches': n_conv, 'avg_launch_us': round(ms_conv / max(n_conv, 1) * 1e3, 2),
                      'algorithmic_gflop_per_launch': round(flop_conv / max(n_conv, 1) / 1e9, 3),
                      'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3)}

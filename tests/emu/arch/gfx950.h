@@ -73,6 +73,8 @@ inline void row_swap_odd_even(unsigned& x, unsigned& y) {
     y = ny;
 }
 
+inline float lane_gather(float v, int byte_index) { return emu::shfl_from(v, (byte_index >> 2) & 63); }
+
 inline float fmed3(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 inline float max_raw(float v, float lo) { return fmaxf(v, lo); }
 inline float exp2_fast(float v) { return exp2f(v); }
@@ -106,6 +108,9 @@ inline void lds_barrier() { __syncthreads(); }
 inline void barrier_only() { __syncthreads(); }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc, 16);
+}
+inline void glds16_untracked_so(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
+    memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(sbase) + voff, 16);
 }
 inline void lds_read1(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr)); }
 template <int N>

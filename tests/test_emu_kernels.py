@@ -38,6 +38,18 @@ def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
 
 
+def test_emu_conv1d_double_buffer_persistent_kernel():
+    """MV_CONV_IMPL=double: the dense 1x1 layers on the double-buffer persistent kernel instead of the ring kernel (the switch is read
+    once per process, hence the subprocess; the default run above takes the ring kernel for cases 17 / 18)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = %r\n"
+            "import layer_checks as lc\nfrom emu_lib import emu_cdll\n"
+            "for idx in (12, 17, 22):\n    lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])\n") % (sys.path,)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_IMPL='double'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_emu_conv1d_rejects_bad_arguments():
     with pytest.raises(RuntimeError, match='reflect padding'):
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)

@@ -52,6 +52,16 @@ def test_gpu_conv1d(idx):
     lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])
 
 
+def test_gpu_conv1d_double_buffer_persistent_kernel():
+    """MV_CONV_IMPL=double (read once per process -> subprocess): the persistent 1x1 cases and the c=1024 golden on the double-buffer kernel"""
+    code = ("import sys; sys.path[:0] = %r\n"
+            "import layer_checks as lc\nfrom mvector import _hip\n"
+            "for idx in (12, 17, 22):\n    lc.conv1d_case(_hip.lib(), 'cuda', seed=idx, **lc.CONV_CASES[idx])\n"
+            "cd, rel = lc.model_case(_hip.lib(), 'cuda', 'ecapa_c1024')\nassert cd < 1e-4, cd\n") % (sys.path,)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_IMPL='double'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0)])
 def test_gpu_linear(shape):
     lc.linear_case(product_lib(), DEV, *shape)

@@ -73,6 +73,11 @@ __device__ __forceinline__ void row_swap_odd_even(unsigned& x, unsigned& y) {
     y = r[1];
 }
 
+// ds_bpermute_b32: every lane reads `v` of lane byte_index / 4 (the LDS crossbar moves the data; LDS memory is not touched)
+__device__ __forceinline__ float lane_gather(float v, int byte_index) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
+}
+
 // ---- arithmetic with a single-instruction spelling ---------------------------------------------------------------------------
 __device__ __forceinline__ float fmed3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 // max(v, lo) as exactly one v_max_f32: fmaxf / v_med3 against +inf are lowered to a canonicalising v_max v, v, v plus the
@@ -123,6 +128,11 @@ __device__ __forceinline__ void wait_vm() {
 // once a later s_waitcnt vmcnt (the caller's, or the compiler's for a younger tracked load) has retired the transfer.
 __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base_addr) : "memory", "m0");
+}
+// the same with the address as uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: a stream that advances by a
+// constant per stage costs one scalar add per stage instead of a 64-bit vector add per transfer
+__device__ __forceinline__ void glds16_untracked_so(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_base_addr) : "memory", "m0");
 }
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain transfers still in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

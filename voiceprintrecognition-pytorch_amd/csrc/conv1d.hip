@@ -591,11 +591,36 @@ constexpr int CVP_LDS_BYTES = CVP_PARAM_OFF + 3 * CVP_PARAM_SLOT;  // 140 288 B 
 // as one partial row per (64-row block, slot): slot 0 = steps of the utterance the block starts in, slot 1 = steps of the
 // next utterance when its first frame lies inside the block (T_out >= 64, so at most one boundary).  stats_finish_kernel
 // adds up the 5-6 partial rows of an utterance in a fixed order (no atomics: results are run-to-run identical).
-template <int STATS>
-__device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* smem, int n0, int co0, int pslot, int wc, int wn,
-                                                    int wave, int lane, float4v (&acc)[8][4]) {
-    (void)wave;
-    const char* par = smem + CVP_PARAM_OFF + pslot * CVP_PARAM_SLOT;
+// Where the epilogue's per-channel parameters (bias / BatchNorm scale / shift of the wave's 128 channels) come from: the lane asks
+// for the four channels  mi * 16 + 4 * (lane >> 4) ..+3  of channel tile mi (0..7).
+struct LdsParams {  // double-buffer kernel: a 3 KiB slot of LDS filled by LDS-DMA with the tile's first stage
+    const char* par;
+    int wc, q;
+    __device__ __forceinline__ float4v at(int array, int mi) const {
+        return *reinterpret_cast<const float4v*>(par + array * 1024 + (wc * 128 + mi * 16 + 4 * q) * 4);
+    }
+    __device__ __forceinline__ float4v bias4(int mi) const { return at(0, mi); }
+    __device__ __forceinline__ float4v scale4(int mi) const { return at(1, mi); }
+    __device__ __forceinline__ float4v shift4(int mi) const { return at(2, mi); }
+};
+struct LaneParams {  // ring kernel (no LDS left): lane L of the wave holds channel  half * 64 + L  of the wave's 128 in six registers;
+    float b[2], s[2], t[2];  // a lane fetches what it needs from the holder lanes through the LDS crossbar (ds_bpermute)
+    int qaddr;               // 16 * (lane >> 4): byte index of holder lane 4 * (lane >> 4)
+    __device__ __forceinline__ float4v get(const float (&h)[2], int mi) const {
+        const float src = h[mi >> 2];
+        float4v r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = lane_gather(src, qaddr + (mi & 3) * 64 + 4 * j);
+        return r;
+    }
+    __device__ __forceinline__ float4v bias4(int mi) const { return get(b, mi); }
+    __device__ __forceinline__ float4v scale4(int mi) const { return get(s, mi); }
+    __device__ __forceinline__ float4v shift4(int mi) const { return get(t, mi); }
+};
+
+template <int STATS, class P>
+__device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& par, int n0, int co0, int wc, int wn, int lane,
+                                                    float4v (&acc)[8][4]) {
     const int r = lane & 15, q = lane >> 4;
     half_t* y = reinterpret_cast<half_t*>(a.y);
     // host admits none / ReLU only: max(v, -inf) is the identity
@@ -614,9 +639,8 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
             float4v sc[4], sh[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int col = wc * 128 + (4 * h + u) * 16 + 4 * q;
-                sc[u] = *reinterpret_cast<const float4v*>(par + 1024 + col * 4);
-                sh[u] = *reinterpret_cast<const float4v*>(par + 2048 + col * 4);
+                sc[u] = par.scale4(4 * h + u);
+                sh[u] = par.shift4(4 * h + u);
             }
             auto finish = [&](const float4v& c, int u) {
                 // pre-activation as one v_max each, BatchNorm affine as two v_pk_fma_f32, post-activation + fp16 saturation
@@ -667,11 +691,12 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
     keep_sum[0] = keep_sum[1] = keep_sq[0] = keep_sq[1] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        float4v shift4[2];
+        float4v shift4[2], scale4[2];
         float4v s_sum[2][2], s_sq[2][2];  // [slot][tile of the pair]
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            shift4[u] = *reinterpret_cast<const float4v*>(par + 2048 + (wc * 128 + (2 * p + u) * 16 + 4 * q) * 4);
+            shift4[u] = par.shift4(2 * p + u);
+            scale4[u] = par.scale4(2 * p + u);
             s_sum[0][u] = s_sum[1][u] = s_sq[0][u] = s_sq[1][u] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
@@ -680,11 +705,10 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, char* sme
             half4v hv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int col = wc * 128 + (2 * p + u) * 16 + 4 * q;
                 float4v v = acc[2 * p + u][ni];  // bias included (accumulator init)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo_pre);
-                v = v * *reinterpret_cast<const float4v*>(par + 1024 + col * 4);  // u = y - shift
+                v = v * scale4[u];  // u = y - shift
                 if (STATS) {
                     float4v w = v;
                     if (a.post_act == MV_ACT_RELU) {  // the moments are those of the stored value
@@ -981,12 +1005,12 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
 #endif
         MV_TRACE(2);
         if (decltype(first)::value) {
-            if (pending) persistent_epilogue<STATS>(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+            if (pending) persistent_epilogue<STATS>(a, LdsParams{smem + CVP_PARAM_OFF + e_ps * CVP_PARAM_SLOT, wc, lane >> 4}, e_n0, e_co0, wc, wn, lane, acc);
             // accumulators start from the bias of their 4 channels (parameter slot of the tile being computed)
-            const char* par = smem + CVP_PARAM_OFF + l_ps * CVP_PARAM_SLOT;
+            const LdsParams par{smem + CVP_PARAM_OFF + l_ps * CVP_PARAM_SLOT, wc, lane >> 4};
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                const float4v b4 = *reinterpret_cast<const float4v*>(par + (wc * 128 + mi * 16 + 4 * (lane >> 4)) * 4);
+                const float4v b4 = par.bias4(mi);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
             }
@@ -1027,7 +1051,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         e_ps = c_ps;
         pending = true;
     }
-    persistent_epilogue<STATS>(a, smem, e_n0, e_co0, e_ps, wc, wn, wave, lane, acc);
+    persistent_epilogue<STATS>(a, LdsParams{smem + CVP_PARAM_OFF + e_ps * CVP_PARAM_SLOT, wc, lane >> 4}, e_n0, e_co0, wc, wn, lane, acc);
 #if defined(MV_PROBE) && MV_PROBE == 3
     MV_TRACE(0);
     if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
@@ -1062,20 +1086,229 @@ extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
 // timeline (MV_PROBE=3, tools/trace_conv.py) shows per K stage ~400 cycles barrier skew, ~1650 cycles MFMA issue per wave
 // (two waves share a SIMD's matrix pipe: 2048 busy cycles) and 1000-2000 cycles until the next stage has landed.
 //
-// Round 2, bytes in flight (profiles/r05a_gemm_load_depth_probe.log, r05b_conv_ring_vs_double.log): the K loop's transfers ALONE scale with
-// the bytes a CU has in flight -- 64 KiB: 82 us (K = 1024) / 1080 us (K = 3072), 96 KiB: 71 / 809 us, 128 KiB: 55 / 785 us (saturated at 22.9 /
-// 14.3 TB/s into LDS), while 32-wide stages (64-byte row segments) stay at 14 / 11 TB/s at any depth (the path counts requests: why the 4-slot
-// ring of round 1 gained nothing).  A kernel built on that -- weight halves of the stages one ahead in a ring of two 32 KiB slots, activation
-// halves two ahead in a ring of three (all 160 KiB of LDS, 96 KiB in flight, vmcnt(4) stage waits, epilogue parameters in six registers per
-// lane behind ds_bpermute) -- is correct and SLOWER: K = 1024 187 -> 200 us, K = 3072 1292 -> 1338 us, end to end 71.7 k -> 70.0 k utt/s
-// (tools/variants/conv1d_ring_persistent.hip.txt).  So the full kernel is not bound by the latency of its transfers either; what the transfers
-// and the MFMA stream share is the LDS itself: per stage and CU 64 KiB of LDS-DMA writes + 192 KiB of fragment reads for 2048 matrix-pipe cycles.
+// Round 2, bytes in flight: see conv1d_ring_persistent_kernel below (the dense 1x1 layers run there by default; this kernel keeps the taps,
+// strides, padding modes and the fused statistics).
 //
 // Measured dead ends (kept out of the build, logs under profiles/): a 256x128 tile with 2 x 32-wide stages (335 TF,
 // r01h), a 256x256 tile with a 4-slot ring of 32-wide stages and counted vmcnt (500 / 775 TF, r01i -- no better than the
 // double buffer), padded leading dimensions (r01k, no effect).  Probes with the K loop reduced to its loads or to its
 // LDS reads + MFMAs (MV_PROBE, r01j) show the 256x256 kernel is bound by the global->LDS path: loads alone take 83 % of
 // the full time (~8.4 TB/s of L2->LDS traffic chip-wide), LDS reads + MFMAs alone reach 1530 TF.
+
+// ---- persistent 256 x 256 kernel, asymmetric LDS ring (round 2) ---------------------------------------------------------------
+// The K loop's transfers ALONE scale with the bytes a CU has in flight on the global -> LDS path (tools/gemm_load_depth_probe.hip,
+// profiles/r05a): one 64 KiB stage in flight 82 us on a K = 1024 layer / 1080 us on the K = 3072 layer (15.2 / 10.4 TB/s into LDS), 96 KiB
+// 71 / 809 us, 128 KiB 55 / 785 us (saturated); 32-wide stages (64-byte rows) stay at 14 / 11 TB/s however many are in flight -- the path
+// counts requests, so halving the row segment halves the rate (why the 4-slot ring of 32-wide stages of round 1 gained nothing).
+// A third 64 KiB stage does not fit the 160 KiB of LDS, a third HALF stage does: the weight half of a stage (L2 / MALL resident, short
+// latency) is requested one stage ahead into a ring of two 32 KiB slots, the activation half (HBM on first touch) two stages ahead into a
+// ring of three -- 5 x 32 KiB = all of the CU's LDS, 96 KiB in flight during every stage.  The vector-memory counter retires in order, so
+// a stage requests its weight transfers BEFORE its activation transfers and the wait in front of the next stage is vmcnt(4): everything
+// has landed except the four youngest transfers of the wave, the activation rows of stage s + 2.  All transfers are issued from inline
+// assembly and every wait is counted by hand ("the compiler's wait counts").  With no LDS left, bias / scale / shift live in
+// six registers per lane (LaneParams) and reach the lanes that need them through the LDS crossbar; a workgroup's channel tile changes at
+// most once per launch in the XCD-aware walk (the walk stride is a multiple of the group width), so the holder registers are reloaded --
+// with a full drain -- only then.
+// History (profiles/r05b, r05l-r05o): the first form kept the generic loader (row maps, 64-bit pointers per transfer, taps) and was 3-7 %
+// SLOWER than the double buffer although its transfers were never waited for: the in-kernel timeline showed ~800 cycles of loader
+// bookkeeping per stage in front of the barrier (moved under the MFMAs it simply made that phase 450 cycles longer: a block of vector
+// arithmetic between two MFMA steps does not overlap with them).  The form below is restricted to what the backbone's layers are --
+// 1x1 convolutions over a dense row range -- where a transfer's address is (uniform tensor base + 128 bytes per stage) + a per-lane
+// 32-bit row offset that is constant for the tile: the loader has no vector arithmetic inside a tile.  K = 3072: 1290 -> 1255 us in the
+// micro-benchmark, K = 1024 unchanged (its tiles are dominated by the tile boundary); in the model, where the activations are cold,
+// 3.66 -> 3.56 ms per step (conv class 968 -> 1008 TFLOP/s, r05o).
+constexpr int CVR_SLOT_BYTES = 32768;
+constexpr int CVR_X_OFF = 2 * CVR_SLOT_BYTES;
+constexpr int CVR_LDS_BYTES = 5 * CVR_SLOT_BYTES;  // 163 840 B
+
+// 1x1 convolutions over a dense row range (k = 1, stride 1, no padding, T_in == T_out, cin % 64 == 0: every TDNNBlock of the backbone
+// but the first): input row = output row, so a transfer's address is  tensor + row offset (per lane, 32 bits, fixed for the tile) +
+// 128 bytes per stage (scalar) -- the loader has no vector arithmetic inside a tile at all.
+__global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a) {
+    constexpr int MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
+    MV_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+#if defined(MV_PROBE) && MV_PROBE == 3
+    int trace_i = 0;
+#endif
+    const int lane = tid & 63;
+    const int wave = MV_UNIFORM(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
+    const int wc = wave / 4, wn = wave % 4;
+    const int lrow = lane >> 3;
+    const int kc = (lane & 7) ^ (lrow & 7);
+    const int total = ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;  // virtual workgroup ids of tile_of_index
+    const int step = (int)gridDim.x;
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* wb = reinterpret_cast<const char*>(a.w);
+    const unsigned xrow_bytes = (unsigned)a.ldx * 2u, wrow_bytes = (unsigned)a.cin_pad * 2u;
+    const int nstages = a.cin_pad / CV_BK;
+    const unsigned smem_base = lds_addr(smem);
+
+    // three walks over the same tile list: the tile being computed, the weight stream (one stage ahead), the activation stream (two)
+    auto first_tile = [&](int vb, int& n_tile, int& co_tile) {  // first valid tile at or after vb; returns total when the walk is over
+        while (vb < total && !tile_of_index(a, vb, n_tile, co_tile)) vb += step;
+        return vb < total ? vb : total;
+    };
+    // -- weight stream
+    unsigned woff[NTW];
+    int w_vb = 0, w_stage = 0, w_slot = 0;
+    bool w_more = false;
+    auto w_open = [&](int vb) {
+        int n_tile = 0, co_tile = 0;
+        w_vb = first_tile(vb, n_tile, co_tile);
+        w_more = w_vb < total;
+        w_stage = 0;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)  // cout % 256 == 0: always inside the packed weights
+            woff[i] = (unsigned)(co_tile * TC + (wave * NTW + i) * 8 + lrow) * wrow_bytes + (unsigned)kc * 16u;
+    };
+    auto dma_w = [&](int i) { glds16_untracked_so(wb + w_stage * (CV_BK * 2), woff[i], smem_base + w_slot * CVR_SLOT_BYTES + (wave * NTW + i) * 1024); };
+    auto w_advance = [&]() {
+        w_slot ^= 1;
+        if (++w_stage == nstages) w_open(w_vb + step);
+    };
+    // -- activation stream (rows beyond the tensor re-read its last row: their results are never stored)
+    unsigned xoff[NTX];
+    int x_vb = 0, x_stage = 0, x_slot = 0;
+    bool x_more = false;
+    auto x_open = [&](int vb) {
+        int n_tile = 0, co_tile = 0;
+        x_vb = first_tile(vb, n_tile, co_tile);
+        x_more = x_vb < total;
+        x_stage = 0;
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) {
+            int n = n_tile * TN + (wave * NTX + i) * 8 + lrow;
+            n = n < a.n_rows ? n : a.n_rows - 1;
+            xoff[i] = (unsigned)n * xrow_bytes + (unsigned)kc * 16u;
+        }
+    };
+    auto dma_x = [&](int i) {
+        glds16_untracked_so(xb + x_stage * (CV_BK * 2), xoff[i], smem_base + CVR_X_OFF + x_slot * CVR_SLOT_BYTES + (wave * NTX + i) * 1024);
+    };
+    auto x_advance = [&]() {
+        x_slot = x_slot == 2 ? 0 : x_slot + 1;
+        if (++x_stage == nstages) x_open(x_vb + step);
+    };
+
+    // -- compute walk
+    int c_vb = 0, c_n0 = 0, c_co0 = 0;
+    {
+        int n_tile = 0, co_tile = 0;
+        c_vb = first_tile(blockIdx.x, n_tile, co_tile);
+        if (c_vb >= total) return;  // whole workgroup leaves before any barrier
+        c_n0 = n_tile * TN;
+        c_co0 = co_tile * TC;
+    }
+    // epilogue parameters of the wave's 128 channels
+    LaneParams hp;
+    hp.qaddr = 16 * (lane >> 4);
+    int held_co0 = -1;
+    auto load_params = [&](int co0) {  // plain loads + an immediate use: the compiler's wait for them (a full drain) sits right here
+        const int c = co0 + wc * 128 + lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            hp.b[h] = a.bias != nullptr ? a.bias[c + 64 * h] : 0.0f;
+            hp.s[h] = a.scale != nullptr ? a.scale[c + 64 * h] : 1.0f;
+            hp.t[h] = a.shift != nullptr ? a.shift[c + 64 * h] : 0.0f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            MV_OPAQUE(hp.b[h]);
+            MV_OPAQUE(hp.s[h]);
+            MV_OPAQUE(hp.t[h]);
+        }
+        held_co0 = co0;
+    };
+    load_params(c_co0);
+
+    // prologue: weights of stage 0, activations of stage 0, activations of stage 1 -- in this order (in-order retirement)
+    w_open(c_vb);
+    x_open(c_vb);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) dma_w(i);
+    w_advance();
+#pragma unroll
+    for (int i = 0; i < NTX; ++i) dma_x(i);
+    x_advance();
+    bool x_ahead = x_more;  // the wave's four youngest transfers belong to a LATER stage than the one about to be computed
+    if (x_more) {
+#pragma unroll
+        for (int i = 0; i < NTX; ++i) dma_x(i);
+        x_advance();
+    }
+
+    float4v acc[MI][NI];
+    bool pending = false;
+    int e_n0 = 0, e_co0 = 0;
+    int cw_slot = 0, cx_slot = 0;  // slots of the stage being computed
+    // One K stage: counted wait, barrier, [first stage of a tile: epilogue of the previous tile, accumulator init], 64 MFMAs with the
+    // weight transfers of stage s + 1 under steps 0-1, the activation transfers of stage s + 2 under steps 2-3 and the streams' advance
+    // (at the end of a tile: the next tile's offsets) under steps 4-5.
+    auto stage = [&](auto first) {
+        const bool do_w = w_more, do_x = x_more;
+        if (x_ahead) {
+            wait_vm<NTX>();
+        } else {
+            wait_vm<0>();
+        }
+        MV_TRACE(0);
+        lds_barrier();  // this stage has landed for every wave; every wave is done with the slots requested below
+        MV_TRACE(1);
+        if (decltype(first)::value) {
+            if (pending) persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+            if (c_co0 != held_co0) load_params(c_co0);  // uniform, at most once per launch on the shipped shapes
+            // accumulators start from the bias of their 4 channels
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float4v b4 = hp.bias4(mi);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
+            }
+        }
+        MV_TRACE(2);
+        const unsigned wt = smem_base + cw_slot * CVR_SLOT_BYTES, xt = smem_base + CVR_X_OFF + cx_slot * CVR_SLOT_BYTES;
+        mma_stage_8x4(wt, xt, wc, wn, lane, acc, [&](int i) {
+            if (i < 2) {
+                if (do_w) {
+                    dma_w(2 * i);
+                    dma_w(2 * i + 1);
+                }
+            } else if (i < 4) {
+                if (do_x) {
+                    dma_x(2 * (i - 2));
+                    dma_x(2 * (i - 2) + 1);
+                }
+            } else if (i == 4) {
+                if (do_w) w_advance();
+            } else if (i == 5) {
+                if (do_x) x_advance();
+            }
+        });
+        MV_TRACE(3);
+        x_ahead = do_x;
+        cw_slot ^= 1;
+        cx_slot = cx_slot == 2 ? 0 : cx_slot + 1;
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    while (c_vb < total) {
+        stage(yes{});
+        for (int s = 1; s < nstages; ++s) stage(no{});
+        e_n0 = c_n0;
+        e_co0 = c_co0;
+        pending = true;
+        int n_tile = 0, co_tile = 0;
+        c_vb = first_tile(c_vb + step, n_tile, co_tile);
+        c_n0 = n_tile * TN;
+        c_co0 = co_tile * TC;
+    }
+    persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+#if defined(MV_PROBE) && MV_PROBE == 3
+    MV_TRACE(0);
+    if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
+#endif
+}
 
 // ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
 template <typename InT>
@@ -1253,6 +1486,16 @@ static int persistent_blocks() {
     return n;
 }
 
+// MV_CONV_IMPL = ring (default) | double: which persistent kernel takes the dense 1x1 layers (A/B switch; both are covered by tests)
+static bool conv_use_ring() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MV_CONV_IMPL");
+        v = (e != nullptr && e[0] == 'd') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k) {
     // Measured (r02a): the DPP row sums put ~6 us per tile into the epilogue, on the critical path of every CU at once --
     // 3 x 32 us on the tdnn2 layers and ~150 us on mfa, as much as the separate time_stats passes they replace (3 x 30 +
@@ -1400,6 +1643,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 1>), CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 2>), CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<false, 0>), CVP_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM(conv1d_ring_persistent_kernel, CVR_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<float, false, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
@@ -1411,7 +1655,12 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
         const bool simple = d.k == 1 && d.cin % CV_BK == 0;
-        if (stats == 2) {
+        // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
+        const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
+                                (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
+        if (conv_use_ring() && stats == 0 && dense_rows) {
+            MV_LAUNCH(conv1d_ring_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVR_LDS_BYTES, stream, a);
+        } else if (stats == 2) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
         } else if (stats == 1) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 1>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
