@@ -1310,6 +1310,12 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
 #endif
 }
 
+// Measured on top of the ring kernel (r05p, parked in tools/variants/conv1d_pingpong_persistent.hip.txt): ping-pong between the two waves of
+// a SIMD -- the workgroup's halves half a K stage out of phase, a stage as four barrier-separated segments in which one half requests the
+// twelve fragments of a K half while the other issues that half's 32 MFMAs from registers with the pipe to itself.  Correct (emulator + GPU
+// tests) and 12 % SLOWER (K = 3072: 1252 -> 1400-1420 us, K = 1024: 190 -> 220 us): a segment is ~512 matrix-pipe cycles + ~280 of barrier
+// and restart, and there are four of them per stage instead of one.
+
 // ---- general path: fp32 or transformed input (second input added, BatchNorm+ReLU on load) through registers -------
 template <typename InT>
 struct RawChunk;
@@ -1487,13 +1493,14 @@ static int persistent_blocks() {
 }
 
 // MV_CONV_IMPL = ring (default) | double: which persistent kernel takes the dense 1x1 layers (A/B switch; both are covered by tests)
-static bool conv_use_ring() {
+// MV_CONV_IMPL = ring (default) | double: which persistent kernel takes the dense 1x1 layers (A/B switch; both are covered by tests)
+static int conv_persist_impl() {  // 0 double buffer, 1 ring
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MV_CONV_IMPL");
-        v = (e != nullptr && e[0] == 'd') ? 0 : 1;
+        v = e == nullptr ? 1 : (e[0] == 'd' ? 0 : 1);
     }
-    return v != 0;
+    return v;
 }
 
 bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k) {
@@ -1658,7 +1665,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
         const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
                                 (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
-        if (conv_use_ring() && stats == 0 && dense_rows) {
+        if (conv_persist_impl() == 1 && stats == 0 && dense_rows) {
             MV_LAUNCH(conv1d_ring_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVR_LDS_BYTES, stream, a);
         } else if (stats == 2) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
