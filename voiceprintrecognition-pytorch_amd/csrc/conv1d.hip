@@ -1310,6 +1310,11 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
 #endif
 }
 
+// Also measured on the ring kernel (r05r): the first stage of a tile requesting its transfers BEFORE the epilogue's stores, with the next
+// stage's wait counted past the 16 store instructions (vmcnt(20)), so that the boundary's store burst drains under two stages instead of in
+// front of stage 1: neutral (K = 1024 190.7-193.8 us vs 191-192), as the same idea had been on the double-buffer kernel -- the ~8 k cycles of
+// a tile boundary are the chip absorbing 32 MiB of output at once, not an ordering artefact of the counter.
+//
 // Measured on top of the ring kernel (r05p, parked in tools/variants/conv1d_pingpong_persistent.hip.txt): ping-pong between the two waves of
 // a SIMD -- the workgroup's halves half a K stage out of phase, a stage as four barrier-separated segments in which one half requests the
 // twelve fragments of a K half while the other issues that half's 32 MFMAs from registers with the pipe to itself.  Correct (emulator + GPU
