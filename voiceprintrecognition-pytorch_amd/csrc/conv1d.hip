@@ -1469,7 +1469,9 @@ int conv1d_cout_pad(int cout) { return (int)round_up(cout, 32); }
 // epilogues together, so a layer's output leaves as bursts of 32 MiB (in isolation the stores cost 27 us of a 187 us K = 1024
 // layer, 83 us of the 1270 us K = 3072 layer: probe 4).  With the streaming bits a K = 1024 layer alone runs 187 -> 173 us
 // (K = 3072: 1280 -> 1310 us), but the layers that consume the output then miss in L2 / MALL: end to end 68.2 k -> 65.7 k
-// utterances/s (r02d, same box).  MV_CONV_STORE_NT = 0 / 1 / 2: never (default) / K <= 1536 / always.
+// utterances/s (r02d, same box).  MV_CONV_STORE_NT = 0 / 1 / 2: never (default) / K <= 1536 / always.  Repeated per role with the ring kernel
+// (r05s, one call, alternating): default 76.1 / 75.9 k utt/s, streaming stores on the tdnn2 outputs only (read by the streaming time_stats /
+// se_gate passes) 74.5 / 74.7 k, on the tdnn1 outputs only (read by the Res2Net chain) 75.4 / 75.1 k, on all K = 1024 layers 74.3 / 74.0 k.
 static int conv_store_policy(int64_t k_total) {
     static int mode = -1;
     if (mode < 0) {
