@@ -388,10 +388,23 @@ def main():
                         e2.cpu()  # D2H of the embeddings, as predict_batch returns numpy
                     torch.cuda.synchronize()
                     res[tag] = B * k / (time.perf_counter() - th)
+                # the same int16 batches through mvector.parallel.embed_stream: uploads / downloads on a copy stream behind the compute
+                from mvector import parallel
+                n_pipe = k + 2
+                it_pipe = parallel.embed_stream(featurizer, model, (host_i16 for _ in range(n_pipe)), device=dev)
+                for it in range(n_pipe):
+                    if it == 2:
+                        torch.cuda.synchronize()
+                        th = time.perf_counter()
+                    next(it_pipe)
+                torch.cuda.synchronize()
+                res['pipelined'] = B * k / (time.perf_counter() - th)
             out['h2d_inclusive'] = {'value_fp32_upload': round(res['fp32'], 1), 'value_int16_upload': round(res['int16'], 1),
+                                    'value_int16_pipelined': round(res['pipelined'], 1),
                                     'unit': 'utterances/s', 'steps': k,
                                     'note': 'waveforms uploaded from pinned host memory and embeddings copied back inside the timed '
-                                    'region; int16 = 16-bit PCM converted on the device (predict_batch path); never the headline value'}
+                                    'region; int16 = 16-bit PCM converted on the device (predict_batch path); pipelined = '
+                                    'mvector.parallel.embed_stream (copy stream, no cosine block); never the headline value'}
             if args.model == 'ecapa1024' and not args.no_other_configs:
                 others = {}
                 for key, fn in (('config3_campp', lambda: short_run('campp', dev, B, 10, 3, 8)),

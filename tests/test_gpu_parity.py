@@ -628,3 +628,32 @@ def test_gpu_rccl_one_rank_group_runs_the_exchange_step():
     ) % (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_gpu_embed_stream_pipeline_matches_batch_by_batch():
+    """parallel.embed_stream: uploads on a copy stream, int16 PCM converted on the device, downloads behind the next batch's compute;
+    seven batches (two shapes, a ragged last one) must come back in order and equal to the sequential path, with and without the
+    reference's dB normalisation."""
+    from mvector import _hip, parallel
+    from mvector.models import EcapaTdnn
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    man, sd, _, _, _ = load_case('ecapa_tiny')
+    m = EcapaTdnn(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+    wav = frontend.synth_waveforms(50, 12000, seed=5) * torch.linspace(0.2, 1.0, 50)[:, None]
+    pcm = (wav * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    batches = [pcm[0:8].pin_memory(), pcm[8:16].pin_memory(), pcm[16:24, :9000].contiguous().pin_memory(), pcm[24:32].pin_memory(),
+               pcm[32:40, :9000].contiguous().pin_memory(), pcm[40:48].pin_memory(), pcm[48:50].pin_memory()]
+    for target_db in (None, -20.0):
+        got = [o.clone() for o in parallel.embed_stream(fz, m, batches, device=DEV, target_db=target_db)]
+        with torch.no_grad():
+            for o, b in zip(got, batches):
+                w, _ = _hip.wave_prepare(b.to(DEV), target_db=target_db)
+                assert torch.equal(o, m(fz(w)).cpu())
+    fl = [b.float().div(32768.0).pin_memory() for b in batches[:3]]  # float32 waveforms take the same pipeline
+    got = [o.clone() for o in parallel.embed_stream(fz, m, fl, device=DEV)]
+    with torch.no_grad():
+        for o, b in zip(got, fl):
+            assert torch.equal(o, m(fz(b.to(DEV))).cpu())

@@ -350,3 +350,23 @@ def test_device_gallery_sums_grow_and_remove_on_cpu_tensors():
     assert np.allclose(dg.matrix()[2].numpy(), np.sum(rows['u3'], axis=0), atol=1e-6)
     dg.add('u2', rows['u2'][0])  # numpy row: one upload, new last row
     assert dg.users[-1] == 'u2' and dg.uploads == 0  # same device: nothing to move
+
+
+def test_embed_stream_cpu_is_the_plain_loop():
+    """parallel.embed_stream on CPU tensors: batch by batch, int16 PCM scaled like the device path, ragged last batch."""
+    from mvector import parallel
+    from mvector.models import EcapaTdnn
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    man, sd, _, _, _ = load_case('ecapa_tiny')
+    m = EcapaTdnn(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval()
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+    wav = frontend.synth_waveforms(7, 8000, seed=3)
+    pcm = (wav * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    batches = [pcm[:3], pcm[3:6], pcm[6:]]
+    outs = list(parallel.embed_stream(fz, m, batches, device='cpu'))
+    assert [o.shape[0] for o in outs] == [3, 3, 1]
+    with torch.no_grad():
+        for o, b in zip(outs, batches):
+            assert torch.equal(o, m(fz(b.float() / 32768.0)))

@@ -110,3 +110,91 @@ def embed_bucketed(featurizer, model, waveforms, max_buckets=8, device=None):
             if rhi > rlo:
                 out[torch.tensor(idx[rlo:rhi], device=device)] = gathered[r * per:r * per + (rhi - rlo)]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Host <-> device pipeline for a stream of batches (pinned-memory upload of 16-bit PCM, conversion and dB
+# normalisation on the device, asynchronous download of the embeddings).  One batch takes 0.5 ms to upload as int16 (24.6 MB for
+# 256 x 3 s) against ~3.5 ms of compute: run back to back on one stream -- what a loop over predict_batch does -- the upload, the
+# download and the host synchronisation cost 15-20 % (bench.py h2d_inclusive); on a copy stream they disappear behind the compute.
+
+@torch.no_grad()
+def embed_stream(featurizer, model, batches, device=None, target_db=None, depth=2):
+    """Generator: embeddings (CPU tensors ``[B_i, D]`` in pinned memory; a result stays valid until the next-but-one result
+    has been requested -- copy it to keep it) of an iterable of waveform batches, in order.
+
+    ``batches`` yields CPU tensors ``[B_i, L_i]``: int16 PCM (converted to float32 / 32768 on the device, with the
+    reference's dB normalisation when ``target_db`` is given, mvector/predict.py:185-212) or float32 waveforms, ideally in
+    pinned memory.  On a CUDA device the upload of batch i+1 and the download of batch i-1 run on a copy stream while batch i
+    computes on the caller's stream (``depth`` device / host buffers per shape); on the CPU it is the plain loop.
+    Results are identical to calling the featurizer and the model batch by batch."""
+    if device is None:
+        device = next(model.parameters()).device
+    device = torch.device(device)
+
+    def compute(dev_batch):
+        if dev_batch.dtype == torch.int16:
+            from mvector import _hip
+            dev_batch, _ = _hip.wave_prepare(dev_batch, target_db=target_db)
+        return model(featurizer(dev_batch))
+
+    if device.type != 'cuda':
+        for host in batches:
+            w = host.to(torch.float32) / 32768.0 if host.dtype == torch.int16 else host
+            yield model(featurizer(w))
+        return
+
+    import collections
+    main = torch.cuda.current_stream(device)
+    copy = torch.cuda.Stream(device)
+    in_bufs, out_bufs = {}, {}       # (shape, dtype) -> ring of device input buffers; (rows, dim) -> ring of pinned result buffers
+    in_free = {}                     # id(device buffer) -> event: the compute that read it has finished
+    out_free = {}                    # id(pinned buffer) -> event: its download has finished (waited for when the ring wraps)
+    inflight = collections.deque()   # (pinned result, download event), oldest first
+    counter = {}
+
+    def ring(store, key, make, size):
+        bufs = store.setdefault(key, [])
+        n = counter.get((id(store), key), 0)
+        counter[(id(store), key)] = n + 1
+        if len(bufs) < size:
+            bufs.append(make())
+            return bufs[-1]
+        return bufs[n % size]
+
+    for host in batches:
+        key = (tuple(host.shape), host.dtype)
+        dev_in = ring(in_bufs, key, lambda: torch.empty(host.shape, dtype=host.dtype, device=device), depth)
+        with torch.cuda.stream(copy):
+            ev = in_free.get(id(dev_in))
+            if ev is not None:
+                copy.wait_event(ev)          # the batch that used this buffer `depth` uploads ago has been consumed
+            dev_in.copy_(host, non_blocking=True)
+            up = torch.cuda.Event()
+            up.record(copy)
+        main.wait_event(up)
+        emb = compute(dev_in)
+        done = torch.cuda.Event()
+        done.record(main)
+        in_free[id(dev_in)] = done
+        okey = tuple(emb.shape)
+        host_out = ring(out_bufs, okey, lambda: torch.empty(emb.shape, dtype=emb.dtype).pin_memory(), depth + 1)
+        prev = out_free.get(id(host_out))
+        if prev is not None:
+            prev.synchronize()               # (its result was handed out long ago)
+        with torch.cuda.stream(copy):
+            copy.wait_event(done)
+            host_out.copy_(emb, non_blocking=True)
+            down = torch.cuda.Event()
+            down.record(copy)
+        emb.record_stream(copy)              # the allocator must not hand `emb` out again before the download has read it
+        out_free[id(host_out)] = down
+        inflight.append((host_out, down))
+        while len(inflight) >= depth:        # keep `depth - 1` batches in flight behind the one being submitted
+            res, ev = inflight.popleft()
+            ev.synchronize()
+            yield res
+    while inflight:
+        res, ev = inflight.popleft()
+        ev.synchronize()
+        yield res
