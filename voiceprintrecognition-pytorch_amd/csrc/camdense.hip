@@ -24,7 +24,10 @@
 // for the 2-stage layers, 36 us for the 16-stage ones = ~14 us of fixed cost -- launch, parameter and first-stage latency, the
 // serial context phase, store drain -- plus ~1.35 us per stage, which is what the in-place transform (~120 VALU per wave) and 20
 // MFMAs cost two waves per SIMD.  The stream is no longer the limit; chaining the layers of a block in one launch is what
-// would remove the fixed part.)  Default cache policy on these loads: the block's buffer --
+// would remove the fixed part.  Measured, r05t: the layers of a block in ONE launch -- layer loop inside the kernel, s_waitcnt vmcnt(0) +
+// barrier between layers, arguments as an array in the kernel argument segment -- is correct and 3 % SLOWER end to end (101.3 k -> 98.4 k
+// utt/s): between two launches the store drain of one workgroup overlaps with the start of the next kernel's workgroup on the same CU,
+// inside one workgroup it is a wait.)  Default cache policy on these loads: the block's buffer --
 // 78 MB for 256 utterances -- is re-read by every later layer and lives in the 256 MB Infinity Cache; non-temporal loads measured
 // 1.5-2.6 TB/s, r03i.
 #include <type_traits>
