@@ -657,3 +657,24 @@ def test_gpu_embed_stream_pipeline_matches_batch_by_batch():
     with torch.no_grad():
         for o, b in zip(got, fl):
             assert torch.equal(o, m(fz(b.to(DEV))).cpu())
+
+
+@pytest.mark.parametrize('name', ['ecapa1024', 'campp'])
+def test_gpu_repeated_full_batches_are_bit_identical(name):
+    """Race detector for the hand-synchronised kernels (counted s_waitcnt rings, the barrier-free K loop of the Res2Net chain, cross-wave
+    LDS hand-overs): the path has no atomics, so the same 256-utterance batch must give bit-identical features and embeddings on every run,
+    also with a different batch going through the same workspace in between (tools/stress_determinism.py runs the long version)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    featurizer, model, _ = bench.build(name, torch.device(DEV))
+    g = torch.Generator().manual_seed(99)
+    wav = (0.1 * torch.randn([256, bench.SAMPLES], generator=g)).clamp(-1, 1).to(DEV)
+    wav2 = wav.flip(0).contiguous() * 0.5
+    with torch.no_grad():
+        f0 = featurizer(wav).clone()
+        e0 = model(f0).clone()
+        for _ in range(12):
+            model(featurizer(wav2))
+            f = featurizer(wav)
+            assert torch.equal(f, f0)
+            assert torch.equal(model(f), e0)
