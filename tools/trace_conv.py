@@ -28,6 +28,13 @@ st = _hip.current_stream(x)
 for _ in range(3):
     _hip.check(lib.mv_conv1d_forward(ctypes.byref(d), st), lib)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    lib.mv_conv1d_forward(ctypes.byref(d), st)
+e1.record()
+torch.cuda.synchronize()
+wall_us = e0.elapsed_time(e1) / 5 * 1e3
 buf = (ctypes.c_ulonglong * 8192)()
 raw.mv_debug_trace_read.restype = ctypes.c_int
 n = raw.mv_debug_trace_read(buf, 8192)
@@ -49,3 +56,4 @@ for i, r in enumerate(rows[: 3 * nst + 2]):
           f'epi+mma+{(r.get(3, 0) - r.get(2, 0))}  | stage start since prev stage end: {None if prev3 is None else r.get(0) - prev3}')
 tot = rows[-1].get(0, 0)
 print('kernel span (cycles):', tot, ' tiles:', (len(rows) - 1) / nst)
+print(f'launch duration (HIP events, probe build): {wall_us:.1f} us -> {tot / wall_us / 1e3:.3f} GHz of s_memtime ticks if the traced workgroup spans the launch')
