@@ -678,3 +678,23 @@ def test_gpu_repeated_full_batches_are_bit_identical(name):
             f = featurizer(wav)
             assert torch.equal(f, f0)
             assert torch.equal(model(f), e0)
+
+
+@pytest.mark.parametrize('B', [250, 300])
+def test_gpu_ecapa1024_batches_with_ragged_last_tiles(B):
+    """B * 298 rows is not a multiple of the 256-row GEMM tile for these batch sizes (and 300 utterances make more tiles than resident
+    workgroups can take in equal shares): the persistent kernels' clamped tail rows and uneven walks inside the real model, checked on the
+    first, a middle and the last utterance against the oracle."""
+    from mvector.models import EcapaTdnn
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    man, sd, _, _, _ = load_case('ecapa_c1024')
+    m = EcapaTdnn(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    wav = frontend.synth_waveforms(B, 48000, seed=B)
+    with torch.no_grad():
+        emb = m(AudioFeaturizer('Fbank', method_args=FB)(wav.to(DEV))).cpu()
+    rows = [0, B // 2, B - 1]
+    ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[rows], None, 'Fbank', FB))
+    d = cos_dist(emb[rows], ref).max().item()
+    assert d < 1e-4, d
