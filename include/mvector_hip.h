@@ -359,6 +359,15 @@ int mv_fcm_conv3x3_f16(const void* x, int32_t Fin, int32_t sf, const void* x2, i
                        const float* bias, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, int32_t Fout,
                        mv_stream_t stream);
 
+/* One BasicResBlock of the CAM++ front-end (mvector/models/campplus.py:221-254) as ONE launch:
+ *   mid = ReLU(BN1(conv3x3, stride (sf, 1))(x)),  y = ReLU(BN2(conv3x3)(mid) + shortcut(x));  the intermediate map stays on the chip.
+ *   x fp16 [B, Fin, T, 32];  Fout = (Fin - 1) / sf + 1;  y element (b, fo, t, co) at y + b * y_sB + fo * y_sF + t * y_sT + co;
+ *   w1 fp16 [9][32 co][32 ci] (tap = 3 * df + dt, BN1 folded), b1 fp32 [32];  w2 fp16 [9 | 10][32][32] (BN2 folded), b2 fp32 [32];
+ *   shortcut != 0: tap 9 of w2 is the block's strided 1x1 shortcut conv with its BatchNorm folded (its shift is part of b2);
+ *   shortcut == 0: identity residual (sf must be 1). */
+int mv_fcm_block_f16(const void* x, int32_t Fin, int32_t sf, const void* w1, const float* b1, const void* w2, const float* b2,
+                     int32_t shortcut, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

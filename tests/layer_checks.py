@@ -449,6 +449,55 @@ def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, 
     return err
 
 
+FCM_BLOCK_CASES = [
+    dict(B=2, Fin=12, T=45, sf=2),                         # strided block with the 1x1 shortcut tap, NT = 1 (B * tiles < CUs: bands)
+    dict(B=2, Fin=6, T=33, sf=1),                          # identity block
+    dict(B=1, Fin=9, T=70, sf=2),                          # odd Fin, NT = 2
+    dict(B=1, Fin=5, T=330, sf=1),                         # two time tiles (T > 318): halo columns across the tile edge
+    dict(B=1, Fin=3, T=16, sf=1),                          # fewer rows than the ring
+    dict(B=9, Fin=4, T=62, sf=2, strided_out=True),        # one band per workgroup, T = tile width, [B, T, F, 32] output layout
+    dict(B=1, Fin=1, T=5, sf=1),                           # a single row
+]
+
+
+def fcm_block_case(cdll, device, B, Fin, T, sf, strided_out=False, seed=0):
+    """BasicResBlock (campplus.py:221-254) in one launch: ReLU(BN2(conv3x3(ReLU(BN1(conv3x3_s(x))))) + shortcut(x)) on fp16 maps,
+    BatchNorms folded.  Reference in fp64 from the fp16 operands with the intermediate map rounded to fp16 (what the kernel feeds
+    to the second conv's MFMAs)."""
+    g = torch.Generator().manual_seed(seed)
+    Fout = (Fin - 1) // sf + 1
+    shortcut = 1 if sf == 2 else 0
+    x = torch.randn(B, Fin, T, 32, generator=g).half()
+    w1 = (torch.randn(9, 32, 32, generator=g) * 0.08).half()
+    w2 = (torch.randn(10 if shortcut else 9, 32, 32, generator=g) * 0.08).half()
+    b1 = torch.randn(32, generator=g) * 0.1
+    b2 = torch.randn(32, generator=g) * 0.1
+    if strided_out:      # y[b, t, fo, co]
+        y = torch.full((B, T, Fout, 32), float('nan')).half().to(device)
+        sB, sF, sT = T * Fout * 32, 32, Fout * 32
+    else:                # y[b, fo, t, co]
+        y = torch.full((B, Fout, T, 32), float('nan')).half().to(device)
+        sB, sF, sT = Fout * T * 32, T * 32, 32
+    xd, w1d, w2d, b1d, b2d = x.to(device), w1.to(device), w2.to(device), b1.to(device), b2.to(device)
+    _hip.check(cdll.mv_fcm_block_f16(xd.data_ptr(), Fin, sf, w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), shortcut,
+                                     y.data_ptr(), sB, sF, sT, B, T, _stream(xd)), cdll)
+    xin = x.double().permute(0, 3, 1, 2)                                         # [B, 32, F, T]
+    k33 = lambda w: w[:9].double().reshape(3, 3, 32, 32).permute(2, 3, 0, 1).contiguous()  # [co, ci, df, dt]
+    mid = F.conv2d(xin, k33(w1), b1.double(), stride=(sf, 1), padding=1).clamp(min=0).half().double()
+    ref = F.conv2d(mid, k33(w2), b2.double(), padding=1)
+    if shortcut:
+        ref = ref + F.conv2d(xin, w2[9].double().reshape(32, 32, 1, 1), None, stride=(sf, 1))
+    else:
+        ref = ref + xin
+    ref = ref.clamp(min=0).permute(0, 3, 2, 1) if strided_out else ref.clamp(min=0).permute(0, 2, 3, 1)
+    out = y.cpu().double()
+    assert torch.isfinite(out).all(), 'unwritten outputs'
+    err = (out - ref).abs().max().item()
+    # fp16 rounding of the stored result + an fp16 ulp flip of the intermediate map where the fp32 accumulation order differs
+    assert err < 3e-3 * max(1.0, ref.abs().max().item()), err
+    return err
+
+
 def wave_prepare_case(cdll, device, B=5, L=5000, normalize=True, seed=0):
     from oracle import frontend
     g = torch.Generator().manual_seed(seed)

@@ -130,6 +130,19 @@ def test_emu_eres2net_rejects_bad_arguments():
         lc._hip.Model('eres2net', cfg, sd_missing, cdll=emu_cdll())
 
 
+@pytest.mark.parametrize('idx', range(len(lc.FCM_BLOCK_CASES)))
+def test_emu_fcm_block(idx):
+    """one BasicResBlock per launch (fcmblock.hip): strided + shortcut tap, identity, bands, two time tiles, ragged sizes"""
+    lc.fcm_block_case(emu_cdll(), 'cpu', seed=idx, **lc.FCM_BLOCK_CASES[idx])
+
+
+def test_emu_fcm_block_balanced_narrow_tiles(monkeypatch):
+    """MV_FCM_BLOCK_NT=2: T = 200 becomes two tiles of 100 output positions (NT = 2, halo columns recomputed at the tile edge)"""
+    monkeypatch.setenv('MV_FCM_BLOCK_NT', '2')
+    lc.fcm_block_case(emu_cdll(), 'cpu', B=1, Fin=5, T=200, sf=2, seed=41)
+    lc.fcm_block_case(emu_cdll(), 'cpu', B=1, Fin=4, T=127, sf=1, seed=42)
+
+
 @pytest.mark.parametrize('idx', range(len(lc.FCM_CASES)))
 @pytest.mark.parametrize('impl', ['band', 'row'])
 def test_emu_fcm_conv3x3(idx, impl, monkeypatch):

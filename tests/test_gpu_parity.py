@@ -537,6 +537,37 @@ def test_gpu_fcm_conv3x3(idx, impl, monkeypatch):
     lc.fcm_conv_case(product_lib(), DEV, seed=idx, **FCM_GPU_CASES[idx])
 
 
+FCM_BLOCK_GPU_CASES = lc.FCM_BLOCK_CASES + [
+    dict(B=9, Fin=80, T=298, sf=2),                      # the shipped geometry: layer1.block0, NT = 5, bands (9 < CUs)
+    dict(B=7, Fin=40, T=298, sf=1),                      # layer1.block1 (identity), ring 3 steps ahead
+    dict(B=300, Fin=40, T=298, sf=2),                    # more workgroups than CUs, one band each: layer2.block0
+    dict(B=2, Fin=20, T=1000, sf=1),                     # 10 s: four time tiles
+    dict(B=260, Fin=20, T=150, sf=1, strided_out=True),  # NT = 3: the deepest ring
+]
+
+
+@pytest.mark.parametrize('idx', range(len(FCM_BLOCK_GPU_CASES)))
+def test_gpu_fcm_block(idx):
+    """BasicResBlock in one launch (fcmblock.hip) against the fp64 reference with an fp16-rounded intermediate map"""
+    lc.fcm_block_case(product_lib(), DEV, seed=idx, **FCM_BLOCK_GPU_CASES[idx])
+
+
+@pytest.mark.parametrize('nt', ['3', '4'])
+def test_gpu_fcm_block_narrow_tiles(nt, monkeypatch):
+    """MV_FCM_BLOCK_NT caps the time tile (A/B knob): two balanced tiles with halo columns for T = 298"""
+    monkeypatch.setenv('MV_FCM_BLOCK_NT', nt)
+    lc.fcm_block_case(product_lib(), DEV, B=3, Fin=10, T=298, sf=2, seed=31)
+    lc.fcm_block_case(product_lib(), DEV, B=3, Fin=10, T=298, sf=1, seed=32)
+
+
+def test_gpu_campp_fused_and_unfused_fcm_agree(monkeypatch):
+    """MV_FCM_FUSED=0 (two launches per BasicResBlock, intermediate map in HBM) and the default (one launch) on the same golden"""
+    cd1, _ = lc.model_case(product_lib(), DEV, 'campp')
+    monkeypatch.setenv('MV_FCM_FUSED', '0')
+    cd0, _ = lc.model_case(product_lib(), DEV, 'campp')
+    assert cd1 < 1e-4 and cd0 < 1e-4, (cd1, cd0)
+
+
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
                                  dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
 def test_gpu_res2net_fused_chain(cfg):

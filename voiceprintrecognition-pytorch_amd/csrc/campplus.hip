@@ -225,12 +225,27 @@ struct CamppModel : MvModelBase {
         const half_t* cur = s.m0;
         int Fc = F;
         half_t* pp[2] = {s.m1, s.m2};
+        // MV_FCM_FUSED=0 (measurement knob) keeps the two launches per BasicResBlock with the intermediate map in HBM
+        const char* fcm_env = getenv("MV_FCM_FUSED");
+        const bool fused_block = !(fcm_env != nullptr && fcm_env[0] == '0');
         for (int i = 0; i < 4; ++i) {
             const ResBlock& r = res[i];
             const int Fo = (Fc - 1) / r.stride + 1;
+            auto so = plain(Fo);
+            if (fused_block) {
+                // one launch per block (fcmblock.hip): x read once, mid map in LDS, output written once
+                half_t* t2 = (cur == pp[0]) ? pp[1] : pp[0];
+                if (fcm_block_supported(t2, so[0], so[1], so[2], T, Fc)) {
+                    if ((rc = fcm_block_launch(cur, Fc, r.stride, r.conv1.w, r.conv1.bias, r.conv2.w, r.conv2.bias, r.has_shortcut ? 1 : 0, t2,
+                                               so[0], so[1], so[2], B, T, st)))
+                        return rc;
+                    cur = t2;
+                    Fc = Fo;
+                    continue;
+                }
+            }
             // conv1 (stride on the frequency axis) + BN + ReLU
             half_t* t1 = (cur == pp[0]) ? pp[1] : pp[0];
-            auto so = plain(Fo);
             if ((rc = fcm_conv3x3_launch(cur, Fc, r.stride, nullptr, 0, 1, 0, r.conv1.w, r.conv1.bias, t1, so[0], so[1], so[2], B, T,
                                          Fo, st)))
                 return rc;

@@ -1,0 +1,342 @@
+// CAM++ front-end, one BasicResBlock per launch (mvector/models/campplus.py:221-254):
+//     mid = ReLU(BN1(conv3x3_stride(sf,1)(x)))        out = ReLU(BN2(conv3x3(mid)) + shortcut(x))
+// with shortcut = BN(conv1x1_stride(sf,1)(x)) when the block is strided, the identity otherwise.  fcm.hip runs the two convs as two
+// launches with the intermediate map making a round trip through HBM (write 1, read 1 of [B, Fout, T, 32] fp16) and the block input
+// read twice (once as conv input, once as residual).  Here the intermediate map never leaves the CU and x is read once:
+// per block HBM sees one read of x and one write of out -- the nine 3x3 convs of the head go from 770 to 410 row-units of traffic
+// (one unit = B * T * 64 bytes), and the fp16 rounding of the intermediate map disappears from the error budget
+// (profiles/r06_campp_error_budget.log).
+//
+// Workgroup = (utterance, time tile, band of output frequency rows), 4 waves, walking the band downwards one MID row per step:
+//   * the block input rows enter an LDS ring by LDS-DMA exactly as in fcm_band_kernel (each row once, LEAD steps ahead, counted
+//     s_waitcnt, zero page for the padding in time and frequency);
+//   * conv1 (9 MFMA taps, BN1 folded, ReLU) produces mid row m for the tile's positions plus one column of halo on each side and
+//     writes it as fp16 into ONE LDS slot (positions outside [0, T) are written as zeros: conv2 pads the mid map, not x);
+//   * conv2 is evaluated in scatter form: mid row m contributes to output rows m+1, m, m-1 through the tap rows df = 0, 1, 2, so the
+//     three output rows in progress live in three accumulator sets in registers and no ring of mid rows is needed; the shortcut
+//     (tenth tap on the centre input row sf*m, which is in the ring at this step; identity = the permuted unit matrix, exact) goes
+//     into the accumulators of row m; after the step row m-1 is complete: bias, ReLU, one 16-byte store per position (8 maps).
+//   * both convs keep their tap matrices in registers as MFMA A fragments with the rows permuted so that a lane owns 8 consecutive
+//     maps of one position (fcm.hip); one wave per SIMD, so the 152 weight + 160 accumulator registers fit.
+// Two barriers per step (ring rows landed / mid row written).  Bands only exist while (utterance, time tile) pairs do not fill the
+// chip (small batches); a band recomputes its two halo mid rows.
+#include "kernels.h"
+
+namespace mv {
+
+constexpr int FBK_C = 32;  // feature maps
+
+__device__ __attribute__((aligned(256))) const unsigned char g_fcmblk_zero_page[256] = {0};
+
+struct FcmBlockArgs {
+    const half_t* x;    // [B, Fin, T, 32]
+    const half_t* w1;   // [9][32 co][32 ci], BN1 folded
+    const float* b1;    // [32]
+    const half_t* w2;   // [9 or 10][32][32], BN2 folded; tap 9 = shortcut 1x1 conv with its BN folded
+    const float* b2;    // [32] BN2 shift (+ shortcut BN shift)
+    half_t* y;
+    int64_t y_sB, y_sF, y_sT;
+    int B, T, Fin, Fout, shortcut, tile_out;  // tile_out: output positions per time tile (<= 64 * NT - 2)
+};
+
+// byte offset of the 16-byte chunk `chunk` of position `pos` inside a row slot (64 B per position, chunks XOR-swizzled so that
+// the 16 lanes x 4 chunks of a fragment read hit distinct banks)
+__device__ __forceinline__ int fbk_off(int pos, int chunk) { return pos * 64 + ((chunk ^ ((pos >> 1) & 3)) << 4); }
+
+template <int NT, int SF>
+struct FcmBlk {
+    static constexpr int MW = 64 * NT;             // mid positions per tile (4 waves x NT x 16): t0 - 1 ... t0 + MW - 2
+    static constexpr int NTR = 4 * NT + 1;         // 1 KiB transfers per input row slot ((MW + 2) positions x 64 B rounded up)
+    static constexpr int TPW = NT + 1;             // transfers per wave and row
+    static constexpr int SLOT_BYTES = NTR * 1024;
+    static constexpr int MID_BYTES = (MW + 2) * 64;  // + 2 positions that the masked last outputs read
+    static constexpr int LDS_MAX = 160 * 1024;
+    static constexpr int lead_fit = ((LDS_MAX - 1024 - MID_BYTES) / SLOT_BYTES - 3) / SF;
+    static constexpr int LEAD = lead_fit > 4 ? 4 : lead_fit;  // steps of input rows in flight beyond the current one
+    static constexpr int RING = 3 + SF * LEAD;
+    static constexpr int MID_OFF = RING * SLOT_BYTES;
+    static constexpr int DUMP_OFF = MID_OFF + MID_BYTES;
+    static constexpr int LDS_BYTES = DUMP_OFF + 1024;
+    static constexpr int AHEAD = (LEAD - 1) * SF * TPW;  // transfers that may stay in flight when a step starts
+    static_assert(LEAD >= 1 && LDS_BYTES <= LDS_MAX && AHEAD <= 63, "fcm block kernel: ring does not fit");
+};
+
+template <int PH>
+struct FbkPhase {
+    static constexpr int C = PH, N = (PH + 1) % 3, P = (PH + 2) % 3;
+};
+
+template <int NT, int SF>
+__global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_ttiles, int n_bands, int band_rows) {
+    typedef FcmBlk<NT, SF> G;
+    MV_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = MV_UNIFORM(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    int wg = blockIdx.x;
+    const int band = wg % n_bands;
+    wg /= n_bands;
+    const int tt = wg % n_ttiles;
+    const int b = wg / n_ttiles;
+    const int t0 = tt * a.tile_out;
+    const int f0 = band * band_rows;
+    const int f1 = f0 + band_rows < a.Fout ? f0 + band_rows : a.Fout;
+    if (f1 <= f0) return;
+    const int mlo = f0 > 0 ? f0 - 1 : 0;                     // mid rows the band needs
+    const int mhi = f1 < a.Fout ? f1 : a.Fout - 1;
+    const int nsteps = mhi - mlo + 1;
+    const int rbase = SF * mlo - 1;                          // input row of ring index 0 (may be -1: zero padding)
+    const int rel_last = SF * (nsteps - 1) + 2;              // last ring index the band needs
+
+    // ---- tap matrices: A fragments with permuted rows (A row i of tile mi <-> map 8*(i>>2) + 4*mi + (i&3)) ----
+    half8v w1f[9][2], w2f[10][2];
+    float bias1[2][4], bias2[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            w1f[tap][mi] = *reinterpret_cast<const half8v*>(a.w1 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
+            w2f[tap][mi] = *reinterpret_cast<const half8v*>(a.w2 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
+        }
+        if (a.shortcut) {
+            w2f[9][mi] = *reinterpret_cast<const half8v*>(a.w2 + ((9 * FBK_C + co) * FBK_C + 8 * fg));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w2f[9][mi][e] = (half_t)(8 * fg + e == co ? 1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bias1[mi][r] = a.b1[8 * fg + 4 * mi + r];
+            bias2[mi][r] = a.b2[8 * fg + 4 * mi + r];
+        }
+    }
+
+    // ---- this lane's share of a row transfer: slot position pi holds frame t0 + pi - 2 ----
+    const half_t* zero = reinterpret_cast<const half_t*>(g_fcmblk_zero_page);
+    int xoff[G::TPW];
+    bool xlive[G::TPW];
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) {
+        const int j = wave + 4 * i;
+        const int q = j * 64 + lane;
+        const int pi = q >> 2;
+        const int c = (q & 3) ^ ((pi >> 1) & 3);
+        const int t = t0 + pi - 2;
+        xlive[i] = j < G::NTR;
+        xoff[i] = (xlive[i] && pi < G::MW + 2 && t >= 0 && t < a.T) ? t * FBK_C + c * 8 : -1;
+    }
+    char* const dump = smem + G::DUMP_OFF;
+    char* const mid = smem + G::MID_OFF;
+
+    int islot = 0, irel = 0;  // ring slot / ring index of the next row to be requested
+    auto issue_row = [&]() {
+        const int fin = rbase + irel;
+        const bool rok = fin >= 0 && fin < a.Fin && irel <= rel_last;  // uniform
+        const half_t* base = a.x + ((int64_t)b * a.Fin + (rok ? fin : 0)) * a.T * FBK_C;
+        char* slot = smem + islot * G::SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < G::TPW; ++i) {
+            const half_t* src = (rok && xoff[i] >= 0) ? base + xoff[i] : zero;
+            glds16(src, xlive[i] ? slot + (wave + 4 * i) * 1024 : dump);
+        }
+        ++irel;
+        islot = islot + 1 == G::RING ? 0 : islot + 1;
+    };
+#pragma unroll 1
+    for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) issue_row();
+
+    float4v acc2[3][2][NT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc2[s][mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int pbase = wave * (16 * NT) + fr;
+    int cslot = 0;  // ring slot of the first input row of the current step
+
+    // output row `fo` from accumulator set `s`: bias, ReLU, 8 consecutive maps of one position per lane
+    auto store_row = [&](const float4v (&acc)[2][NT], int fo) __attribute__((always_inline)) {
+        half_t* yrow = a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF + 8 * fg;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int j = pbase + ni * 16;
+            const int t = t0 + j;
+            half8v o;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * mi + r] = (half_t)fmed3(acc[mi][ni][r] + bias2[mi][r], 0.0f, 65504.0f);
+            if (j < a.tile_out && t < a.T) *MV_AS_GLOBAL(half8v, yrow + (int64_t)t * a.y_sT) = o;
+        }
+    };
+
+    auto step = [&](auto ph, int i) __attribute__((always_inline)) {
+        typedef decltype(ph) PH;
+        const int m = mlo + i;
+        wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
+        lds_barrier();        // ... in every wave; everybody is done with the mid slot and with the ring slots requested next
+#pragma unroll
+        for (int s = 0; s < SF; ++s) issue_row();
+
+        // ---- conv1 + BN1 + ReLU -> mid row m (positions t0 - 1 + p) ----
+        float4v acc1[2][NT];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc1[mi][ni] = float4v{bias1[mi][0], bias1[mi][1], bias1[mi][2], bias1[mi][3]};
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+            int sl = cslot + df;
+            sl = sl >= G::RING ? sl - G::RING : sl;
+            const char* row = smem + sl * G::SLOT_BYTES;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const half8v bf = *reinterpret_cast<const half8v*>(row + fbk_off(pbase + ni * 16 + dt, fg));
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[df * 3 + dt][mi], bf, acc1[mi][ni], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int p = pbase + ni * 16;
+            const int t = t0 - 1 + p;
+            const bool ok = t >= 0 && t < a.T;
+            half8v o;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * mi + r] = ok ? (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f) : (half_t)0.0f;
+            *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
+        }
+        lds_barrier();
+
+        // ---- conv2 in scatter form: row m+1 is born, row m takes the shortcut and its centre taps, row m-1 is completed ----
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc2[PH::N][mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            int sl = cslot + 1;  // centre input row = row sf * m of x
+            sl = sl >= G::RING ? sl - G::RING : sl;
+            const char* row = smem + sl * G::SLOT_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const half8v bf = *reinterpret_cast<const half8v*>(row + fbk_off(pbase + ni * 16 + 2, fg));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc2[PH::C][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[9][mi], bf, acc2[PH::C][mi][ni], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const half8v bf = *reinterpret_cast<const half8v*>(mid + fbk_off(pbase + ni * 16 + dt, fg));
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc2[PH::N][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[0 + dt][mi], bf, acc2[PH::N][mi][ni], 0, 0, 0);
+                    acc2[PH::C][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[3 + dt][mi], bf, acc2[PH::C][mi][ni], 0, 0, 0);
+                    acc2[PH::P][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[6 + dt][mi], bf, acc2[PH::P][mi][ni], 0, 0, 0);
+                }
+            }
+        if (m - 1 >= f0) store_row(acc2[PH::P], m - 1);
+        if (i == nsteps - 1 && m < f1) store_row(acc2[PH::C], m);  // the band ends at the last row of the map
+        cslot += SF;
+        cslot = cslot >= G::RING ? cslot - G::RING : cslot;
+    };
+
+#pragma unroll 1
+    for (int i = 0; i < nsteps; i += 3) {
+        step(FbkPhase<0>(), i);
+        if (i + 1 < nsteps) step(FbkPhase<1>(), i + 1);
+        if (i + 2 < nsteps) step(FbkPhase<2>(), i + 2);
+    }
+}
+
+template <int NT, int SF>
+static int fcm_block_launch_one(const FcmBlockArgs& a, int n_ttiles, hipStream_t stream) {
+    typedef FcmBlk<NT, SF> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (MV_SET_MAX_SMEM((fcm_block_kernel<NT, SF>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm block kernel: LDS size rejected");
+        attr_set = true;
+    }
+    // one workgroup per CU is resident (LDS): bands only while (utterance, time tile) pairs alone do not fill the chip
+    const int64_t pairs = (int64_t)a.B * n_ttiles;
+    const int cus = device_cu_count();
+    int n_bands = (int)ceil_div((int64_t)cus, pairs);
+    const int max_bands = a.Fout / 4 > 0 ? a.Fout / 4 : 1;
+    n_bands = n_bands < 1 ? 1 : (n_bands > max_bands ? max_bands : n_bands);
+    const int band_rows = (int)ceil_div(a.Fout, n_bands);
+    n_bands = (int)ceil_div(a.Fout, band_rows);
+    MV_REQUIRE(pairs * n_bands < ((int64_t)1 << 31), "fcm_block: grid too large");
+    MV_LAUNCH((fcm_block_kernel<NT, SF>), ((unsigned)(pairs * n_bands), 1, 1), (256, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands, band_rows);
+    return check_launch("fcm_block_kernel");
+}
+
+template <int NT>
+static int fcm_block_launch_nt(const FcmBlockArgs& a, int n_ttiles, hipStream_t stream) {
+    return a.Fin == a.Fout ? fcm_block_launch_one<NT, 1>(a, n_ttiles, stream) : fcm_block_launch_one<NT, 2>(a, n_ttiles, stream);
+}
+
+bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin) {
+    return y_sB % 8 == 0 && y_sF % 8 == 0 && y_sT % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+           (int64_t)T * FBK_C * (int64_t)Fin < ((int64_t)1 << 31);
+}
+
+int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int shortcut,
+                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && w1 != nullptr && b1 != nullptr && w2 != nullptr && b2 != nullptr && y != nullptr, "fcm_block: null tensor");
+    MV_REQUIRE(B > 0 && T > 0 && Fin > 0 && (sf == 1 || sf == 2), "fcm_block: bad geometry");
+    MV_REQUIRE(sf == 1 || shortcut != 0, "fcm_block: a strided block needs its shortcut conv (the identity cannot change the row count)");
+    MV_REQUIRE(fcm_block_supported(y, y_sB, y_sF, y_sT, T, Fin), "fcm_block: output rows must be 16-byte aligned and a map below 2^31 elements");
+    FcmBlockArgs a;
+    a.x = x;
+    a.w1 = w1;
+    a.b1 = b1;
+    a.w2 = w2;
+    a.b2 = b2;
+    a.y = y;
+    a.y_sB = y_sB;
+    a.y_sF = y_sF;
+    a.y_sT = y_sT;
+    a.B = B;
+    a.T = T;
+    a.Fin = Fin;
+    a.Fout = (Fin - 1) / sf + 1;
+    a.shortcut = shortcut;
+    // time tiles: as few as possible (every tile recomputes one column of mid halo per side), equal shares, then the smallest NT
+    // that covers a share (+ 2 halo columns).  MV_FCM_BLOCK_NT caps NT (A/B runs: narrower tiles = deeper ring).
+    int nt_max = 5;
+    if (const char* e = getenv("MV_FCM_BLOCK_NT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 5) nt_max = v;
+    }
+    const int n_ttiles = (int)ceil_div(T, 64 * nt_max - 2);
+    a.tile_out = (int)ceil_div(T, n_ttiles);
+    const int nt = (int)ceil_div(a.tile_out + 2, 64);
+    switch (nt) {
+        case 1: return fcm_block_launch_nt<1>(a, n_ttiles, stream);
+        case 2: return fcm_block_launch_nt<2>(a, n_ttiles, stream);
+        case 3: return fcm_block_launch_nt<3>(a, n_ttiles, stream);
+        case 4: return fcm_block_launch_nt<4>(a, n_ttiles, stream);
+        default: return fcm_block_launch_nt<5>(a, n_ttiles, stream);
+    }
+}
+
+}  // namespace mv
+
+extern "C" {
+int mv_fcm_block_f16(const void* x, int32_t Fin, int32_t sf, const void* w1, const float* b1, const void* w2, const float* b2,
+                     int32_t shortcut, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream) {
+    return mv::fcm_block_launch(reinterpret_cast<const half_t*>(x), Fin, sf, reinterpret_cast<const half_t*>(w1), b1,
+                                reinterpret_cast<const half_t*>(w2), b2, shortcut, reinterpret_cast<half_t*>(y), y_sB, y_sF, y_sT, B, T,
+                                static_cast<hipStream_t>(stream));
+}
+}

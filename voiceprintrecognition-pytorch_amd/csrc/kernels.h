@@ -35,6 +35,10 @@ int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const floa
 int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F2, int sf2, int mode2, const half_t* w,
                        const float* bias, half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, int Fout,
                        hipStream_t stream);
+// one BasicResBlock of the FCM head (campplus.py:221-254) as one launch, intermediate map kept in LDS (fcmblock.hip)
+bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin);
+int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int shortcut,
+                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream);
 // one CAMDenseTDNNLayer (campplus.py:114-150) as one launch, one workgroup per utterance (camdense.hip); T2 <= 160 frames
 bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len);
 int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
