@@ -301,8 +301,10 @@ def test_native_handle_cache_is_not_part_of_module_state(tmp_path):
     class Handle:  # what _hip.Model holds: raw pointers and a CDLL
         def __init__(self):
             self.h, self.lib = ctypes.c_void_p(1234), ctypes.CDLL(None)
-    v0 = m._params_version()
-    m.__dict__['_native_handles'] = {0: (Handle(), v0)}
+    tensors = m._forward_tensors(m.state_dict(keep_vars=True))   # the list the handle caches: the per-forward check walks it, not state_dict()
+    v0 = m._params_version(tensors)
+    assert v0 == m._params_version()
+    m.__dict__['_native_handles'] = {0: (Handle(), v0, tensors)}
     c = copy.deepcopy(m)
     assert '_native_handles' not in c.__dict__ and '_native_handles' in m.__dict__
     assert all(torch.equal(a, b) for a, b in zip(c.state_dict().values(), m.state_dict().values()))
@@ -313,7 +315,7 @@ def test_native_handle_cache_is_not_part_of_module_state(tmp_path):
     # an in-place edit under no_grad (EMA swap, weight surgery) changes the version key the handle was built under
     with torch.no_grad():
         m.fc.conv.weight.mul_(1.0)
-    assert m._params_version() != v0
+    assert m._params_version() != v0 and m._params_version(tensors) != v0
     # gradient analysis with respect to the input needs the torch graph; plain inference (grad mode on, default
     # requires_grad parameters -- what the reference's predictor does) must stay on the native path
     x = torch.zeros(1, 20, man['kwargs']['input_size'])

@@ -222,6 +222,51 @@ __device__ __forceinline__ void store16_streaming(void* p, const unsigned (&o)[4
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(ou) : "memory");
 }
 
+// ---- hand-scheduled pieces of the fused FCM block kernel (fcmblock.hip): NT position tiles x 2 map tiles per tap ------------------
+// NT 16-byte fragment reads at addr + i * 1024 (16 positions x 64 B apart), no wait
+template <int NT>
+__device__ __forceinline__ void lds_read_tiles(half8v (&d)[NT], unsigned addr) {
+    static_assert(NT >= 1 && NT <= 5, "lds_read_tiles: 1..5 tiles");
+    if constexpr (NT == 1) asm volatile("ds_read_b128 %0, %1" : "=&v"(d[0]) : "v"(addr) : "memory");
+    if constexpr (NT == 2) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(d[0]), "=&v"(d[1]) : "v"(addr) : "memory");
+    if constexpr (NT == 3) asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(addr) : "memory");
+    if constexpr (NT == 4) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(addr) : "memory");
+    if constexpr (NT == 5) asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1024\n\tds_read_b128 %2, %5 offset:2048\n\tds_read_b128 %3, %5 offset:3072\n\tds_read_b128 %4, %5 offset:4096" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]) : "v"(addr) : "memory");
+}
+// wait until at most WAIT LDS operations are outstanding, then 2 * NT MFMAs: (a0 | a1) x b[0..NT) into c0[] | c1[], the accumulators in
+// AccVGPRs (one wave per SIMD: the 256 architectural registers hold the tap matrices and fragments, the accumulators live beside them).
+// A following block accumulates into the same registers 2 * NT MFMAs later: the blocks of 2 and 4 pad that distance with s_nop (the
+// compiler's hazard recogniser does not look into inline assembly).
+template <int NT, int WAIT>
+__device__ __forceinline__ void mfma_tiles_acc(float4v (&c0)[NT], float4v (&c1)[NT], const half8v& a0, const half8v& a1, const half8v (&b)[NT]) {
+    static_assert(NT >= 1 && NT <= 5, "mfma_tiles_acc: 1..5 tiles");
+    if constexpr (NT == 1)
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_f16 %1, %3, %4, %1\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "+a"(c0[0]), "+a"(c1[0])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "n"(WAIT)
+                     : "memory");
+    if constexpr (NT == 2)
+        asm volatile("s_waitcnt lgkmcnt(%8)\n\tv_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_f16 %2, %5, %6, %2\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, %1\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, %3\n\ts_nop 7\n\ts_nop 3"
+                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c1[0]), "+a"(c1[1])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "n"(WAIT)
+                     : "memory");
+    if constexpr (NT == 3)
+        asm volatile("s_waitcnt lgkmcnt(%11)\n\tv_mfma_f32_16x16x32_f16 %0, %6, %8, %0\n\tv_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\tv_mfma_f32_16x16x32_f16 %1, %6, %9, %1\n\tv_mfma_f32_16x16x32_f16 %4, %7, %9, %4\n\tv_mfma_f32_16x16x32_f16 %2, %6, %10, %2\n\tv_mfma_f32_16x16x32_f16 %5, %7, %10, %5"
+                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "n"(WAIT)
+                     : "memory");
+    if constexpr (NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(%14)\n\tv_mfma_f32_16x16x32_f16 %0, %8, %10, %0\n\tv_mfma_f32_16x16x32_f16 %4, %9, %10, %4\n\tv_mfma_f32_16x16x32_f16 %1, %8, %11, %1\n\tv_mfma_f32_16x16x32_f16 %5, %9, %11, %5\n\tv_mfma_f32_16x16x32_f16 %2, %8, %12, %2\n\tv_mfma_f32_16x16x32_f16 %6, %9, %12, %6\n\tv_mfma_f32_16x16x32_f16 %3, %8, %13, %3\n\tv_mfma_f32_16x16x32_f16 %7, %9, %13, %7"
+                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c0[3]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2]), "+a"(c1[3])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
+                     : "memory");
+    if constexpr (NT == 5)
+        asm volatile("s_waitcnt lgkmcnt(%17)\n\tv_mfma_f32_16x16x32_f16 %0, %10, %12, %0\n\tv_mfma_f32_16x16x32_f16 %5, %11, %12, %5\n\tv_mfma_f32_16x16x32_f16 %1, %10, %13, %1\n\tv_mfma_f32_16x16x32_f16 %6, %11, %13, %6\n\tv_mfma_f32_16x16x32_f16 %2, %10, %14, %2\n\tv_mfma_f32_16x16x32_f16 %7, %11, %14, %7\n\tv_mfma_f32_16x16x32_f16 %3, %10, %15, %3\n\tv_mfma_f32_16x16x32_f16 %8, %11, %15, %8\n\tv_mfma_f32_16x16x32_f16 %4, %10, %16, %4\n\tv_mfma_f32_16x16x32_f16 %9, %11, %16, %9"
+                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c0[3]), "+a"(c0[4]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2]), "+a"(c1[3]), "+a"(c1[4])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "n"(WAIT)
+                     : "memory");
+}
+
 // compute units of the current device (persistent kernels launch one workgroup per CU)
 inline int device_cu_count() {
     int dev = 0;

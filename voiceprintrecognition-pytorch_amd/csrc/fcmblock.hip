@@ -156,6 +156,14 @@ __global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_tt
 
     const int pbase = wave * (16 * NT) + fr;
     int cslot = 0;  // ring slot of the first input row of the current step
+    // this lane's fragment addresses for the three time taps: position pbase + dt of a ring slot / of the mid slot (tile ni is
+    // 16 positions = 1024 bytes further: 16 keeps the swizzle bits)
+    unsigned a_in[3], a_mid[3];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        a_in[dt] = lds_addr(smem) + (unsigned)fbk_off(pbase + dt, fg);
+        a_mid[dt] = lds_addr(smem) + (unsigned)(G::MID_OFF + fbk_off(pbase + dt, fg));
+    }
 
     // output row `fo` from accumulator set `s`: bias, ReLU, 8 consecutive maps of one position per lane
     auto store_row = [&](const float4v (&acc)[2][NT], int fo) __attribute__((always_inline)) {
@@ -182,26 +190,35 @@ __global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_tt
         for (int s = 0; s < SF; ++s) issue_row();
 
         // ---- conv1 + BN1 + ReLU -> mid row m (positions t0 - 1 + p) ----
+        // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
+        // groups, counted lgkmcnt): with one wave per SIMD nobody else hides the LDS latency
         float4v acc1[2][NT];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) acc1[mi][ni] = float4v{bias1[mi][0], bias1[mi][1], bias1[mi][2], bias1[mi][3]};
+        unsigned rowb[3];  // ring slots of the three input rows (uniform byte offsets)
 #pragma unroll
         for (int df = 0; df < 3; ++df) {
             int sl = cslot + df;
             sl = sl >= G::RING ? sl - G::RING : sl;
-            const char* row = smem + sl * G::SLOT_BYTES;
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni) {
-                    const half8v bf = *reinterpret_cast<const half8v*>(row + fbk_off(pbase + ni * 16 + dt, fg));
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        acc1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[df * 3 + dt][mi], bf, acc1[mi][ni], 0, 0, 0);
-                }
+            rowb[df] = (unsigned)(sl * G::SLOT_BYTES);
         }
+        half8v bq[2][NT];
+        lds_read_tiles<NT>(bq[0], a_in[0] + rowb[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) {
+                lds_read_tiles<NT>(bq[(tap + 1) & 1], a_in[(tap + 1) % 3] + rowb[(tap + 1) / 3]);
+                mfma_tiles_acc<NT, NT>(acc1[0], acc1[1], w1f[tap][0], w1f[tap][1], bq[tap & 1]);
+            } else {
+                // the shortcut's fragments (centre input row, position + 2) ride behind the last tap
+                lds_read_tiles<NT>(bq[1], a_in[2] + rowb[1]);
+                mfma_tiles_acc<NT, NT>(acc1[0], acc1[1], w1f[8][0], w1f[8][1], bq[0]);
+            }
+        }
+        mfma_hazard_pad();
+        mfma_hazard_pad();
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int p = pbase + ni * 16;
@@ -214,37 +231,28 @@ __global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                 for (int r = 0; r < 4; ++r) o[4 * mi + r] = ok ? (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f) : (half_t)0.0f;
             *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
         }
-        lds_barrier();
-
         // ---- conv2 in scatter form: row m+1 is born, row m takes the shortcut and its centre taps, row m-1 is completed ----
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) acc2[PH::N][mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        {
-            int sl = cslot + 1;  // centre input row = row sf * m of x
-            sl = sl >= G::RING ? sl - G::RING : sl;
-            const char* row = smem + sl * G::SLOT_BYTES;
+        // shortcut tap (x, not mid): its MFMAs run while the other waves arrive at the barrier
+        mfma_tiles_acc<NT, 0>(acc2[PH::C][0], acc2[PH::C][1], w2f[9][0], w2f[9][1], bq[1]);
+        lds_barrier();
+        lds_read_tiles<NT>(bq[0], a_mid[0]);
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const half8v bf = *reinterpret_cast<const half8v*>(row + fbk_off(pbase + ni * 16 + 2, fg));
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc2[PH::C][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[9][mi], bf, acc2[PH::C][mi][ni], 0, 0, 0);
+        for (int dt = 0; dt < 3; ++dt) {
+            if (dt < 2) lds_read_tiles<NT>(bq[(dt + 1) & 1], a_mid[dt + 1]);
+            if (dt < 2) {
+                mfma_tiles_acc<NT, NT>(acc2[PH::N][0], acc2[PH::N][1], w2f[0 + dt][0], w2f[0 + dt][1], bq[dt & 1]);
+            } else {
+                mfma_tiles_acc<NT, 0>(acc2[PH::N][0], acc2[PH::N][1], w2f[0 + dt][0], w2f[0 + dt][1], bq[dt & 1]);
             }
+            mfma_tiles_acc<NT, NT>(acc2[PH::C][0], acc2[PH::C][1], w2f[3 + dt][0], w2f[3 + dt][1], bq[dt & 1]);
+            mfma_tiles_acc<NT, NT>(acc2[PH::P][0], acc2[PH::P][1], w2f[6 + dt][0], w2f[6 + dt][1], bq[dt & 1]);
         }
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const half8v bf = *reinterpret_cast<const half8v*>(mid + fbk_off(pbase + ni * 16 + dt, fg));
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    acc2[PH::N][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[0 + dt][mi], bf, acc2[PH::N][mi][ni], 0, 0, 0);
-                    acc2[PH::C][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[3 + dt][mi], bf, acc2[PH::C][mi][ni], 0, 0, 0);
-                    acc2[PH::P][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[6 + dt][mi], bf, acc2[PH::P][mi][ni], 0, 0, 0);
-                }
-            }
+        mfma_hazard_pad();
+        mfma_hazard_pad();
         if (m - 1 >= f0) store_row(acc2[PH::P], m - 1);
         if (i == nsteps - 1 && m < f1) store_row(acc2[PH::C], m);  // the band ends at the last row of the map
         cslot += SF;
