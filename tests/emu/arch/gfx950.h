@@ -148,16 +148,20 @@ inline void mfma10_step(float4v* c0, float4v* c1, const half8v& a0, const half8v
         c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
     }
 }
-template <int NT>
-inline void lds_read_tiles(half8v (&d)[NT], unsigned addr) {
-    for (int i = 0; i < NT; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 1024 * i));
+template <int N>
+inline void lds_read_tiles(half8v (&d)[N], unsigned addr) {
+    for (int i = 0; i < N; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 1024 * i));
 }
-template <int NT, int WAIT>
-inline void mfma_tiles_acc(float4v (&c0)[NT], float4v (&c1)[NT], const half8v& a0, const half8v& a1, const half8v (&b)[NT]) {
-    for (int i = 0; i < NT; ++i) {
+template <int N, int WAIT>
+inline void mfma_tiles2(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N]) {
+    for (int i = 0; i < N; ++i) {
         c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
         c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
     }
+}
+template <int N, int WAIT>
+inline void mfma_tiles1(float4v (&c)[N], const half8v& a, const half8v (&b)[N]) {
+    for (int i = 0; i < N; ++i) c[i] = emu_mfma_f32_16x16x32_f16(a, b[i], c[i]);
 }
 inline void mfma_hazard_pad() {}
 inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }

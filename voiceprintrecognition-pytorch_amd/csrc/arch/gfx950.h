@@ -222,48 +222,147 @@ __device__ __forceinline__ void store16_streaming(void* p, const unsigned (&o)[4
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(ou) : "memory");
 }
 
-// ---- hand-scheduled pieces of the fused FCM block kernel (fcmblock.hip): NT position tiles x 2 map tiles per tap ------------------
-// NT 16-byte fragment reads at addr + i * 1024 (16 positions x 64 B apart), no wait
-template <int NT>
-__device__ __forceinline__ void lds_read_tiles(half8v (&d)[NT], unsigned addr) {
-    static_assert(NT >= 1 && NT <= 5, "lds_read_tiles: 1..5 tiles");
-    if constexpr (NT == 1) asm volatile("ds_read_b128 %0, %1" : "=&v"(d[0]) : "v"(addr) : "memory");
-    if constexpr (NT == 2) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(d[0]), "=&v"(d[1]) : "v"(addr) : "memory");
-    if constexpr (NT == 3) asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(addr) : "memory");
-    if constexpr (NT == 4) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(addr) : "memory");
-    if constexpr (NT == 5) asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1024\n\tds_read_b128 %2, %5 offset:2048\n\tds_read_b128 %3, %5 offset:3072\n\tds_read_b128 %4, %5 offset:4096" : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]) : "v"(addr) : "memory");
+// ---- hand-scheduled pieces of the fused FCM block kernel (fcmblock.hip) ----------------------------------------------------------
+// N 16-byte fragment reads at addr + i * 1024 (16 positions x 64 B apart), no wait
+template <int N>
+__device__ __forceinline__ void lds_read_tiles(half8v (&d)[N], unsigned addr) {
+    static_assert(N >= 1 && N <= 10, "lds_read_tiles: 1..10 tiles");
+    if constexpr (N == 1)
+        asm volatile("ds_read_b128 %0, %1"
+                     : "=&v"(d[0])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 2)
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"
+                     : "=&v"(d[0]), "=&v"(d[1])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 3)
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 4)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 5)
+        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1024\n\tds_read_b128 %2, %5 offset:2048\n\tds_read_b128 %3, %5 offset:3072\n\tds_read_b128 %4, %5 offset:4096"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 6)
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\tds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 7)
+        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:1024\n\tds_read_b128 %2, %7 offset:2048\n\tds_read_b128 %3, %7 offset:3072\n\tds_read_b128 %4, %7 offset:4096\n\tds_read_b128 %5, %7 offset:5120\n\tds_read_b128 %6, %7 offset:6144"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 8)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 9)
+        asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %9 offset:1024\n\tds_read_b128 %2, %9 offset:2048\n\tds_read_b128 %3, %9 offset:3072\n\tds_read_b128 %4, %9 offset:4096\n\tds_read_b128 %5, %9 offset:5120\n\tds_read_b128 %6, %9 offset:6144\n\tds_read_b128 %7, %9 offset:7168\n\tds_read_b128 %8, %9 offset:8192"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8])
+                     : "v"(addr)
+                     : "memory");
+    if constexpr (N == 10)
+        asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:1024\n\tds_read_b128 %2, %10 offset:2048\n\tds_read_b128 %3, %10 offset:3072\n\tds_read_b128 %4, %10 offset:4096\n\tds_read_b128 %5, %10 offset:5120\n\tds_read_b128 %6, %10 offset:6144\n\tds_read_b128 %7, %10 offset:7168\n\tds_read_b128 %8, %10 offset:8192\n\tds_read_b128 %9, %10 offset:9216"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9])
+                     : "v"(addr)
+                     : "memory");
 }
-// wait until at most WAIT LDS operations are outstanding, then 2 * NT MFMAs: (a0 | a1) x b[0..NT) into c0[] | c1[], the accumulators in
-// AccVGPRs (one wave per SIMD: the 256 architectural registers hold the tap matrices and fragments, the accumulators live beside them).
-// A following block accumulates into the same registers 2 * NT MFMAs later: the blocks of 2 and 4 pad that distance with s_nop (the
-// compiler's hazard recogniser does not look into inline assembly).
-template <int NT, int WAIT>
-__device__ __forceinline__ void mfma_tiles_acc(float4v (&c0)[NT], float4v (&c1)[NT], const half8v& a0, const half8v& a1, const half8v (&b)[NT]) {
-    static_assert(NT >= 1 && NT <= 5, "mfma_tiles_acc: 1..5 tiles");
-    if constexpr (NT == 1)
+// wait until at most WAIT LDS operations are outstanding, then 2 * N MFMAs: (a0 | a1) x b[0..N) into c0[] | c1[].  A following block
+// accumulates into the same registers 2 * N MFMAs later: the short blocks pad that distance with s_nop (the compiler's hazard
+// recogniser does not look into inline assembly).
+template <int N, int WAIT>
+__device__ __forceinline__ void mfma_tiles2(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N]) {
+    static_assert(N >= 1 && N <= 5, "mfma_tiles2: 1..5 tiles");
+    if constexpr (N == 1)
         asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_f16 %1, %3, %4, %1\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
-                     : "+a"(c0[0]), "+a"(c1[0])
+                     : "+v"(c0[0]), "+v"(c1[0])
                      : "v"(a0), "v"(a1), "v"(b[0]), "n"(WAIT)
                      : "memory");
-    if constexpr (NT == 2)
+    if constexpr (N == 2)
         asm volatile("s_waitcnt lgkmcnt(%8)\n\tv_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_f16 %2, %5, %6, %2\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, %1\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, %3\n\ts_nop 7\n\ts_nop 3"
-                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c1[0]), "+a"(c1[1])
+                     : "+v"(c0[0]), "+v"(c0[1]), "+v"(c1[0]), "+v"(c1[1])
                      : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "n"(WAIT)
                      : "memory");
-    if constexpr (NT == 3)
+    if constexpr (N == 3)
         asm volatile("s_waitcnt lgkmcnt(%11)\n\tv_mfma_f32_16x16x32_f16 %0, %6, %8, %0\n\tv_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\tv_mfma_f32_16x16x32_f16 %1, %6, %9, %1\n\tv_mfma_f32_16x16x32_f16 %4, %7, %9, %4\n\tv_mfma_f32_16x16x32_f16 %2, %6, %10, %2\n\tv_mfma_f32_16x16x32_f16 %5, %7, %10, %5"
-                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2])
+                     : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2])
                      : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "n"(WAIT)
                      : "memory");
-    if constexpr (NT == 4)
+    if constexpr (N == 4)
         asm volatile("s_waitcnt lgkmcnt(%14)\n\tv_mfma_f32_16x16x32_f16 %0, %8, %10, %0\n\tv_mfma_f32_16x16x32_f16 %4, %9, %10, %4\n\tv_mfma_f32_16x16x32_f16 %1, %8, %11, %1\n\tv_mfma_f32_16x16x32_f16 %5, %9, %11, %5\n\tv_mfma_f32_16x16x32_f16 %2, %8, %12, %2\n\tv_mfma_f32_16x16x32_f16 %6, %9, %12, %6\n\tv_mfma_f32_16x16x32_f16 %3, %8, %13, %3\n\tv_mfma_f32_16x16x32_f16 %7, %9, %13, %7"
-                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c0[3]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2]), "+a"(c1[3])
+                     : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3])
                      : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
                      : "memory");
-    if constexpr (NT == 5)
+    if constexpr (N == 5)
         asm volatile("s_waitcnt lgkmcnt(%17)\n\tv_mfma_f32_16x16x32_f16 %0, %10, %12, %0\n\tv_mfma_f32_16x16x32_f16 %5, %11, %12, %5\n\tv_mfma_f32_16x16x32_f16 %1, %10, %13, %1\n\tv_mfma_f32_16x16x32_f16 %6, %11, %13, %6\n\tv_mfma_f32_16x16x32_f16 %2, %10, %14, %2\n\tv_mfma_f32_16x16x32_f16 %7, %11, %14, %7\n\tv_mfma_f32_16x16x32_f16 %3, %10, %15, %3\n\tv_mfma_f32_16x16x32_f16 %8, %11, %15, %8\n\tv_mfma_f32_16x16x32_f16 %4, %10, %16, %4\n\tv_mfma_f32_16x16x32_f16 %9, %11, %16, %9"
-                     : "+a"(c0[0]), "+a"(c0[1]), "+a"(c0[2]), "+a"(c0[3]), "+a"(c0[4]), "+a"(c1[0]), "+a"(c1[1]), "+a"(c1[2]), "+a"(c1[3]), "+a"(c1[4])
+                     : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c0[4]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), "+v"(c1[4])
                      : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "n"(WAIT)
+                     : "memory");
+}
+// the same with one map tile: N MFMAs a x b[0..N) into c[]
+template <int N, int WAIT>
+__device__ __forceinline__ void mfma_tiles1(float4v (&c)[N], const half8v& a, const half8v (&b)[N]) {
+    static_assert(N >= 1 && N <= 10, "mfma_tiles1: 1..10 tiles");
+    if constexpr (N == 1)
+        asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "+v"(c[0])
+                     : "v"(a), "v"(b[0]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 2)
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_f16 %1, %2, %4, %1\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "+v"(c[0]), "+v"(c[1])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 3)
+        asm volatile("s_waitcnt lgkmcnt(%7)\n\tv_mfma_f32_16x16x32_f16 %0, %3, %4, %0\n\tv_mfma_f32_16x16x32_f16 %1, %3, %5, %1\n\tv_mfma_f32_16x16x32_f16 %2, %3, %6, %2\n\ts_nop 7\n\ts_nop 3"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%9)\n\tv_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %6, %1\n\tv_mfma_f32_16x16x32_f16 %2, %4, %7, %2\n\tv_mfma_f32_16x16x32_f16 %3, %4, %8, %3\n\ts_nop 7\n\ts_nop 3"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(%11)\n\tv_mfma_f32_16x16x32_f16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %7, %1\n\tv_mfma_f32_16x16x32_f16 %2, %5, %8, %2\n\tv_mfma_f32_16x16x32_f16 %3, %5, %9, %3\n\tv_mfma_f32_16x16x32_f16 %4, %5, %10, %4"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt lgkmcnt(%13)\n\tv_mfma_f32_16x16x32_f16 %0, %6, %7, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %8, %1\n\tv_mfma_f32_16x16x32_f16 %2, %6, %9, %2\n\tv_mfma_f32_16x16x32_f16 %3, %6, %10, %3\n\tv_mfma_f32_16x16x32_f16 %4, %6, %11, %4\n\tv_mfma_f32_16x16x32_f16 %5, %6, %12, %5"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 7)
+        asm volatile("s_waitcnt lgkmcnt(%15)\n\tv_mfma_f32_16x16x32_f16 %0, %7, %8, %0\n\tv_mfma_f32_16x16x32_f16 %1, %7, %9, %1\n\tv_mfma_f32_16x16x32_f16 %2, %7, %10, %2\n\tv_mfma_f32_16x16x32_f16 %3, %7, %11, %3\n\tv_mfma_f32_16x16x32_f16 %4, %7, %12, %4\n\tv_mfma_f32_16x16x32_f16 %5, %7, %13, %5\n\tv_mfma_f32_16x16x32_f16 %6, %7, %14, %6"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(%17)\n\tv_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n\tv_mfma_f32_16x16x32_f16 %1, %8, %10, %1\n\tv_mfma_f32_16x16x32_f16 %2, %8, %11, %2\n\tv_mfma_f32_16x16x32_f16 %3, %8, %12, %3\n\tv_mfma_f32_16x16x32_f16 %4, %8, %13, %4\n\tv_mfma_f32_16x16x32_f16 %5, %8, %14, %5\n\tv_mfma_f32_16x16x32_f16 %6, %8, %15, %6\n\tv_mfma_f32_16x16x32_f16 %7, %8, %16, %7"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 9)
+        asm volatile("s_waitcnt lgkmcnt(%19)\n\tv_mfma_f32_16x16x32_f16 %0, %9, %10, %0\n\tv_mfma_f32_16x16x32_f16 %1, %9, %11, %1\n\tv_mfma_f32_16x16x32_f16 %2, %9, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %9, %13, %3\n\tv_mfma_f32_16x16x32_f16 %4, %9, %14, %4\n\tv_mfma_f32_16x16x32_f16 %5, %9, %15, %5\n\tv_mfma_f32_16x16x32_f16 %6, %9, %16, %6\n\tv_mfma_f32_16x16x32_f16 %7, %9, %17, %7\n\tv_mfma_f32_16x16x32_f16 %8, %9, %18, %8"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 10)
+        asm volatile("s_waitcnt lgkmcnt(%21)\n\tv_mfma_f32_16x16x32_f16 %0, %10, %11, %0\n\tv_mfma_f32_16x16x32_f16 %1, %10, %12, %1\n\tv_mfma_f32_16x16x32_f16 %2, %10, %13, %2\n\tv_mfma_f32_16x16x32_f16 %3, %10, %14, %3\n\tv_mfma_f32_16x16x32_f16 %4, %10, %15, %4\n\tv_mfma_f32_16x16x32_f16 %5, %10, %16, %5\n\tv_mfma_f32_16x16x32_f16 %6, %10, %17, %6\n\tv_mfma_f32_16x16x32_f16 %7, %10, %18, %7\n\tv_mfma_f32_16x16x32_f16 %8, %10, %19, %8\n\tv_mfma_f32_16x16x32_f16 %9, %10, %20, %9"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "n"(WAIT)
                      : "memory");
 }
 

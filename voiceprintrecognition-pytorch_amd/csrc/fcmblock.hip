@@ -7,19 +7,24 @@
 // (one unit = B * T * 64 bytes), and the fp16 rounding of the intermediate map disappears from the error budget
 // (profiles/r06_campp_error_budget.log).
 //
-// Workgroup = (utterance, time tile, band of output frequency rows), 4 waves, walking the band downwards one MID row per step:
-//   * the block input rows enter an LDS ring by LDS-DMA exactly as in fcm_band_kernel (each row once, LEAD steps ahead, counted
-//     s_waitcnt, zero page for the padding in time and frequency);
-//   * conv1 (9 MFMA taps, BN1 folded, ReLU) produces mid row m for the tile's positions plus one column of halo on each side and
-//     writes it as fp16 into ONE LDS slot (positions outside [0, T) are written as zeros: conv2 pads the mid map, not x);
-//   * conv2 is evaluated in scatter form: mid row m contributes to output rows m+1, m, m-1 through the tap rows df = 0, 1, 2, so the
-//     three output rows in progress live in three accumulator sets in registers and no ring of mid rows is needed; the shortcut
-//     (tenth tap on the centre input row sf*m, which is in the ring at this step; identity = the permuted unit matrix, exact) goes
-//     into the accumulators of row m; after the step row m-1 is complete: bias, ReLU, one 16-byte store per position (8 maps).
-//   * both convs keep their tap matrices in registers as MFMA A fragments with the rows permuted so that a lane owns 8 consecutive
-//     maps of one position (fcm.hip); one wave per SIMD, so the 152 weight + 160 accumulator registers fit.
-// Two barriers per step (ring rows landed / mid row written).  Bands only exist while (utterance, time tile) pairs do not fill the
-// chip (small batches); a band recomputes its two halo mid rows.
+// Workgroup = (utterance, time tile, band of output frequency rows) walking the band downwards one MID row per step, 8 waves in two
+// groups that share each SIMD's matrix pipe (one wave of each group per SIMD):
+//   * PRODUCERS (waves 0-3): the block input rows enter an LDS ring by LDS-DMA exactly as in fcm_band_kernel (each row once, LEAD
+//     steps ahead, counted s_waitcnt, zero page for the padding in time and frequency); conv1 (9 MFMA taps, BN1 folded, ReLU)
+//     produces mid row m for the tile's positions plus one column of halo on each side and writes it as fp16 into one of TWO LDS
+//     slots (positions outside [0, T) are written as zeros: conv2 pads the mid map, not x);
+//   * CONSUMERS (waves 4-7), one step behind: conv2 in scatter form -- mid row m contributes to output rows m+1, m, m-1 through the
+//     tap rows df = 0, 1, 2, so the three output rows in progress live in three accumulator sets in registers and no ring of mid
+//     rows is needed; the shortcut (tenth tap on the centre input row sf*m, which is in the ring while the producers work on mid row
+//     m; identity = the permuted unit matrix, exact) goes into the accumulators of row m when they are born; after mid row m row m-1
+//     is complete: bias, ReLU, one 16-byte store per position (8 maps);
+//   * each group keeps its tap matrices in registers as MFMA A fragments with the rows permuted so that a lane owns consecutive maps
+//     of one position (fcm.hip): a producer wave both map tiles of a quarter of the positions (8 maps per lane: 16-byte LDS
+//     writes), a consumer wave one map tile of half of the positions (4 maps per lane, 8-byte stores).
+// ONE barrier per step.  The first form of this kernel ran both convs on the same 4 waves (one wave per SIMD, two barriers per
+// step): 146-155 us for the 40-row blocks, the matrix pipe idle during both epilogues, the row requests and the barriers
+// (profiles/r06b); with two groups the epilogue / request / barrier time of one wave is matrix time of the other.
+// Bands only exist while (utterance, time tile) pairs do not fill the chip (small batches); a band recomputes its two halo mid rows.
 #include "kernels.h"
 
 namespace mv {
@@ -47,31 +52,33 @@ template <int NT, int SF>
 struct FcmBlk {
     static constexpr int MW = 64 * NT;             // mid positions per tile (4 waves x NT x 16): t0 - 1 ... t0 + MW - 2
     static constexpr int NTR = 4 * NT + 1;         // 1 KiB transfers per input row slot ((MW + 2) positions x 64 B rounded up)
-    static constexpr int TPW = NT + 1;             // transfers per wave and row
+    static constexpr int TPW = NT + 1;             // transfers per producer wave and row
     static constexpr int SLOT_BYTES = NTR * 1024;
     static constexpr int MID_BYTES = (MW + 2) * 64;  // + 2 positions that the masked last outputs read
     static constexpr int LDS_MAX = 160 * 1024;
-    static constexpr int lead_fit = ((LDS_MAX - 1024 - MID_BYTES) / SLOT_BYTES - 3) / SF;
+    static constexpr int lead_fit = ((LDS_MAX - 1024 - 2 * MID_BYTES) / SLOT_BYTES - 3) / SF;
     static constexpr int LEAD = lead_fit > 4 ? 4 : lead_fit;  // steps of input rows in flight beyond the current one
     static constexpr int RING = 3 + SF * LEAD;
     static constexpr int MID_OFF = RING * SLOT_BYTES;
-    static constexpr int DUMP_OFF = MID_OFF + MID_BYTES;
+    static constexpr int DUMP_OFF = MID_OFF + 2 * MID_BYTES;
     static constexpr int LDS_BYTES = DUMP_OFF + 1024;
     static constexpr int AHEAD = (LEAD - 1) * SF * TPW;  // transfers that may stay in flight when a step starts
     static_assert(LEAD >= 1 && LDS_BYTES <= LDS_MAX && AHEAD <= 63, "fcm block kernel: ring does not fit");
 };
 
 template <int PH>
-struct FbkPhase {
-    static constexpr int C = PH, N = (PH + 1) % 3, P = (PH + 2) % 3;
+struct FbkPhase {  // accumulator sets of the consumers' step i (PH = i % 3): born / centre / completed
+    static constexpr int N = PH, C = (PH + 2) % 3, P = (PH + 1) % 3;
 };
 
 template <int NT, int SF>
-__global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_ttiles, int n_bands, int band_rows) {
+__global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_ttiles, int n_bands, int band_rows) {
     typedef FcmBlk<NT, SF> G;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = MV_UNIFORM(tid >> 6);
+    const int wave8 = MV_UNIFORM(tid >> 6);
+    const int wave = wave8 & 3;          // position share inside the group
+    const bool producer = wave8 < 4;     // uniform
     const int fr = lane & 15, fg = lane >> 4;
     int wg = blockIdx.x;
     const int band = wg % n_bands;
@@ -88,182 +95,196 @@ __global__ __launch_bounds__(256) void fcm_block_kernel(FcmBlockArgs a, int n_tt
     const int rbase = SF * mlo - 1;                          // input row of ring index 0 (may be -1: zero padding)
     const int rel_last = SF * (nsteps - 1) + 2;              // last ring index the band needs
 
-    // ---- tap matrices: A fragments with permuted rows (A row i of tile mi <-> map 8*(i>>2) + 4*mi + (i&3)) ----
-    half8v w1f[9][2], w2f[10][2];
-    float bias1[2][4], bias2[2][4];
+    if (producer) {
+        const int pbase = wave * (16 * NT) + fr;
+        // this lane's fragment addresses for the three time taps: position pbase + dt of a ring slot (tile ni is 16 positions = 1024
+        // bytes further: 16 keeps the swizzle bits)
+        unsigned a_in[3];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);
+        for (int dt = 0; dt < 3; ++dt) a_in[dt] = lds_addr(smem) + (unsigned)fbk_off(pbase + dt, fg);
+        // ================= conv1: x rows (ring) -> mid row (LDS) =================
+        half8v w1f[9][2];
+        float bias1[2][4];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            w1f[tap][mi] = *reinterpret_cast<const half8v*>(a.w1 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
-            w2f[tap][mi] = *reinterpret_cast<const half8v*>(a.w2 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
+        for (int mi = 0; mi < 2; ++mi) {
+            const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);  // A row fr of tile mi <-> map co: a lane ends up with maps 8*fg .. 8*fg+7
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) w1f[tap][mi] = *reinterpret_cast<const half8v*>(a.w1 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias1[mi][r] = a.b1[8 * fg + 4 * mi + r];
         }
-        if (a.shortcut) {
-            w2f[9][mi] = *reinterpret_cast<const half8v*>(a.w2 + ((9 * FBK_C + co) * FBK_C + 8 * fg));
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w2f[9][mi][e] = (half_t)(8 * fg + e == co ? 1.0f : 0.0f);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bias1[mi][r] = a.b1[8 * fg + 4 * mi + r];
-            bias2[mi][r] = a.b2[8 * fg + 4 * mi + r];
-        }
-    }
-
-    // ---- this lane's share of a row transfer: slot position pi holds frame t0 + pi - 2 ----
-    const half_t* zero = reinterpret_cast<const half_t*>(g_fcmblk_zero_page);
-    int xoff[G::TPW];
-    bool xlive[G::TPW];
-#pragma unroll
-    for (int i = 0; i < G::TPW; ++i) {
-        const int j = wave + 4 * i;
-        const int q = j * 64 + lane;
-        const int pi = q >> 2;
-        const int c = (q & 3) ^ ((pi >> 1) & 3);
-        const int t = t0 + pi - 2;
-        xlive[i] = j < G::NTR;
-        xoff[i] = (xlive[i] && pi < G::MW + 2 && t >= 0 && t < a.T) ? t * FBK_C + c * 8 : -1;
-    }
-    char* const dump = smem + G::DUMP_OFF;
-    char* const mid = smem + G::MID_OFF;
-
-    int islot = 0, irel = 0;  // ring slot / ring index of the next row to be requested
-    auto issue_row = [&]() {
-        const int fin = rbase + irel;
-        const bool rok = fin >= 0 && fin < a.Fin && irel <= rel_last;  // uniform
-        const half_t* base = a.x + ((int64_t)b * a.Fin + (rok ? fin : 0)) * a.T * FBK_C;
-        char* slot = smem + islot * G::SLOT_BYTES;
+        // this lane's share of a row transfer: slot position pi holds frame t0 + pi - 2
+        const half_t* zero = reinterpret_cast<const half_t*>(g_fcmblk_zero_page);
+        int xoff[G::TPW];
+        bool xlive[G::TPW];
 #pragma unroll
         for (int i = 0; i < G::TPW; ++i) {
-            const half_t* src = (rok && xoff[i] >= 0) ? base + xoff[i] : zero;
-            glds16(src, xlive[i] ? slot + (wave + 4 * i) * 1024 : dump);
+            const int j = wave + 4 * i;
+            const int q = j * 64 + lane;
+            const int pi = q >> 2;
+            const int c = (q & 3) ^ ((pi >> 1) & 3);
+            const int t = t0 + pi - 2;
+            xlive[i] = j < G::NTR;
+            xoff[i] = (xlive[i] && pi < G::MW + 2 && t >= 0 && t < a.T) ? t * FBK_C + c * 8 : -1;
         }
-        ++irel;
-        islot = islot + 1 == G::RING ? 0 : islot + 1;
-    };
+        char* const dump = smem + G::DUMP_OFF;
+        int islot = 0, irel = 0;  // ring slot / ring index of the next row to be requested
+        auto issue_row = [&]() {
+            const int fin = rbase + irel;
+            const bool rok = fin >= 0 && fin < a.Fin && irel <= rel_last;  // uniform
+            const half_t* base = a.x + ((int64_t)b * a.Fin + (rok ? fin : 0)) * a.T * FBK_C;
+            char* slot = smem + islot * G::SLOT_BYTES;
+#pragma unroll
+            for (int i = 0; i < G::TPW; ++i) {
+                const half_t* src = (rok && xoff[i] >= 0) ? base + xoff[i] : zero;
+                glds16(src, xlive[i] ? slot + (wave + 4 * i) * 1024 : dump);
+            }
+            ++irel;
+            islot = islot + 1 == G::RING ? 0 : islot + 1;
+        };
 #pragma unroll 1
-    for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) issue_row();
+        for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) issue_row();
 
-    float4v acc2[3][2][NT];
+        int cslot = 0;  // ring slot of the first input row of the current step
+#pragma unroll 1
+        for (int i = 0; i < nsteps; ++i) {
+            wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
+            lds_barrier();        // ... in every wave; the consumers are done with the mid slot written now and with the ring slots requested next
+#pragma unroll
+            for (int s = 0; s < SF; ++s) issue_row();
+            // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
+            // groups, counted lgkmcnt)
+            float4v acc1[2][NT];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc1[mi][ni] = float4v{bias1[mi][0], bias1[mi][1], bias1[mi][2], bias1[mi][3]};
+            unsigned rowb[3];  // ring slots of the three input rows (uniform byte offsets)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                int sl = cslot + df;
+                sl = sl >= G::RING ? sl - G::RING : sl;
+                rowb[df] = (unsigned)(sl * G::SLOT_BYTES);
+            }
+            half8v bq[2][NT];
+            lds_read_tiles<NT>(bq[0], a_in[0] + rowb[0]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap < 8) {
+                    lds_read_tiles<NT>(bq[(tap + 1) & 1], a_in[(tap + 1) % 3] + rowb[(tap + 1) / 3]);
+                    mfma_tiles2<NT, NT>(acc1[0], acc1[1], w1f[tap][0], w1f[tap][1], bq[tap & 1]);
+                } else {
+                    mfma_tiles2<NT, 0>(acc1[0], acc1[1], w1f[8][0], w1f[8][1], bq[0]);
+                }
+            }
+            mfma_hazard_pad();
+            mfma_hazard_pad();
+            // mid row i -> slot i & 1 (positions t0 - 1 + p; zeros outside [0, T))
+            char* const mid = smem + G::MID_OFF + (i & 1) * G::MID_BYTES;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int p = pbase + ni * 16;
+                const int t = t0 - 1 + p;
+                const bool ok = t >= 0 && t < a.T;
+                half8v o;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[4 * mi + r] = ok ? (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f) : (half_t)0.0f;
+                *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
+            }
+            cslot += SF;
+            cslot = cslot >= G::RING ? cslot - G::RING : cslot;
+        }
+        lds_barrier();  // the consumers' last step
+        return;
+    }
+
+    // ================= conv2 (scatter form) + shortcut + ReLU: mid rows (LDS) -> output rows =================
+    // a consumer wave owns ONE map tile (16 of the 32 maps) over half of the tile's positions: three accumulator sets of 2 * NT
+    // position tiles = 24 * NT registers beside 40 of weights (with both map tiles per wave the sets alone would take 240 of the
+    // 256 registers a wave has at two waves per SIMD)
+    constexpr int N2 = 2 * NT;
+    const int cmi = wave & 1;
+    const int pbase = (wave >> 1) * (16 * N2) + fr;
+    unsigned a_in2, a_mid[3];
+    a_in2 = lds_addr(smem) + (unsigned)fbk_off(pbase + 2, fg);
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) a_mid[dt] = lds_addr(smem) + (unsigned)(G::MID_OFF + fbk_off(pbase + dt, fg));
+    half8v w2f[10];
+    float bias2[4];
+    {
+        const int co = 8 * (fr >> 2) + 4 * cmi + (fr & 3);  // A row fr <-> map co: the lane ends up with maps 8*fg + 4*cmi .. + 3
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) w2f[tap] = *reinterpret_cast<const half8v*>(a.w2 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
+        if (a.shortcut) {
+            w2f[9] = *reinterpret_cast<const half8v*>(a.w2 + ((9 * FBK_C + co) * FBK_C + 8 * fg));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w2f[9][e] = (half_t)(8 * fg + e == co ? 1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias2[r] = a.b2[8 * fg + 4 * cmi + r];
+    }
+    float4v acc2[3][N2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) acc2[s][mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ni = 0; ni < N2; ++ni) acc2[s][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 
-    const int pbase = wave * (16 * NT) + fr;
-    int cslot = 0;  // ring slot of the first input row of the current step
-    // this lane's fragment addresses for the three time taps: position pbase + dt of a ring slot / of the mid slot (tile ni is
-    // 16 positions = 1024 bytes further: 16 keeps the swizzle bits)
-    unsigned a_in[3], a_mid[3];
+    // output row `fo` from an accumulator set: bias, ReLU, 4 consecutive maps of one position per lane
+    auto store_row = [&](const float4v (&acc)[N2], int fo) __attribute__((always_inline)) {
+        half_t* yrow = a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF + 8 * fg + 4 * cmi;
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt) {
-        a_in[dt] = lds_addr(smem) + (unsigned)fbk_off(pbase + dt, fg);
-        a_mid[dt] = lds_addr(smem) + (unsigned)(G::MID_OFF + fbk_off(pbase + dt, fg));
-    }
-
-    // output row `fo` from accumulator set `s`: bias, ReLU, 8 consecutive maps of one position per lane
-    auto store_row = [&](const float4v (&acc)[2][NT], int fo) __attribute__((always_inline)) {
-        half_t* yrow = a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF + 8 * fg;
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
+        for (int ni = 0; ni < N2; ++ni) {
             const int j = pbase + ni * 16;
             const int t = t0 + j;
-            half8v o;
+            half4v o;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[4 * mi + r] = (half_t)fmed3(acc[mi][ni][r] + bias2[mi][r], 0.0f, 65504.0f);
-            if (j < a.tile_out && t < a.T) *MV_AS_GLOBAL(half8v, yrow + (int64_t)t * a.y_sT) = o;
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)fmed3(acc[ni][r] + bias2[r], 0.0f, 65504.0f);
+            if (j < a.tile_out && t < a.T) *MV_AS_GLOBAL(half4v, yrow + (int64_t)t * a.y_sT) = o;
         }
     };
 
+    int cslot = 0;
+    // step i (0 ... nsteps): the accumulators of output row mlo + i are born (set N) and take the shortcut tap from the centre
+    // input row of the producers' step i; mid row mlo + i - 1 (written in the producers' step i - 1) is scattered into the rows
+    // mlo + i (N), mlo + i - 1 (C), mlo + i - 2 (P); row mlo + i - 2 is then complete
     auto step = [&](auto ph, int i) __attribute__((always_inline)) {
         typedef decltype(ph) PH;
-        const int m = mlo + i;
-        wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
-        lds_barrier();        // ... in every wave; everybody is done with the mid slot and with the ring slots requested next
-#pragma unroll
-        for (int s = 0; s < SF; ++s) issue_row();
-
-        // ---- conv1 + BN1 + ReLU -> mid row m (positions t0 - 1 + p) ----
-        // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
-        // groups, counted lgkmcnt): with one wave per SIMD nobody else hides the LDS latency
-        float4v acc1[2][NT];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) acc1[mi][ni] = float4v{bias1[mi][0], bias1[mi][1], bias1[mi][2], bias1[mi][3]};
-        unsigned rowb[3];  // ring slots of the three input rows (uniform byte offsets)
-#pragma unroll
-        for (int df = 0; df < 3; ++df) {
-            int sl = cslot + df;
-            sl = sl >= G::RING ? sl - G::RING : sl;
-            rowb[df] = (unsigned)(sl * G::SLOT_BYTES);
-        }
-        half8v bq[2][NT];
-        lds_read_tiles<NT>(bq[0], a_in[0] + rowb[0]);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) {
-                lds_read_tiles<NT>(bq[(tap + 1) & 1], a_in[(tap + 1) % 3] + rowb[(tap + 1) / 3]);
-                mfma_tiles_acc<NT, NT>(acc1[0], acc1[1], w1f[tap][0], w1f[tap][1], bq[tap & 1]);
-            } else {
-                // the shortcut's fragments (centre input row, position + 2) ride behind the last tap
-                lds_read_tiles<NT>(bq[1], a_in[2] + rowb[1]);
-                mfma_tiles_acc<NT, NT>(acc1[0], acc1[1], w1f[8][0], w1f[8][1], bq[0]);
-            }
-        }
-        mfma_hazard_pad();
-        mfma_hazard_pad();
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const int p = pbase + ni * 16;
-            const int t = t0 - 1 + p;
-            const bool ok = t >= 0 && t < a.T;
-            half8v o;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[4 * mi + r] = ok ? (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f) : (half_t)0.0f;
-            *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
-        }
-        // ---- conv2 in scatter form: row m+1 is born, row m takes the shortcut and its centre taps, row m-1 is completed ----
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) acc2[PH::N][mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        // shortcut tap (x, not mid): its MFMAs run while the other waves arrive at the barrier
-        mfma_tiles_acc<NT, 0>(acc2[PH::C][0], acc2[PH::C][1], w2f[9][0], w2f[9][1], bq[1]);
         lds_barrier();
-        lds_read_tiles<NT>(bq[0], a_mid[0]);
+        half8v bq[N2];
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-            if (dt < 2) lds_read_tiles<NT>(bq[(dt + 1) & 1], a_mid[dt + 1]);
-            if (dt < 2) {
-                mfma_tiles_acc<NT, NT>(acc2[PH::N][0], acc2[PH::N][1], w2f[0 + dt][0], w2f[0 + dt][1], bq[dt & 1]);
-            } else {
-                mfma_tiles_acc<NT, 0>(acc2[PH::N][0], acc2[PH::N][1], w2f[0 + dt][0], w2f[0 + dt][1], bq[dt & 1]);
-            }
-            mfma_tiles_acc<NT, NT>(acc2[PH::C][0], acc2[PH::C][1], w2f[3 + dt][0], w2f[3 + dt][1], bq[dt & 1]);
-            mfma_tiles_acc<NT, NT>(acc2[PH::P][0], acc2[PH::P][1], w2f[6 + dt][0], w2f[6 + dt][1], bq[dt & 1]);
+        for (int ni = 0; ni < N2; ++ni) acc2[PH::N][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < nsteps) {
+            int sl = cslot + 1;  // centre input row = row sf * (mlo + i) of x; output position j <-> slot position j + 2
+            sl = sl >= G::RING ? sl - G::RING : sl;
+            lds_read_tiles<N2>(bq, a_in2 + (unsigned)(sl * G::SLOT_BYTES));
+            mfma_tiles1<N2, 0>(acc2[PH::N], w2f[9], bq);
         }
-        mfma_hazard_pad();
-        mfma_hazard_pad();
-        if (m - 1 >= f0) store_row(acc2[PH::P], m - 1);
-        if (i == nsteps - 1 && m < f1) store_row(acc2[PH::C], m);  // the band ends at the last row of the map
+        if (i > 0) {
+            const unsigned mo = (unsigned)(((i - 1) & 1) * G::MID_BYTES);
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                lds_read_tiles<N2>(bq, a_mid[dt] + mo);
+                mfma_tiles1<N2, 0>(acc2[PH::N], w2f[0 + dt], bq);
+                mfma_tiles1<N2, 0>(acc2[PH::C], w2f[3 + dt], bq);
+                mfma_tiles1<N2, 0>(acc2[PH::P], w2f[6 + dt], bq);
+            }
+            mfma_hazard_pad();
+            mfma_hazard_pad();
+            const int m = mlo + i - 1;  // the mid row just consumed
+            if (m - 1 >= f0) store_row(acc2[PH::P], m - 1);
+            if (i == nsteps && m < f1) store_row(acc2[PH::C], m);  // the band ends at the last row of the map
+        }
         cslot += SF;
         cslot = cslot >= G::RING ? cslot - G::RING : cslot;
     };
-
 #pragma unroll 1
-    for (int i = 0; i < nsteps; i += 3) {
+    for (int i = 0; i <= nsteps; i += 3) {
         step(FbkPhase<0>(), i);
-        if (i + 1 < nsteps) step(FbkPhase<1>(), i + 1);
-        if (i + 2 < nsteps) step(FbkPhase<2>(), i + 2);
+        if (i + 1 <= nsteps) step(FbkPhase<1>(), i + 1);
+        if (i + 2 <= nsteps) step(FbkPhase<2>(), i + 2);
     }
 }
 
@@ -284,7 +305,7 @@ static int fcm_block_launch_one(const FcmBlockArgs& a, int n_ttiles, hipStream_t
     const int band_rows = (int)ceil_div(a.Fout, n_bands);
     n_bands = (int)ceil_div(a.Fout, band_rows);
     MV_REQUIRE(pairs * n_bands < ((int64_t)1 << 31), "fcm_block: grid too large");
-    MV_LAUNCH((fcm_block_kernel<NT, SF>), ((unsigned)(pairs * n_bands), 1, 1), (256, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands, band_rows);
+    MV_LAUNCH((fcm_block_kernel<NT, SF>), ((unsigned)(pairs * n_bands), 1, 1), (512, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands, band_rows);
     return check_launch("fcm_block_kernel");
 }
 
