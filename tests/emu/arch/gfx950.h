@@ -163,6 +163,19 @@ template <int N, int WAIT>
 inline void mfma_tiles1(float4v (&c)[N], const half8v& a, const half8v (&b)[N]) {
     for (int i = 0; i < N; ++i) c[i] = emu_mfma_f32_16x16x32_f16(a, b[i], c[i]);
 }
+template <int N, int WAIT>
+inline void mfma_tiles2_init(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N], const float4v& i0,
+                             const float4v& i1) {
+    for (int i = 0; i < N; ++i) {
+        c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], i0);
+        c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], i1);
+    }
+}
+template <int N, int WAIT>
+inline void mfma_tiles1_init(float4v (&c)[N], const half8v& a, const half8v (&b)[N], const float4v& init) {
+    for (int i = 0; i < N; ++i) c[i] = emu_mfma_f32_16x16x32_f16(a, b[i], init);
+}
+inline void glds16_untracked_so_fresh(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) { glds16_untracked_so(sbase, voff, lds_wave_base_addr); }
 inline void mfma_hazard_pad() {}
 inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }
 

@@ -366,6 +366,98 @@ __device__ __forceinline__ void mfma_tiles1(float4v (&c)[N], const half8v& a, co
                      : "memory");
 }
 
+// first tap of an accumulation: c0[] | c1[] = (a0 | a1) x b[] + (i0 | i1) -- the initial value (a bias) is the MFMA's C operand, so the
+// accumulators need no initialisation instructions
+template <int N, int WAIT>
+__device__ __forceinline__ void mfma_tiles2_init(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N],
+                                                 const float4v& i0, const float4v& i1) {
+    static_assert(N >= 1 && N <= 5, "mfma_tiles2_init: 1..5 tiles");
+    if constexpr (N == 1)
+        asm volatile("s_waitcnt lgkmcnt(%7)\n\tv_mfma_f32_16x16x32_f16 %0, %2, %4, %5\n\tv_mfma_f32_16x16x32_f16 %1, %3, %4, %6\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c0[0]), "=&v"(c1[0])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(i0), "v"(i1), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 2)
+        asm volatile("s_waitcnt lgkmcnt(%10)\n\tv_mfma_f32_16x16x32_f16 %0, %4, %6, %8\n\tv_mfma_f32_16x16x32_f16 %2, %5, %6, %9\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, %8\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, %9\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c0[0]), "=&v"(c0[1]), "=&v"(c1[0]), "=&v"(c1[1])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(i0), "v"(i1), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 3)
+        asm volatile("s_waitcnt lgkmcnt(%13)\n\tv_mfma_f32_16x16x32_f16 %0, %6, %8, %11\n\tv_mfma_f32_16x16x32_f16 %3, %7, %8, %12\n\tv_mfma_f32_16x16x32_f16 %1, %6, %9, %11\n\tv_mfma_f32_16x16x32_f16 %4, %7, %9, %12\n\tv_mfma_f32_16x16x32_f16 %2, %6, %10, %11\n\tv_mfma_f32_16x16x32_f16 %5, %7, %10, %12"
+                     : "=&v"(c0[0]), "=&v"(c0[1]), "=&v"(c0[2]), "=&v"(c1[0]), "=&v"(c1[1]), "=&v"(c1[2])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(i0), "v"(i1), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%16)\n\tv_mfma_f32_16x16x32_f16 %0, %8, %10, %14\n\tv_mfma_f32_16x16x32_f16 %4, %9, %10, %15\n\tv_mfma_f32_16x16x32_f16 %1, %8, %11, %14\n\tv_mfma_f32_16x16x32_f16 %5, %9, %11, %15\n\tv_mfma_f32_16x16x32_f16 %2, %8, %12, %14\n\tv_mfma_f32_16x16x32_f16 %6, %9, %12, %15\n\tv_mfma_f32_16x16x32_f16 %3, %8, %13, %14\n\tv_mfma_f32_16x16x32_f16 %7, %9, %13, %15"
+                     : "=&v"(c0[0]), "=&v"(c0[1]), "=&v"(c0[2]), "=&v"(c0[3]), "=&v"(c1[0]), "=&v"(c1[1]), "=&v"(c1[2]), "=&v"(c1[3])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(i0), "v"(i1), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(%19)\n\tv_mfma_f32_16x16x32_f16 %0, %10, %12, %17\n\tv_mfma_f32_16x16x32_f16 %5, %11, %12, %18\n\tv_mfma_f32_16x16x32_f16 %1, %10, %13, %17\n\tv_mfma_f32_16x16x32_f16 %6, %11, %13, %18\n\tv_mfma_f32_16x16x32_f16 %2, %10, %14, %17\n\tv_mfma_f32_16x16x32_f16 %7, %11, %14, %18\n\tv_mfma_f32_16x16x32_f16 %3, %10, %15, %17\n\tv_mfma_f32_16x16x32_f16 %8, %11, %15, %18\n\tv_mfma_f32_16x16x32_f16 %4, %10, %16, %17\n\tv_mfma_f32_16x16x32_f16 %9, %11, %16, %18"
+                     : "=&v"(c0[0]), "=&v"(c0[1]), "=&v"(c0[2]), "=&v"(c0[3]), "=&v"(c0[4]), "=&v"(c1[0]), "=&v"(c1[1]), "=&v"(c1[2]), "=&v"(c1[3]), "=&v"(c1[4])
+                     : "v"(a0), "v"(a1), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(i0), "v"(i1), "n"(WAIT)
+                     : "memory");
+}
+template <int N, int WAIT>
+__device__ __forceinline__ void mfma_tiles1_init(float4v (&c)[N], const half8v& a, const half8v (&b)[N], const float4v& init) {
+    static_assert(N >= 1 && N <= 10, "mfma_tiles1_init: 1..10 tiles");
+    if constexpr (N == 1)
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %3\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c[0])
+                     : "v"(a), "v"(b[0]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 2)
+        asm volatile("s_waitcnt lgkmcnt(%6)\n\tv_mfma_f32_16x16x32_f16 %0, %2, %3, %5\n\tv_mfma_f32_16x16x32_f16 %1, %2, %4, %5\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c[0]), "=&v"(c[1])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 3)
+        asm volatile("s_waitcnt lgkmcnt(%8)\n\tv_mfma_f32_16x16x32_f16 %0, %3, %4, %7\n\tv_mfma_f32_16x16x32_f16 %1, %3, %5, %7\n\tv_mfma_f32_16x16x32_f16 %2, %3, %6, %7\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%10)\n\tv_mfma_f32_16x16x32_f16 %0, %4, %5, %9\n\tv_mfma_f32_16x16x32_f16 %1, %4, %6, %9\n\tv_mfma_f32_16x16x32_f16 %2, %4, %7, %9\n\tv_mfma_f32_16x16x32_f16 %3, %4, %8, %9\n\ts_nop 7\n\ts_nop 3"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(%12)\n\tv_mfma_f32_16x16x32_f16 %0, %5, %6, %11\n\tv_mfma_f32_16x16x32_f16 %1, %5, %7, %11\n\tv_mfma_f32_16x16x32_f16 %2, %5, %8, %11\n\tv_mfma_f32_16x16x32_f16 %3, %5, %9, %11\n\tv_mfma_f32_16x16x32_f16 %4, %5, %10, %11"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt lgkmcnt(%14)\n\tv_mfma_f32_16x16x32_f16 %0, %6, %7, %13\n\tv_mfma_f32_16x16x32_f16 %1, %6, %8, %13\n\tv_mfma_f32_16x16x32_f16 %2, %6, %9, %13\n\tv_mfma_f32_16x16x32_f16 %3, %6, %10, %13\n\tv_mfma_f32_16x16x32_f16 %4, %6, %11, %13\n\tv_mfma_f32_16x16x32_f16 %5, %6, %12, %13"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 7)
+        asm volatile("s_waitcnt lgkmcnt(%16)\n\tv_mfma_f32_16x16x32_f16 %0, %7, %8, %15\n\tv_mfma_f32_16x16x32_f16 %1, %7, %9, %15\n\tv_mfma_f32_16x16x32_f16 %2, %7, %10, %15\n\tv_mfma_f32_16x16x32_f16 %3, %7, %11, %15\n\tv_mfma_f32_16x16x32_f16 %4, %7, %12, %15\n\tv_mfma_f32_16x16x32_f16 %5, %7, %13, %15\n\tv_mfma_f32_16x16x32_f16 %6, %7, %14, %15"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(%18)\n\tv_mfma_f32_16x16x32_f16 %0, %8, %9, %17\n\tv_mfma_f32_16x16x32_f16 %1, %8, %10, %17\n\tv_mfma_f32_16x16x32_f16 %2, %8, %11, %17\n\tv_mfma_f32_16x16x32_f16 %3, %8, %12, %17\n\tv_mfma_f32_16x16x32_f16 %4, %8, %13, %17\n\tv_mfma_f32_16x16x32_f16 %5, %8, %14, %17\n\tv_mfma_f32_16x16x32_f16 %6, %8, %15, %17\n\tv_mfma_f32_16x16x32_f16 %7, %8, %16, %17"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 9)
+        asm volatile("s_waitcnt lgkmcnt(%20)\n\tv_mfma_f32_16x16x32_f16 %0, %9, %10, %19\n\tv_mfma_f32_16x16x32_f16 %1, %9, %11, %19\n\tv_mfma_f32_16x16x32_f16 %2, %9, %12, %19\n\tv_mfma_f32_16x16x32_f16 %3, %9, %13, %19\n\tv_mfma_f32_16x16x32_f16 %4, %9, %14, %19\n\tv_mfma_f32_16x16x32_f16 %5, %9, %15, %19\n\tv_mfma_f32_16x16x32_f16 %6, %9, %16, %19\n\tv_mfma_f32_16x16x32_f16 %7, %9, %17, %19\n\tv_mfma_f32_16x16x32_f16 %8, %9, %18, %19"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), "=&v"(c[8])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(init), "n"(WAIT)
+                     : "memory");
+    if constexpr (N == 10)
+        asm volatile("s_waitcnt lgkmcnt(%22)\n\tv_mfma_f32_16x16x32_f16 %0, %10, %11, %21\n\tv_mfma_f32_16x16x32_f16 %1, %10, %12, %21\n\tv_mfma_f32_16x16x32_f16 %2, %10, %13, %21\n\tv_mfma_f32_16x16x32_f16 %3, %10, %14, %21\n\tv_mfma_f32_16x16x32_f16 %4, %10, %15, %21\n\tv_mfma_f32_16x16x32_f16 %5, %10, %16, %21\n\tv_mfma_f32_16x16x32_f16 %6, %10, %17, %21\n\tv_mfma_f32_16x16x32_f16 %7, %10, %18, %21\n\tv_mfma_f32_16x16x32_f16 %8, %10, %19, %21\n\tv_mfma_f32_16x16x32_f16 %9, %10, %20, %21"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), "=&v"(c[8]), "=&v"(c[9])
+                     : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(init), "n"(WAIT)
+                     : "memory");
+}
+// glds16_untracked_so for a base the scalar ALU has just computed: a vector-memory instruction may read a scalar register only five
+// wait states after its write (s_nop 4), and m0 one state after its own (s_nop 0 inside)
+__device__ __forceinline__ void glds16_untracked_so_fresh(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_base_addr) : "memory", "m0");
+}
+
 // compute units of the current device (persistent kernels launch one workgroup per CU)
 inline int device_cu_count() {
     int dev = 0;

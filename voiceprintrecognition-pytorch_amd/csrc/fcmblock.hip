@@ -104,19 +104,23 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
         for (int dt = 0; dt < 3; ++dt) a_in[dt] = lds_addr(smem) + (unsigned)fbk_off(pbase + dt, fg);
         // ================= conv1: x rows (ring) -> mid row (LDS) =================
         half8v w1f[9][2];
-        float bias1[2][4];
+        float4v bias1v[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);  // A row fr of tile mi <-> map co: a lane ends up with maps 8*fg .. 8*fg+7
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) w1f[tap][mi] = *reinterpret_cast<const half8v*>(a.w1 + ((tap * FBK_C + co) * FBK_C + 8 * fg));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias1[mi][r] = a.b1[8 * fg + 4 * mi + r];
+            for (int r = 0; r < 4; ++r) bias1v[mi][r] = a.b1[8 * fg + 4 * mi + r];
         }
-        // this lane's share of a row transfer: slot position pi holds frame t0 + pi - 2
+        // this lane's share of a row transfer: slot position pi holds frame t0 + pi - 2.  Transfer i of this wave is the slot's KiB
+        // j = wave + 4 * i = positions 16 * j ... 16 * j + 15; whether all / none of its lanes lie inside [0, T) is known per wave,
+        // so a row request is TPW x (scalar slot address, scalar row base, per-lane 32-bit offset): the first form selected a 64-bit
+        // source pointer per lane and transfer and cost ~1000 cycles of issue per row (profiles/r06j timeline)
         const half_t* zero = reinterpret_cast<const half_t*>(g_fcmblk_zero_page);
-        int xoff[G::TPW];
-        bool xlive[G::TPW];
+        unsigned xoff[G::TPW];   // byte offset inside an input row
+        bool xok[G::TPW];        // this lane reads the row (otherwise zeros)
+        int xkind[G::TPW];       // uniform: 2 = every lane reads the row, 0 = none does (padding / dump transfer), 1 = mixed
 #pragma unroll
         for (int i = 0; i < G::TPW; ++i) {
             const int j = wave + 4 * i;
@@ -124,23 +128,47 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             const int pi = q >> 2;
             const int c = (q & 3) ^ ((pi >> 1) & 3);
             const int t = t0 + pi - 2;
-            xlive[i] = j < G::NTR;
-            xoff[i] = (xlive[i] && pi < G::MW + 2 && t >= 0 && t < a.T) ? t * FBK_C + c * 8 : -1;
+            const bool live = j < G::NTR;
+            xok[i] = live && pi < G::MW + 2 && t >= 0 && t < a.T;
+            xoff[i] = xok[i] ? (unsigned)(t * FBK_C + c * 8) * 2u : 0u;
+            const int tlo = t0 + 16 * j - 2, thi = tlo + 15;
+            const bool all = live && 16 * j + 15 < G::MW + 2 && tlo >= 0 && thi < a.T;
+            const bool none = !live || 16 * j >= G::MW + 2 || thi < 0 || tlo >= a.T;
+            xkind[i] = all ? 2 : (none ? 0 : 1);
         }
-        char* const dump = smem + G::DUMP_OFF;
+        const unsigned lds0 = lds_addr(smem);
+        const half8v zero8 = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
         int islot = 0, irel = 0;  // ring slot / ring index of the next row to be requested
-        auto issue_row = [&]() {
+        struct RowReq {            // one row request, uniform: source row (or the zero page) and ring slot
+            const half_t* base;
+            unsigned slot;
+            bool rok;
+        };
+        auto next_row = [&]() {
             const int fin = rbase + irel;
-            const bool rok = fin >= 0 && fin < a.Fin && irel <= rel_last;  // uniform
-            const half_t* base = a.x + ((int64_t)b * a.Fin + (rok ? fin : 0)) * a.T * FBK_C;
-            char* slot = smem + islot * G::SLOT_BYTES;
-#pragma unroll
-            for (int i = 0; i < G::TPW; ++i) {
-                const half_t* src = (rok && xoff[i] >= 0) ? base + xoff[i] : zero;
-                glds16(src, xlive[i] ? slot + (wave + 4 * i) * 1024 : dump);
-            }
+            RowReq r;
+            r.rok = fin >= 0 && fin < a.Fin && irel <= rel_last;
+            r.base = a.x + ((int64_t)b * a.Fin + (r.rok ? fin : 0)) * a.T * FBK_C;
+            r.slot = lds0 + (unsigned)(islot * G::SLOT_BYTES);
             ++irel;
             islot = islot + 1 == G::RING ? 0 : islot + 1;
+            return r;
+        };
+        // transfer i (0 ... TPW - 1) of a row request
+        auto issue_part = [&](const RowReq& r, int i) __attribute__((always_inline)) {
+            const int j = wave + 4 * i;
+            const unsigned dst = j < G::NTR ? r.slot + (unsigned)(j * 1024) : lds0 + (unsigned)G::DUMP_OFF;
+            if (r.rok && xkind[i] == 1) {  // a tile edge inside this transfer: per-lane source (row or zero page)
+                glds16_untracked(xok[i] ? reinterpret_cast<const char*>(r.base) + xoff[i] : reinterpret_cast<const char*>(zero), dst);
+            } else {                       // everything from the row, or everything from the zero page: scalar selects only
+                const bool from_row = r.rok && xkind[i] == 2;
+                glds16_untracked_so_fresh(from_row ? static_cast<const void*>(r.base) : static_cast<const void*>(zero), from_row ? xoff[i] : 0u, dst);
+            }
+        };
+        auto issue_row = [&]() {
+            const RowReq r = next_row();
+#pragma unroll
+            for (int i = 0; i < G::TPW; ++i) issue_part(r, i);
         };
 #pragma unroll 1
         for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) issue_row();
@@ -150,15 +178,15 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
         for (int i = 0; i < nsteps; ++i) {
             wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
             lds_barrier();        // ... in every wave; the consumers are done with the mid slot written now and with the ring slots requested next
+            // this step's row requests go out one or two per tap, behind that tap's MFMAs: a transfer takes ~150 cycles to issue
+            // (r06k timeline: 900 cycles for six in a row, with the matrix pipe idle), the ten MFMAs in front of it keep the pipe busy
+            // for as long
+            RowReq req[SF];
 #pragma unroll
-            for (int s = 0; s < SF; ++s) issue_row();
+            for (int s = 0; s < SF; ++s) req[s] = next_row();
             // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
             // groups, counted lgkmcnt)
-            float4v acc1[2][NT];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni) acc1[mi][ni] = float4v{bias1[mi][0], bias1[mi][1], bias1[mi][2], bias1[mi][3]};
+            float4v acc1[2][NT];  // born in the first tap: the bias is that MFMA's C operand
             unsigned rowb[3];  // ring slots of the three input rows (uniform byte offsets)
 #pragma unroll
             for (int df = 0; df < 3; ++df) {
@@ -170,12 +198,18 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             lds_read_tiles<NT>(bq[0], a_in[0] + rowb[0]);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                if (tap < 8) {
+                if (tap == 0) {
+                    lds_read_tiles<NT>(bq[1], a_in[1] + rowb[0]);
+                    mfma_tiles2_init<NT, NT>(acc1[0], acc1[1], w1f[0][0], w1f[0][1], bq[0], bias1v[0], bias1v[1]);
+                } else if (tap < 8) {
                     lds_read_tiles<NT>(bq[(tap + 1) & 1], a_in[(tap + 1) % 3] + rowb[(tap + 1) / 3]);
                     mfma_tiles2<NT, NT>(acc1[0], acc1[1], w1f[tap][0], w1f[tap][1], bq[tap & 1]);
                 } else {
                     mfma_tiles2<NT, 0>(acc1[0], acc1[1], w1f[8][0], w1f[8][1], bq[0]);
                 }
+#pragma unroll
+                for (int q = 0; q < SF * G::TPW; ++q)
+                    if (q * 9 / (SF * G::TPW) == tap) issue_part(req[q / G::TPW], q % G::TPW);
             }
             mfma_hazard_pad();
             mfma_hazard_pad();
@@ -186,11 +220,13 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                 const int p = pbase + ni * 16;
                 const int t = t0 - 1 + p;
                 const bool ok = t >= 0 && t < a.T;
+                const int tfirst = t0 - 1 + wave * (16 * NT) + ni * 16;  // uniform: the tile's positions tfirst ... tfirst + 15
                 half8v o;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[4 * mi + r] = ok ? (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f) : (half_t)0.0f;
+                    for (int r = 0; r < 4; ++r) o[4 * mi + r] = (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f);
+                if (tfirst < 0 || tfirst + 15 >= a.T) o = ok ? o : zero8;  // only edge tiles pay for the selects (scalar branch)
                 *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
             }
             cslot += SF;
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt) a_mid[dt] = lds_addr(smem) + (unsigned)(G::MID_OFF + fbk_off(pbase + dt, fg));
     half8v w2f[10];
-    float bias2[4];
+    float4v bias2;
     {
         const int co = 8 * (fr >> 2) + 4 * cmi + (fr & 3);  // A row fr <-> map co: the lane ends up with maps 8*fg + 4*cmi .. + 3
 #pragma unroll
@@ -226,51 +262,84 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias2[r] = a.b2[8 * fg + 4 * cmi + r];
     }
-    float4v acc2[3][N2];
+    // accumulator sets [set][half of this wave's positions][tile]; a set is born holding the bias
+    float4v acc2[3][2][NT];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int ni = 0; ni < N2; ++ni) acc2[s][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc2[s][h][ni] = bias2;
 
-    // output row `fo` from an accumulator set: bias, ReLU, 4 consecutive maps of one position per lane
-    auto store_row = [&](const float4v (&acc)[N2], int fo) __attribute__((always_inline)) {
-        half_t* yrow = a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF + 8 * fg + 4 * cmi;
+    // output row `fo` from an accumulator set: ReLU, 4 consecutive maps of one position per lane.  Address = uniform row / tile base
+    // (scalar registers) + one per-lane 32-bit byte offset: ten hoisted 64-bit tile addresses do not fit beside the accumulators.
+    const unsigned ylane = (unsigned)(((int64_t)(t0 + pbase) * a.y_sT + 8 * fg + 4 * cmi) * 2);
+    const int jlim = (a.tile_out < a.T - t0 ? a.tile_out : a.T - t0) - pbase;  // tile k of this lane is stored iff 16 * k < jlim
+    auto store_row = [&](const float4v (&acc)[2][NT], int fo) __attribute__((always_inline)) {
+        char* const yrow = reinterpret_cast<char*>(a.y + (int64_t)b * a.y_sB + (int64_t)fo * a.y_sF);  // uniform
+        const int64_t tile_bytes = 32 * a.y_sT;                                                          // 16 positions
 #pragma unroll
-        for (int ni = 0; ni < N2; ++ni) {
-            const int j = pbase + ni * 16;
-            const int t = t0 + j;
-            half4v o;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)fmed3(acc[ni][r] + bias2[r], 0.0f, 65504.0f);
-            if (j < a.tile_out && t < a.T) *MV_AS_GLOBAL(half4v, yrow + (int64_t)t * a.y_sT) = o;
-        }
+            for (int ni = 0; ni < NT; ++ni) {
+                const int k = h * NT + ni;
+                half4v o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)fmed3(acc[h][ni][r], 0.0f, 65504.0f);
+                if (16 * k < jlim) *MV_AS_GLOBAL(half4v, yrow + k * tile_bytes + ylane) = o;
+            }
     };
 
     int cslot = 0;
     // step i (0 ... nsteps): the accumulators of output row mlo + i are born (set N) and take the shortcut tap from the centre
     // input row of the producers' step i; mid row mlo + i - 1 (written in the producers' step i - 1) is scattered into the rows
-    // mlo + i (N), mlo + i - 1 (C), mlo + i - 2 (P); row mlo + i - 2 is then complete
+    // mlo + i (N), mlo + i - 1 (C), mlo + i - 2 (P); row mlo + i - 2 is then complete.
+    // Fragments are read half a wave-share (NT tiles) at a time into two register groups: the reads of one half are in flight under
+    // the MFMAs of the other.
     auto step = [&](auto ph, int i) __attribute__((always_inline)) {
         typedef decltype(ph) PH;
         lds_barrier();
-        half8v bq[N2];
-#pragma unroll
-        for (int ni = 0; ni < N2; ++ni) acc2[PH::N][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        if (i < nsteps) {
+        half8v bq[2][NT];
+        const bool sc = i < nsteps, sm = i > 0;  // uniform
+        const unsigned mo = (unsigned)(((i - 1) & 1) * G::MID_BYTES);
+        if (sc) {
             int sl = cslot + 1;  // centre input row = row sf * (mlo + i) of x; output position j <-> slot position j + 2
             sl = sl >= G::RING ? sl - G::RING : sl;
-            lds_read_tiles<N2>(bq, a_in2 + (unsigned)(sl * G::SLOT_BYTES));
-            mfma_tiles1<N2, 0>(acc2[PH::N], w2f[9], bq);
-        }
-        if (i > 0) {
-            const unsigned mo = (unsigned)(((i - 1) & 1) * G::MID_BYTES);
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt) {
-                lds_read_tiles<N2>(bq, a_mid[dt] + mo);
-                mfma_tiles1<N2, 0>(acc2[PH::N], w2f[0 + dt], bq);
-                mfma_tiles1<N2, 0>(acc2[PH::C], w2f[3 + dt], bq);
-                mfma_tiles1<N2, 0>(acc2[PH::P], w2f[6 + dt], bq);
+            const unsigned ra = a_in2 + (unsigned)(sl * G::SLOT_BYTES);
+            lds_read_tiles<NT>(bq[0], ra);
+            lds_read_tiles<NT>(bq[1], ra + NT * 1024);
+            // the set is born here: bias as the C operand of its first MFMAs (no initialisation instructions)
+            if (sm) {
+                mfma_tiles1_init<NT, NT>(acc2[PH::N][0], w2f[9], bq[0], bias2);
+                lds_read_tiles<NT>(bq[0], a_mid[0] + mo);
+                mfma_tiles1_init<NT, NT>(acc2[PH::N][1], w2f[9], bq[1], bias2);
+                lds_read_tiles<NT>(bq[1], a_mid[0] + mo + NT * 1024);
+            } else {
+                mfma_tiles1_init<NT, NT>(acc2[PH::N][0], w2f[9], bq[0], bias2);
+                mfma_tiles1_init<NT, 0>(acc2[PH::N][1], w2f[9], bq[1], bias2);
             }
+        } else {  // last step: no row is born (the set only collects the df = 0 taps of a row outside the band)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc2[PH::N][h][ni] = bias2;
+            lds_read_tiles<NT>(bq[0], a_mid[0] + mo);
+            lds_read_tiles<NT>(bq[1], a_mid[0] + mo + NT * 1024);
+        }
+        if (sm) {
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (dt == 2 && h == 1) {
+                        mfma_tiles1<NT, 0>(acc2[PH::N][h], w2f[0 + dt], bq[h]);
+                    } else {
+                        mfma_tiles1<NT, NT>(acc2[PH::N][h], w2f[0 + dt], bq[h]);
+                    }
+                    mfma_tiles1<NT, NT>(acc2[PH::C][h], w2f[3 + dt], bq[h]);
+                    mfma_tiles1<NT, NT>(acc2[PH::P][h], w2f[6 + dt], bq[h]);
+                    if (dt < 2) lds_read_tiles<NT>(bq[h], a_mid[dt + 1] + mo + h * (NT * 1024));
+                }
             mfma_hazard_pad();
             mfma_hazard_pad();
             const int m = mlo + i - 1;  // the mid row just consumed
