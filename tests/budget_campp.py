@@ -111,6 +111,46 @@ class Sim:
         return self.bn(xv.sub('dense.nonlinear.batchnorm'), emb)
 
 
+class Sim2(Sim):
+    """per-layer switches: names like 'w:layer1.0.conv1', 'm:layer1.0.mid', 'm:layer1.0.out', 'm:c1', 'm:rows'"""
+    def __init__(self, on, fine):
+        super().__init__(on); self.fine = set(fine); self.cur = ''
+    def fold(self, p, conv, bn, group, eps=1e-5):
+        w, t = super().fold(p, conv, bn, 'none')
+        name = 'w:' + p.prefix[len('head.'):] + conv
+        if name in self.fine: w = r16(w)
+        return w, t
+    def q(self, group, x):
+        if group.startswith('fcm_'):
+            return x  # handled in block override
+        return super().q(group, x)
+    def block(self, p, x, stride):
+        n = p.prefix[len('head.'):-1]
+        w1, t1 = self.fold(p, 'conv1', 'bn1', '')
+        mid = torch.relu(F.conv2d(x, w1, t1, stride=(stride, 1), padding=1))
+        if 'm:' + n + '.mid' in self.fine: mid = r16(mid)
+        w2, t2 = self.fold(p, 'conv2', 'bn2', '')
+        out = F.conv2d(mid, w2, t2, padding=1)
+        if p.has('shortcut.0.weight'):
+            ws, ts = self.fold(p, 'shortcut.0', 'shortcut.1', '')
+            x = F.conv2d(x, ws, ts, stride=(stride, 1))
+        out = torch.relu(out + x)
+        if 'm:' + n + '.out' in self.fine: out = r16(out)
+        return out
+    def fcm(self, p, x):
+        x = x.unsqueeze(1)
+        w, t = Sim.fold(self, p, 'conv1', 'bn1', 'none')
+        out = torch.relu(F.conv2d(x, w, t, padding=1))
+        if 'm:c1' in self.fine: out = r16(out)
+        for layer in ('layer1', 'layer2'):
+            out = self.block(p.sub(f'{layer}.0'), out, 2)
+            out = self.block(p.sub(f'{layer}.1'), out, 1)
+        w, t = self.fold(p, 'conv2', 'bn2', '')
+        out = torch.relu(F.conv2d(out, w, t, stride=(2, 1), padding=1))
+        if 'm:rows' in self.fine: out = r16(out)
+        return out.reshape(out.shape[0], out.shape[1] * out.shape[2], out.shape[3])
+
+
 ALL = ['w_fcm', 'w_xv', 'fcm_c1', 'fcm_mid', 'fcm_out', 'fcm_rows', 'xv_store', 'xv_pre', 'xv_h']
 
 
@@ -133,5 +173,26 @@ def main():
         print(f'{"only fcm_* maps":48s} {run([g for g in ALL if g.startswith("fcm_")]):.3e}')
 
 
+def per_layer():
+    """every FCM rounding site on its own (weights of each conv, each stored map): no single owner of the miss"""
+    man, sd, x, emb, _ = load_case(sys.argv[1] if len(sys.argv) > 1 else 'campp_stress')
+    blocks = ['layer1.0', 'layer1.1', 'layer2.0', 'layer2.1']
+    fine_all = (['m:c1', 'm:rows', 'w:conv2'] + [f'w:{b}.{c}' for b in blocks for c in ('conv1', 'conv2')] +
+                ['w:layer1.0.shortcut.0', 'w:layer2.0.shortcut.0'] + [f'm:{b}.{s}' for b in blocks for s in ('mid', 'out')])
+    xv = ['w_xv', 'xv_store', 'xv_pre', 'xv_h']
+    with torch.no_grad():
+        run = lambda on, fine: cos_dist(Sim2(on, fine).forward(sd, x), emb).max().item()
+        print(f'{"x-vector sites only (FCM exact)":48s} {run(xv, []):.3e}')
+        print(f'{"every site":48s} {run(xv, fine_all):.3e}')
+        for f in fine_all:
+            print(f'{"only " + f:48s} {run([], [f]):.3e}')
+        l1 = [f for f in fine_all if 'layer1' in f or f == 'm:c1']
+        print(f'{"x-vector + layer2 + head (layer1, c1 exact)":48s} {run(xv, [f for f in fine_all if f not in l1]):.3e}')
+        print(f'{"x-vector + layer1 + c1 (layer2, head exact)":48s} {run(xv, l1):.3e}')
+        print(f'{"x-vector + FCM weights only":48s} {run(xv, [f for f in fine_all if f.startswith("w:")]):.3e}')
+        print(f'{"x-vector + FCM maps only":48s} {run(xv, [f for f in fine_all if f.startswith("m:")]):.3e}')
+
+
 if __name__ == '__main__':
     main()
+    per_layer()
