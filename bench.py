@@ -22,8 +22,11 @@ Output: ONE JSON line on rank 0 (metric = utterances/sec embedded, BASELINE.json
   * ``h2d_inclusive`` (N=1): the same step with the waveform batch uploaded from pinned host memory inside the timed
     region (fp32, and int16 PCM converted on the device as ``predict_batch`` does),
   * ``other_configs`` (N=1, default model only): the other single-GPU shares of BASELINE.json's configs -- CAM++ (config 3),
-    EcapaTdnn-512 + MelSpectrogram (config 4, per-GPU share) and the ~55 M ERes2NetV2 on a 1-10 s length-bucketed batch
-    (config 5, per-GPU share) -- each with its own label, throughput and parity.
+    EcapaTdnn-512 + MelSpectrogram (config 4, per-GPU share: this rank's 256 rows scored against a 2048-row gallery) and the
+    ~55 M ERes2NetV2 on a 1-10 s length-bucketed batch (config 5, per-GPU share, with the conv2d class against the fp32 MFMA
+    peak) -- each with its own label, throughput and parity over EVERY row (config 5: one row of every length bucket),
+  * ``latency_batch1`` (N=1, default model only): p50 / p90 of a ``predict()``-shaped call -- one 3 s utterance resident on the
+    device -> features -> embedding -> host -- for EcapaTdnn-1024 and CAM++, eager launches and hipGraph replay.
 """
 import argparse
 import json
@@ -118,44 +121,60 @@ def one_minus_cos(a, b):
     return (1 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)).max().item()
 
 
-def short_run(name, dev, B, steps, warmup, parity_rows):
-    """throughput + parity of one of the other configurations (N=1, after the headline's timed region)"""
+def short_run(name, dev, B, steps, warmup, parity_rows, gallery_rows=0):
+    """throughput + parity of one of the other configurations (N=1, after the headline's timed region).  gallery_rows > B: the
+    scoring step of a sharded run (BASELINE config 4): this rank's B rows against a gallery of that many rows, as after the
+    all-gather -- the other rows are embeddings of other seeded batches, computed before the timed region."""
     from mvector import _hip
+    from oracle import scoring
     featurizer, model, state_cpu = build(name, dev)
     g = torch.Generator().manual_seed(1234)
     wav = (0.1 * torch.randn([B, SAMPLES], generator=g)).clamp(-1, 1).to(dev)
     with torch.no_grad():
+        gallery = None
+        if gallery_rows > B:
+            others = [model(featurizer((0.1 * torch.randn([B, SAMPLES], generator=g)).clamp(-1, 1).to(dev))) for _ in range(gallery_rows // B - 1)]
+            gallery = torch.cat([torch.zeros_like(others[0])] + others)   # rows [0, B) are overwritten by this rank's embeddings every step
         for _ in range(warmup):
             emb = model(featurizer(wav))
             _hip.cosine(emb, emb)
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fb_ms = 0.0
-        for _ in range(steps):
-            e[0].record()
+        for i in range(steps):
+            e[i][0].record()
             feats = featurizer(wav)
-            e[1].record()
+            e[i][1].record()
             emb = model(feats)
-            _hip.cosine(emb, emb)
+            if gallery is not None:
+                gallery[:B].copy_(emb)
+                scores = _hip.cosine(emb, gallery)
+            else:
+                scores = _hip.cosine(emb, emb)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        fb_ms = e[0].elapsed_time(e[1])
+        fb_ms = sum(a.elapsed_time(b) for a, b in e) / steps   # averaged over the timed steps (was: the last step only)
         ref, _ = oracle_embeddings(name, state_cpu, wav[:parity_rows].cpu())
     T = feats.shape[1]
     fb_gbs = B * frontend_bytes_per_utt(name, T) / (fb_ms * 1e-3) / 1e9
+    all_rows = gallery if gallery is not None else emb
+    score_err = float(abs(scores.cpu().numpy() - scoring.cosine_similarity(emb.cpu().numpy(), all_rows.cpu().numpy())).max())
     out = {'metric': metric_name(name, B), 'workload': MODELS[name][5], 'value': round(B * steps / dt, 1), 'unit': 'utterances/s',
            'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'dtype': 'f32' if MODELS[name][0].startswith('ERes2Net') else 'f16',
            'frontend_us': round(fb_ms * 1e3, 1), 'frontend_hbm_frac': round(fb_gbs / HBM_PEAK_GBS, 4),
-           'parity': {'max_one_minus_cos': one_minus_cos(emb[:parity_rows].cpu(), ref), 'utterances': parity_rows, 'tolerance': 1e-4}}
+           'parity': {'max_one_minus_cos': one_minus_cos(emb[:parity_rows].cpu(), ref), 'utterances': parity_rows, 'tolerance': 1e-4},
+           'cosine_block': {'shape': [int(scores.shape[0]), int(scores.shape[1])], 'max_abs_err_vs_oracle_scoring': score_err, 'tolerance': 2e-6}}
     if MODELS[name][4]:
         out['backbone_plus_frontend_tflops'] = round(B * MODELS[name][4] * steps / dt / 1e3, 1)
     return out
 
 
-def bucketed_run(name, dev, n_utt, passes, parity_rows):
-    """BASELINE config 5 (per-GPU share): variable-length 1-10 s utterances, <= 8 length buckets (mvector.parallel.embed_bucketed)"""
-    from mvector import parallel
+def bucketed_run(name, dev, n_utt, passes):
+    """BASELINE config 5 (per-GPU share): variable-length 1-10 s utterances, <= 8 length buckets (mvector.parallel.embed_bucketed).
+    Parity: the first row of EVERY bucket against the oracle with predict_batch semantics inside the bucket (padding to the bucket
+    maximum); roofline: the conv2d launches of one profiled pass (algorithmic FLOPs, HIP events) against the fp32 MFMA peak."""
+    import ctypes
+    from mvector import _hip, parallel
     from oracle import frontend as ofe, models as om
     featurizer, model, state_cpu = build(name, dev)
     cls, _, method, margs, _, label, _ = MODELS[name]
@@ -169,23 +188,90 @@ def bucketed_run(name, dev, n_utt, passes, parity_rows):
         emb = parallel.embed_bucketed(featurizer, model, waves, max_buckets=8, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # parity: the shortest bucket's first rows, with predict_batch semantics inside the bucket (padding to the bucket maximum)
-    idx = parallel.length_buckets(lens, 8)[0]
-    longest = max(lens[i] for i in idx)
-    rows = idx[:parity_rows]
-    padded = torch.zeros(len(idx), longest)
-    for r, i in enumerate(idx):
-        padded[r, :lens[i]] = waves[i].cpu()
-    ratio = torch.tensor([lens[i] / longest for i in idx], dtype=torch.float32)
+    cdll = _hip.lib()
+    n0, ms0, w0 = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    cdll.mv_profile_read(2, ctypes.byref(n0), ctypes.byref(ms0), ctypes.byref(w0), 1)   # reset the conv2d class
+    cdll.mv_profile_enable(1)
+    parallel.embed_bucketed(featurizer, model, waves, max_buckets=8, device=dev)
+    torch.cuda.synchronize()
+    cdll.mv_profile_enable(0)
+    _hip.check(cdll.mv_profile_read(2, ctypes.byref(n0), ctypes.byref(ms0), ctypes.byref(w0), 1), cdll)
+    conv_tflops = w0.value / (ms0.value * 1e-3) / 1e12 if ms0.value > 0 else 0.0
+    worst, rows = 0.0, 0
     with torch.no_grad():
-        ref = om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(padded[:len(rows)], ratio[:len(rows)], method, margs))
+        for idx in parallel.length_buckets(lens, 8):
+            longest = max(lens[i] for i in idx)
+            padded = torch.zeros(1, longest)
+            padded[0, :lens[idx[0]]] = waves[idx[0]].cpu()
+            ratio = torch.tensor([lens[idx[0]] / longest], dtype=torch.float32)
+            ref = om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(padded, ratio, method, margs))
+            worst = max(worst, one_minus_cos(emb[torch.tensor(idx[:1])].cpu(), ref))
+            rows += 1
     secs = sum(lens) / 16000.0
     return {'metric': f'utterances/sec embedded (1-10 s@16 kHz length-bucketed, Fbank-80, {cls} 54.9 M, {n_utt} utterances)',
             'workload': label.replace('3 s@16 kHz synthetic', f'{n_utt} utterances of 1-10 s (seeded uniform), 8 length buckets'),
             'value': round(n_utt * passes / dt, 1), 'unit': 'utterances/s', 'audio_seconds_per_s': round(secs * passes / dt, 1),
             'ms_per_pass': round(dt / passes * 1e3, 1), 'passes': passes, 'dtype': 'f32',
-            'parity': {'max_one_minus_cos': one_minus_cos(emb[torch.tensor(rows)].cpu(), ref), 'utterances': len(rows),
-                       'tolerance': 1e-4, 'rows': 'first rows of the shortest bucket'}}
+            'algorithmic_gflop_per_utt_conv2d': round(w0.value / n_utt / 1e9, 2),
+            'algorithmic_gflop_per_audio_second_conv2d': round(w0.value / secs / 1e9, 2),
+            'roofline': {'kernel': 'conv2d_kernel / conv2d_1x1_kernel (fp32 MFMA), all launches of one pass over the buckets', 'bound': 'mfma',
+                         'achieved': round(conv_tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(conv_tflops / MFMA_F32_PEAK_TFLOPS, 4), 'launches': n0.value,
+                         'share_of_pass': round(ms0.value / (dt / passes * 1e3), 3), 'traffic': None},
+            'parity': {'max_one_minus_cos': worst, 'utterances': rows, 'tolerance': 1e-4, 'rows': 'the first row of every length bucket'}}
+
+
+def latency_batch1(name, dev, n=200):
+    """A predict()-shaped call (mvector/predict.py:214-229): one 3 s utterance on the device -> features -> embedding -> host numpy.
+    p50 / p90 over n calls of the eager launch sequence and of a hipGraph replay of the same sequence (identical results)."""
+    import numpy as np
+    featurizer, model, _ = build(name, dev)
+    g = torch.Generator().manual_seed(99)
+    wav = (0.1 * torch.randn([1, SAMPLES], generator=g)).clamp(-1, 1).to(dev)
+    with torch.no_grad():
+        def fwd(w):
+            return model(featurizer(w))
+        for _ in range(5):
+            ref = fwd(wav)
+
+        def timed(call):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call().cpu()
+                ts.append((time.perf_counter() - t0) * 1e6)
+            return float(np.percentile(ts, 50)), float(np.percentile(ts, 90))
+        eager = timed(lambda: fwd(wav))
+        # GPU time of the same call (events on the launch stream): what is left of the latency is host time
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            fwd(wav)
+        e1.record()
+        torch.cuda.synchronize()
+        gpu_us = e0.elapsed_time(e1) / 20 * 1e3
+        static_in = wav.clone()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd(static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            out = fwd(static_in)
+
+        def replay():
+            graph.replay()
+            return out
+        replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out, ref))
+        graphed = timed(replay)
+    return {'workload': MODELS[name][5].replace('bs=256', 'bs=1'), 'unit': 'us', 'calls': n,
+            'eager_p50': round(eager[0], 1), 'eager_p90': round(eager[1], 1), 'gpu_us_back_to_back': round(gpu_us, 1),
+            'hipgraph_p50': round(graphed[0], 1), 'hipgraph_p90': round(graphed[1], 1), 'hipgraph_identical': same}
 
 
 def main():
@@ -340,6 +426,12 @@ def main():
             out['roofline_backbone'] = {'kernel': f'whole {cls} backbone stage ({bb_kernels})', 'bound': 'mfma',
                                         'achieved': round(bb_tflops, 1), 'peak': mfma_peak, 'unit': 'TFLOP/s',
                                         'frac': round(bb_tflops / mfma_peak, 4), 'algorithmic_gflop_per_utt': gflop_per_utt}
+            if args.model == 'ecapa1024':
+                # the kernels execute the hoisted ASP form: the mean / std columns of the [3C -> 128] attention conv become a
+                # per-utterance bias (2 * 2C * 128 * T FLOP less than pooling.py:110-117 spends); both figures are stated
+                ex = gflop_per_utt - 2 * 2 * 3072 * 128 * T / 1e9
+                out['roofline_backbone'].update({'executed_gflop_per_utt': round(ex, 3), 'achieved_executed': round(B * ex / (bb_ms * 1e-3) / 1e3, 1),
+                                                 'frac_executed': round(B * ex / (bb_ms * 1e-3) / 1e3 / mfma_peak, 4)})
         if world == 1:
             # ---- parity gate + CPU baseline (oracle = test infrastructure; outside the timed region) ----
             host_cores = os.cpu_count()
@@ -407,15 +499,23 @@ def main():
                                     'mvector.parallel.embed_stream (copy stream, no cosine block); never the headline value'}
             if args.model == 'ecapa1024' and not args.no_other_configs:
                 others = {}
-                for key, fn in (('config3_campp', lambda: short_run('campp', dev, B, 10, 3, 8)),
-                                ('config4_share_ecapa512_mel', lambda: short_run('ecapa512_mel', dev, B, 10, 3, 8)),
-                                ('config5_share_eres2netv2_bucketed', lambda: bucketed_run('eres2netv2_w96s4', dev, 64, 2, 2))):
+                for key, fn in (('config3_campp', lambda: short_run('campp', dev, B, 10, 3, B)),
+                                ('config4_share_ecapa512_mel', lambda: short_run('ecapa512_mel', dev, B, 10, 3, B, gallery_rows=8 * B)),
+                                ('config5_share_eres2netv2_bucketed', lambda: bucketed_run('eres2netv2_w96s4', dev, 64, 2))):
                     try:
                         others[key] = fn()
                     except Exception as ex:  # a failing side leg must not take the headline line with it
                         others[key] = {'error': f'{type(ex).__name__}: {ex}'}
                     torch.cuda.empty_cache()
                 out['other_configs'] = others
+                lat = {}
+                for key in ('ecapa1024', 'campp'):
+                    try:
+                        lat[key] = latency_batch1(key, dev)
+                    except Exception as ex:
+                        lat[key] = {'error': f'{type(ex).__name__}: {ex}'}
+                    torch.cuda.empty_cache()
+                out['latency_batch1'] = lat
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -372,3 +372,30 @@ def test_embed_stream_cpu_is_the_plain_loop():
     with torch.no_grad():
         for o, b in zip(outs, batches):
             assert torch.equal(o, m(fz(b.float() / 32768.0)))
+
+
+def test_embed_stream_cpu_applies_the_reference_db_normalisation():
+    """the CPU branch of embed_stream ignored target_db.  int16 rows of different loudness must come out as the
+    embeddings of the normalised waveforms (AudioSegment.normalize as called at predict.py:210-211: gain = target - 10 log10(mean x^2)),
+    a silent row stays unscaled."""
+    from mvector import parallel
+    from mvector.models import EcapaTdnn
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    man, sd, _, _, _ = load_case('ecapa_tiny')
+    m = EcapaTdnn(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval()
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+    wav = frontend.synth_waveforms(3, 8000, seed=5) * torch.tensor([0.05, 0.5, 0.0])[:, None]
+    pcm = (wav * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    (out,) = list(parallel.embed_stream(fz, m, [pcm], device='cpu', target_db=-20.0))
+    w = pcm.float() / 32768.0
+    ref = w.clone()
+    for i in range(2):
+        rms_db = 10.0 * torch.log10((w[i] ** 2).mean())
+        ref[i] = w[i] * 10.0 ** ((-20.0 - rms_db) / 20.0)
+    with torch.no_grad():
+        expect = m(fz(ref))
+    assert torch.allclose(out, expect, atol=1e-5) and torch.isfinite(out).all()
+    (plain,) = list(parallel.embed_stream(fz, m, [pcm], device='cpu'))
+    assert not torch.allclose(plain[:2], expect[:2], atol=1e-3)   # the gain matters for these rows

@@ -530,9 +530,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     InStats st;  // (INSTATS) time sums of the stage before the current one, reduced and stored under the current stage's MFMAs
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
-#if !defined(MV_PROBE) || MV_PROBE != 1   // probe 1: no global->LDS traffic in the K loop (tools/probe only)
         if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
-#endif
         const char* wt = smem + buf * STAGE_BYTES;
         if constexpr (INSTATS) {
             // the statistics of the stage in two halves, each behind one K half's MFMAs: the matrix pipe works off its 20 issues while
@@ -543,9 +541,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
             mma_half_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, 1, acc);
             input_stats_accumulate<TN>(st, wt + TC * CV_BK * 2, wave, lane);
         } else {
-#if !defined(MV_PROBE) || MV_PROBE != 2   // probe 2: no LDS reads / MFMAs in the K loop
             mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
-#endif
         }
         wait_all_loads();
         __syncthreads();
@@ -672,15 +668,11 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
                     const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
                     half8v ov;
                     __builtin_memcpy(&ov, o, 16);
-#if defined(MV_PROBE) && MV_PROBE == 4   // timing probe 4 (tools/probe only): the epilogue computes but never stores
-                    if (n < a.n_rows && a.ldy < 0) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
-#else
                     if (a.store_nt) {  // uniform
                         if (n < a.n_rows) store16_streaming(yrow + p * 32, o);
                     } else {
                         if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
                     }
-#endif
                 }
             }
         }
@@ -842,26 +834,12 @@ int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int 
     return check_launch("in_stats_finish_kernel");
 }
 
-// timing probe 3 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at four points of every stage
-#if defined(MV_PROBE) && MV_PROBE == 3
-__device__ unsigned long long g_trace[8192];
-__device__ int g_trace_n;
-#define MV_TRACE(tag)                                                                              \
-    do {                                                                                           \
-        if (blockIdx.x == 0 && tid == 0 && trace_i < 8190) g_trace[trace_i++] = (__builtin_readcyclecounter() << 2) | (tag); \
-    } while (0)
-#else
-#define MV_TRACE(tag) ((void)0)
-#endif
 
 template <bool SIMPLE, int STATS>
 __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a) {
     constexpr int WN = 4, MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x;
-#if defined(MV_PROBE) && MV_PROBE == 3
-    int trace_i = 0;
-#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / WN, wn = wave % WN;
@@ -993,17 +971,11 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
             if (more) prepare(0, buf ^ 1);
         }
         wait_all_loads();
-        MV_TRACE(0);
         __syncthreads();  // stage s has landed in `buf`; every wave is done with the other buffer
-        MV_TRACE(1);
         if (decltype(last)::value && more) {
             l_ps = l_ps == 2 ? 0 : l_ps + 1;
             issue_params();
         }
-#if defined(MV_PROBE) && MV_PROBE == 1   // timing probe 1 (tools/probe only): no global->LDS traffic inside a tile
-        if (!decltype(last)::value) feed = false;
-#endif
-        MV_TRACE(2);
         if (decltype(first)::value) {
             if (pending) persistent_epilogue<STATS>(a, LdsParams{smem + CVP_PARAM_OFF + e_ps * CVP_PARAM_SLOT, wc, lane >> 4}, e_n0, e_co0, wc, wn, lane, acc);
             // accumulators start from the bias of their 4 channels (parameter slot of the tile being computed)
@@ -1015,10 +987,6 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
             }
         }
-#if defined(MV_PROBE) && MV_PROBE == 2   // timing probe 2: no LDS reads / MFMAs
-        if (feed)
-            for (int i = 0; i < NTX + NTW; ++i) dma(i);
-#else
         const unsigned wt = smem_base + buf * CVP_STAGE_BYTES;
         // CVP_DMA_STEPS = over how many of the 8 MFMA steps the 8 transfers are spread (8: one per step; 4: two per step
         // in the first half, so the youngest transfer has half a stage more to land)
@@ -1035,8 +1003,6 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
                 }
             });
         }
-#endif
-        MV_TRACE(3);
         buf ^= 1;
     };
     using yes = std::integral_constant<bool, true>;
@@ -1052,22 +1018,8 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         pending = true;
     }
     persistent_epilogue<STATS>(a, LdsParams{smem + CVP_PARAM_OFF + e_ps * CVP_PARAM_SLOT, wc, lane >> 4}, e_n0, e_co0, wc, wn, lane, acc);
-#if defined(MV_PROBE) && MV_PROBE == 3
-    MV_TRACE(0);
-    if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
-#endif
 }
 
-#if defined(MV_PROBE) && MV_PROBE == 3
-extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
-    int n = 0;
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(int));
-    n = n < max_n ? n : max_n;
-    hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), (size_t)n * sizeof(unsigned long long));
-    return n;
-}
-#endif
 
 // Measured dead ends of the persistent kernel (r01s..r01v logs under profiles/): touching the lines of stage s+3 with one
 // 4-byte load each to pull them into L2 early (slower: the touches sit in the same in-order vmcnt queue; repeated in round 2
@@ -1128,9 +1080,6 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     constexpr int MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x;
-#if defined(MV_PROBE) && MV_PROBE == 3
-    int trace_i = 0;
-#endif
     const int lane = tid & 63;
     const int wave = MV_UNIFORM(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
     const int wc = wave / 4, wn = wave % 4;
@@ -1252,9 +1201,7 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
         } else {
             wait_vm<0>();
         }
-        MV_TRACE(0);
         lds_barrier();  // this stage has landed for every wave; every wave is done with the slots requested below
-        MV_TRACE(1);
         if (decltype(first)::value) {
             if (pending) persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
             if (c_co0 != held_co0) load_params(c_co0);  // uniform, at most once per launch on the shipped shapes
@@ -1266,7 +1213,6 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
             }
         }
-        MV_TRACE(2);
         const unsigned wt = smem_base + cw_slot * CVR_SLOT_BYTES, xt = smem_base + CVR_X_OFF + cx_slot * CVR_SLOT_BYTES;
         mma_stage_8x4(wt, xt, wc, wn, lane, acc, [&](int i) {
             if (i < 2) {
@@ -1285,7 +1231,6 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
                 if (do_x) x_advance();
             }
         });
-        MV_TRACE(3);
         x_ahead = do_x;
         cw_slot ^= 1;
         cx_slot = cx_slot == 2 ? 0 : cx_slot + 1;
@@ -1304,10 +1249,6 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
         c_co0 = co_tile * TC;
     }
     persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
-#if defined(MV_PROBE) && MV_PROBE == 3
-    MV_TRACE(0);
-    if (blockIdx.x == 0 && tid == 0) g_trace_n = trace_i;
-#endif
 }
 
 // Also measured on the ring kernel (r05r): the first stage of a tile requesting its transfers BEFORE the epilogue's stores, with the next

@@ -187,15 +187,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
             }
             if (q + FB_WAVES < nquads) load_quad(q + FB_WAVES, enext, epnext);
         } else {
-#if defined(MV_PROBE) && MV_PROBE == 3   // timing probe: samples from LDS instead of global memory
-#pragma unroll
-            for (int n1 = 0; n1 < NG; ++n1) {
-                e[n1] = cload(lwin + 32 * n1 + 2 * l16 + (q & 1));
-                eprev[n1] = lwin[32 * n1 + 2 * l16 + 3];
-            }
-#else
             load_quad(q, e, eprev);
-#endif
         }
         mask_tail(e);
         // ---- DC removal (frame mean over the `win` samples), pre-emphasis y[j] = d[j] - c d[j-1] and window:
@@ -232,9 +224,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
         for (int n2 = 0; n2 < 16; ++n2) z[n2] = slot[l16 * FB_TSTRIDE + n2];
         MV_WAVE_FENCE();
         // ---- stage 2: radix-16 over n2 -> Z[l16 + 16*k2] ----
-#if !defined(MV_PROBE) || MV_PROBE != 4   // timing probe 4: no second butterfly
         fft16(z);
-#endif
         // ---- real-input post-processing: X[k] from Z[k] and Z[256-k]; |X|^2 = (|2X|^2) / 4 ----
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) slot[l16 + 16 * k2] = z[k2];
@@ -270,11 +260,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
                 const int ngrp = a.tab.pass_steps[p] >> 2;
                 const float* ap = arow + mstart[p];
                 const float* bp = melb + moff * 64 + lane * 4;
-#if defined(MV_PROBE) && MV_PROBE == 1   // timing probe (tools/probe only): no mel loop
-                for (int g = 0; g < 0; ++g) {
-#else
                 for (int g = 0; g < ngrp; ++g) {
-#endif
                     const float4v av = *reinterpret_cast<const float4v*>(ap + 4 * g);
                     const float4v bv = *reinterpret_cast<const float4v*>(bp + g * 256);
                     acc = fb_mfma4(av[0], bv[0], acc);
@@ -302,9 +288,6 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
                     for (int r = 0; r < 4; ++r)  // the clamp keeps the argument normal: one v_log_f32 (log2) and a scale
                         val[r] = a.use_log ? fb_log2(fmaxf(acc[r], 1.1920928955078125e-07f)) * 0.69314718055994531f : acc[r];
                     float* dst = orow + (int64_t)q * 4 * nbins + m;
-#if defined(MV_PROBE) && MV_PROBE == 2   // timing probe: (almost) no stores
-                    if (val[0] != 12345.0f) continue;
-#endif
                     if (frames_here == 4) {
                         csum[p] += (val[0] + val[1]) + (val[2] + val[3]);
 #pragma unroll

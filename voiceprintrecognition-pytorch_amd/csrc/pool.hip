@@ -442,12 +442,8 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
         for (int tt = 0; tt < ntiles; ++tt) {
             const bool more = tt + 1 < ntiles;
             if (more) {  // next tile's rows are in flight while this tile computes
-#if !defined(MV_PROBE) || MV_PROBE != 2   // timing probes (tools/probe only): 1 = no x loads, 2 = no h loads, 3 = no element math
                 load_h((tt + 1) * 16, hnext);
-#endif
-#if !defined(MV_PROBE) || MV_PROBE != 1
                 load_x((tt + 1) * 16, xnext);
-#endif
             }
             // rows beyond T (last tile only) get a logit of -inf: e = 0, they add nothing
             const float voff = tt * 16 + fr < a.T ? 0.0f : -INFINITY;
@@ -462,10 +458,6 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
                     const half8v wf = lds_load_half8(wl, (mi * KS + kk) * 512);
                     l = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hcur[kk], l, 0, 0, 0);
                 }
-#if defined(MV_PROBE) && MV_PROBE == 3
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s0[mi][r] += l[r] + (float)xcur[r >> 1][r];
-#else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ci = 4 * mi + r;
@@ -487,7 +479,6 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
                         m[mi][r] = nm;
                     }
                 }
-#endif
             }
             if (more) {
 #pragma unroll
@@ -552,11 +543,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     const int b = blockIdx.y;
     const int c0 = (blockIdx.x * 4 + wave) * 64;  // (C is a multiple of 256 here: every wave has a tile and reaches every barrier)
     const int fr = lane & 15, fg = lane >> 4;
-#if defined(MV_PROBE) && MV_PROBE == 25   // probe: prologue + epilogue only
-    const int ntiles = a.T < 0 ? 1 : 0;
-#else
     const int ntiles = (a.T + 15) / 16;
-#endif
     const half_t* hb = a.h + (int64_t)b * a.T * a.A;
     const half_t* xb = a.x + (int64_t)b * a.T * a.ldx + c0;
     const int cl = c0 + 16 * fg;
@@ -578,11 +565,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     }
     const int64_t xstep = 16 * a.ldx;
     auto issue_x = [&](int tile, int slot) {
-#if defined(MV_PROBE) && MV_PROBE == 27   // probe: every address through the clamp + multiply path
-        const bool whole = false;
-#else
         const bool whole = tile * 16 + 16 <= a.T;  // uniform
-#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const half_t* src = xsrc[j];
@@ -603,11 +586,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     const half_t* hsrc = hb + (int64_t)hrow * a.A + hch;
     const int hstep = 16 * a.A;
     auto issue_h = [&](int tile, int slot) {
-#if defined(MV_PROBE) && MV_PROBE == 27
-        const bool whole = false;
-#else
         const bool whole = tile * 16 + 16 <= a.T;
-#endif
         const half_t* src = hsrc;
         if (!whole) {
             const int t = tile * 16 + hrow;
@@ -650,23 +629,12 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             l[mi] = float4v{voff, voff, voff, voff};
-#if !defined(MV_PROBE) || MV_PROBE != 24   // timing probes (tools/probe only): 21 = no x transfers, 22 = no h transfers, 23 = no element math, 24 = no MFMA
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) l[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], hf[kk], l[mi], 0, 0, 0);
-#else
-            for (int kk = 0; kk < KS; ++kk) l[mi][kk & 3] += (float)hf[kk][0] * (float)wf[mi][kk][0];
-#endif
         }
         lds_wait<0>(xv0, xv1);
     };
     auto pool = [&](const float4v (&l)[4], const half8v& xv0, const half8v& xv1) {
-#if defined(MV_PROBE) && MV_PROBE == 23
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            s0[mi][0] += float2v{l[mi][0], l[mi][1]};
-            s0[mi][1] += float2v{l[mi][2] + (float)xv0[mi], l[mi][3] + (float)xv1[mi]};
-        }
-#else
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -682,7 +650,6 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
                 s2[mi][q] = __builtin_elementwise_fma(ed, d, s2[mi][q]);
             }
         }
-#endif
     };
     issue_x(0, 0);
 #pragma unroll
@@ -726,12 +693,8 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     fetch(0, 0, 0, la, xa0, xa1);
     int hs = 5, xs = 0;  // ring slots of h(tt+5) and x(tt+6)
     auto step = [&](int tt, float4v (&lcur)[4], half8v& xc0, half8v& xc1, float4v (&lnext)[4], half8v& xn0, half8v& xn1) {
-#if !defined(MV_PROBE) || (MV_PROBE != 22 && MV_PROBE != 28)   // 28 = neither stream
         issue_h(tt + 5, hs);
-#endif
-#if !defined(MV_PROBE) || (MV_PROBE != 21 && MV_PROBE != 28)
         issue_x(tt + 6, xs);
-#endif
         wait_vm<14>();
         lds_barrier();
         hs = hs == ASP_HRING - 1 ? 0 : hs + 1;   // now the slot of h(tt)  ... and of h(tt+6) next step

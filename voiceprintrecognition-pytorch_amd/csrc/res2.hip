@@ -72,17 +72,6 @@ __device__ __forceinline__ void r2_wait_vm() { wait_vm<N>(); }
 __device__ __forceinline__ void r2_lds_barrier() { lds_barrier(); }
 __device__ __forceinline__ float r2_clamp_h(float v) { return fmed3(v, -65504.0f, 65504.0f); }  // fp16 saturation
 
-// timing probe 1 (tools/probe only): wave 0 of workgroup 0 logs s_memtime at tagged points (tools/trace_res2.py)
-#if defined(MV_PROBE) && MV_PROBE == 1
-__device__ unsigned long long g_r2_trace[4096];
-__device__ int g_r2_trace_n;
-#define R2_TRACE(tag)                                                                                              \
-    do {                                                                                                           \
-        if (blockIdx.x == 0 && tid == 0 && trace_i < 4090) g_r2_trace[trace_i++] = (__builtin_readcyclecounter() << 4) | (tag); \
-    } while (0)
-#else
-#define R2_TRACE(tag) ((void)0)
-#endif
 
 // MI = output channel tiles per wave (width = 64 * MI)
 template <int MI, bool DIRECT = false>
@@ -97,9 +86,6 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     char* abuf = smem + (DIRECT ? R2_XNEXT_BYTES : R2_RING * R2_WSTAGE_BYTES);   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = MV_UNIFORM(wave);
-#if defined(MV_PROBE) && MV_PROBE == 1
-    int trace_i = 0;
-#endif
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.x;
     const int T = a.T;
@@ -176,9 +162,9 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         load_ahead(1, 1, wf[1]);
     }
 
-    R2_TRACE(0);  // prologue done (slice copy + first input staged)
+
     for (int j = 1; j <= a.steps; ++j) {
-        R2_TRACE(1);  // step start
+
         const half_t* wj = a.w[j - 1];
         auto issue_w = [&](int s, int buf) {
             const int tap = s / kstages_per_tap;
@@ -217,9 +203,9 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             } else {
                 r2_wait_vm<0>();
             }
-            R2_TRACE(2);  // stage's weights (and everything older) landed
+
             r2_lds_barrier();
-            R2_TRACE(3);  // barrier passed
+
             if (s + R2_RING - 1 < nstages) issue_w(s + R2_RING - 1, (s + R2_RING - 1) % R2_RING);
             if constexpr (decltype(LAST)::value) {
 #pragma unroll
@@ -298,7 +284,6 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             };
             auto stage = [&](int s, half8v (&cur)[2][2], half8v (&ahead)[2][2], auto LAST) __attribute__((always_inline)) {
                 load_ahead(j, s + 2, ahead);
-                R2_TRACE(3);
                 const unsigned bp1 = b_addr(s, 1);
                 mfma10_step<0>(&acc[0][0], &acc[1][0], cur[0][0], cur[0][1], bA);
                 lds_read5<0, 16 * ROWB>(bA, bp1);  // (these registers were last sourced by the step above)
@@ -331,7 +316,6 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     mfma10_step<5>(&acc[0][NG], &acc[1][NG], cur[1][0], cur[1][1], bB);
                     lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, np0);
                 }
-                R2_TRACE(2);
             };
             r2_lds_barrier();  // publishes the activation buffer written by the previous epilogue (or the prologue); x_{j+1} of the
                                // previous step has been read by everyone
@@ -364,9 +348,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             for (int s = 0; s + 1 < nstages; ++s) do_stage(s, std::false_type{});
             do_stage(nstages - 1, std::true_type{});  // peeled: the x_{j+1} registers exist from here on only
         }
-        R2_TRACE(4);  // last stage's MFMAs issued
+
         r2_lds_barrier();  // every wave is done with the activation buffer and the weight ring
-        R2_TRACE(5);
         // ---- epilogue: y_j = BN(ReLU(acc + bias)); next input = x_{j+1} + y_j written over the activation buffer,
         //      rows 1..PAD and T-1-PAD..T-2 also into the halo rows that mirror them ----
         if constexpr (MI == 2) {
@@ -454,23 +437,10 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         }
         }
         // the next step's first stage barrier publishes these LDS writes
-        R2_TRACE(6);  // epilogue issued
+
     }
-#if defined(MV_PROBE) && MV_PROBE == 1
-    if (blockIdx.x == 0 && tid == 0) g_r2_trace_n = trace_i;
-#endif
 }
 
-#if defined(MV_PROBE) && MV_PROBE == 1
-extern "C" int mv_debug_trace_read(unsigned long long* dst, int max_n) {
-    int n = 0;
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_r2_trace_n), sizeof(int));
-    n = n < max_n ? n : max_n;
-    hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_r2_trace), (size_t)n * sizeof(unsigned long long));
-    return n;
-}
-#endif
 
 static bool res2_direct(int T, int width, int k) {  // (k * 2 K stages per step: the rotation of three fragment sets wants a multiple of 3)
     return R2_DIRECT && width == 128 && k % 3 == 0 && ((T + 3) & ~3) * width * 2 <= R2_XNEXT_BYTES;

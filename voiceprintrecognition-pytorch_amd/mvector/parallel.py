@@ -123,11 +123,16 @@ def embed_stream(featurizer, model, batches, device=None, target_db=None, depth=
     """Generator: embeddings (CPU tensors ``[B_i, D]`` in pinned memory; a result stays valid until the next-but-one result
     has been requested -- copy it to keep it) of an iterable of waveform batches, in order.
 
-    ``batches`` yields CPU tensors ``[B_i, L_i]``: int16 PCM (converted to float32 / 32768 on the device, with the
-    reference's dB normalisation when ``target_db`` is given, mvector/predict.py:185-212) or float32 waveforms, ideally in
-    pinned memory.  On a CUDA device the upload of batch i+1 and the download of batch i-1 run on a copy stream while batch i
-    computes on the caller's stream (``depth`` device / host buffers per shape); on the CPU it is the plain loop.
-    Results are identical to calling the featurizer and the model batch by batch."""
+    ``batches`` yields CPU tensors ``[B_i, L_i]``: int16 PCM (converted to float32 / 32768, with the reference's dB
+    normalisation when ``target_db`` is given, mvector/predict.py:185-212) or float32 waveforms, ideally in pinned memory.
+    On a CUDA device the upload of batch i+1 and the download of batch i-1 run on a copy stream while batch i computes on the
+    caller's stream.  Device memory is bounded: ``depth`` input slots and ``depth + 1`` pinned result slots, each a flat buffer
+    that only grows to the largest batch seen (a length-sorted evaluation list with a different ``L`` per batch reuses the
+    same slots; the first version kept one ring per distinct shape and grew without bound).
+
+    Contract for the producer: a yielded host batch is read by an ASYNCHRONOUS copy -- it must stay untouched until the result
+    of that batch has been returned (a producer that refills one pinned staging buffer needs ``depth + 1`` of them).
+    Results are identical to calling the featurizer and the model batch by batch, on the GPU and on the CPU."""
     if device is None:
         device = next(model.parameters()).device
     device = torch.device(device)
@@ -140,35 +145,49 @@ def embed_stream(featurizer, model, batches, device=None, target_db=None, depth=
 
     if device.type != 'cuda':
         for host in batches:
-            w = host.to(torch.float32) / 32768.0 if host.dtype == torch.int16 else host
+            if host.dtype == torch.int16:
+                w = host.to(torch.float32) / 32768.0
+                if target_db is not None:  # AudioSegment.normalize (predict.py:210-211): gain from the mean square over the row
+                    rms_db = 10.0 * torch.log10(w.pow(2).mean(dim=1, keepdim=True).clamp_min(1e-30))
+                    gain = target_db - rms_db
+                    w = torch.where(gain <= 300.0, w * torch.pow(10.0, gain / 20.0), w)  # silence stays unscaled, as on the device
+            else:
+                w = host
             yield model(featurizer(w))
         return
 
     import collections
     main = torch.cuda.current_stream(device)
     copy = torch.cuda.Stream(device)
-    in_bufs, out_bufs = {}, {}       # (shape, dtype) -> ring of device input buffers; (rows, dim) -> ring of pinned result buffers
-    in_free = {}                     # id(device buffer) -> event: the compute that read it has finished
-    out_free = {}                    # id(pinned buffer) -> event: its download has finished (waited for when the ring wraps)
     inflight = collections.deque()   # (pinned result, download event), oldest first
-    counter = {}
 
-    def ring(store, key, make, size):
-        bufs = store.setdefault(key, [])
-        n = counter.get((id(store), key), 0)
-        counter[(id(store), key)] = n + 1
-        if len(bufs) < size:
-            bufs.append(make())
-            return bufs[-1]
-        return bufs[n % size]
+    class Slots:
+        """ring of flat buffers that grow on demand; ``free[k]`` = event after which slot k may be overwritten"""
+
+        def __init__(self, n, make):
+            self.n, self.make, self.bufs, self.free, self.count = n, make, [None] * n, [None] * n, 0
+
+        def take(self, shape, dtype, wait):
+            k = self.count % self.n
+            self.count += 1
+            if self.free[k] is not None:
+                wait(self.free[k])
+            numel = 1
+            for d in shape:
+                numel *= int(d)
+            nbytes = numel * torch.empty((), dtype=dtype).element_size()
+            if self.bufs[k] is None or self.bufs[k].numel() < nbytes:
+                if self.free[k] is not None:
+                    self.free[k].synchronize()   # the old buffer is released: its last reader must be done
+                self.bufs[k] = self.make(nbytes)
+            return k, self.bufs[k][:nbytes].view(dtype).view(tuple(shape))
+
+    dev_slots = Slots(depth, lambda n: torch.empty(n, dtype=torch.uint8, device=device))
+    out_slots = Slots(depth + 1, lambda n: torch.empty(n, dtype=torch.uint8).pin_memory())
 
     for host in batches:
-        key = (tuple(host.shape), host.dtype)
-        dev_in = ring(in_bufs, key, lambda: torch.empty(host.shape, dtype=host.dtype, device=device), depth)
         with torch.cuda.stream(copy):
-            ev = in_free.get(id(dev_in))
-            if ev is not None:
-                copy.wait_event(ev)          # the batch that used this buffer `depth` uploads ago has been consumed
+            k_in, dev_in = dev_slots.take(host.shape, host.dtype, copy.wait_event)  # the batch `depth` uploads ago has been consumed
             dev_in.copy_(host, non_blocking=True)
             up = torch.cuda.Event()
             up.record(copy)
@@ -176,19 +195,15 @@ def embed_stream(featurizer, model, batches, device=None, target_db=None, depth=
         emb = compute(dev_in)
         done = torch.cuda.Event()
         done.record(main)
-        in_free[id(dev_in)] = done
-        okey = tuple(emb.shape)
-        host_out = ring(out_bufs, okey, lambda: torch.empty(emb.shape, dtype=emb.dtype).pin_memory(), depth + 1)
-        prev = out_free.get(id(host_out))
-        if prev is not None:
-            prev.synchronize()               # (its result was handed out long ago)
+        dev_slots.free[k_in] = done
+        k_out, host_out = out_slots.take(emb.shape, emb.dtype, lambda ev: ev.synchronize())  # (its result was handed out long ago)
         with torch.cuda.stream(copy):
             copy.wait_event(done)
             host_out.copy_(emb, non_blocking=True)
             down = torch.cuda.Event()
             down.record(copy)
         emb.record_stream(copy)              # the allocator must not hand `emb` out again before the download has read it
-        out_free[id(host_out)] = down
+        out_slots.free[k_out] = down
         inflight.append((host_out, down))
         while len(inflight) >= depth:        # keep `depth - 1` batches in flight behind the one being submitted
             res, ev = inflight.popleft()
