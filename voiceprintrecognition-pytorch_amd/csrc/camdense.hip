@@ -27,7 +27,13 @@
 // would remove the fixed part.  Measured, r05t: the layers of a block in ONE launch -- layer loop inside the kernel, s_waitcnt vmcnt(0) +
 // barrier between layers, arguments as an array in the kernel argument segment -- is correct and 3 % SLOWER end to end (101.3 k -> 98.4 k
 // utt/s): between two launches the store drain of one workgroup overlaps with the start of the next kernel's workgroup on the same CU,
-// inside one workgroup it is a wait.)  Default cache policy on these loads: the block's buffer --
+// inside one workgroup it is a wait.)  Round 3 timeline (profiles/r07b_cam_dense_inkernel_timeline.log, mean over the 52 layers,
+// 24.4 us): BN1 tables 1.0 us, parameters + first x stage 5.6 us, stage loop 11.7 us (1.3 us per stage), h 1.2, context 2.6,
+// k = 3 conv + stores 2.3.  Moving the parameter requests behind the last stage's transfers (r07c) only moves the wait behind the
+// loop (4 us: every workgroup of the launch asks the same L2 lines for the same 90 KB at the same moment) -- the fixed part of a
+// layer is memory latency of a chip-wide synchronised start, which only a prefetch across the layer boundary (persistent
+// per-block kernel that requests layer l + 1's parameters and first stages under layer l's context phase) removes.
+// Default cache policy on these loads: the block's buffer --
 // 78 MB for 256 utterances -- is re-read by every later layer and lives in the 256 MB Infinity Cache; non-temporal loads measured
 // 1.5-2.6 TB/s, r03i.
 #include <type_traits>
