@@ -6,8 +6,13 @@
 // Precision: fp32 maps, fp32 weights, v_mfma_f32_16x16x4_f32.  Unlike the TDNN-style backbones this family does not
 // tolerate 11-bit operands: ~50 clamped layers amplify a relative perturbation of 1e-6 at the input to 2e-4 at the
 // embedding, and rounding either the weights or the activations to fp16 moves the embedding by 6-8 % (1 - cos 2e-3..5e-3
-// against the 1e-4 bar; measured with the oracle).  The fp32 matrix pipe runs at a quarter of the
-// fp16 rate, which these small-channel, memory-heavy layers can afford.
+// against the 1e-4 bar; measured with the oracle).  The fp32 matrix pipe runs at 1/16 of the fp16 rate
+// (157 vs 2500 TFLOP/s, MI355X_MICROARCH.md), so a hi + lo fp16 split of both operands (3 MFMA passes) would cut the matrix
+// time 5.3 x -- but the matrix pipe is not what these layers wait for: with only ONE of every four fp32 MFMAs issued (wrong
+// results, same loads / staging / stores: tools/probe_conv2d.py, profiles/r07e) the 54.9 M ERes2NetV2 runs 99.5 -> 77.1 ms
+// (1.29 x) and the m32 model 36.9 -> 32.4 ms (1.14 x).  That is the upper bound of the split before its own cost (three VALU
+// operations per activation element to form hi / lo); the family is bound by operand delivery -- fp32 activation traffic on the
+// large maps, weight fetch latency on the small ones -- and stays on the fp32 pipe.
 //
 // Layout: feature maps are channel-last fp32 [B, H = frequency, W = time, C]; the channel counts of the model (13 ... 512)
 // are padded to multiples of 16 when the weights are packed (zero rows / columns), so padded channels carry exact zeros.
