@@ -166,7 +166,8 @@ def test_emu_melspec_fft_kernel_and_dft_kernel(monkeypatch):
     """default geometry (n_fft 400, 128 mels) = melspec_tile_kernel: edge frames with reflect padding, a masked row, feature
     rows beyond the LDS block (T = 241 > 212 rows) and fewer; MV_MELSPEC_IMPL=dft keeps the dense-DFT kernels alive"""
     assert _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
-    assert not _hip.MelSpec(dict(n_fft=512), cdll=emu_cdll()).info()['tile_kernel']
+    assert _hip.MelSpec(dict(n_fft=512), cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
+    assert not _hip.MelSpec(dict(n_fft=600, win_length=600), cdll=emu_cdll()).info()['tile_kernel']   # neither 400 nor a power of two: dense DFT
     wav = frontend.synth_waveforms(2, 48000, seed=31)
     lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([0.71, 1.0]), {})          # T = 241: 212 rows in LDS, 29 through global
     lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :5000 + 3], None, {})                # T = 26, odd length
@@ -182,9 +183,33 @@ def test_emu_melspec_default_and_masked():
 
 
 def test_emu_melspec_other_geometry():
+    """n_fft 256 with a shorter window = melspec_pow2_kernel on the zero-extended frame (every fourth bin of the 1024-point transform);
+    n_fft 600 = dense DFT"""
     wav = frontend.synth_waveforms(1, 1500, seed=13)
-    lc.melspec_case(emu_cdll(), 'cpu', wav, None, dict(sample_rate=16000, n_fft=256, win_length=200, hop_length=80, f_min=50,
-                                                      f_max=7000, n_mels=40))
+    args = dict(sample_rate=16000, n_fft=256, win_length=200, hop_length=80, f_min=50, f_max=7000, n_mels=40)
+    assert _hip.MelSpec(args, cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
+    lc.melspec_case(emu_cdll(), 'cpu', wav, None, args)
+    lc.melspec_case(emu_cdll(), 'cpu', wav, None, dict(sample_rate=16000, n_fft=600, win_length=600, hop_length=150, n_mels=32))
+
+
+def test_emu_melspec_pow2_kernel_readme_geometry():
+    """the reference README's MelSpectrogram run (n_fft 1024, hop 320, 64 mels, f_max above Nyquist: README_en.md:263-269) and
+    n_fft 512 with 128 mels (two mel passes), both on melspec_pow2_kernel: edge frames (reflect padding), a masked row, a ragged last
+    quad of frames; MV_MELSPEC_IMPL=dft keeps the dense-DFT kernels alive"""
+    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    assert _hip.MelSpec(readme, cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
+    wav = frontend.synth_waveforms(2, 7000, seed=14)
+    lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([1.0, 0.6]), readme)
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :3333], None, dict(n_fft=512, hop_length=128))
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :2000], None, dict(n_fft=512, win_length=400, hop_length=200, center=False, n_mels=80))
+
+
+def test_emu_melspec_pow2_kernel_matches_reference_wrapper_golden():
+    z = np.load(os.path.join(GOLDEN, 'featurizer_ref.npz'))
+    wav = frontend.synth_waveforms(4, 48000)[:1]   # the waveforms oracle/make_golden.py fed to the reference's wrapper
+    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    out = _hip.MelSpec(readme, cdll=emu_cdll())(wav).numpy()
+    assert np.abs(out - z['mel_readme']).max() < 2e-4 * float(np.abs(z['mel_readme']).max())
 
 
 @pytest.mark.parametrize('cfg', [dict(), dict(online=True), dict(B=5, T=9, C=72, A=64, ldx=80, centred=False),

@@ -499,7 +499,16 @@ def test_gpu_melspec_golden_and_variants():
     outv = ms(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy()[2:]
     assert np.abs(outv - z['mel_var']).max() <= 2e-4 * np.abs(z['mel_var']).max()
     readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    from mvector import _hip
+    assert _hip.MelSpec(readme).info()['kernel'] == 'melspec_pow2_kernel'   # the README's run takes the FFT kernel (round 3), not the dense DFT
     lc.melspec_case(product_lib(), DEV, wav[:1], None, readme)
+    lc.melspec_case(product_lib(), DEV, frontend.synth_waveforms(5, 48000, seed=8), torch.tensor([1.0, 0.4, 0.77, 0.5, 0.9]), readme)
+    for n_fft, extra in ((512, dict(hop_length=128)), (256, dict(win_length=200, hop_length=80, n_mels=40, f_min=50, f_max=7000)),
+                         (128, dict(hop_length=64, n_mels=32)), (512, dict(center=False, n_mels=80))):
+        args = dict(n_fft=n_fft, **extra)
+        assert _hip.MelSpec(args).info()['kernel'] == 'melspec_pow2_kernel'
+        lc.melspec_case(product_lib(), DEV, frontend.synth_waveforms(3, 20000 + 13, seed=n_fft), torch.tensor([1.0, 0.35, 0.8]), args)
+    lc.melspec_case(product_lib(), DEV, frontend.synth_waveforms(2, 160000, seed=9), None, readme)   # 10 s: 501 frames, beyond the LDS tile
     lc.melspec_case(product_lib(), DEV, frontend.synth_waveforms(3, 16000 + 37, seed=5), torch.tensor([1.0, 0.3, 0.81]), {})
 
 

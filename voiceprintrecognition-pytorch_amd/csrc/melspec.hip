@@ -20,6 +20,7 @@
 
 #include "frontend_common.h"
 #include "kernels.h"
+#include "melfft.h"
 
 namespace mv {
 
@@ -514,6 +515,10 @@ struct MvMelSpec {
     float* d_tw400 = nullptr;
     float* d_melb = nullptr;
     mv::MelPlan plan;
+    // melspec_pow2_kernel (power-of-two n_fft <= 1024, melfft.hip)
+    bool pow2_kernel = false;
+    float* d_tw512 = nullptr;
+    float* d_w1024 = nullptr;
 };
 
 // instantiated mel geometry: 128 HTK filters over 0 .. 8 kHz on the 201 bins of n_fft = 400 = two passes of 16 filter groups
@@ -629,13 +634,41 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
             }
         }
     }
+    // ---- FFT path for power-of-two transforms (melspec_pow2_kernel: the README's n_fft 1024 / hop 320 / 64 mels, and 128 ... 512) ----
+    if (!h->tile_kernel && (n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024) && cfg->power == 2.0f && (cfg->n_mels & 3) == 0 &&
+        cfg->n_mels <= 128) {
+        std::vector<std::vector<float>> banks(cfg->n_mels, std::vector<float>(h->nbin, 0.0f));
+        for (int j = 0; j < cfg->n_mels; ++j)
+            for (int k = 0; k < h->nbin; ++k) banks[j][k] = fbT[(size_t)j * h->nbin_pad + k];
+        std::vector<float> melb;
+        if (mv::build_mel_plan(banks, mv::MF_PSTR, &h->plan, &melb)) {
+            std::vector<float> tw(32 * 16 * 2), w1(17 * 2);
+            for (int k1 = 0; k1 < 32; ++k1)
+                for (int l = 0; l < 16; ++l) {
+                    tw[2 * (k1 * 16 + l)] = (float)cos(2.0 * pi * (l * k1) / 512.0);
+                    tw[2 * (k1 * 16 + l) + 1] = (float)sin(2.0 * pi * (l * k1) / 512.0);
+                }
+            for (int l = 0; l <= 16; ++l) {
+                w1[2 * l] = (float)cos(2.0 * pi * l / 1024.0);
+                w1[2 * l + 1] = (float)sin(2.0 * pi * l / 1024.0);
+            }
+            if ((rc = upload_vec(tw, &h->d_tw512)) || (rc = upload_vec(w1, &h->d_w1024)) || (rc = upload_vec(melb, &h->d_melb))) {
+                mv_melspec_destroy(h);
+                return rc;
+            }
+            h->pow2_kernel = true;
+            if (const char* e = getenv("MV_MELSPEC_IMPL")) {  // measurement knob: "dft" keeps the dense-DFT kernels
+                if (strcmp(e, "dft") == 0) h->pow2_kernel = false;
+            }
+        }
+    }
     *out = h;
     return MV_OK;
 }
 
 int mv_melspec_info(const MvMelSpec* h, int32_t* tile_kernel) {
     MV_REQUIRE(h != nullptr && tile_kernel != nullptr, "mv_melspec_info: null argument");
-    *tile_kernel = h->tile_kernel ? 1 : 0;
+    *tile_kernel = h->tile_kernel ? 1 : (h->pow2_kernel ? 2 : 0);  // 1 = melspec_tile_kernel (n_fft 400), 2 = melspec_pow2_kernel
     return MV_OK;
 }
 
@@ -647,6 +680,8 @@ int mv_melspec_destroy(MvMelSpec* h) {
     hipFree(h->d_fbT);
     hipFree(h->d_tw400);
     hipFree(h->d_melb);
+    hipFree(h->d_tw512);
+    hipFree(h->d_w1024);
     delete h;
     return MV_OK;
 }
@@ -693,6 +728,23 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
         MV_LAUNCH((mv::melspec_tile_kernel<MST_G0, MST_G1>), ((unsigned)B, 1, 1), (mv::MST_WAVES * 64, 1, 1), smem, static_cast<hipStream_t>(stream), t);
         mv::prof_end(prof, static_cast<hipStream_t>(stream));
         return mv::check_launch("melspec_tile_kernel");
+    }
+    if (h->pow2_kernel && (int64_t)T * h->cfg.n_mels < ((int64_t)1 << 31)) {
+        mv::MelFftArgs t;
+        t.wav = wav; t.wav_stride = wav_stride; t.L = L; t.lens_ratio = lens_ratio; t.out = out;
+        t.window = h->d_window; t.tw512 = h->d_tw512; t.w1024 = h->d_w1024; t.melb = h->d_melb;
+        t.B = B; t.T = (int)T; t.n_fft = h->cfg.n_fft; t.hop = h->cfg.hop_length; t.pad = h->pad; t.n_mels = h->cfg.n_mels;
+        t.cmn = h->cfg.subtract_time_mean;
+        t.plan = h->plan;
+        const size_t fixed = mv::melfft_fixed_lds_bytes();
+        int64_t rows = (int64_t)((160 * 1024 - fixed) / ((size_t)h->cfg.n_mels * sizeof(float))) & ~(int64_t)3;
+        const int64_t need = (T + 3) & ~(int64_t)3;
+        t.tile_rows = (int)(rows < need ? rows : need);
+        const size_t smem = fixed + (size_t)t.tile_rows * h->cfg.n_mels * sizeof(float);
+        const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->cfg.n_mels), static_cast<hipStream_t>(stream));
+        const int rc = mv::melfft_launch(t, smem, static_cast<hipStream_t>(stream));
+        mv::prof_end(prof, static_cast<hipStream_t>(stream));
+        return rc;
     }
     MV_REQUIRE(workspace_bytes >= mv_melspec_workspace_bytes(h, B, L), "mv_melspec_forward: workspace too small");
     MV_REQUIRE((int64_t)B * T < ((int64_t)1 << 31), "mv_melspec_forward: too many frames");

@@ -294,10 +294,11 @@ class MelSpec:
         check(self._cdll.mv_melspec_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
 
     def info(self):
-        """{'tile_kernel': bool}: True when the FFT kernel (n_fft = 400) runs, False for the dense-DFT kernels"""
+        """{'tile_kernel': bool, 'kernel': name}: True when an FFT kernel runs -- melspec_tile_kernel (n_fft = 400) or melspec_pow2_kernel
+        (n_fft 128 ... 1024, power of two) --, False for the dense-DFT kernels"""
         tk = c_i32()
         check(self._cdll.mv_melspec_info(self._h, ctypes.byref(tk)), self._cdll)
-        return {'tile_kernel': bool(tk.value)}
+        return {'tile_kernel': bool(tk.value), 'kernel': {0: 'stft_power_kernel (dense DFT)', 1: 'melspec_tile_kernel', 2: 'melspec_pow2_kernel'}[tk.value]}
 
     def num_frames(self, num_samples):
         t = c_i64()
