@@ -181,6 +181,12 @@ int mv_eres2net_create(const MvEres2Cfg* cfg, const MvTensorRef* tensors, int32_
 
 int mv_model_destroy(MvModel* m);
 int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
+/* Model-specific facts (tests, logs).  Keys:
+ *   MV_INFO_CAMPP_HEAD_F32     1.0 when the CAM++ handle evaluates its FCM head on fp32 maps (conv2d kernels), 0.0 for the fp16 head;
+ *   MV_INFO_CAMPP_CALIBRATION  1 - cos between the embeddings of the two heads on the handle's calibration input (mv_campp_create). */
+#define MV_INFO_CAMPP_HEAD_F32 1
+#define MV_INFO_CAMPP_CALIBRATION 2
+int mv_model_info(const MvModel* m, int32_t key, float* value);
 int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes);
 /* feats: [B, T, F] fp32 (the AudioFeaturizer output layout); emb: [B, embd_dim] fp32. */
 int mv_model_forward(const MvModel* m, const float* feats, int32_t B, int32_t T, float* emb, void* workspace,
@@ -235,11 +241,13 @@ typedef struct MvConv2dDesc {
     const float* res;    /* epi 0: optional residual; epi 2: first AFF operand; [B, Ho, Wo, ldres] */
     const float* res2;   /* epi 2: second AFF operand */
     int64_t ldres, ldres2;
-    float* y;            /* [B, Ho, Wo, ldy], Ho = (H + 2*(ks/2) - ks)/stride + 1 */
+    float* y;            /* [B, Ho, Wo, ldy], Ho = (H + 2*(ks/2) - ks)/stride + 1, Wo likewise with stride_w */
     int64_t ldy;
     int32_t B, H, W, cin16, cout16, ks, stride, epi;
     float lo, hi;
     int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
+    int32_t stride_w;          /* stride along W when it differs from `stride` (then the stride along H); 0 = same.  The CAM++ head
+                                * (campplus.py:221-292) strides the frequency axis only: stride 2, stride_w 1 */
 } MvConv2dDesc;
 int mv_conv2d_forward(const MvConv2dDesc* d, mv_stream_t stream);
 /* first ERes2Net conv: features fp32 [B, T, F] -> fp32 [B, F, T, C] = relu(conv3x3(1 -> C) + bias), w fp32 [C][9] */

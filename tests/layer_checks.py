@@ -174,7 +174,7 @@ def conv1d_window_case(cdll, device, B=3, T=300, F_=80, k=5, cout=512, tile=0, s
     return err
 
 
-def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, x2_mode=0, epi=0, with_res=False,
+def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, stride_w=0, x2_mode=0, epi=0, with_res=False,
                 lo=0.0, hi=20.0, seed=0):
     """mv_conv2d_forward against F.conv2d in fp32 (ERes2Net layer: conv -> folded BN -> epilogue)."""
     g = torch.Generator().manual_seed(seed)
@@ -188,7 +188,8 @@ def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, 
     bn_scale = torch.rand(cout, generator=g) + 0.5
     bias = rn(cout) * 0.3
     p = ks // 2
-    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // stride + 1
+    sw = stride_w or stride
+    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // sw + 1
     c16 = r16(cout)
     ldy = c16 + 4
     res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
@@ -219,6 +220,7 @@ def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, 
     d.res2, d.ldres2 = (res2d.data_ptr() if res2 is not None else None), c16
     d.y, d.ldy = y.data_ptr(), ldy
     d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
+    d.stride_w = stride_w
     d.lo, d.hi = lo, hi
     _hip.check(cdll.mv_conv2d_forward(ctypes.byref(d), _stream(xad)), cdll)
     if device != 'cpu':
@@ -230,7 +232,7 @@ def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, 
     elif x2_mode == 2:
         xin = torch.cat([xin, xb.float()[..., :cin_a]], dim=-1)
     weff = w * bn_scale.view(-1, 1, 1, 1)
-    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias, stride=stride, padding=p).permute(0, 2, 3, 1)
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias, stride=(stride, sw), padding=p).permute(0, 2, 3, 1)
     if epi == 0:
         if with_res:
             ref = ref + res.float()[..., :cout]
@@ -264,6 +266,8 @@ CONV2D_CASES = [
     dict(cin=48, cout=208, ks=1, H=2, W=37, B=2, with_res=True),             # 1x1: 13 blocks -> 4 tiles of 4 (3 clamped blocks)
     dict(cin=32, cout=48, ks=1, stride=2, H=5, W=37, B=2),                   # strided 1x1 on odd sizes: 5 x 37 -> 3 x 19
     dict(cin=16, cout=32, ks=3, stride=2, H=5, W=33, B=1, x2_mode=1),        # strided 3x3 on odd sizes with the input sum
+    dict(cin=32, cout=32, ks=3, stride=2, stride_w=1, H=9, W=45, B=2, hi=65504.0),   # CAM++ head (fp32 form): stride on the frequency axis only
+    dict(cin=32, cout=32, ks=1, stride=2, stride_w=1, H=8, W=37, B=2, hi=65504.0, lo=-65504.0),  # its 1x1 shortcut conv
 ]
 
 
@@ -526,8 +530,9 @@ def fbank_case(cdll, device, wav, ratio, method_args):
     return d.max().item()
 
 
-def model_case(cdll, device, case, tol=1e-4, max_batch=None):
-    """Golden case through the native model handle (weights from the manifest, reference embedding from golden)."""
+def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None):
+    """Golden case through the native model handle (weights from the manifest, reference embedding from golden).  `info`: a dict
+    that receives {key: mv_model_info(key)} for the keys it holds (CAM++: 1 = head on fp32 maps, 2 = creation-time calibration)."""
     from helpers import load_case, cos_dist
     man, sd, x, emb_ref, _ = load_case(case)
     if max_batch is not None:
@@ -562,6 +567,9 @@ def model_case(cdll, device, case, tol=1e-4, max_batch=None):
         kind = 'campp'
     sd_dev = {k: v.to(device) for k, v in sd.items()}
     m = _hip.Model(kind, cfg, sd_dev, cdll=cdll)
+    if info is not None:
+        for key in list(info):
+            info[key] = m.info(key)
     emb = m.forward(x.to(device)).cpu()
     cd = cos_dist(emb, emb_ref).max().item()
     rel = ((emb - emb_ref).norm(dim=1) / emb_ref.norm(dim=1)).max().item()

@@ -157,9 +157,16 @@ def test_emu_ecapa_tiny_end_to_end():
 
 
 @pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~90 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
-def test_emu_campp_short_end_to_end():
+def test_emu_campp_short_end_to_end(monkeypatch):
+    """fp16 head (forced: the creation-time calibration would run two more forwards under the emulator), then the fp32 head through the
+    conv2d kernels (frequency-only stride, residual epilogue, rows cast)"""
+    monkeypatch.setenv('MV_CAMPP_HEAD', 'f16')
     cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short')
     assert rel < 1e-2
+    monkeypatch.setenv('MV_CAMPP_HEAD', 'f32')
+    info = {1: None}
+    cd32, _ = lc.model_case(emu_cdll(), 'cpu', 'campp_short', max_batch=1, info=info)
+    assert info[1] == 1.0 and cd32 < 1e-5
 
 
 def test_emu_melspec_fft_kernel_and_dft_kernel(monkeypatch):

@@ -13,7 +13,18 @@
 //             (one launch per layer for utterances of up to 160 strided frames: camdense.hip; five launches beyond)
 //             transit: 1x1 conv with BN/ReLU on load; out_nonlinear + StatsPool (unbiased std) fused into one reduction;
 //             dense + BN(affine=False) folded into one fp32 linear layer.
+//
+// Head precision.  The fp16 head (fp16 maps and tap matrices, fp32 accumulation) reproduces trained-like checkpoints to 6e-8, but a head
+// with large BatchNorm gains amplifies the 2^-11 operand rounding of its ~20 sites ~100 x (tests/budget_campp.py: the stress golden
+// lands at 4e-4, no single site owning it).  So the handle also carries the head as fp32 weights for the conv2d kernels of the ERes2Net
+// family (conv2d.hip: fp32 maps, v_mfma_f32_16x16x4_f32, the frequency-only stride through MvConv2dDesc.stride_w) and DECIDES AT CREATION
+// which one it runs: both heads embed one fixed pseudo-random utterance; if their embeddings differ by more than 5e-6 in 1 - cos the
+// checkpoint is ill-conditioned for fp16 maps and the handle takes the fp32 head (~4 x the step time), otherwise the fp16 head.
+// (Measured, r07h: trained-like goldens 4e-7 and 1.8e-6, the stress golden 3.4e-5 -- and 3.3e-4 on its own test input, ten times its
+// calibration figure; 5e-6 keeps that factor inside the 1e-4 bar.)
+// MV_CAMPP_HEAD=f16|f32 forces the choice (measurements, tests); mv_model_info reports it.
 #include <array>
+#include <cfloat>
 #include <memory>
 
 #include "kernels.h"
@@ -30,6 +41,9 @@ struct CamppModel : MvModelBase {
         half_t* w = nullptr;  // [ntaps][32][32]
         float* bias = nullptr;
         int ntaps = 9;
+        // the same conv for the fp32 head (conv2d.hip layout [32 co][9 taps][32 ci], BN folded) and its own BN shift; the block's
+        // shortcut conv separately ([32][1][32] + its BN shift)
+        float *w32 = nullptr, *b32 = nullptr, *sc_w32 = nullptr, *sc_b32 = nullptr;
     };
     struct ResBlock {
         Conv2d conv1, conv2;  // conv2 carries the shortcut tap when the block has one
@@ -57,6 +71,8 @@ struct CamppModel : MvModelBase {
     float *out_s = nullptr, *out_t = nullptr;
     float *dense_w = nullptr, *dense_b = nullptr;
     int F8 = 0, bn_ch = 0, cfin = 0;
+    bool head_f32 = false;          // which head forward() runs (decided in create())
+    float calibration = -1.0f;      // 1 - cos between the two heads on the calibration utterance (-1: forced by MV_CAMPP_HEAD)
 
     int fold_conv2d(const Weights& w, const std::string& conv, const std::string& bn, const std::string& sc_conv,
                     const std::string& sc_bn, Conv2d* out) {
@@ -83,7 +99,20 @@ struct CamppModel : MvModelBase {
         if (out->w == nullptr) return fail(MV_ERR_HIP, "campp create: out of device memory");
         MV_HIP_OK(hipMemcpy(out->w, ph.data(), ph.size() * sizeof(half_t), hipMemcpyHostToDevice));
         out->bias = upload(bias);
-        return out->bias ? MV_OK : fail(MV_ERR_HIP, "campp create: upload failed");
+        {   // fp32 head: [co][tap][ci]
+            std::vector<float> w32((size_t)32 * 9 * 32), scw;
+            for (int co = 0; co < 32; ++co)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ci = 0; ci < 32; ++ci) w32[((size_t)co * 9 + tap) * 32 + ci] = packed[((size_t)tap * 32 + co) * 32 + ci];
+            out->w32 = upload(w32);
+            out->b32 = upload(t);
+            if (sc) {
+                scw.assign(packed.begin() + (size_t)9 * 32 * 32, packed.end());  // [co][ci]
+                out->sc_w32 = upload(scw);
+                out->sc_b32 = upload(ts);
+            }
+        }
+        return out->bias && out->w32 && out->b32 ? MV_OK : fail(MV_ERR_HIP, "campp create: upload failed");
     }
 
     int create(const MvCamppCfg& c, const Weights& w) {
@@ -169,10 +198,66 @@ struct CamppModel : MvModelBase {
                                     "xvector.dense.nonlinear.batchnorm", c.embd_dim, 2 * cfin, &dense_w, &dense_b)))
             return rc;
         MV_HIP_OK(hipDeviceSynchronize());
+        return choose_head();
+    }
+
+    int info(int key, float* value) const override {
+        if (key == MV_INFO_CAMPP_HEAD_F32) {
+            *value = head_f32 ? 1.0f : 0.0f;
+            return MV_OK;
+        }
+        if (key == MV_INFO_CAMPP_CALIBRATION) {
+            *value = calibration;
+            return MV_OK;
+        }
+        return MvModelBase::info(key, value);
+    }
+
+    // one fixed pseudo-random utterance (96 frames) through both heads; the embeddings decide (header comment)
+    int choose_head() {
+        if (const char* e = getenv("MV_CAMPP_HEAD")) {
+            if (strcmp(e, "f32") == 0 || strcmp(e, "f16") == 0) {
+                head_f32 = e[1] == '3';
+                return MV_OK;
+            }
+        }
+        const int T = 96, F = cfg.input_size, D = cfg.embd_dim;
+        std::vector<float> feats((size_t)T * F);
+        uint32_t lcg = 0x2545F491u;
+        for (float& v : feats) {  // uniform in [-3, 3): the scale of mean-normalised log-mel features
+            lcg = lcg * 1664525u + 1013904223u;
+            v = ((float)(lcg >> 8) / 16777216.0f - 0.5f) * 6.0f;
+        }
+        size_t b16 = carve(nullptr, 1, T, false).bytes, b32 = carve(nullptr, 1, T, true).bytes;
+        const size_t wsb = b16 > b32 ? b16 : b32;
+        float *dfe = nullptr, *demb = nullptr;
+        void* ws = nullptr;
+        MV_HIP_OK(hipMalloc(reinterpret_cast<void**>(&dfe), feats.size() * sizeof(float)));
+        MV_HIP_OK(hipMalloc(reinterpret_cast<void**>(&demb), (size_t)2 * D * sizeof(float)));
+        MV_HIP_OK(hipMalloc(&ws, wsb));
+        MV_HIP_OK(hipMemcpy(dfe, feats.data(), feats.size() * sizeof(float), hipMemcpyHostToDevice));
+        int rc = forward_impl(dfe, 1, T, demb, ws, wsb, nullptr, false);
+        if (rc == MV_OK) rc = forward_impl(dfe, 1, T, demb + D, ws, wsb, nullptr, true);
+        std::vector<float> e((size_t)2 * D);
+        if (rc == MV_OK && hipMemcpy(e.data(), demb, e.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MV_ERR_HIP, "campp create: calibration copy failed");
+        hipFree(dfe);
+        hipFree(demb);
+        hipFree(ws);
+        if (rc != MV_OK) return rc;
+        double ab = 0.0, aa = 0.0, bb = 0.0;
+        for (int i = 0; i < D; ++i) {
+            ab += (double)e[i] * e[D + i];
+            aa += (double)e[i] * e[i];
+            bb += (double)e[D + i] * e[D + i];
+        }
+        const double cosv = (aa > 0.0 && bb > 0.0) ? ab / sqrt(aa * bb) : 0.0;
+        calibration = (float)(1.0 - cosv);
+        head_f32 = !(calibration <= 5e-6f);  // also taken when the fp16 head produced a non-finite embedding
         return MV_OK;
     }
 
     struct Ws {
+        float *f0, *fa, *fb, *fc;  // fp32 head: the full-resolution map and three half-resolution ones
         half_t *m0, *m1, *m2;  // FCM maps (ping-pong)
         half_t* rows;          // [B, T, 32*F8]
         half_t* xb[3];         // dense-block buffers [B, T2, c_out]
@@ -183,16 +268,26 @@ struct CamppModel : MvModelBase {
         int T2, nseg;
     };
 
-    Ws carve(void* base, int B, int T) const {
+    Ws carve(void* base, int B, int T, bool f32) const {
         Carver c(base);
         Ws s;
         const int F = cfg.input_size;
         s.T2 = (T - 1) / 2 + 1;
         s.nseg = (s.T2 + 99) / 100;
         const size_t full = (size_t)B * F * T * 32;
-        s.m0 = c.take<half_t>(full);
-        s.m1 = c.take<half_t>(full / 2);
-        s.m2 = c.take<half_t>(full / 2);
+        const size_t half = (size_t)B * ((F + 1) / 2) * T * 32;
+        s.f0 = s.fa = s.fb = s.fc = nullptr;
+        s.m0 = s.m1 = s.m2 = nullptr;
+        if (f32) {
+            s.f0 = c.take<float>(full);
+            s.fa = c.take<float>(half);
+            s.fb = c.take<float>(half);
+            s.fc = c.take<float>(half);
+        } else {
+            s.m0 = c.take<half_t>(full);
+            s.m1 = c.take<half_t>(half);
+            s.m2 = c.take<half_t>(half);
+        }
         s.rows = c.take<half_t>((size_t)B * T * 32 * F8);
         const size_t N2 = (size_t)B * s.T2;
         for (int i = 0; i < 3; ++i) s.xb[i] = c.take<half_t>(N2 * blocks[i].c_out);
@@ -208,18 +303,76 @@ struct CamppModel : MvModelBase {
 
     int workspace_bytes(int B, int T, size_t* bytes) const override {
         MV_REQUIRE(B > 0 && T > 0 && bytes != nullptr, "workspace_bytes: bad argument");
-        *bytes = carve(nullptr, B, T).bytes;
+        *bytes = carve(nullptr, B, T, head_f32).bytes;
         return MV_OK;
     }
 
     int forward(const float* feats, int B, int T, float* emb, void* ws, size_t ws_bytes, hipStream_t st) const override {
+        return forward_impl(feats, B, T, emb, ws, ws_bytes, st, head_f32);
+    }
+
+    // FCM head on fp32 maps [B, F, T, 32] through the conv2d kernels (header comment): s.rows <- fp16 [B, T, F8, 32]
+    int head_fp32(const float* feats, int B, int T, const Ws& s, hipStream_t st) const {
+        const int F = cfg.input_size;
+        int rc;
+        if ((rc = conv2d_first_launch(feats, s.f0, c1_w, c1_b, B, T, F, 32, st))) return rc;
+        auto conv = [&](const float* x, int H, const float* w, const float* bias, int ks, int stride, const float* res, bool relu, float* y) {
+            Conv2dDesc d{};
+            d.x = x;
+            d.ldx = 32;
+            d.w = w;
+            d.bias = bias;
+            d.res = res;
+            d.ldres = 32;
+            d.y = y;
+            d.ldy = 32;
+            d.B = B;
+            d.H = H;
+            d.W = T;
+            d.cin16 = d.cout16 = 32;
+            d.ks = ks;
+            d.stride = stride;
+            d.stride_w = 1;
+            d.epi = 0;
+            d.lo = relu ? 0.0f : -FLT_MAX;
+            d.hi = FLT_MAX;
+            return conv2d_launch(d, st);
+        };
+        const float* cur = s.f0;
+        int Fc = F;
+        for (int i = 0; i < 4; ++i) {
+            const ResBlock& r = res[i];
+            const int Fo = (Fc - 1) / r.stride + 1;
+            // buffers: block 0 f0 -> fc, block 1 fc -> fb, block 2 fb -> f0, block 3 f0 -> fb (conv1 output always in fa; shortcut of
+            // block 0 in fb, of block 2 in fc)
+            float* out = i == 0 ? s.fc : (i == 2 ? s.f0 : s.fb);
+            float* scb = i == 0 ? s.fb : s.fc;
+            if ((rc = conv(cur, Fc, r.conv1.w32, r.conv1.b32, 3, r.stride, nullptr, true, s.fa))) return rc;
+            const float* resid = cur;
+            if (r.has_shortcut) {
+                if ((rc = conv(cur, Fc, r.conv2.sc_w32, r.conv2.sc_b32, 1, r.stride, nullptr, false, scb))) return rc;
+                resid = scb;
+            }
+            if ((rc = conv(s.fa, Fo, r.conv2.w32, r.conv2.b32, 3, 1, resid, true, out))) return rc;
+            cur = out;
+            Fc = Fo;
+        }
+        MV_REQUIRE((Fc - 1) / 2 + 1 == F8, "campp forward: unexpected frequency size after the head");
+        if ((rc = conv(cur, Fc, head_out.w32, head_out.b32, 3, 2, nullptr, true, s.fa))) return rc;
+        return fcm_rows_from_f32_launch(s.fa, s.rows, B, T, F8, st);
+    }
+
+    int forward_impl(const float* feats, int B, int T, float* emb, void* ws, size_t ws_bytes, hipStream_t st, bool f32) const {
         MV_REQUIRE(feats != nullptr && emb != nullptr && ws != nullptr, "campp forward: null buffer");
         MV_REQUIRE(B > 0 && T >= 3, "campp forward: needs at least 3 frames (unbiased std over the strided time axis)");
-        const Ws s = carve(ws, B, T);
+        const Ws s = carve(ws, B, T, f32);
         if (s.bytes > ws_bytes) return fail(MV_ERR_WORKSPACE, "campp forward: workspace too small");
         const int F = cfg.input_size;
         int rc;
         // ---- head ----
+        if (f32) {
+            if ((rc = head_fp32(feats, B, T, s, st))) return rc;
+        } else {
         if ((rc = fcm_conv1_launch(feats, s.m0, c1_w, c1_b, B, T, F, st))) return rc;
         auto plain = [&](int Fd) { return std::array<int64_t, 3>{(int64_t)Fd * T * 32, (int64_t)T * 32, 32}; };
         const half_t* cur = s.m0;
@@ -269,6 +422,7 @@ struct CamppModel : MvModelBase {
                                          (int64_t)F8 * 32, B, T, Fo, st)))
                 return rc;
         }
+        }  // fp16 head
         // ---- xvector.tdnn: k=5, stride 2, zero pad 2, BN, ReLU -> first slice of block 1's buffer ----
         const int T2 = s.T2;
         {

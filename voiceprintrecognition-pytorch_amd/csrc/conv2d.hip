@@ -45,7 +45,7 @@ struct Conv2dArgs {
     int64_t ldx, ldx2, ldres, ldres2, ldy;
     int x2_mode;        // 0 none, 1 added to x, 2 concatenated behind the cin1 channels of x
     int cin1, cin16, cout16;
-    int B, H, W, Ho, Wo, ks, stride;
+    int B, H, W, Ho, Wo, ks, stride, stride_w;  // stride = rows (H), stride_w = columns (W): the CAM++ head strides the frequency axis only
     int epi;            // 0: clamp(v [+ res], lo, hi); 1: SiLU; 2: AFF mix  res*(1+tanh v) + res2*(1-tanh v)
     float lo, hi;
 };
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int b = blockIdx.y;
     const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
     constexpr int taps = 9;
-    const int s = a.stride;
+    const int s = a.stride_w, sh = a.stride;   // column / row stride
     const int ncols = 15 * s + 3;              // input columns behind one segment
     const int seg_floats = 3 * ncols * C2_RS;
     const int per_seg = 3 * ncols * 4;          // 16-byte pieces of one segment's patch
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int st_sg = sg0 + st_slot;
     const bool st_ok = st_sg < nseg;
     const int st_ho = st_ok ? st_sg / nsegw : 0;
-    const int st_h0 = st_ho * s - 1;                              // input row of kh = 0
+    const int st_h0 = st_ho * sh - 1;                             // input row of kh = 0
     const int st_w0 = (st_sg - st_ho * nsegw) * 16 * s - 1;       // input column of col = 0
     const int ncols_magic = 65536 / ncols + 1;                    // rc / ncols for rc < 99
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void conv2d_1x1_kernel(Conv2dArgs a) {
     const int st = blockIdx.x % stiles, ct = blockIdx.x / stiles;
     const int b = blockIdx.y;
     const int sg0 = st * C2_SEGS, co0 = ct * NB * 16;
-    const int s = a.stride;
+    const int s = a.stride_w, sh = a.stride;
 
     float4v acc[2][NB];
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void conv2d_1x1_kernel(Conv2dArgs a) {
         wo_u[u] = sg < nseg ? (sg - ho_u[u] * nsegw) * 16 : 0;
         const int wo = wo_u[u] + j16;
         const bool ok = ho_u[u] >= 0 && wo < a.Wo;
-        const int64_t pix = ok ? ((int64_t)b * a.H + ho_u[u] * s) * a.W + wo * s : 0;
+        const int64_t pix = ok ? ((int64_t)b * a.H + ho_u[u] * sh) * a.W + wo * s : 0;
         xp[u] = ok ? a.x + pix * a.ldx + q * 4 : nullptr;
         x2p[u] = ok && a.x2_mode != 0 ? a.x2 + pix * a.ldx2 + q * 4 : nullptr;
     }
@@ -307,6 +307,8 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2d: null pointer");
     MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0, "conv2d: empty input");
     MV_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv2d: kernel 1 or 3, stride 1 or 2");
+    MV_REQUIRE(d.stride_w == 0 || d.stride_w == 1 || d.stride_w == 2, "conv2d: stride_w must be 0 (= stride), 1 or 2");
+    const int stride_w = d.stride_w == 0 ? d.stride : d.stride_w;
     MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2d: channels must be padded to 16");
     MV_REQUIRE(d.ldx % 4 == 0 && d.ldy % 4 == 0, "conv2d: leading dimensions");
     MV_REQUIRE(d.x2_mode >= 0 && d.x2_mode <= 2 && (d.x2_mode == 0 || (d.x2 != nullptr && d.ldx2 % 4 == 0)), "conv2d: second input");
@@ -317,10 +319,10 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     a.x = d.x; a.x2 = d.x2; a.w = d.w; a.bias = d.bias; a.res = d.res; a.res2 = d.res2; a.y = d.y;
     a.ldx = d.ldx; a.ldx2 = d.ldx2; a.ldres = d.ldres; a.ldres2 = d.ldres2; a.ldy = d.ldy;
     a.x2_mode = d.x2_mode; a.cin1 = d.x2_mode == 2 ? d.cin1 : d.cin16; a.cin16 = d.cin16; a.cout16 = d.cout16;
-    a.B = d.B; a.H = d.H; a.W = d.W; a.ks = d.ks; a.stride = d.stride;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.ks = d.ks; a.stride = d.stride; a.stride_w = stride_w;
     const int p = d.ks / 2;
     a.Ho = (d.H + 2 * p - d.ks) / d.stride + 1;
-    a.Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
+    a.Wo = (d.W + 2 * p - d.ks) / stride_w + 1;
     a.epi = d.epi; a.lo = d.lo; a.hi = d.hi;
     // channel tiles: one when the layer has <= 8 blocks of 16 channels, else the most even split into tiles of <= 8 blocks
     const int nblk = d.cout16 / 16;
@@ -344,7 +346,7 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const int stiles = (a.Ho * nsegw + C2_SEGS - 1) / C2_SEGS;
     const dim3 grid((unsigned)(stiles * ctiles), (unsigned)d.B, 1);
     MV_REQUIRE(d.B <= 65535, "conv2d: batch too large for one launch");
-    const size_t lds = conv2d_lds_bytes(d.stride);
+    const size_t lds = conv2d_lds_bytes(stride_w);
     static bool smem_set = false;
     if (!smem_set) {
         const int big = (int)conv2d_lds_bytes(2);

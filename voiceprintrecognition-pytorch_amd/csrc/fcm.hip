@@ -391,6 +391,34 @@ __global__ __launch_bounds__(256) void fcm_band_kernel(FcmConvArgs a, int n_ttil
     }
 }
 
+// fp32 head (campplus.hip): [B, F8, T, 32] fp32 -> [B, T, F8, 32] fp16; thread = 8 maps of one (b, f, t)
+__global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* maps, half_t* rows, int64_t n8, int T, int F8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c8 = (int)(i & 3);
+    int64_t p = i >> 2;               // (b * F8 + f) * T + t
+    const int t = (int)(p % T);
+    p /= T;
+    const int f = (int)(p % F8);
+    const int64_t b = p / F8;
+    const float4v lo = *reinterpret_cast<const float4v*>(maps + i * 8), hi = *reinterpret_cast<const float4v*>(maps + i * 8 + 4);
+    half8v o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)fmed3(lo[e], -65504.0f, 65504.0f);
+        o[4 + e] = (half_t)fmed3(hi[e], -65504.0f, 65504.0f);
+    }
+    *reinterpret_cast<half8v*>(rows + ((b * T + t) * F8 + f) * FCM_C + c8 * 8) = o;
+}
+
+int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int F8, hipStream_t stream) {
+    MV_REQUIRE(maps != nullptr && rows != nullptr && B > 0 && T > 0 && F8 > 0, "fcm_rows_from_f32: bad argument");
+    const int64_t n8 = (int64_t)B * F8 * T * 4;
+    MV_REQUIRE(ceil_div(n8, 256) < ((int64_t)1 << 31), "fcm_rows_from_f32: grid too large");
+    MV_LAUNCH(fcm_rows_from_f32_kernel, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, maps, rows, n8, T, F8);
+    return check_launch("fcm_rows_from_f32_kernel");
+}
+
 int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F,
                      hipStream_t stream) {
     MV_REQUIRE(feats != nullptr && out != nullptr && w != nullptr && bias != nullptr && B > 0 && T > 0 && F > 0, "fcm_conv1: bad argument");

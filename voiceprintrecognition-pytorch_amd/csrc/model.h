@@ -29,6 +29,8 @@ struct MvModelBase {
     virtual ~MvModelBase();
     virtual int workspace_bytes(int B, int T, size_t* bytes) const = 0;
     virtual int forward(const float* feats, int B, int T, float* emb, void* ws, size_t ws_bytes, hipStream_t st) const = 0;
+    // model-specific facts for tests and logs (mv_model_info): MV_INFO_* keys; unknown key -> error
+    virtual int info(int key, float* value) const;
 
     void* dev_alloc(size_t bytes);
     float* upload(const std::vector<float>& v);

@@ -18,6 +18,8 @@ namespace mv {
 
 // ------------------------------------------------------------------------------------------ helpers
 
+int MvModelBase::info(int, float*) const { return fail(MV_ERR_INVALID_ARGUMENT, "mv_model_info: this model has no such key"); }
+
 MvModelBase::~MvModelBase() {
     for (void* p : owned) hipFree(p);
 }
@@ -703,6 +705,11 @@ int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim) {
     MV_REQUIRE(m != nullptr && embd_dim != nullptr, "mv_model_embd_dim: null argument");
     *embd_dim = reinterpret_cast<const mv::MvModelBase*>(m)->embd_dim;
     return MV_OK;
+}
+
+int mv_model_info(const MvModel* m, int32_t key, float* value) {
+    MV_REQUIRE(m != nullptr && value != nullptr, "mv_model_info: null argument");
+    return reinterpret_cast<const mv::MvModelBase*>(m)->info(key, value);
 }
 
 int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes) {

@@ -58,7 +58,7 @@ class MvConv2dDesc(ctypes.Structure):
                 ('w', c_vp), ('bias', c_vp), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64),
                 ('y', c_vp), ('ldy', c_i64), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('cin16', c_i32),
                 ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32), ('lo', c_f32), ('hi', c_f32),
-                ('cin_alg', c_i32), ('cout_alg', c_i32)]
+                ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32)]
 
 
 class MvTdnnCfg(ctypes.Structure):
@@ -103,6 +103,7 @@ _SIGNATURES = {
     'mv_tstp_f32': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_model_destroy': (c_i32, [c_vp]),
     'mv_model_embd_dim': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
+    'mv_model_info': (c_i32, [c_vp, c_i32, ctypes.POINTER(c_f32)]),
     'mv_model_workspace_bytes': (c_i32, [c_vp, c_i32, c_i32, ctypes.POINTER(c_sz)]),
     'mv_model_forward': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
     'mv_cosine_f32': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
@@ -362,6 +363,12 @@ class Model:
         n = c_sz()
         check(self._cdll.mv_model_workspace_bytes(self._h, B, T, ctypes.byref(n)), self._cdll)
         return n.value
+
+    def info(self, key):
+        """mv_model_info: 1 = CAM++ head on fp32 maps (1.0 / 0.0), 2 = its creation-time calibration 1 - cos"""
+        v = c_f32()
+        check(self._cdll.mv_model_info(self._h, key, ctypes.byref(v)), self._cdll)
+        return v.value
 
     def forward(self, feats):
         assert feats.dim() == 3 and feats.dtype == torch.float32
