@@ -809,15 +809,18 @@ __global__ void in_stats_finish_kernel(const float* psum, const float* psq, int 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (c >= C || b >= B) return;
-    float s = 0.0f, q2 = 0.0f;
+    // The tile partials are fp32 sums; their combination and E[x^2] - mean^2 run in double: for a channel with |mean| >> std the
+    // difference cancels the leading bits, and every fp32 rounding of s / T, m * m, q / T in front of it would be amplified by
+    // (mean / std)^2 on top of the partials' own rounding (the reference's two-pass form, pooling.py, has no such term)
+    double s = 0.0, q2 = 0.0;
     for (int k = 0; k < tiles_per_utt; ++k) {
-        s += psum[((int64_t)b * tiles_per_utt + k) * C + c];
-        q2 += psq[((int64_t)b * tiles_per_utt + k) * C + c];
+        s += (double)psum[((int64_t)b * tiles_per_utt + k) * C + c];
+        q2 += (double)psq[((int64_t)b * tiles_per_utt + k) * C + c];
     }
-    const float m = s / (float)T;
-    mean[(int64_t)b * ld_out + c] = m;
+    const double m = s / (double)T;
+    mean[(int64_t)b * ld_out + c] = (float)m;
     if (stdv != nullptr) {
-        float var = fmaxf(q2 / (float)T - m * m, 0.0f);
+        float var = (float)fmax(q2 / (double)T - m * m, 0.0);
         if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
         stdv[(int64_t)b * ld_out + c] = sqrtf(var);
     }
