@@ -598,6 +598,21 @@ def test_gpu_fcm_block_narrow_tiles(nt, monkeypatch):
     lc.fcm_block_case(product_lib(), DEV, B=3, Fin=10, T=298, sf=1, seed=32)
 
 
+def test_gpu_campp_block_kernel_and_layer_kernels_agree(monkeypatch):
+    """MV_CAMPP_BLOCK=0 (one launch per dense layer) and the default (cam_dense_block_kernel: all layers of a block in one launch) compute the
+    same arithmetic in the same order: bit-identical embeddings, also on a batch larger than the chip (300 workgroups)"""
+    import mvector.models as M
+    man, sd, x, _, _ = load_case('campp')
+    m = M.CAMPPlus(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    xb = x.repeat(150, 1, 1)[:300].to(DEV) * torch.linspace(0.5, 1.5, 300, device=DEV)[:, None, None]
+    e1 = m(xb).cpu()
+    monkeypatch.setenv('MV_CAMPP_BLOCK', '0')
+    e0 = m(xb).cpu()
+    assert torch.equal(e0, e1) and torch.isfinite(e1).all()
+
+
 def test_gpu_campp_fused_and_unfused_fcm_agree(monkeypatch):
     """MV_FCM_FUSED=0 (two launches per BasicResBlock, intermediate map in HBM) and the default (one launch) on the same golden"""
     cd1, _ = lc.model_case(product_lib(), DEV, 'campp')

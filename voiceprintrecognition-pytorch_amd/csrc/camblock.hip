@@ -1,0 +1,482 @@
+// All CAMDenseTDNNLayers of one CAM++ block (mvector/models/campplus.py:153-181) in ONE launch, one workgroup per utterance walking
+// the layers.  Per layer it is the algorithm of cam_dense_layer_kernel (camdense.hip: 1x1 GEMM with both operand streams on LDS-DMA
+// rings and the BN1 + ReLU transform in place, bottleneck h in LDS, context gate on the workgroup's own lanes, k = 3 conv from LDS);
+// what changes is what happens BETWEEN two layers.  As separate launches a layer costs 24.4 us of which 12.7 are fixed (profiles/r07b
+// timeline): every workgroup of a launch starts at the same moment and waits for its parameters (5.6 us) and first stages, and the
+// epilogue / context / k = 3 phases (6 us) run with the memory system idle.  Here layer l + 1's first operands travel under layer l's
+// tail:
+//   * after the stage loop of layer l the rings are idle: x stages 0 and 1 (channels 0..127: never this block's new channels) of layer
+//     l + 1 are requested into ring slots 0 / 1 at once, its BN1 tables into registers;
+//   * h lives in x slots 2 and 3 without halo rows (the k = 3 conv masks its out-of-range taps), the phase B scratch in the idle W ring
+//     (the next layer's W1 stages 0 and 1 follow the context phase: they are L2 hits, the x stages are the slow ones);
+//   * the context parameters of layer l + 1 are requested when layer l's context phase has consumed its own (same registers), the
+//     k = 3 weights after layer l's k = 3 conv;
+//   * layer entry: s_waitcnt vmcnt(0) (this wave's y stores are in L2: another wave's transfer may read them) + barrier, then x stage 2
+//     -- the request pattern of the stage loop (stage s requests x(s + 3) and W1(s + 2), five transfers per wave and stage, counted
+//     waits) is the one of cam_dense_layer_kernel from there on.
+// The first form of "all layers in one launch" (r05t: the layer loop around the unchanged body, vmcnt(0) + barrier between layers)
+// measured 3 % slower than separate launches -- it removed the launch boundary and kept every wait.
+// Measured (profiles/r08a, r08b timeline): 23.1 us per layer against 24.4 (CAM++ 2.28 -> 2.25 ms per step).  The layer entry costs 1.4 us
+// (was 1.0 + 5.6), the stage loop is unchanged (1.17 us per stage: five transfer issues, the in-place transform and a barrier per 20
+// MFMAs of a wave -- issue-bound per CU, not bandwidth-bound: 31 GB/s per CU), the tail grew from 6 to 9 us: all 256 workgroups walk
+// the layers in lockstep, so the prefetch of all of them is in flight while all of them issue their parameter loads and y stores.  Things
+// the compiler does to such a loop and what keeps it from them: the tail's per-thread addresses are loop-invariant and were hoisted into
+// ~130 registers (76 spilled, each reload an s_waitcnt vmcnt(0)): they hang on a per-layer MV_OPAQUE thread id; the layer descriptors
+// were read with vector loads (the kernel stores to global memory) whose wait drained the prefetch: they are copied to LDS once and read
+// into scalar registers; a select on a loaded table value puts the wait behind the load: index clamp instead; the compiler's own waits for
+// the parameter loads are pulled to the layer entry with MV_OPAQUE touches.
+#include "kernels.h"
+
+namespace mv {
+
+constexpr int CB_THREADS = 512;
+constexpr int CB_TT = 10;                           // time tiles of 16 frames: T2 <= 160
+constexpr int CB_ROWS = CB_TT * 16;
+constexpr int CB_BN = 128;                          // bottleneck channels
+constexpr int CB_G = 32;                            // growth rate
+constexpr int CB_XS_BYTES = CB_ROWS * 128;          // one x stage: [160 rows][64 fp16]
+constexpr int CB_WS_BYTES = CB_BN * 128;            // one W1 stage: [128 rows][64 fp16]
+constexpr int CB_RING = 3, CB_XRING = 4;
+constexpr int CB_MAX_SEG = 2;
+constexpr int CB_MAX_CIN = 1024;                    // BN1 tables of two layers live in LDS
+constexpr int CB_H_OFF = 2 * CB_XS_BYTES;           // h = x slots 2, 3: [160 rows][128 fp16], no halo rows
+static_assert(CB_ROWS * CB_BN * 2 == 2 * CB_XS_BYTES, "h fills exactly two x slots");
+constexpr int CB_F_OFF = CB_XRING * CB_XS_BYTES + CB_RING * CB_WS_BYTES;  // fp32 area behind the rings
+constexpr int CB_F_CTX = 0, CB_F_G1 = CB_F_CTX + CB_MAX_SEG * CB_BN, CB_F_GATE = CB_F_G1 + CB_MAX_SEG * 64,
+              CB_F_TAB = CB_F_GATE + CB_MAX_SEG * CB_G,               // [2 layers][scale | shift][CB_MAX_CIN]
+              CB_F_END = CB_F_TAB + 4 * CB_MAX_CIN;
+constexpr int CB_MAX_LAYERS = 24;
+constexpr size_t CB_DESC_OFF = CB_F_OFF + CB_F_END * sizeof(float) + 1024;   // behind the KiB that swallows the padding transfers
+constexpr size_t CB_LDS_BYTES = CB_DESC_OFF + CB_MAX_LAYERS * sizeof(MvCamLayerDesc);
+static_assert(CB_LDS_BYTES <= 160 * 1024, "cam block kernel: LDS");
+static_assert(32 * CB_MAX_SEG * CB_BN * 4 <= CB_RING * CB_WS_BYTES, "phase B scratch lives in the idle W ring");
+
+__device__ __attribute__((aligned(256))) const unsigned char g_cb_zero_page[256] = {0};
+
+struct CamBlockArgs {
+    half_t* x;             // [B, T2, ldx]: the block's concat buffer
+    int64_t ldx;
+    const MvCamLayerDesc* layers;  // device array
+    int nlayers, T2, dil, seg_len;
+};
+
+__global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArgs a) {
+    MV_DYN_SMEM(smem);
+    char* xs = smem;
+    char* ws = xs + CB_XRING * CB_XS_BYTES;
+    char* hbuf = xs + CB_H_OFF;
+    float* fsm = reinterpret_cast<float*>(smem + CB_F_OFF);
+    float* ctx = fsm + CB_F_CTX;
+    float* g1 = fsm + CB_F_G1;
+    float* gate = fsm + CB_F_GATE;
+    float* tabs = fsm + CB_F_TAB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.x;
+    const int T2 = a.T2;
+    half_t* xb = a.x + (int64_t)b * T2 * a.ldx;
+    const int cw = wave & 3, th = wave >> 2;
+    const int lrow = lane >> 3, kc = (lane & 7) ^ lrow;
+    const unsigned xs_addr = lds_addr(xs), ws_addr = lds_addr(ws);
+    const unsigned dump_addr = lds_addr(smem + CB_F_OFF + CB_F_END * sizeof(float));
+    const half_t* zero = reinterpret_cast<const half_t*>(g_cb_zero_page);
+    const int wave_u = MV_UNIFORM(wave);
+    // The per-layer descriptors are copied into LDS once and read from there into SCALAR registers: read from global memory the
+    // compiler uses vector loads (the kernel also stores to global memory), and its wait for a descriptor field of layer l + 1 -- an
+    // s_waitcnt vmcnt(0) in the middle of the tail -- drained the operand requests that had just gone out.
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(a.layers);
+        unsigned* dst = reinterpret_cast<unsigned*>(smem + CB_DESC_OFF);
+        for (int i = tid; i < a.nlayers * (int)(sizeof(MvCamLayerDesc) / 4); i += CB_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    auto layer_desc = [&](int l) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(smem + CB_DESC_OFF) + l * (int)(sizeof(MvCamLayerDesc) / 4);
+        union {
+            MvCamLayerDesc d;
+            unsigned w[sizeof(MvCamLayerDesc) / 4];
+        } u;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(MvCamLayerDesc) / 4); ++i) u.w[i] = (unsigned)MV_UNIFORM((int)p[i]);
+        return u.d;
+    };
+
+    // ---- operand requests of a layer: every wave issues exactly 3 x transfers and 2 W1 transfers per stage (stages beyond the last one
+    // and the x transfers 20..23 read a constant page into the dump KiB), so the waits can be counted ----
+    auto issue_x = [&](int s, int nst) {
+        const bool real = s < nst;
+        const unsigned dst = xs_addr + (unsigned)((s & (CB_XRING - 1)) * CB_XS_BYTES);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tr = wave_u + 8 * u;
+            int row = tr * 8 + lrow;
+            row = row < T2 ? row : T2 - 1;
+            const bool live = real && tr < CB_ROWS / 8;  // uniform
+            glds16_untracked(live ? xb + (int64_t)row * a.ldx + s * 64 + kc * 8 : zero, live ? dst + (unsigned)(tr * 1024) : dump_addr);
+        }
+    };
+    auto issue_w = [&](int s, int nst, const half_t* w1, int cin_pad) {
+        const bool real = s < nst;
+        const unsigned dst = ws_addr + (unsigned)((s % CB_RING) * CB_WS_BYTES);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tr = wave_u * 2 + u;
+            const int co = tr * 8 + lrow;
+            glds16_untracked(real ? w1 + (int64_t)co * cin_pad + s * 64 + kc * 8 : zero, real ? dst + (unsigned)(tr * 1024) : dump_addr);
+        }
+    };
+    // BN1 + ReLU in fp32, in place (camdense.hip): rows >= T2 and channels >= cin become zero
+    const int xchunk = tid & 7, xrow0 = tid >> 3;
+    auto transform = [&](int s, int cin, const float* lbn_s, const float* lbn_t) {
+        const int c = s * 64 + xchunk * 8;
+        const bool live = c < cin;
+        const float4v s0 = *reinterpret_cast<const float4v*>(lbn_s + c), s1 = *reinterpret_cast<const float4v*>(lbn_s + c + 4);
+        const float4v t0 = *reinterpret_cast<const float4v*>(lbn_t + c), t1 = *reinterpret_cast<const float4v*>(lbn_t + c + 4);
+        char* tile = xs + (s & (CB_XRING - 1)) * CB_XS_BYTES;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int row = xrow0 + 64 * p;
+            if (row < CB_ROWS) {
+                half8v* cell = reinterpret_cast<half8v*>(tile + row * 128 + ((xchunk ^ (row & 7)) << 4));
+                const half8v r = *cell;
+                half8v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)fmaxf((float)r[e] * s0[e] + t0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)r[4 + e] * s1[e] + t1[e], 0.0f);
+                }
+                if (!(row < T2 && live)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)0.0f;
+                }
+                *cell = o;
+            }
+        }
+    };
+    // BN1 tables of a layer: two floats of scale and of shift per thread (cin_pad <= 1024) -- loaded early into registers, stored late
+    auto load_tables = [&](const MvCamLayerDesc& L, float (&ts)[2], float (&tt)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * CB_THREADS;
+            const int ic = i < L.cin ? i : L.cin - 1;  // always a load, never a select on its result: the compiler waits where a value is first USED
+            ts[j] = L.bn1_s[ic];
+            tt[j] = L.bn1_t[ic];
+        }
+    };
+    auto store_tables = [&](int buf, int cin, const float (&ts)[2], const float (&tt)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * CB_THREADS;
+            tabs[buf * 2 * CB_MAX_CIN + i] = i < cin ? ts[j] : 0.0f;
+            tabs[buf * 2 * CB_MAX_CIN + CB_MAX_CIN + i] = i < cin ? tt[j] : 0.0f;
+        }
+    };
+    auto h_off = [&](int row, int chunk) { return row * (CB_BN * 2) + ((chunk ^ (row & 15)) << 4); };
+
+    // ---- parameters of a layer's later phases (registers) ----
+    float4v e_bn2s[2], e_bn2t[2], e_wa[4], e_wb;
+    float e_ba, e_bb;
+    half8v e_wl[3][4];
+    auto load_ctx_params = [&](const MvCamLayerDesc& L) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            e_bn2s[mi] = *reinterpret_cast<const float4v*>(L.bn2_s + (cw * 2 + mi) * 16 + 4 * fg);
+            e_bn2t[mi] = *reinterpret_cast<const float4v*>(L.bn2_t + (cw * 2 + mi) * 16 + 4 * fg);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e_wa[u] = *reinterpret_cast<const float4v*>(L.wa + (tid >> 3) * CB_BN + (tid & 7) * 16 + 4 * u);
+        e_wb = *reinterpret_cast<const float4v*>(L.wb + (tid >> 4) * 64 + (tid & 15) * 4);
+        e_ba = L.ba[tid >> 3];
+        e_bb = L.bb[tid >> 4];
+    };
+    auto load_wl = [&](const MvCamLayerDesc& L) {
+        const half_t* wrow = L.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CB_BN + 8 * fg;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) e_wl[tap][kk] = *reinterpret_cast<const half8v*>(wrow + tap * CB_BN + kk * 32);
+    };
+
+    // ---- first layer: the start-up of cam_dense_layer_kernel ----
+    {
+        const MvCamLayerDesc L0 = layer_desc(0);
+        const int nst0 = L0.cin_pad / 64;
+        float ts[2], tt[2];
+        load_tables(L0, ts, tt);
+        store_tables(0, L0.cin, ts, tt);
+        load_ctx_params(L0);
+        load_wl(L0);
+        issue_x(0, nst0);
+        issue_x(1, nst0);
+        issue_w(0, nst0, L0.w1, L0.cin_pad);
+        issue_w(1, nst0, L0.w1, L0.cin_pad);
+        __syncthreads();  // tables visible
+    }
+
+#pragma unroll 1
+    for (int l = 0; l < a.nlayers; ++l) {
+        const MvCamLayerDesc L = layer_desc(l);
+        const int nst = L.cin_pad / 64;
+        const float* lbn_s = tabs + (l & 1) * 2 * CB_MAX_CIN;
+        const float* lbn_t = lbn_s + CB_MAX_CIN;
+        // ---- layer entry: x(0), x(1), W1(0), W1(1) have been requested (by the previous layer's tail or by the start-up); everything
+        // this wave has in flight -- them, the parameter loads, the previous layer's y stores -- is waited for, then x(2) goes out ----
+        wait_vm<0>();
+        // the parameter loads of this layer are the only vector loads the compiler tracks; touching what they deliver puts ITS wait for them
+        // here, behind ours -- left where the values are first used (epilogue, context phase, k = 3 conv) it would be an s_waitcnt vmcnt(0)
+        // in the middle of the tail, draining the next layer's operand requests that have just gone out
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            MV_OPAQUE(e_bn2s[mi]);
+            MV_OPAQUE(e_bn2t[mi]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) MV_OPAQUE(e_wa[u]);
+        MV_OPAQUE(e_wb);
+        MV_OPAQUE(e_ba);
+        MV_OPAQUE(e_bb);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) MV_OPAQUE(e_wl[tap][kk]);
+        __syncthreads();   // every wave's stores are in L2, the tables of this layer are in LDS, h (x slots 2, 3) is dead
+        issue_x(2, nst);
+        transform(0, L.cin, lbn_s, lbn_t);
+        float4v acc[2][5];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        // ---- phase A: h = ReLU(BN2(W1 . ReLU(BN1(x)))) ----
+#pragma unroll 1
+        for (int s = 0; s < nst; ++s) {
+            // W1(s) and x(s+1) have landed: younger are x(s+2) [3 transfers] and, from stage 1 on, W1(s+1) [2]
+            if (s == 0) {
+                wait_vm<3>();   // (W1(1) was requested before x(2) at the layer boundary: older than the three transfers that may stay)
+            } else {
+                wait_vm<5>();
+            }
+            lds_barrier();  // ... in every wave; x(s) is transformed; every wave is done with x(s-1) and W1(s-1), whose slots are requested now
+            issue_x(s + 3, nst);
+            issue_w(s + 2, nst, L.w1, L.cin_pad);
+            const char* wt = ws + (s % CB_RING) * CB_WS_BYTES;
+            const char* xt = xs + (s & (CB_XRING - 1)) * CB_XS_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                half8v af[2], bf[5];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int row = (cw * 2 + mi) * 16 + fr;
+                    af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 5; ++ni) {
+                    const int row = (th * 5 + ni) * 16 + fr;
+                    bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 5; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (s + 1 < nst) transform(s + 1, L.cin, lbn_s, lbn_t);  // uniform
+        }
+        wait_vm<0>();   // only padding transfers are left: nothing may still be landing when the rings are reused
+        lds_barrier();  // every wave is done with both rings
+        // The tail's per-thread LDS / global addresses are derived from a thread id the optimiser must treat as new in every layer:
+        // otherwise it hoists all of them out of the layer loop (they are loop-invariant) into ~130 long-lived registers and spills.
+        int tid_t = tid;
+        MV_OPAQUE(tid_t);
+        const int lane_t = tid_t & 63, wave_t = tid_t >> 6;
+        const int fr_t = lane_t & 15, fg_t = lane_t >> 4, cw_t = wave_t & 3, th_t = wave_t >> 2;
+        // ---- the next layer's first operands travel under this layer's tail ----
+        const bool more = l + 1 < a.nlayers;  // uniform
+        MvCamLayerDesc Ln = L;
+        float nts[2] = {0.0f, 0.0f}, ntt[2] = {0.0f, 0.0f};
+        if (more) {
+            Ln = layer_desc(l + 1);
+            const int nstn = Ln.cin_pad / 64;
+            issue_x(0, nstn);
+            issue_x(1, nstn);
+            load_tables(Ln, nts, ntt);   // (its W1 stages follow the context phase: the idle W ring is that phase's scratch)
+        }
+        // epilogue A: BN2 + ReLU -> h (fp16, swizzled 16-byte chunks: chunk ^= row & 15); frames >= T2 are zero
+        for (int i = T2 * CB_BN * 2 + tid_t * 16; i < CB_ROWS * CB_BN * 2; i += CB_THREADS * 16)
+            *reinterpret_cast<float4v*>(hbuf + i) = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int co = (cw_t * 2 + mi) * 16 + 4 * fg_t;
+            const float4v sc = e_bn2s[mi], sh = e_bn2t[mi];
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni) {
+                const int t = (th_t * 5 + ni) * 16 + fr_t;
+                half4v hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+                if (t < T2) *reinterpret_cast<half4v*>(hbuf + h_off(t, co >> 3) + (co & 7) * 2) = hv;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: context gate per 100-frame segment ----
+        {
+            // partial sums: thread = (8-channel chunk, 32 row phases); scratch [32][2][128] floats in the idle W ring
+            float* part = reinterpret_cast<float*>(ws);
+            const int cg = tid_t & 15, rp = tid_t >> 4;
+            float sum[CB_MAX_SEG][8];
+#pragma unroll
+            for (int sg = 0; sg < CB_MAX_SEG; ++sg)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[sg][e] = 0.0f;
+            for (int t = rp; t < T2; t += 32) {
+                const half8v v = *reinterpret_cast<const half8v*>(hbuf + h_off(t, cg));
+                if (t < a.seg_len) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum[0][e] += (float)v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum[1][e] += (float)v[e];
+                }
+            }
+#pragma unroll
+            for (int sg = 0; sg < CB_MAX_SEG; ++sg)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part[(rp * CB_MAX_SEG + sg) * CB_BN + cg * 8 + e] = sum[sg][e];
+            __syncthreads();
+            if (tid_t < CB_MAX_SEG * CB_BN) {
+                const int sg = tid_t / CB_BN, c = tid_t - sg * CB_BN;
+                const float* part = reinterpret_cast<const float*>(ws);
+                float v = 0.0f, other = 0.0f;
+                for (int p = 0; p < 32; ++p) {
+                    v += part[(p * CB_MAX_SEG + sg) * CB_BN + c];
+                    other += part[(p * CB_MAX_SEG + (1 - sg)) * CB_BN + c];
+                }
+                const int t0 = sg * a.seg_len;
+                const int len = (t0 + a.seg_len < T2 ? t0 + a.seg_len : T2) - t0;
+                ctx[sg * CB_BN + c] = len > 0 ? (v + other) / (float)T2 + v / (float)len : 0.0f;
+            }
+            __syncthreads();
+            {   // g1 = ReLU(Wa ctx + ba): 8 threads per output row, both segments
+                const int j = tid_t >> 3, part8 = tid_t & 7;
+#pragma unroll
+                for (int sg = 0; sg < CB_MAX_SEG; ++sg) {
+                    const float* cx = ctx + sg * CB_BN + part8 * 16;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4v c4 = *reinterpret_cast<const float4v*>(cx + 4 * u);
+                        v = fmaf(e_wa[u][0], c4[0], v);
+                        v = fmaf(e_wa[u][1], c4[1], v);
+                        v = fmaf(e_wa[u][2], c4[2], v);
+                        v = fmaf(e_wa[u][3], c4[3], v);
+                    }
+                    v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);
+                    v += dpp_mov<DPP_QUAD_XOR2>(0.0f, v);
+                    v += dpp_mov<DPP_ROW_HALF_MIRROR>(0.0f, v);
+                    if (part8 == 0) g1[sg * 64 + j] = fmaxf(v + e_ba, 0.0f);
+                }
+            }
+            __syncthreads();
+            {   // gate = sigmoid(Wb g1 + bb): 16 threads per output row (one DPP row), both segments
+                const int co = tid_t >> 4, part16 = tid_t & 15;
+#pragma unroll
+                for (int sg = 0; sg < CB_MAX_SEG; ++sg) {
+                    const float4v g4 = *reinterpret_cast<const float4v*>(g1 + sg * 64 + part16 * 4);
+                    float v = e_wb[0] * g4[0];
+                    v = fmaf(e_wb[1], g4[1], v);
+                    v = fmaf(e_wb[2], g4[2], v);
+                    v = fmaf(e_wb[3], g4[3], v);
+                    v = row16_sum(v);
+                    if (part16 == 0) gate[sg * CB_G + co] = 1.0f / (1.0f + expf(-(v + e_bb)));
+                }
+            }
+            __syncthreads();
+        }
+        // this layer's context parameters are consumed: the next layer's take their registers now; the W ring is free again: the next
+        // layer's first two W1 stages.  (These fifteen vector-memory instructions double the k = 3 phase that follows -- 10.4 k ticks against
+        // 4.8 k in cam_dense_layer_kernel, r08b timeline: every workgroup of the launch is in the same phase at the same moment with its x
+        // prefetch in flight -- but requested behind that phase instead they lengthen the layer entry by more, r08c.)
+        if (more) {
+            load_ctx_params(Ln);
+            const int nstn = Ln.cin_pad / 64;
+            issue_w(0, nstn, Ln.w1, Ln.cin_pad);
+            issue_w(1, nstn, Ln.w1, Ln.cin_pad);
+        }
+
+        // ---- phase C: y = conv_k3(h) * gate -> channels [cin, cin + 32) of x; taps outside [0, T2) are the conv's zero padding ----
+        {
+            const int ct = wave_t & 1, tg = MV_UNIFORM(wave_t >> 1);  // channel tile, time tiles tg, tg + 4, tg + 8
+            float4v yc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            const half8v zero8 = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const half8v af = e_wl[tap][kk];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int tile = tg + 4 * j;
+                        if (tile < CB_TT) {  // uniform per wave
+                            const int r = tile * 16 + fr_t + (tap - 1) * a.dil;
+                            const bool in = r >= 0 && r < CB_ROWS;   // rows T2 .. 159 of h are zero
+                            const int rc = r < 0 ? 0 : (r < CB_ROWS ? r : CB_ROWS - 1);
+                            half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(rc, kk * 4 + fg_t));
+                            bfr = in ? bfr : zero8;
+                            yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const int co = ct * 16 + 4 * fg_t;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int tile = tg + 4 * j;
+                const int t = tile * 16 + fr_t;
+                if (tile < CB_TT && t < T2) {
+                    const float* gt = gate + (t / a.seg_len) * CB_G + co;
+                    half4v hv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(yc[j][r] * gt[r], -65504.0f, 65504.0f);
+                    *reinterpret_cast<half4v*>(xb + (int64_t)t * a.ldx + L.cin + co) = hv;
+                }
+            }
+        }
+        if (more) {
+            load_wl(Ln);                       // the k = 3 weights of this layer are consumed
+            store_tables((l + 1) & 1, Ln.cin, nts, ntt);  // read by transform() of the next layer, behind its entry barrier
+        }
+    }
+}
+
+bool cam_dense_block_supported(int T2, int c_in, int c_out, int bottleneck, int growth, int dil, int seg_len) {
+    return (c_out - c_in) / CB_G <= CB_MAX_LAYERS && bottleneck == CB_BN && growth == CB_G && T2 >= 1 && T2 <= CB_ROWS && c_in >= 128 && c_in % 32 == 0 && c_out <= CB_MAX_CIN + CB_G &&
+           dil >= 1 && dil <= 2 && seg_len > 0 && (T2 + seg_len - 1) / seg_len <= CB_MAX_SEG;
+}
+
+int cam_dense_block_launch(half_t* x, int64_t ldx, int B, int T2, const MvCamLayerDesc* layers_dev, int nlayers, int dil, int seg_len,
+                           hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && layers_dev != nullptr && B > 0 && nlayers > 0 && nlayers <= CB_MAX_LAYERS, "cam_dense_block: bad argument");
+    MV_REQUIRE(T2 >= 1 && T2 <= CB_ROWS && dil >= 1 && dil <= 2 && seg_len > 0 && (T2 + seg_len - 1) / seg_len <= CB_MAX_SEG,
+               "cam_dense_block: unsupported geometry");
+    MV_REQUIRE((ldx % 8) == 0, "cam_dense_block: rows must be 16-byte aligned");
+    static bool smem_set = false;
+    if (!smem_set) {
+        if (MV_SET_MAX_SMEM(cam_dense_block_kernel, CB_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_block: cannot reserve LDS");
+        smem_set = true;
+    }
+    CamBlockArgs a;
+    a.x = x;
+    a.ldx = ldx;
+    a.layers = layers_dev;
+    a.nlayers = nlayers;
+    a.T2 = T2;
+    a.dil = dil;
+    a.seg_len = seg_len;
+    MV_LAUNCH(cam_dense_block_kernel, ((unsigned)B, 1, 1), (CB_THREADS, 1, 1), CB_LDS_BYTES, stream, a);
+    return check_launch("cam_dense_block_kernel");
+}
+
+}  // namespace mv

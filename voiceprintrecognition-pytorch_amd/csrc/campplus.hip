@@ -66,6 +66,7 @@ struct CamppModel : MvModelBase {
         std::vector<DenseLayer> layers;
         float *tr_s, *tr_t;  // transit BN
         ConvLayer transit;
+        MvCamLayerDesc* descs = nullptr;  // device array for cam_dense_block_kernel
     };
     Block blocks[3];
     float *out_s = nullptr, *out_t = nullptr;
@@ -184,6 +185,16 @@ struct CamppModel : MvModelBase {
                 L.wb = upload(t);
                 if ((rc = w.host(p + ".cam_layer.linear2.bias", c.growth_rate, t))) return rc;
                 L.bb = upload(t);
+            }
+            {   // the block's layers as one device array (camblock.hip)
+                std::vector<MvCamLayerDesc> hd(B.layers.size());
+                for (size_t li = 0; li < B.layers.size(); ++li) {
+                    const DenseLayer& L = B.layers[li];
+                    hd[li] = MvCamLayerDesc{L.lin1.w, L.bn1_s, L.bn1_t, L.bn2_s, L.bn2_t, L.local.w, L.wa, L.ba, L.wb, L.bb, L.cin, conv1d_cin_pad(L.cin)};
+                }
+                B.descs = static_cast<MvCamLayerDesc*>(dev_alloc(hd.size() * sizeof(MvCamLayerDesc)));
+                if (B.descs == nullptr) return fail(MV_ERR_HIP, "campp create: out of device memory");
+                MV_HIP_OK(hipMemcpy(B.descs, hd.data(), hd.size() * sizeof(MvCamLayerDesc), hipMemcpyHostToDevice));
             }
             channels += nlayers[bi] * c.growth_rate;
             B.c_out = channels;
@@ -457,7 +468,16 @@ struct CamppModel : MvModelBase {
             const Block& Bk = blocks[bi];
             half_t* X = s.xb[bi];
             const int64_t ld = Bk.c_out;
+            // all layers of the block in one launch, the next layer's first operands requested under the current layer's tail
+            // (camblock.hip); MV_CAMPP_BLOCK=0 (measurement knob) keeps one launch per layer
+            const char* blk_env = getenv("MV_CAMPP_BLOCK");
+            const bool block_kernel = fused_dense && !(blk_env != nullptr && blk_env[0] == '0') &&
+                                      cam_dense_block_supported(T2, Bk.c_in, Bk.c_out, bn_ch, G, Bk.dil, 100);
+            if (block_kernel) {
+                if ((rc = cam_dense_block_launch(X, ld, B, T2, Bk.descs, (int)Bk.layers.size(), Bk.dil, 100, st))) return rc;
+            }
             for (const DenseLayer& L : Bk.layers) {
+                if (block_kernel) break;
                 // utterances of up to 160 strided frames (3.2 s): the whole layer is one launch with the bottleneck kept in LDS
                 if (fused_dense && cam_dense_layer_supported(T2, L.cin, bn_ch, G, Bk.dil, 100)) {
                     if ((rc = cam_dense_layer_launch(X, ld, B, T2, L.cin, L.lin1.w, L.bn1_s, L.bn1_t, L.bn2_s, L.bn2_t, L.local.w, L.wa, L.ba,

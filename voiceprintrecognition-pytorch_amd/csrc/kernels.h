@@ -46,6 +46,18 @@ bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int 
 int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
                            const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
                            const float* bb, int dil, int seg_len, hipStream_t stream);
+// all dense layers of one CAM++ block in one launch (camblock.hip): per-layer parameters as a device array
+struct MvCamLayerDesc {
+    const half_t* w1;                 // packed [128][1][cin_pad]
+    const float *bn1_s, *bn1_t;       // [cin]
+    const float *bn2_s, *bn2_t;       // [128]
+    const half_t* wl;                 // packed [32][3][128]
+    const float *wa, *ba, *wb, *bb;   // context FCs
+    int cin, cin_pad;
+};
+bool cam_dense_block_supported(int T2, int c_in, int c_out, int bottleneck, int growth, int dil, int seg_len);
+int cam_dense_block_launch(half_t* x, int64_t ldx, int B, int T2, const MvCamLayerDesc* layers_dev, int nlayers, int dil, int seg_len,
+                           hipStream_t stream);
 int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_len, float* ctx, hipStream_t stream);
 int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, const half_t* res, int64_t ldr, half_t* out,
                             int64_t ldo, int B, int T, int C, hipStream_t stream);
