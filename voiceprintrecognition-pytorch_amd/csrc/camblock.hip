@@ -24,7 +24,8 @@
 // ~130 registers (76 spilled, each reload an s_waitcnt vmcnt(0)): they hang on a per-layer MV_OPAQUE thread id; the layer descriptors
 // were read with vector loads (the kernel stores to global memory) whose wait drained the prefetch: they are copied to LDS once and read
 // into scalar registers; a select on a loaded table value puts the wait behind the load: index clamp instead; the compiler's own waits for
-// the parameter loads are pulled to the layer entry with MV_OPAQUE touches.
+// the parameter loads are pulled to the layer entry with MV_OPAQUE touches.  Starting the odd workgroups 4 - 20 us late (so that half the
+// chip is in its stage loop while the other half is in its tail) changed nothing: 2.23 - 2.27 ms for every delay (r08d).
 #include "kernels.h"
 
 namespace mv {
