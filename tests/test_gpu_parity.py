@@ -270,6 +270,13 @@ def test_gpu_campp_stress_golden_takes_the_fp32_head(monkeypatch):
     print(f'campp_stress forced onto the fp16 head: 1 - cos = {cd16:.3e}')
 
 
+def test_gpu_model_info_is_model_specific():
+    """mv_model_info: the CAM++ keys do not exist on other backbones (error, not a silent zero)"""
+    info = {1: None}
+    with pytest.raises(RuntimeError, match='no such key'):
+        lc.model_case(product_lib(), DEV, 'ecapa_tiny', info=info)
+
+
 @pytest.mark.parametrize('case', ['campp', 'campp_short'])
 def test_gpu_campp_well_conditioned_checkpoints_keep_the_fp16_head(case, monkeypatch):
     """trained-like BatchNorm gains: the calibration difference is ~1e-7, the handle keeps the fp16 head (the fast one); forced onto
