@@ -4,7 +4,9 @@
 
 namespace mv {
 
-constexpr int MF_WAVES = 4;                        // one wave per SIMD: the transform holds ~190 registers (8 waves: 52 spilled, r07f A/B)
+// waves per workgroup (melfft_waves()): 4 = prefetch form, ~380 registers, one wave per SIMD; 8 = no prefetch, 232 registers, two per SIMD;
+// 12 = 168-register cap, 36 spilled.  README geometry, 256 x 3 s (profiles/r09a_melspec_pow2_waves_ab.log): 107.6 / 70.1 / 87.1 us
+constexpr int MF_WAVES_DEFAULT = 8;
 constexpr int MF_ROW = 65;                          // complex elements per transpose row: [4 frames][16 lanes] + 1 pad
 constexpr int MF_PSTR = 520;                        // floats between the power rows of the wave's four frames (513 bins + pad)
 constexpr int MF_SLOT_FLOATS = 16 * MF_ROW * 2;     // 2080 floats per wave: 16 transpose rows = 4 power rows
@@ -18,12 +20,13 @@ struct MelFftArgs {
     float* out;               // [B, T, n_mels]
     const float* window;      // [n_fft]
     const float* tw512;       // [32 k1][16 l][2]: cos, sin of 2 pi l k1 / 512
-    const float* w1024;       // [17][2]: cos, sin of 2 pi l / 1024
+    const float* w1024;       // [512][2]: cos, sin of 2 pi k / 1024
     const float* melb;        // MFMA B-operand order (frontend_common.h), passes back to back
     int B, T, n_fft, hop, pad, n_mels, cmn, tile_rows;
     MelPlan plan;
 };
 
+int melfft_waves();
 size_t melfft_fixed_lds_bytes();
 int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream);
 

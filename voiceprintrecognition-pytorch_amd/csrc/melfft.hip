@@ -16,7 +16,16 @@
 //     bins among themselves);
 //   * |X|^2 -> power rows in the transpose slot -> banded mel (weights streamed from L1 in MFMA operand order, run-time step counts:
 //     the plan of frontend_common.h for whatever filter bank the arguments give) -> tile -> time mean, mask, single write.
+//
+// Occupancy (round 3, r09a): the first form (4 waves, next quad's samples prefetched into a second register set) held ~400 registers = one
+// wave per SIMD and ran the README geometry in 104-108 us.  Of those registers ~80 were loop-invariant ADDRESSES: the tables sat behind the
+// 66 KB of wave slots, beyond the 16-bit immediate of an LDS instruction, so each of the 80 table reads of a quad got its own address
+// register; another ~50 were the split twiddles W1024^k and the power-row addresses, hoisted out of the frame loop.  Tables first in LDS,
+// W1024^k from an LDS table, opaque per-quad store offsets, no divergent branch around the power stores: 232 registers without the
+// prefetch = 8 waves per workgroup, two per SIMD, 70 us (n_fft 512: 97 -> 63 us, 256: 173 -> 108 us).  12 waves (168-register cap)
+// spill 36 registers: 87 us.  MV_MELFFT_WAVES = 4 | 8 | 12 selects the form (profiles/r09a_melspec_pow2_waves_ab.log).
 // hipcc-flags: -fno-slp-vectorize -fno-signed-zeros
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -61,13 +70,20 @@ __device__ __forceinline__ void split_pair(cplx za, cplx zb, float wc, float ws,
     p_hi = 0.25f * (br * br + bi * bi);
 }
 
-__global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) {
+// WAVES per workgroup and whether the next quad's samples are PREFETCHed into a second register set (~190 registers: one wave per SIMD)
+// or loaded at the top of the quad (~130: two or three waves per SIMD hide the latency for each other)
+template <int WAVES, bool PREFETCH>
+__global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) {
+    constexpr int MF_WAVES = WAVES;
     constexpr int THREADS = MF_WAVES * 64;
     MV_DYN_SMEM(smem);
-    float* xbuf = reinterpret_cast<float*>(smem);                  // [MF_WAVES][MF_SLOT_FLOATS]: transpose rows, then power rows
-    float* lwin = xbuf + MF_WAVES * MF_SLOT_FLOATS;                // [1024] window (zero beyond n_fft)
+    // (the tables come FIRST: their reads are base + compile-time offset, and an LDS offset is a 16-bit immediate -- behind the 66 KB of
+    // wave slots every one of the 80 table reads of a quad had its own loop-invariant address register)
+    float* lwin = reinterpret_cast<float*>(smem);                  // [1024] window (zero beyond n_fft)
     float* ltw = lwin + 1024;                                      // [32 k1][16 l][2]: cos, sin of 2 pi l k1 / 512
-    float* tile = ltw + 1024;                                      // [tile_rows][n_mels]
+    float* lwk = ltw + 1024;                                       // [512][2]: cos, sin of 2 pi k / 1024 (the real-input split)
+    float* xbuf = lwk + 1024;                                      // [MF_WAVES][MF_SLOT_FLOATS]: transpose rows, then power rows
+    float* tile = xbuf + MF_WAVES * MF_SLOT_FLOATS;                // [tile_rows][n_mels]
     float* colsum = xbuf;                                          // [MF_WAVES][256] then mean[256], after the frame loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,6 +99,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
     for (int i = tid; i < 1024; i += THREADS) {
         lwin[i] = i < n_fft ? a.window[i] : 0.0f;
         ltw[i] = a.tw512[i];
+        lwk[i] = a.w1024[i];
     }
     for (int i = tid; i < MF_WAVES * MF_SLOT_FLOATS; i += THREADS) xbuf[i] = 0.0f;  // pads of the power rows meet zero weights: keep them finite
     __syncthreads();
@@ -93,9 +110,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
     const cplx* ra_read = reinterpret_cast<const cplx*>(wslot) + rowa * MF_ROW + 16 * fs;
     const cplx* rb_read = reinterpret_cast<const cplx*>(wslot) + rowb * MF_ROW + 16 * fs;
     float* prow = wslot + fs * MF_PSTR;
-    // W1024^l16 (lane 0: 1) and, for lane 0's second set, W1024^16
-    const float wlc = a.w1024[2 * l16], wls = a.w1024[2 * l16 + 1];
-    const float w16c = a.w1024[32], w16s = a.w1024[33];
+    // W1024^k of this lane's bins k = l16 + 32 k2 (lane 0's second set: 16 + 32 k2) come from the LDS table at + 64 k2 floats.  (They --
+    // and the sixteen power-row addresses below -- are the same in every quad: computed from per-lane constants the compiler hoists
+    // all of them out of the frame loop, ~80 registers that either spill or cost the second wave per SIMD; a table read and an
+    // address the compiler cannot see through per quad keep them out of the loop-carried set.)
+    const float* wk_own = lwk + 2 * l16;
     const bool keep = (l16 & (sb - 1)) == 0;   // this lane's bins exist in the n_fft-point transform
     const float* arow = wslot + (lane & 3) * MF_PSTR;
     const int blk = lane >> 2;
@@ -166,12 +185,13 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
         // window (zero beyond n_fft: the frame is zero-extended to 1024 samples)
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
-            const float2v we = *reinterpret_cast<const float2v*>(lwin + 64 * h + 2 * l16);
-            const float2v wo = *reinterpret_cast<const float2v*>(lwin + 64 * h + 32 + 2 * l16);
+            const float2v we = lds_load_unmerged(reinterpret_cast<const float2v*>(lwin + 64 * h + 2 * l16));
+            const float2v wo = lds_load_unmerged(reinterpret_cast<const float2v*>(lwin + 64 * h + 32 + 2 * l16));
             ev[h] = cmul_elem(ev[h], we[0], we[1]);
             od[h] = cmul_elem(od[h], wo[0], wo[1]);
         }
-        if (q + MF_WAVES < nquads) load_quad(q + MF_WAVES, ev_next, od_next);
+        if constexpr (PREFETCH)
+            if (q + MF_WAVES < nquads) load_quad(q + MF_WAVES, ev_next, od_next);
         // ---- Y[k1], k1 = 0..31: fft32 = two fft16 + radix-2 ----
         fft16(ev);
         fft16(od);
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
         cplx za[16], zb[16];
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
-            const float2v tw = *reinterpret_cast<const float2v*>(ltw + 2 * (k1 * 16 + l16));
+            const float2v tw = lds_load_unmerged(reinterpret_cast<const float2v*>(ltw + 2 * (k1 * 16 + l16)));
             tw_write[k1 * MF_ROW] = cmul_conjtw(ev[k1] + od[k1], tw[0], tw[1]);
             od[k1] = ev[k1] - od[k1];   // the second half's value: ev is dead from here on (32 registers less across the transpose)
         }
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
         MV_WAVE_FENCE();
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
-            const float2v tw = *reinterpret_cast<const float2v*>(ltw + 2 * ((16 + k1) * 16 + l16));
+            const float2v tw = lds_load_unmerged(reinterpret_cast<const float2v*>(ltw + 2 * ((16 + k1) * 16 + l16)));
             tw_write[k1 * MF_ROW] = cmul_conjtw(od[k1], tw[0], tw[1]);
         }
         MV_WAVE_FENCE();
@@ -204,27 +224,30 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
         fft16(zb);  // zb[k2] = Z[32 - l16 + 32 k2]   (lane 0: Z[16 + 32 k2])
         // ---- real-input split + power ----
         const bool lane0 = l16 == 0;
+        // bin k = l16 + 32 k2 lives at k >> sbl (exact for the lanes that keep it); the other lanes (n_fft < 1024: their bins do not exist in
+        // the n_fft-point transform) store into the row's pad, which meets zero mel weights -- no divergent branch around 32 stores
+        int o_lo = keep ? l16 >> sbl : 516, o_hi = keep ? (512 >> sbl) - (l16 >> sbl) : 517;
+        const int o_step = keep ? 32 >> sbl : 0;
+        MV_OPAQUE(o_lo);
+        MV_OPAQUE(o_hi);
         static_for<16>([&](auto ic) {
             constexpr int k2 = decltype(ic)::value;
             // k = l16 + 32 k2: partner zb[15 - k2]; lane 0 (k = 32 k2): partner za[16 - k2] (k2 = 0: itself -> X[0], X[512])
             const cplx pa = za[k2];
             const cplx other = zb[15 - k2], self = za[(16 - k2) & 15];
             const cplx pb = cmake(lane0 ? self.re : other.re, lane0 ? self.im : other.im);
-            const cplx wk = mul_w32<k2>(cmake(wlc, -wls));  // W1024^k = W1024^l16 W32^k2 = wk.re + i wk.im (im = -sin)
+            const float2v wk = lds_load_unmerged(reinterpret_cast<const float2v*>(wk_own + 64 * k2));  // (cos, sin) of 2 pi k / 1024
             float p_lo, p_hi;
-            split_pair(pa, pb, wk.re, -wk.im, p_lo, p_hi);
-            if (keep) {
-                const int k = l16 + 32 * k2;
-                prow[k >> sbl] = p_lo;
-                prow[(512 - k) >> sbl] = p_hi;
-            }
+            split_pair(pa, pb, wk[0], wk[1], p_lo, p_hi);
+            prow[o_lo + k2 * o_step] = p_lo;
+            prow[o_hi - k2 * o_step] = p_hi;
         });
         if (lane0 && (16 & (sb - 1)) == 0) {  // lane 0's second set: k = 16 + 32 k2 pairs with 16 + 32 (15 - k2) inside the set
             static_for<8>([&](auto ic) {
                 constexpr int k2 = decltype(ic)::value;
-                const cplx wk = mul_w32<k2>(cmake(w16c, -w16s));
+                const float2v wk = lds_load_unmerged(reinterpret_cast<const float2v*>(lwk + 2 * (16 + 32 * k2)));
                 float p_lo, p_hi;
-                split_pair(zb[k2], zb[15 - k2], wk.re, -wk.im, p_lo, p_hi);
+                split_pair(zb[k2], zb[15 - k2], wk[0], wk[1], p_lo, p_hi);
                 const int k = 16 + 32 * k2;
                 prow[k >> sbl] = p_lo;
                 prow[(512 - k) >> sbl] = p_hi;
@@ -302,12 +325,18 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
             }
         }
     };
-    {
+    if constexpr (PREFETCH) {
         cplx ea[16], oa[16], eb[16], ob[16];
         if (wave < nquads) load_quad(wave, ea, oa);
         for (int q = wave; q < nquads; q += 2 * MF_WAVES) {
             process_quad(q, ea, oa, eb, ob);
             if (q + MF_WAVES < nquads) process_quad(q + MF_WAVES, eb, ob, ea, oa);
+        }
+    } else {
+        cplx ea[16], oa[16];
+        for (int q = wave; q < nquads; q += MF_WAVES) {
+            load_quad(q, ea, oa);
+            process_quad(q, ea, oa, ea, oa);
         }
     }
 
@@ -345,16 +374,37 @@ __global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs 
     }
 }
 
-size_t melfft_fixed_lds_bytes() { return ((size_t)MF_WAVES * MF_SLOT_FLOATS + 2048) * sizeof(float); }
+// MV_MELFFT_WAVES = 4 (prefetch form) | 8 | 12 (default MF_WAVES_DEFAULT): A/B knob, every form is covered by the tests
+int melfft_waves() {
+    static int w = -1;
+    if (w < 0) {
+        const char* e = std::getenv("MV_MELFFT_WAVES");
+        const int v = e != nullptr ? std::atoi(e) : MF_WAVES_DEFAULT;
+        w = (v == 4 || v == 8 || v == 12) ? v : MF_WAVES_DEFAULT;
+    }
+    return w;
+}
 
-int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream) {
+size_t melfft_fixed_lds_bytes() { return ((size_t)melfft_waves() * MF_SLOT_FLOATS + 3072) * sizeof(float); }
+
+template <int WAVES, bool PREFETCH>
+static int melfft_launch_as(const MelFftArgs& a, size_t smem, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (MV_SET_MAX_SMEM(melspec_pow2_kernel, 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "melspec_pow2_kernel: cannot reserve dynamic LDS");
+        if (MV_SET_MAX_SMEM((melspec_pow2_kernel<WAVES, PREFETCH>), 160 * 1024) != hipSuccess)
+            return fail(MV_ERR_HIP, "melspec_pow2_kernel: cannot reserve dynamic LDS");
         attr_set = true;
     }
-    MV_LAUNCH(melspec_pow2_kernel, ((unsigned)a.B, 1, 1), (MF_WAVES * 64, 1, 1), smem, stream, a);
+    MV_LAUNCH((melspec_pow2_kernel<WAVES, PREFETCH>), ((unsigned)a.B, 1, 1), (WAVES * 64, 1, 1), smem, stream, a);
     return check_launch("melspec_pow2_kernel");
+}
+
+int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream) {
+    switch (melfft_waves()) {
+        case 4: return melfft_launch_as<4, true>(a, smem, stream);
+        case 8: return melfft_launch_as<8, false>(a, smem, stream);
+        default: return melfft_launch_as<12, false>(a, smem, stream);
+    }
 }
 
 }  // namespace mv

@@ -642,15 +642,15 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
             for (int k = 0; k < h->nbin; ++k) banks[j][k] = fbT[(size_t)j * h->nbin_pad + k];
         std::vector<float> melb;
         if (mv::build_mel_plan(banks, mv::MF_PSTR, &h->plan, &melb)) {
-            std::vector<float> tw(32 * 16 * 2), w1(17 * 2);
+            std::vector<float> tw(32 * 16 * 2), w1(512 * 2);
             for (int k1 = 0; k1 < 32; ++k1)
                 for (int l = 0; l < 16; ++l) {
                     tw[2 * (k1 * 16 + l)] = (float)cos(2.0 * pi * (l * k1) / 512.0);
                     tw[2 * (k1 * 16 + l) + 1] = (float)sin(2.0 * pi * (l * k1) / 512.0);
                 }
-            for (int l = 0; l <= 16; ++l) {
-                w1[2 * l] = (float)cos(2.0 * pi * l / 1024.0);
-                w1[2 * l + 1] = (float)sin(2.0 * pi * l / 1024.0);
+            for (int k = 0; k < 512; ++k) {
+                w1[2 * k] = (float)cos(2.0 * pi * k / 1024.0);
+                w1[2 * k + 1] = (float)sin(2.0 * pi * k / 1024.0);
             }
             if ((rc = upload_vec(tw, &h->d_tw512)) || (rc = upload_vec(w1, &h->d_w1024)) || (rc = upload_vec(melb, &h->d_melb))) {
                 mv_melspec_destroy(h);
