@@ -376,6 +376,16 @@ int mv_fcm_conv3x3_f16(const void* x, int32_t Fin, int32_t sf, const void* x2, i
 int mv_fcm_block_f16(const void* x, int32_t Fin, int32_t sf, const void* w1, const float* b1, const void* w2, const float* b2,
                      int32_t shortcut, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream);
 
+/* The FIRST BasicResBlock of the CAM++ front-end together with the conv in front of it (campplus.py:262-264,283-285: head.conv1 + bn1 +
+ * ReLU, then head.layer1[0], stride (2, 1) with its shortcut conv) as ONE launch: the 32-map image of the features is evaluated inside the
+ * kernel and never written.  feats fp32 [B, T, F];  c1a = mv_fcm_c1_pack of the folded conv weights, c1b fp32 [32] = the folded BN shift;
+ * the other arguments as mv_fcm_block_f16 with sf = 2, shortcut = 1.  The conv weights act as fp16 (like every other conv of the fp16
+ * head), the features exactly (as x_hi + x_lo). */
+int mv_fcm_block_c1_f16(const float* feats, int32_t F, const void* c1a, const float* c1b, const void* w1, const float* b1, const void* w2,
+                        const float* b2, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream);
+/* host -> host: w fp32 [32 maps][3 mel taps][3 time taps] (BatchNorm scale folded) -> out fp16 [2][64][8], the MFMA operand order of the kernel */
+int mv_fcm_c1_pack(const float* w, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -502,6 +502,53 @@ def fcm_block_case(cdll, device, B, Fin, T, sf, strided_out=False, seed=0):
     return err
 
 
+FCM_BLOCK_C1_CASES = [
+    dict(B=2, F=12, T=45),      # NT = 1, bands; frames outside [0, T) on both sides of the only tile
+    dict(B=1, F=9, T=70),       # odd F (the last mid row reads the padding row below the map), NT = 2
+    dict(B=1, F=5, T=330),      # two time tiles: halo columns across the tile edge
+    dict(B=3, F=3, T=16),       # the smallest map: every row touches a padding bin
+    dict(B=1, F=80, T=131),     # the product's row count
+]
+
+
+def fcm_block_c1_case(cdll, device, B, F, T, seed=0, scale=4.0):
+    """head.conv1 + bn1 + ReLU (campplus.py:262-264,283) and the first BasicResBlock in one launch (mv_fcm_block_c1_f16).  Reference in
+    fp64: the conv of the fp32 features with the fp16-rounded folded weights, rounded to fp16 (the map the block's MFMAs read), then
+    the block as in fcm_block_case."""
+    import ctypes
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(seed)
+    Fout = (F - 1) // 2 + 1
+    feats = torch.randn(B, T, F, generator=g) * scale
+    feats[0, T // 2, F // 2] = 20000.0                    # far beyond fp16 precision of the hi part alone; exact as hi + lo
+    c1w = torch.randn(32, 3, 3, generator=g) * 0.3        # [co][df][dt]
+    c1b = torch.randn(32, generator=g) * 0.1
+    w1 = (torch.randn(9, 32, 32, generator=g) * 0.08).half()
+    w2 = (torch.randn(10, 32, 32, generator=g) * 0.08).half()
+    b1 = torch.randn(32, generator=g) * 0.1
+    b2 = torch.randn(32, generator=g) * 0.1
+    packed = torch.zeros(2 * 64 * 8, dtype=torch.float16)
+    c1w_c = c1w.contiguous()
+    _hip.check(cdll.mv_fcm_c1_pack(c1w_c.data_ptr(), packed.data_ptr()), cdll)
+    y = torch.full((B, Fout, T, 32), float('nan')).half().to(device)
+    sB, sF, sT = Fout * T * 32, T * 32, 32
+    fd, pd, cbd, w1d, w2d, b1d, b2d = (t.to(device) for t in (feats, packed, c1b, w1, w2, b1, b2))
+    _hip.check(cdll.mv_fcm_block_c1_f16(fd.data_ptr(), F, pd.data_ptr(), cbd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(),
+                                        b2d.data_ptr(), y.data_ptr(), sB, sF, sT, B, T, _stream(fd)), cdll)
+    xin = feats.double().permute(0, 2, 1).unsqueeze(1)                                       # [B, 1, F, T]
+    c1 = Fn.conv2d(xin, c1w.half().double().unsqueeze(1), c1b.double(), padding=1).clamp(min=0, max=65504).half().double()   # [B, 32, F, T]
+    k33 = lambda w: w[:9].double().reshape(3, 3, 32, 32).permute(2, 3, 0, 1).contiguous()   # [co, ci, df, dt]
+    mid = Fn.conv2d(c1, k33(w1), b1.double(), stride=(2, 1), padding=1).clamp(min=0).half().double()
+    ref = Fn.conv2d(mid, k33(w2), b2.double(), padding=1) + Fn.conv2d(c1, w2[9].double().reshape(32, 32, 1, 1), None, stride=(2, 1))
+    ref = ref.clamp(min=0, max=65504).permute(0, 2, 3, 1)
+    out = y.cpu().double()
+    assert torch.isfinite(out).all(), 'unwritten outputs'
+    err = ((out - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+    # fp16 rounding of the stored result + fp16 ulp flips of the two intermediate maps where the fp32 accumulation order differs
+    assert err < 4e-3, err
+    return err
+
+
 def wave_prepare_case(cdll, device, B=5, L=5000, normalize=True, seed=0):
     from oracle import frontend
     g = torch.Generator().manual_seed(seed)

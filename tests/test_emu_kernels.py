@@ -136,6 +136,12 @@ def test_emu_fcm_block(idx):
     lc.fcm_block_case(emu_cdll(), 'cpu', seed=idx, **lc.FCM_BLOCK_CASES[idx])
 
 
+@pytest.mark.parametrize('idx', range(len(lc.FCM_BLOCK_C1_CASES)))
+def test_emu_fcm_block_with_first_conv(idx):
+    """the head's first conv evaluated by the producers of the first block's kernel (no [B, F, T, 32] map in memory)"""
+    lc.fcm_block_c1_case(emu_cdll(), 'cpu', seed=50 + idx, **lc.FCM_BLOCK_C1_CASES[idx])
+
+
 def test_emu_fcm_block_balanced_narrow_tiles(monkeypatch):
     """MV_FCM_BLOCK_NT=2: T = 200 becomes two tiles of 100 output positions (NT = 2, halo columns recomputed at the tile edge)"""
     monkeypatch.setenv('MV_FCM_BLOCK_NT', '2')

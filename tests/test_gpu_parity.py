@@ -628,6 +628,24 @@ def test_gpu_campp_fused_and_unfused_fcm_agree(monkeypatch):
     assert cd1 < 1e-4 and cd0 < 1e-4, (cd1, cd0)
 
 
+@pytest.mark.parametrize('idx', range(len(lc.FCM_BLOCK_C1_CASES) + 2))
+def test_gpu_fcm_block_with_first_conv(idx):
+    """head.conv1 evaluated inside the first block's kernel: the emulator's cases + the product shape (80 bins x 298 frames) and a ragged one"""
+    cases = lc.FCM_BLOCK_C1_CASES + [dict(B=5, F=80, T=298), dict(B=2, F=41, T=621)]
+    lc.fcm_block_c1_case(product_lib(), DEV, seed=60 + idx, **cases[idx])
+
+
+def test_gpu_campp_first_conv_inside_and_outside_the_block_agree(monkeypatch):
+    """MV_FCM_C1=0 (head.conv1 as its own launch, fp32 weights, map in HBM) and the default (inside the first block's kernel, fp16 weights)
+    on the same goldens: both inside the tolerance"""
+    for case in ('campp', 'campp_short'):
+        monkeypatch.delenv('MV_FCM_C1', raising=False)
+        cd1, _ = lc.model_case(product_lib(), DEV, case)
+        monkeypatch.setenv('MV_FCM_C1', '0')
+        cd0, _ = lc.model_case(product_lib(), DEV, case)
+        assert cd1 < 1e-4 and cd0 < 1e-4, (case, cd1, cd0)
+
+
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
                                  dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
 def test_gpu_res2net_fused_chain(cfg):

@@ -37,6 +37,7 @@ struct CamppModel : MvModelBase {
     // head
     float* c1_w = nullptr;  // [32][9] fp32 (BN folded)
     float* c1_b = nullptr;
+    half_t* c1_a = nullptr;  // the same weights as MFMA fragments (fcm_c1_pack): first conv inside the first block's kernel
     struct Conv2d {
         half_t* w = nullptr;  // [ntaps][32][32]
         float* bias = nullptr;
@@ -133,6 +134,11 @@ struct CamppModel : MvModelBase {
                 for (int j = 0; j < 9; ++j) W[co * 9 + j] *= s[co];
             c1_w = upload(W);
             c1_b = upload(t);
+            std::vector<half_t> frag(2 * 64 * 8);
+            fcm_c1_pack(W.data(), frag.data());
+            c1_a = static_cast<half_t*>(dev_alloc(frag.size() * sizeof(half_t)));
+            if (c1_a == nullptr) return fail(MV_ERR_HIP, "campp create: out of device memory");
+            MV_HIP_OK(hipMemcpy(c1_a, frag.data(), frag.size() * sizeof(half_t), hipMemcpyHostToDevice));
         }
         const char* names[4] = {"head.layer1.0", "head.layer1.1", "head.layer2.0", "head.layer2.1"};
         for (int i = 0; i < 4; ++i) {
@@ -384,14 +390,20 @@ struct CamppModel : MvModelBase {
         if (f32) {
             if ((rc = head_fp32(feats, B, T, s, st))) return rc;
         } else {
-        if ((rc = fcm_conv1_launch(feats, s.m0, c1_w, c1_b, B, T, F, st))) return rc;
         auto plain = [&](int Fd) { return std::array<int64_t, 3>{(int64_t)Fd * T * 32, (int64_t)T * 32, 32}; };
         const half_t* cur = s.m0;
         int Fc = F;
         half_t* pp[2] = {s.m1, s.m2};
-        // MV_FCM_FUSED=0 (measurement knob) keeps the two launches per BasicResBlock with the intermediate map in HBM
+        // MV_FCM_FUSED=0 (measurement knob) keeps the two launches per BasicResBlock with the intermediate map in HBM; MV_FCM_C1=0 keeps
+        // head.conv1 as its own launch (fcm_conv1_kernel: fp32 weights on the vector pipe, the 32-map image of the features in HBM)
         const char* fcm_env = getenv("MV_FCM_FUSED");
         const bool fused_block = !(fcm_env != nullptr && fcm_env[0] == '0');
+        const char* c1_env = getenv("MV_FCM_C1");
+        const bool c1_inside = fused_block && !(c1_env != nullptr && c1_env[0] == '0') && res[0].stride == 2 && res[0].has_shortcut && F >= 3 &&
+                               (int64_t)B * T * F < ((int64_t)1 << 31) &&
+                               fcm_block_supported(pp[0], plain((F - 1) / 2 + 1)[0], plain((F - 1) / 2 + 1)[1], 32, T, F);
+        if (!c1_inside)
+            if ((rc = fcm_conv1_launch(feats, s.m0, c1_w, c1_b, B, T, F, st))) return rc;
         for (int i = 0; i < 4; ++i) {
             const ResBlock& r = res[i];
             const int Fo = (Fc - 1) / r.stride + 1;
@@ -400,8 +412,9 @@ struct CamppModel : MvModelBase {
                 // one launch per block (fcmblock.hip): x read once, mid map in LDS, output written once
                 half_t* t2 = (cur == pp[0]) ? pp[1] : pp[0];
                 if (fcm_block_supported(t2, so[0], so[1], so[2], T, Fc)) {
-                    if ((rc = fcm_block_launch(cur, Fc, r.stride, r.conv1.w, r.conv1.bias, r.conv2.w, r.conv2.bias, r.has_shortcut ? 1 : 0, t2,
-                                               so[0], so[1], so[2], B, T, st)))
+                    const bool c1 = i == 0 && c1_inside;  // the block's input rows are made from the features inside the kernel
+                    if ((rc = fcm_block_launch(c1 ? nullptr : cur, Fc, r.stride, r.conv1.w, r.conv1.bias, r.conv2.w, r.conv2.bias,
+                                               r.has_shortcut ? 1 : 0, t2, so[0], so[1], so[2], B, T, st, c1 ? feats : nullptr, c1_a, c1_b)))
                         return rc;
                     cur = t2;
                     Fc = Fo;

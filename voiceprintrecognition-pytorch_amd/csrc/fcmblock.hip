@@ -42,6 +42,10 @@ struct FcmBlockArgs {
     half_t* y;
     int64_t y_sB, y_sF, y_sT;
     int B, T, Fin, Fout, shortcut, tile_out;  // tile_out: output positions per time tile (<= 64 * NT - 2)
+    // C1 form (the head's first block): x is not read -- its rows are head.conv1 + bn1 + ReLU of the features, evaluated by the producers
+    const float* feats;  // [B, T, Fin] fp32
+    const half_t* c1a;   // [2 map tiles][64 lanes][8]: the MFMA A fragments of fcm_c1_pack
+    const float* c1b;    // [32] folded BN shift
 };
 
 // byte offset of the 16-byte chunk `chunk` of position `pos` inside a row slot (64 B per position, chunks XOR-swizzled so that
@@ -71,8 +75,15 @@ struct FbkPhase {  // accumulator sets of the consumers' step i (PH = i % 3): bo
     static constexpr int N = PH, C = (PH + 2) % 3, P = (PH + 1) % 3;
 };
 
-template <int NT, int SF>
+// C1: the block input (head.conv1 + bn1 + ReLU of the fp32 features, campplus.py:262-264,283 -- one input map, 3 x 3, zero padding) is
+// evaluated by the producers straight into the ring instead of being read from HBM: one MFMA per 16 positions and map tile with
+//     K slot 8 dt + e:  e = 0..2  x_hi[f - 1 + e][t + dt - 1],   e = 3..5  x_lo[f - 1 + e - 3][t + dt - 1],   e = 6, 7 and dt = 3: unused
+// (x = x_hi + x_lo as two fp16 values: the features enter exactly; the folded weights as fp16 like every other FCM conv), so a lane's B
+// fragment is ONE 12-byte load (three neighbouring mel bins of one frame) + 6 conversions, no staging in LDS.  The [B, 80, T, 32] map
+// (390 MB per 256 x 3 s batch, written by fcm_conv1_kernel and read back here) and its launch disappear.
+template <int NT, int SF, bool C1 = false>
 __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_ttiles, int n_bands, int band_rows) {
+    static_assert(!C1 || SF == 2, "the first block of the head is the strided one");
     typedef FcmBlk<NT, SF> G;
     MV_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,13 +153,16 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
         struct RowReq {            // one row request, uniform: source row (or the zero page) and ring slot
             const half_t* base;
             unsigned slot;
+            int fin, slot_off;     // input row, byte offset of the slot (C1)
             bool rok;
         };
         auto next_row = [&]() {
             const int fin = rbase + irel;
             RowReq r;
             r.rok = fin >= 0 && fin < a.Fin && irel <= rel_last;
-            r.base = a.x + ((int64_t)b * a.Fin + (r.rok ? fin : 0)) * a.T * FBK_C;
+            r.fin = fin;
+            r.slot_off = islot * G::SLOT_BYTES;
+            r.base = C1 ? nullptr : a.x + ((int64_t)b * a.Fin + (r.rok ? fin : 0)) * a.T * FBK_C;
             r.slot = lds0 + (unsigned)(islot * G::SLOT_BYTES);
             ++irel;
             islot = islot + 1 == G::RING ? 0 : islot + 1;
@@ -170,13 +184,121 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
 #pragma unroll
             for (int i = 0; i < G::TPW; ++i) issue_part(r, i);
         };
+        // ---- C1: the ring rows are computed here ----
+        // tile ni < NT of this wave = positions wave * 16 NT + 16 ni ... + 15 of the slot; tile NT = the slot's last two positions
+        // (MW, MW + 1; one wave takes it).  Position q holds frame t = t0 - 2 + q; lane (fr, fg) of a tile supplies the K slots of the
+        // time tap dt = fg (fg = 3: unused slots, it repeats dt = 1) and ends up with the maps 8 fg ... 8 fg + 7 of position fr.
+        // Everything that depends on the lane and the tile only -- frame offsets, validity, slot offsets -- is the same for every row.
+        typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+        constexpr int NC1 = C1 ? NT + 1 : 1;
+        half8v c1a[2];
+        float4v c1bv[2];
+        int c1_toff[NC1];      // element offset of the tap's frame inside the utterance's features (clamped into [0, T))
+        unsigned c1_qoff[NC1]; // byte offset of (position, chunk fg) inside a slot
+        unsigned c1_tap_ok = 0, c1_pos_ok = 0, c1_tile_inside = 0;  // bit ni: the tap's frame / the position's frame lies inside [0, T); every lane's do (uniform)
+        const float* fb = nullptr;
+        if constexpr (C1) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                c1a[mi] = *reinterpret_cast<const half8v*>(a.c1a + (mi * 64 + lane) * 8);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c1bv[mi][r] = a.c1b[8 * fg + 4 * mi + r];
+            }
+            fb = a.feats + (int64_t)b * a.T * a.Fin;
+            const int dtl = fg < 3 ? fg : 1;
+#pragma unroll
+            for (int ni = 0; ni < NC1; ++ni) {
+                const int q0 = ni < NT ? wave * (16 * NT) + 16 * ni : G::MW;
+                const int q = q0 + fr;
+                const int t = t0 - 2 + q;
+                const int tt_ = t + dtl - 1;
+                const int tc = tt_ < 0 ? 0 : (tt_ >= a.T ? a.T - 1 : tt_);
+                c1_toff[ni] = tc * a.Fin;
+                c1_qoff[ni] = (unsigned)fbk_off(q, fg);
+                if (tt_ >= 0 && tt_ < a.T) c1_tap_ok |= 1u << ni;
+                if (t >= 0 && t < a.T) c1_pos_ok |= 1u << ni;
+                const int tlo = t0 - 2 + q0;  // frames tlo - 1 ... tlo + 16 are touched by the tile
+                if (tlo - 1 >= 0 && tlo + 16 < a.T) c1_tile_inside |= 1u << ni;
+            }
+        }
+        // the features a row needs: ONE 12-byte load per tile (mel bins lo ... lo + 2 of the tap's frame, lo = f - 1 clamped into the row)
+        auto c1_load = [&](const RowReq& r, int extra_wave, float3u (&pf)[NC1]) __attribute__((always_inline)) {
+            if (!r.rok) return;
+            const int lo = r.fin - 1 < 0 ? 0 : (r.fin + 1 >= a.Fin ? a.Fin - 3 : r.fin - 1);
+            const float* rowp = fb + lo;
+#pragma unroll
+            for (int ni = 0; ni < NC1; ++ni) {
+                if (ni == NT && wave != extra_wave) continue;
+                pf[ni] = *reinterpret_cast<const float3u*>(rowp + c1_toff[ni]);
+            }
+        };
+        // conv + bias + ReLU of the row into its ring slot (zeros for rows outside the map and frames outside [0, T): conv1 of the block pads
+        // THIS map, not the features)
+        auto c1_make = [&](const RowReq& r, int extra_wave, const float3u (&pf)[NC1]) __attribute__((always_inline)) {
+            char* const slot = smem + r.slot_off;
+            const bool first = r.fin == 0, last = r.fin == a.Fin - 1;  // uniform: the bin below / above the row is padding
+#pragma unroll
+            for (int ni = 0; ni < NC1; ++ni) {
+                if (ni == NT && wave != extra_wave) continue;
+                half8v o = zero8;
+                if (r.rok) {
+                    float y0 = pf[ni][0], y1 = pf[ni][1], y2 = pf[ni][2];
+                    if (first) {        // loaded bins 0, 1, 2: the taps are (padding, 0, 1)
+                        y2 = y1;
+                        y1 = y0;
+                        y0 = 0.0f;
+                    } else if (last) {  // loaded bins F - 3, F - 2, F - 1: the taps are (F - 2, F - 1, padding)
+                        y0 = y1;
+                        y1 = y2;
+                        y2 = 0.0f;
+                    }
+                    if (!((c1_tile_inside >> ni) & 1)) {  // uniform: only edge tiles pay for the selects
+                        const bool ok = (c1_tap_ok >> ni) & 1;
+                        y0 = ok ? y0 : 0.0f;
+                        y1 = ok ? y1 : 0.0f;
+                        y2 = ok ? y2 : 0.0f;
+                    }
+                    y0 = fmed3(y0, -65504.0f, 65504.0f);
+                    y1 = fmed3(y1, -65504.0f, 65504.0f);
+                    y2 = fmed3(y2, -65504.0f, 65504.0f);
+                    const half_t h0 = (half_t)y0, h1 = (half_t)y1, h2 = (half_t)y2;
+                    half8v bf;
+                    bf[0] = h0;
+                    bf[1] = h1;
+                    bf[2] = h2;
+                    bf[3] = (half_t)(y0 - (float)h0);
+                    bf[4] = (half_t)(y1 - (float)h1);
+                    bf[5] = (half_t)(y2 - (float)h2);
+                    bf[6] = (half_t)0.0f;
+                    bf[7] = (half_t)0.0f;
+                    const float4v m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1a[0], bf, c1bv[0], 0, 0, 0);
+                    const float4v m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1a[1], bf, c1bv[1], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (half_t)fmed3(m0[e], 0.0f, 65504.0f);
+                        o[4 + e] = (half_t)fmed3(m1[e], 0.0f, 65504.0f);
+                    }
+                    if (!((c1_tile_inside >> ni) & 1)) o = ((c1_pos_ok >> ni) & 1) ? o : zero8;
+                }
+                *reinterpret_cast<half8v*>(slot + c1_qoff[ni]) = o;
+            }
+        };
 #pragma unroll 1
-        for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) issue_row();
+        for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) {
+            if constexpr (C1) {
+                const RowReq rq = next_row();
+                float3u pf[NC1];
+                c1_load(rq, 2 + (r & 1), pf);
+                c1_make(rq, 2 + (r & 1), pf);
+            } else {
+                issue_row();
+            }
+        }
 
         int cslot = 0;  // ring slot of the first input row of the current step
 #pragma unroll 1
         for (int i = 0; i < nsteps; ++i) {
-            wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
+            if constexpr (!C1) wait_vm<G::AHEAD>();  // the input rows of this step have landed (this wave's share) ...
             lds_barrier();        // ... in every wave; the consumers are done with the mid slot written now and with the ring slots requested next
             // this step's row requests go out one or two per tap, behind that tap's MFMAs: a transfer takes ~150 cycles to issue
             // (r06k timeline: 900 cycles for six in a row, with the matrix pipe idle), the ten MFMAs in front of it keep the pipe busy
@@ -184,6 +306,13 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             RowReq req[SF];
 #pragma unroll
             for (int s = 0; s < SF; ++s) req[s] = next_row();
+            // C1: the features of the rows made at the end of this step are requested now (12 bytes per tile and lane: their latency runs
+            // under the nine taps)
+            float3u pf[SF][NC1];
+            if constexpr (C1) {
+#pragma unroll
+                for (int s = 0; s < SF; ++s) c1_load(req[s], 2 + s, pf[s]);
+            }
             // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
             // groups, counted lgkmcnt)
             float4v acc1[2][NT];  // born in the first tap: the bias is that MFMA's C operand
@@ -207,9 +336,11 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                 } else {
                     mfma_tiles2<NT, 0>(acc1[0], acc1[1], w1f[8][0], w1f[8][1], bq[0]);
                 }
+                if constexpr (!C1) {
 #pragma unroll
-                for (int q = 0; q < SF * G::TPW; ++q)
-                    if (q * 9 / (SF * G::TPW) == tap) issue_part(req[q / G::TPW], q % G::TPW);
+                    for (int q = 0; q < SF * G::TPW; ++q)
+                        if (q * 9 / (SF * G::TPW) == tap) issue_part(req[q / G::TPW], q % G::TPW);
+                }
             }
             mfma_hazard_pad();
             mfma_hazard_pad();
@@ -228,6 +359,10 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                     for (int r = 0; r < 4; ++r) o[4 * mi + r] = (half_t)fmed3(acc1[mi][ni][r], 0.0f, 65504.0f);
                 if (tfirst < 0 || tfirst + 15 >= a.T) o = ok ? o : zero8;  // only edge tiles pay for the selects (scalar branch)
                 *reinterpret_cast<half8v*>(mid + fbk_off(p, fg)) = o;
+            }
+            if constexpr (C1) {  // the ring rows of step i + LEAD
+#pragma unroll
+                for (int s = 0; s < SF; ++s) c1_make(req[s], 2 + s, pf[s]);
             }
             cslot += SF;
             cslot = cslot >= G::RING ? cslot - G::RING : cslot;
@@ -357,12 +492,12 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
     }
 }
 
-template <int NT, int SF>
+template <int NT, int SF, bool C1 = false>
 static int fcm_block_launch_one(const FcmBlockArgs& a, int n_ttiles, hipStream_t stream) {
     typedef FcmBlk<NT, SF> G;
     static bool attr_set = false;
     if (!attr_set) {
-        if (MV_SET_MAX_SMEM((fcm_block_kernel<NT, SF>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm block kernel: LDS size rejected");
+        if (MV_SET_MAX_SMEM((fcm_block_kernel<NT, SF, C1>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm block kernel: LDS size rejected");
         attr_set = true;
     }
     // one workgroup per CU is resident (LDS): bands only while (utterance, time tile) pairs alone do not fill the chip
@@ -374,13 +509,30 @@ static int fcm_block_launch_one(const FcmBlockArgs& a, int n_ttiles, hipStream_t
     const int band_rows = (int)ceil_div(a.Fout, n_bands);
     n_bands = (int)ceil_div(a.Fout, band_rows);
     MV_REQUIRE(pairs * n_bands < ((int64_t)1 << 31), "fcm_block: grid too large");
-    MV_LAUNCH((fcm_block_kernel<NT, SF>), ((unsigned)(pairs * n_bands), 1, 1), (512, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands, band_rows);
+    MV_LAUNCH((fcm_block_kernel<NT, SF, C1>), ((unsigned)(pairs * n_bands), 1, 1), (512, 1, 1), G::LDS_BYTES, stream, a, n_ttiles, n_bands, band_rows);
     return check_launch("fcm_block_kernel");
 }
 
 template <int NT>
 static int fcm_block_launch_nt(const FcmBlockArgs& a, int n_ttiles, hipStream_t stream) {
+    if (a.feats != nullptr) return fcm_block_launch_one<NT, 2, true>(a, n_ttiles, stream);
     return a.Fin == a.Fout ? fcm_block_launch_one<NT, 1>(a, n_ttiles, stream) : fcm_block_launch_one<NT, 2>(a, n_ttiles, stream);
+}
+
+// head.conv1 (BN folded, [32 maps][3 df][3 dt] fp32) as the two MFMA A fragments of the C1 form: lane (fr, fg) of map tile mi holds row
+// A[fr] = map 8 (fr >> 2) + 4 mi + (fr & 3), K slots 8 fg ... 8 fg + 7 = the weights of time tap dt = fg for the mel taps df = 0, 1, 2
+// twice (they meet x_hi and x_lo), two unused slots; fg = 3 is unused.  out: [2][64][8] fp16
+void fcm_c1_pack(const float* w, half_t* out) {
+    for (int mi = 0; mi < 2; ++mi)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fr = lane & 15, fg = lane >> 4;
+            const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);
+            for (int e = 0; e < 8; ++e) {
+                float v = 0.0f;
+                if (fg < 3 && e < 6) v = w[co * 9 + (e % 3) * 3 + fg];
+                out[(mi * 64 + lane) * 8 + e] = (half_t)v;
+            }
+        }
 }
 
 bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin) {
@@ -389,13 +541,20 @@ bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_
 }
 
 int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int shortcut,
-                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream) {
-    MV_REQUIRE(x != nullptr && w1 != nullptr && b1 != nullptr && w2 != nullptr && b2 != nullptr && y != nullptr, "fcm_block: null tensor");
+                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream, const float* feats,
+                     const half_t* c1a, const float* c1b) {
+    MV_REQUIRE((x != nullptr) != (feats != nullptr), "fcm_block: either the input map or the features it is made from");
+    MV_REQUIRE(w1 != nullptr && b1 != nullptr && w2 != nullptr && b2 != nullptr && y != nullptr, "fcm_block: null tensor");
     MV_REQUIRE(B > 0 && T > 0 && Fin > 0 && (sf == 1 || sf == 2), "fcm_block: bad geometry");
+    MV_REQUIRE(feats == nullptr || (c1a != nullptr && c1b != nullptr && sf == 2 && Fin >= 3 && (int64_t)B * T * Fin < ((int64_t)1 << 31)),
+               "fcm_block: the first-conv form needs its weights, the strided block and at least 3 mel bins");
     MV_REQUIRE(sf == 1 || shortcut != 0, "fcm_block: a strided block needs its shortcut conv (the identity cannot change the row count)");
     MV_REQUIRE(fcm_block_supported(y, y_sB, y_sF, y_sT, T, Fin), "fcm_block: output rows must be 16-byte aligned and a map below 2^31 elements");
     FcmBlockArgs a;
     a.x = x;
+    a.feats = feats;
+    a.c1a = c1a;
+    a.c1b = c1b;
     a.w1 = w1;
     a.b1 = b1;
     a.w2 = w2;
@@ -431,6 +590,19 @@ int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const f
 }  // namespace mv
 
 extern "C" {
+int mv_fcm_c1_pack(const float* w, void* out) {
+    if (w == nullptr || out == nullptr) return mv::fail(MV_ERR_INVALID_ARGUMENT, "mv_fcm_c1_pack: null argument");
+    mv::fcm_c1_pack(w, reinterpret_cast<half_t*>(out));
+    return MV_OK;
+}
+
+int mv_fcm_block_c1_f16(const float* feats, int32_t F, const void* c1a, const float* c1b, const void* w1, const float* b1, const void* w2,
+                        const float* b2, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream) {
+    return mv::fcm_block_launch(nullptr, F, 2, reinterpret_cast<const half_t*>(w1), b1, reinterpret_cast<const half_t*>(w2), b2, 1,
+                                reinterpret_cast<half_t*>(y), y_sB, y_sF, y_sT, B, T, static_cast<hipStream_t>(stream), feats,
+                                reinterpret_cast<const half_t*>(c1a), c1b);
+}
+
 int mv_fcm_block_f16(const void* x, int32_t Fin, int32_t sf, const void* w1, const float* b1, const void* w2, const float* b2,
                      int32_t shortcut, void* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int32_t B, int32_t T, mv_stream_t stream) {
     return mv::fcm_block_launch(reinterpret_cast<const half_t*>(x), Fin, sf, reinterpret_cast<const half_t*>(w1), b1,

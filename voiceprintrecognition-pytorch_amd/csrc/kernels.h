@@ -39,8 +39,12 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
 int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int F8, hipStream_t stream);
 // one BasicResBlock of the FCM head (campplus.py:221-254) as one launch, intermediate map kept in LDS (fcmblock.hip)
 bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin);
+// feats != nullptr (then x == nullptr, sf == 2): the block input is head.conv1 + bn1 + ReLU of the fp32 features [B, T, Fin], evaluated inside
+// the kernel from the fcm_c1_pack fragments c1a and the folded shift c1b
 int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int shortcut,
-                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream);
+                     half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, hipStream_t stream, const float* feats = nullptr,
+                     const half_t* c1a = nullptr, const float* c1b = nullptr);
+void fcm_c1_pack(const float* w, half_t* out);  // [32][3 df][3 dt] fp32 (BN folded) -> [2][64][8] fp16 MFMA A fragments
 // one CAMDenseTDNNLayer (campplus.py:114-150) as one launch, one workgroup per utterance (camdense.hip); T2 <= 160 frames
 bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len);
 int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
