@@ -77,9 +77,12 @@ struct FbkPhase {  // accumulator sets of the consumers' step i (PH = i % 3): bo
 
 // C1: the block input (head.conv1 + bn1 + ReLU of the fp32 features, campplus.py:262-264,283 -- one input map, 3 x 3, zero padding) is
 // evaluated by the producers straight into the ring instead of being read from HBM: one MFMA per 16 positions and map tile with
-//     K slot 8 dt + e:  e = 0..2  x_hi[f - 1 + e][t + dt - 1],   e = 3..5  x_lo[f - 1 + e - 3][t + dt - 1],   e = 6, 7 and dt = 3: unused
-// (x = x_hi + x_lo as two fp16 values: the features enter exactly; the folded weights as fp16 like every other FCM conv), so a lane's B
-// fragment is ONE 12-byte load (three neighbouring mel bins of one frame) + 6 conversions, no staging in LDS.  The [B, 80, T, 32] map
+//     K slot 8 dt + 2 df + p:  p = 0: x_hi, p = 1: x_lo of mel bin f - 1 + df at frame t + dt - 1;  slots 8 dt + 6, + 7 and dt = 3: unused
+// (x = x_hi + x_lo as two fp16 values: the features enter exactly; the folded weights as fp16 like every other FCM conv).  A lane's B
+// fragment is three packed (hi, lo) registers, two of them kept from the row below: one 4-byte load and one split per tile and row, no
+// staging in LDS.  Measured (B = 256, T = 298, one box each; profiles/r09b, r09c): the block on the stored map 138-155 us per launch, with the
+// conv inside 168-190 us (first form, three bins loaded and split per row: 179-197 us) against the 98 us launch it replaces; CAM++ end to end
+// 122.2 k -> 128.3 k utterances/s (2.095 -> 1.995 ms per step), MV_FCM_C1=0 | 1 alternating in one call.  The [B, 80, T, 32] map
 // (390 MB per 256 x 3 s batch, written by fcm_conv1_kernel and read back here) and its launch disappear.
 template <int NT, int SF, bool C1 = false>
 __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_ttiles, int n_bands, int band_rows) {
@@ -154,13 +157,14 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             const half_t* base;
             unsigned slot;
             int fin, slot_off;     // input row, byte offset of the slot (C1)
-            bool rok;
+            bool rok, win;         // win (C1): mel bin fin + 1 exists and the row is part of the band's sequence
         };
         auto next_row = [&]() {
             const int fin = rbase + irel;
             RowReq r;
             r.rok = fin >= 0 && fin < a.Fin && irel <= rel_last;
             r.fin = fin;
+            r.win = fin + 1 >= 0 && fin + 1 < a.Fin && irel <= rel_last;
             r.slot_off = islot * G::SLOT_BYTES;
             r.base = C1 ? nullptr : a.x + ((int64_t)b * a.Fin + (r.rok ? fin : 0)) * a.T * FBK_C;
             r.slot = lds0 + (unsigned)(islot * G::SLOT_BYTES);
@@ -186,16 +190,20 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
         };
         // ---- C1: the ring rows are computed here ----
         // tile ni < NT of this wave = positions wave * 16 NT + 16 ni ... + 15 of the slot; tile NT = the slot's last two positions
-        // (MW, MW + 1; one wave takes it).  Position q holds frame t = t0 - 2 + q; lane (fr, fg) of a tile supplies the K slots of the
-        // time tap dt = fg (fg = 3: unused slots, it repeats dt = 1) and ends up with the maps 8 fg ... 8 fg + 7 of position fr.
-        // Everything that depends on the lane and the tile only -- frame offsets, validity, slot offsets -- is the same for every row.
-        typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+        // (MW, MW + 1: wave 3, and only when the tile's last outputs reach them).  Position q holds frame t = t0 - 2 + q; lane (fr, fg) of
+        // a tile supplies the K slots of the time tap dt = fg (fg = 3: unused slots, it repeats dt = 1) and ends up with the maps
+        // 8 fg ... 8 fg + 7 of position fr.  Everything that depends on the lane and the tile only -- frame offsets, validity, slot
+        // offsets -- is the same for every row.  Rows are made in ascending order, so a lane keeps the two lower mel bins of its tap frame
+        // (already split and packed) from the previous row: a row costs ONE 4-byte load and one split per tile.
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
         constexpr int NC1 = C1 ? NT + 1 : 1;
         half8v c1a[2];
         float4v c1bv[2];
-        int c1_toff[NC1];      // element offset of the tap's frame inside the utterance's features (clamped into [0, T))
-        unsigned c1_qoff[NC1]; // byte offset of (position, chunk fg) inside a slot
-        unsigned c1_tap_ok = 0, c1_pos_ok = 0, c1_tile_inside = 0;  // bit ni: the tap's frame / the position's frame lies inside [0, T); every lane's do (uniform)
+        int c1_toff[NC1];       // element offset of the tap's frame inside the utterance's features (clamped into [0, T))
+        unsigned c1_qoff[NC1];  // byte offset of (position, chunk fg) inside a slot
+        unsigned c1_w0[NC1], c1_w1[NC1];  // (x_hi, x_lo) of mel bins f - 1, f of the NEXT row f to be made, at this lane's tap frame
+        // bit ni: the tile is made by this wave (uniform) / every frame it touches lies inside [0, T) (uniform) / this lane's tap frame / position does
+        unsigned c1_need = 0, c1_tile_inside = 0, c1_tap_ok = 0, c1_pos_ok = 0;
         const float* fb = nullptr;
         if constexpr (C1) {
 #pragma unroll
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             }
             fb = a.feats + (int64_t)b * a.T * a.Fin;
             const int dtl = fg < 3 ? fg : 1;
+            const int q_last = a.tile_out + 3;  // the last output (tile_out - 1) reads mid positions up to tile_out + 1, those read slot positions up to this
 #pragma unroll
             for (int ni = 0; ni < NC1; ++ni) {
                 const int q0 = ni < NT ? wave * (16 * NT) + 16 * ni : G::MW;
@@ -215,62 +224,44 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                 const int tc = tt_ < 0 ? 0 : (tt_ >= a.T ? a.T - 1 : tt_);
                 c1_toff[ni] = tc * a.Fin;
                 c1_qoff[ni] = (unsigned)fbk_off(q, fg);
+                if (q0 <= q_last && (ni < NT || wave == 3)) c1_need |= 1u << ni;
                 if (tt_ >= 0 && tt_ < a.T) c1_tap_ok |= 1u << ni;
                 if (t >= 0 && t < a.T) c1_pos_ok |= 1u << ni;
                 const int tlo = t0 - 2 + q0;  // frames tlo - 1 ... tlo + 16 are touched by the tile
                 if (tlo - 1 >= 0 && tlo + 16 < a.T) c1_tile_inside |= 1u << ni;
             }
+            c1_need = MV_UNIFORM(c1_need);
+            c1_tile_inside = MV_UNIFORM(c1_tile_inside);
         }
-        // the features a row needs: ONE 12-byte load per tile (mel bins lo ... lo + 2 of the tap's frame, lo = f - 1 clamped into the row)
-        auto c1_load = [&](const RowReq& r, int extra_wave, float3u (&pf)[NC1]) __attribute__((always_inline)) {
-            if (!r.rok) return;
-            const int lo = r.fin - 1 < 0 ? 0 : (r.fin + 1 >= a.Fin ? a.Fin - 3 : r.fin - 1);
-            const float* rowp = fb + lo;
+        // x -> (x_hi, x_lo) as two fp16 values in one register; zero for a tap frame outside [0, T) (only edge tiles pay for the select)
+        auto c1_split = [&](float y, int ni) __attribute__((always_inline)) {
+            if (!((c1_tile_inside >> ni) & 1)) y = ((c1_tap_ok >> ni) & 1) ? y : 0.0f;
+            y = fmed3(y, -65504.0f, 65504.0f);
+            half2v hl;
+            hl[0] = (half_t)y;
+            hl[1] = (half_t)(y - (float)hl[0]);
+            return __builtin_bit_cast(unsigned, hl);
+        };
+        // the one new mel bin a row needs (f + 1; nothing when that is the padding above the map or the row is behind the band)
+        auto c1_load = [&](const RowReq& r, float (&pf)[NC1]) __attribute__((always_inline)) {
+            if (!r.win) return;
+            const float* rowp = fb + (r.fin + 1);
 #pragma unroll
-            for (int ni = 0; ni < NC1; ++ni) {
-                if (ni == NT && wave != extra_wave) continue;
-                pf[ni] = *reinterpret_cast<const float3u*>(rowp + c1_toff[ni]);
-            }
+            for (int ni = 0; ni < NC1; ++ni)
+                if ((c1_need >> ni) & 1) pf[ni] = rowp[c1_toff[ni]];
         };
         // conv + bias + ReLU of the row into its ring slot (zeros for rows outside the map and frames outside [0, T): conv1 of the block pads
-        // THIS map, not the features)
-        auto c1_make = [&](const RowReq& r, int extra_wave, const float3u (&pf)[NC1]) __attribute__((always_inline)) {
+        // THIS map, not the features), then the window moves up one bin
+        auto c1_make = [&](const RowReq& r, const float (&pf)[NC1]) __attribute__((always_inline)) {
             char* const slot = smem + r.slot_off;
-            const bool first = r.fin == 0, last = r.fin == a.Fin - 1;  // uniform: the bin below / above the row is padding
 #pragma unroll
             for (int ni = 0; ni < NC1; ++ni) {
-                if (ni == NT && wave != extra_wave) continue;
+                if (!((c1_need >> ni) & 1)) continue;
+                const unsigned pn = r.win ? c1_split(pf[ni], ni) : 0u;
                 half8v o = zero8;
                 if (r.rok) {
-                    float y0 = pf[ni][0], y1 = pf[ni][1], y2 = pf[ni][2];
-                    if (first) {        // loaded bins 0, 1, 2: the taps are (padding, 0, 1)
-                        y2 = y1;
-                        y1 = y0;
-                        y0 = 0.0f;
-                    } else if (last) {  // loaded bins F - 3, F - 2, F - 1: the taps are (F - 2, F - 1, padding)
-                        y0 = y1;
-                        y1 = y2;
-                        y2 = 0.0f;
-                    }
-                    if (!((c1_tile_inside >> ni) & 1)) {  // uniform: only edge tiles pay for the selects
-                        const bool ok = (c1_tap_ok >> ni) & 1;
-                        y0 = ok ? y0 : 0.0f;
-                        y1 = ok ? y1 : 0.0f;
-                        y2 = ok ? y2 : 0.0f;
-                    }
-                    y0 = fmed3(y0, -65504.0f, 65504.0f);
-                    y1 = fmed3(y1, -65504.0f, 65504.0f);
-                    y2 = fmed3(y2, -65504.0f, 65504.0f);
-                    const half_t h0 = (half_t)y0, h1 = (half_t)y1, h2 = (half_t)y2;
-                    half8v bf;
-                    bf[0] = h0;
-                    bf[1] = h1;
-                    bf[2] = h2;
-                    bf[3] = (half_t)(y0 - (float)h0);
-                    bf[4] = (half_t)(y1 - (float)h1);
-                    bf[5] = (half_t)(y2 - (float)h2);
-                    bf[6] = (half_t)0.0f;
-                    bf[7] = (half_t)0.0f;
+                    const uint4v bu = {c1_w0[ni], c1_w1[ni], pn, 0u};
+                    const half8v bf = __builtin_bit_cast(half8v, bu);
                     const float4v m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1a[0], bf, c1bv[0], 0, 0, 0);
                     const float4v m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1a[1], bf, c1bv[1], 0, 0, 0);
 #pragma unroll
@@ -281,15 +272,26 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                     if (!((c1_tile_inside >> ni) & 1)) o = ((c1_pos_ok >> ni) & 1) ? o : zero8;
                 }
                 *reinterpret_cast<half8v*>(slot + c1_qoff[ni]) = o;
+                c1_w0[ni] = c1_w1[ni];
+                c1_w1[ni] = pn;
             }
         };
+        if constexpr (C1) {  // the window in front of the first row rbase: mel bins rbase - 1, rbase (a band may start inside the map)
+#pragma unroll
+            for (int ni = 0; ni < NC1; ++ni) {
+                c1_w0[ni] = c1_w1[ni] = 0u;
+                if (!((c1_need >> ni) & 1)) continue;
+                if (rbase - 1 >= 0 && rbase - 1 < a.Fin) c1_w0[ni] = c1_split(fb[c1_toff[ni] + rbase - 1], ni);
+                if (rbase >= 0 && rbase < a.Fin) c1_w1[ni] = c1_split(fb[c1_toff[ni] + rbase], ni);
+            }
+        }
 #pragma unroll 1
         for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) {
             if constexpr (C1) {
                 const RowReq rq = next_row();
-                float3u pf[NC1];
-                c1_load(rq, 2 + (r & 1), pf);
-                c1_make(rq, 2 + (r & 1), pf);
+                float pf[NC1];
+                c1_load(rq, pf);
+                c1_make(rq, pf);
             } else {
                 issue_row();
             }
@@ -308,10 +310,10 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             for (int s = 0; s < SF; ++s) req[s] = next_row();
             // C1: the features of the rows made at the end of this step are requested now (12 bytes per tile and lane: their latency runs
             // under the nine taps)
-            float3u pf[SF][NC1];
+            float pf[SF][NC1];
             if constexpr (C1) {
 #pragma unroll
-                for (int s = 0; s < SF; ++s) c1_load(req[s], 2 + s, pf[s]);
+                for (int s = 0; s < SF; ++s) c1_load(req[s], pf[s]);
             }
             // one tap = NT fragment reads + 2 * NT MFMAs; the reads of tap k + 1 are issued before the MFMAs of tap k (two register
             // groups, counted lgkmcnt)
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
             }
             if constexpr (C1) {  // the ring rows of step i + LEAD
 #pragma unroll
-                for (int s = 0; s < SF; ++s) c1_make(req[s], 2 + s, pf[s]);
+                for (int s = 0; s < SF; ++s) c1_make(req[s], pf[s]);
             }
             cslot += SF;
             cslot = cslot >= G::RING ? cslot - G::RING : cslot;
@@ -520,8 +522,8 @@ static int fcm_block_launch_nt(const FcmBlockArgs& a, int n_ttiles, hipStream_t 
 }
 
 // head.conv1 (BN folded, [32 maps][3 df][3 dt] fp32) as the two MFMA A fragments of the C1 form: lane (fr, fg) of map tile mi holds row
-// A[fr] = map 8 (fr >> 2) + 4 mi + (fr & 3), K slots 8 fg ... 8 fg + 7 = the weights of time tap dt = fg for the mel taps df = 0, 1, 2
-// twice (they meet x_hi and x_lo), two unused slots; fg = 3 is unused.  out: [2][64][8] fp16
+// A[fr] = map 8 (fr >> 2) + 4 mi + (fr & 3), K slots 8 fg ... 8 fg + 7 = the weights of time tap dt = fg for the mel taps df = 0, 0, 1, 1, 2, 2
+// (each meets x_hi and x_lo of its bin), two unused slots; fg = 3 is unused.  out: [2][64][8] fp16
 void fcm_c1_pack(const float* w, half_t* out) {
     for (int mi = 0; mi < 2; ++mi)
         for (int lane = 0; lane < 64; ++lane) {
@@ -529,7 +531,7 @@ void fcm_c1_pack(const float* w, half_t* out) {
             const int co = 8 * (fr >> 2) + 4 * mi + (fr & 3);
             for (int e = 0; e < 8; ++e) {
                 float v = 0.0f;
-                if (fg < 3 && e < 6) v = w[co * 9 + (e % 3) * 3 + fg];
+                if (fg < 3 && e < 6) v = w[co * 9 + (e >> 1) * 3 + fg];
                 out[(mi * 64 + lane) * 8 + e] = (half_t)v;
             }
         }
