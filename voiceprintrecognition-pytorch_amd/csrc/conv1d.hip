@@ -54,7 +54,6 @@ struct ConvArgs {
     int pre_act, post_act, y_f16, gate_seg_len, gate_nseg;
     int n_rows, n_tiles, co_tiles;
     int store_nt;  // persistent kernel: output stores carry the streaming policy bits (see conv_store_policy)
-    int walk_rev;  // tile walk from the last row tile down (conv1d_set_walk_reverse: the rows a predecessor wrote last are read first)
     float* stat_sum;  // optional partial time sums of the output (persistent kernel): [ceil(n_rows / 64)][2][cout]
     float* stat_sq;   // optional partial sums of squares (about the BatchNorm shift), same layout
     // one-shot 128 x 160 kernel: tiles never straddle utterances (tile = (utterance, 160-frame block)), and the workgroups of channel
@@ -369,9 +368,7 @@ __device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n
     const int n_local = idx / gw;
     co_tile = base + idx - n_local * gw;
     n_tile = xcd + 8 * n_local;
-    if (n_tile >= a.n_tiles) return false;
-    if (a.walk_rev) n_tile = a.n_tiles - 1 - n_tile;
-    return true;
+    return n_tile < a.n_tiles;
 }
 
 __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
@@ -1436,11 +1433,6 @@ static int cu_count() {
 
 // Resident workgroups of the persistent kernel: one per CU (a multiple of 8 keeps  id mod 8 == XCD  across the walk).
 // MV_CONV_PERSIST_BLOCKS overrides it (tests walk several tiles per workgroup on small problems; 0 disables the kernel).
-// Direction of the tile walk of the launches that follow (process-wide, set by the model forwards around single launches): 0 = row tiles
-// in ascending order, 1 = descending.  Results do not depend on it; it decides which rows are still in L2 / Infinity Cache for the successor.
-static int g_walk_rev = 0;
-void conv1d_set_walk_reverse(int rev) { g_walk_rev = rev != 0; }
-
 static int persistent_blocks() {
     static int n = -1;
     if (n < 0) {
@@ -1509,7 +1501,6 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     MV_REQUIRE((int64_t)d.B * d.T_out < ((int64_t)1 << 31) - CV_TN, "conv1d: too many rows for 32-bit indexing");
 
     ConvArgs a;
-    a.walk_rev = g_walk_rev;
     a.x = d.x;
     a.x2 = d.x2;
     a.ldx = d.ldx;

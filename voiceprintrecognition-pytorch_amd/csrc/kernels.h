@@ -11,8 +11,6 @@ bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k);
 int conv_stats_finish_launch(const float* psum, const float* psq, const float* shift, int B, int T, int C, float* mean, float* stdv,
                              int64_t ld_out, float clamp_eps, hipStream_t stream);
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream);
-void conv1d_set_walk_reverse(int rev);  // tile walk direction of the conv launches that follow (results do not depend on it)
-void pool_set_walk_reverse(int mask);  // bit 0: time_stats, bit 1: se_gate_residual walk their rows from the last one down
 // fused time statistics of a 1x1 layer's INPUT (MvConv1dDesc.in_stat_sum / in_stat_sq): partial buffer size and the finish pass
 int64_t conv_in_stats_elems(int B, int T, int cin);
 int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,

@@ -170,13 +170,6 @@ int run_conv(const ConvLayer& L, const void* x, int x_dtype, int64_t ldx, const 
 
 // --------------------------------------------------------------------------------------- ASP tail
 
-// Walk directions inside an SE-Res2Net block (MV_WALK = bit mask, read per forward): 1 time_stats, 2 se_gate_residual, 4 tdnn1, 8 tdnn2,
-// 16 mfa, 64 the ASP hidden conv, 128 the ASP pooling pass start at the LAST rows; 32 = se_gate_residual with two row chunks per trip.  A pass that starts where its predecessor ended finds those rows in L2 / Infinity Cache.
-static int ecapa_walk_mask() {
-    const char* e = getenv("MV_WALK");
-    return e != nullptr ? atoi(e) : 0;
-}
-
 int AspLayer::create(MvModelBase* m, const Weights& w, const std::string& prefix, int C_, int A_, bool global_ctx_) {
     C = C_;
     A = A_;
@@ -265,18 +258,11 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
         d.pad_mode = MV_PAD_REFLECT;
         d.in_stat_sum = psum;
         d.in_stat_sq = psq;
-        const int walk = ecapa_walk_mask();
-        conv1d_set_walk_reverse(walk & 64);
-        rc = conv1d_launch(d, stream);
-        conv1d_set_walk_reverse(0);
-        if (rc) return rc;
+        if ((rc = conv1d_launch(d, stream))) return rc;
         if ((rc = conv_in_stats_finish_launch(psum, psq, B, T, C, gstats, gstats + C, 2 * C, 1e-12f, stream))) return rc;
         if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream))) return rc;
         if ((rc = asp_hidden_act_launch(h, ctxb, bn_scale, bn_shift, B, T, A, stream))) return rc;
-        pool_set_walk_reverse((walk & 128) ? 8 : 0);
-        rc = asp_pool_launch(h, conv.w, x, ldx, gstats, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
-        pool_set_walk_reverse(0);
-        return rc;
+        return asp_pool_launch(h, conv.w, x, ldx, gstats, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
     }
     if (!have_gstats) {  // else: already written by the producer's fused epilogue statistics
         if ((rc = time_stats_launch(x, ldx, B, T, C, gstats, gstats + C, 2 * C, 0, 1e-12f, stream))) return rc;
@@ -335,7 +321,6 @@ int fold_final_linear(MvModelBase* m, const Weights& w, const std::string& weigh
 }
 
 // --------------------------------------------------------------------------------------- EcapaTdnn
-
 
 struct EcapaModel : MvModelBase {
     MvEcapaCfg cfg;
@@ -509,7 +494,6 @@ struct EcapaModel : MvModelBase {
         const half_t* xin = s.a0;
         int64_t ldin = cfg.channels[0];
         int cat_off = 0;
-        const int walk = ecapa_walk_mask();
         for (int i = 0; i < nblocks; ++i) {
             const SeRes2& b = blocks[i];
             const int C = b.cout;
@@ -522,11 +506,9 @@ struct EcapaModel : MvModelBase {
                 res = s.sc;
                 ldres = C;
             }
-            conv1d_set_walk_reverse(walk & 4);
-            rc = run_conv(b.tdnn1.conv, xin, MV_DT_F16, ldin, nullptr, 0, s.t1, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
-                          b.tdnn1.scale, b.tdnn1.shift, MV_ACT_NONE, nullptr, true, st);
-            conv1d_set_walk_reverse(0);
-            if (rc) return rc;
+            if ((rc = run_conv(b.tdnn1.conv, xin, MV_DT_F16, ldin, nullptr, 0, s.t1, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
+                               b.tdnn1.scale, b.tdnn1.shift, MV_ACT_NONE, nullptr, true, st)))
+                return rc;
             const int steps = cfg.res2net_scale - 1;
             if (res2_chain_supported(T, b.width, steps, b.k, b.dil)) {
                 // whole chain in one launch, one workgroup per utterance (res2.hip)
@@ -558,19 +540,14 @@ struct EcapaModel : MvModelBase {
             // SE: squeeze -> FC/ReLU -> FC/sigmoid -> gate * y + residual, written into the aggregation slice.  The squeeze
             // (mean over time, ecapa_tdnn.py:79) comes out of tdnn2's epilogue when that layer runs on the persistent kernel.
             const bool fused_sq = conv1d_can_fuse_stats(B, T, C, C, 1);
-            conv1d_set_walk_reverse(walk & 8);
-            rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
-                          b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st, nullptr, 0, nullptr, 0,
-                          fused_sq ? s.stat_sum : nullptr, nullptr);
-            conv1d_set_walk_reverse(0);
-            if (rc) return rc;
+            if ((rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
+                               b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st, nullptr, 0, nullptr, 0,
+                               fused_sq ? s.stat_sum : nullptr, nullptr)))
+                return rc;
             if (fused_sq) {
                 if ((rc = conv_stats_finish_launch(s.stat_sum, nullptr, b.tdnn2.shift, B, T, C, s.se_mean, nullptr, C, 0.0f, st))) return rc;
             } else {
-                pool_set_walk_reverse(walk & 1);
-                rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st);
-                pool_set_walk_reverse(0);
-                if (rc) return rc;
+                if ((rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st))) return rc;
             }
             if ((rc = linear_f32_launch(s.se_mean, C, b.se_w1, C, b.se_b1, MV_ACT_RELU, s.se_hid, cfg.se_channels, B, C,
                                         cfg.se_channels, 0, st)))
@@ -579,10 +556,7 @@ struct EcapaModel : MvModelBase {
                                         B, cfg.se_channels, C, 0, st)))
                 return rc;
             half_t* out = s.cat + cat_off;
-            pool_set_walk_reverse((walk & 2) | ((walk & 32) ? 4 : 0));
-            rc = se_gate_residual_launch(s.t2, C, s.gate, res, ldres, out, ccat, B, T, C, st);
-            pool_set_walk_reverse(0);
-            if (rc) return rc;
+            if ((rc = se_gate_residual_launch(s.t2, C, s.gate, res, ldres, out, ccat, B, T, C, st))) return rc;
             xin = out;
             ldin = ccat;
             cat_off += C;
@@ -591,31 +565,16 @@ struct EcapaModel : MvModelBase {
         const int Cm = cfg.channels[4];
         // the ASP global mean / std (pooling.py:104-109) come out of the mfa epilogue on the persistent kernel
         const bool fused_gs = asp.global_ctx && cfg.kernel_sizes[4] == 1 && conv1d_can_fuse_stats(B, T, ccat, Cm, 1);
-        // MV_ASP_CHUNKS = n: the aggregation conv and the pooling head run over n slices of the batch, one after the other, so that a
-        // slice's [Bc, T, Cm] output (234 MB for 128 x 298 x 3072) is still in the 256 MB Infinity Cache when the hidden conv and the pooling
-        // pass read it.  Utterances are independent: same results.
-        int chunks = 1;
-        if (const char* e = getenv("MV_ASP_CHUNKS")) chunks = atoi(e);
-        if (chunks < 1 || fused_gs || cfg.kernel_sizes[4] != 1) chunks = 1;
-        if (chunks > B) chunks = B;
-        for (int c = 0; c < chunks; ++c) {
-            const int b0 = (int)((int64_t)B * c / chunks), b1 = (int)((int64_t)B * (c + 1) / chunks);
-            const int Bc = b1 - b0;
-            const size_t r0 = (size_t)b0 * T;
-            conv1d_set_walk_reverse(walk & 16);
-            rc = run_conv(mfa.conv, s.cat + r0 * ccat, MV_DT_F16, ccat, nullptr, 0, s.mfa + r0 * Cm, MV_DT_F16, Cm, Bc, T, T, cfg.dilations[4],
-                          cfg.dilations[4] * (cfg.kernel_sizes[4] - 1) / 2, R, MV_ACT_RELU, mfa.scale, mfa.shift, MV_ACT_NONE,
-                          nullptr, true, st, nullptr, 0, nullptr, 0, fused_gs ? s.stat_sum : nullptr, fused_gs ? s.stat_sq : nullptr);
-            conv1d_set_walk_reverse(0);
-            if (rc) return rc;
-            if (fused_gs) {
-                float* gstats = s.asp_f;  // [B, 2 Cm]: mean | std, the layout AspLayer::forward expects
-                if ((rc = conv_stats_finish_launch(s.stat_sum, s.stat_sq, mfa.shift, B, T, Cm, gstats, gstats + Cm, 2 * Cm, 1e-12f, st)))
-                    return rc;
-            }
-            if ((rc = asp.forward(s.mfa + r0 * Cm, Cm, Bc, T, s.h + r0 * cfg.attention_channels, s.asp_f, s.pooled + (size_t)b0 * 2 * Cm, st, fused_gs)))
+        if ((rc = run_conv(mfa.conv, s.cat, MV_DT_F16, ccat, nullptr, 0, s.mfa, MV_DT_F16, Cm, B, T, T, cfg.dilations[4],
+                           cfg.dilations[4] * (cfg.kernel_sizes[4] - 1) / 2, R, MV_ACT_RELU, mfa.scale, mfa.shift, MV_ACT_NONE,
+                           nullptr, true, st, nullptr, 0, nullptr, 0, fused_gs ? s.stat_sum : nullptr, fused_gs ? s.stat_sq : nullptr)))
+            return rc;
+        if (fused_gs) {
+            float* gstats = s.asp_f;  // [B, 2 Cm]: mean | std, the layout AspLayer::forward expects
+            if ((rc = conv_stats_finish_launch(s.stat_sum, s.stat_sq, mfa.shift, B, T, Cm, gstats, gstats + Cm, 2 * Cm, 1e-12f, st)))
                 return rc;
         }
+        if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st, fused_gs))) return rc;
         // asp_bn folded into fc
         return linear_f32_launch(s.pooled, 2 * Cm, fc_w, 2 * Cm, fc_b, MV_ACT_NONE, emb, cfg.embd_dim, B, 2 * Cm, cfg.embd_dim, 0,
                                  st);

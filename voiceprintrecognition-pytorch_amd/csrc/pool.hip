@@ -19,18 +19,13 @@ namespace mv {
 // (x - mean)^2 form -- |mean - k| is of the order of the spread -- and makes a constant channel's variance exactly zero:
 //   mean = k + s1 / T,   var = (s2 - s1^2 / T) / (T or T - 1)
 // Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
-// Walk direction of the two streaming passes (set by the model forwards, results do not depend on it): bit 0 time_stats, bit 1
-// se_gate_residual start at the LAST utterance / row -- the rows their predecessor touched last are the ones still cached.
-static int g_pool_rev = 0;
-void pool_set_walk_reverse(int mask) { g_pool_rev = mask; }
-
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
                                                          float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
-                                                         const float* in_scale, const float* in_shift, int rev) {
+                                                         const float* in_scale, const float* in_shift) {
     __shared__ float red[2][4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, rp = lane >> 4;
-    const int b = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int b = blockIdx.y;
     const int cg0 = blockIdx.x * 128;
     const int c0 = cg0 + c16 * 8;
     const bool active = c0 < C;
@@ -113,7 +108,7 @@ int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* m
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
     MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
-              ld_out, unbiased, clamp_eps, in_scale, in_shift, g_pool_rev & 1);
+              ld_out, unbiased, clamp_eps, in_scale, in_shift);
     return check_launch("time_stats_kernel");
 }
 
@@ -174,47 +169,29 @@ int seg_mean_launch(const half_t* x, int64_t ld, int B, int T, int C, int seg_le
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[n, c] = gate[b(n), c] * y[n, c] + res[n, c]   (8 channels per thread, grid-stride; U row chunks per trip so that 2 U 16-byte loads
-// of a lane are in flight together)
-template <int U>
+// out[n, c] = gate[b(n), c] * y[n, c] + res[n, c]   (8 channels per thread, grid-stride)
 __global__ __launch_bounds__(256) void se_gate_residual_kernel(const half_t* y, int64_t ldy, const float* gate,
                                                                const half_t* res, int64_t ldr, half_t* out, int64_t ldo,
-                                                               int T, int C, int64_t n_rows, int rev) {
+                                                               int T, int C, int64_t n_rows) {
     const int cgroups = C / 8;
     const int64_t total = n_rows * cgroups;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += U * stride) {
-        half8v yv[U], rv[U];
-        float4v g0[U], g1[U];
-        int64_t n[U];
-        int c[U];
-        bool ok[U];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / cgroups;
+        const int c = (int)(i - n * cgroups) * 8;
+        const int b = (int)(n / T);
+        const half8v yv = *reinterpret_cast<const half8v*>(y + n * ldy + c);
+        const half8v rv = *reinterpret_cast<const half8v*>(res + n * ldr + c);
+        const float4v g0 = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c);
+        const float4v g1 = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c + 4);
+        half8v ov;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + u * stride;
-            ok[u] = i < total;
-            const int64_t ic = ok[u] ? i : i0;  // (clamped: the loads are unconditional, the store is not)
-            const int64_t nf = ic / cgroups;
-            c[u] = (int)(ic - nf * cgroups) * 8;
-            n[u] = rev ? n_rows - 1 - nf : nf;
-            const int b = (int)(n[u] / T);
-            yv[u] = *reinterpret_cast<const half8v*>(y + n[u] * ldy + c[u]);
-            rv[u] = *reinterpret_cast<const half8v*>(res + n[u] * ldr + c[u]);
-            g0[u] = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c[u]);
-            g1[u] = *reinterpret_cast<const float4v*>(gate + (int64_t)b * C + c[u] + 4);
+        for (int e = 0; e < 8; ++e) {
+            const float g = e < 4 ? g0[e] : g1[e - 4];
+            float v = g * (float)yv[e] + (float)rv[e];
+            v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            ov[e] = (half_t)v;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            half8v ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = e < 4 ? g0[u][e] : g1[u][e - 4];
-                float v = g * (float)yv[u][e] + (float)rv[u][e];
-                v = fminf(fmaxf(v, -65504.0f), 65504.0f);
-                ov[e] = (half_t)v;
-            }
-            if (ok[u]) *reinterpret_cast<half8v*>(out + n[u] * ldo + c[u]) = ov;
-        }
+        *reinterpret_cast<half8v*>(out + n * ldo + c) = ov;
     }
 }
 
@@ -225,11 +202,7 @@ int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, con
     const int64_t n_rows = (int64_t)B * T;
     const int64_t total = n_rows * (C / 8);
     const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
-    if (g_pool_rev & 4) {
-        MV_LAUNCH(se_gate_residual_kernel<2>, (grid, 1, 1), (256, 1, 1), 0, stream, y, ldy, gate, res, ldr, out, ldo, T, C, n_rows, (g_pool_rev >> 1) & 1);
-    } else {
-        MV_LAUNCH(se_gate_residual_kernel<1>, (grid, 1, 1), (256, 1, 1), 0, stream, y, ldy, gate, res, ldr, out, ldo, T, C, n_rows, (g_pool_rev >> 1) & 1);
-    }
+    MV_LAUNCH(se_gate_residual_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, y, ldy, gate, res, ldr, out, ldo, T, C, n_rows);
     return check_launch("se_gate_residual_kernel");
 }
 
@@ -373,7 +346,6 @@ struct AspArgs {
     float* out;         // [B, 2C]: mean | std
     int B, T, C, C_pad, A, A_pad;
     float eps;
-    int rev;  // ring kernel: utterances from the last one down (pool_set_walk_reverse bit 3)
 };
 
 __device__ __forceinline__ float asp_exp2(float v) { return exp2_fast(v); }  // v_exp_f32: arguments are <= 0 (online) or within +-60 (NOMAX)
@@ -568,7 +540,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     MV_DYN_SMEM(smem);  // the workgroup's h ring (ASP_HRING tiles), then four private x rings (ASP_XRING tiles each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = MV_UNIFORM(tid >> 6);
-    const int b = a.rev ? a.B - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int b = blockIdx.y;
     const int c0 = (blockIdx.x * 4 + wave) * 64;  // (C is a multiple of 256 here: every wave has a tile and reaches every barrier)
     const int fr = lane & 15, fg = lane >> 4;
     const int ntiles = (a.T + 15) / 16;
@@ -790,7 +762,6 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, i
     a.C_pad = (int)round_up(C, 32);
     a.A_pad = (int)round_up(A, 64);
     a.eps = 1e-12f;
-    a.rev = (g_pool_rev >> 3) & 1;
     const unsigned gx = (unsigned)ceil_div(C, 64);
     const bool nomax = logit_bound_log2 >= 0.0f && logit_bound_log2 <= 60.0f;
     // ring form: whole tiles, aligned rows, no partial h fragments; MV_ASP_IMPL=regs keeps the register form (A/B runs)
