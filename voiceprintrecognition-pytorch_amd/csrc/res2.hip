@@ -33,6 +33,13 @@
 // in-order counter for loads and stores, and the chip-wide store burst of an epilogue takes thousands of cycles to retire), ~6 k epilogue,
 // ~2.7 k in the barrier in front of the step.
 //
+// Round 3 (r10b/c, tools/variants/res2_chain_drip_stores.patch.txt, profiles/r10b_res2_chain_drip_stores_ab.log): "drip" form -- y_j written into the
+// LDS region of x_{j+1} by the epilogue (slice 0 by the prologue) and stored to HBM during the NEXT step's K loop, two 16-byte stores per wave
+// and stage right in front of the transfers that refill the rows, so that no burst of ten stores per lane sits in front of the next step's
+// fragment loads.  Correct (parity tests) and 13 % SLOWER (107-108 -> 120-122 us): the untracked stores share the in-order counter with the
+// fragment loads the compiler waits for, every fragment wait now also waits for the stores of the stage before (the chain without ANY y
+// stores: 95 us, so the stores cost 15 us in the epilogue and 26 us in the loop).  Parked.
+//
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
 #include <type_traits>
