@@ -330,6 +330,12 @@ int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,
                       int32_t unbiased, float clamp_eps, mv_stream_t stream);
 
+/* Pre-activation written out once: y[n, c] = fp16(relu(x[n, c] * scale[c] + shift[c])) over channel-last fp16 rows (eval BatchNorm
+ * folded to scale / shift + ReLU in front of a 1x1 conv: the CAM++ transit layers, mvector/models/campplus.py:186-189), so that the
+ * conv behind it takes the direct global -> LDS path instead of transforming on load.  C % 8 == 0, 16-byte aligned rows / parameters. */
+int mv_bn_relu_rows_f16(const void* x, int64_t ldx, const float* scale, const float* shift, void* y, int64_t ldy, int64_t n_rows,
+                        int32_t C, mv_stream_t stream);
+
 /* Per-kernel-class timing with HIP events recorded on the launch stream (used by bench.py for its roofline legs; off by
  * default, not thread-safe).  work = algorithmic FLOPs (MV_PROF_CONV1D: 2*B*T_out*cin*cout*k per launch) or algorithmic
  * bytes (MV_PROF_FBANK: B*(4*L + 4*T*num_mel_bins) per launch).  mv_profile_read waits for the recorded launches. */

@@ -375,6 +375,24 @@ def time_stats_case(cdll, device, B=3, T=29, C=520, ld=528, unbiased=0, eps=1e-1
     return e1, e2
 
 
+def bn_relu_rows_case(cdll, device, rows=77, C=520, ldx=528, ldy=544, seed=0):
+    """the pre-activation pass of the CAM++ transit layers: relu(x * scale + shift) rounded once to fp16 (saturating), pad columns untouched"""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(rows, ldx, generator=g) * 3).half()
+    x[0, 0], x[0, 1] = 60000.0, -60000.0
+    sc = torch.randn(C, generator=g) * 2
+    sh = torch.randn(C, generator=g)
+    sc[0], sc[1] = 2.0, 2.0  # overflow of the fp16 range: saturates at 65504 / clamps at 0
+    xd, scd, shd = x.to(device), sc.to(device), sh.to(device)
+    y = torch.full((rows, ldy), -7.0, dtype=torch.half, device=device)
+    _hip.check(cdll.mv_bn_relu_rows_f16(xd.data_ptr(), ldx, scd.data_ptr(), shd.data_ptr(), y.data_ptr(), ldy, rows, C, _stream(xd)), cdll)
+    ref = torch.clamp(torch.relu(x.float()[:, :C] * sc + sh), max=65504.0).half()
+    out = y.cpu()
+    assert torch.equal(out[:, :C], ref), (out[:, :C].float() - ref.float()).abs().max()
+    assert bool((out[:, C:] == -7.0).all())
+    assert out[0, 0] == 65504.0 and out[0, 1] == 0.0
+
+
 def asp_pool_case(cdll, device, B=3, T=45, C=192, A=128, ldx=None, online=False, centred=True, wscale=0.08, seed=0):
     """softmax over time of W2 . h (+ b2, which cancels), weighted mean / std of x (pooling.py:117-125)."""
     g = torch.Generator().manual_seed(seed)

@@ -71,6 +71,11 @@ def test_emu_time_stats(unbiased, eps):
     lc.time_stats_case(emu_cdll(), 'cpu', unbiased=unbiased, eps=eps)
 
 
+def test_emu_bn_relu_rows():
+    lc.bn_relu_rows_case(emu_cdll(), 'cpu')
+    lc.bn_relu_rows_case(emu_cdll(), 'cpu', rows=5, C=1024, ldx=1024, ldy=1024, seed=1)
+
+
 def test_emu_fbank_fixed_and_ragged():
     wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)  # odd stride -> scalar-load path
     wav[2, 9000:] = 0

@@ -94,6 +94,19 @@ def test_gpu_time_stats(unbiased, eps):
     lc.time_stats_case(product_lib(), DEV, B=7, T=298, C=3072, ld=3072, unbiased=unbiased, eps=eps, seed=2)
 
 
+def test_gpu_bn_relu_rows():
+    lc.bn_relu_rows_case(product_lib(), DEV)
+    lc.bn_relu_rows_case(product_lib(), DEV, rows=38144, C=1024, ldx=1024, ldy=1024, seed=3)
+
+
+@pytest.mark.parametrize('mode', ['load', 'pre'])
+def test_gpu_campp_transit_forms_agree_with_the_golden(mode, monkeypatch):
+    """the transit layers with the pre-activation applied on load (register path) and written out once (direct path): both meet the golden"""
+    monkeypatch.setenv('MV_CAMPP_TRANSIT', mode)
+    cd, _ = lc.model_case(product_lib(), DEV, 'campp')
+    assert cd < 1e-4, cd
+
+
 def test_gpu_fbank_golden_fixed_and_ragged():
     z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
     wav = frontend.synth_waveforms(4, 48000)

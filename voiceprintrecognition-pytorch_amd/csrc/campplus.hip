@@ -280,6 +280,7 @@ struct CamppModel : MvModelBase {
         half_t* xb[3];         // dense-block buffers [B, T2, c_out]
         half_t* last;          // [B, T2, cfin]
         half_t* h;             // [B, T2, 128]
+        half_t* act;           // [B, T2, widest block]: pre-activated transit input
         float *ctx, *g1, *gate, *stats;
         size_t bytes;
         int T2, nseg;
@@ -310,6 +311,11 @@ struct CamppModel : MvModelBase {
         for (int i = 0; i < 3; ++i) s.xb[i] = c.take<half_t>(N2 * blocks[i].c_out);
         s.last = c.take<half_t>(N2 * cfin);
         s.h = c.take<half_t>(N2 * bn_ch);
+        {
+            size_t widest = 0;
+            for (int i = 0; i < 3; ++i) widest = (size_t)blocks[i].c_out > widest ? (size_t)blocks[i].c_out : widest;
+            s.act = c.take<half_t>(N2 * widest);
+        }
         s.ctx = c.take<float>((size_t)B * s.nseg * bn_ch);
         s.g1 = c.take<float>((size_t)B * s.nseg * (bn_ch / 2));
         s.gate = c.take<float>((size_t)B * s.nseg * cfg.growth_rate);
@@ -549,14 +555,19 @@ struct CamppModel : MvModelBase {
                 d.pad_mode = MV_PAD_ZERO;
                 if ((rc = conv1d_launch(d, st))) return rc;
             }
-            // transit: BN + ReLU on load, 1x1 conv halves the channels into the next block's buffer
+            // transit: BN + ReLU, then a 1x1 conv that halves the channels into the next block's buffer.  Wide blocks (>= 1024 channels: the conv
+            // is 40 GFLOP at the bench shape) write the pre-activation out once (bn_relu_rows_kernel) and run the conv on the direct global -> LDS
+            // path; narrower ones apply it on load (register path).  MV_CAMPP_TRANSIT=load | pre forces either.
+            const char* tr_env = getenv("MV_CAMPP_TRANSIT");
+            const bool pre = tr_env != nullptr ? strcmp(tr_env, "pre") == 0 : Bk.c_out >= 1024;
+            if (pre && (rc = bn_relu_rows_launch(X, ld, Bk.tr_s, Bk.tr_t, s.act, Bk.c_out, (int64_t)B * T2, Bk.c_out, st))) return rc;
             MvConv1dDesc d;
             memset(&d, 0, sizeof(d));
-            d.x = X;
+            d.x = pre ? s.act : X;
             d.x_dtype = MV_DT_F16;
-            d.ldx = ld;
-            d.in_scale = Bk.tr_s;
-            d.in_shift = Bk.tr_t;
+            d.ldx = ld;  // (the pre-activated copy keeps the block buffer's leading dimension)
+            d.in_scale = pre ? nullptr : Bk.tr_s;
+            d.in_shift = pre ? nullptr : Bk.tr_t;
             d.w_packed = Bk.transit.w;
             d.bias = Bk.transit.bias;
             d.y = bi < 2 ? s.xb[bi + 1] : s.last;

@@ -16,6 +16,8 @@ int64_t conv_in_stats_elems(int B, int T, int cin);
 int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
                                 float clamp_eps, hipStream_t stream);
 // zh[b, t, :] <- tanh(relu(zh[b, t, :] + row_bias[b, :]) * scale + shift), fp16 in place: the deferred epilogue of the ASP hidden layer
+int bn_relu_rows_launch(const half_t* x, int64_t ldx, const float* scale, const float* shift, half_t* y, int64_t ldy, int64_t n_rows, int C,
+                        hipStream_t stream);
 int asp_hidden_act_launch(half_t* zh, const float* row_bias, const float* scale, const float* shift, int B, int T, int A, hipStream_t stream);
 
 typedef MvConv2dDesc Conv2dDesc;

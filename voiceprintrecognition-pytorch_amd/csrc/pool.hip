@@ -308,6 +308,39 @@ __global__ __launch_bounds__(256) void asp_hidden_act_kernel(half_t* zh, const f
     }
 }
 
+// y[n, c] = fp16(relu(x[n, c] * scale[c] + shift[c])) for channel-last fp16 rows: a pre-activation (BatchNorm + ReLU in front of a 1x1 conv,
+// campplus.py:139-141 / 186-189) written out once so that the conv behind it can take the direct global -> LDS path.  Same rounding point as the
+// conv kernels' transform-on-load (fp32 affine + ReLU, then one rounding to fp16 with saturation).
+__global__ __launch_bounds__(256) void bn_relu_rows_kernel(const half_t* x, int64_t ldx, const float* scale, const float* shift, half_t* y,
+                                                           int64_t ldy, int64_t n_rows, int C8) {
+    const int64_t total = n_rows * C8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / C8;
+        const int c = (int)(i - n * C8) * 8;
+        const half8v v = *reinterpret_cast<const half8v*>(x + n * ldx + c);
+        half8v o;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4v sc = *reinterpret_cast<const float4v*>(scale + c + 4 * q), sh = *reinterpret_cast<const float4v*>(shift + c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * q + e] = (half_t)fminf(fmaxf((float)v[4 * q + e] * sc[e] + sh[e], 0.0f), 65504.0f);
+        }
+        *reinterpret_cast<half8v*>(y + n * ldy + c) = o;
+    }
+}
+
+int bn_relu_rows_launch(const half_t* x, int64_t ldx, const float* scale, const float* shift, half_t* y, int64_t ldy, int64_t n_rows, int C,
+                        hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && y != nullptr && scale != nullptr && shift != nullptr, "bn_relu_rows: null tensor");
+    MV_REQUIRE(n_rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(shift) & 15) == 0,
+               "bn_relu_rows: rows and parameters must be 16-byte aligned, channels a multiple of 8");
+    const int64_t total = n_rows * (C / 8);
+    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    MV_LAUNCH(bn_relu_rows_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, x, ldx, scale, shift, y, ldy, n_rows, C / 8);
+    return check_launch("bn_relu_rows_kernel");
+}
+
 int asp_hidden_act_launch(half_t* zh, const float* row_bias, const float* scale, const float* shift, int B, int T, int A, hipStream_t stream) {
     MV_REQUIRE(zh != nullptr && row_bias != nullptr && scale != nullptr && shift != nullptr, "asp_hidden_act: null tensor");
     MV_REQUIRE(B > 0 && T > 0 && A > 0 && A % 8 == 0, "asp_hidden_act: bad geometry");
@@ -796,6 +829,12 @@ int mv_asp_pool_f16(const void* h, const void* w2_packed, const void* x, int64_t
     return mv::asp_pool_launch(reinterpret_cast<const half_t*>(h), reinterpret_cast<const half_t*>(w2_packed),
                                reinterpret_cast<const half_t*>(x), ldx, gmean, gmean_ld, out, B, T, C, A, logit_bound_log2,
                                static_cast<hipStream_t>(stream));
+}
+
+int mv_bn_relu_rows_f16(const void* x, int64_t ldx, const float* scale, const float* shift, void* y, int64_t ldy, int64_t n_rows,
+                        int32_t C, mv_stream_t stream) {
+    return mv::bn_relu_rows_launch(reinterpret_cast<const half_t*>(x), ldx, scale, shift, reinterpret_cast<half_t*>(y), ldy, n_rows, C,
+                                   static_cast<hipStream_t>(stream));
 }
 
 int mv_time_stats_f16(const void* x, int64_t ld, int32_t B, int32_t T, int32_t C, float* mean, float* std,

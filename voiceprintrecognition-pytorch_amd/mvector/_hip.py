@@ -127,6 +127,7 @@ _SIGNATURES = {
     'mv_fcm_block_c1_f16': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     'mv_fcm_c1_pack': (c_i32, [c_vp, c_vp]),
     'mv_time_stats_f16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_f32, c_vp]),
+    'mv_bn_relu_rows_f16': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
