@@ -78,7 +78,7 @@ def test_gpu_conv1d_double_buffer_persistent_kernel():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0), (250, 4180, 40, 0), (2048, 6144, 192, 0)])
 def test_gpu_linear(shape):
     lc.linear_case(product_lib(), DEV, *shape)
 

@@ -12,6 +12,11 @@
 // reduce through LDS.  Each lane loads float4 of x and of w along K (16 rows x 64 B per instruction) and
 // feeds the four components to four MFMAs, which is a consistent permutation of the K index for both
 // operands.
+//
+// Measured (r10f, tools/bench_linear.py): an XCD-aware workgroup -> tile map for the K = 6144 layers (every XCD owning two row tiles of x, so
+// that x passes through one L2 instead of eight) changes nothing -- 24.3 / 24.7 us warm and 28 us behind a cache flush in both forms, and
+// [2048, 6144] x [192, 6144] takes 8 x the time of 256 rows: the launch is bound by the workgroup's own chain (three dependent load trips + 96
+// fp32 MFMAs per wave, four waves per SIMD), not by operand delivery through the fabric.
 #include "common.h"
 
 namespace mv {
