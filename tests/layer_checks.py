@@ -386,9 +386,13 @@ def bn_relu_rows_case(cdll, device, rows=77, C=520, ldx=528, ldy=544, seed=0):
     xd, scd, shd = x.to(device), sc.to(device), sh.to(device)
     y = torch.full((rows, ldy), -7.0, dtype=torch.half, device=device)
     _hip.check(cdll.mv_bn_relu_rows_f16(xd.data_ptr(), ldx, scd.data_ptr(), shd.data_ptr(), y.data_ptr(), ldy, rows, C, _stream(xd)), cdll)
-    ref = torch.clamp(torch.relu(x.float()[:, :C] * sc + sh), max=65504.0).half()
+    # (the kernel's x * scale + shift is one fused multiply-add, torch rounds the product first: the fp32 results differ by an ulp now and then,
+    # which moves a value across an fp16 rounding boundary in ~1e-4 of the elements -- one fp16 ulp at most)
+    ref64 = torch.clamp(torch.relu(x.double()[:, :C] * sc.double() + sh.double()), max=65504.0)
     out = y.cpu()
-    assert torch.equal(out[:, :C], ref), (out[:, :C].float() - ref.float()).abs().max()
+    err = (out[:, :C].double() - ref64).abs()
+    tol = ref64.abs() * 2.0 ** -11 * 1.001 + 2.0 ** -25   # half an fp16 ulp of the exact value (subnormals: 2^-25)
+    assert bool((err <= tol).all()), (err - tol).max()
     assert bool((out[:, C:] == -7.0).all())
     assert out[0, 0] == 65504.0 and out[0, 1] == 0.0
 

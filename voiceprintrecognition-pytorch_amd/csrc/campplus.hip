@@ -555,17 +555,19 @@ struct CamppModel : MvModelBase {
                 d.pad_mode = MV_PAD_ZERO;
                 if ((rc = conv1d_launch(d, st))) return rc;
             }
-            // transit: BN + ReLU, then a 1x1 conv that halves the channels into the next block's buffer.  Wide blocks (>= 1024 channels: the conv
-            // is 40 GFLOP at the bench shape) write the pre-activation out once (bn_relu_rows_kernel) and run the conv on the direct global -> LDS
-            // path; narrower ones apply it on load (register path).  MV_CAMPP_TRANSIT=load | pre forces either.
+            // transit: BN + ReLU, then a 1x1 conv that halves the channels into the next block's buffer.  The pre-activation is written out once
+            // (bn_relu_rows_kernel) and the conv runs on the direct global -> LDS path (ring kernel, 256 x 256 tiles) instead of transforming on
+            // load through registers: 124 -> 83 us for the two 1024-channel blocks, 60 -> ~35 for the 512-channel one (r10d, r10i).
+            // MV_CAMPP_TRANSIT=load | pre forces either form.
             const char* tr_env = getenv("MV_CAMPP_TRANSIT");
-            const bool pre = tr_env != nullptr ? strcmp(tr_env, "pre") == 0 : Bk.c_out >= 1024;
+            const bool pre = tr_env != nullptr ? strcmp(tr_env, "pre") == 0 : Bk.c_out >= 512;
             if (pre && (rc = bn_relu_rows_launch(X, ld, Bk.tr_s, Bk.tr_t, s.act, Bk.c_out, (int64_t)B * T2, Bk.c_out, st))) return rc;
             MvConv1dDesc d;
             memset(&d, 0, sizeof(d));
             d.x = pre ? s.act : X;
             d.x_dtype = MV_DT_F16;
             d.ldx = ld;  // (the pre-activated copy keeps the block buffer's leading dimension)
+            if (pre && (Bk.c_out / 2) % 256 == 0) d.tile = 256;  // 256 x 256 tiles on the ring kernel even where they do not fill the chip (149 tiles for the first transit: r10i)
             d.in_scale = pre ? nullptr : Bk.tr_s;
             d.in_shift = pre ? nullptr : Bk.tr_t;
             d.w_packed = Bk.transit.w;
