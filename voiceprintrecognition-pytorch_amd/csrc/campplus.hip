@@ -567,7 +567,7 @@ struct CamppModel : MvModelBase {
             d.x = pre ? s.act : X;
             d.x_dtype = MV_DT_F16;
             d.ldx = ld;  // (the pre-activated copy keeps the block buffer's leading dimension)
-            if (pre && (Bk.c_out / 2) % 256 == 0) d.tile = 256;  // 256 x 256 tiles on the ring kernel even where they do not fill the chip (149 tiles for the first transit: r10i)
+            if (pre && (Bk.c_out / 2) % 256 == 0 && (int64_t)B * T2 >= 16384) d.tile = 256;  // 256 x 256 tiles on the ring kernel even where they do not fill the chip (149 tiles for the first transit: r10i)
             d.in_scale = pre ? nullptr : Bk.tr_s;
             d.in_shift = pre ? nullptr : Bk.tr_t;
             d.w_packed = Bk.transit.w;
