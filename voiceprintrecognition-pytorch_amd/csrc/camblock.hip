@@ -26,10 +26,19 @@
 // into scalar registers; a select on a loaded table value puts the wait behind the load: index clamp instead; the compiler's own waits for
 // the parameter loads are pulled to the layer entry with MV_OPAQUE touches.  Starting the odd workgroups 4 - 20 us late (so that half the
 // chip is in its stage loop while the other half is in its tail) changed nothing: 2.23 - 2.27 ms for every delay (r08d).
+// Round 3, r10j: one interleaved schedule per stage (MV_CB_INTERLEAVE, default; 0 = the three-phase stage as an A/B arm): CAM++ 134.5 k -> 137.5 k
+// utt/s in one call (1.903 -> 1.862 ms), bit-identical.  What bounds the stage loop is NOT the issue rate of a CU (the reading of r08b) but the x
+// stream of the whole chip: every layer re-reads its utterance's concat prefix (149 x cin fp16: 90 / 186 / 224 KB on average in the three blocks,
+// 9.1 MB per utterance and step, 2.34 GB per 256-batch = the 43-45 MB per layer launch of the PMC pass), 32 utterances x 305 KB per XCD do not
+// fit a 4 MB L2, so the stream comes from the Infinity Cache / HBM: 2.34 GB at the practical 5.5 TB/s are 425 us of the ~590 us the 52 stage loops
+// take.  A layer's floor is therefore ~8 us of streaming + the ~9.5 us tail (17 us against 22 measured), not the 12-15 us of work VERDICT r2 assumed.
 #include "kernels.h"
 
 namespace mv {
 
+#ifndef MV_CB_INTERLEAVE
+#define MV_CB_INTERLEAVE 1  // 0: the stage as three phases (requests, MFMAs, transform), the form of rounds 2-3 (A/B arm)
+#endif
 constexpr int CB_THREADS = 512;
 constexpr int CB_TT = 10;                           // time tiles of 16 frames: T2 <= 160
 constexpr int CB_ROWS = CB_TT * 16;
@@ -259,6 +268,97 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 wait_vm<5>();
             }
             lds_barrier();  // ... in every wave; x(s) is transformed; every wave is done with x(s-1) and W1(s-1), whose slots are requested now
+#if MV_CB_INTERLEAVE
+            // One schedule for the whole stage (r10j): the five transfer requests of x(s+3) / W1(s+2), the 20 MFMAs on x(s) / W1(s) and the in-place
+            // BN1 + ReLU of x(s+1) are interleaved -- requests and transform cells between groups of MFMAs -- instead of running as three phases
+            // that every wave of the workgroup enters at the same moment (requests ~750 cycles, MFMAs ~400, transform ~600 of a 2300-cycle stage).
+            // The transform of the stage behind the last one works on a dead slot (its result is never read).
+            const char* wt = ws + (s % CB_RING) * CB_WS_BYTES;
+            const char* xt = xs + (s & (CB_XRING - 1)) * CB_XS_BYTES;
+            const bool xreal = s + 3 < nst, wreal = s + 2 < nst;
+            const unsigned xdst = xs_addr + (unsigned)(((s + 3) & (CB_XRING - 1)) * CB_XS_BYTES);
+            const unsigned wdst = ws_addr + (unsigned)(((s + 2) % CB_RING) * CB_WS_BYTES);
+            auto dma_x = [&](int u) {
+                const int tr = wave_u + 8 * u;
+                int row = tr * 8 + lrow;
+                row = row < T2 ? row : T2 - 1;
+                const bool live = xreal && tr < CB_ROWS / 8;  // uniform
+                glds16_untracked(live ? xb + (int64_t)row * a.ldx + (s + 3) * 64 + kc * 8 : zero, live ? xdst + (unsigned)(tr * 1024) : dump_addr);
+            };
+            auto dma_w = [&](int u) {
+                const int tr = wave_u * 2 + u;
+                const int co = tr * 8 + lrow;
+                glds16_untracked(wreal ? L.w1 + (int64_t)co * L.cin_pad + (s + 2) * 64 + kc * 8 : zero, wreal ? wdst + (unsigned)(tr * 1024) : dump_addr);
+            };
+            // transform cells of x(s+1)
+            const int tc = (s + 1) * 64 + xchunk * 8;
+            const bool tlive = tc < L.cin;
+            const float4v ts0 = *reinterpret_cast<const float4v*>(lbn_s + tc), ts1 = *reinterpret_cast<const float4v*>(lbn_s + tc + 4);
+            const float4v tt0 = *reinterpret_cast<const float4v*>(lbn_t + tc), tt1 = *reinterpret_cast<const float4v*>(lbn_t + tc + 4);
+            char* ttile = xs + ((s + 1) & (CB_XRING - 1)) * CB_XS_BYTES;
+            auto cell_ptr = [&](int p) {
+                const int row = xrow0 + 64 * p;
+                return reinterpret_cast<half8v*>(ttile + row * 128 + ((xchunk ^ (row & 7)) << 4));
+            };
+            auto cell_math = [&](int p, const half8v& r) {
+                const int row = xrow0 + 64 * p;
+                half8v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)fmaxf((float)r[e] * ts0[e] + tt0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)r[4 + e] * ts1[e] + tt1[e], 0.0f);
+                }
+                if (!(row < T2 && tlive)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)0.0f;
+                }
+                return o;
+            };
+            const bool cell2 = xrow0 + 128 < CB_ROWS;
+            half8v af[2], bf[5], r0, r1, r2 = half8v{}, o0, o1;
+            auto load_frags = [&](int kk) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int row = (cw * 2 + mi) * 16 + fr;
+                    af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 5; ++ni) {
+                    const int row = (th * 5 + ni) * 16 + fr;
+                    bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                }
+            };
+            auto mm = [&](int ni) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            };
+            load_frags(0);
+            r0 = *cell_ptr(0);
+            dma_x(0);
+            mm(0);
+            mm(1);
+            o0 = cell_math(0, r0);
+            dma_x(1);
+            mm(2);
+            mm(3);
+            *cell_ptr(0) = o0;
+            r1 = *cell_ptr(1);
+            dma_x(2);
+            mm(4);
+            load_frags(1);
+            o1 = cell_math(1, r1);
+            dma_w(0);
+            mm(0);
+            mm(1);
+            *cell_ptr(1) = o1;
+            if (cell2) r2 = *cell_ptr(2);
+            dma_w(1);
+            mm(2);
+            mm(3);
+            mm(4);
+            if (cell2) *cell_ptr(2) = cell_math(2, r2);
+        }
+#else
             issue_x(s + 3, nst);
             issue_w(s + 2, nst, L.w1, L.cin_pad);
             const char* wt = ws + (s % CB_RING) * CB_WS_BYTES;
@@ -283,6 +383,7 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             }
             if (s + 1 < nst) transform(s + 1, L.cin, lbn_s, lbn_t);  // uniform
         }
+#endif
         wait_vm<0>();   // only padding transfers are left: nothing may still be landing when the rings are reused
         lds_barrier();  // every wave is done with both rings
         // The tail's per-thread LDS / global addresses are derived from a thread id the optimiser must treat as new in every layer:
