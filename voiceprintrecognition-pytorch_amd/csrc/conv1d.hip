@@ -1254,6 +1254,10 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
 }
 
+// Wave priorities (r10k): s_setprio 1 around every group of eight MFMAs, and the opposite (priority outside the groups), as probe builds of
+// this file against the default in one call: 76.5 / 77.0 k (default), 76.5 / 76.7 k, 76.6 / 76.7 k utt/s -- no effect; the two waves of a SIMD
+// do not compete for issue slots in a way an arbitration hint changes.
+//
 // Also measured on the ring kernel (r05r): the first stage of a tile requesting its transfers BEFORE the epilogue's stores, with the next
 // stage's wait counted past the 16 store instructions (vmcnt(20)), so that the boundary's store burst drains under two stages instead of in
 // front of stage 1: neutral (K = 1024 190.7-193.8 us vs 191-192), as the same idea had been on the double-buffer kernel -- the ~8 k cycles of
