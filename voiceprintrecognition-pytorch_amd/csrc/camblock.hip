@@ -26,12 +26,15 @@
 // into scalar registers; a select on a loaded table value puts the wait behind the load: index clamp instead; the compiler's own waits for
 // the parameter loads are pulled to the layer entry with MV_OPAQUE touches.  Starting the odd workgroups 4 - 20 us late (so that half the
 // chip is in its stage loop while the other half is in its tail) changed nothing: 2.23 - 2.27 ms for every delay (r08d).
-// Round 3, r10j: one interleaved schedule per stage (MV_CB_INTERLEAVE, default; 0 = the three-phase stage as an A/B arm): CAM++ 134.5 k -> 137.5 k
-// utt/s in one call (1.903 -> 1.862 ms), bit-identical.  What bounds the stage loop is NOT the issue rate of a CU (the reading of r08b) but the x
-// stream of the whole chip: every layer re-reads its utterance's concat prefix (149 x cin fp16: 90 / 186 / 224 KB on average in the three blocks,
-// 9.1 MB per utterance and step, 2.34 GB per 256-batch = the 43-45 MB per layer launch of the PMC pass), 32 utterances x 305 KB per XCD do not
-// fit a 4 MB L2, so the stream comes from the Infinity Cache / HBM: 2.34 GB at the practical 5.5 TB/s are 425 us of the ~590 us the 52 stage loops
-// take.  A layer's floor is therefore ~8 us of streaming + the ~9.5 us tail (17 us against 22 measured), not the 12-15 us of work VERDICT r2 assumed.
+// Round 3, r10j-r10n: one interleaved schedule per stage (MV_CB_INTERLEAVE, default; 0 = the three-phase stage as an A/B arm): CAM++ 134.5 k ->
+// 137.5 k utt/s in one call (1.903 -> 1.862 ms), bit-identical.  Probes on that form (text / macro arms of this file, one call each, wrong results
+// on purpose): the x transfers of the loop reading a constant page instead of the concat buffer (same instructions, no x traffic): no change at
+// all -- the loop is NOT bound by the 2.34 GB per step its x stream moves (every layer re-reads its utterance's prefix; 32 x 305 KB per XCD do
+// not fit an L2), and marking the stages behind the first k as non-temporal (so that the first k x 64 channels of every utterance stay in L2)
+// changes nothing either (k = 0..8: 130.6-131.9 k against 131.9-132.6 k); without the transform (its LDS round trip: 20 KB read + 20 KB written
+// per stage) -168 us per step of 2083, without the MFMAs -110 us; the transform as v_fma_mixlo/hi_f16 + v_pk_max_f16 (12 instead of 36 vector
+// instructions per cell, the same bits: kept) no change.  What is left of a stage (0.6 of 1.17 us) is the barrier, the five transfer requests
+// and the fourteen fragment reads of a wave.
 #include "kernels.h"
 
 namespace mv {
@@ -283,7 +286,9 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 int row = tr * 8 + lrow;
                 row = row < T2 ? row : T2 - 1;
                 const bool live = xreal && tr < CB_ROWS / 8;  // uniform
-                glds16_untracked(live ? xb + (int64_t)row * a.ldx + (s + 3) * 64 + kc * 8 : zero, live ? xdst + (unsigned)(tr * 1024) : dump_addr);
+                const half_t* src = live ? xb + (int64_t)row * a.ldx + (s + 3) * 64 + kc * 8 : zero;
+                const unsigned dst = live ? xdst + (unsigned)(tr * 1024) : dump_addr;
+                glds16_untracked(src, dst);
             };
             auto dma_w = [&](int u) {
                 const int tr = wave_u * 2 + u;
@@ -302,11 +307,18 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             };
             auto cell_math = [&](int p, const half8v& r) {
                 const int row = xrow0 + 64 * p;
+                // fp32 FMA on the fp16 value, ONE rounding to fp16, then ReLU on the packed halves -- the same result as ReLU in fp32 before the
+                // rounding (rounding is monotonic and keeps zero), but a form the compiler maps to v_fma_mixlo/hi_f16 + v_pk_max_f16: 12
+                // instructions per 16-byte cell instead of 36 (cvt, fma, max, cvt per element)
                 half8v o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (half_t)fmaxf((float)r[e] * ts0[e] + tt0[e], 0.0f);
-                    o[4 + e] = (half_t)fmaxf((float)r[4 + e] * ts1[e] + tt1[e], 0.0f);
+                    o[e] = (half_t)__builtin_fmaf((float)r[e], ts0[e], tt0[e]);
+                    o[4 + e] = (half_t)__builtin_fmaf((float)r[4 + e], ts1[e], tt1[e]);
+                }
+                {
+                    const half8v z8 = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                    o = __builtin_elementwise_max(o, z8);
                 }
                 if (!(row < T2 && tlive)) {
 #pragma unroll
