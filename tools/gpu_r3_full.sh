@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $REPO
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 rocminfo | grep -E "Marketing Name|Compute Unit" | head -4 > $OUT/rocminfo.txt 2>&1; nproc >> $OUT/rocminfo.txt
-echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -rA -p no:cacheprovider -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -rA -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 grep -E "passed|failed|Error|FAILED" $OUT/pytest_gpu.log | tail -8
 echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
 echo "== bench"; timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
