@@ -34,7 +34,8 @@
 // changes nothing either (k = 0..8: 130.6-131.9 k against 131.9-132.6 k); without the transform (its LDS round trip: 20 KB read + 20 KB written
 // per stage) -168 us per step of 2083, without the MFMAs -110 us; the transform as v_fma_mixlo/hi_f16 + v_pk_max_f16 (12 instead of 36 vector
 // instructions per cell, the same bits: kept) no change.  What is left of a stage (0.6 of 1.17 us) is the barrier, the five transfer requests
-// and the fourteen fragment reads of a wave.
+// and the fourteen fragment reads of a wave.  W1 for free (no W1 transfers, no W1 fragment reads: the upper bound of the Res2Net chain's
+// "weight fragments straight into registers" form, r10q): -4.4 % of the CAM++ step -- not worth the ~48 registers the kernel does not have.
 #include "kernels.h"
 
 namespace mv {
