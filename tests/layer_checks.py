@@ -599,11 +599,18 @@ def fbank_case(cdll, device, wav, ratio, method_args):
     return d.max().item()
 
 
-def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None):
+def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=None):
     """Golden case through the native model handle (weights from the manifest, reference embedding from golden).  `info`: a dict
-    that receives {key: mv_model_info(key)} for the keys it holds (CAM++: 1 = head on fp32 maps, 2 = creation-time calibration)."""
+    that receives {key: mv_model_info(key)} for the keys it holds (CAM++: 1 = head on fp32 maps, 2 = creation-time calibration).
+    `frames`: instead of the golden input, one seeded utterance of that many frames with the golden input's statistics, the reference
+    embedding from the oracle (pinned to the reference modules by the goldens)."""
     from helpers import load_case, cos_dist
     man, sd, x, emb_ref, _ = load_case(case)
+    if frames is not None:
+        from oracle import models as omodels
+        g = torch.Generator().manual_seed(frames)
+        x = torch.randn(1, frames, x.shape[2], generator=g) * x.std() + x.mean()
+        emb_ref = omodels.FORWARDS[man['model']](sd, x)
     if max_batch is not None:
         x, emb_ref = x[:max_batch], emb_ref[:max_batch]
     kw = man['kwargs']

@@ -106,6 +106,14 @@ def test_emu_fbank_edge_cases():
         lc._hip.Fbank(dict(sample_frequency=8000, num_mel_bins=40), cdll=emu_cdll())
 
 
+@pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~3 min under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_backbones_long_and_short_utterances)')
+def test_emu_campp_long_utterance_two_launch_dense_layers(monkeypatch):
+    """T = 372 frames -> 186 strided frames: two chunks of 160, segments 0 / 1 split over the chunks (camdense.hip, long utterances)"""
+    monkeypatch.setenv('MV_CAMPP_HEAD', 'f16')
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short', frames=372)
+    assert rel < 1e-2
+
+
 @pytest.mark.parametrize('case', ['eres2net_tiny', 'eres2netv2_tiny'])
 def test_emu_eres2net_tiny_end_to_end(case):
     cd, rel = lc.model_case(emu_cdll(), 'cpu', case, tol=1e-8, max_batch=1)  # fp32 operands: far inside the 1e-4 bar

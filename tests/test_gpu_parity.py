@@ -695,11 +695,13 @@ def test_gpu_model_forward_is_hipgraph_capturable(case):
 
 
 @pytest.mark.parametrize('case,T', [('ecapa_c1024', 305), ('ecapa_c1024', 321), ('ecapa_c1024', 998), ('ecapa_c512', 998), ('ecapa_c512', 9),
-                                    ('campp', 998), ('campp', 23), ('tdnn', 998), ('tdnn', 30)])
+                                    ('campp', 998), ('campp', 23), ('campp', 322), ('campp', 640), ('campp', 803), ('tdnn', 998), ('tdnn', 30)])
 def test_gpu_backbones_long_and_short_utterances(case, T):
     """Frame counts outside the golden fixtures (1-10 s is the range BASELINE configs[4] names): T = 305 / 321 leave the Res2Net
     chain's direct form / fused form (its limits are 304 / 320 frames), 998 frames = 10 s takes the multi-tile paths of the ASP
-    pooling and the CAM dense layers, the short ones are close to the reflect-padding minimum.  Reference = the oracle on the CPU."""
+    pooling and the CAM dense layers (T/2 > 160 strided frames: two launches per layer over 160-frame chunks -- 322 -> one full chunk + one
+    frame, 640 -> exactly two chunks, 803 -> three chunks with the segment boundaries inside them), the short ones are close to the
+    reflect-padding minimum.  Reference = the oracle on the CPU."""
     from mvector import models as pmodels
     man, sd, x, _, _ = load_case(case)
     g = torch.Generator().manual_seed(T)
@@ -712,6 +714,25 @@ def test_gpu_backbones_long_and_short_utterances(case, T):
         emb = model(feats.to(DEV)).cpu()
     d = cos_dist(emb, ref).max().item()
     assert d < 1e-4, d
+
+
+def test_gpu_campp_long_utterance_forms_agree(monkeypatch):
+    """CAM++ beyond 3.2 s: the two-launch dense layers (default) and the five-launch form (MV_CAMPP_LONG=0) against the oracle and each other"""
+    from mvector import models as pmodels
+    man, sd, x, _, _ = load_case('campp')
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(3, 700, x.shape[2], generator=g) * x.std() + x.mean()
+    ref = omodels.FORWARDS[man['model']](sd, feats)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('MV_CAMPP_LONG', mode)
+        model = getattr(pmodels, man['model'])(**man['kwargs'])
+        model.load_state_dict(sd)
+        model.eval().to(DEV)
+        with torch.no_grad():
+            out[mode] = model(feats.to(DEV)).cpu()
+        assert cos_dist(out[mode], ref).max().item() < 1e-4
+    assert cos_dist(out['1'], out['0']).max().item() < 1e-6
 
 
 def test_gpu_rccl_one_rank_group_runs_the_exchange_step():

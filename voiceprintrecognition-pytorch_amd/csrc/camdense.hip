@@ -407,4 +407,376 @@ int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const
     return check_launch("cam_dense_layer_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Long utterances (T2 > 160 strided frames = more than 3.2 s of audio): the layer as TWO launches over chunks of 160 frames instead of the
+// five launches of the unfused path (r10r: 163 k instead of 368 k audio-seconds per second beyond 3.2 s).  The context couples all frames of an
+// utterance, so one grid-wide boundary is needed; everything else stays fused:
+//   launch A, workgroup = (chunk, utterance): phase A of cam_dense_layer_kernel on the chunk's rows (both operand streams on LDS-DMA rings,
+//            BN1 + ReLU in place, BN2 + ReLU epilogue), h rows to a global fp16 buffer [B, T2, 128], time sums of h per (chunk, 100-frame
+//            segment inside the chunk: at most three) to a small fp32 buffer -- no atomics, deterministic;
+//   launch B, workgroup = (chunk, utterance): context = total / T2 + segment sum / segment length from those partial sums, the two FCs and
+//            the sigmoid for the chunk's (at most three) segments, h rows of the chunk + dil halo rows from the global buffer into LDS
+//            (zero outside [0, T2): the k = 3 conv's zero padding), k = 3 conv, gate, 32 new channels of x.
+constexpr int CL_MAX_SEG = 3;  // 100-frame segments a 160-frame chunk can touch
+
+struct CamLongArgs {
+    half_t* x;            // [B, T2, ldx]
+    int64_t ldx;
+    const half_t* w1;
+    const float *bn1_s, *bn1_t, *bn2_s, *bn2_t;
+    const half_t* wl;
+    const float *wa, *ba, *wb, *bb;
+    half_t* hws;          // [B, T2, 128] fp16
+    float* hpart;         // [B, nchunks, CL_MAX_SEG, 128] fp32
+    int T2, cin, cin_pad, dil, seg_len, nchunks;
+    int chunk_rows;       // rows per chunk: T2 spread evenly over the chunks, a multiple of 16, <= 160
+};
+
+__global__ __launch_bounds__(CD_THREADS) void cam_dense_long_gemm_kernel(CamLongArgs a) {
+    MV_DYN_SMEM(smem);
+    char* xs = smem;
+    char* ws = xs + CD_XRING * CD_XS_BYTES;
+    char* hbuf = xs;                                            // [160 rows][128] fp16 after the stage loop (40 KiB) ...
+    float* part = reinterpret_cast<float*>(xs + CD_ROWS * CD_BN * 2);  // ... then [32][3][128] fp32 partial sums (48 KiB): x ring + W ring are one idle block
+    static_assert(CD_ROWS * CD_BN * 2 + 32 * CL_MAX_SEG * CD_BN * 4 <= CD_XRING * CD_XS_BYTES + CD_RING * CD_WS_BYTES, "h and the partial sums live in the idle rings");
+    float* fsm = reinterpret_cast<float*>(ws + CD_RING * CD_WS_BYTES);
+    float* lbn_s = fsm + CD_MAX_SEG * (CD_BN + 64 + CD_G);
+    float* lbn_t = lbn_s + a.cin_pad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int r0 = chunk * a.chunk_rows;
+    const int Tn = a.T2 - r0 < a.chunk_rows ? a.T2 - r0 : a.chunk_rows;   // rows of this chunk (>= 1)
+    const half_t* xb = a.x + ((int64_t)b * a.T2 + r0) * a.ldx;
+    const int nst = a.cin_pad / 64;
+    for (int i = tid; i < a.cin_pad; i += CD_THREADS) {
+        lbn_s[i] = i < a.cin ? a.bn1_s[i] : 0.0f;
+        lbn_t[i] = i < a.cin ? a.bn1_t[i] : 0.0f;
+    }
+    __syncthreads();
+    const int cw = wave & 3, th = wave >> 2;
+    float4v e_bn2s[2], e_bn2t[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        e_bn2s[mi] = *reinterpret_cast<const float4v*>(a.bn2_s + (cw * 2 + mi) * 16 + 4 * fg);
+        e_bn2t[mi] = *reinterpret_cast<const float4v*>(a.bn2_t + (cw * 2 + mi) * 16 + 4 * fg);
+    }
+    const int lrow = lane >> 3, kc = (lane & 7) ^ lrow;
+    const unsigned xs_addr = lds_addr(xs), ws_addr = lds_addr(ws);
+    const unsigned dump_addr = lds_addr(reinterpret_cast<char*>(fsm + CD_MAX_SEG * (CD_BN + 64 + CD_G) + 2 * CD_MAX_CIN));
+    const half_t* zero = reinterpret_cast<const half_t*>(g_cd_zero_page);
+    const int wave_u = MV_UNIFORM(wave);
+    auto issue_x = [&](int s) {
+        const bool real = s < nst;
+        const unsigned dst = xs_addr + (unsigned)((s & (CD_XRING - 1)) * CD_XS_BYTES);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tr = wave_u + 8 * u;
+            int row = tr * 8 + lrow;
+            row = row < Tn ? row : Tn - 1;
+            const bool live = real && tr < CD_ROWS / 8;  // uniform
+            glds16_untracked(live ? xb + (int64_t)row * a.ldx + s * 64 + kc * 8 : zero, live ? dst + (unsigned)(tr * 1024) : dump_addr);
+        }
+    };
+    auto issue_w = [&](int s) {
+        const bool real = s < nst;
+        const unsigned dst = ws_addr + (unsigned)((s % CD_RING) * CD_WS_BYTES);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tr = wave_u * 2 + u;
+            const int co = tr * 8 + lrow;
+            glds16_untracked(real ? a.w1 + (int64_t)co * a.cin_pad + s * 64 + kc * 8 : zero, real ? dst + (unsigned)(tr * 1024) : dump_addr);
+        }
+    };
+    const int xchunk = tid & 7, xrow0 = tid >> 3;
+    auto transform = [&](int s) {
+        const int c = s * 64 + xchunk * 8;
+        const bool live = c < a.cin;
+        const float4v s0 = *reinterpret_cast<const float4v*>(lbn_s + c), s1 = *reinterpret_cast<const float4v*>(lbn_s + c + 4);
+        const float4v t0 = *reinterpret_cast<const float4v*>(lbn_t + c), t1 = *reinterpret_cast<const float4v*>(lbn_t + c + 4);
+        char* tile = xs + (s & (CD_XRING - 1)) * CD_XS_BYTES;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int row = xrow0 + 64 * p;
+            if (row < CD_ROWS) {
+                half8v* cell = reinterpret_cast<half8v*>(tile + row * 128 + ((xchunk ^ (row & 7)) << 4));
+                const half8v r = *cell;
+                half8v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)fmaxf((float)r[e] * s0[e] + t0[e], 0.0f);
+                    o[4 + e] = (half_t)fmaxf((float)r[4 + e] * s1[e] + t1[e], 0.0f);
+                }
+                if (!(row < Tn && live)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)0.0f;
+                }
+                *cell = o;
+            }
+        }
+    };
+    issue_x(0);
+    issue_x(1);
+    issue_w(0);
+    issue_x(2);
+    issue_w(1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        MV_OPAQUE(e_bn2s[mi]);
+        MV_OPAQUE(e_bn2t[mi]);
+    }
+    wait_vm<10>();
+    lds_barrier();
+    transform(0);
+    float4v acc[2][5];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int s = 0; s < nst; ++s) {
+        wait_vm<5>();
+        lds_barrier();
+        issue_x(s + 3);
+        issue_w(s + 2);
+        const char* wt = ws + (s % CD_RING) * CD_WS_BYTES;
+        const char* xt = xs + (s & (CD_XRING - 1)) * CD_XS_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8v af[2], bf[5];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = (cw * 2 + mi) * 16 + fr;
+                af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni) {
+                const int row = (th * 5 + ni) * 16 + fr;
+                bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 5; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (s + 1 < nst) transform(s + 1);  // uniform
+    }
+    wait_vm<0>();
+    lds_barrier();
+    // epilogue: BN2 + ReLU -> hbuf rows [0, Tn) (swizzled 16-byte chunks: chunk ^= row & 15)
+    auto h_off = [&](int row, int chunk16) { return row * (CD_BN * 2) + ((chunk16 ^ (row & 15)) << 4); };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int co = (cw * 2 + mi) * 16 + 4 * fg;
+        const float4v sc = e_bn2s[mi], sh = e_bn2t[mi];
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) {
+            const int t = (th * 5 + ni) * 16 + fr;
+            half4v hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+            if (t < Tn) *reinterpret_cast<half4v*>(hbuf + h_off(t, co >> 3) + (co & 7) * 2) = hv;
+        }
+    }
+    __syncthreads();
+    // the chunk's rows of h to the global buffer (16-byte pieces, un-swizzled), and its time sums per segment
+    {
+        half_t* hdst = a.hws + ((int64_t)b * a.T2 + r0) * CD_BN;
+        for (int i = tid; i < Tn * 16; i += CD_THREADS) {
+            const int t = i >> 4, c16 = i & 15;
+            *reinterpret_cast<half8v*>(hdst + (int64_t)t * CD_BN + c16 * 8) = *reinterpret_cast<const half8v*>(hbuf + h_off(t, c16));
+        }
+        const int first_seg = r0 / a.seg_len;
+        const int cg = tid & 15, rp = tid >> 4;
+        float sum[CL_MAX_SEG][8];
+#pragma unroll
+        for (int sg = 0; sg < CL_MAX_SEG; ++sg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[sg][e] = 0.0f;
+        for (int t = rp; t < Tn; t += 32) {
+            const half8v v = *reinterpret_cast<const half8v*>(hbuf + h_off(t, cg));
+            const int sg = (r0 + t) / a.seg_len - first_seg;
+#pragma unroll
+            for (int q = 0; q < CL_MAX_SEG; ++q)
+                if (sg == q) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum[q][e] += (float)v[e];
+                }
+        }
+#pragma unroll
+        for (int sg = 0; sg < CL_MAX_SEG; ++sg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[(rp * CL_MAX_SEG + sg) * CD_BN + cg * 8 + e] = sum[sg][e];
+        __syncthreads();
+        if (tid < CL_MAX_SEG * CD_BN) {
+            float v = 0.0f;
+            for (int p = 0; p < 32; ++p) v += part[p * CL_MAX_SEG * CD_BN + tid];   // tid = sg * 128 + c
+            a.hpart[((int64_t)b * a.nchunks + chunk) * CL_MAX_SEG * CD_BN + tid] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(CD_THREADS) void cam_dense_long_conv_kernel(CamLongArgs a) {
+    __shared__ __attribute__((aligned(16))) char hbuf[(CD_ROWS + 2 * CD_PAD) * CD_BN * 2];
+    __shared__ float ctx[CL_MAX_SEG * CD_BN], g1[CL_MAX_SEG * 64], gate[CL_MAX_SEG * CD_G];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int T2 = a.T2;
+    const int r0 = chunk * a.chunk_rows;
+    const int Tn = T2 - r0 < a.chunk_rows ? T2 - r0 : a.chunk_rows;
+    const int first_seg = r0 / a.seg_len;
+    auto h_off = [&](int row, int chunk16) { return row * (CD_BN * 2) + ((chunk16 ^ (row & 15)) << 4); };
+    // parameters first (their latency runs under the staging of h)
+    float4v e_wa[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e_wa[u] = *reinterpret_cast<const float4v*>(a.wa + (tid >> 3) * CD_BN + (tid & 7) * 16 + 4 * u);
+    const float4v e_wb = *reinterpret_cast<const float4v*>(a.wb + (tid >> 4) * 64 + (tid & 15) * 4);
+    const float e_ba = a.ba[tid >> 3], e_bb = a.bb[tid >> 4];
+    half8v e_wl[3][4];
+    {
+        const half_t* wrow = a.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CD_BN + 8 * fg;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) e_wl[tap][kk] = *reinterpret_cast<const half8v*>(wrow + tap * CD_BN + kk * 32);
+    }
+    // h rows [r0 - PAD, r0 + 160 + PAD) into LDS (row index + PAD), zeros outside [0, T2)
+    {
+        const half_t* hsrc = a.hws + (int64_t)b * T2 * CD_BN;
+        for (int i = tid; i < (CD_ROWS + 2 * CD_PAD) * 16; i += CD_THREADS) {
+            const int row = i >> 4, c16 = i & 15;
+            const int t = r0 + row - CD_PAD;
+            half8v v = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+            if (t >= 0 && t < T2 && row - CD_PAD < Tn + CD_PAD) v = *reinterpret_cast<const half8v*>(hsrc + (int64_t)t * CD_BN + c16 * 8);
+            *reinterpret_cast<half8v*>(hbuf + h_off(row, c16)) = v;
+        }
+    }
+    // context of the chunk's segments: total over all chunks / T2 + segment sum / segment length
+    if (tid < CL_MAX_SEG * CD_BN) {
+        const int sg = tid / CD_BN, c = tid - sg * CD_BN;
+        const int seg = first_seg + sg;
+        const float* hp = a.hpart + (int64_t)b * a.nchunks * CL_MAX_SEG * CD_BN + c;
+        float total = 0.0f, mine = 0.0f;
+        for (int cc = 0; cc < a.nchunks; ++cc) {
+            const int fs = cc * a.chunk_rows / a.seg_len;
+#pragma unroll
+            for (int q = 0; q < CL_MAX_SEG; ++q) {
+                const float v = hp[(cc * CL_MAX_SEG + q) * CD_BN];
+                total += v;
+                if (fs + q == seg) mine += v;
+            }
+        }
+        const int t0 = seg * a.seg_len;
+        const int len = (t0 + a.seg_len < T2 ? t0 + a.seg_len : T2) - t0;
+        ctx[sg * CD_BN + c] = len > 0 ? total / (float)T2 + mine / (float)len : 0.0f;
+    }
+    __syncthreads();
+    {
+        const int j = tid >> 3, part8 = tid & 7;
+#pragma unroll
+        for (int sg = 0; sg < CL_MAX_SEG; ++sg) {
+            const float* cx = ctx + sg * CD_BN + part8 * 16;
+            float v = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4v c4 = *reinterpret_cast<const float4v*>(cx + 4 * u);
+                v = fmaf(e_wa[u][0], c4[0], v);
+                v = fmaf(e_wa[u][1], c4[1], v);
+                v = fmaf(e_wa[u][2], c4[2], v);
+                v = fmaf(e_wa[u][3], c4[3], v);
+            }
+            v += dpp_mov<DPP_QUAD_XOR1>(0.0f, v);
+            v += dpp_mov<DPP_QUAD_XOR2>(0.0f, v);
+            v += dpp_mov<DPP_ROW_HALF_MIRROR>(0.0f, v);
+            if (part8 == 0) g1[sg * 64 + j] = fmaxf(v + e_ba, 0.0f);
+        }
+    }
+    __syncthreads();
+    {
+        const int co = tid >> 4, part16 = tid & 15;
+#pragma unroll
+        for (int sg = 0; sg < CL_MAX_SEG; ++sg) {
+            const float4v g4 = *reinterpret_cast<const float4v*>(g1 + sg * 64 + part16 * 4);
+            float v = e_wb[0] * g4[0];
+            v = fmaf(e_wb[1], g4[1], v);
+            v = fmaf(e_wb[2], g4[2], v);
+            v = fmaf(e_wb[3], g4[3], v);
+            v = row16_sum(v);
+            if (part16 == 0) gate[sg * CD_G + co] = 1.0f / (1.0f + expf(-(v + e_bb)));
+        }
+    }
+    __syncthreads();
+    {
+        half_t* xb = a.x + ((int64_t)b * T2 + r0) * a.ldx;
+        const int ct = wave & 1, tg = wave >> 1;
+        float4v yc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const half8v af = e_wl[tap][kk];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int tile = tg + 4 * j;
+                    if (tile < CD_TT) {  // uniform per wave
+                        const int row = tile * 16 + fr + (tap - 1) * a.dil + CD_PAD;
+                        const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
+                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int co = ct * 16 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tile = tg + 4 * j;
+            const int t = tile * 16 + fr;
+            if (tile < CD_TT && t < Tn) {
+                const float* gt = gate + ((r0 + t) / a.seg_len - first_seg) * CD_G + co;
+                half4v hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(yc[j][r] * gt[r], -65504.0f, 65504.0f);
+                *reinterpret_cast<half4v*>(xb + (int64_t)t * a.ldx + a.cin + co) = hv;
+            }
+        }
+    }
+}
+
+bool cam_dense_long_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len) {
+    // (a 160-frame chunk touches at most three segments when a segment is at least 80 frames long)
+    return bottleneck == CD_BN && growth == CD_G && T2 > CD_ROWS && cin % 32 == 0 && cin >= 32 && cin <= CD_MAX_CIN - 64 && dil >= 1 && dil <= CD_PAD &&
+           seg_len >= 80;
+}
+
+int64_t cam_dense_long_part_floats(int B, int T2) { return (int64_t)B * ceil_div(T2, CD_ROWS) * CL_MAX_SEG * CD_BN; }
+
+int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
+                          const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
+                          const float* bb, int dil, int seg_len, half_t* hws, float* hpart, hipStream_t stream) {
+    MV_REQUIRE(cam_dense_long_supported(T2, cin, CD_BN, CD_G, dil, seg_len), "cam_dense_long: unsupported geometry");
+    MV_REQUIRE(ldx >= cin + CD_G && (ldx % 8) == 0, "cam_dense_long: the row must hold the inputs and 32 new channels (16-byte aligned chunks)");
+    MV_REQUIRE(hws != nullptr && hpart != nullptr && (reinterpret_cast<uintptr_t>(hws) & 15) == 0, "cam_dense_long: workspace");
+    static bool smem_set = false;
+    if (!smem_set) {
+        if (MV_SET_MAX_SMEM(cam_dense_long_gemm_kernel, CD_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_long: cannot reserve LDS");
+        smem_set = true;
+    }
+    CamLongArgs a;
+    a.x = x; a.ldx = ldx; a.w1 = w1; a.bn1_s = bn1_s; a.bn1_t = bn1_t; a.bn2_s = bn2_s; a.bn2_t = bn2_t; a.wl = wl;
+    a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.hws = hws; a.hpart = hpart;
+    a.T2 = T2; a.cin = cin; a.cin_pad = conv1d_cin_pad(cin); a.dil = dil; a.seg_len = seg_len;
+    a.nchunks = (int)ceil_div(T2, CD_ROWS);
+    a.chunk_rows = (int)round_up(ceil_div(T2, a.nchunks), 16);   // even chunks (165 frames: 96 + 69, not 160 + 5); the last one takes what is left
+    a.nchunks = (int)ceil_div(T2, a.chunk_rows);
+    MV_LAUNCH(cam_dense_long_gemm_kernel, ((unsigned)a.nchunks, (unsigned)B, 1), (CD_THREADS, 1, 1), CD_LDS_BYTES, stream, a);
+    int rc = check_launch("cam_dense_long_gemm_kernel");
+    if (rc != MV_OK) return rc;
+    MV_LAUNCH(cam_dense_long_conv_kernel, ((unsigned)a.nchunks, (unsigned)B, 1), (CD_THREADS, 1, 1), 0, stream, a);
+    return check_launch("cam_dense_long_conv_kernel");
+}
+
 }  // namespace mv

@@ -10,7 +10,8 @@
 //                 ctx = mean_T(h) + segmean_100(h)             (campplus.py:94-111) -> [B, nseg, 128]
 //                 m   = sigmoid(W_b . ReLU(W_a . ctx + b_a) + b_b)   evaluated once per segment, not per frame
 //                 y   = conv_k3(h) * m                          gate multiplied in the conv epilogue
-//             (one launch per layer for utterances of up to 160 strided frames: camdense.hip; five launches beyond)
+//             (one launch per block / layer for utterances of up to 160 strided frames: camblock.hip, camdense.hip; two launches per layer over
+//             160-frame chunks beyond: camdense.hip "long utterances"; five launches per layer only where neither form applies)
 //             transit: 1x1 conv with BN/ReLU on load; out_nonlinear + StatsPool (unbiased std) fused into one reduction;
 //             dense + BN(affine=False) folded into one fp32 linear layer.
 //
@@ -282,6 +283,7 @@ struct CamppModel : MvModelBase {
         half_t* h;             // [B, T2, 128]
         half_t* act;           // [B, T2, widest block]: pre-activated transit input
         float *ctx, *g1, *gate, *stats;
+        float* hpart;          // long utterances: time sums of h per (utterance, 160-frame chunk, segment inside the chunk)
         size_t bytes;
         int T2, nseg;
     };
@@ -317,6 +319,7 @@ struct CamppModel : MvModelBase {
             s.act = c.take<half_t>(N2 * widest);
         }
         s.ctx = c.take<float>((size_t)B * s.nseg * bn_ch);
+        s.hpart = c.take<float>((size_t)cam_dense_long_part_floats(B, s.T2));
         s.g1 = c.take<float>((size_t)B * s.nseg * (bn_ch / 2));
         s.gate = c.take<float>((size_t)B * s.nseg * cfg.growth_rate);
         s.stats = c.take<float>((size_t)B * 2 * cfin);
@@ -503,6 +506,17 @@ struct CamppModel : MvModelBase {
                                                      L.wb, L.bb, Bk.dil, 100, st)))
                         return rc;
                     continue;
+                }
+                // longer utterances: two launches per layer over chunks of 160 strided frames (camdense.hip, "long utterances");
+                // MV_CAMPP_LONG=0 keeps the five launches below (A/B arm)
+                {
+                    const char* long_env = getenv("MV_CAMPP_LONG");
+                    if (fused_dense && !(long_env != nullptr && long_env[0] == '0') && cam_dense_long_supported(T2, L.cin, bn_ch, G, Bk.dil, 100)) {
+                        if ((rc = cam_dense_long_launch(X, ld, B, T2, L.cin, L.lin1.w, L.bn1_s, L.bn1_t, L.bn2_s, L.bn2_t, L.local.w, L.wa, L.ba, L.wb,
+                                                        L.bb, Bk.dil, 100, s.h, s.hpart, st)))
+                            return rc;
+                        continue;
+                    }
                 }
                 MvConv1dDesc d;
                 memset(&d, 0, sizeof(d));

@@ -48,6 +48,11 @@ int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const f
                      const half_t* c1a = nullptr, const float* c1b = nullptr);
 void fcm_c1_pack(const float* w, half_t* out);  // [32][3 df][3 dt] fp32 (BN folded) -> [2][64][8] fp16 MFMA A fragments
 // one CAMDenseTDNNLayer (campplus.py:114-150) as one launch, one workgroup per utterance (camdense.hip); T2 <= 160 frames
+bool cam_dense_long_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len);
+int64_t cam_dense_long_part_floats(int B, int T2);
+int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
+                          const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
+                          const float* bb, int dil, int seg_len, half_t* hws, float* hpart, hipStream_t stream);
 bool cam_dense_layer_supported(int T2, int cin, int bottleneck, int growth, int dil, int seg_len);
 int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
                            const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
