@@ -538,13 +538,51 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_long_gemm_kernel(CamLong
     for (int s = 0; s < nst; ++s) {
         wait_vm<5>();
         lds_barrier();
-        issue_x(s + 3);
-        issue_w(s + 2);
+        // one interleaved schedule per stage, as in cam_dense_block_kernel (camblock.hip, r10j): the five transfer requests of x(s+3) / W1(s+2)
+        // and the in-place BN1 + ReLU of x(s+1) (fp32 FMA -> fp16, packed max) between the MFMA groups on x(s) / W1(s); the transform of the
+        // stage behind the last one works on a dead slot
         const char* wt = ws + (s % CD_RING) * CD_WS_BYTES;
         const char* xt = xs + (s & (CD_XRING - 1)) * CD_XS_BYTES;
+        const bool xreal = s + 3 < nst, wreal = s + 2 < nst;
+        const unsigned xdst = xs_addr + (unsigned)(((s + 3) & (CD_XRING - 1)) * CD_XS_BYTES);
+        const unsigned wdst = ws_addr + (unsigned)(((s + 2) % CD_RING) * CD_WS_BYTES);
+        auto dma_x = [&](int u) {
+            const int tr = wave_u + 8 * u;
+            int row = tr * 8 + lrow;
+            row = row < Tn ? row : Tn - 1;
+            const bool live = xreal && tr < CD_ROWS / 8;  // uniform
+            glds16_untracked(live ? xb + (int64_t)row * a.ldx + (s + 3) * 64 + kc * 8 : zero, live ? xdst + (unsigned)(tr * 1024) : dump_addr);
+        };
+        auto dma_w = [&](int u) {
+            const int tr = wave_u * 2 + u;
+            const int co = tr * 8 + lrow;
+            glds16_untracked(wreal ? a.w1 + (int64_t)co * a.cin_pad + (s + 2) * 64 + kc * 8 : zero, wreal ? wdst + (unsigned)(tr * 1024) : dump_addr);
+        };
+        const int tc = (s + 1) * 64 + xchunk * 8;
+        const bool tlive = tc < a.cin;
+        const float4v ts0 = *reinterpret_cast<const float4v*>(lbn_s + tc), ts1 = *reinterpret_cast<const float4v*>(lbn_s + tc + 4);
+        const float4v tt0 = *reinterpret_cast<const float4v*>(lbn_t + tc), tt1 = *reinterpret_cast<const float4v*>(lbn_t + tc + 4);
+        char* ttile = xs + ((s + 1) & (CD_XRING - 1)) * CD_XS_BYTES;
+        auto cell_ptr = [&](int p) {
+            const int row = xrow0 + 64 * p;
+            return reinterpret_cast<half8v*>(ttile + row * 128 + ((xchunk ^ (row & 7)) << 4));
+        };
+        auto cell_math = [&](int p, const half8v& r) {
+            const int row = xrow0 + 64 * p;
+            half8v o;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8v af[2], bf[5];
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (half_t)__builtin_fmaf((float)r[e], ts0[e], tt0[e]);
+                o[4 + e] = (half_t)__builtin_fmaf((float)r[4 + e], ts1[e], tt1[e]);
+            }
+            const half8v z8 = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+            o = __builtin_elementwise_max(o, z8);
+            if (!(row < Tn && tlive)) o = z8;
+            return o;
+        };
+        const bool cell2 = xrow0 + 128 < CD_ROWS;
+        half8v af[2], bf[5], r0c, r1c, r2c = half8v{}, o0, o1;
+        auto load_frags = [&](int kk) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int row = (cw * 2 + mi) * 16 + fr;
@@ -555,12 +593,36 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_long_gemm_kernel(CamLong
                 const int row = (th * 5 + ni) * 16 + fr;
                 bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
             }
+        };
+        auto mm = [&](int ni) {
 #pragma unroll
-            for (int ni = 0; ni < 5; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (s + 1 < nst) transform(s + 1);  // uniform
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        };
+        load_frags(0);
+        r0c = *cell_ptr(0);
+        dma_x(0);
+        mm(0);
+        mm(1);
+        o0 = cell_math(0, r0c);
+        dma_x(1);
+        mm(2);
+        mm(3);
+        *cell_ptr(0) = o0;
+        r1c = *cell_ptr(1);
+        dma_x(2);
+        mm(4);
+        load_frags(1);
+        o1 = cell_math(1, r1c);
+        dma_w(0);
+        mm(0);
+        mm(1);
+        *cell_ptr(1) = o1;
+        if (cell2) r2c = *cell_ptr(2);
+        dma_w(1);
+        mm(2);
+        mm(3);
+        mm(4);
+        if (cell2) *cell_ptr(2) = cell_math(2, r2c);
     }
     wait_vm<0>();
     lds_barrier();
