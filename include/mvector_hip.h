@@ -316,7 +316,8 @@ int mv_conv1d_stats_finish(const float* stat_sum, const float* stat_sq, const fl
 /* Fused Res2Net chain (mvector/models/ecapa_tdnn.py:39-51): x, y fp16 [B, T, C]; `groups` channel groups of width C/groups;
  * y[..., 0:w] = x[..., 0:w];  y_j = BN(ReLU(conv_j(x_j + y_{j-1}))) for j = 1..groups-1 with reflect "same" padding.
  * Arrays of groups-1 pointers (host arrays of device pointers): packed weights, bias, folded BN scale / shift.
- * One workgroup per utterance; returns MV_ERR_UNSUPPORTED unless width is 64 or 128 and T <= 320. */
+ * One workgroup per utterance up to 320 frames; longer utterances are cut into chunks of equal length that carry the chain's receptive field
+ * ((groups-1) * dilation * (k-1)/2 frames) as halo on either side, one workgroup each.  Returns MV_ERR_UNSUPPORTED unless width is 64 or 128. */
 int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, const float* const* bias,
                          const float* const* scale, const float* const* shift, int32_t B, int32_t T, int32_t C,
                          int32_t groups, int32_t k, int32_t dilation, mv_stream_t stream);

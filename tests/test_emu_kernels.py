@@ -247,7 +247,8 @@ def test_emu_asp_pool(cfg):
     lc.asp_pool_case(emu_cdll(), 'cpu', **cfg)
 
 
-@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1), dict(width=128, T=75, dil=3, B=2)])
+@pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=33, dil=4, B=1), dict(width=64, T=170, dil=2, B=1), dict(width=128, T=75, dil=3, B=2),
+                                 dict(width=64, T=400, dil=2, B=1), dict(width=128, T=331, dil=4, B=1)])   # > 320 frames: two chunks with halo rows
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
 

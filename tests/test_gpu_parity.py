@@ -660,7 +660,8 @@ def test_gpu_campp_first_conv_inside_and_outside_the_block_agree(monkeypatch):
 
 
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
-                                 dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2)])
+                                 dict(width=128, T=320, dil=3, B=2), dict(width=128, T=17, dil=2, B=2),
+                                 dict(width=128, T=321, dil=4, B=3), dict(width=128, T=998, dil=2, B=2), dict(width=64, T=600, dil=3, B=2), dict(width=128, T=600, dil=3, B=128)])   # > 320 frames: chunks with halo rows
 def test_gpu_res2net_fused_chain(cfg):
     lc.res2_chain_case(product_lib(), DEV, **cfg)
 

@@ -40,6 +40,10 @@
 // fragment loads the compiler waits for, every fragment wait now also waits for the stores of the stage before (the chain without ANY y
 // stores: 95 us, so the stores cost 15 us in the epilogue and 26 us in the loop).  Parked.
 //
+// Long utterances (r10u): beyond 320 frames the launcher cuts an utterance into chunks (Res2Args::nchunks / useful / halo) -- the kernel body runs
+// unchanged on a chunk's rows + halo, only the row base and the y store mask are per chunk: EcapaTdnn-1024 at 6 s 177 -> 204 k audio-seconds/s
+// against one launch per step.
+//
 // Work split: 8 waves; wave w owns output channel tiles {MI*(w&3) .. +MI} and the time tiles of half (w>>2).
 // torch.chunk / torch.cat never exist: slices are addressed inside the [B, T, C] tensors, slice 0 is copied through.
 #include <type_traits>
@@ -69,6 +73,11 @@ struct Res2Args {
     const float* scale[R2_MAX_STEPS];
     const float* shift[R2_MAX_STEPS];
     int T, C, width, steps, k, dil, kpad;  // kpad = round_up(width, 64)
+    // Long utterances (T beyond what the LDS buffer holds): nchunks workgroups per utterance.  Chunk c produces the rows [c * useful, (c + 1) * useful)
+    // and runs the whole chain on them + `halo` = steps * pad rows on either side (clipped to the utterance): the receptive field of the chain,
+    // so every produced row sees exactly what it sees in the unchunked run; the halo rows' own results (wrong towards an interior edge, where the
+    // kernel reflects instead of seeing the neighbour's rows) are never stored.  nchunks = 1: the whole utterance, as before.
+    int nchunks, useful, halo;
 };
 
 // (LDS-DMA transfers, counted waits, the LDS-only barrier and the fp16 saturation are the arch header's glds16 / wait_vm /
@@ -94,11 +103,15 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = MV_UNIFORM(wave);
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.x;
-    const int T = a.T;
+    const int b = a.nchunks > 1 ? (int)blockIdx.x / a.nchunks : (int)blockIdx.x;
+    const int chunk = a.nchunks > 1 ? (int)blockIdx.x - b * a.nchunks : 0;
+    const int u0 = chunk * a.useful, u1 = u0 + a.useful < a.T ? u0 + a.useful : a.T;   // rows this workgroup produces
+    const int l0 = u0 - a.halo > 0 ? u0 - a.halo : 0, l1 = u1 + a.halo < a.T ? u1 + a.halo : a.T;   // rows it works on
+    const int T = l1 - l0;                        // local frame count: everything below is the unchunked kernel on rows [l0, l1)
+    const int st0 = u0 - l0, st1 = u1 - l0;       // local rows whose results are stored
     const int half_k = (a.k - 1) / 2;
     const int PAD = half_k * a.dil;
-    const int64_t rowbase = (int64_t)b * T;
+    const int64_t rowbase = (int64_t)b * a.T + l0;
     const half_t* xb = a.x + rowbase * a.C;
     half_t* yb = a.y + rowbase * a.C;
     auto a_off = [&](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CPR - 1))) << 4); };
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         if (t >= -PAD && t < T + PAD) {
             const int ts = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)ts * a.C + WIDTH + ch * 8);
-            if (t >= 0 && t < T)
+            if (t >= st0 && t < st1)
                 *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + ch * 8) = *reinterpret_cast<const half8v*>(xb + (int64_t)t * a.C + ch * 8);
         }
         *reinterpret_cast<half8v*>(abuf + a_off(row, ch)) = v1;
@@ -400,8 +413,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     xnext = *reinterpret_cast<const half8v*>(wbuf + tc * ROWB + (((co8 >> 3) ^ (tc & 15)) << 4));
                 }
                 const half8v nv = __builtin_elementwise_max(__builtin_elementwise_min(ov + xnext, hi8), -hi8);
+                if (t >= st0 && t < st1) *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
                 if (t < T) {
-                    *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
                     if (more) {
                         *reinterpret_cast<half8v*>(abuf + a_off(t + PAD, co8 >> 3)) = nv;
                         if (t >= 1 && t <= PAD) *reinterpret_cast<half8v*>(abuf + a_off(PAD - t, co8 >> 3)) = nv;
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     const half4v hi4 = {(half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f};
                     nv = __builtin_elementwise_max(__builtin_elementwise_min(sum, hi4), -hi4);
                 }
+                if (t >= st0 && t < st1) *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
                 if (t < T) {
-                    *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
                     if (more) {
                         const int cb = (co & 7) * 2;
                         *reinterpret_cast<half4v*>(abuf + a_off(t + PAD, co >> 3) + cb) = nv;
@@ -458,9 +471,29 @@ size_t res2_chain_lds_bytes(int T, int width, int k) {
     return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)R2_ROWS * width * 2;
 }
 
+// frames one workgroup can hold (direct form: the x_{j+1} region; ring form: the 20 time tiles of the accumulators)
+static int res2_local_limit(int width, int k) { return R2_DIRECT && width == 128 && k % 3 == 0 ? 304 : 16 * 2 * R2_NH; }
+
+// utterances beyond 320 frames: chunks of equal useful length with steps * pad halo rows per side (Res2Args); {1, T} when one workgroup holds it
+static void res2_chunking(int T, int width, int steps, int k, int dil, int* nchunks, int* useful) {
+    *nchunks = 1;
+    *useful = T;
+    if (T <= 16 * 2 * R2_NH) return;
+    if (const char* e = getenv("MV_RES2_CHUNK")) if (e[0] == '0') return;   // A/B arm: long utterances as one launch per step (model.hip)
+    const int per = res2_local_limit(width, k) - 2 * steps * (dil * (k - 1) / 2);
+    if (per < 64) return;  // (not worth it: the caller falls back to one launch per step)
+    *nchunks = (T + per - 1) / per;
+    *useful = (T + *nchunks - 1) / *nchunks;
+}
+
 bool res2_chain_supported(int T, int width, int steps, int k, int dil) {
-    return (width == 64 || width == 128) && T <= 16 * 2 * R2_NH && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1 &&
-           dil * (k - 1) / 2 <= R2_MAXPAD && dil * (k - 1) / 2 < T;
+    if (!((width == 64 || width == 128) && steps >= 1 && steps <= R2_MAX_STEPS && (k % 2) == 1 && dil * (k - 1) / 2 <= R2_MAXPAD &&
+          dil * (k - 1) / 2 < T))
+        return false;
+    if (T <= 16 * 2 * R2_NH) return true;
+    int nchunks, useful;
+    res2_chunking(T, width, steps, k, dil, &nchunks, &useful);
+    return nchunks > 1;
 }
 
 int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const float* const* bias, const float* const* scale,
@@ -483,16 +516,20 @@ int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const 
     a.k = k;
     a.dil = dil;
     a.kpad = conv1d_cin_pad(width);
-    const size_t lds = res2_chain_lds_bytes(T, width, k);
-    if (res2_direct(T, width, k)) {
+    res2_chunking(T, width, steps, k, dil, &a.nchunks, &a.useful);
+    a.halo = a.nchunks > 1 ? steps * (dil * (k - 1) / 2) : 0;
+    const int Tl = a.nchunks > 1 ? (a.useful + 2 * a.halo < T ? a.useful + 2 * a.halo : T) : T;   // most frames a workgroup works on
+    const size_t lds = res2_chain_lds_bytes(Tl, width, k);
+    const unsigned grid = (unsigned)B * (unsigned)a.nchunks;
+    if (res2_direct(Tl, width, k)) {
         if (MV_SET_MAX_SMEM((res2_chain_kernel<2, true>), lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
-        MV_LAUNCH((res2_chain_kernel<2, true>), ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+        MV_LAUNCH((res2_chain_kernel<2, true>), (grid, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
     } else if (width == 128) {
         if (MV_SET_MAX_SMEM(res2_chain_kernel<2>, lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
-        MV_LAUNCH(res2_chain_kernel<2>, ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+        MV_LAUNCH(res2_chain_kernel<2>, (grid, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
     } else {
         if (MV_SET_MAX_SMEM(res2_chain_kernel<1>, lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
-        MV_LAUNCH(res2_chain_kernel<1>, ((unsigned)B, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
+        MV_LAUNCH(res2_chain_kernel<1>, (grid, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
     }
     return check_launch("res2_chain_kernel");
 }
@@ -510,7 +547,7 @@ int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, co
     const int width = C / groups;
     if (!mv::res2_chain_supported(T, width, groups - 1, k, dilation))
         return mv::fail(MV_ERR_UNSUPPORTED,
-                        "mv_res2net_chain_f16: fused chain needs width 64/128, T <= 320, an odd kernel and padding <= 8 (< T)");
+                        "mv_res2net_chain_f16: fused chain needs width 64/128, an odd kernel and padding <= 8 (< T)");
     return mv::res2_chain_launch(reinterpret_cast<const half_t*>(x), reinterpret_cast<half_t*>(y),
                                  reinterpret_cast<const half_t* const*>(w_packed), bias, scale, shift, B, T, C, width, groups - 1, k,
                                  dilation, static_cast<hipStream_t>(stream));
