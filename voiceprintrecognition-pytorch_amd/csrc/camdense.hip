@@ -814,7 +814,7 @@ bool cam_dense_long_supported(int T2, int cin, int bottleneck, int growth, int d
            seg_len >= 80;
 }
 
-int64_t cam_dense_long_part_floats(int B, int T2) { return (int64_t)B * ceil_div(T2, CD_ROWS) * CL_MAX_SEG * CD_BN; }
+int64_t cam_dense_long_part_floats(int B, int T2) { return (int64_t)B * (ceil_div(T2, CD_ROWS) + 4) * CL_MAX_SEG * CD_BN; }  // (+ 4: the launcher may take up to four more chunks)
 
 int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const half_t* w1, const float* bn1_s, const float* bn1_t,
                           const float* bn2_s, const float* bn2_t, const half_t* wl, const float* wa, const float* ba, const float* wb,
@@ -831,9 +831,27 @@ int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const 
     a.x = x; a.ldx = ldx; a.w1 = w1; a.bn1_s = bn1_s; a.bn1_t = bn1_t; a.bn2_s = bn2_s; a.bn2_t = bn2_t; a.wl = wl;
     a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.hws = hws; a.hpart = hpart;
     a.T2 = T2; a.cin = cin; a.cin_pad = conv1d_cin_pad(cin); a.dil = dil; a.seg_len = seg_len;
-    a.nchunks = (int)ceil_div(T2, CD_ROWS);
-    a.chunk_rows = (int)round_up(ceil_div(T2, a.nchunks), 16);   // even chunks (165 frames: 96 + 69, not 160 + 5); the last one takes what is left
-    a.nchunks = (int)ceil_div(T2, a.chunk_rows);
+    // Even chunks (165 frames: 96 + 69, not 160 + 5), and as many of them as make the rounds of workgroups cheapest: one workgroup per CU at a time,
+    // a workgroup's time ~ 0.45 + 0.55 * rows / 160 of a full one (r10s: the per-stage cost is mostly fixed), so 76 utterances x 4 chunks of 125 rows
+    // (304 workgroups: a second round for 48 of them) lose to 6 chunks of 96 (456: two rounds of cheaper workgroups).
+    {
+        static int cus = -1;
+        if (cus < 0) cus = device_cu_count();
+        const int nmin = (int)ceil_div(T2, CD_ROWS);
+        double best = 0.0;
+        a.nchunks = nmin;
+        a.chunk_rows = (int)round_up(ceil_div(T2, nmin), 16);
+        for (int n = nmin; n <= nmin + 4; ++n) {
+            const int rows = (int)round_up(ceil_div(T2, n), 16);
+            const int chunks = (int)ceil_div(T2, rows);
+            const double cost = (double)ceil_div((int64_t)B * chunks, cus > 0 ? cus : 256) * (0.45 + 0.55 * rows / CD_ROWS);
+            if (n == nmin || cost < best * 0.97) {   // (3 % margin: stay with fewer workgroups on a tie)
+                best = cost;
+                a.nchunks = chunks;
+                a.chunk_rows = rows;
+            }
+        }
+    }
     MV_LAUNCH(cam_dense_long_gemm_kernel, ((unsigned)a.nchunks, (unsigned)B, 1), (CD_THREADS, 1, 1), CD_LDS_BYTES, stream, a);
     int rc = check_launch("cam_dense_long_gemm_kernel");
     if (rc != MV_OK) return rc;
