@@ -696,7 +696,8 @@ def test_gpu_model_forward_is_hipgraph_capturable(case):
 
 
 @pytest.mark.parametrize('case,T', [('ecapa_c1024', 305), ('ecapa_c1024', 321), ('ecapa_c1024', 998), ('ecapa_c512', 998), ('ecapa_c512', 9),
-                                    ('campp', 998), ('campp', 23), ('campp', 322), ('campp', 640), ('campp', 803), ('tdnn', 998), ('tdnn', 30)])
+                                    ('campp', 998), ('campp', 23), ('campp', 322), ('campp', 640), ('campp', 803), ('tdnn', 998), ('tdnn', 30),
+                                    ('campp', 3001), ('ecapa_c512', 3001), ('ecapa_c1024', 1501)])   # 30 s / 15 s: many chunks per utterance
 def test_gpu_backbones_long_and_short_utterances(case, T):
     """Frame counts outside the golden fixtures (1-10 s is the range BASELINE configs[4] names): T = 305 / 321 leave the Res2Net
     chain's direct form / fused form (its limits are 304 / 320 frames), 998 frames = 10 s takes the multi-tile paths of the ASP
