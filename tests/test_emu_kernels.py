@@ -294,3 +294,14 @@ def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypat
     monkeypatch.setenv('MV_FBANK_IMPL', 'generic')
     assert not _hip.Fbank(FB, cdll=emu_cdll()).info()['tile_kernel']
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB)
+
+
+def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms(monkeypatch):
+    """utterances beyond the LDS block on a chip the batch does not fill: chunks of 288 frames, one workgroup each, + the finish pass (default);
+    MV_FBANK_CHUNK=0 keeps one workgroup per utterance.  Both against the oracle (1000 frames = 4 chunks; ragged lengths through the ratio mask)."""
+    wav = frontend.synth_waveforms(3, 400 + 160 * 999, seed=31)
+    ratio = torch.tensor([0.41, 1.0, 0.77])
+    lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:1], None, FB)
+    monkeypatch.setenv('MV_FBANK_CHUNK', '0')
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:2], ratio[:2], FB)

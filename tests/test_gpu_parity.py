@@ -94,6 +94,24 @@ def test_gpu_time_stats(unbiased, eps):
     lc.time_stats_case(product_lib(), DEV, B=7, T=298, C=3072, ld=3072, unbiased=unbiased, eps=eps, seed=2)
 
 
+def test_gpu_fbank_long_utterances_chunked_and_single_workgroup_forms(monkeypatch):
+    """utterances beyond the LDS block with fewer utterances than CUs: chunks of 288 frames + the finish pass (default), MV_FBANK_CHUNK=0 = one
+    workgroup per utterance; 10 s x 3 with ragged lengths, 30 s x 1, and 128 x 6 s (half a chip of utterances) against the oracle / each other"""
+    from mvector import _hip
+    FB = dict(sample_frequency=16000, num_mel_bins=80)
+    wav = frontend.synth_waveforms(3, 400 + 160 * 999, seed=31)
+    ratio = torch.tensor([0.41, 1.0, 0.77])
+    lc.fbank_case(product_lib(), DEV, wav, ratio, FB)
+    lc.fbank_case(product_lib(), DEV, frontend.synth_waveforms(1, 480000, seed=32), None, FB)
+    big = (0.1 * torch.randn(128, 96000, generator=torch.Generator().manual_seed(33))).to(DEV)
+    fb = _hip.Fbank(FB)
+    a = fb(big)
+    monkeypatch.setenv('MV_FBANK_CHUNK', '0')
+    lc.fbank_case(product_lib(), DEV, wav, ratio, FB)
+    b = fb(big)
+    assert (a - b).abs().max().item() < 2e-4   # (the time mean is summed in a different order)
+
+
 def test_gpu_bn_relu_rows():
     lc.bn_relu_rows_case(product_lib(), DEV)
     lc.bn_relu_rows_case(product_lib(), DEV, rows=38144, C=1024, ldx=1024, ldy=1024, seed=3)

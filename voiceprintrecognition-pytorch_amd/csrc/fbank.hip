@@ -67,6 +67,11 @@ struct FbankArgs {
     int64_t L;
     int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
                       // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
+    // fbank_tile_kernel, long utterances on a chip the batch does not fill: nchunks workgroups per utterance, chunk c takes the quads (4 frames)
+    // [c * chunk_quads, (c + 1) * chunk_quads), writes its raw rows and its column sums (part: [B, nchunks, 128]); fbank_cmn_finish_kernel
+    // subtracts the mean and applies the mask afterwards.  nchunks = 1: one workgroup per utterance, everything in one launch.
+    int nchunks, chunk_quads;
+    float* part;
     FbankTables tab;
 };
 
@@ -393,7 +398,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int wave = tid >> 6;
     const int l16 = lane & 15;
     const int fs = lane >> 4;
-    const int b = blockIdx.x;
+    const int b = a.nchunks > 1 ? (int)blockIdx.x / a.nchunks : (int)blockIdx.x;
+    const int chunk = a.nchunks > 1 ? (int)blockIdx.x - b * a.nchunks : 0;
     const int Tout = a.T;
     int T = a.T;
     if (a.num_samples != nullptr) {
@@ -441,7 +447,9 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int tile_rows = a.tile_rows;
 
     __syncthreads();  // window taps
-    const int nquads = (T + 3) >> 2;
+    const int nquads_all = (T + 3) >> 2;
+    const int qbeg = chunk * a.chunk_quads;                                        // (nchunks = 1: chunk_quads covers the utterance)
+    const int nquads = qbeg + a.chunk_quads < nquads_all ? qbeg + a.chunk_quads : nquads_all;   // end of this workgroup's quads
     // samples of one quad: lane holds {x[j-1], x[j], x[j+1]} at j = 32 n1 + 2 l16 -- the sample pair and, for the
     // pre-emphasis, the sample before it -- as ONE 12-byte load per group whose three result registers are consumed as
     // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
@@ -627,12 +635,25 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         }
     };
     float3u ra[NG], rb[NG];
-    if (wave < nquads) load_quad(wave, ra);
-    for (int q = wave; q < nquads; q += 2 * FBT_WAVES) {
+    if (qbeg + wave < nquads) load_quad(qbeg + wave, ra);
+    for (int q = qbeg + wave; q < nquads; q += 2 * FBT_WAVES) {
         process_quad(q, ra, rb);
         if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, rb, ra);
     }
 
+    if (a.nchunks > 1) {  // uniform: this chunk's column sums; mean, mask and zero rows belong to fbank_cmn_finish_kernel
+        __syncthreads();
+        if (own0) colsum[wave * 128 + m0] = csum0;
+        if (own1) colsum[wave * 128 + m1] = csum1;
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < FBT_WAVES; ++w) v += colsum[w * 128 + tid];
+            a.part[((int64_t)b * a.nchunks + chunk) * 128 + tid] = tid < nbins ? v : 0.0f;
+        }
+        return;
+    }
     const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;
     if (!second_pass && tile_rows == 0) return;
 
@@ -673,9 +694,33 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     }
 }
 
+// second launch of the chunked form: feat[b, t, :] = t < mask_len ? raw - mean : 0 with mean = sum of the chunks' column sums / T (featurizer.py:79,
+// 119-132); one thread per (row, group of 4 bins), grid-stride
+__global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const float* part, const float* lens_ratio, int B, int T, int nbins,
+                                                               int nchunks, int cmn) {
+    const int qn = nbins >> 2;
+    const int64_t total = (int64_t)B * T * qn;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / qn;
+        const int cg = (int)(i - row * qn);
+        const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+        float4v m4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if (cmn) {
+            for (int c = 0; c < nchunks; ++c) m4 += *reinterpret_cast<const float4v*>(part + ((int64_t)b * nchunks + c) * 128 + 4 * cg);
+            m4 = m4 / (float)T;
+        }
+        int mask_len = T;
+        if (lens_ratio != nullptr) mask_len = (int)rintf(lens_ratio[b] * (float)T);  // round half to even
+        float4v* p = reinterpret_cast<float4v*>(out + row * nbins) + cg;
+        *p = t < mask_len ? *p - m4 : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+}
+
 }  // namespace mv
 
 // ------------------------------------------------------------------------------------------ host side
+
+constexpr int FB_MAX_CHUNK_WGS = 4096;   // (utterance, chunk) workgroups the chunked long-utterance form may use (2 MB of column sums)
 
 struct MvFbank {
     MvFbankCfg cfg;
@@ -685,6 +730,7 @@ struct MvFbank {
     float* d_tw256 = nullptr;
     float* d_tw512 = nullptr;
     float* d_melb = nullptr;
+    float* d_part = nullptr;   // column sums of the chunked long-utterance form: [FB_MAX_CHUNK_WGS][128]
     mv::FbankTables tab;
     size_t smem_bytes = 0;
     int waves = 15;  // fbank_kernel: workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
@@ -869,6 +915,13 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         mv_fbank_destroy(h);
         return rc;
     }
+    {
+        std::vector<float> zeros((size_t)FB_MAX_CHUNK_WGS * 128, 0.0f);
+        if ((rc = upload(zeros, &h->d_part))) {
+            mv_fbank_destroy(h);
+            return rc;
+        }
+    }
     tab.window = h->d_window;
     tab.window_half = h->d_window_half;
     tab.tw256 = h->d_tw256;
@@ -910,6 +963,7 @@ int mv_fbank_destroy(MvFbank* h) {
     hipFree(h->d_tw256);
     hipFree(h->d_tw512);
     hipFree(h->d_melb);
+    hipFree(h->d_part);
     delete h;
     return MV_OK;
 }
@@ -970,6 +1024,9 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.cmn = h->cfg.subtract_time_mean;
     a.L = L;
     a.tile_rows = 0;
+    a.nchunks = 1;
+    a.chunk_quads = (int)((T + 3) >> 2);
+    a.part = nullptr;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
     const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
@@ -980,7 +1037,28 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
         const int64_t fit = (int64_t)((160 * 1024 - fixed) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
         const int64_t need = (T + 3) & ~(int64_t)3;
         a.tile_rows = (int)(fit < need ? fit : need);
-        fbank_tile_launch(B, fixed + (size_t)a.tile_rows * h->nbins * sizeof(float), static_cast<hipStream_t>(stream), a, vec2);
+        // Utterances longer than the LDS block on a chip the batch does not fill (one workgroup per utterance: 128 x 6 s leave half of the CUs idle,
+        // one 30 s utterance all but one): chunks of `fit` frames, one workgroup each, + the finish pass.  MV_FBANK_CHUNK=0: always one workgroup.
+        static int cus = -1;
+        if (cus < 0) cus = mv::device_cu_count();
+        const char* chunk_env = getenv("MV_FBANK_CHUNK");   // (read per call: an A/B knob)
+        const bool chunk_on = !(chunk_env != nullptr && chunk_env[0] == '0');
+        const int64_t nchunks = (need + fit - 1) / fit;
+        if (chunk_on && num_samples == nullptr && nchunks > 1 && B < cus && (int64_t)B * nchunks <= FB_MAX_CHUNK_WGS && h->nbins % 4 == 0) {
+            a.nchunks = (int)nchunks;
+            a.chunk_quads = (int)(fit / 4);
+            a.tile_rows = 0;
+            a.part = h->d_part;
+            fbank_tile_launch(B * (int)nchunks, fixed, static_cast<hipStream_t>(stream), a, vec2);
+            const int64_t total = (int64_t)B * T * (h->nbins / 4);
+            const int grid = (int)(mv::ceil_div(total, 256) < 4096 ? mv::ceil_div(total, 256) : 4096);
+            if (a.cmn || lens_ratio != nullptr) {
+                MV_LAUNCH(mv::fbank_cmn_finish_kernel, (grid, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), out, h->d_part, lens_ratio, B, (int)T,
+                          h->nbins, (int)nchunks, a.cmn);
+            }
+        } else {
+            fbank_tile_launch(B, fixed + (size_t)a.tile_rows * h->nbins * sizeof(float), static_cast<hipStream_t>(stream), a, vec2);
+        }
     } else {
         fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
     }
