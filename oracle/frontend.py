@@ -112,6 +112,67 @@ def kaldi_fbank(waveform, **kwargs):
     return mel
 
 
+def kaldi_fbank_f64(waveform, **kwargs):
+    """fp64 ARBITER of kaldi_fbank: the same steps on the same fp32 samples with every intermediate (window, filterbank, DC removal,
+    pre-emphasis, FFT, power, mel sums, log) in float64.  Neither torchaudio nor the kernel computes this; it says which of two fp32
+    evaluations that disagree on a near-floor log energy is the closer one (tests: |HIP - f64| against |oracle32 - f64|)."""
+    a = dict(FBANK_DEFAULTS)
+    a.update(kwargs)
+    w = torch.as_tensor(waveform, dtype=torch.float32)
+    if w.dim() == 2:
+        w = w[max(a['channel'], 0)]
+    w = w.double()
+    sf = a['sample_frequency']
+    shift = int(sf * a['frame_shift'] * 0.001)
+    size = int(sf * a['frame_length'] * 0.001)
+    padded = _next_pow2(size) if a['round_to_power_of_two'] else size
+    L = w.shape[0]
+    nbins = a['num_mel_bins']
+    if L < a['min_duration'] * sf or L < size:
+        return torch.empty(0, nbins, dtype=torch.float64)
+    m = 1 + (L - size) // shift
+    frames = w.as_strided((m, size), (shift, 1)).clone()
+    if a['remove_dc_offset']:
+        frames = frames - frames.mean(dim=1, keepdim=True)
+    pc = a['preemphasis_coefficient']
+    if pc != 0.0:
+        prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)
+        frames = frames - pc * prev
+    frames = frames * torch.hann_window(size, periodic=False, dtype=torch.float64).pow(0.85).unsqueeze(0)
+    if padded != size:
+        frames = F.pad(frames, (0, padded - size))
+    spec = torch.fft.rfft(frames).abs()
+    if a['use_power']:
+        spec = spec.pow(2.0)
+    num_fft_bins = padded // 2
+    nyquist = 0.5 * sf
+    high = a['high_freq'] + nyquist if a['high_freq'] <= 0.0 else a['high_freq']
+    mel_lo = 1127.0 * math.log(1.0 + a['low_freq'] / 700.0)
+    mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
+    delta = (mel_hi - mel_lo) / (nbins + 1)
+    b = torch.arange(nbins, dtype=torch.float64).unsqueeze(1)
+    left, center, right = mel_lo + b * delta, mel_lo + (b + 1.0) * delta, mel_lo + (b + 2.0) * delta
+    mel_f = (1127.0 * (1.0 + ((sf / padded) * torch.arange(num_fft_bins, dtype=torch.float64)) / 700.0).log()).unsqueeze(0)
+    banks = torch.clamp(torch.min((mel_f - left) / (center - left), (right - mel_f) / (right - center)), min=0.0)
+    banks = F.pad(banks, (0, 1))
+    mel = torch.mm(spec, banks.T)
+    if a['use_log_fbank']:
+        mel = torch.clamp(mel, min=EPS_F32).log()
+    return mel
+
+
+def audio_featurizer_fbank_f64(waveforms, input_lens_ratio=None, method_args=None):
+    """AudioFeaturizer.forward (Fbank) on the fp64 arbiter: [B, L] fp32 -> [B, T, F] fp64, time mean subtracted in fp64, the same mask."""
+    feats = torch.stack([kaldi_fbank_f64(w, **dict(method_args or {})) for w in torch.as_tensor(waveforms, dtype=torch.float32)])
+    feats = feats - feats.mean(1, keepdim=True)
+    if input_lens_ratio is not None:
+        ratio = torch.as_tensor(input_lens_ratio, dtype=torch.float32)
+        mask_lens = torch.round(ratio * feats.shape[1]).long().unsqueeze(1)
+        mask = (torch.arange(feats.shape[1]).repeat(feats.shape[0], 1) < mask_lens).unsqueeze(-1)
+        feats = torch.where(mask, feats, torch.zeros_like(feats))
+    return feats
+
+
 def htk_mel_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
     """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)

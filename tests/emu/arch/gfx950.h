@@ -180,5 +180,8 @@ inline void mfma_hazard_pad() {}
 inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }
 
 inline int device_cu_count() { return 8; }
+struct DeviceOnce { bool flag = false; };
+inline bool device_once_pending(DeviceOnce& o, int* slot) { *slot = 0; return !o.flag; }
+inline void device_once_done(DeviceOnce& o, int) { o.flag = true; }
 
 }  // namespace mv

@@ -593,9 +593,16 @@ def fbank_case(cdll, device, wav, ratio, method_args):
     ref = frontend.audio_featurizer(wav, ratio, 'Fbank', method_args)
     assert out.shape == ref.shape
     d = (out - ref).abs()
-    # near the log floor both fp32 implementations carry ~3e-4 of noise against an fp64 evaluation
+    # Two fp32 evaluations of a near-floor log energy (a small difference of fp32 spectra) differ by more than either differs from the exact
+    # value, so the STATED bar (SURVEY 8(c) / BASELINE.md 3: max-abs <= 1e-3) is asserted against the fp64 arbiter of the same algorithm, next
+    # to the fp32 oracle's own distance from it; kernel vs fp32 oracle keeps the looser 2e-3.
     assert d.max().item() < 2e-3, d.max().item()
     assert d.mean().item() < 2e-5, d.mean().item()
+    if wav.numel() and out.numel():
+        ref64 = frontend.audio_featurizer_fbank_f64(wav, ratio, method_args)
+        e_hip, e_o32 = (out.double() - ref64).abs(), (ref.double() - ref64).abs()
+        assert e_hip.max().item() <= 1e-3, (e_hip.max().item(), e_o32.max().item())
+        assert e_hip.mean().item() <= 1e-5, e_hip.mean().item()
     return d.max().item()
 
 

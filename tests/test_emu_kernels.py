@@ -296,12 +296,23 @@ def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypat
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB)
 
 
-def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms(monkeypatch):
-    """utterances beyond the LDS block on a chip the batch does not fill: chunks of 288 frames, one workgroup each, + the finish pass (default);
-    MV_FBANK_CHUNK=0 keeps one workgroup per utterance.  Both against the oracle (1000 frames = 4 chunks; ragged lengths through the ratio mask)."""
+def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms():
+    """utterances beyond the LDS block on a chip the batch does not fill: several workgroups per utterance + the finish pass (caller workspace);
+    without a workspace one workgroup per utterance.  Both against the oracle (1000 frames = 4 chunks; ragged lengths through the ratio mask) and
+    BIT-IDENTICAL to each other and across batch sizes: an utterance's time sum is formed in an order that depends on its own length only."""
     wav = frontend.synth_waveforms(3, 400 + 160 * 999, seed=31)
     ratio = torch.tensor([0.41, 1.0, 0.77])
     lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1], None, FB)
-    monkeypatch.setenv('MV_FBANK_CHUNK', '0')
-    lc.fbank_case(emu_cdll(), 'cpu', wav[:2], ratio[:2], FB)
+    fb = _hip.Fbank(FB, cdll=emu_cdll())
+    chunked = fb(wav, ratio)
+    single = fb(wav, ratio, workspace=False)
+    assert torch.equal(chunked, single)
+    assert torch.equal(fb(wav[1:2], ratio[1:2]), chunked[1:2]) and torch.equal(fb(wav[2:3], ratio[2:3], workspace=False), chunked[2:3])
+    # 3 s utterances (298 frames = 2 chunks of 152 + 146 frames): the ordinary sub-chip batch
+    wav3 = frontend.synth_waveforms(9, 48000, seed=32)   # the emulator's chip has 8 CUs: 9 rows take the one-workgroup form, fewer the chunk form
+    full = fb(wav3)
+    for nb in (1, 2, 5):
+        assert torch.equal(fb(wav3[:nb]), full[:nb])
+    nsamp = torch.tensor([48000, 48000, 48000])
+    assert torch.equal(fb(wav3[:3], num_samples=nsamp), fb(wav3[:3], torch.ones(3), workspace=False))   # the variable-length entry sums the same way

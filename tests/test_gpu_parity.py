@@ -94,9 +94,10 @@ def test_gpu_time_stats(unbiased, eps):
     lc.time_stats_case(product_lib(), DEV, B=7, T=298, C=3072, ld=3072, unbiased=unbiased, eps=eps, seed=2)
 
 
-def test_gpu_fbank_long_utterances_chunked_and_single_workgroup_forms(monkeypatch):
-    """utterances beyond the LDS block with fewer utterances than CUs: chunks of 288 frames + the finish pass (default), MV_FBANK_CHUNK=0 = one
-    workgroup per utterance; 10 s x 3 with ragged lengths, 30 s x 1, and 128 x 6 s (half a chip of utterances) against the oracle / each other"""
+def test_gpu_fbank_long_utterances_chunked_and_single_workgroup_forms():
+    """utterances beyond the LDS block with fewer utterances than CUs: several workgroups per utterance + the finish pass (caller workspace), or one
+    workgroup per utterance (no workspace); 10 s x 3 with ragged lengths, 30 s x 1, and 128 x 6 s (half a chip of utterances) against the oracle and
+    BIT-IDENTICAL to each other (the time sum of an utterance is formed in an order fixed by its own length, csrc/fbank.hip FbankArgs)"""
     from mvector import _hip
     FB = dict(sample_frequency=16000, num_mel_bins=80)
     wav = frontend.synth_waveforms(3, 400 + 160 * 999, seed=31)
@@ -106,10 +107,54 @@ def test_gpu_fbank_long_utterances_chunked_and_single_workgroup_forms(monkeypatc
     big = (0.1 * torch.randn(128, 96000, generator=torch.Generator().manual_seed(33))).to(DEV)
     fb = _hip.Fbank(FB)
     a = fb(big)
-    monkeypatch.setenv('MV_FBANK_CHUNK', '0')
-    lc.fbank_case(product_lib(), DEV, wav, ratio, FB)
-    b = fb(big)
-    assert (a - b).abs().max().item() < 2e-4   # (the time mean is summed in a different order)
+    b = fb(big, workspace=False)
+    assert torch.equal(a, b)
+    w, r = wav.to(DEV), ratio.to(DEV)
+    assert torch.equal(fb(w, r), fb(w, r, workspace=False))
+
+
+def test_gpu_fbank_row_bits_do_not_depend_on_the_batch_size():
+    """featurizer.py:125-130 computes every row on its own: row i of a batch must carry the same bits at B = 1 / 32 / 128 / 256 (the forms the
+    launcher picks by batch size -- one workgroup per utterance on a full chip, two per 3 s utterance below -- sum the time mean in one order)"""
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    wav = frontend.synth_waveforms(256, 48000, seed=5).to(DEV)
+    full = fb(wav)
+    for nb in (1, 32, 128, 255):
+        assert torch.equal(fb(wav[:nb]), full[:nb]), nb
+        assert torch.equal(fb(wav[256 - nb:]), full[256 - nb:]), nb
+    ratio = torch.linspace(0.3, 1.0, 256).to(DEV)
+    fullr = fb(wav, ratio)
+    for nb in (1, 32, 128):
+        assert torch.equal(fb(wav[:nb], ratio[:nb]), fullr[:nb]), nb
+    nsamp = torch.full((32,), 48000, dtype=torch.int64, device=DEV)
+    assert torch.equal(fb(wav[:32], num_samples=nsamp), full[:32])   # the variable-length entry point too
+    long = frontend.synth_waveforms(40, 400 + 160 * 700, seed=6).to(DEV)   # 7 s: three chunks
+    fl = fb(long)
+    for nb in (1, 7):
+        assert torch.equal(fb(long[:nb]), fl[:nb]), nb
+
+
+def test_gpu_fbank_one_handle_two_streams_is_reentrant():
+    """include/mvector_hip.h: handles are immutable after create -- ONE Fbank handle driven from two streams at once (sub-chip batches of 3 s
+    utterances: the several-workgroups form with its per-call scratch) gives, 100 times over, the bits of the serial run"""
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    wa = frontend.synth_waveforms(32, 48000, seed=11).to(DEV)
+    wb = frontend.synth_waveforms(48, 48000 + 160 * 300, seed=12).to(DEV)
+    ra, rb = fb(wa).clone(), fb(wb).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for it in range(100):
+        with torch.cuda.stream(s1):
+            oa = fb(wa)
+        with torch.cuda.stream(s2):
+            ob = fb(wb)
+        s1.synchronize()
+        s2.synchronize()
+        bad += int(not torch.equal(oa, ra)) + int(not torch.equal(ob, rb))
+    assert bad == 0, bad
 
 
 def test_gpu_bn_relu_rows():
@@ -206,8 +251,17 @@ def test_gpu_fbank_full_batch_properties():
     assert torch.equal(fb(wav[perm]), out[perm])             # utterances are independent
     ref = frontend.audio_featurizer(wav.cpu(), None, 'Fbank', FB)
     err = (out.cpu() - ref).abs()
-    # 6.1 M log energies: mean error 1e-6; the 2e-3 bar of the small cases is crossed by a handful of near-floor bins (a log energy
-    # that is a small difference of fp32 spectra: r07a measured a maximum of 2.5e-3), so the full batch asserts the distribution
+    # 6.1 M log energies.  The stated bar is max-abs <= 1e-3.  Against the fp64 ARBITER of the same algorithm
+    # (oracle.frontend.kaldi_fbank_f64) the kernel meets it; the torch-fp32 oracle itself sits 1.12e-3 from the arbiter on this batch (two
+    # near-floor bins above 1e-3), which is why kernel-vs-fp32-oracle (two fp32 evaluations of a small difference of fp32 spectra) shows
+    # up to 2.5e-3 on a handful of bins: that distance is asserted as a distribution only.
+    ref64 = frontend.audio_featurizer_fbank_f64(wav.cpu(), None, FB)
+    e_hip, e_o32 = (out.cpu().double() - ref64).abs(), (ref.double() - ref64).abs()
+    print(f'fbank 256 x 3 s: |HIP - f64| max {e_hip.max().item():.3e} mean {e_hip.mean().item():.3e} n>1e-3 {int((e_hip > 1e-3).sum())}; '
+          f'|oracle32 - f64| max {e_o32.max().item():.3e} mean {e_o32.mean().item():.3e} n>1e-3 {int((e_o32 > 1e-3).sum())}; '
+          f'|HIP - oracle32| max {err.max().item():.3e} mean {err.mean().item():.3e} n>2e-3 {int((err > 2e-3).sum())}')
+    assert e_hip.max().item() <= 1e-3, e_hip.max().item()
+    assert e_hip.mean().item() <= 1e-5
     assert err.mean().item() < 2e-5 and (err > 2e-3).float().mean().item() < 1e-5 and err.max().item() < 5e-3, (err.mean().item(), err.max().item())
 
 

@@ -47,6 +47,22 @@ def test_oracle_fbank_matches_hf_kaldi_port():
         assert d.max() < 3e-4 and d.mean() < 1e-5, (d.max(), d.mean())
 
 
+def test_oracle_fbank_fp64_arbiter_brackets_the_fp32_oracle():
+    """oracle.frontend.kaldi_fbank_f64 = the same algorithm in float64 (the arbiter of the GPU tests).  The torch-fp32 oracle is within
+    1.2e-3 of it on BASELINE-style input with a mean distance of 3e-6: the noise of near-floor log energies in fp32, the reason why the
+    1e-3 bar of SURVEY 8(c) is asserted against the arbiter and not between two fp32 evaluations."""
+    wav = frontend.synth_waveforms(48, 48000)
+    ratio = torch.linspace(0.5, 1.0, 48)
+    ref32 = frontend.audio_featurizer(wav, ratio, 'Fbank', FB)
+    ref64 = frontend.audio_featurizer_fbank_f64(wav, ratio, FB)
+    assert ref64.dtype == torch.float64 and ref64.shape == ref32.shape
+    d = (ref32.double() - ref64).abs()
+    assert d.max().item() < 1.2e-3 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    assert torch.equal(ref64 == 0, ref32 == 0) or ((ref64 == 0) != (ref32 == 0)).sum().item() < 4   # the same rows are masked
+    raw = frontend.kaldi_fbank_f64(wav[0], **FB)
+    assert raw.shape == (298, 80) and frontend.kaldi_fbank_f64(torch.zeros(100), **FB).shape == (0, 80)
+
+
 def test_oracle_melspec_filterbank_matches_hf():
     from transformers.audio_utils import mel_filter_bank
     with warnings.catch_warnings():

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -458,11 +459,41 @@ __device__ __forceinline__ void glds16_untracked_so_fresh(const void* sbase, uns
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_base_addr) : "memory", "m0");
 }
 
-// compute units of the current device (persistent kernels launch one workgroup per CU)
-inline int device_cu_count() {
+// index of the current device, clamped to the per-device tables below
+constexpr int MV_MAX_DEVICES = 64;
+inline int current_device_slot() {
     int dev = 0;
-    hipDeviceProp_t prop;
-    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < MV_MAX_DEVICES ? dev : MV_MAX_DEVICES - 1;
 }
+
+// compute units of the current device (persistent kernels launch one workgroup per CU); cached per device -- one process may drive several GPUs
+inline int device_cu_count() {
+    static std::atomic<int> cache[MV_MAX_DEVICES];
+    const int slot = current_device_slot();
+    int n = cache[slot].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cache[slot].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// "done once per device" flag for per-device function attributes (hipFuncSetAttribute of the dynamic LDS size applies to the current device's
+// code object): `static DeviceOnce once; if (once.first()) { ...set attributes...; once.done(); }`.  Two threads racing through the
+// first launch both set the attribute -- harmless.
+struct DeviceOnce {
+    std::atomic<bool> flag[MV_MAX_DEVICES];
+    int slot = 0;
+    DeviceOnce() {
+        for (auto& f : flag) f.store(false, std::memory_order_relaxed);
+    }
+};
+inline bool device_once_pending(DeviceOnce& o, int* slot) {
+    *slot = current_device_slot();
+    return !o.flag[*slot].load(std::memory_order_acquire);
+}
+inline void device_once_done(DeviceOnce& o, int slot) { o.flag[slot].store(true, std::memory_order_release); }
 
 }  // namespace mv

@@ -577,10 +577,11 @@ int cam_dense_block_launch(half_t* x, int64_t ldx, int B, int T2, const MvCamLay
     MV_REQUIRE(T2 >= 1 && T2 <= CB_ROWS && dil >= 1 && dil <= 2 && seg_len > 0 && (T2 + seg_len - 1) / seg_len <= CB_MAX_SEG,
                "cam_dense_block: unsupported geometry");
     MV_REQUIRE((ldx % 8) == 0, "cam_dense_block: rows must be 16-byte aligned");
-    static bool smem_set = false;
-    if (!smem_set) {
+    static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
+    int smem_set_slot;
+    if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM(cam_dense_block_kernel, CB_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_block: cannot reserve LDS");
-        smem_set = true;
+        device_once_done(smem_set, smem_set_slot);
     }
     CamBlockArgs a;
     a.x = x;

@@ -394,10 +394,11 @@ int cam_dense_layer_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const
                            const float* bb, int dil, int seg_len, hipStream_t stream) {
     MV_REQUIRE(cam_dense_layer_supported(T2, cin, CD_BN, CD_G, dil, seg_len), "cam_dense_layer: unsupported geometry");
     MV_REQUIRE(ldx >= cin + CD_G && (ldx % 8) == 0, "cam_dense_layer: the row must hold the inputs and 32 new channels (16-byte aligned chunks)");
-    static bool smem_set = false;
-    if (!smem_set) {
+    static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
+    int smem_set_slot;
+    if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM(cam_dense_layer_kernel, CD_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_layer: cannot reserve LDS");
-        smem_set = true;
+        device_once_done(smem_set, smem_set_slot);
     }
     CamDenseArgs a;
     a.x = x; a.ldx = ldx; a.w1 = w1; a.bn1_s = bn1_s; a.bn1_t = bn1_t; a.bn2_s = bn2_s; a.bn2_t = bn2_t; a.wl = wl;
@@ -822,10 +823,11 @@ int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const 
     MV_REQUIRE(cam_dense_long_supported(T2, cin, CD_BN, CD_G, dil, seg_len), "cam_dense_long: unsupported geometry");
     MV_REQUIRE(ldx >= cin + CD_G && (ldx % 8) == 0, "cam_dense_long: the row must hold the inputs and 32 new channels (16-byte aligned chunks)");
     MV_REQUIRE(hws != nullptr && hpart != nullptr && (reinterpret_cast<uintptr_t>(hws) & 15) == 0, "cam_dense_long: workspace");
-    static bool smem_set = false;
-    if (!smem_set) {
+    static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
+    int smem_set_slot;
+    if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM(cam_dense_long_gemm_kernel, CD_LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "cam_dense_long: cannot reserve LDS");
-        smem_set = true;
+        device_once_done(smem_set, smem_set_slot);
     }
     CamLongArgs a;
     a.x = x; a.ldx = ldx; a.w1 = w1; a.bn1_s = bn1_s; a.bn1_t = bn1_t; a.bn2_s = bn2_s; a.bn2_t = bn2_t; a.wl = wl;
@@ -835,8 +837,7 @@ int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const 
     // a workgroup's time ~ 0.45 + 0.55 * rows / 160 of a full one (r10s: the per-stage cost is mostly fixed), so 76 utterances x 4 chunks of 125 rows
     // (304 workgroups: a second round for 48 of them) lose to 6 chunks of 96 (456: two rounds of cheaper workgroups).
     {
-        static int cus = -1;
-        if (cus < 0) cus = device_cu_count();
+        const int cus = device_cu_count();
         const int nmin = (int)ceil_div(T2, CD_ROWS);
         double best = 0.0;
         a.nchunks = nmin;

@@ -1430,9 +1430,7 @@ static int conv_store_policy(int64_t k_total) {
 }
 
 static int cu_count() {
-    static int n = -1;
-    if (n < 0) n = device_cu_count();
-    return n;
+    return device_cu_count();   // (cached per device)
 }
 
 // Resident workgroups of the persistent kernel: one per CU (a multiple of 8 keeps  id mod 8 == XCD  across the walk).
@@ -1595,8 +1593,9 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.co_tiles = (int)ceil_div(d.cout, tc);
     a.store_nt = conv_store_policy((int64_t)d.k * a.cin_pad);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
-    static bool smem_set = false;
-    if (!smem_set) {
+    static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
+    int smem_set_slot;
+    if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
@@ -1610,7 +1609,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, true, false>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_mfma_kernel<half_t, false, true>), CV_LDS_BYTES) != hipSuccess)
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
-        smem_set = true;
+        device_once_done(smem_set, smem_set_slot);
     }
     const int prof = prof_begin(MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
     if (persist) {

@@ -347,15 +347,16 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const dim3 grid((unsigned)(stiles * ctiles), (unsigned)d.B, 1);
     MV_REQUIRE(d.B <= 65535, "conv2d: batch too large for one launch");
     const size_t lds = conv2d_lds_bytes(stride_w);
-    static bool smem_set = false;
-    if (!smem_set) {
+    static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
+    int smem_set_slot;
+    if (device_once_pending(smem_set, &smem_set_slot)) {
         const int big = (int)conv2d_lds_bytes(2);
         if (MV_SET_MAX_SMEM(conv2d_kernel<1>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<2>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<3>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<4>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<5>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<6>, big) != hipSuccess ||
             MV_SET_MAX_SMEM(conv2d_kernel<7>, big) != hipSuccess || MV_SET_MAX_SMEM(conv2d_kernel<8>, big) != hipSuccess)
             return fail(MV_ERR_HIP, "conv2d: cannot reserve dynamic LDS");
-        smem_set = true;
+        device_once_done(smem_set, smem_set_slot);
     }
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * a.Ho * a.Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
                                                 (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);

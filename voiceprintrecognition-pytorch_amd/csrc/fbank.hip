@@ -67,10 +67,13 @@ struct FbankArgs {
     int64_t L;
     int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
                       // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
-    // fbank_tile_kernel, long utterances on a chip the batch does not fill: nchunks workgroups per utterance, chunk c takes the quads (4 frames)
-    // [c * chunk_quads, (c + 1) * chunk_quads), writes its raw rows and its column sums (part: [B, nchunks, 128]); fbank_cmn_finish_kernel
-    // subtracts the mean and applies the mask afterwards.  nchunks = 1: one workgroup per utterance, everything in one launch.
-    int nchunks, chunk_quads;
+    // fbank_tile_kernel: the time sum of an utterance is DEFINED chunk-wise, whatever the launch form (so that a row's bits depend on its
+    // own length only, never on the batch size): its quads (4 frames) are cut into nch = ceil(nquads / fit_quads) chunks of
+    // cq = ceil(nquads / nch) quads; inside a chunk wave w sums the quads c * cq + w + 8 k in order of k, its running sum takes the chunk
+    // sums in order of c, the utterance's sum is the sum over w = 0..7 in order.  chunked = 0: one workgroup per utterance walks all
+    // chunks; chunked = 1: grid = B * nch workgroups, workgroup (b, c) writes its raw rows and the eight per-wave sums of its chunk to
+    // part[b][c][w][128] (caller workspace), fbank_cmn_finish_kernel forms the same sums in the same order, subtracts and masks.
+    int fit_quads, chunked, nchunks;
     float* part;
     FbankTables tab;
 };
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int wave = tid >> 6;
     const int l16 = lane & 15;
     const int fs = lane >> 4;
-    const int b = a.nchunks > 1 ? (int)blockIdx.x / a.nchunks : (int)blockIdx.x;
-    const int chunk = a.nchunks > 1 ? (int)blockIdx.x - b * a.nchunks : 0;
+    const int b = a.chunked ? (int)blockIdx.x / a.nchunks : (int)blockIdx.x;
+    const int chunk = a.chunked ? (int)blockIdx.x - b * a.nchunks : 0;
     const int Tout = a.T;
     int T = a.T;
     if (a.num_samples != nullptr) {
@@ -443,13 +446,15 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int m0 = 4 * (a.tab.pass_gbase[0] + blk) + (lane & 3);                // pass 0: one block per filter group
     const int m1 = 4 * (a.tab.pass_gbase[1] + blk / split1) + (lane & 3);
     const bool own0 = m0 < nbins, own1 = m1 < nbins && (blk & (split1 - 1)) == 0;
-    float csum0 = 0.0f, csum1 = 0.0f;
+    float csum0 = 0.0f, csum1 = 0.0f;   // this wave's sums over its quads of the current chunk
+    float run0 = 0.0f, run1 = 0.0f;     // ... and over the chunks it has finished (FbankArgs: the chunk-wise definition of the time sum)
     const int tile_rows = a.tile_rows;
 
     __syncthreads();  // window taps
     const int nquads_all = (T + 3) >> 2;
-    const int qbeg = chunk * a.chunk_quads;                                        // (nchunks = 1: chunk_quads covers the utterance)
-    const int nquads = qbeg + a.chunk_quads < nquads_all ? qbeg + a.chunk_quads : nquads_all;   // end of this workgroup's quads
+    const int nch = nquads_all > a.fit_quads ? (nquads_all + a.fit_quads - 1) / a.fit_quads : 1;   // chunks of THIS utterance (own length)
+    const int cq = (nquads_all + nch - 1) / nch;                                                   // quads per chunk
+    const int c_end = a.chunked ? chunk + 1 : nch;                                                  // this workgroup's chunks: [chunk, c_end)
     // samples of one quad: lane holds {x[j-1], x[j], x[j+1]} at j = 32 n1 + 2 l16 -- the sample pair and, for the
     // pre-emphasis, the sample before it -- as ONE 12-byte load per group whose three result registers are consumed as
     // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
@@ -468,19 +473,18 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             // frame), their surplus taps are zeroed when the group is consumed
             int j = idx;
             if (!full) j = idx < a.win ? idx : a.win - 2;
-            if (n1 == 0) {
-                const int jp = j > 0 ? j - 1 : 0;
-                r[n1] = float3u{fp[jp], fp[j], fp[j + 1]};
-            } else {
-                r[n1] = *reinterpret_cast<const float3u*>(fp + j - 1);
-            }
+            // first group, lane 0: x[-1] := x[0] (replicate) -- it loads {x[0], x[1], x[2]} and picks its pair when the group is consumed
+            // (one 12-byte load like every other lane: a lane-dependent {x[0], x[0], x[1]} assembled from two loads made the compiler copy
+            // the components out right behind the prefetch, i.e. wait for it)
+            const int jl = (n1 == 0 && j == 0) ? 1 : j;
+            r[n1] = *reinterpret_cast<const float3u*>(fp + jl - 1);
         }
     };
     // The next quad's samples are requested as soon as this quad's have been consumed (window stage): their HBM latency runs
     // under the two FFTs, the post-processing and the mel stage instead of stalling the top of every iteration (two waves
     // per SIMD cannot hide it: PMC r03b, waves 61 % parked with the VALU 30 % busy).  Two register sets used alternately --
     // the loop below is unrolled by two -- so the prefetched values are consumed where the loads put them.
-    auto process_quad = [&](int q, float3u (&r)[NG], float3u (&r_next)[NG]) __attribute__((always_inline)) {
+    auto process_quad = [&](int q, float3u (&r)[NG], float3u (&r_next)[NG], int q_next, bool has_next) __attribute__((always_inline)) {
         float x0[NG], x1[NG];
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
@@ -488,6 +492,10 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
             x0[n1] = full || idx < a.win ? r[n1][1] : 0.0f;
             x1[n1] = full || idx + 1 < a.win ? r[n1][2] : 0.0f;
+        }
+        if (l16 == 0) {  // (see load_quad: lane 0 of a frame row holds {x[0], x[1], x[2]} in its first group)
+            x1[0] = r[0][1];
+            x0[0] = r[0][0];
         }
         // ---- DC removal, pre-emphasis, window (see fbank_kernel) ----
         float dc = 0.0f;
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         }
 #pragma unroll
         for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
-        if (q + FBT_WAVES < nquads) load_quad(q + FBT_WAVES, r_next);
+        if (has_next) load_quad(q_next, r_next);
         // ---- stage 1 + twiddle ----
         fft16(z);
 #pragma unroll
@@ -634,24 +642,56 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             }
         }
     };
+    // this wave's quads, chunk by chunk (wave-uniform bookkeeping): q = c * cq + wave + 8 k below the chunk's end
+    int c = chunk, q = -1, qe = 0;
+    auto enter_chunk = [&]() {  // first quad of this wave in chunk c or a later one; false when the workgroup's chunks are used up
+        for (; c < c_end; ++c) {
+            q = c * cq + wave;
+            qe = (c + 1) * cq < nquads_all ? (c + 1) * cq : nquads_all;
+            if (q < qe) return true;
+        }
+        return false;
+    };
+    auto advance = [&](bool& crossed) {  // next quad of this wave; crossed = the chunk (or the walk) ended behind the current quad
+        crossed = false;
+        if (q + FBT_WAVES < qe) {
+            q += FBT_WAVES;
+            return true;
+        }
+        crossed = true;
+        ++c;
+        return enter_chunk();
+    };
     float3u ra[NG], rb[NG];
-    if (qbeg + wave < nquads) load_quad(qbeg + wave, ra);
-    for (int q = qbeg + wave; q < nquads; q += 2 * FBT_WAVES) {
-        process_quad(q, ra, rb);
-        if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, rb, ra);
+    bool more = enter_chunk();
+    if (more) load_quad(q, ra);
+    while (more) {
+        int q_cur = q;
+        bool crossed;
+        more = advance(crossed);
+        process_quad(q_cur, ra, rb, q, more);
+        if (crossed) {
+            run0 += csum0;
+            run1 += csum1;
+            csum0 = 0.0f;
+            csum1 = 0.0f;
+        }
+        if (!more) break;
+        q_cur = q;
+        more = advance(crossed);
+        process_quad(q_cur, rb, ra, q, more);
+        if (crossed) {
+            run0 += csum0;
+            run1 += csum1;
+            csum0 = 0.0f;
+            csum1 = 0.0f;
+        }
     }
 
-    if (a.nchunks > 1) {  // uniform: this chunk's column sums; mean, mask and zero rows belong to fbank_cmn_finish_kernel
-        __syncthreads();
-        if (own0) colsum[wave * 128 + m0] = csum0;
-        if (own1) colsum[wave * 128 + m1] = csum1;
-        __syncthreads();
-        if (tid < 128) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < FBT_WAVES; ++w) v += colsum[w * 128 + tid];
-            a.part[((int64_t)b * a.nchunks + chunk) * 128 + tid] = tid < nbins ? v : 0.0f;
-        }
+    if (a.chunked) {  // uniform: this chunk's per-wave column sums; mean, mask and zero rows belong to fbank_cmn_finish_kernel
+        float* pw = a.part + (((int64_t)b * a.nchunks + chunk) * FBT_WAVES + wave) * 128;
+        if (own0) pw[m0] = run0;
+        if (own1) pw[m1] = run1;
         return;
     }
     const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;
@@ -659,8 +699,8 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 
     // ---- per-utterance time mean (featurizer.py:79) ----
     __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
-    if (own0) colsum[wave * 128 + m0] = csum0;   // (lanes that own no filter summed values nobody reads)
-    if (own1) colsum[wave * 128 + m1] = csum1;
+    if (own0) colsum[wave * 128 + m0] = run0;   // (lanes that own no filter summed values nobody reads)
+    if (own1) colsum[wave * 128 + m1] = run1;
     __syncthreads();
     float* mean = colsum + FBT_WAVES * 128;
     if (tid < 128) {
@@ -694,24 +734,37 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     }
 }
 
-// second launch of the chunked form: feat[b, t, :] = t < mask_len ? raw - mean : 0 with mean = sum of the chunks' column sums / T (featurizer.py:79,
-// 119-132); one thread per (row, group of 4 bins), grid-stride
-__global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const float* part, const float* lens_ratio, int B, int T, int nbins,
-                                                               int nchunks, int cmn) {
-    const int qn = nbins >> 2;
-    const int64_t total = (int64_t)B * T * qn;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / qn;
-        const int cg = (int)(i - row * qn);
-        const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
-        float4v m4 = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        if (cmn) {
-            for (int c = 0; c < nchunks; ++c) m4 += *reinterpret_cast<const float4v*>(part + ((int64_t)b * nchunks + c) * 128 + 4 * cg);
-            m4 = m4 / (float)T;
+// second launch of the chunked form: feat[b, t, :] = t < mask_len ? raw - mean : 0 (featurizer.py:79, 119-132) with the time sum formed
+// exactly as the one-workgroup form forms it (FbankArgs): per wave slot the chunk sums in chunk order, then the eight slots in order.
+// Workgroup = (utterance, block of FBF_ROWS rows); one thread per group of 4 bins.
+constexpr int FBF_ROWS = 64;
+__global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const float* part, const float* lens_ratio, int T, int nbins,
+                                                               int nchunks, int row_blocks, int cmn) {
+    __shared__ float mean[128];
+    const int b = (int)blockIdx.x / row_blocks, rb = (int)blockIdx.x - b * row_blocks;
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        float v = 0.0f;
+        if (cmn && tid < nbins) {
+            for (int w = 0; w < FBT_WAVES; ++w) {
+                float run = 0.0f;
+                for (int c = 0; c < nchunks; ++c) run += part[(((int64_t)b * nchunks + c) * FBT_WAVES + w) * 128 + tid];
+                v += run;
+            }
+            v = v / (float)T;
         }
-        int mask_len = T;
-        if (lens_ratio != nullptr) mask_len = (int)rintf(lens_ratio[b] * (float)T);  // round half to even
-        float4v* p = reinterpret_cast<float4v*>(out + row * nbins) + cg;
+        mean[tid] = v;
+    }
+    __syncthreads();
+    int mask_len = T;
+    if (lens_ratio != nullptr) mask_len = (int)rintf(lens_ratio[b] * (float)T);  // round half to even
+    const int qn = nbins >> 2;
+    const int t1 = (rb + 1) * FBF_ROWS < T ? (rb + 1) * FBF_ROWS : T;
+    const int64_t row0 = (int64_t)b * T;
+    for (int i = rb * FBF_ROWS * qn + tid; i < t1 * qn; i += 256) {
+        const int t = i / qn, cg = i - t * qn;
+        const float4v m4 = *reinterpret_cast<const float4v*>(mean + 4 * cg);
+        float4v* p = reinterpret_cast<float4v*>(out + (row0 + t) * nbins) + cg;
         *p = t < mask_len ? *p - m4 : float4v{0.0f, 0.0f, 0.0f, 0.0f};
     }
 }
@@ -719,8 +772,6 @@ __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const
 }  // namespace mv
 
 // ------------------------------------------------------------------------------------------ host side
-
-constexpr int FB_MAX_CHUNK_WGS = 4096;   // (utterance, chunk) workgroups the chunked long-utterance form may use (2 MB of column sums)
 
 struct MvFbank {
     MvFbankCfg cfg;
@@ -730,7 +781,6 @@ struct MvFbank {
     float* d_tw256 = nullptr;
     float* d_tw512 = nullptr;
     float* d_melb = nullptr;
-    float* d_part = nullptr;   // column sums of the chunked long-utterance form: [FB_MAX_CHUNK_WGS][128]
     mv::FbankTables tab;
     size_t smem_bytes = 0;
     int waves = 15;  // fbank_kernel: workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
@@ -915,13 +965,6 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         mv_fbank_destroy(h);
         return rc;
     }
-    {
-        std::vector<float> zeros((size_t)FB_MAX_CHUNK_WGS * 128, 0.0f);
-        if ((rc = upload(zeros, &h->d_part))) {
-            mv_fbank_destroy(h);
-            return rc;
-        }
-    }
     tab.window = h->d_window;
     tab.window_half = h->d_window_half;
     tab.tw256 = h->d_tw256;
@@ -963,7 +1006,6 @@ int mv_fbank_destroy(MvFbank* h) {
     hipFree(h->d_tw256);
     hipFree(h->d_tw512);
     hipFree(h->d_melb);
-    hipFree(h->d_part);
     delete h;
     return MV_OK;
 }
@@ -982,24 +1024,58 @@ int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps) {
     return MV_OK;
 }
 
+// Geometry of one forward.  `fit` = feature rows that fit next to the wave slots in LDS (a multiple of 4); an utterance of more rows is
+// cut into nch chunks (FbankArgs) -- by its own length only, so a row's bits never depend on the batch around it.
+struct FbankPlan {
+    int64_t T = 0, fit = 0, need = 0;
+    int nch = 1;
+    bool chunk_form = false;   // B * nch workgroups + the finish pass (needs the caller's workspace): pays when the batch does not fill the chip
+    size_t workspace_bytes = 0;
+};
+
+static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
+    FbankPlan p;
+    mv_fbank_num_frames(h, L, &p.T);
+    if (!h->tile_kernel || B <= 0 || p.T <= 0) return p;
+    p.fit = (int64_t)((160 * 1024 - fbank_tile_fixed_lds_bytes()) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
+    p.need = (p.T + 3) & ~(int64_t)3;
+    if (p.fit >= 64 && p.need > p.fit) p.nch = (int)((p.need + p.fit - 1) / p.fit);
+    // one workgroup per utterance leaves CUs idle when there are fewer utterances than CUs (one 30 s utterance: all but one)
+    p.chunk_form = p.nch > 1 && B < mv::device_cu_count() && (int64_t)B * p.nch <= 65535 * 16;
+    if (p.chunk_form) p.workspace_bytes = (size_t)B * p.nch * mv::FBT_WAVES * 128 * sizeof(float);
+    return p;
+}
+
 static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
-                              const int64_t* num_samples, float* out, mv_stream_t stream);
+                              const int64_t* num_samples, float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream);
 
 int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                      const float* lens_ratio, float* out, mv_stream_t stream) {
-    return fbank_forward_impl(h, wav, B, L, wav_stride, lens_ratio, nullptr, out, stream);
+    return fbank_forward_impl(h, wav, B, L, wav_stride, lens_ratio, nullptr, out, nullptr, 0, stream);
+}
+
+int mv_fbank_workspace_bytes(const MvFbank* h, int32_t B, int64_t L, size_t* bytes) {
+    MV_REQUIRE(h != nullptr && bytes != nullptr, "mv_fbank_workspace_bytes: null argument");
+    *bytes = fbank_plan(h, B, L).workspace_bytes;
+    return MV_OK;
+}
+
+int mv_fbank_forward_ws(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
+                        float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream) {
+    return fbank_forward_impl(h, wav, B, L, wav_stride, lens_ratio, nullptr, out, workspace, workspace_bytes, stream);
 }
 
 int mv_fbank_forward_varlen(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                             const int64_t* num_samples, float* out, mv_stream_t stream) {
     MV_REQUIRE(num_samples != nullptr, "mv_fbank_forward_varlen: null length array");
-    return fbank_forward_impl(h, wav, B, L, wav_stride, nullptr, num_samples, out, stream);
+    return fbank_forward_impl(h, wav, B, L, wav_stride, nullptr, num_samples, out, nullptr, 0, stream);
 }
 
 static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
-                              const int64_t* num_samples, float* out, mv_stream_t stream) {
+                              const int64_t* num_samples, float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream) {
     MV_REQUIRE(h != nullptr, "mv_fbank_forward: null handle");
     MV_REQUIRE(B >= 0 && L >= 0 && wav_stride >= L, "mv_fbank_forward: bad batch geometry");
+    const FbankPlan plan = fbank_plan(h, B, L);
     int64_t T = 0;
     mv_fbank_num_frames(h, L, &T);
     if (B == 0 || T == 0) return MV_OK;  // empty output, like kaldi.fbank on a too-short input
@@ -1024,39 +1100,33 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.cmn = h->cfg.subtract_time_mean;
     a.L = L;
     a.tile_rows = 0;
+    a.fit_quads = plan.fit >= 64 ? (int)(plan.fit / 4) : 0x3fffffff;
+    a.chunked = 0;
     a.nchunks = 1;
-    a.chunk_quads = (int)((T + 3) >> 2);
     a.part = nullptr;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
     const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
     if (h->tile_kernel) {
-        // feature rows that fit next to the wave slots stay in LDS until the time mean is known (288 of the 298 frames of a
-        // 3 s utterance at 80 bins); the rest go through global memory
         const size_t fixed = fbank_tile_fixed_lds_bytes();
-        const int64_t fit = (int64_t)((160 * 1024 - fixed) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
-        const int64_t need = (T + 3) & ~(int64_t)3;
-        a.tile_rows = (int)(fit < need ? fit : need);
-        // Utterances longer than the LDS block on a chip the batch does not fill (one workgroup per utterance: 128 x 6 s leave half of the CUs idle,
-        // one 30 s utterance all but one): chunks of `fit` frames, one workgroup each, + the finish pass.  MV_FBANK_CHUNK=0: always one workgroup.
-        static int cus = -1;
-        if (cus < 0) cus = mv::device_cu_count();
-        const char* chunk_env = getenv("MV_FBANK_CHUNK");   // (read per call: an A/B knob)
-        const bool chunk_on = !(chunk_env != nullptr && chunk_env[0] == '0');
-        const int64_t nchunks = (need + fit - 1) / fit;
-        if (chunk_on && num_samples == nullptr && nchunks > 1 && B < cus && (int64_t)B * nchunks <= FB_MAX_CHUNK_WGS && h->nbins % 4 == 0) {
-            a.nchunks = (int)nchunks;
-            a.chunk_quads = (int)(fit / 4);
-            a.tile_rows = 0;
-            a.part = h->d_part;
-            fbank_tile_launch(B * (int)nchunks, fixed, static_cast<hipStream_t>(stream), a, vec2);
-            const int64_t total = (int64_t)B * T * (h->nbins / 4);
-            const int grid = (int)(mv::ceil_div(total, 256) < 4096 ? mv::ceil_div(total, 256) : 4096);
+        // The chunk form and the one-workgroup form give the same bits (FbankArgs), so taking it is a matter of time only.  It needs scratch for
+        // the chunks' per-wave sums, which belongs to the CALL, not to the handle: without the caller's workspace (mv_fbank_forward, the
+        // variable-length entry point) every utterance runs on one workgroup.
+        if (plan.chunk_form && num_samples == nullptr && workspace != nullptr && workspace_bytes >= plan.workspace_bytes &&
+            (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+            a.chunked = 1;
+            a.nchunks = plan.nch;
+            a.part = static_cast<float*>(workspace);
+            fbank_tile_launch(B * plan.nch, fixed, static_cast<hipStream_t>(stream), a, vec2);
             if (a.cmn || lens_ratio != nullptr) {
-                MV_LAUNCH(mv::fbank_cmn_finish_kernel, (grid, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), out, h->d_part, lens_ratio, B, (int)T,
-                          h->nbins, (int)nchunks, a.cmn);
+                const int row_blocks = (int)mv::ceil_div(T, mv::FBF_ROWS);
+                MV_LAUNCH(mv::fbank_cmn_finish_kernel, (B * row_blocks, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), out, a.part, lens_ratio,
+                          (int)T, h->nbins, plan.nch, row_blocks, a.cmn);
             }
         } else {
+            // feature rows that fit next to the wave slots stay in LDS until the time mean is known (all 298 frames of a 3 s utterance at
+            // 80 bins fit?  no: `fit` of them); the rest take the write / re-read / rewrite route through global memory
+            a.tile_rows = (int)(plan.fit < plan.need ? plan.fit : plan.need);
             fbank_tile_launch(B, fixed + (size_t)a.tile_rows * h->nbins * sizeof(float), static_cast<hipStream_t>(stream), a, vec2);
         }
     } else {

@@ -431,10 +431,11 @@ int fcm_conv1_launch(const float* feats, half_t* out, const float* w, const floa
 template <int NI, int SF, bool HAS2>
 static int fcm_band_launch_one(const FcmConvArgs& a, int n_ttiles, hipStream_t stream) {
     typedef FcmBand<NI, SF, HAS2> G;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;   // (per device: the attribute belongs to the current device's code object)
+    int attr_set_slot;
+    if (device_once_pending(attr_set, &attr_set_slot)) {
         if (MV_SET_MAX_SMEM((fcm_band_kernel<NI, SF, HAS2>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm band kernel: LDS size rejected");
-        attr_set = true;
+        device_once_done(attr_set, attr_set_slot);
     }
     // one workgroup per CU is resident (LDS): split the output rows into bands only while (utterance, time tile) pairs alone do
     // not fill the chip; every band re-reads its two halo rows

@@ -497,10 +497,11 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
 template <int NT, int SF, bool C1 = false>
 static int fcm_block_launch_one(const FcmBlockArgs& a, int n_ttiles, hipStream_t stream) {
     typedef FcmBlk<NT, SF> G;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;   // (per device: the attribute belongs to the current device's code object)
+    int attr_set_slot;
+    if (device_once_pending(attr_set, &attr_set_slot)) {
         if (MV_SET_MAX_SMEM((fcm_block_kernel<NT, SF, C1>), G::LDS_BYTES) != hipSuccess) return fail(MV_ERR_HIP, "fcm block kernel: LDS size rejected");
-        attr_set = true;
+        device_once_done(attr_set, attr_set_slot);
     }
     // one workgroup per CU is resident (LDS): bands only while (utterance, time tile) pairs alone do not fill the chip
     const int64_t pairs = (int64_t)a.B * n_ttiles;

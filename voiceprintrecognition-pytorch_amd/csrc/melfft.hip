@@ -389,11 +389,12 @@ size_t melfft_fixed_lds_bytes() { return ((size_t)melfft_waves() * MF_SLOT_FLOAT
 
 template <int WAVES, bool PREFETCH>
 static int melfft_launch_as(const MelFftArgs& a, size_t smem, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;   // (per device: the attribute belongs to the current device's code object)
+    int attr_set_slot;
+    if (device_once_pending(attr_set, &attr_set_slot)) {
         if (MV_SET_MAX_SMEM((melspec_pow2_kernel<WAVES, PREFETCH>), 160 * 1024) != hipSuccess)
             return fail(MV_ERR_HIP, "melspec_pow2_kernel: cannot reserve dynamic LDS");
-        attr_set = true;
+        device_once_done(attr_set, attr_set_slot);
     }
     MV_LAUNCH((melspec_pow2_kernel<WAVES, PREFETCH>), ((unsigned)a.B, 1, 1), (WAVES * 64, 1, 1), smem, stream, a);
     return check_launch("melspec_pow2_kernel");

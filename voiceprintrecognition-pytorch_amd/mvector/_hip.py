@@ -85,6 +85,8 @@ _SIGNATURES = {
     'mv_fbank_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     'mv_fbank_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'mv_fbank_forward_varlen': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'mv_fbank_workspace_bytes': (c_i32, [c_vp, c_i32, c_i64, ctypes.POINTER(ctypes.c_size_t)]),
+    'mv_fbank_forward_ws': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     'mv_melspec_default_cfg': (None, [ctypes.POINTER(MvMelSpecCfg)]),
     'mv_melspec_create': (c_i32, [ctypes.POINTER(MvMelSpecCfg), ctypes.POINTER(c_vp)]),
     'mv_melspec_info': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
@@ -232,9 +234,10 @@ class Fbank:
         check(self._cdll.mv_fbank_info(self._h, ctypes.byref(tk), steps), self._cdll)
         return {'tile_kernel': bool(tk.value), 'pass_steps': (steps[0], steps[1])}
 
-    def __call__(self, wav, lens_ratio=None, num_samples=None):
+    def __call__(self, wav, lens_ratio=None, num_samples=None, workspace=True):
         """wav [B, L] fp32 -> [B, T(L), F].  ``lens_ratio``: the reference's batched semantics (mean over all T frames,
-        then mask).  ``num_samples`` (int64 [B]): every row featurised on its own length, zero rows beyond it."""
+        then mask).  ``num_samples`` (int64 [B]): every row featurised on its own length, zero rows beyond it.
+        ``workspace=False`` keeps one workgroup per utterance (mv_fbank_forward without scratch; same bits, see the header)."""
         assert wav.dim() == 2 and wav.dtype == torch.float32
         assert lens_ratio is None or num_samples is None
         if wav.stride(1) != 1:
@@ -251,8 +254,13 @@ class Fbank:
             return out
         if lens_ratio is not None:
             lens_ratio = lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
-        check(self._cdll.mv_fbank_forward(self._h, wav.data_ptr(), B, L, wav.stride(0), _ptr(lens_ratio), out.data_ptr(),
-                                          current_stream(wav)), self._cdll)
+        # per-call scratch of the several-workgroups-per-utterance form (long utterances, batch smaller than the chip): from torch's
+        # stream-aware caching allocator, so concurrent forwards on other streams never share it (the handle owns no mutable state)
+        need = ctypes.c_size_t()
+        check(self._cdll.mv_fbank_workspace_bytes(self._h, B, L, ctypes.byref(need)), self._cdll)
+        ws = torch.empty(need.value, dtype=torch.uint8, device=wav.device) if need.value and workspace else None
+        check(self._cdll.mv_fbank_forward_ws(self._h, wav.data_ptr(), B, L, wav.stride(0), _ptr(lens_ratio), out.data_ptr(), _ptr(ws),
+                                             need.value if ws is not None else 0, current_stream(wav)), self._cdll)
         return out
 
     def __del__(self):
