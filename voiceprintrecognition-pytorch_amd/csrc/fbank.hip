@@ -68,15 +68,22 @@ struct FbankArgs {
     int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
                       // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
     // fbank_tile_kernel: the time sum of an utterance is DEFINED chunk-wise, whatever the launch form (so that a row's bits depend on its
-    // own length only, never on the batch size): its quads (4 frames) are cut into nch = ceil(nquads / fit_quads) chunks of
-    // cq = ceil(nquads / nch) quads; inside a chunk wave w sums the quads c * cq + w + 8 k in order of k, its running sum takes the chunk
-    // sums in order of c, the utterance's sum is the sum over w = 0..7 in order.  chunked = 0: one workgroup per utterance walks all
-    // chunks; chunked = 1: grid = B * nch workgroups, workgroup (b, c) writes its raw rows and the eight per-wave sums of its chunk to
+    // own length only, never on the batch size): its quads (4 frames) are cut into chunks of cq = fbank_chunk_quads(nquads, fit_quads)
+    // quads, a multiple of 8; wave w owns the quads q = w (mod 8), sums those of a chunk in order, its running sum takes its chunk sums in
+    // chunk order, the utterance's sum is the sum over w = 0..7 in order.  chunked = 0: one workgroup per utterance walks all chunks;
+    // chunked = 1: grid = B * nchunks workgroups, workgroup (b, c) writes its raw rows and the eight per-wave sums of its chunk to
     // part[b][c][w][128] (caller workspace), fbank_cmn_finish_kernel forms the same sums in the same order, subtracts and masks.
     int fit_quads, chunked, nchunks;
     float* part;
     FbankTables tab;
 };
+
+// quads per chunk of an utterance of nquads quads when fit_quads quads fit the LDS block: even chunks, rounded up to the 8 waves' stride
+__host__ __device__ inline int fbank_chunk_quads(int nquads, int fit_quads) {
+    if (nquads <= fit_quads) return (nquads + 7) & ~7;
+    const int n0 = (nquads + fit_quads - 1) / fit_quads;
+    return ((nquads + n0 - 1) / n0 + 7) & ~7;
+}
 
 // NG = groups of 32 samples that cover the window (13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512);
 // VEC2: rows and frames start on 8-byte boundaries, samples are fetched as float2
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = MV_UNIFORM(tid >> 6);   // scalar: the quad / chunk bookkeeping below runs on the scalar unit
     const int l16 = lane & 15;
     const int fs = lane >> 4;
     const int b = a.chunked ? (int)blockIdx.x / a.nchunks : (int)blockIdx.x;
@@ -452,9 +459,9 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 
     __syncthreads();  // window taps
     const int nquads_all = (T + 3) >> 2;
-    const int nch = nquads_all > a.fit_quads ? (nquads_all + a.fit_quads - 1) / a.fit_quads : 1;   // chunks of THIS utterance (own length)
-    const int cq = (nquads_all + nch - 1) / nch;                                                   // quads per chunk
-    const int c_end = a.chunked ? chunk + 1 : nch;                                                  // this workgroup's chunks: [chunk, c_end)
+    const int cq = fbank_chunk_quads(nquads_all, a.fit_quads);                     // quads per chunk of THIS utterance (own length)
+    const int qbeg = a.chunked ? chunk * cq : 0;                                   // this workgroup's quads: [qbeg, nquads)
+    const int nquads = a.chunked && qbeg + cq < nquads_all ? qbeg + cq : nquads_all;
     // samples of one quad: lane holds {x[j-1], x[j], x[j+1]} at j = 32 n1 + 2 l16 -- the sample pair and, for the
     // pre-emphasis, the sample before it -- as ONE 12-byte load per group whose three result registers are consumed as
     // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     // under the two FFTs, the post-processing and the mel stage instead of stalling the top of every iteration (two waves
     // per SIMD cannot hide it: PMC r03b, waves 61 % parked with the VALU 30 % busy).  Two register sets used alternately --
     // the loop below is unrolled by two -- so the prefetched values are consumed where the loads put them.
-    auto process_quad = [&](int q, float3u (&r)[NG], float3u (&r_next)[NG], int q_next, bool has_next) __attribute__((always_inline)) {
+    auto process_quad = [&](int q, float3u (&r)[NG], float3u (&r_next)[NG]) __attribute__((always_inline)) {
         float x0[NG], x1[NG];
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         }
 #pragma unroll
         for (int n1 = NG; n1 < 16; ++n1) z[n1] = cmake(0.0f, 0.0f);
-        if (has_next) load_quad(q_next, r_next);
+        if (q + FBT_WAVES < nquads) load_quad(q + FBT_WAVES, r_next);
         // ---- stage 1 + twiddle ----
         fft16(z);
 #pragma unroll
@@ -642,51 +649,28 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             }
         }
     };
-    // this wave's quads, chunk by chunk (wave-uniform bookkeeping): q = c * cq + wave + 8 k below the chunk's end
-    int c = chunk, q = -1, qe = 0;
-    auto enter_chunk = [&]() {  // first quad of this wave in chunk c or a later one; false when the workgroup's chunks are used up
-        for (; c < c_end; ++c) {
-            q = c * cq + wave;
-            qe = (c + 1) * cq < nquads_all ? (c + 1) * cq : nquads_all;
-            if (q < qe) return true;
-        }
-        return false;
-    };
-    auto advance = [&](bool& crossed) {  // next quad of this wave; crossed = the chunk (or the walk) ended behind the current quad
-        crossed = false;
-        if (q + FBT_WAVES < qe) {
-            q += FBT_WAVES;
-            return true;
-        }
-        crossed = true;
-        ++c;
-        return enter_chunk();
-    };
     float3u ra[NG], rb[NG];
-    bool more = enter_chunk();
-    if (more) load_quad(q, ra);
-    while (more) {
-        int q_cur = q;
-        bool crossed;
-        more = advance(crossed);
-        process_quad(q_cur, ra, rb, q, more);
-        if (crossed) {
+    int cend = qbeg + cq;   // end of the chunk this wave is in (scalar bookkeeping: wave is uniform)
+    auto fold = [&](int q_next) {  // the wave's next quad lies behind the chunk's end: the chunk sum joins the running sum
+        if (q_next >= cend) {
             run0 += csum0;
             run1 += csum1;
             csum0 = 0.0f;
             csum1 = 0.0f;
+            cend += cq;
         }
-        if (!more) break;
-        q_cur = q;
-        more = advance(crossed);
-        process_quad(q_cur, rb, ra, q, more);
-        if (crossed) {
-            run0 += csum0;
-            run1 += csum1;
-            csum0 = 0.0f;
-            csum1 = 0.0f;
+    };
+    if (qbeg + wave < nquads) load_quad(qbeg + wave, ra);
+    for (int q = qbeg + wave; q < nquads; q += 2 * FBT_WAVES) {
+        process_quad(q, ra, rb);
+        fold(q + FBT_WAVES);
+        if (q + FBT_WAVES < nquads) {
+            process_quad(q + FBT_WAVES, rb, ra);
+            fold(q + 2 * FBT_WAVES);
         }
     }
+    run0 += csum0;   // the utterance ended inside a chunk (behind a fold this adds zero)
+    run1 += csum1;
 
     if (a.chunked) {  // uniform: this chunk's per-wave column sums; mean, mask and zero rows belong to fbank_cmn_finish_kernel
         float* pw = a.part + (((int64_t)b * a.nchunks + chunk) * FBT_WAVES + wave) * 128;
@@ -1039,7 +1023,10 @@ static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
     if (!h->tile_kernel || B <= 0 || p.T <= 0) return p;
     p.fit = (int64_t)((160 * 1024 - fbank_tile_fixed_lds_bytes()) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
     p.need = (p.T + 3) & ~(int64_t)3;
-    if (p.fit >= 64 && p.need > p.fit) p.nch = (int)((p.need + p.fit - 1) / p.fit);
+    if (p.fit >= 64 && p.need > p.fit) {
+        const int nquads = (int)(p.need / 4);
+        p.nch = (int)mv::ceil_div(nquads, mv::fbank_chunk_quads(nquads, (int)(p.fit / 4)));
+    }
     // one workgroup per utterance leaves CUs idle when there are fewer utterances than CUs (one 30 s utterance: all but one)
     p.chunk_form = p.nch > 1 && B < mv::device_cu_count() && (int64_t)B * p.nch <= 65535 * 16;
     if (p.chunk_form) p.workspace_bytes = (size_t)B * p.nch * mv::FBT_WAVES * 128 * sizeof(float);
