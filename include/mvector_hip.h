@@ -77,14 +77,14 @@ int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps);
  * fp32, contiguous. */
 int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                      const float* lens_ratio, float* out, mv_stream_t stream);
-/* The same forward with a caller workspace.  A batch of fewer utterances than the chip has CUs whose utterances are longer than
- * the feature block one workgroup keeps in LDS (about 2.9 s at 80 bins) is faster as several workgroups per utterance + a
- * finish pass; that form needs per-CALL scratch for partial time sums, which the handle must not own (two forwards on two
- * streams share the handle).  mv_fbank_workspace_bytes reports what this (B, L) needs on the current device (0 = none);
- * `workspace` must be 16-byte aligned and stay untouched until the forward has run on `stream`.  With a NULL or short
- * workspace -- and in mv_fbank_forward / mv_fbank_forward_varlen -- every utterance runs on one workgroup.  The two forms
- * produce IDENTICAL bits: the time mean of an utterance is summed in an order that depends on its own length only
- * (csrc/fbank.hip, FbankArgs), never on the batch size, the form or the stream. */
+/* The same forward with a caller workspace.  A batch of fewer utterances than the chip has CUs (predict()'s single utterance,
+ * predict_batch()'s 32) is faster as several workgroups per utterance + a finish pass; that form needs per-CALL scratch for the
+ * column sums of every 4-frame group, which the handle must not own (two forwards on two streams share the handle).
+ * mv_fbank_workspace_bytes reports what this (B, L) needs on the current device (0 = none); `workspace` must be 16-byte aligned
+ * and stay untouched until the forward has run on `stream`.  With a NULL or short workspace -- and in mv_fbank_forward /
+ * mv_fbank_forward_varlen -- every utterance runs on one workgroup.  The two forms produce IDENTICAL bits: the time mean of an
+ * utterance is summed in one fixed order (csrc/fbank.hip, FbankArgs) that depends on its own length only, never on the batch
+ * size, the form or the stream. */
 int mv_fbank_workspace_bytes(const MvFbank* h, int32_t B, int64_t L, size_t* bytes);
 int mv_fbank_forward_ws(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
                         float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream);

@@ -299,7 +299,8 @@ def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypat
 def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms():
     """utterances beyond the LDS block on a chip the batch does not fill: several workgroups per utterance + the finish pass (caller workspace);
     without a workspace one workgroup per utterance.  Both against the oracle (1000 frames = 4 chunks; ragged lengths through the ratio mask) and
-    BIT-IDENTICAL to each other and across batch sizes: an utterance's time sum is formed in an order that depends on its own length only."""
+    BIT-IDENTICAL to each other and across batch sizes: an utterance's time sum is formed in one order (wave slot w adds its quads w, w + 8, ...;
+    the chunk form hands the per-quad sums to the finish pass, which adds them in that order)."""
     wav = frontend.synth_waveforms(3, 400 + 160 * 999, seed=31)
     ratio = torch.tensor([0.41, 1.0, 0.77])
     lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)
@@ -309,7 +310,7 @@ def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms():
     single = fb(wav, ratio, workspace=False)
     assert torch.equal(chunked, single)
     assert torch.equal(fb(wav[1:2], ratio[1:2]), chunked[1:2]) and torch.equal(fb(wav[2:3], ratio[2:3], workspace=False), chunked[2:3])
-    # 3 s utterances (298 frames = 2 chunks of 152 + 146 frames): the ordinary sub-chip batch
+    # 3 s utterances, the ordinary sub-chip batch: the launcher cuts every utterance into about CUs / B chunks
     wav3 = frontend.synth_waveforms(9, 48000, seed=32)   # the emulator's chip has 8 CUs: 9 rows take the one-workgroup form, fewer the chunk form
     full = fb(wav3)
     for nb in (1, 2, 5):

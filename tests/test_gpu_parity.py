@@ -115,7 +115,8 @@ def test_gpu_fbank_long_utterances_chunked_and_single_workgroup_forms():
 
 def test_gpu_fbank_row_bits_do_not_depend_on_the_batch_size():
     """featurizer.py:125-130 computes every row on its own: row i of a batch must carry the same bits at B = 1 / 32 / 128 / 256 (the forms the
-    launcher picks by batch size -- one workgroup per utterance on a full chip, two per 3 s utterance below -- sum the time mean in one order)"""
+    launcher picks by batch size -- one workgroup per utterance on a full chip, about CUs / B workgroups per utterance below -- sum the time
+    mean in one order)"""
     from mvector import _hip
     fb = _hip.Fbank(FB)
     wav = frontend.synth_waveforms(256, 48000, seed=5).to(DEV)
@@ -129,7 +130,7 @@ def test_gpu_fbank_row_bits_do_not_depend_on_the_batch_size():
         assert torch.equal(fb(wav[:nb], ratio[:nb]), fullr[:nb]), nb
     nsamp = torch.full((32,), 48000, dtype=torch.int64, device=DEV)
     assert torch.equal(fb(wav[:32], num_samples=nsamp), full[:32])   # the variable-length entry point too
-    long = frontend.synth_waveforms(40, 400 + 160 * 700, seed=6).to(DEV)   # 7 s: three chunks
+    long = frontend.synth_waveforms(40, 400 + 160 * 700, seed=6).to(DEV)   # 7 s: beyond the LDS block of the one-workgroup form
     fl = fb(long)
     for nb in (1, 7):
         assert torch.equal(fb(long[:nb]), fl[:nb]), nb

@@ -67,23 +67,16 @@ struct FbankArgs {
     int64_t L;
     int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
                       // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
-    // fbank_tile_kernel: the time sum of an utterance is DEFINED chunk-wise, whatever the launch form (so that a row's bits depend on its
-    // own length only, never on the batch size): its quads (4 frames) are cut into chunks of cq = fbank_chunk_quads(nquads, fit_quads)
-    // quads, a multiple of 8; wave w owns the quads q = w (mod 8), sums those of a chunk in order, its running sum takes its chunk sums in
-    // chunk order, the utterance's sum is the sum over w = 0..7 in order.  chunked = 0: one workgroup per utterance walks all chunks;
-    // chunked = 1: grid = B * nchunks workgroups, workgroup (b, c) writes its raw rows and the eight per-wave sums of its chunk to
-    // part[b][c][w][128] (caller workspace), fbank_cmn_finish_kernel forms the same sums in the same order, subtracts and masks.
-    int fit_quads, chunked, nchunks;
+    // fbank_tile_kernel: the time sum of an utterance has ONE order whatever the launch form, so a row's bits depend on its own length only,
+    // never on the batch size: wave slot w (of 8) adds the sums of the quads (4 frames) q = w, w + 8, w + 16, ... in that order, the
+    // utterance's sum is the sum of the eight slots in order.  chunked = 0: one workgroup per utterance does exactly that.  chunked = 1:
+    // grid = B * nchunks workgroups, workgroup (b, c) takes the quads [c * chunk_quads, (c + 1) * chunk_quads) (chunk_quads a multiple of 8,
+    // so its wave w meets slot w's quads), writes its raw rows and every quad's column sums to part[b][q][128] (caller workspace);
+    // fbank_cmn_finish_kernel adds them up in the same order, subtracts the mean and applies the mask.
+    int chunked, nchunks, chunk_quads;
     float* part;
     FbankTables tab;
 };
-
-// quads per chunk of an utterance of nquads quads when fit_quads quads fit the LDS block: even chunks, rounded up to the 8 waves' stride
-__host__ __device__ inline int fbank_chunk_quads(int nquads, int fit_quads) {
-    if (nquads <= fit_quads) return (nquads + 7) & ~7;
-    const int n0 = (nquads + fit_quads - 1) / fit_quads;
-    return ((nquads + n0 - 1) / n0 + 7) & ~7;
-}
 
 // NG = groups of 32 samples that cover the window (13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512);
 // VEC2: rows and frames start on 8-byte boundaries, samples are fetched as float2
@@ -453,15 +446,14 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     const int m0 = 4 * (a.tab.pass_gbase[0] + blk) + (lane & 3);                // pass 0: one block per filter group
     const int m1 = 4 * (a.tab.pass_gbase[1] + blk / split1) + (lane & 3);
     const bool own0 = m0 < nbins, own1 = m1 < nbins && (blk & (split1 - 1)) == 0;
-    float csum0 = 0.0f, csum1 = 0.0f;   // this wave's sums over its quads of the current chunk
-    float run0 = 0.0f, run1 = 0.0f;     // ... and over the chunks it has finished (FbankArgs: the chunk-wise definition of the time sum)
+    float csum0 = 0.0f, csum1 = 0.0f;   // this wave's column sums (slot `wave` of FbankArgs' summation order)
     const int tile_rows = a.tile_rows;
 
     __syncthreads();  // window taps
     const int nquads_all = (T + 3) >> 2;
-    const int cq = fbank_chunk_quads(nquads_all, a.fit_quads);                     // quads per chunk of THIS utterance (own length)
-    const int qbeg = a.chunked ? chunk * cq : 0;                                   // this workgroup's quads: [qbeg, nquads)
-    const int nquads = a.chunked && qbeg + cq < nquads_all ? qbeg + cq : nquads_all;
+    const int qbeg = a.chunked ? chunk * a.chunk_quads : 0;                                   // this workgroup's quads: [qbeg, nquads)
+    const int nquads = a.chunked && qbeg + a.chunk_quads < nquads_all ? qbeg + a.chunk_quads : nquads_all;
+    float* part_b = a.chunked ? a.part + (int64_t)b * (a.nchunks * a.chunk_quads) * 128 : nullptr;
     // samples of one quad: lane holds {x[j-1], x[j], x[j+1]} at j = 32 n1 + 2 l16 -- the sample pair and, for the
     // pre-emphasis, the sample before it -- as ONE 12-byte load per group whose three result registers are consumed as
     // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
@@ -624,8 +616,13 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
                 }
             }
         }
-        csum0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
-        csum1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        const float qs0 = (v0[0] + v0[1]) + (v0[2] + v0[3]), qs1 = (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        csum0 += qs0;
+        csum1 += qs1;
+        if (a.chunked) {  // uniform: the quad's column sums for the finish pass (FbankArgs)
+            if (own0) part_b[q * 128 + m0] = qs0;
+            if (own1) part_b[q * 128 + m1] = qs1;
+        }
         const int row0 = q * 4 * nbins;
         if (q * 4 < tile_rows) {  // uniform (tile_rows is a multiple of 4): LDS block [t][m]
             auto d0 = MV_AS_LDS(float, tile + row0 + m0);
@@ -650,41 +647,20 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         }
     };
     float3u ra[NG], rb[NG];
-    int cend = qbeg + cq;   // end of the chunk this wave is in (scalar bookkeeping: wave is uniform)
-    auto fold = [&](int q_next) {  // the wave's next quad lies behind the chunk's end: the chunk sum joins the running sum
-        if (q_next >= cend) {
-            run0 += csum0;
-            run1 += csum1;
-            csum0 = 0.0f;
-            csum1 = 0.0f;
-            cend += cq;
-        }
-    };
     if (qbeg + wave < nquads) load_quad(qbeg + wave, ra);
     for (int q = qbeg + wave; q < nquads; q += 2 * FBT_WAVES) {
         process_quad(q, ra, rb);
-        fold(q + FBT_WAVES);
-        if (q + FBT_WAVES < nquads) {
-            process_quad(q + FBT_WAVES, rb, ra);
-            fold(q + 2 * FBT_WAVES);
-        }
+        if (q + FBT_WAVES < nquads) process_quad(q + FBT_WAVES, rb, ra);
     }
-    run0 += csum0;   // the utterance ended inside a chunk (behind a fold this adds zero)
-    run1 += csum1;
+    if (a.chunked) return;  // uniform: mean, mask and zero rows belong to fbank_cmn_finish_kernel
 
-    if (a.chunked) {  // uniform: this chunk's per-wave column sums; mean, mask and zero rows belong to fbank_cmn_finish_kernel
-        float* pw = a.part + (((int64_t)b * a.nchunks + chunk) * FBT_WAVES + wave) * 128;
-        if (own0) pw[m0] = run0;
-        if (own1) pw[m1] = run1;
-        return;
-    }
     const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;
     if (!second_pass && tile_rows == 0) return;
 
     // ---- per-utterance time mean (featurizer.py:79) ----
     __syncthreads();  // every wave has left the frame loop: the slot area becomes the reduction buffer
-    if (own0) colsum[wave * 128 + m0] = run0;   // (lanes that own no filter summed values nobody reads)
-    if (own1) colsum[wave * 128 + m1] = run1;
+    if (own0) colsum[wave * 128 + m0] = csum0;   // (lanes that own no filter summed values nobody reads)
+    if (own1) colsum[wave * 128 + m1] = csum1;
     __syncthreads();
     float* mean = colsum + FBT_WAVES * 128;
     if (tid < 128) {
@@ -719,25 +695,30 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 }
 
 // second launch of the chunked form: feat[b, t, :] = t < mask_len ? raw - mean : 0 (featurizer.py:79, 119-132) with the time sum formed
-// exactly as the one-workgroup form forms it (FbankArgs): per wave slot the chunk sums in chunk order, then the eight slots in order.
-// Workgroup = (utterance, block of FBF_ROWS rows); one thread per group of 4 bins.
-constexpr int FBF_ROWS = 64;
+// exactly as the one-workgroup form forms it (FbankArgs): per wave slot the quad sums q = w, w + 8, ... in order, then the eight slots in
+// order.  Workgroup = (utterance, block of FBF_ROWS rows); one thread per group of 4 bins.
+constexpr int FBF_ROWS = 32;
 __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const float* part, const float* lens_ratio, int T, int nbins,
-                                                               int nchunks, int row_blocks, int cmn) {
+                                                               int part_quads, int row_blocks, int cmn) {
+    __shared__ float slot[FBT_WAVES][128];
     __shared__ float mean[128];
     const int b = (int)blockIdx.x / row_blocks, rb = (int)blockIdx.x - b * row_blocks;
     const int tid = threadIdx.x;
+    const int nquads = (T + 3) >> 2;
+    const float* pb = part + (int64_t)b * part_quads * 128;
+    for (int i = tid; i < FBT_WAVES * 128; i += 256) {  // thread = (slot w, bin m)
+        const int w = i >> 7, m = i & 127;
+        float run = 0.0f;
+        if (cmn && m < nbins)
+            for (int q = w; q < nquads; q += FBT_WAVES) run += pb[q * 128 + m];
+        slot[w][m] = run;
+    }
+    __syncthreads();
     if (tid < 128) {
         float v = 0.0f;
-        if (cmn && tid < nbins) {
-            for (int w = 0; w < FBT_WAVES; ++w) {
-                float run = 0.0f;
-                for (int c = 0; c < nchunks; ++c) run += part[(((int64_t)b * nchunks + c) * FBT_WAVES + w) * 128 + tid];
-                v += run;
-            }
-            v = v / (float)T;
-        }
-        mean[tid] = v;
+#pragma unroll
+        for (int w = 0; w < FBT_WAVES; ++w) v += slot[w][tid];
+        mean[tid] = (cmn && T > 0 && tid < nbins) ? v / (float)T : 0.0f;
     }
     __syncthreads();
     int mask_len = T;
@@ -1008,12 +989,13 @@ int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps) {
     return MV_OK;
 }
 
-// Geometry of one forward.  `fit` = feature rows that fit next to the wave slots in LDS (a multiple of 4); an utterance of more rows is
-// cut into nch chunks (FbankArgs) -- by its own length only, so a row's bits never depend on the batch around it.
+// Geometry of one forward.  `fit` = feature rows that fit next to the wave slots in LDS (a multiple of 4).  The several-workgroups form
+// (chunk_form) is a matter of time only -- both forms sum an utterance's time mean in one order (FbankArgs) -- and pays whenever there are
+// fewer utterances than CUs: chunks of a multiple of 8 quads so that (utterance, chunk) workgroups about fill the chip.
 struct FbankPlan {
     int64_t T = 0, fit = 0, need = 0;
-    int nch = 1;
-    bool chunk_form = false;   // B * nch workgroups + the finish pass (needs the caller's workspace): pays when the batch does not fill the chip
+    int nch = 1, chunk_quads = 0;
+    bool chunk_form = false;   // B * nch workgroups + the finish pass; needs the caller's workspace
     size_t workspace_bytes = 0;
 };
 
@@ -1023,13 +1005,17 @@ static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
     if (!h->tile_kernel || B <= 0 || p.T <= 0) return p;
     p.fit = (int64_t)((160 * 1024 - fbank_tile_fixed_lds_bytes()) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
     p.need = (p.T + 3) & ~(int64_t)3;
-    if (p.fit >= 64 && p.need > p.fit) {
-        const int nquads = (int)(p.need / 4);
-        p.nch = (int)mv::ceil_div(nquads, mv::fbank_chunk_quads(nquads, (int)(p.fit / 4)));
+    const int cus = mv::device_cu_count();
+    const int nquads = (int)(p.need / 4);
+    if (B < cus && nquads >= 2 * mv::FBT_WAVES) {
+        const int want = (int)mv::ceil_div(cus, B);                                    // chunks per utterance that fill the chip once
+        const int most = nquads / mv::FBT_WAVES;                                       // (every wave of a chunk gets a quad)
+        const int nch0 = want < most ? want : most;
+        p.chunk_quads = (int)mv::round_up(mv::ceil_div(nquads, nch0), mv::FBT_WAVES);
+        p.nch = (int)mv::ceil_div(nquads, p.chunk_quads);
+        p.chunk_form = p.nch > 1;
     }
-    // one workgroup per utterance leaves CUs idle when there are fewer utterances than CUs (one 30 s utterance: all but one)
-    p.chunk_form = p.nch > 1 && B < mv::device_cu_count() && (int64_t)B * p.nch <= 65535 * 16;
-    if (p.chunk_form) p.workspace_bytes = (size_t)B * p.nch * mv::FBT_WAVES * 128 * sizeof(float);
+    if (p.chunk_form) p.workspace_bytes = (size_t)B * p.nch * p.chunk_quads * 128 * sizeof(float);
     return p;
 }
 
@@ -1087,9 +1073,9 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.cmn = h->cfg.subtract_time_mean;
     a.L = L;
     a.tile_rows = 0;
-    a.fit_quads = plan.fit >= 64 ? (int)(plan.fit / 4) : 0x3fffffff;
     a.chunked = 0;
     a.nchunks = 1;
+    a.chunk_quads = 0;
     a.part = nullptr;
     a.tab = h->tab;
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
@@ -1103,16 +1089,17 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
             (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
             a.chunked = 1;
             a.nchunks = plan.nch;
+            a.chunk_quads = plan.chunk_quads;
             a.part = static_cast<float*>(workspace);
             fbank_tile_launch(B * plan.nch, fixed, static_cast<hipStream_t>(stream), a, vec2);
             if (a.cmn || lens_ratio != nullptr) {
                 const int row_blocks = (int)mv::ceil_div(T, mv::FBF_ROWS);
                 MV_LAUNCH(mv::fbank_cmn_finish_kernel, (B * row_blocks, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), out, a.part, lens_ratio,
-                          (int)T, h->nbins, plan.nch, row_blocks, a.cmn);
+                          (int)T, h->nbins, plan.nch * plan.chunk_quads, row_blocks, a.cmn);
             }
         } else {
-            // feature rows that fit next to the wave slots stay in LDS until the time mean is known (all 298 frames of a 3 s utterance at
-            // 80 bins fit?  no: `fit` of them); the rest take the write / re-read / rewrite route through global memory
+            // the first `fit` feature rows stay in LDS next to the wave slots until the time mean is known (292 of the 298 frames of a 3 s
+            // utterance at 80 bins); the rest take the write / re-read / rewrite route through global memory
             a.tile_rows = (int)(plan.fit < plan.need ? plan.fit : plan.need);
             fbank_tile_launch(B, fixed + (size_t)a.tile_rows * h->nbins * sizeof(float), static_cast<hipStream_t>(stream), a, vec2);
         }
