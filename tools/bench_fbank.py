@@ -8,7 +8,20 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 48000
 import ctypes
 cdll = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else None
-fb = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80), cdll=cdll)
+fb_h = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80), cdll=cdll)
+T = fb_h.num_frames(L)
+_out = torch.empty((B, T, 80), dtype=torch.float32, device='cuda')
+
+
+def fb(wav):
+    """mv_fbank_forward (one workgroup per utterance; the entry point every library revision has) -- or the product call with MV_BENCH_WS=1"""
+    if os.environ.get('MV_BENCH_WS') == '1':
+        return fb_h(wav)
+    _hip.check(fb_h._cdll.mv_fbank_forward(fb_h._h, wav.data_ptr(), B, L, wav.stride(0), None, _out.data_ptr(), _hip.current_stream(wav)), fb_h._cdll)
+    return _out
+
+
+fb.info = fb_h.info
 g = torch.Generator().manual_seed(1234)
 wav = (0.1 * torch.randn([B, L], generator=g)).clamp(-1, 1).cuda()
 for _ in range(5):
