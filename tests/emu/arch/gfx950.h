@@ -177,7 +177,6 @@ inline void mfma_tiles1_init(float4v (&c)[N], const half8v& a, const half8v (&b)
 }
 inline void glds16_untracked_so_fresh(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) { glds16_untracked_so(sbase, voff, lds_wave_base_addr); }
 inline void mfma_hazard_pad() {}
-inline void store16_streaming(void* p, const unsigned (&o)[4]) { memcpy(p, o, 16); }
 
 inline int device_cu_count() { return 8; }
 struct DeviceOnce { bool flag = false; };

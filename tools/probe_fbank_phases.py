@@ -58,6 +58,25 @@ def edits(name):
               ('        } else {\n            auto d0 = MV_AS_GLOBAL(float, orow + row0 + m0);', '        } else if (q < -1) {\n            auto d0 = MV_AS_GLOBAL(float, orow + row0 + m0);', 'only'),
               ('    const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;\n    if (!second_pass && tile_rows == 0) return;\n',
                '    if (csum0 + csum1 != 12345.0f) return;  // PROBE: no CMN sweep\n    const bool second_pass = a.cmn || a.lens_ratio != nullptr || a.num_samples != nullptr;\n', 'only')]
+    elif name == 'noloop':
+        E += [('    for (int q = qbeg + wave; q < nquads; q += 2 * FBT_WAVES) {\n        process_quad(q, ra, rb);', '    for (int q = qbeg + wave; q < 0; q += 2 * FBT_WAVES) {\n        process_quad(q, ra, rb);', 'only')]
+    elif name == 'notrans':
+        E += [('        for (int k1 = 0; k1 < 16; ++k1) tw_write[k1 * FBT_ROW] = z[k1];\n        MV_WAVE_FENCE();\n#pragma unroll\n        for (int n2 = 0; n2 < 16; ++n2) z[n2] = lds_read_single(tw_read + n2);\n',
+               '        for (int k1 = 0; k1 < 0; ++k1) tw_write[k1 * FBT_ROW] = z[k1];\n        MV_WAVE_FENCE();\n', 'only')]
+    elif name == 'nopost':
+        E += [('            const float t = dpp_mov_all<DPP_ROW_MIRROR>(src[c]);\n                bp[c] = dpp_mov<DPP_ROW_SHR1>(own_alt[c], t);', '            bp[c] = src[c] + own_alt[c];', 'only')]
+    elif name == 'nowin':
+        E += [('            const float2v w2 = lds_load_unmerged(reinterpret_cast<const float2v*>(cwin + 32 * n1));\n            const float y0 = fmaf(npre, r[n1][0], x0[n1]) - dc;',
+               '            const float2v w2 = float2v{0.5f, 0.25f + 0.01f * n1};\n            const float y0 = fmaf(npre, r[n1][0], x0[n1]) - dc;', 'last')]
+    elif name == 'notw':
+        E += [('            const float2v tw = lds_load_unmerged(reinterpret_cast<const float2v*>(ctw1 + 32 * k1));\n            z[k1] = cmul_conjtw(z[k1], tw[0], tw[1]);',
+               '            const float2v tw = float2v{0.7f, 0.1f * k1};\n            z[k1] = cmul_conjtw(z[k1], tw[0], tw[1]);', 'last')]
+    elif name == 'nolog':
+        E += [('            v0[r] = fb_log2(fmaxf(a0[r], 1.1920928955078125e-07f)) * 0.69314718055994531f;\n            v1[r] = fb_log2(fmaxf(a1[r], 1.1920928955078125e-07f)) * 0.69314718055994531f;',
+               '            v0[r] = fmaxf(a0[r], 1.1920928955078125e-07f) * 0.69314718055994531f;\n            v1[r] = fmaxf(a1[r], 1.1920928955078125e-07f) * 0.69314718055994531f;', 'last')]
+    elif name == 'nopower':
+        E += [('        for (int j = 0; j < 8; ++j) p_own[16 * j] = pk[j];\n        p_par0[16 * 15] = pp[0];\n#pragma unroll\n        for (int j = 1; j < 8; ++j) p_par[16 * (15 - j)] = pp[j];\n',
+               '        for (int j = 0; j < 1; ++j) p_own[16 * j] = pk[0] + pk[1] + pk[2] + pk[3] + pk[4] + pk[5] + pk[6] + pk[7] + pp[0] + pp[1] + pp[2] + pp[3] + pp[4] + pp[5] + pp[6] + pp[7];\n', 'only')]
     elif name == 'occ4':
         E += [('__global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel', '__global__ __launch_bounds__(FBT_WAVES * 64, 4) void fbank_tile_kernel', 'only'),
               ('            a.tile_rows = (int)(plan.fit < plan.need ? plan.fit : plan.need);\n', '            a.tile_rows = 0;  // PROBE: no LDS block -> 70 KB per workgroup, two workgroups per CU\n', 'only')]
@@ -131,6 +150,6 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'run':
         run()
     else:
-        names = sys.argv[1:] or ['base', 'trace', 'noload', 'nomel', 'nofft', 'notile', 'occ4']
+        names = sys.argv[1:] or ['base', 'trace', 'noload', 'nomel', 'nofft', 'notile', 'noloop', 'notrans', 'nopost', 'nowin', 'notw', 'nolog', 'nopower']
         for n in names:
             build(n)

@@ -216,13 +216,6 @@ __device__ __forceinline__ void mfma10_step(float4v* c0, float4v* c1, const half
 }
 // MFMA results are read by VALU code only after a barrier and a round of transfers; pad the hazard anyway
 __device__ __forceinline__ void mfma_hazard_pad() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
-// 16-byte store with the streaming policy bits (write-through, no L2 allocation)
-__device__ __forceinline__ void store16_streaming(void* p, const unsigned (&o)[4]) {
-    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-    const uint4v ou = {o[0], o[1], o[2], o[3]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(ou) : "memory");
-}
-
 // ---- hand-scheduled pieces of the fused FCM block kernel (fcmblock.hip) ----------------------------------------------------------
 // N 16-byte fragment reads at addr + i * 1024 (16 positions x 64 B apart), no wait
 template <int N>

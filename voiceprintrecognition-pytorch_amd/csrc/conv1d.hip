@@ -53,7 +53,6 @@ struct ConvArgs {
     int B, T_in, T_out, cin, cin_pad, cout, cout_pad, k, dil, stride, pad, pad_mode;
     int pre_act, post_act, y_f16, gate_seg_len, gate_nseg;
     int n_rows, n_tiles, co_tiles;
-    int store_nt;  // persistent kernel: output stores carry the streaming policy bits (see conv_store_policy)
     float* stat_sum;  // optional partial time sums of the output (persistent kernel): [ceil(n_rows / 64)][2][cout]
     float* stat_sq;   // optional partial sums of squares (about the BatchNorm shift), same layout
     // one-shot 128 x 160 kernel: tiles never straddle utterances (tile = (utterance, 160-frame block)), and the workgroups of channel
@@ -668,11 +667,7 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
                     const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
                     half8v ov;
                     __builtin_memcpy(&ov, o, 16);
-                    if (a.store_nt) {  // uniform
-                        if (n < a.n_rows) store16_streaming(yrow + p * 32, o);
-                    } else {
-                        if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
-                    }
+                    if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
                 }
             }
         }
@@ -1413,22 +1408,10 @@ __global__ void pack_conv_weight_kernel(const float* w, int cout, int cin, int k
 int conv1d_cin_pad(int cin) { return (int)round_up(cin, CV_BK); }
 int conv1d_cout_pad(int cout) { return (int)round_up(cout, 32); }
 
-// Streaming ("sc1 nt") output stores for the persistent kernel -- measured, OFF by default.  All workgroups reach their
-// epilogues together, so a layer's output leaves as bursts of 32 MiB (in isolation the stores cost 27 us of a 187 us K = 1024
-// layer, 83 us of the 1270 us K = 3072 layer: probe 4).  With the streaming bits a K = 1024 layer alone runs 187 -> 173 us
-// (K = 3072: 1280 -> 1310 us), but the layers that consume the output then miss in L2 / MALL: end to end 68.2 k -> 65.7 k
-// utterances/s (r02d, same box).  MV_CONV_STORE_NT = 0 / 1 / 2: never (default) / K <= 1536 / always.  Repeated per role with the ring kernel
-// (r05s, one call, alternating): default 76.1 / 75.9 k utt/s, streaming stores on the tdnn2 outputs only (read by the streaming time_stats /
-// se_gate passes) 74.5 / 74.7 k, on the tdnn1 outputs only (read by the Res2Net chain) 75.4 / 75.1 k, on all K = 1024 layers 74.3 / 74.0 k.
-static int conv_store_policy(int64_t k_total) {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = std::getenv("MV_CONV_STORE_NT");
-        mode = e != nullptr ? std::atoi(e) : 0;
-    }
-    return mode == 2 || (mode == 1 && k_total <= 1536) ? 1 : 0;
-}
-
+// Streaming ("sc1 nt") output stores for the persistent kernels were measured and dropped: all workgroups reach their epilogues together, so a
+// layer's output leaves as bursts of 32 MiB (in isolation the stores cost 27 us of a 187 us K = 1024 layer); with the streaming bits a
+// K = 1024 layer alone runs 187 -> 173 us, but the layers that consume the output then miss in L2 / MALL: end to end 68.2 k -> 65.7 k
+// utterances/s (r02d), and per role with the ring kernel 76.1 k -> 74.0-75.4 k (r05s).
 static int cu_count() {
     return device_cu_count();   // (cached per device)
 }
@@ -1443,32 +1426,6 @@ static int persistent_blocks() {
         n = v > 0 ? (int)round_up(v, 8) : 0;
     }
     return n;
-}
-
-// MV_CONV_IMPL = ring (default) | double: which persistent kernel takes the dense 1x1 layers (A/B switch; both are covered by tests)
-// MV_CONV_IMPL = ring (default) | double: which persistent kernel takes the dense 1x1 layers (A/B switch; both are covered by tests)
-static int conv_persist_impl() {  // 0 double buffer, 1 ring
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MV_CONV_IMPL");
-        v = e == nullptr ? 1 : (e[0] == 'd' ? 0 : 1);
-    }
-    return v;
-}
-
-bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k) {
-    // Measured (r02a): the DPP row sums put ~6 us per tile into the epilogue, on the critical path of every CU at once --
-    // 3 x 32 us on the tdnn2 layers and ~150 us on mfa, as much as the separate time_stats passes they replace (3 x 30 +
-    // 100-150 us), so the model keeps the separate passes unless MV_FUSE_STATS=1 asks for the fused form.
-    static const bool enabled = [] {
-        const char* e = getenv("MV_FUSE_STATS");
-        return e != nullptr && atoi(e) != 0;
-    }();
-    if (!enabled) return false;
-    // mirrors the launcher's choice of the persistent kernel for an aligned fp16 TDNN layer (bias, ReLU, BatchNorm affine)
-    const int64_t n_rows = (int64_t)B * T;
-    return k == 1 && cin % CV_BK == 0 && cin >= 2 * CV_BK && cout % 256 == 0 && T >= 64 && persistent_blocks() > 0 &&
-           ceil_div(n_rows, 256) * (cout / 256) >= 256;
 }
 
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
@@ -1591,7 +1548,6 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
     a.n_tiles = a.per_utt ? d.B * a.tiles_per_utt : (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
-    a.store_nt = conv_store_policy((int64_t)d.k * a.cin_pad);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
     static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
     int smem_set_slot;
@@ -1619,7 +1575,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
         const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
                                 (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
-        if (conv_persist_impl() == 1 && stats == 0 && dense_rows) {
+        if (stats == 0 && dense_rows) {
             MV_LAUNCH(conv1d_ring_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVR_LDS_BYTES, stream, a);
         } else if (stats == 2) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);

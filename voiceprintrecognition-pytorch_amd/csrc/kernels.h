@@ -6,8 +6,7 @@ namespace mv {
 
 int conv1d_cin_pad(int cin);
 int conv1d_cout_pad(int cout);
-// true when a [B, T, cin] -> [B, T, cout] fp16 1x1 TDNN layer takes the persistent kernel, whose epilogue can emit time statistics
-bool conv1d_can_fuse_stats(int B, int T, int cin, int cout, int k);
+// finish pass of the time statistics a persistent-kernel epilogue can emit (MvConv1dDesc.stat_sum / stat_sq)
 int conv_stats_finish_launch(const float* psum, const float* psq, const float* shift, int B, int T, int C, float* mean, float* stdv,
                              int64_t ld_out, float clamp_eps, hipStream_t stream);
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream);

@@ -220,12 +220,6 @@ size_t AspLayer::workspace_floats(int B, int T) const {
     return (size_t)B * (2 * C + A) + 2 * (size_t)conv_in_stats_elems(B, T, C);
 }
 
-// MV_ASP_FUSE_STATS=0 keeps the separate global-statistics pass in front of the hidden conv (A/B runs); read per call
-static bool asp_fuse_stats_enabled() {
-    const char* e = getenv("MV_ASP_FUSE_STATS");
-    return e == nullptr || atoi(e) != 0;
-}
-
 // x: [B, T, ldx] fp16 -> pooled [B, 2C] fp32.  h: [B*T, A] fp16 scratch, fws: workspace_floats(B) fp32 scratch.
 int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, float* fws, float* pooled,
                       hipStream_t stream, bool have_gstats) const {
@@ -233,7 +227,7 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     float* gstats = fws;                     // [B, 2C]  mean | std
     float* ctxb = fws + (size_t)B * 2 * C;   // [B, A]
     const float* gmean = nullptr;
-    if (global_ctx && !have_gstats && A <= 128 && A % 8 == 0 && ldx % 8 == 0 && asp_fuse_stats_enabled()) {
+    if (global_ctx && !have_gstats && A <= 128 && A % 8 == 0 && ldx % 8 == 0) {
         // x is streamed ONCE for the global statistics and the hidden layer: the 1x1 conv over x collects the time sums of its own x
         // tiles and leaves the pre-activation z = Wx . x in h; the context columns [mean; std] enter as a per-utterance bias that
         // is added afterwards, together with ReLU -> BatchNorm -> tanh (asp_hidden_act_kernel, in place).  Saves the separate
@@ -367,7 +361,6 @@ struct EcapaModel : MvModelBase {
         // CONTIGUOUS values starting at row t of the reflect-padded features, so block 0 is a 1x1 conv with cin = k*F and
         // row stride F (rows overlap).  K = 5*80 = 400 -> 7 stages of 64 instead of 5 taps x 128 (80 padded) = 10.
         block0_window = c.dilations[0] == 1 && c.input_size % 8 == 0 && c.kernel_sizes[0] > 1 && (c.kernel_sizes[0] % 2) == 1;
-        if (const char* e = std::getenv("MV_BLOCK0_WINDOW")) block0_window = block0_window && std::atoi(e) != 0;  // A/B switch
         if (block0_window) {
             const int F = c.input_size, k0 = c.kernel_sizes[0], C0 = c.channels[0];
             std::vector<float> w0, wr((size_t)C0 * k0 * F);
@@ -426,7 +419,7 @@ struct EcapaModel : MvModelBase {
 
     struct Ws {
         half_t *x16, *a0, *cat, *t1, *r2, *t2, *sc, *mfa, *h, *rs[2];
-        float *se_mean, *se_hid, *gate, *asp_f, *pooled, *stat_sum, *stat_sq;
+        float *se_mean, *se_hid, *gate, *asp_f, *pooled;
         size_t bytes;
     };
 
@@ -434,10 +427,6 @@ struct EcapaModel : MvModelBase {
         const size_t N = (size_t)B * T;
         Carver c(base);
         Ws s;
-        // partial rows of the time statistics fused into the tdnn2 / mfa epilogues (widest layer: mfa)
-        const int cwide = cfg.channels[4] > cmax ? cfg.channels[4] : cmax;
-        s.stat_sum = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cwide));
-        s.stat_sq = c.take<float>((size_t)mv_conv1d_stats_elems(B, T, cfg.channels[4]));
         s.x16 = c.take<half_t>((size_t)B * (T + cfg.kernel_sizes[0]) * round_up(cfg.input_size, 8));  // incl. the reflect halo rows
         s.a0 = c.take<half_t>(N * cfg.channels[0]);
         s.cat = c.take<half_t>(N * ccat);
@@ -537,18 +526,13 @@ struct EcapaModel : MvModelBase {
                         return rc;
                 }
             }
-            // SE: squeeze -> FC/ReLU -> FC/sigmoid -> gate * y + residual, written into the aggregation slice.  The squeeze
-            // (mean over time, ecapa_tdnn.py:79) comes out of tdnn2's epilogue when that layer runs on the persistent kernel.
-            const bool fused_sq = conv1d_can_fuse_stats(B, T, C, C, 1);
+            // SE: squeeze -> FC/ReLU -> FC/sigmoid -> gate * y + residual, written into the aggregation slice.  The squeeze (mean over
+            // time, ecapa_tdnn.py:79) is its own single pass: taken in tdnn2's epilogue (MvConv1dDesc.stat_sum) it costs that layer as
+            // much as the pass it replaces (r02a: +32 us against 29 us).
             if ((rc = run_conv(b.tdnn2.conv, s.r2, MV_DT_F16, C, nullptr, 0, s.t2, MV_DT_F16, C, B, T, T, 1, 0, R, MV_ACT_RELU,
-                               b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st, nullptr, 0, nullptr, 0,
-                               fused_sq ? s.stat_sum : nullptr, nullptr)))
+                               b.tdnn2.scale, b.tdnn2.shift, MV_ACT_NONE, nullptr, true, st)))
                 return rc;
-            if (fused_sq) {
-                if ((rc = conv_stats_finish_launch(s.stat_sum, nullptr, b.tdnn2.shift, B, T, C, s.se_mean, nullptr, C, 0.0f, st))) return rc;
-            } else {
-                if ((rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st))) return rc;
-            }
+            if ((rc = time_stats_launch(s.t2, C, B, T, C, s.se_mean, nullptr, C, 0, 0.0f, st))) return rc;
             if ((rc = linear_f32_launch(s.se_mean, C, b.se_w1, C, b.se_b1, MV_ACT_RELU, s.se_hid, cfg.se_channels, B, C,
                                         cfg.se_channels, 0, st)))
                 return rc;
@@ -563,18 +547,12 @@ struct EcapaModel : MvModelBase {
         }
         // multi-layer feature aggregation reads the three block outputs in place
         const int Cm = cfg.channels[4];
-        // the ASP global mean / std (pooling.py:104-109) come out of the mfa epilogue on the persistent kernel
-        const bool fused_gs = asp.global_ctx && cfg.kernel_sizes[4] == 1 && conv1d_can_fuse_stats(B, T, ccat, Cm, 1);
+        // (the ASP global mean / std of pooling.py:104-109 are collected by the ASP hidden conv from its own input tiles: AspLayer::forward)
         if ((rc = run_conv(mfa.conv, s.cat, MV_DT_F16, ccat, nullptr, 0, s.mfa, MV_DT_F16, Cm, B, T, T, cfg.dilations[4],
                            cfg.dilations[4] * (cfg.kernel_sizes[4] - 1) / 2, R, MV_ACT_RELU, mfa.scale, mfa.shift, MV_ACT_NONE,
-                           nullptr, true, st, nullptr, 0, nullptr, 0, fused_gs ? s.stat_sum : nullptr, fused_gs ? s.stat_sq : nullptr)))
+                           nullptr, true, st)))
             return rc;
-        if (fused_gs) {
-            float* gstats = s.asp_f;  // [B, 2 Cm]: mean | std, the layout AspLayer::forward expects
-            if ((rc = conv_stats_finish_launch(s.stat_sum, s.stat_sq, mfa.shift, B, T, Cm, gstats, gstats + Cm, 2 * Cm, 1e-12f, st)))
-                return rc;
-        }
-        if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st, fused_gs))) return rc;
+        if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st))) return rc;
         // asp_bn folded into fc
         return linear_f32_launch(s.pooled, 2 * Cm, fc_w, 2 * Cm, fc_b, MV_ACT_NONE, emb, cfg.embd_dim, B, 2 * Cm, cfg.embd_dim, 0,
                                  st);

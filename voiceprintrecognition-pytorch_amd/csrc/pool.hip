@@ -797,11 +797,10 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, i
     a.eps = 1e-12f;
     const unsigned gx = (unsigned)ceil_div(C, 64);
     const bool nomax = logit_bound_log2 >= 0.0f && logit_bound_log2 <= 60.0f;
-    // ring form: whole tiles, aligned rows, no partial h fragments; MV_ASP_IMPL=regs keeps the register form (A/B runs)
-    const char* impl = getenv("MV_ASP_IMPL");
+    // ring form: whole tiles, aligned rows, no partial h fragments (other widths / unbounded logits: the register form below)
     const bool ring_ok = nomax && C % 256 == 0 && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && A == a.A_pad &&
                          (gmean == nullptr || (gmean_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(gmean) & 15) == 0)) &&
-                         (reinterpret_cast<uintptr_t>(h) & 15) == 0 && !(impl != nullptr && strcmp(impl, "regs") == 0);
+                         (reinterpret_cast<uintptr_t>(h) & 15) == 0;
     if (ring_ok && (a.A_pad == 64 || a.A_pad == 128)) {
         const unsigned gxw = (unsigned)ceil_div(C, 256);
         if (a.A_pad == 64) {

@@ -479,11 +479,11 @@ static void res2_chunking(int T, int width, int steps, int k, int dil, int* nchu
     *nchunks = 1;
     *useful = T;
     if (T <= 16 * 2 * R2_NH) return;
-    if (const char* e = getenv("MV_RES2_CHUNK")) if (e[0] == '0') return;   // A/B arm: long utterances as one launch per step (model.hip)
     const int per = res2_local_limit(width, k) - 2 * steps * (dil * (k - 1) / 2);
     if (per < 64) return;  // (not worth it: the caller falls back to one launch per step)
-    *nchunks = (T + per - 1) / per;
-    *useful = (T + *nchunks - 1) / *nchunks;
+    const int n0 = (T + per - 1) / per;
+    *useful = (T + n0 - 1) / n0;
+    *nchunks = (T + *useful - 1) / *useful;   // (rounding `useful` up can save a chunk: no chunk may start at or behind T)
 }
 
 bool res2_chain_supported(int T, int width, int steps, int k, int dil) {
