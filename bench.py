@@ -121,13 +121,15 @@ def one_minus_cos(a, b):
     return (1 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)).max().item()
 
 
-def short_run(name, dev, B, steps, warmup, parity_rows, gallery_rows=0):
+def short_run(name, dev, B, steps, warmup, parity_rows, gallery_rows=0, head=None):
     """throughput + parity of one of the other configurations (N=1, after the headline's timed region).  gallery_rows > B: the
     scoring step of a sharded run (BASELINE config 4): this rank's B rows against a gallery of that many rows, as after the
     all-gather -- the other rows are embeddings of other seeded batches, computed before the timed region."""
     from mvector import _hip
     from oracle import scoring
     featurizer, model, state_cpu = build(name, dev)
+    if head is not None:
+        model.head_precision = head   # CAM++: pin the FCM head ('f32' = the head an ill-conditioned checkpoint gets: its price as a number)
     g = torch.Generator().manual_seed(1234)
     wav = (0.1 * torch.randn([B, SAMPLES], generator=g)).clamp(-1, 1).to(dev)
     with torch.no_grad():
@@ -166,6 +168,8 @@ def short_run(name, dev, B, steps, warmup, parity_rows, gallery_rows=0):
            'cosine_block': {'shape': [int(scores.shape[0]), int(scores.shape[1])], 'max_abs_err_vs_oracle_scoring': score_err, 'tolerance': 2e-6}}
     if MODELS[name][4]:
         out['backbone_plus_frontend_tflops'] = round(B * MODELS[name][4] * steps / dt / 1e3, 1)
+    if hasattr(model, 'native_head'):
+        out['fcm_head'] = dict(model.native_head() or {}, pinned=head is not None)
     return out
 
 
@@ -533,6 +537,7 @@ def main():
             if args.model == 'ecapa1024' and not args.no_other_configs:
                 others = {}
                 for key, fn in (('config3_campp', lambda: short_run('campp', dev, B, 10, 3, B)),
+                                ('config3_campp_fp32_head', lambda: short_run('campp', dev, B, 5, 2, B, head='f32')),
                                 ('config4_share_ecapa512_mel', lambda: short_run('ecapa512_mel', dev, B, 10, 3, B, gallery_rows=8 * B)),
                                 ('config5_share_eres2netv2_bucketed', lambda: bucketed_run('eres2netv2_w96s4', dev, 64, 2))):
                     try:

@@ -35,7 +35,7 @@ extern "C" {
 #define MV_ERR_WORKSPACE (-4)
 #define MV_ERR_MISSING_TENSOR (-5)
 
-#define MV_ABI_VERSION 1
+#define MV_ABI_VERSION 2
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -163,7 +163,12 @@ typedef struct MvCamppCfg {
     int32_t growth_rate;   /* 32 */
     int32_t bn_size;       /* 4 */
     int32_t init_channels; /* 128 */
+    int32_t head_precision; /* MV_CAMPP_HEAD_AUTO (0): decided at create from three probe utterances; _F16 / _F32 pin it -- e.g. the
+                             * same value on every rank of a distributed run, so that enrol and verify embeddings share one numerics */
 } MvCamppCfg;
+#define MV_CAMPP_HEAD_AUTO 0
+#define MV_CAMPP_HEAD_F16 1
+#define MV_CAMPP_HEAD_F32 2
 int mv_campp_create(const MvCamppCfg* cfg, const MvTensorRef* tensors, int32_t num_tensors, MvModel** out);
 
 /* TDNN.forward (mvector/models/tdnn.py:46-68), pooling_type "ASP". */
@@ -194,9 +199,12 @@ int mv_model_destroy(MvModel* m);
 int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
 /* Model-specific facts (tests, logs).  Keys:
  *   MV_INFO_CAMPP_HEAD_F32     1.0 when the CAM++ handle evaluates its FCM head on fp32 maps (conv2d kernels), 0.0 for the fp16 head;
- *   MV_INFO_CAMPP_CALIBRATION  1 - cos between the embeddings of the two heads on the handle's calibration input (mv_campp_create). */
+ *   MV_INFO_CAMPP_CALIBRATION  largest 1 - cos between the embeddings of the two heads over the handle's three probe utterances
+ *                              (mv_campp_create; -1 when MvCamppCfg.head_precision pinned the head);
+ *   MV_INFO_CAMPP_PROBE0 + p   the figure of probe p = 0..2 (white uniform / white bell-shaped / smooth voiced-like). */
 #define MV_INFO_CAMPP_HEAD_F32 1
 #define MV_INFO_CAMPP_CALIBRATION 2
+#define MV_INFO_CAMPP_PROBE0 3
 int mv_model_info(const MvModel* m, int32_t key, float* value);
 int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes);
 /* feats: [B, T, F] fp32 (the AudioFeaturizer output layout); emb: [B, embd_dim] fp32. */

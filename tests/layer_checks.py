@@ -333,6 +333,7 @@ CONV_CASES = [
     dict(k=1, dil=1, cin=320, cout=128, T=298, B=3, in_stats=True, y_f32=True, pre_act=0, affine=False),  # two tiles, ragged second one
     dict(k=1, dil=1, cin=72, cout=64, T=160, B=2, in_stats=True, extra_ld=0),                            # exact tile, partial K stage, fp16 out with epilogue
     dict(k=1, dil=1, cin=128, cout=128, T=1, B=5, in_stats=True, y_f32=True, pre_act=0, affine=False),    # single frame: std = sqrt(eps)
+    dict(k=1, dil=1, stride=2, pad_mode='zero', cin=128, cout=256, T=151, B=4, tile=256),   # persistent, 1x1 with a time stride: the double-buffer kernel's plain form (the ring kernel takes dense rows only)
 ]
 
 
@@ -439,7 +440,7 @@ FCM_CASES = [
 ]
 
 
-def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, seed=0):
+def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, seed=0, padded_out=False):
     """3x3 conv2d over (frequency, time) with 32 maps + folded BN bias + (1x1 shortcut | identity) + ReLU (campplus.py:221-292)."""
     g = torch.Generator().manual_seed(seed)
     Fout = (Fin - 1) // sf + 1
@@ -452,6 +453,9 @@ def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, 
     if strided_out:      # y[b, t, fo, co]
         y = torch.full((B, T, Fout, 32), float('nan')).half().to(device)
         sB, sF, sT = T * Fout * 32, 32, Fout * 32
+    elif padded_out:     # y[b, fo, t, co (+ 4 pad)]: rows 72 bytes apart -- not 16-byte aligned, the one-row-per-workgroup kernel's 8-byte stores
+        y = torch.full((B, Fout, T, 36), float('nan')).half().to(device)
+        sB, sF, sT = Fout * T * 36, T * 36, 36
     else:                # y[b, fo, t, co]
         y = torch.full((B, Fout, T, 32), float('nan')).half().to(device)
         sB, sF, sT = Fout * T * 32, T * 32, 32
@@ -469,6 +473,9 @@ def fcm_conv_case(cdll, device, B, Fin, T, sf, mode2, sf2=1, strided_out=False, 
         ref = ref + x2.double().permute(0, 3, 1, 2)[:, :, ::sf2][:, :, :Fout]
     ref = ref.clamp(min=0).permute(0, 3, 2, 1) if strided_out else ref.clamp(min=0).permute(0, 2, 3, 1)
     out = y.cpu().double()
+    if padded_out:
+        assert torch.isnan(out[..., 32:]).all(), 'wrote into the padding'
+        out = out[..., :32]
     assert torch.isfinite(out).all(), 'unwritten outputs'
     err = (out - ref).abs().max().item()
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), err   # the fp16 rounding of the stored result
@@ -606,7 +613,7 @@ def fbank_case(cdll, device, wav, ratio, method_args):
     return d.max().item()
 
 
-def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=None):
+def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=None, head=0):
     """Golden case through the native model handle (weights from the manifest, reference embedding from golden).  `info`: a dict
     that receives {key: mv_model_info(key)} for the keys it holds (CAM++: 1 = head on fp32 maps, 2 = creation-time calibration).
     `frames`: instead of the golden input, one seeded utterance of that many frames with the golden input's statistics, the reference
@@ -647,6 +654,7 @@ def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=N
         cfg = _hip.MvCamppCfg()
         cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 512)
         cfg.growth_rate, cfg.bn_size, cfg.init_channels = 32, 4, 128
+        cfg.head_precision = head   # MV_CAMPP_HEAD_AUTO (0) / _F16 (1) / _F32 (2)
         kind = 'campp'
     sd_dev = {k: v.to(device) for k, v in sd.items()}
     m = _hip.Model(kind, cfg, sd_dev, cdll=cdll)

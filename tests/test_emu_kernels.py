@@ -38,18 +38,6 @@ def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
 
 
-def test_emu_conv1d_double_buffer_persistent_kernel():
-    """MV_CONV_IMPL=double: the dense 1x1 layers on the double-buffer persistent kernel instead of the ring kernel (the switch is read
-    once per process, hence the subprocess; the default run above takes the ring kernel for cases 17 / 18)."""
-    import subprocess
-    import sys
-    code = ("import sys; sys.path[:0] = %r\n"
-            "import layer_checks as lc\nfrom emu_lib import emu_cdll\n"
-            "for idx in (12, 17, 22):\n    lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])\n") % (sys.path,)
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_IMPL='double'), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
 def test_emu_conv1d_rejects_bad_arguments():
     with pytest.raises(RuntimeError, match='reflect padding'):
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)
@@ -107,10 +95,9 @@ def test_emu_fbank_edge_cases():
 
 
 @pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~3 min under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_backbones_long_and_short_utterances)')
-def test_emu_campp_long_utterance_two_launch_dense_layers(monkeypatch):
+def test_emu_campp_long_utterance_two_launch_dense_layers():
     """T = 372 frames -> 186 strided frames: two chunks of 160, segments 0 / 1 split over the chunks (camdense.hip, long utterances)"""
-    monkeypatch.setenv('MV_CAMPP_HEAD', 'f16')
-    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short', frames=372)
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short', frames=372, head=1)
     assert rel < 1e-2
 
 
@@ -155,19 +142,17 @@ def test_emu_fcm_block_with_first_conv(idx):
     lc.fcm_block_c1_case(emu_cdll(), 'cpu', seed=50 + idx, **lc.FCM_BLOCK_C1_CASES[idx])
 
 
-def test_emu_fcm_block_balanced_narrow_tiles(monkeypatch):
-    """MV_FCM_BLOCK_NT=2: T = 200 becomes two tiles of 100 output positions (NT = 2, halo columns recomputed at the tile edge)"""
-    monkeypatch.setenv('MV_FCM_BLOCK_NT', '2')
-    lc.fcm_block_case(emu_cdll(), 'cpu', B=1, Fin=5, T=200, sf=2, seed=41)
-    lc.fcm_block_case(emu_cdll(), 'cpu', B=1, Fin=4, T=127, sf=1, seed=42)
-
-
 @pytest.mark.parametrize('idx', range(len(lc.FCM_CASES)))
 @pytest.mark.parametrize('impl', ['band', 'row'])
-def test_emu_fcm_conv3x3(idx, impl, monkeypatch):
-    """the band kernel (LDS ring of input rows, default) and the one-row-per-workgroup kernel (MV_FCM_IMPL=row)"""
-    monkeypatch.setenv('MV_FCM_IMPL', impl)
-    lc.fcm_conv_case(emu_cdll(), 'cpu', seed=idx, **lc.FCM_CASES[idx])
+def test_emu_fcm_conv3x3(idx, impl):
+    """the band kernel (LDS ring of input rows; 16-byte aligned output rows) and the one-row-per-workgroup kernel every other output layout
+    falls to (here: rows 72 bytes apart)"""
+    cfg = dict(lc.FCM_CASES[idx])
+    if impl == 'row':
+        if cfg.pop('strided_out', False):
+            pytest.skip('the padded layout of the row-kernel arm replaces the [B, T, F, 32] layout of this case')
+        cfg['padded_out'] = True
+    lc.fcm_conv_case(emu_cdll(), 'cpu', seed=idx, **cfg)
 
 
 def test_emu_ecapa_tiny_end_to_end():
@@ -176,21 +161,19 @@ def test_emu_ecapa_tiny_end_to_end():
 
 
 @pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~90 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
-def test_emu_campp_short_end_to_end(monkeypatch):
-    """fp16 head (forced: the creation-time calibration would run two more forwards under the emulator), then the fp32 head through the
+def test_emu_campp_short_end_to_end():
+    """fp16 head (pinned: the creation-time calibration would run six more forwards under the emulator), then the fp32 head through the
     conv2d kernels (frequency-only stride, residual epilogue, rows cast)"""
-    monkeypatch.setenv('MV_CAMPP_HEAD', 'f16')
-    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short')
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_short', head=1)
     assert rel < 1e-2
-    monkeypatch.setenv('MV_CAMPP_HEAD', 'f32')
     info = {1: None}
-    cd32, _ = lc.model_case(emu_cdll(), 'cpu', 'campp_short', max_batch=1, info=info)
+    cd32, _ = lc.model_case(emu_cdll(), 'cpu', 'campp_short', max_batch=1, info=info, head=2)
     assert info[1] == 1.0 and cd32 < 1e-5
 
 
-def test_emu_melspec_fft_kernel_and_dft_kernel(monkeypatch):
+def test_emu_melspec_fft_kernel_and_dft_kernel():
     """default geometry (n_fft 400, 128 mels) = melspec_tile_kernel: edge frames with reflect padding, a masked row, feature
-    rows beyond the LDS block (T = 241 > 212 rows) and fewer; MV_MELSPEC_IMPL=dft keeps the dense-DFT kernels alive"""
+    rows beyond the LDS block (T = 241 > 212 rows) and fewer; every n_fft that is neither 400 nor a power of two runs the dense-DFT kernels"""
     assert _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
     assert _hip.MelSpec(dict(n_fft=512), cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
     assert not _hip.MelSpec(dict(n_fft=600, win_length=600), cdll=emu_cdll()).info()['tile_kernel']   # neither 400 nor a power of two: dense DFT
@@ -198,9 +181,7 @@ def test_emu_melspec_fft_kernel_and_dft_kernel(monkeypatch):
     lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([0.71, 1.0]), {})          # T = 241: 212 rows in LDS, 29 through global
     lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :5000 + 3], None, {})                # T = 26, odd length
     lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :9000], None, dict(hop_length=160))  # other hop
-    monkeypatch.setenv('MV_MELSPEC_IMPL', 'dft')
-    assert not _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
-    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :6000], None, {})
+    lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :6000], None, dict(n_fft=600, win_length=600))   # dense DFT, default hop / mels
 
 
 def test_emu_melspec_default_and_masked():
@@ -221,7 +202,7 @@ def test_emu_melspec_other_geometry():
 def test_emu_melspec_pow2_kernel_readme_geometry():
     """the reference README's MelSpectrogram run (n_fft 1024, hop 320, 64 mels, f_max above Nyquist: README_en.md:263-269) and
     n_fft 512 with 128 mels (two mel passes), both on melspec_pow2_kernel: edge frames (reflect padding), a masked row, a ragged last
-    quad of frames; MV_MELSPEC_IMPL=dft keeps the dense-DFT kernels alive"""
+    quad of frames"""
     readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
     assert _hip.MelSpec(readme, cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
     wav = frontend.synth_waveforms(2, 7000, seed=14)
@@ -281,9 +262,9 @@ def test_emu_fbank_odd_window_length():
     lc.fbank_case(emu_cdll(), 'cpu', w, None, args)
 
 
-def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypatch):
-    """80 bins run fbank_tile_kernel: feature block in LDS up to 298 frames (3 s), second pass over global memory beyond
-    that (311 frames here); MV_FBANK_IMPL=generic keeps fbank_kernel for the same geometry.  All three against the oracle."""
+def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel():
+    """80 bins run fbank_tile_kernel: feature block in LDS up to 292 frames, second pass over global memory beyond that (311 frames
+    here); other mel geometries (23 bins, 40 bins) run fbank_kernel.  All against the oracle."""
     wav = frontend.synth_waveforms(2, 400 + 160 * 310, seed=23)
     ratio = torch.tensor([0.83, 1.0])
     assert _hip.Fbank(FB, cdll=emu_cdll()).info() == {'tile_kernel': True, 'pass_steps': (28, 12)}
@@ -291,9 +272,9 @@ def test_emu_fbank_tile_kernel_long_utterance_and_generic_kernel_agree(monkeypat
     lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, FB)              # tile kernel, no LDS block (T = 311)
     lc.fbank_case(emu_cdll(), 'cpu', wav[:, :48000], ratio, FB)   # tile kernel, LDS block at its largest (T = 298)
     lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :48160], None, FB)   # one frame more: back to the global second pass
-    monkeypatch.setenv('MV_FBANK_IMPL', 'generic')
-    assert not _hip.Fbank(FB, cdll=emu_cdll()).info()['tile_kernel']
-    lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB)
+    FB40 = dict(sample_frequency=16000, num_mel_bins=40)
+    assert not _hip.Fbank(FB40, cdll=emu_cdll()).info()['tile_kernel']
+    lc.fbank_case(emu_cdll(), 'cpu', wav[:1, :20000], ratio[:1], FB40)
 
 
 def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms():

@@ -28,7 +28,7 @@ def product_lib():
 def test_gpu_library_is_the_hip_build():
     from mvector import _hip
     lib = product_lib()
-    assert lib.mv_abi_version() == 1
+    assert lib.mv_abi_version() == 2
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
@@ -52,29 +52,19 @@ def test_gpu_conv1d(idx):
     lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])
 
 
-@pytest.mark.parametrize('impl', ['ring', 'double'])
-def test_gpu_conv1d_persistent_walks_many_tiles(impl):
-    """MV_CONV_PERSIST_BLOCKS=8: eight resident workgroups walk 5-10 tiles each (full tiles, a ragged last one, 2-3 channel tiles), so the
-    tile-boundary machinery of the persistent kernels (epilogue inside the next tile's first stage, transfers requested ahead of the
-    output stores and the counted wait behind them, parameter reload when the channel tile changes) runs on the device."""
+def test_gpu_conv1d_persistent_walks_many_tiles():
+    """MV_CONV_PERSIST_BLOCKS=8 (test hook, read once per process -> subprocess): eight resident workgroups walk 5-10 tiles each (full tiles, a
+    ragged last one, 2-3 channel tiles), so the tile-boundary machinery of the persistent kernels (epilogue inside the next tile's first stage,
+    transfers requested ahead of the output stores and the counted wait behind them, parameter reload when the channel tile changes) runs on the
+    device: dense 1x1 layers on the ring kernel, a k = 3 layer on the double-buffer kernel."""
     code = ("import sys; sys.path[:0] = %r\n"
             "import layer_checks as lc\nfrom mvector import _hip\n"
             "for seed, cfg in enumerate([dict(k=1, dil=1, cin=256, cout=512, T=298, B=16, tile=256),\n"
             "                            dict(k=1, dil=1, cin=1024, cout=768, T=300, B=11, tile=256),\n"
+            "                            dict(k=3, dil=2, cin=256, cout=512, T=298, B=16, tile=256),\n"
             "                            dict(k=1, dil=1, cin=128, cout=256, T=64, B=40, tile=256, affine=False)]):\n"
             "    lc.conv1d_case(_hip.lib(), 'cuda', seed=seed, **cfg)\n") % (sys.path,)
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_IMPL=impl, MV_CONV_PERSIST_BLOCKS='8'),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
-def test_gpu_conv1d_double_buffer_persistent_kernel():
-    """MV_CONV_IMPL=double (read once per process -> subprocess): the persistent 1x1 cases and the c=1024 golden on the double-buffer kernel"""
-    code = ("import sys; sys.path[:0] = %r\n"
-            "import layer_checks as lc\nfrom mvector import _hip\n"
-            "for idx in (12, 17, 22):\n    lc.conv1d_case(_hip.lib(), 'cuda', seed=idx, **lc.CONV_CASES[idx])\n"
-            "cd, rel = lc.model_case(_hip.lib(), 'cuda', 'ecapa_c1024')\nassert cd < 1e-4, cd\n") % (sys.path,)
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_IMPL='double'), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_PERSIST_BLOCKS='8'), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
@@ -163,82 +153,6 @@ def test_gpu_bn_relu_rows():
     lc.bn_relu_rows_case(product_lib(), DEV, rows=38144, C=1024, ldx=1024, ldy=1024, seed=3)
 
 
-@pytest.mark.parametrize('mode', ['load', 'pre'])
-def test_gpu_campp_transit_forms_agree_with_the_golden(mode, monkeypatch):
-    """the transit layers with the pre-activation applied on load (register path) and written out once (direct path): both meet the golden"""
-    monkeypatch.setenv('MV_CAMPP_TRANSIT', mode)
-    cd, _ = lc.model_case(product_lib(), DEV, 'campp')
-    assert cd < 1e-4, cd
-
-
-def test_gpu_fbank_golden_fixed_and_ragged():
-    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
-    wav = frontend.synth_waveforms(4, 48000)
-    from mvector import _hip
-    fb = _hip.Fbank(FB)
-    out = fb(wav.to(DEV)).cpu().numpy()
-    d = np.abs(out - z['fbank'])
-    assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
-    lens = z['lens']
-    wav_var = torch.zeros(4, 48000)
-    for i, n in enumerate(lens):
-        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
-    outv = fb(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy()
-    dv = np.abs(outv - z['fbank_var'])
-    assert dv.max() < 2e-3 and dv.mean() < 2e-5, (dv.max(), dv.mean())
-    for i, n in enumerate(lens):  # frames beyond round_half_even(ratio*T) are exactly zero (Q2/Q3)
-        ml = int(torch.round(torch.tensor(n / 48000, dtype=torch.float32) * 298).item())
-        assert np.all(outv[i, ml:] == 0) and np.any(outv[i, ml - 1] != 0)
-
-
-def test_gpu_featurizer_matches_reference_wrapper_golden():
-    """AudioFeaturizer.forward on the HIP path against tests/golden/featurizer_ref.npz = the REFERENCE's own featurizer.py wrapper
-    (KaldiFbank loop, transposes, CMN, torch.round mask) run by oracle/make_golden.py under a stub torchaudio (a3 pin)."""
-    from mvector.data_utils.featurizer import AudioFeaturizer
-    z = np.load(os.path.join(GOLDEN, 'featurizer_ref.npz'))
-    wav = frontend.synth_waveforms(4, 48000)
-    wav_var = torch.zeros(4, 48000)
-    for i, n in enumerate(z['lens']):
-        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
-    ratio, half = torch.from_numpy(z['ratio']).to(DEV), torch.from_numpy(z['half']).to(DEV)
-    fz = AudioFeaturizer('Fbank', method_args=FB)
-
-    def close(got, want):
-        d = np.abs(got - want)
-        assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
-        # masked frames are exactly zero, frame by frame, on both sides (Q3: the edge sits where torch.round puts it)
-        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
-    out = fz(wav[:2].to(DEV))
-    assert out.is_cuda and out.dtype == torch.float32
-    close(out.cpu().numpy(), z['fbank'])
-    close(fz(wav_var.to(DEV), ratio).cpu().numpy(), z['fbank_var'])
-    close(fz(wav_var.to(DEV), half).cpu().numpy()[:, :24], z['fbank_half'])
-    close(fz(wav[1, :16000].to(DEV)).cpu().numpy(), z['fbank_1d'])  # 1-D input is unsqueezed (featurizer.py:63-64)
-    mz = AudioFeaturizer('MelSpectrogram', method_args={})
-    scale = float(np.abs(z['mel']).max())
-    for got, want in ((mz(wav[:2].to(DEV)), z['mel']), (mz(wav_var.to(DEV), ratio)[2:], z['mel_var']),
-                      (mz(wav_var[:1].to(DEV), half[:1]), z['mel_half'])):
-        got = got.cpu().numpy()
-        assert np.abs(got - want).max() < 2e-4 * scale
-        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
-    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
-    got = AudioFeaturizer('MelSpectrogram', method_args=readme)(wav[:1].to(DEV)).cpu().numpy()
-    assert np.abs(got - z['mel_readme']).max() < 2e-4 * float(np.abs(z['mel_readme']).max())
-
-
-def test_gpu_fbank_ragged_strides_and_edges():
-    wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)
-    wav[2, 9000:] = 0
-    lc.fbank_case(product_lib(), DEV, wav, torch.tensor([1.0, 0.61, 9000 / 16037]), FB)
-    from mvector import _hip
-    fb = _hip.Fbank(FB)
-    assert fb(torch.zeros(2, 399, device=DEV)).shape == (2, 0, 80)
-    assert fb(torch.zeros(1, 1200, device=DEV)).abs().max().item() < 1e-5
-    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
-    real = torch.from_numpy(z['pcm16'].astype(np.float32) / 32768.0).to(DEV)
-    assert np.abs(fb(real).cpu().numpy() - z['fbank']).max() < 2e-3
-
-
 def test_gpu_fbank_full_batch_properties():
     """BASELINE size (256 x 3 s): size-independent properties + EVERY row against the oracle."""
     from mvector import _hip
@@ -300,31 +214,6 @@ def test_gpu_cosine_properties_full_size():
     assert np.abs(s[:64].cpu().numpy() - ref).max() < 2e-6
 
 
-def test_gpu_fused_time_statistics_model_path():
-    """MV_FUSE_STATS=1: SE squeeze and ASP global statistics come out of the tdnn2 / mfa epilogues (needs a batch that fills
-    the persistent kernel).  The knob is read once per process, hence the subprocess."""
-    code = (
-        "import sys, torch\n"
-        "sys.path[:0] = [%r, %r, %r]\n"
-        "from helpers import load_case, cos_dist\n"
-        "from oracle import frontend, models as omodels\n"
-        "from mvector.data_utils.featurizer import AudioFeaturizer\n"
-        "from mvector.models import EcapaTdnn\n"
-        "man, sd, _, _, _ = load_case('ecapa_c1024')\n"
-        "m = EcapaTdnn(**man['kwargs']); m.load_state_dict(sd); m.eval().cuda()\n"
-        "FB = dict(sample_frequency=16000, num_mel_bins=80)\n"
-        "wav = frontend.synth_waveforms(256, 48000)\n"
-        "emb = m(AudioFeaturizer('Fbank', method_args=FB)(wav.cuda()))\n"
-        "ref = omodels.ecapa_tdnn(sd, frontend.audio_featurizer(wav[:2], None, 'Fbank', FB))\n"
-        "d = cos_dist(emb[:2].cpu(), ref).max().item()\n"
-        "assert d < 1e-4, d\n"
-        "print('fused-stats parity', d)\n"
-    ) % (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd'))
-    env = dict(os.environ, MV_FUSE_STATS='1')
-    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
 @pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'tdnn', 'campp', 'campp_short'])
 def test_gpu_native_model_matches_reference_golden(case):
     cd, rel = lc.model_case(product_lib(), DEV, case)
@@ -339,21 +228,35 @@ def test_gpu_fp16_backbone_stress_golden_ecapa():
     print(f'ecapa_stress: 1 - cos = {cd:.3e}, max rel err {rel:.3e}')
 
 
-def test_gpu_campp_stress_golden_takes_the_fp32_head(monkeypatch):
+def test_gpu_campp_stress_golden_takes_the_fp32_head():
     """The same stress on CAM++.  The FCM head of this checkpoint amplifies a relative perturbation ~100 x: with
     fp16 maps and tap matrices the embedding lands at 1 - cos = 4e-4, every one of the head's ~20 rounding sites contributing
-    (tests/budget_campp.py, profiles/r06_campp_error_budget.log).  The handle measures that at creation -- both heads embed one fixed
-    utterance -- and takes the fp32 head (conv2d kernels): the golden is met at the north-star bar.  Forced onto the fp16 head the same
-    checkpoint shows the miss the calibration saw."""
-    info = {1: None, 2: None}
+    (tests/budget_campp.py, profiles/r06_campp_error_budget.log).  The handle measures that at creation -- both heads embed three probe
+    utterances -- and takes the fp32 head (conv2d kernels): the golden is met at the north-star bar.  Pinned onto the fp16 head
+    (MvCamppCfg.head_precision) the same checkpoint shows the miss the calibration saw."""
+    info = {1: None, 2: None, 3: None, 4: None, 5: None}
     cd, rel = lc.model_case(product_lib(), DEV, 'campp_stress', tol=1e-4, info=info)
-    print(f'campp_stress: head fp32 = {info[1]}, calibration 1 - cos = {info[2]:.3e}; golden 1 - cos = {cd:.3e}, max rel err {rel:.3e}')
-    assert info[1] == 1.0 and info[2] > 5e-6
-    monkeypatch.setenv('MV_CAMPP_HEAD', 'f16')
-    info16 = {1: None}
-    cd16, _ = lc.model_case(product_lib(), DEV, 'campp_stress', tol=1e-3, info=info16)
-    assert info16[1] == 0.0 and cd16 > cd
-    print(f'campp_stress forced onto the fp16 head: 1 - cos = {cd16:.3e}')
+    print(f'campp_stress: head fp32 = {info[1]}, calibration 1 - cos = {info[2]:.3e} (probes {info[3]:.2e} {info[4]:.2e} {info[5]:.2e}); '
+          f'golden 1 - cos = {cd:.3e}, max rel err {rel:.3e}')
+    assert info[1] == 1.0 and info[2] > 5e-6 and info[2] == max(info[3], info[4], info[5])
+    info16 = {1: None, 2: None}
+    cd16, _ = lc.model_case(product_lib(), DEV, 'campp_stress', tol=1e-3, info=info16, head=1)
+    assert info16[1] == 0.0 and info16[2] == -1.0 and cd16 > cd
+    print(f'campp_stress pinned onto the fp16 head: 1 - cos = {cd16:.3e}')
+    assert info[2] > cd16 / 4, 'the probes under-read the miss on the test input by more than 4 x'
+
+
+@pytest.mark.parametrize('case', ['campp_mid_a', 'campp_mid_b'])
+def test_gpu_campp_borderline_checkpoints_meet_the_bar_under_the_automatic_choice(case):
+    """checkpoints BETWEEN the trained-like and the stress golden (BatchNorm statistics interpolated between independent draws and the
+    train-mode calibration, oracle/make_golden.py `mid`): the fp16 head misses the embedding by a figure around the 5e-6 threshold (a) and just
+    below the 1e-4 bar (b).  Whatever head the probes pick, the golden must be met at 1e-4; pinned to either head the figures are printed."""
+    info = {1: None, 2: None, 3: None, 4: None, 5: None}
+    cd, _ = lc.model_case(product_lib(), DEV, case, tol=1e-4, info=info)
+    cd16, _ = lc.model_case(product_lib(), DEV, case, tol=1e-3, head=1)
+    cd32, _ = lc.model_case(product_lib(), DEV, case, tol=1e-4, head=2)
+    print(f'{case}: automatic head fp32 = {info[1]} (probes {info[3]:.2e} {info[4]:.2e} {info[5]:.2e}) 1 - cos {cd:.2e}; fp16 head {cd16:.2e}, fp32 head {cd32:.2e}')
+    assert info[1] == 1.0 or cd16 < 1e-4
 
 
 def test_gpu_model_info_is_model_specific():
@@ -364,15 +267,14 @@ def test_gpu_model_info_is_model_specific():
 
 
 @pytest.mark.parametrize('case', ['campp', 'campp_short'])
-def test_gpu_campp_well_conditioned_checkpoints_keep_the_fp16_head(case, monkeypatch):
-    """trained-like BatchNorm gains: the calibration difference is ~1e-7, the handle keeps the fp16 head (the fast one); forced onto
-    the fp32 head the golden is met as well (the two heads are the same function)"""
+def test_gpu_campp_well_conditioned_checkpoints_keep_the_fp16_head(case):
+    """trained-like BatchNorm gains: the calibration difference is ~1e-7 on every probe, the handle keeps the fp16 head (the fast one); pinned
+    onto the fp32 head the golden is met as well (the two heads are the same function)"""
     info = {1: None, 2: None}
     cd, _ = lc.model_case(product_lib(), DEV, case, info=info)
     assert info[1] == 0.0 and 0.0 <= info[2] < 5e-6, info
-    monkeypatch.setenv('MV_CAMPP_HEAD', 'f32')
     info32 = {1: None}
-    cd32, _ = lc.model_case(product_lib(), DEV, case, info=info32)
+    cd32, _ = lc.model_case(product_lib(), DEV, case, info=info32, head=2)
     assert info32[1] == 1.0 and cd32 < 1e-5, (cd32, info32)
     print(f'{case}: fp16 head 1 - cos {cd:.2e} (calibration {info[2]:.2e}), fp32 head {cd32:.2e}')
 
@@ -663,9 +565,15 @@ FCM_GPU_CASES = lc.FCM_CASES + [
 
 @pytest.mark.parametrize('idx', range(len(FCM_GPU_CASES)))
 @pytest.mark.parametrize('impl', ['band', 'row'])
-def test_gpu_fcm_conv3x3(idx, impl, monkeypatch):
-    monkeypatch.setenv('MV_FCM_IMPL', impl)
-    lc.fcm_conv_case(product_lib(), DEV, seed=idx, **FCM_GPU_CASES[idx])
+def test_gpu_fcm_conv3x3(idx, impl):
+    """the band kernel (16-byte aligned output rows) and the one-row-per-workgroup kernel that takes every other output layout (here: rows
+    72 bytes apart)"""
+    cfg = dict(FCM_GPU_CASES[idx])
+    if impl == 'row':
+        if cfg.pop('strided_out', False):
+            pytest.skip('the padded layout of the row-kernel arm replaces the [B, T, F, 32] layout of this case')
+        cfg['padded_out'] = True
+    lc.fcm_conv_case(product_lib(), DEV, seed=idx, **cfg)
 
 
 FCM_BLOCK_GPU_CASES = lc.FCM_BLOCK_CASES + [
@@ -674,6 +582,7 @@ FCM_BLOCK_GPU_CASES = lc.FCM_BLOCK_CASES + [
     dict(B=300, Fin=40, T=298, sf=2),                    # more workgroups than CUs, one band each: layer2.block0
     dict(B=2, Fin=20, T=1000, sf=1),                     # 10 s: four time tiles
     dict(B=260, Fin=20, T=150, sf=1, strided_out=True),  # NT = 3: the deepest ring
+    dict(B=3, Fin=10, T=200, sf=2),                      # NT = 4
 ]
 
 
@@ -683,53 +592,11 @@ def test_gpu_fcm_block(idx):
     lc.fcm_block_case(product_lib(), DEV, seed=idx, **FCM_BLOCK_GPU_CASES[idx])
 
 
-@pytest.mark.parametrize('nt', ['3', '4'])
-def test_gpu_fcm_block_narrow_tiles(nt, monkeypatch):
-    """MV_FCM_BLOCK_NT caps the time tile (A/B knob): two balanced tiles with halo columns for T = 298"""
-    monkeypatch.setenv('MV_FCM_BLOCK_NT', nt)
-    lc.fcm_block_case(product_lib(), DEV, B=3, Fin=10, T=298, sf=2, seed=31)
-    lc.fcm_block_case(product_lib(), DEV, B=3, Fin=10, T=298, sf=1, seed=32)
-
-
-def test_gpu_campp_block_kernel_and_layer_kernels_agree(monkeypatch):
-    """MV_CAMPP_BLOCK=0 (one launch per dense layer) and the default (cam_dense_block_kernel: all layers of a block in one launch) compute the
-    same arithmetic in the same order: bit-identical embeddings, also on a batch larger than the chip (300 workgroups)"""
-    import mvector.models as M
-    man, sd, x, _, _ = load_case('campp')
-    m = M.CAMPPlus(**man['kwargs'])
-    m.load_state_dict(sd)
-    m.eval().to(DEV)
-    xb = x.repeat(150, 1, 1)[:300].to(DEV) * torch.linspace(0.5, 1.5, 300, device=DEV)[:, None, None]
-    e1 = m(xb).cpu()
-    monkeypatch.setenv('MV_CAMPP_BLOCK', '0')
-    e0 = m(xb).cpu()
-    assert torch.equal(e0, e1) and torch.isfinite(e1).all()
-
-
-def test_gpu_campp_fused_and_unfused_fcm_agree(monkeypatch):
-    """MV_FCM_FUSED=0 (two launches per BasicResBlock, intermediate map in HBM) and the default (one launch) on the same golden"""
-    cd1, _ = lc.model_case(product_lib(), DEV, 'campp')
-    monkeypatch.setenv('MV_FCM_FUSED', '0')
-    cd0, _ = lc.model_case(product_lib(), DEV, 'campp')
-    assert cd1 < 1e-4 and cd0 < 1e-4, (cd1, cd0)
-
-
 @pytest.mark.parametrize('idx', range(len(lc.FCM_BLOCK_C1_CASES) + 2))
 def test_gpu_fcm_block_with_first_conv(idx):
     """head.conv1 evaluated inside the first block's kernel: the emulator's cases + the product shape (80 bins x 298 frames) and a ragged one"""
     cases = lc.FCM_BLOCK_C1_CASES + [dict(B=5, F=80, T=298), dict(B=2, F=41, T=621)]
     lc.fcm_block_c1_case(product_lib(), DEV, seed=60 + idx, **cases[idx])
-
-
-def test_gpu_campp_first_conv_inside_and_outside_the_block_agree(monkeypatch):
-    """MV_FCM_C1=0 (head.conv1 as its own launch, fp32 weights, map in HBM) and the default (inside the first block's kernel, fp16 weights)
-    on the same goldens: both inside the tolerance"""
-    for case in ('campp', 'campp_short'):
-        monkeypatch.delenv('MV_FCM_C1', raising=False)
-        cd1, _ = lc.model_case(product_lib(), DEV, case)
-        monkeypatch.setenv('MV_FCM_C1', '0')
-        cd0, _ = lc.model_case(product_lib(), DEV, case)
-        assert cd1 < 1e-4 and cd0 < 1e-4, (case, cd1, cd0)
 
 
 @pytest.mark.parametrize('cfg', [dict(width=64, T=45, dil=3), dict(width=128, T=298, dil=4, B=5), dict(width=64, T=298, dil=2, B=3),
@@ -791,23 +658,22 @@ def test_gpu_backbones_long_and_short_utterances(case, T):
     assert d < 1e-4, d
 
 
-def test_gpu_campp_long_utterance_forms_agree(monkeypatch):
-    """CAM++ beyond 3.2 s: the two-launch dense layers (default) and the five-launch form (MV_CAMPP_LONG=0) against the oracle and each other"""
+def test_gpu_campp_long_utterance_two_launch_dense_layers():
+    """CAM++ beyond 3.2 s: the two-launch dense layers over even chunks (camdense.hip) against the oracle, in a batch and alone (the chunk
+    count follows the batch size; the embeddings agree to rounding)"""
     from mvector import models as pmodels
     man, sd, x, _, _ = load_case('campp')
     g = torch.Generator().manual_seed(5)
     feats = torch.randn(3, 700, x.shape[2], generator=g) * x.std() + x.mean()
     ref = omodels.FORWARDS[man['model']](sd, feats)
-    out = {}
-    for mode in ('1', '0'):
-        monkeypatch.setenv('MV_CAMPP_LONG', mode)
-        model = getattr(pmodels, man['model'])(**man['kwargs'])
-        model.load_state_dict(sd)
-        model.eval().to(DEV)
-        with torch.no_grad():
-            out[mode] = model(feats.to(DEV)).cpu()
-        assert cos_dist(out[mode], ref).max().item() < 1e-4
-    assert cos_dist(out['1'], out['0']).max().item() < 1e-6
+    model = getattr(pmodels, man['model'])(**man['kwargs'])
+    model.load_state_dict(sd)
+    model.eval().to(DEV)
+    with torch.no_grad():
+        out = model(feats.to(DEV)).cpu()
+        one = model(feats[:1].to(DEV)).cpu()
+    assert cos_dist(out, ref).max().item() < 1e-4
+    assert cos_dist(one, out[:1]).max().item() < 1e-6
 
 
 def test_gpu_rccl_one_rank_group_runs_the_exchange_step():

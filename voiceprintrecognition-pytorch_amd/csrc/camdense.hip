@@ -823,6 +823,7 @@ int cam_dense_long_launch(half_t* x, int64_t ldx, int B, int T2, int cin, const 
     MV_REQUIRE(cam_dense_long_supported(T2, cin, CD_BN, CD_G, dil, seg_len), "cam_dense_long: unsupported geometry");
     MV_REQUIRE(ldx >= cin + CD_G && (ldx % 8) == 0, "cam_dense_long: the row must hold the inputs and 32 new channels (16-byte aligned chunks)");
     MV_REQUIRE(hws != nullptr && hpart != nullptr && (reinterpret_cast<uintptr_t>(hws) & 15) == 0, "cam_dense_long: workspace");
+    MV_REQUIRE(B <= 65535, "cam_dense_long: batch too large for one launch (grid.y)");
     static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
     int smem_set_slot;
     if (device_once_pending(smem_set, &smem_set_slot)) {

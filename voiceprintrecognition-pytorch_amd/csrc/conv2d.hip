@@ -328,18 +328,8 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const int nblk = d.cout16 / 16;
     // 1x1 kernel: at most 4 blocks of 16 channels per workgroup -- 124 VGPRs = 4 waves per SIMD instead of 2 at 8 blocks, which
     // hides more of the operand latency than reading the B operands once more from L2 costs (ERes2NetV2-m32 6.56 k -> 6.86 k
-    // utt/s; 2 blocks: 6.62 k).  MV_CONV2D_NB1X1 overrides for measurements.
-    static int nb_cap_1x1 = -1;
-    if (nb_cap_1x1 < 0) {
-        const char* e = std::getenv("MV_CONV2D_NB1X1");
-        nb_cap_1x1 = e != nullptr && std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 4;
-    }
-    static int nb_cap_3x3 = -1;
-    if (nb_cap_3x3 < 0) {
-        const char* e = std::getenv("MV_CONV2D_NB3X3");
-        nb_cap_3x3 = e != nullptr && std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 8;
-    }
-    const int cap = d.ks == 1 ? nb_cap_1x1 : nb_cap_3x3;
+    // utt/s; 2 blocks: 6.62 k).  The 3x3 kernel keeps up to 8 blocks.
+    const int cap = d.ks == 1 ? 4 : 8;
     const int ctiles = (nblk + cap - 1) / cap;
     const int nb = (nblk + ctiles - 1) / ctiles;
     const int nsegw = (a.Wo + 15) / 16;

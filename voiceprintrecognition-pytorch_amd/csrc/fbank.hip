@@ -748,8 +748,8 @@ struct MvFbank {
     float* d_melb = nullptr;
     mv::FbankTables tab;
     size_t smem_bytes = 0;
-    int waves = 15;  // fbank_kernel: workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance).  Knob: MV_FBANK_WAVES = 8 | 12 | 15
-    bool tile_kernel = false;  // the mel geometry matches an instantiation of fbank_tile_kernel (MV_FBANK_IMPL=generic turns it off)
+    int waves = 15;  // fbank_kernel: workgroup size in waves (15 waves x 5 quads = the 75 quads of a 3 s utterance); 12 / 8 when a long mel table leaves less LDS
+    bool tile_kernel = false;  // the mel geometry matches an instantiation of fbank_tile_kernel (every other geometry: fbank_kernel)
 };
 
 namespace {
@@ -935,10 +935,6 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     tab.tw256 = h->d_tw256;
     tab.tw512 = h->d_tw512;
     tab.melb = h->d_melb;
-    if (const char* e = getenv("MV_FBANK_WAVES")) {
-        const int w = atoi(e);
-        if (w == 8 || w == 12 || w == 15) h->waves = w;
-    }
     auto lds_need = [&](int waves) { return ((size_t)waves * 4 * mv::FB_SLOT_FLOATS + 3 * 512 + melb.size()) * sizeof(float); };
     if (lds_need(h->waves) > 160 * 1024 && h->waves > 12) h->waves = 12;  // a long mel table leaves room for fewer frame slots
     if (lds_need(h->waves) > 160 * 1024) h->waves = 8;
@@ -952,9 +948,6 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_kernel");
     }
     h->tile_kernel = fbank_tile_geometry_ok(h);
-    if (const char* e = getenv("MV_FBANK_IMPL")) {  // measurement knob: "generic" keeps fbank_kernel for every geometry
-        if (strcmp(e, "generic") == 0) h->tile_kernel = false;
-    }
     if (h->tile_kernel && (fbank_tile_set_smem<13, true>() != hipSuccess || fbank_tile_set_smem<13, false>() != hipSuccess ||
                            fbank_tile_set_smem<16, true>() != hipSuccess || fbank_tile_set_smem<16, false>() != hipSuccess)) {
         mv_fbank_destroy(h);

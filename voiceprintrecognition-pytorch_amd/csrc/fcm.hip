@@ -459,12 +459,6 @@ static int fcm_band_launch_ni(const FcmConvArgs& a, int n_ttiles, hipStream_t st
     return fcm_band_launch_one<NI, 1, false>(a, n_ttiles, stream);
 }
 
-// MV_FCM_IMPL=row keeps the one-row-per-workgroup kernel (A/B runs); read per call, not cached
-static bool fcm_band_enabled() {
-    const char* e = getenv("MV_FCM_IMPL");
-    return e == nullptr || strcmp(e, "row") != 0;
-}
-
 int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F2, int sf2, int mode2, const half_t* w,
                        const float* bias, half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int B, int T, int Fout,
                        hipStream_t stream) {
@@ -492,7 +486,7 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
     // band kernel: 16-byte stores need 8-map alignment of the output rows; the residual conv is never strided (BasicResBlock)
     const bool band_ok = (sf == 1 || sf == 2) && (mode2 == 0 || sf == 1) && y_sB % 8 == 0 && y_sF % 8 == 0 && y_sT % 8 == 0 &&
                          (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (int64_t)T * FCM_C * (int64_t)(Fin > F2 ? Fin : F2) < ((int64_t)1 << 31);
-    if (band_ok && fcm_band_enabled()) {
+    if (band_ok) {  // (else: the one-row-per-workgroup kernel below, 8-byte stores, any 4-element-aligned output layout)
         // time tiles of 64 * NI frames, NI <= 5: as few tiles as possible, then the smallest NI that covers T
         const int n16 = (int)ceil_div(T, 16);
         const int n_ttiles = (int)ceil_div(n16, 20);

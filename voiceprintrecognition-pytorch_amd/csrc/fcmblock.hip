@@ -572,12 +572,8 @@ int fcm_block_launch(const half_t* x, int Fin, int sf, const half_t* w1, const f
     a.Fout = (Fin - 1) / sf + 1;
     a.shortcut = shortcut;
     // time tiles: as few as possible (every tile recomputes one column of mid halo per side), equal shares, then the smallest NT
-    // that covers a share (+ 2 halo columns).  MV_FCM_BLOCK_NT caps NT (A/B runs: narrower tiles = deeper ring).
-    int nt_max = 5;
-    if (const char* e = getenv("MV_FCM_BLOCK_NT")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 5) nt_max = v;
-    }
+    // that covers a share (+ 2 halo columns)
+    constexpr int nt_max = 5;
     const int n_ttiles = (int)ceil_div(T, 64 * nt_max - 2);
     a.tile_out = (int)ceil_div(T, n_ttiles);
     const int nt = (int)ceil_div(a.tile_out + 2, 64);

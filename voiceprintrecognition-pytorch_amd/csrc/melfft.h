@@ -4,9 +4,9 @@
 
 namespace mv {
 
-// waves per workgroup (melfft_waves()): 4 = prefetch form, ~380 registers, one wave per SIMD; 8 = no prefetch, 232 registers, two per SIMD;
-// 12 = 168-register cap, 36 spilled.  README geometry, 256 x 3 s (profiles/r09a_melspec_pow2_waves_ab.log): 107.6 / 70.1 / 87.1 us
-constexpr int MF_WAVES_DEFAULT = 8;
+// waves per workgroup: 8 = no prefetch, 232 registers, two per SIMD (measured against 4 = prefetch form, ~380 registers, one wave per SIMD, and
+// 12 = 168-register cap, 36 spilled.  README geometry, 256 x 3 s (profiles/r09a_melspec_pow2_waves_ab.log): 70.1 / 107.6 / 87.1 us)
+constexpr int MF_WAVES = 8;
 constexpr int MF_ROW = 65;                          // complex elements per transpose row: [4 frames][16 lanes] + 1 pad
 constexpr int MF_PSTR = 520;                        // floats between the power rows of the wave's four frames (513 bins + pad)
 constexpr int MF_SLOT_FLOATS = 16 * MF_ROW * 2;     // 2080 floats per wave: 16 transpose rows = 4 power rows
@@ -26,7 +26,6 @@ struct MelFftArgs {
     MelPlan plan;
 };
 
-int melfft_waves();
 size_t melfft_fixed_lds_bytes();
 int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream);
 

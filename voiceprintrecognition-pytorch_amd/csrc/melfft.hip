@@ -70,11 +70,9 @@ __device__ __forceinline__ void split_pair(cplx za, cplx zb, float wc, float ws,
     p_hi = 0.25f * (br * br + bi * bi);
 }
 
-// WAVES per workgroup and whether the next quad's samples are PREFETCHed into a second register set (~190 registers: one wave per SIMD)
-// or loaded at the top of the quad (~130: two or three waves per SIMD hide the latency for each other)
-template <int WAVES, bool PREFETCH>
-__global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) {
-    constexpr int MF_WAVES = WAVES;
+// MF_WAVES = 8 waves per workgroup, the quad's samples loaded at the top of the quad (two waves per SIMD hide the latency for each other:
+// README geometry 70 us; a second register set for a prefetched quad = one wave per SIMD 108 us, 12 waves with 36 spills 87 us: r09a)
+__global__ __launch_bounds__(MF_WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) {
     constexpr int THREADS = MF_WAVES * 64;
     MV_DYN_SMEM(smem);
     // (the tables come FIRST: their reads are base + compile-time offset, and an LDS offset is a 16-bit immediate -- behind the 66 KB of
@@ -181,7 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) 
     };
     // the next quad's samples are requested as soon as this quad's are windowed (two register sets, loop unrolled by two): their
     // latency runs under the transform (one wave per SIMD: nobody else hides it)
-    auto process_quad = [&](int q, cplx (&ev)[16], cplx (&od)[16], cplx (&ev_next)[16], cplx (&od_next)[16]) __attribute__((always_inline)) {
+    auto process_quad = [&](int q, cplx (&ev)[16], cplx (&od)[16]) __attribute__((always_inline)) {
         // window (zero beyond n_fft: the frame is zero-extended to 1024 samples)
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
@@ -190,8 +188,6 @@ __global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) 
             ev[h] = cmul_elem(ev[h], we[0], we[1]);
             od[h] = cmul_elem(od[h], wo[0], wo[1]);
         }
-        if constexpr (PREFETCH)
-            if (q + MF_WAVES < nquads) load_quad(q + MF_WAVES, ev_next, od_next);
         // ---- Y[k1], k1 = 0..31: fft32 = two fft16 + radix-2 ----
         fft16(ev);
         fft16(od);
@@ -325,18 +321,11 @@ __global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) 
             }
         }
     };
-    if constexpr (PREFETCH) {
-        cplx ea[16], oa[16], eb[16], ob[16];
-        if (wave < nquads) load_quad(wave, ea, oa);
-        for (int q = wave; q < nquads; q += 2 * MF_WAVES) {
-            process_quad(q, ea, oa, eb, ob);
-            if (q + MF_WAVES < nquads) process_quad(q + MF_WAVES, eb, ob, ea, oa);
-        }
-    } else {
+    {
         cplx ea[16], oa[16];
         for (int q = wave; q < nquads; q += MF_WAVES) {
             load_quad(q, ea, oa);
-            process_quad(q, ea, oa, ea, oa);
+            process_quad(q, ea, oa);
         }
     }
 
@@ -374,38 +363,18 @@ __global__ __launch_bounds__(WAVES * 64) void melspec_pow2_kernel(MelFftArgs a) 
     }
 }
 
-// MV_MELFFT_WAVES = 4 (prefetch form) | 8 | 12 (default MF_WAVES_DEFAULT): A/B knob, every form is covered by the tests
-int melfft_waves() {
-    static int w = -1;
-    if (w < 0) {
-        const char* e = std::getenv("MV_MELFFT_WAVES");
-        const int v = e != nullptr ? std::atoi(e) : MF_WAVES_DEFAULT;
-        w = (v == 4 || v == 8 || v == 12) ? v : MF_WAVES_DEFAULT;
-    }
-    return w;
-}
+size_t melfft_fixed_lds_bytes() { return ((size_t)MF_WAVES * MF_SLOT_FLOATS + 3072) * sizeof(float); }
 
-size_t melfft_fixed_lds_bytes() { return ((size_t)melfft_waves() * MF_SLOT_FLOATS + 3072) * sizeof(float); }
-
-template <int WAVES, bool PREFETCH>
-static int melfft_launch_as(const MelFftArgs& a, size_t smem, hipStream_t stream) {
+int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream) {
     static DeviceOnce attr_set;   // (per device: the attribute belongs to the current device's code object)
     int attr_set_slot;
     if (device_once_pending(attr_set, &attr_set_slot)) {
-        if (MV_SET_MAX_SMEM((melspec_pow2_kernel<WAVES, PREFETCH>), 160 * 1024) != hipSuccess)
+        if (MV_SET_MAX_SMEM(melspec_pow2_kernel, 160 * 1024) != hipSuccess)
             return fail(MV_ERR_HIP, "melspec_pow2_kernel: cannot reserve dynamic LDS");
         device_once_done(attr_set, attr_set_slot);
     }
-    MV_LAUNCH((melspec_pow2_kernel<WAVES, PREFETCH>), ((unsigned)a.B, 1, 1), (WAVES * 64, 1, 1), smem, stream, a);
+    MV_LAUNCH(melspec_pow2_kernel, ((unsigned)a.B, 1, 1), (MF_WAVES * 64, 1, 1), smem, stream, a);
     return check_launch("melspec_pow2_kernel");
-}
-
-int melfft_launch(const MelFftArgs& a, size_t smem, hipStream_t stream) {
-    switch (melfft_waves()) {
-        case 4: return melfft_launch_as<4, true>(a, smem, stream);
-        case 8: return melfft_launch_as<8, false>(a, smem, stream);
-        default: return melfft_launch_as<12, false>(a, smem, stream);
-    }
 }
 
 }  // namespace mv

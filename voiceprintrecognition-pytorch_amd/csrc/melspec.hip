@@ -625,9 +625,6 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
                 return rc;
             }
             h->tile_kernel = true;
-            if (const char* e = getenv("MV_MELSPEC_IMPL")) {  // measurement knob: "dft" keeps the dense-DFT kernels
-                if (strcmp(e, "dft") == 0) h->tile_kernel = false;
-            }
             if (h->tile_kernel && MV_SET_MAX_SMEM((mv::melspec_tile_kernel<MST_G0, MST_G1>), 160 * 1024) != hipSuccess) {
                 mv_melspec_destroy(h);
                 return mv::fail(MV_ERR_HIP, "mv_melspec_create: cannot reserve dynamic LDS for melspec_tile_kernel");
@@ -657,9 +654,6 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
                 return rc;
             }
             h->pow2_kernel = true;
-            if (const char* e = getenv("MV_MELSPEC_IMPL")) {  // measurement knob: "dft" keeps the dense-DFT kernels
-                if (strcmp(e, "dft") == 0) h->pow2_kernel = false;
-            }
         }
     }
     *out = h;

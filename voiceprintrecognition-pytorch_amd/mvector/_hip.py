@@ -44,7 +44,7 @@ class MvEcapaCfg(ctypes.Structure):
 
 class MvCamppCfg(ctypes.Structure):
     _fields_ = [('input_size', c_i32), ('embd_dim', c_i32), ('growth_rate', c_i32), ('bn_size', c_i32),
-                ('init_channels', c_i32)]
+                ('init_channels', c_i32), ('head_precision', c_i32)]
 
 
 class MvEres2Cfg(ctypes.Structure):
@@ -169,7 +169,7 @@ def lib():
                 f'{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` or '
                 f'`python voiceprintrecognition-pytorch_amd/build_native.py`). There is no non-HIP device path.')
         cdll = bind(ctypes.CDLL(LIB_PATH))
-        if cdll.mv_abi_version() != 1:
+        if cdll.mv_abi_version() != 2:
             raise RuntimeError('libmvector_hip.so ABI version mismatch')
         _lib = cdll
     return _lib
@@ -376,10 +376,15 @@ class Model:
         return n.value
 
     def info(self, key):
-        """mv_model_info: 1 = CAM++ head on fp32 maps (1.0 / 0.0), 2 = its creation-time calibration 1 - cos"""
+        """mv_model_info: 1 = CAM++ head on fp32 maps (1.0 / 0.0), 2 = its creation-time calibration 1 - cos, 3 + p = probe p's figure"""
         v = c_f32()
         check(self._cdll.mv_model_info(self._h, key, ctypes.byref(v)), self._cdll)
         return v.value
+
+    def campp_head(self):
+        """CAM++ handles: {'head': 'f16' | 'f32', 'calibration': largest probe figure (-1 when pinned), 'probes': the three figures} -- the
+        FCM head the handle chose at create (include/mvector_hip.h, MvCamppCfg.head_precision)"""
+        return {'head': 'f32' if self.info(1) == 1.0 else 'f16', 'calibration': self.info(2), 'probes': tuple(self.info(3 + p) for p in range(3))}
 
     def forward(self, feats):
         assert feats.dim() == 3 and feats.dtype == torch.float32

@@ -27,6 +27,10 @@ class NativeBackbone:
     def _native_supported(self):
         return True, ''
 
+    def _native_created(self, handle, build):
+        """hook: a freshly built handle (``build()`` builds another one from the same parameters); returns the handle to keep"""
+        return handle
+
     def invalidate_native(self):
         self.__dict__['_native_handles'] = {}
 
@@ -90,6 +94,7 @@ class NativeBackbone:
                     if v.device != x.device:
                         raise RuntimeError(f'{type(self).__name__} parameters are on {v.device} but the input is on '
                                            f'{x.device}')
-                h = _hip.Model(self._native_kind, self._native_cfg(), {k: v.detach() for k, v in live.items()})
+                build = lambda: _hip.Model(self._native_kind, self._native_cfg(), {k: v.detach() for k, v in live.items()})
+                h = self._native_created(build(), build)
                 handles[key] = (h, self._params_version(tensors), tensors)
             return h.forward(x if x.dtype == torch.float32 else x.float())

@@ -129,6 +129,10 @@ class CAMPPlus(NativeBackbone, nn.Module):
         self._cfg = dict(input_size=input_size, growth_rate=growth_rate, bn_size=bn_size, init_channels=init_channels,
                          config_str=config_str)
         self.memory_efficient = memory_efficient  # activation checkpointing of the reference's training path: not used here
+        # MI355X path: 'auto' lets the native handle pick the FCM head's precision from three probe utterances when it is built (fp16 maps, or
+        # fp32 maps for a checkpoint whose head amplifies the fp16 rounding); 'f16' / 'f32' pin it.  Not a constructor argument: the reference's
+        # signature stays.  In a torch.distributed job rank 0's choice is broadcast, so every rank embeds with the same numerics.
+        self.head_precision = 'auto'
         self.head = _head(32, input_size)
         bottleneck = bn_size * growth_rate
         kids = [('tdnn', _node(('linear', _conv1d(self.head.out_channels, init_channels, 5, stride=2)),
@@ -164,7 +168,32 @@ class CAMPPlus(NativeBackbone, nn.Module):
         cfg = _hip.MvCamppCfg()
         cfg.input_size, cfg.embd_dim = self._cfg['input_size'], self.embd_dim
         cfg.growth_rate, cfg.bn_size, cfg.init_channels = self._cfg['growth_rate'], self._cfg['bn_size'], self._cfg['init_channels']
+        cfg.head_precision = {'auto': 0, 'f16': 1, 'f32': 2}[self.head_precision]
         return cfg
+
+    def _native_created(self, handle, build):
+        """rank 0's automatic head choice for every rank (enrol and verify embeddings must come out of one numerics)"""
+        import torch.distributed as dist
+        if self.head_precision != 'auto' or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return handle
+        dev = next(self.parameters()).device
+        flag = torch.tensor([1 if handle.campp_head()['head'] == 'f32' else 0], dtype=torch.int32, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.broadcast(flag, 0)
+        want = 'f32' if int(flag.item()) else 'f16'
+        if want == handle.campp_head()['head']:
+            return handle
+        self.head_precision = want
+        try:
+            return build()
+        finally:
+            self.head_precision = 'auto'
+
+    def native_head(self):
+        """{'head', 'calibration', 'probes'} of the native handle on the current device (None before the first CUDA forward)"""
+        hs = self.__dict__.get('_native_handles', {})
+        for h, _, _ in hs.values():
+            return h.campp_head()
+        return None
 
     def forward(self, x):
         """x: (B, T, F) -> (B, embd_dim)."""
