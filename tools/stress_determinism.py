@@ -28,5 +28,27 @@ for name in ('ecapa1024', 'ecapa512', 'campp', 'ecapa512_mel', 'eres2netv2'):
                 bad += 1
     torch.cuda.synchronize()
     print(json.dumps({'model': name, 'steps': steps, 'batch': B, 'mismatching_steps': bad}), flush=True)
-    del model, featurizer
+    # two-stream arm: ONE featurizer handle driven from two streams at once (the handles own no mutable state, include/mvector_hip.h), each
+    # stream with its own model handle + workspace (a Python Model keeps one workspace); sub-chip batches, i.e. the several-workgroups form of
+    # the front-end with its per-call scratch.  Every result must carry the bits of the serial run above.
+    import copy
+    halves = [wav[:96].contiguous(), wav[96:224].contiguous()]
+    models = [model, copy.deepcopy(model)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bad2 = 0
+    with torch.no_grad():
+        refs = [(featurizer(h).clone(), models[k](featurizer(h)).clone()) for k, h in enumerate(halves)]
+        torch.cuda.synchronize()
+        for i in range(steps):
+            outs = []
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    f = featurizer(halves[k])
+                    outs.append((f, models[k](f)))
+            torch.cuda.synchronize()
+            bad2 += sum(int(not (torch.equal(f, rf) and torch.equal(e, re))) for (f, e), (rf, re) in zip(outs, refs))
+        # ... and a row's bits do not depend on the batch it sits in (featurizer.py:125-130 computes every row alone)
+        same_rows = bool(torch.equal(refs[0][0], f0[:96]) and torch.equal(refs[1][0], f0[96:224]))
+    print(json.dumps({'model': name, 'two_streams_one_featurizer': {'steps': steps, 'mismatching_results': bad2, 'feature_rows_equal_full_batch': same_rows}}), flush=True)
+    del model, featurizer, models
     torch.cuda.empty_cache()

@@ -31,6 +31,7 @@ constexpr int CV_BK = 64;   // K elements per stage
 constexpr int CV_THREADS = 256;
 constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
 constexpr int CV_LDS_BYTES_WIDE = 2 * (CV_TC + 160) * CV_BK * 2;  // 128 x 160 tile: 72 KiB
+constexpr int CV_LDS_BYTES_SMALL = 2 * (64 + 64) * CV_BK * 2;      // 64 x 64 tile (small problems): 32 KiB
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -434,7 +435,8 @@ __device__ __forceinline__ void input_stats_reduce_store(const ConvArgs& a, cons
 
 // ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
 // Workgroup tile = (WC*MI*16) output channels x (WN*NI*16) time steps, WC x WN waves.  Two instances are built:
-//   <2,2,4,4>  128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU)  -- narrow layers and small problems
+//   <2,2,4,4>  128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU)  -- narrow layers
+//   <2,2,2,2>  64 x 64, 4 waves, 32 KiB LDS                           -- small problems (a few utterances): four times the workgroups
 //   <2,4,8,4>  256 x 256, 8 waves, 128 KiB LDS (1 workgroup per CU)  -- wide layers: each wave owns 128 x 64, i.e. 12
 //              fragment reads per 32 MFMAs instead of 8 per 16, and half the global->LDS bytes per FLOP; the 128^2
 //              kernel is LDS-bandwidth bound (reads + DMA writes ~1200 LDS cycles vs 1024 MFMA cycles per K stage).
@@ -1534,6 +1536,11 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         }
     }
     if (d.tile == 160) MV_REQUIRE(direct && !big, "conv1d: the 160-row tile belongs to the plain fp16 path");
+    // Small problems (one utterance, a handful: predict() / small predict_batch calls): 128 x 128 tiles leave most of the chip idle -- one 3 s
+    // utterance through a 1024 -> 1024 layer is 3 x 8 = 24 workgroups walking 16 serial K stages each.  64 x 64 tiles give four times the
+    // workgroups (each K stage is a quarter of the bytes: shorter round trips), still one launch.
+    const bool small = direct && !big && !wide && d.tile == 0 && d.cout >= 64 &&
+                       ceil_div(a.n_rows, CV_TN) * ceil_div(d.cout, CV_TC) * 2 <= (int64_t)cu_count();
     if (stats)
         MV_REQUIRE(persist && d.k == 1 && d.cin % CV_BK == 0 && d.T_out >= 64,
                    "conv1d: fused time statistics need the persistent 1x1 kernel (fp16 in/out, cout % 256 == 0, cin % 64 == 0, "
@@ -1545,7 +1552,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         a.per_utt = 1;
         a.tiles_per_utt = (int)ceil_div(d.T_out, CV_IN_STATS_TN);
     }
-    const int tn = big ? 256 : (wide ? 160 : CV_TN), tc = big ? 256 : CV_TC;
+    const int tn = big ? 256 : (wide ? 160 : (small ? 64 : CV_TN)), tc = big ? 256 : (small ? 64 : CV_TC);
     a.n_tiles = a.per_utt ? d.B * a.tiles_per_utt : (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
     const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
@@ -1553,6 +1560,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     int smem_set_slot;
     if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 2, 2>), CV_LDS_BYTES_SMALL) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
@@ -1592,6 +1600,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5, true>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (wide) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
+    } else if (small) {
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 2, 2>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_SMALL, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else if (f16 && has_x2 && !in_aff) {
