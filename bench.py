@@ -117,6 +117,55 @@ def oracle_embeddings(name, state_cpu, wav_cpu, chunk=32):
     return torch.cat(outs), time.perf_counter() - t0
 
 
+def cpu_baseline_all_cores(name, B, seed, threads, host_cores):
+    """The oracle on ALL host cores (north_star: "all host cores, count stated"): host_cores // threads worker PROCESSES of `threads` torch threads
+    each, every worker on its own disjoint chunk of the batch (one process with all the threads oversubscribes: 0.3 utt/s).  The workers build the
+    same seeded model and waveforms, warm up, report ready, start together; value = utterances / the slowest worker's time."""
+    import subprocess, sys
+    nproc = max(1, host_cores // threads)
+    per = -(-B // nproc)
+    code = (
+        "import sys, time, torch\n"
+        "sys.path[:0] = %r\n"
+        "import bench\n"
+        "name, B, seed, threads, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])\n"
+        "torch.set_num_threads(threads)\n"
+        "_, _, state = bench.build(name, torch.device('cpu'))\n"
+        "g = torch.Generator().manual_seed(seed)\n"
+        "wav = (0.1 * torch.randn([B, bench.SAMPLES], generator=g)).clamp(-1, 1)[lo:hi]\n"
+        "with torch.no_grad():\n"
+        "    bench.oracle_embeddings(name, state, wav[:2])\n"
+        "    print('ready', flush=True)\n"
+        "    sys.stdin.readline()\n"
+        "    _, s = bench.oracle_embeddings(name, state, wav)\n"
+        "print('done', hi - lo, s, flush=True)\n") % (sys.path,)
+    procs = []
+    for i in range(nproc):
+        lo, hi = i * per, min(B, (i + 1) * per)
+        if lo >= hi:
+            break
+        procs.append(subprocess.Popen([sys.executable, '-c', code, name, str(B), str(seed), str(threads), str(lo), str(hi)], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads))))
+    for p in procs:
+        line = p.stdout.readline()
+        if not line.startswith('ready'):
+            raise RuntimeError('cpu baseline worker failed to start')
+    t0 = time.perf_counter()
+    for p in procs:
+        p.stdin.write('\n')
+        p.stdin.flush()
+    n, slowest = 0, 0.0
+    for p in procs:
+        tag, cnt, sec = p.stdout.readline().split()
+        n += int(cnt)
+        slowest = max(slowest, float(sec))
+        p.wait()
+    wall = time.perf_counter() - t0
+    return {'value': round(n / wall, 2), 'unit': 'utterances/s', 'cores': len(procs) * threads, 'host_cores': host_cores, 'kind': 'port',
+            'processes': len(procs), 'threads_per_process': threads, 'autograd': 'off (best case)',
+            'sample': f'{n} utterances in disjoint chunks of {per}, one chunk per process, wall {wall:.1f} s (slowest worker {slowest:.1f} s)'}
+
+
 def one_minus_cos(a, b):
     return (1 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)).max().item()
 
@@ -498,6 +547,10 @@ def main():
                                                   'host_cores': host_cores, 'kind': 'port', 'autograd': 'on, as mvector/predict.py:228,262',
                                                   'sample': f'{n_sh} utterances, {sh_s:.1f} s'}
                 del state_grad
+                try:
+                    out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(args.model, B, 1234 + rank, threads, host_cores)
+                except Exception as ex:
+                    out['cpu_baseline_all_cores'] = {'error': f'{type(ex).__name__}: {ex}'}
             # ---- the same step with the upload inside the timed region ----
             host_f32 = wav_cpu.pin_memory()
             host_i16 = (wav_cpu * 32768.0).round().clamp(-32768, 32767).to(torch.int16).pin_memory()
