@@ -337,6 +337,39 @@ CONV_CASES = [
 ]
 
 
+def in_stats_forms_case(cdll, device, B_big, T=298, cin=320, cout=128, seed=0):
+    """The ASP hidden layer's conv with fused INPUT statistics in its two launch forms: a batch that fills the chip takes the fused kernel
+    (per-utterance 160-frame tiles, statistics beside the MFMAs), one utterance alone takes the stand-alone statistics kernel + the conv on
+    64 x 64 tiles.  Row 0 must come out with the SAME bits either way: pre-activations and the partial rows of the statistics."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B_big, T, cin, generator=g).half().to(device)
+    w = (torch.randn(cout, cin, 1, generator=g) * (2.0 / cin) ** 0.5).to(device)
+    packed = pack_weight(cdll, w)
+
+    def run(xb):
+        B = xb.shape[0]
+        y = torch.full((B, T, cout), 7.0, dtype=torch.float16, device=device)
+        nin = cdll.mv_conv1d_in_stats_elems(B, T, cin)
+        isum = torch.full((nin,), float('nan'), device=device)
+        isq = torch.full((nin,), float('nan'), device=device)
+        d = _hip.MvConv1dDesc()
+        d.x, d.x_dtype, d.ldx = xb.data_ptr(), _hip.MV_DT_F16, cin
+        d.w_packed = packed.data_ptr()
+        d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout
+        d.B, d.T_in, d.T_out, d.cin, d.cout, d.k = B, T, T, cin, cout, 1
+        d.dilation, d.stride, d.pad, d.pad_mode = 1, 1, 0, _hip.MV_PAD_REFLECT
+        d.in_stat_sum, d.in_stat_sq = isum.data_ptr(), isq.data_ptr()
+        _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xb)), cdll)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return y.cpu(), isum.cpu().view(B, -1), isq.cpu().view(B, -1)
+    yb, sb, qb = run(x)
+    y1, s1, q1 = run(x[:1].contiguous())
+    assert torch.isfinite(yb.float()).all() and torch.isfinite(sb).all()
+    assert torch.equal(y1[0], yb[0]), (y1[0].float() - yb[0].float()).abs().max().item()
+    assert torch.equal(s1[0], sb[0]) and torch.equal(q1[0], qb[0])
+
+
 def linear_case(cdll, device, B=5, K=100, O=37, act=1, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, K, generator=g)

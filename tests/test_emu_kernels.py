@@ -38,6 +38,12 @@ def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
 
 
+def test_emu_conv1d_input_statistics_two_launch_forms_agree():
+    """fused kernel (3 utterances on the emulator's 8-CU chip) vs stand-alone statistics + small-tile conv (1 utterance): identical bits"""
+    lc.in_stats_forms_case(emu_cdll(), 'cpu', B_big=3, T=298, cin=192)
+    lc.in_stats_forms_case(emu_cdll(), 'cpu', B_big=5, T=161, cin=136, seed=1)
+
+
 def test_emu_conv1d_rejects_bad_arguments():
     with pytest.raises(RuntimeError, match='reflect padding'):
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)

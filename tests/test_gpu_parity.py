@@ -68,6 +68,12 @@ def test_gpu_conv1d_persistent_walks_many_tiles():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_gpu_conv1d_input_statistics_two_launch_forms_agree():
+    """the ASP hidden layer's conv: fused statistics kernel (40 utterances) vs stand-alone statistics + 64 x 64 tiles (1 utterance): same bits"""
+    lc.in_stats_forms_case(product_lib(), DEV, B_big=40, T=298, cin=3072)
+    lc.in_stats_forms_case(product_lib(), DEV, B_big=36, T=161, cin=1536, seed=1)
+
+
 @pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0), (250, 4180, 40, 0), (2048, 6144, 192, 0)])
 def test_gpu_linear(shape):
     lc.linear_case(product_lib(), DEV, *shape)
@@ -218,6 +224,26 @@ def test_gpu_cosine_properties_full_size():
 def test_gpu_native_model_matches_reference_golden(case):
     cd, rel = lc.model_case(product_lib(), DEV, case)
     assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
+
+
+@pytest.mark.parametrize('case', ['ecapa_c1024', 'tdnn'])
+def test_gpu_embedding_bits_do_not_depend_on_the_batch_size(case):
+    """the reference embeds every utterance on its own data: whatever launch forms the batch size selects (64 x 64 / 128 x 128 / 256 x 256 conv
+    tiles -- one accumulation order --, fused or stand-alone ASP input statistics, Fbank chunk form), row i carries the same bits alone, in a
+    small batch and on a full chip"""
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    import mvector.models as M
+    man, sd, _, _, _ = load_case(case)
+    m = getattr(M, man['model'])(**man['kwargs'])
+    m.load_state_dict(sd)
+    m.eval().to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=dict(sample_frequency=16000, num_mel_bins=man['kwargs']['input_size']))
+    wav = frontend.synth_waveforms(256, 48000, seed=8).to(DEV)
+    with torch.no_grad():
+        full = m(fz(wav))
+        for nb in (1, 8, 40, 130):
+            e = m(fz(wav[:nb]))
+            assert torch.equal(e, full[:nb]), (nb, (e - full[:nb]).abs().max().item())
 
 
 def test_gpu_fp16_backbone_stress_golden_ecapa():

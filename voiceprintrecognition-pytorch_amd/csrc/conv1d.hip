@@ -555,6 +555,44 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     }
 }
 
+// ---- the fused input statistics WITHOUT the GEMM (small batches) --------------------------------------------------------------------------
+// With a handful of utterances the INSTATS kernel above is two workgroups per utterance walking 48 serial K stages (one 3 s utterance through
+// the ASP hidden layer: 84-93 us).  Small batches therefore split the work: the conv runs on 64 x 64 tiles (no statistics), and this kernel
+// produces the partial rows -- one workgroup per (utterance tile of CV_IN_STATS_TN frames, K stage of 64 channels), the SAME LDS image of the
+// x tile and the SAME input_stats_accumulate / input_stats_reduce_store, so the partial rows carry the bits of the fused form (a row's
+// embedding does not depend on the batch it sits in).  1x1, stride 1, no padding (the fused form's own requirements).
+constexpr int CV_IN_STATS_TN_K = 160;
+__global__ __launch_bounds__(CV_THREADS) void conv1d_in_stats_kernel(ConvArgs a) {
+    constexpr int TN = CV_IN_STATS_TN_K, NW = CV_THREADS / 64, NTX = TN / 8 / NW;
+    MV_DYN_SMEM(smem);
+    const int n_tile = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ub = n_tile / a.tiles_per_utt;
+    const int n0 = ub * a.T_out + (n_tile - ub * a.tiles_per_utt) * TN, n_end = (ub + 1) * a.T_out;
+    const int lrow = lane >> 3;
+    const int kc = (lane & 7) ^ (lrow & 7);
+    const int c0 = s * CV_BK;
+    const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
+    const bool ch_ok = c0 + kc * 8 < a.cin;
+#pragma unroll
+    for (int i = 0; i < NTX; ++i) {
+        const int n = n0 + (wave * NTX + i) * 8 + lrow;
+        const half_t* src = zero;
+        if (n < n_end && ch_ok) {
+            const int b = n / a.T_out, t = n - b * a.T_out;
+            src = xbase + ((int64_t)b * a.T_in + t) * a.ldx + kc * 8 + c0;
+        }
+        glds16(src, smem + (wave * NTX + i) * 1024);
+    }
+    wait_all_loads();
+    __syncthreads();
+    InStats st;
+    input_stats_accumulate<TN>(st, smem, wave, lane);
+    input_stats_reduce_store(a, st, c0, n_tile, wave, lane);
+}
+
 // ---- persistent 256 x 256 kernel: one workgroup per CU walks a list of tiles ------------------------------------
 // The 256^2 kernel above runs one workgroup per CU (128 KiB of LDS), so nothing overlaps a tile's prologue (first
 // stage in flight, nothing to compute) and epilogue (128 KiB of stores, all CUs at once, memory pipes idle during the
@@ -824,6 +862,7 @@ __global__ void in_stats_finish_kernel(const float* psum, const float* psq, int 
 }
 
 constexpr int CV_IN_STATS_TN = 160;  // the tile of the kernel that takes them
+static_assert(CV_IN_STATS_TN == CV_IN_STATS_TN_K, "the stand-alone statistics kernel mirrors the fused form's tile");
 int64_t conv_in_stats_elems(int B, int T, int cin) { return (int64_t)B * ceil_div(T, CV_IN_STATS_TN) * cin; }
 
 int conv_in_stats_finish_launch(const float* psum, const float* psq, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
@@ -1545,6 +1584,26 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
         MV_REQUIRE(persist && d.k == 1 && d.cin % CV_BK == 0 && d.T_out >= 64,
                    "conv1d: fused time statistics need the persistent 1x1 kernel (fp16 in/out, cout % 256 == 0, cin % 64 == 0, "
                    "plain bias / ReLU / affine epilogue, T_out >= 64)");
+    if (in_stats && direct && d.k == 1 && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out && d.cout <= CV_TC && d.tile == 0 && d.cin % 8 == 0 &&
+        (reinterpret_cast<uintptr_t>(d.in_stat_sum) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.in_stat_sq) & 15) == 0 &&
+        (int64_t)d.B * ceil_div(d.T_out, CV_IN_STATS_TN) * 4 <= (int64_t)cu_count() && d.B <= 16384) {
+        // small batch: the statistics from their own launch (bit-identical partial rows), the conv on small tiles
+        a.per_utt = 1;
+        a.tiles_per_utt = (int)ceil_div(d.T_out, CV_IN_STATS_TN);
+        static DeviceOnce once;
+        int slot;
+        if (device_once_pending(once, &slot)) {
+            if (MV_SET_MAX_SMEM(conv1d_in_stats_kernel, CV_IN_STATS_TN * CV_BK * 2) != hipSuccess) return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
+            device_once_done(once, slot);
+        }
+        MV_LAUNCH(conv1d_in_stats_kernel, ((unsigned)(d.B * a.tiles_per_utt), (unsigned)(a.cin_pad / CV_BK), 1), (CV_THREADS, 1, 1), CV_IN_STATS_TN * CV_BK * 2, stream, a);
+        int rc = check_launch("conv1d_in_stats_kernel");
+        if (rc != MV_OK) return rc;
+        MvConv1dDesc d2 = d;
+        d2.in_stat_sum = nullptr;
+        d2.in_stat_sq = nullptr;
+        return conv1d_launch(d2, stream);
+    }
     if (in_stats) {
         MV_REQUIRE(direct && wide && d.k == 1 && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out && d.cout <= CV_TC && d.tile != 128 &&
                        d.tile != 256 && (reinterpret_cast<uintptr_t>(d.in_stat_sum) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.in_stat_sq) & 15) == 0,
