@@ -220,6 +220,21 @@ __device__ __forceinline__ float4v act4(float4v v, int act) {
 }
 
 // n_end: first row behind the tile's valid rows (the tensor's row count, or the end of the tile's utterance)
+// Accumulators start from the bias (a lane holds channels co .. co + 3 of tile mi for every time tile): EVERY conv kernel of this file
+// does, the persistent ones included, so that acc = bias + sum over K in one order whatever tile shape the launcher picks -- a row's
+// result does not depend on the batch it sits in.
+template <int MI, int NI>
+__device__ __forceinline__ void conv_acc_init(const ConvArgs& a, int co0, int wc, int lane, float4v (&acc)[MI][NI]) {
+    const int crow = 4 * (lane >> 4);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int co = co0 + wc * (MI * 16) + mi * 16 + crow;
+        const float4v b4 = (a.bias != nullptr && co < a.cout) ? *reinterpret_cast<const float4v*>(a.bias + co) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = b4;
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int n_end, int co0, int wc, int wn, int lane,
                                               float4v (&acc)[MI][NI]) {
@@ -241,14 +256,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int n0, int n_e
     for (int mi = 0; mi < MI; ++mi) {
         const int co = co0 + wc * (MI * 16) + mi * 16 + crow;
         if (co >= a.cout) continue;
-        const float4v bias4 = a.bias != nullptr ? *reinterpret_cast<const float4v*>(a.bias + co) : zero4;
         const float4v scale4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.scale + co) : one4;
         const float4v shift4 = a.scale != nullptr ? *reinterpret_cast<const float4v*>(a.shift + co) : zero4;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = nn[ni];
             if (n >= n_end) continue;
-            float4v v = acc[mi][ni] + bias4;
+            float4v v = acc[mi][ni];   // (the bias is already in the accumulators: conv_acc_init)
             if (a.row_bias != nullptr) v += *reinterpret_cast<const float4v*>(a.row_bias + (int64_t)nb[ni] * a.cout + co);
             v = act4(v, a.pre_act);
             v = v * scale4 + shift4;
@@ -303,13 +317,12 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
         const int col = wc * (MI * 16) + mi * 16 + crow;
         const int co = co0 + col;
         const bool cok = co < a.cout;
-        const float4v bias4 = (cok && a.bias != nullptr) ? *reinterpret_cast<const float4v*>(a.bias + co) : zero4;
         const float4v scale4 = (cok && a.scale != nullptr) ? *reinterpret_cast<const float4v*>(a.scale + co) : one4;
         const float4v shift4 = (cok && a.scale != nullptr) ? *reinterpret_cast<const float4v*>(a.shift + co) : zero4;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const bool ok = cok && n0 + nl[ni] < n_end;
-            float4v v = acc[mi][ni] + bias4;
+            float4v v = acc[mi][ni];   // (the bias is already in the accumulators: conv_acc_init)
             if (a.row_bias != nullptr && ok) v += *reinterpret_cast<const float4v*>(a.row_bias + (int64_t)nb[ni] * a.cout + co);
             v = act4(v, a.pre_act);
             v = v * scale4 + shift4;
@@ -520,10 +533,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     };
 
     float4v acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    conv_acc_init<MI, NI>(a, co0, wc, lane, acc);
 
     issue(0, 0);
     wait_all_loads();
@@ -1413,10 +1423,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
     };
 
     float4v acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    conv_acc_init<4, 4>(a, co0, wc, lane, acc);
 
     issue_loads(0);
     store_lds(0, 0);
