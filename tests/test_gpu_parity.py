@@ -226,7 +226,7 @@ def test_gpu_native_model_matches_reference_golden(case):
     assert cd < 1e-4 and rel < 1.4e-2, (cd, rel)
 
 
-@pytest.mark.parametrize('case', ['ecapa_c1024', 'tdnn'])
+@pytest.mark.parametrize('case', ['ecapa_c1024', 'tdnn', 'campp', 'eres2netv2_tiny'])
 def test_gpu_embedding_bits_do_not_depend_on_the_batch_size(case):
     """the reference embeds every utterance on its own data: whatever launch forms the batch size selects (64 x 64 / 128 x 128 / 256 x 256 conv
     tiles -- one accumulation order --, fused or stand-alone ASP input statistics, Fbank chunk form), row i carries the same bits alone, in a
@@ -243,7 +243,7 @@ def test_gpu_embedding_bits_do_not_depend_on_the_batch_size(case):
         full = m(fz(wav))
         for nb in (1, 8, 40, 130):
             e = m(fz(wav[:nb]))
-            assert torch.equal(e, full[:nb]), (nb, (e - full[:nb]).abs().max().item())
+            assert torch.equal(e, full[:nb]), (case, nb, (e - full[:nb]).abs().max().item())
 
 
 def test_gpu_fp16_backbone_stress_golden_ecapa():
