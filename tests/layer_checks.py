@@ -713,7 +713,7 @@ def melspec_case(cdll, device, wav, ratio, method_args, rtol=2e-4):
     return err / scale
 
 
-def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0):
+def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0, alone_rows=0):
     """Fused Res2Net chain vs a torch fp32 evaluation that rounds to fp16 exactly where the kernel does."""
     g = torch.Generator().manual_seed(seed)
     C = width * groups
@@ -746,4 +746,14 @@ def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, see
     ref = torch.cat(outs, 1).transpose(1, 2)
     err = (y.cpu().float() - ref).abs().max().item()
     assert err < 1e-2 * max(1.0, ref.abs().max().item()), err
+    if alone_rows:
+        # the same utterances one at a time: a small batch takes the 5-tile chunk form (<= 160 frames per workgroup, halo rows), a batch that
+        # fills the chip one workgroup per utterance (or 304-frame chunks) -- every stored row is computed from the rows it sees in the unchunked
+        # run with the same arithmetic, so the bits agree
+        for b in range(min(alone_rows, B)):
+            y1 = torch.full((1, T, C), 9.0, dtype=torch.float16, device=device)
+            x1 = xd[b:b + 1].contiguous()
+            _hip.check(cdll.mv_res2net_chain_f16(x1.data_ptr(), y1.data_ptr(), arr(packed), arr(dev[0]), arr(dev[1]), arr(dev[2]), 1, T, C,
+                                                 groups, k, dil, _stream(xd)), cdll)
+            assert torch.equal(y1[0].cpu(), y[b].cpu()), (b, (y1[0].cpu().float() - y[b].cpu().float()).abs().max().item())
     return err

@@ -240,6 +240,13 @@ def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
 
 
+def test_emu_res2net_chain_small_batch_form_carries_the_same_bits():
+    """one utterance alone (three workgroups of the 5-tile form on <= 160-frame chunks with halo rows) against the same utterance in a batch
+    that takes one workgroup per utterance: identical bits (the emulator's chip has 8 CUs: 5 utterances are not a small batch)"""
+    lc.res2_chain_case(emu_cdll(), 'cpu', width=128, T=298, dil=3, B=5, alone_rows=1)
+    lc.res2_chain_case(emu_cdll(), 'cpu', width=128, T=130, dil=4, B=5, alone_rows=1, seed=2)
+
+
 def test_emu_fbank_variable_length_batch():
     """mv_fbank_forward_varlen: own frame count and time mean per row, zero rows behind it (reader.py:100-106 + collate_fn.py)"""
     wav = frontend.synth_waveforms(4, 2400, seed=17)

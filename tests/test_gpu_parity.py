@@ -634,6 +634,13 @@ def test_gpu_res2net_fused_chain(cfg):
     lc.res2_chain_case(product_lib(), DEV, **cfg)
 
 
+@pytest.mark.parametrize('cfg', [dict(T=298, dil=2), dict(T=298, dil=3), dict(T=298, dil=4), dict(T=150, dil=3), dict(T=500, dil=2), dict(T=81, dil=4)])
+def test_gpu_res2net_chain_small_batch_form_carries_the_same_bits(cfg):
+    """small batches run the chain as <= 160-frame chunks on the 5-tile form of the kernel (one 3 s utterance: three workgroups instead of one); the
+    same utterances in a batch that fills the chip take one workgroup each: identical bits, checked row by row"""
+    lc.res2_chain_case(product_lib(), DEV, width=128, B=200, alone_rows=2, seed=7, **cfg)
+
+
 @pytest.mark.parametrize('case', ['campp_short', 'ecapa_tiny', 'tdnn'])
 def test_gpu_model_forward_is_hipgraph_capturable(case):
     """a model forward is a fixed launch sequence on the caller's stream over the caller's workspace (no allocation, no

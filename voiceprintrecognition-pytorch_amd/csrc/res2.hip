@@ -90,16 +90,21 @@ __device__ __forceinline__ float r2_clamp_h(float v) { return fmed3(v, -65504.0f
 
 
 // MI = output channel tiles per wave (width = 64 * MI)
-template <int MI, bool DIRECT = false>
+// NHT = time tiles (16 frames) per wave half: 10 (<= 320 frames per workgroup; direct form 304) or, direct form only, 5 (<= 160 frames: the chunks
+// of a SMALL batch -- one utterance as three workgroups instead of one, each with half the matrix work, epilogue and LDS traffic per step)
+template <int MI, bool DIRECT = false, int NHT = R2_NH>
 __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     static_assert(!DIRECT || MI == 2, "the direct form is written for width 128");
+    static_assert(NHT == R2_NH || (DIRECT && NHT == 5), "5 time tiles per wave half exist in the direct form only");
+    constexpr int ROWS_T = 2 * NHT * 16 + 2 * R2_MAXPAD;            // rows of the activation buffer
+    constexpr int XNEXT_T = NHT == R2_NH ? R2_XNEXT_BYTES : 2 * NHT * 16 * 64 * MI * 2;   // direct form: the next channel group's rows
     MV_DYN_SMEM(smem);
     constexpr int WIDTH = 64 * MI;
     constexpr int CPR = WIDTH / 8;       // 16-byte chunks per activation row
     constexpr int ROWB = WIDTH * 2;      // bytes per activation row
     constexpr int TP = MI;               // weight transfers per stage per wave (WIDTH/8 transfers over 8 waves)
     char* wbuf = smem;                               // R2_RING x R2_WSTAGE_BYTES  (direct form: the next channel group instead)
-    char* abuf = smem + (DIRECT ? R2_XNEXT_BYTES : R2_RING * R2_WSTAGE_BYTES);   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
+    char* abuf = smem + (DIRECT ? XNEXT_T : R2_RING * R2_WSTAGE_BYTES);   // [R2_ROWS][WIDTH] fp16, row r = t + PAD, chunk index ^= r & (CPR-1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = MV_UNIFORM(wave);
     const int fr = lane & 15, fg = lane >> 4;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     auto a_off = [&](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CPR - 1))) << 4); };
 
     // ---- slice 0 passes through; slice 1 (with its reflected halo) becomes the first step's input; rows beyond stay zero ----
-    for (int i = tid; i < R2_ROWS * CPR; i += R2_THREADS) {
+    for (int i = tid; i < ROWS_T * CPR; i += R2_THREADS) {
         const int row = i / CPR, ch = i - row * CPR;
         const int t = row - PAD;
         half8v v1;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
 
     const int cw = wave & 3;   // channel tile group
     const int th = wave >> 2;  // time half
-    const int nh0 = th * R2_NH;  // first time tile of this wave
+    const int nh0 = th * NHT;  // first time tile of this wave
     const int kstages_per_tap = a.kpad / 64;
     const int nstages = a.k * kstages_per_tap;
     // weight transfers: a stage is [WIDTH rows][64] = WIDTH/8 transfers of 1 KiB; wave w issues transfers w, w+8
@@ -200,16 +205,16 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
         // branch + full wait per load; the last step simply re-reads its own group and ignores the values.)
         const bool more = j < a.steps;
         const int next_group = more ? j + 1 : j;
-        half4v xn[MI][R2_NH];   // MI == 1: this wave's 4 channels per tile
-        half8v xp[R2_NH];       // MI == 2: 8 consecutive channels per lane (paired layout of the epilogue)
+        half4v xn[MI][NHT];   // MI == 1: this wave's 4 channels per tile
+        half8v xp[NHT];       // MI == 2: 8 consecutive channels per lane (paired layout of the epilogue)
         const int co8 = (cw * 2 + (fg & 1)) * 16 + 8 * (fg >> 1);
         if constexpr (!DIRECT)
             for (int s0 = 0; s0 < R2_RING - 1 && s0 < nstages; ++s0) issue_w(s0, s0);
-        float4v acc[MI][R2_NH];
+        float4v acc[MI][NHT];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < R2_NH; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ni = 0; ni < NHT; ++ni) acc[mi][ni] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         // Weight stages run up to R2_RING-1 ahead of the MFMAs: wait (counted) for stage s, barrier, refill the slot that
         // stage s-1 just released with stage s+3, compute stage s.  One barrier per stage; it also publishes the
         // activation buffer written by the previous step's epilogue.
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             if (s + R2_RING - 1 < nstages) issue_w(s + R2_RING - 1, (s + R2_RING - 1) % R2_RING);
             if constexpr (decltype(LAST)::value) {
 #pragma unroll
-                for (int ni = 0; ni < R2_NH; ++ni) {
+                for (int ni = 0; ni < NHT; ++ni) {
                     int t = (nh0 + ni) * 16 + fr;
                     t = t < T ? t : T - 1;
                     MV_OPAQUE(t);
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             // before the MFMAs of phase p, so an LDS round trip never sits in front of the matrix pipe (the compiler's own
             // order "reads, wait, MFMAs" per half costs 2.45 k cycles per stage for 1.3 k cycles of matrix work: in-kernel
             // timeline r02j).  WIDTH is a multiple of 64, so both K halves hold real weights.
-            static_assert(R2_NH % 2 == 0, "time tiles are processed in two groups");
-            constexpr int NG = R2_NH / 2;
+            static_assert(DIRECT || NHT % 2 == 0, "time tiles are processed in two groups");
+            constexpr int NG = NHT / 2 > 0 ? (NHT + 1) / 2 : 1;
             half8v af[2][MI];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -290,8 +295,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             phase(std::integral_constant<int, 3>{});
         };
         if constexpr (DIRECT) {
-            constexpr int NG = R2_NH / 2;
-            static_assert(NG == 5, "mfma10_step takes five time tiles");
+            constexpr int NG = 5;   // mfma10_step takes five time tiles: two groups per wave half (NHT = 10) or one (NHT = 5)
             // x_{j+1} transfers per wave and stage: ceil(76 / 8) = 10 per wave spread over the step's stages (>= 6: k >= 3)
             constexpr int XPS = 2;
             half8v bA[5], bB[5];
@@ -305,6 +309,37 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             auto stage = [&](int s, half8v (&cur)[2][2], half8v (&ahead)[2][2], auto LAST) __attribute__((always_inline)) {
                 load_ahead(j, s + 2, ahead);
                 const unsigned bp1 = b_addr(s, 1);
+                if constexpr (NHT == 5) {
+                    // one group of five time tiles: bA holds K half 0 of this stage (requested one phase earlier), bB takes K half 1 while the
+                    // MFMAs of half 0 run, bA then takes half 0 of the next stage under the MFMAs of half 1
+                    lds_read5<0, 16 * ROWB>(bB, bp1);
+                {
+                    // Request x_{next_group}: 4 rows of 256 B per transfer, row r's 16-byte chunk c lands at chunk position c ^ (r & 15);
+                    // XPS transfers per wave and stage, so that the memory pipe takes them between the weight loads instead of as one
+                    // burst of 80 per CU that the waves would sit behind (r05f: 3-4 k cycles in front of the MFMAs of stage 0).
+                    // Untracked, and issued behind the stage's first MFMAs: the compiler counts the waits for the weight fragments from
+                    // the loads it knows, so a transfer in front of a fragment's first use would be waited for with it.
+                    const int nrow4 = (T + 3) >> 2;
+#pragma unroll
+                    for (int u = 0; u < XPS; ++u) {
+                        const int i = wave_u + 8 * (s * XPS + u);
+                        if (i < nrow4) {
+                            int row = 4 * i + (lane >> 4);
+                            row = row < T ? row : T - 1;
+                            const int chunk = (lane & 15) ^ (row & 15);
+                            glds16_untracked(xb + (int64_t)row * a.C + next_group * WIDTH + chunk * 8, lds_addr(wbuf) + i * 1024);
+                        }
+                    }
+                }
+                    mfma10_step<5>(&acc[0][0], &acc[1][0], cur[0][0], cur[0][1], bA);
+                    if constexpr (decltype(LAST)::value) {
+                        mfma10_step<0>(&acc[0][0], &acc[1][0], cur[1][0], cur[1][1], bB);
+                    } else {
+                        const unsigned np0 = b_addr(s + 1, 0);
+                        lds_read5<0, 16 * ROWB>(bA, np0);
+                        mfma10_step<5>(&acc[0][0], &acc[1][0], cur[1][0], cur[1][1], bB);
+                    }
+                } else {
                 mfma10_step<0>(&acc[0][0], &acc[1][0], cur[0][0], cur[0][1], bA);
                 lds_read5<0, 16 * ROWB>(bA, bp1);  // (these registers were last sourced by the step above)
                 {
@@ -336,13 +371,14 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     mfma10_step<5>(&acc[0][NG], &acc[1][NG], cur[1][0], cur[1][1], bB);
                     lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, np0);
                 }
+                }
             };
             r2_lds_barrier();  // publishes the activation buffer written by the previous epilogue (or the prologue); x_{j+1} of the
                                // previous step has been read by everyone
             {
                 const unsigned bp0 = b_addr(0, 0);
                 lds_read5<0, 16 * ROWB>(bA, bp0);
-                lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp0);
+                if constexpr (NHT != 5) lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp0);
             }
             // nstages is a multiple of 3 here (launcher), so the rotation of the three fragment sets is static
             for (int s = 0; s + 3 < nstages; s += 3) {
@@ -387,7 +423,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 shift4[mi] = *reinterpret_cast<const float4v*>(a.shift[j - 1] + co);
             }
 #pragma unroll
-            for (int ni = 0; ni < R2_NH; ++ni) {
+            for (int ni = 0; ni < NHT; ++ni) {
                 int t = (nh0 + ni) * 16 + fr;
                 MV_OPAQUE(t);
                 unsigned w[2][2];
@@ -430,7 +466,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             const float4v scale4 = *reinterpret_cast<const float4v*>(a.scale[j - 1] + co);
             const float4v shift4 = *reinterpret_cast<const float4v*>(a.shift[j - 1] + co);
 #pragma unroll
-            for (int ni = 0; ni < R2_NH; ++ni) {
+            for (int ni = 0; ni < NHT; ++ni) {
                 const int t = (nh0 + ni) * 16 + fr;
                 half4v hv, nv;
 #pragma unroll
@@ -466,6 +502,9 @@ static bool res2_direct(int T, int width, int k) {  // (k * 2 K stages per step:
     return R2_DIRECT && width == 128 && k % 3 == 0 && ((T + 3) & ~3) * width * 2 <= R2_XNEXT_BYTES;
 }
 
+constexpr int R2_SMALL_ROWS = 160;   // frames a workgroup of the 5-tile direct form holds (small batches)
+constexpr int R2_SMALL_LDS = R2_SMALL_ROWS * 128 * 2 + (R2_SMALL_ROWS + 2 * R2_MAXPAD) * 128 * 2;   // next channel group + activation buffer
+
 size_t res2_chain_lds_bytes(int T, int width, int k) {
     if (res2_direct(T, width, k)) return (size_t)R2_XNEXT_BYTES + (size_t)R2_ROWS * width * 2;  // 163 840 B: all of the CU's LDS
     return R2_RING * (size_t)R2_WSTAGE_BYTES + (size_t)R2_ROWS * width * 2;
@@ -474,12 +513,27 @@ size_t res2_chain_lds_bytes(int T, int width, int k) {
 // frames one workgroup can hold (direct form: the x_{j+1} region; ring form: the 20 time tiles of the accumulators)
 static int res2_local_limit(int width, int k) { return R2_DIRECT && width == 128 && k % 3 == 0 ? 304 : 16 * 2 * R2_NH; }
 
-// utterances beyond 320 frames: chunks of equal useful length with steps * pad halo rows per side (Res2Args); {1, T} when one workgroup holds it
-static void res2_chunking(int T, int width, int steps, int k, int dil, int* nchunks, int* useful) {
+// utterances beyond 320 frames: chunks of equal useful length with steps * pad halo rows per side (Res2Args); {1, T} when one workgroup holds it.
+// Small batches of the direct form's geometry (B utterances on a chip of many more CUs) are cut into chunks of <= 160 frames for the 5-tile
+// kernel whatever their length: one 3 s utterance = three workgroups with half the per-step work each instead of one (a produced row sees
+// exactly the rows it sees in the unchunked run, so the bits are the same).
+static void res2_chunking(int B, int T, int width, int steps, int k, int dil, int* nchunks, int* useful, bool* small) {
     *nchunks = 1;
     *useful = T;
+    *small = false;
+    const int halo2 = 2 * steps * (dil * (k - 1) / 2);
+    if (R2_DIRECT && width == 128 && k % 3 == 0 && R2_SMALL_ROWS - halo2 >= 64 && T > R2_SMALL_ROWS / 2) {
+        const int per = R2_SMALL_ROWS - halo2;
+        const int n0 = (T + per - 1) / per;
+        if ((int64_t)B * n0 * 2 <= device_cu_count()) {   // (the chunks fill at most half of the chip: a small batch)
+            *useful = T <= R2_SMALL_ROWS ? T : (T + n0 - 1) / n0;
+            *nchunks = (T + *useful - 1) / *useful;
+            *small = true;
+            return;
+        }
+    }
     if (T <= 16 * 2 * R2_NH) return;
-    const int per = res2_local_limit(width, k) - 2 * steps * (dil * (k - 1) / 2);
+    const int per = res2_local_limit(width, k) - halo2;
     if (per < 64) return;  // (not worth it: the caller falls back to one launch per step)
     const int n0 = (T + per - 1) / per;
     *useful = (T + n0 - 1) / n0;
@@ -492,7 +546,8 @@ bool res2_chain_supported(int T, int width, int steps, int k, int dil) {
         return false;
     if (T <= 16 * 2 * R2_NH) return true;
     int nchunks, useful;
-    res2_chunking(T, width, steps, k, dil, &nchunks, &useful);
+    bool small;
+    res2_chunking(1 << 20, T, width, steps, k, dil, &nchunks, &useful, &small);   // (a batch that never takes the small-batch form)
     return nchunks > 1;
 }
 
@@ -516,12 +571,17 @@ int res2_chain_launch(const half_t* x, half_t* y, const half_t* const* w, const 
     a.k = k;
     a.dil = dil;
     a.kpad = conv1d_cin_pad(width);
-    res2_chunking(T, width, steps, k, dil, &a.nchunks, &a.useful);
+    bool small = false;
+    res2_chunking(B, T, width, steps, k, dil, &a.nchunks, &a.useful, &small);
     a.halo = a.nchunks > 1 ? steps * (dil * (k - 1) / 2) : 0;
     const int Tl = a.nchunks > 1 ? (a.useful + 2 * a.halo < T ? a.useful + 2 * a.halo : T) : T;   // most frames a workgroup works on
     const size_t lds = res2_chain_lds_bytes(Tl, width, k);
     const unsigned grid = (unsigned)B * (unsigned)a.nchunks;
-    if (res2_direct(Tl, width, k)) {
+    if (small) {
+        MV_REQUIRE(Tl <= R2_SMALL_ROWS, "res2_chain: small-batch chunk too long");
+        if (MV_SET_MAX_SMEM((res2_chain_kernel<2, true, 5>), R2_SMALL_LDS) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
+        MV_LAUNCH((res2_chain_kernel<2, true, 5>), (grid, 1, 1), (R2_THREADS, 1, 1), R2_SMALL_LDS, stream, a);
+    } else if (res2_direct(Tl, width, k)) {
         if (MV_SET_MAX_SMEM((res2_chain_kernel<2, true>), lds) != hipSuccess) return fail(MV_ERR_HIP, "res2_chain: cannot reserve LDS");
         MV_LAUNCH((res2_chain_kernel<2, true>), (grid, 1, 1), (R2_THREADS, 1, 1), lds, stream, a);
     } else if (width == 128) {
