@@ -709,8 +709,17 @@ __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const
     for (int i = tid; i < FBT_WAVES * 128; i += 256) {  // thread = (slot w, bin m)
         const int w = i >> 7, m = i & 127;
         float run = 0.0f;
-        if (cmn && m < nbins)
-            for (int q = w; q < nquads; q += FBT_WAVES) run += pb[q * 128 + m];
+        if (cmn && m < nbins) {
+            int q = w;
+            for (; q + 7 * FBT_WAVES < nquads; q += 8 * FBT_WAVES) {   // eight loads in flight, added in order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = pb[(q + u * FBT_WAVES) * 128 + m];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) run += v[u];
+            }
+            for (; q < nquads; q += FBT_WAVES) run += pb[q * 128 + m];
+        }
         slot[w][m] = run;
     }
     __syncthreads();
