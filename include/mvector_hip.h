@@ -306,7 +306,7 @@ typedef struct MvConv1dDesc {
     void* sum_dst;        /* x_{j+1} + y_j of the next Res2Net step (ecapa_tdnn.py:47) produced by this step's epilogue */
     int64_t ld_add, ld_sum;
     int32_t B, T_in, T_out, cin, cout, k, dilation, stride, pad, pad_mode;
-    int32_t tile;         /* workgroup tile: 0 = choose (256x256 for wide layers that fill the chip, else 128x128), 128, 160, 256 */
+    int32_t tile;         /* workgroup tile: 0 = choose (256x256 for wide layers that fill the chip, 64x64 for small problems, else 128x128 / 128x160), 64, 128, 160, 256 */
     /* optional fused time statistics of y (SE squeeze ecapa_tdnn.py:79, ASP global mean / std pooling.py:104-109): fp32 partial
      * buffers of mv_conv1d_stats_elems(B, T_out, cout) floats each; stat_sq may be NULL (mean only).  Only on the persistent
      * 1x1 path: fp16 in/out, cout % 256 == 0, cin % 64 == 0, no row_bias / gate, T_out >= 64.  Finish with

@@ -6,10 +6,14 @@ import torch
 from mvector import _hip
 import layer_checks as lc
 lib = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else _hip.lib()
-B, T = 256, 298
+B, T = int(os.environ.get('MV_BENCH_B', '256')), 298
+TILES = [int(t) for t in os.environ.get('MV_BENCH_TILES', '128,256').split(',')]
 shapes = [('c2c 1024->1024 k1', 1024, 1024, 1, 1), ('mfa 3072->3072 k1', 3072, 3072, 1, 1), ('asp 3072->128 k1', 3072, 128, 1, 1),
           ('res2 128->128 k3d3', 128, 128, 3, 3), ('c2c 512->512 k1', 512, 512, 1, 1), ('mfa 1536->1536', 1536, 1536, 1, 1)]
+only = os.environ.get('MV_BENCH_SHAPES')
 for name, cin, cout, k, dil in shapes:
+    if only and not any(o in name for o in only.split(',')):
+        continue
     PADX = int(os.environ.get('MV_PADX', '0'))
     xfull = (torch.randn(B, T, cin + PADX, device='cuda') * 0.5).half()
     x = xfull
@@ -19,7 +23,7 @@ for name, cin, cout, k, dil in shapes:
     scale = torch.rand(cout, device='cuda') + 0.5
     shift = torch.randn(cout, device='cuda') * 0.1
     y = torch.empty(B, T, cout + PADX, dtype=torch.float16, device='cuda')
-    for tile in (128, 256):
+    for tile in TILES:
         if tile == 256 and cout % 256:
             continue
         d = _hip.MvConv1dDesc()
@@ -42,4 +46,4 @@ for name, cin, cout, k, dil in shapes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         tf = 2.0 * B * T * cin * cout * k / us / 1e6
-        print(json.dumps(dict(shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))), flush=True)
+        print(json.dumps(dict(B=B, shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))), flush=True)

@@ -1557,10 +1557,13 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool f16 = d.x_dtype == MV_DT_F16;
     const bool has_x2 = d.x2 != nullptr, in_aff = d.in_scale != nullptr;
     // 256 x 256 tiles for wide layers with enough work to fill the chip (one workgroup per CU)
-    MV_REQUIRE(d.tile == 0 || d.tile == 128 || d.tile == 160 || d.tile == 256, "conv1d: tile must be 0 (auto), 128, 160 or 256");
+    MV_REQUIRE(d.tile == 0 || d.tile == 64 || d.tile == 128 || d.tile == 160 || d.tile == 256, "conv1d: tile must be 0 (auto), 64, 128, 160 or 256");
     const bool big_ok = f16 && !has_x2 && !in_aff && d.cout % 256 == 0;
     if (d.tile == 256) MV_REQUIRE(big_ok, "conv1d: 256-wide tiles need the plain fp16 path and cout % 256 == 0");
-    const bool big = !in_stats && big_ok && d.tile != 128 && (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) >= 256);
+    // (auto: from 5/8 of a round of 256 x 256 tiles on -- 48 utterances of 3 s through a 1024-channel layer are 224 tiles = 39.5 us in one round, against 57-74 us
+    //  on 128-row tiles and 60 us on 64 x 64 ones: profiles/r12j_conv_tiles_by_batch.log)
+    const bool big = !in_stats && big_ok && d.tile != 128 && d.tile != 64 && d.tile != 160 &&
+                     (d.tile == 256 || (int64_t)ceil_div(a.n_rows, 256) * (d.cout / 256) * 8 >= (int64_t)cu_count() * 5);
     // persistent form of the 256^2 kernel: fp16 output, plain bias / ReLU / affine epilogue
     const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
@@ -1585,15 +1588,15 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     // Small problems (one utterance, a handful: predict() / small predict_batch calls): 128 x 128 tiles leave most of the chip idle -- one 3 s
     // utterance through a 1024 -> 1024 layer is 3 x 8 = 24 workgroups walking 16 serial K stages each.  64 x 64 tiles give four times the
     // workgroups (each K stage is a quarter of the bytes: shorter round trips), still one launch.
-    const bool small = direct && !big && !wide && d.tile == 0 && d.cout >= 64 &&
-                       ceil_div(a.n_rows, CV_TN) * ceil_div(d.cout, CV_TC) * 2 <= (int64_t)cu_count();
+    const bool small = direct && !big && !wide && d.cout >= 64 &&
+                       (d.tile == 64 || (d.tile == 0 && ceil_div(a.n_rows, CV_TN) * ceil_div(d.cout, CV_TC) * 2 <= (int64_t)cu_count()));
     if (stats)
         MV_REQUIRE(persist && d.k == 1 && d.cin % CV_BK == 0 && d.T_out >= 64,
                    "conv1d: fused time statistics need the persistent 1x1 kernel (fp16 in/out, cout % 256 == 0, cin % 64 == 0, "
                    "plain bias / ReLU / affine epilogue, T_out >= 64)");
     if (in_stats && direct && d.k == 1 && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out && d.cout <= CV_TC && d.tile == 0 && d.cin % 8 == 0 &&
         (reinterpret_cast<uintptr_t>(d.in_stat_sum) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.in_stat_sq) & 15) == 0 &&
-        (int64_t)d.B * ceil_div(d.T_out, CV_IN_STATS_TN) * 4 <= (int64_t)cu_count() && d.B <= 16384) {
+        (int64_t)d.B * ceil_div(d.T_out, CV_IN_STATS_TN) * 2 <= (int64_t)cu_count() && d.B <= 16384) {
         // small batch: the statistics from their own launch (bit-identical partial rows), the conv on small tiles
         a.per_utt = 1;
         a.tiles_per_utt = (int)ceil_div(d.T_out, CV_IN_STATS_TN);
