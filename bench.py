@@ -461,6 +461,9 @@ def main():
         except OSError:
             pass
 
+        traffic_note = ('per-launch HBM bytes of the committed PMC pass (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
+                        '2 x FETCH + WRITE per the gfx950 correction) -- a constant read from the file, not a counter of this run')
+
         def pmc_bytes(prefix):
             # the PMC pass was taken on the headline workload: no number for the other models
             hits = [v for k, v in traffic.items() if k.startswith(prefix)] if args.model == 'ecapa1024' else []
@@ -479,14 +482,14 @@ def main():
                      'frac': round(conv_tflops / mfma_peak, 4), 'traffic': pmc_bytes('mv::conv1d_ring_persistent_kernel') or pmc_bytes('mv::conv1d_glds_persistent_kernel'),
                      'launches': n_conv, 'avg_launch_us': round(ms_conv / max(n_conv, 1) * 1e3, 2),
                      'algorithmic_gflop_per_launch': round(flop_conv / max(n_conv, 1) / 1e9, 3),
-                     'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3)}
+                     'share_of_step': round(ms_conv / len(range(0, args.steps, 4)) / ms_per_step, 3), 'traffic_source': traffic_note}
         fe_kernel = 'fbank_tile_kernel (Fbank-80 + CMN + mask, one launch)' if method == 'Fbank' else \
             'melspec front-end (STFT power + HTK mel + CMN + mask)'
         if n_fb > 0:
             roof_fe = {'kernel': fe_kernel, 'bound': 'hbm', 'achieved': round(fb_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(fb_gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_bytes('mv::fbank_tile_kernel') or pmc_bytes('mv::fbank_kernel'),
                        'launches': n_fb, 'avg_launch_us': round(ms_fb / max(n_fb, 1) * 1e3, 2),
-                       'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1))}
+                       'algorithmic_bytes_per_launch': int(byte_fb / max(n_fb, 1)), 'traffic_source': traffic_note}
         else:  # front-ends without a per-launch profile class: the stage time between events on the launch stream
             fe_bytes = B * frontend_bytes_per_utt(args.model, T)
             roof_fe = {'kernel': fe_kernel + ', stage time', 'bound': 'hbm', 'achieved': round(fe_bytes / (fb_ms * 1e-3) / 1e9, 1),
