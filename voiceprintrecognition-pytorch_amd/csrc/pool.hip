@@ -19,6 +19,8 @@ namespace mv {
 // (x - mean)^2 form -- |mean - k| is of the order of the spread -- and makes a constant channel's variance exactly zero:
 //   mean = k + s1 / T,   var = (s2 - s1^2 / T) / (T or T - 1)
 // Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
+// PIPE: four rows in flight per lane (small grids; costs registers, i.e. waves per SIMD, which a full batch needs more than the overlap)
+template <bool PIPE>
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
                                                          float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
                                                          const float* in_scale, const float* in_shift) {
@@ -53,9 +55,10 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
             for (int e = 0; e < nvalid; ++e) k8[e] = val(xb[e], e);
         }
         int t = t_first;
-        if (nvalid == 8) {
-            // four rows in flight per lane (same order of the additions): with one utterance on the chip the pass is a chain of dependent
-            // load trips, 19 of them for 3 s -- 13 us for 610 KB
+        if (PIPE && nvalid == 8) {
+            // small grids only: four rows in flight per lane, same order of the additions -- with one utterance on the chip the pass is
+            // a chain of dependent load trips, 19 of them for 3 s: 13 -> 10 us for 610 KB.  A full batch (2048 workgroups) streams at the HBM rate
+            // with one load per lane in flight and LOSES with four (29 -> 38 us at 256 x 3 s, r12l: fewer waves per SIMD)
             for (; t + 48 < T; t += 64) {
                 half8v v4[4];
 #pragma unroll
@@ -126,8 +129,13 @@ int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* m
     MV_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
-    MV_LAUNCH(time_stats_kernel, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
-              ld_out, unbiased, clamp_eps, in_scale, in_shift);
+    if (ceil_div(C, 128) * (int64_t)B <= 1024) {
+        MV_LAUNCH(time_stats_kernel<true>, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
+                  ld_out, unbiased, clamp_eps, in_scale, in_shift);
+    } else {
+        MV_LAUNCH(time_stats_kernel<false>, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
+                  ld_out, unbiased, clamp_eps, in_scale, in_shift);
+    }
     return check_launch("time_stats_kernel");
 }
 
