@@ -35,7 +35,7 @@ extern "C" {
 #define MV_ERR_WORKSPACE (-4)
 #define MV_ERR_MISSING_TENSOR (-5)
 
-#define MV_ABI_VERSION 2
+#define MV_ABI_VERSION 3
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -275,6 +275,51 @@ int mv_conv2d_first(const float* feats, float* out, const float* w, const float*
 /* temporal statistics pooling of fp32 [B, H, W, ld] (C real channels) -> fp32 [B, 2*C*H]: mean | sqrt(unbiased var + 1e-8),
  * index c*H + h as the reference flattens [B, C, H] */
 int mv_tstp_f32(const float* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The same layers on the fp16 matrix pipe with split operands (csrc/conv2ds.hip; what mv_eres2net_create's handles run since ABI 3).
+ * Maps are "S16": channel-last with 4 bytes per channel like the fp32 maps above (same pointers, leading dimensions and
+ * 16-channel slices), but a unit of 16 channels holds [16 x hi | 16 x lo] fp16 of 64 * value (hi = fp16(V), lo = fp16(V - hi)):
+ * 22 significant bits, |value| saturates at 1023.5.  mv_map_split_f32 / mv_map_merge_f32 convert n = pixels * ld fp32
+ * elements (whole units) to and from that form.  Weights: mv_conv2ds_pack_weight scales a layer by a power of two, splits it the
+ * same way into [cout16][k*k][round_up(cin16, 32) / 16 units][32] (mv_conv2ds_packed_elems 4-byte elements) and returns the factor
+ * `oscale` the accumulator is multiplied with (synchronises the stream: weights are read back to the host).
+ *   y = epi( oscale * sum_taps W . in + bias ),  in = x | cat(x, x2)  (x2 != NULL: cin1 channels from x, the rest from x2)
+ *   epi as above; optionally y2 = y + add (the input of the next 3x3 conv of a Res2Net block, eres2net.py:92)
+ * ------------------------------------------------------------------------------------------------ */
+int64_t mv_conv2ds_packed_elems(int32_t cout, int32_t cin, int32_t ks);
+int mv_conv2ds_pack_weight(const float* w, const float* out_scale, int32_t cout, int32_t cin, int32_t ks, void* packed, float* oscale,
+                           mv_stream_t stream);
+int mv_map_split_f32(const float* x, void* y, int64_t n, mv_stream_t stream);
+int mv_map_merge_f32(const void* x, float* y, int64_t n, mv_stream_t stream);
+typedef struct MvConv2dsDesc {
+    const void* x;       /* S16 [B, H, W, ldx] */
+    const void* x2;      /* optional: channels cin1 .. cin16 of the input come from here (AFF concatenation, eres2net.py:49) */
+    int32_t cin1;
+    int64_t ldx, ldx2;
+    const void* w;       /* from mv_conv2ds_pack_weight */
+    const float* bias;   /* [cout16] */
+    float oscale;        /* from mv_conv2ds_pack_weight */
+    const void* res;     /* epi 0: optional residual; epi 2: first AFF operand; S16 [B, Ho, Wo, ldres] */
+    const void* res2;    /* epi 2: second AFF operand */
+    int64_t ldres, ldres2;
+    const void* add;     /* optional with y2: S16 [B, Ho, Wo, ldadd] */
+    int64_t ldadd;
+    void* y;             /* S16 [B, Ho, Wo, ldy], Ho = (H + 2*(ks/2) - ks)/stride + 1, Wo likewise */
+    int64_t ldy;
+    void* y2;            /* optional second output y + add */
+    int64_t ldy2;
+    int32_t B, H, W, cin16, cout16, ks, stride, epi;
+    float lo, hi;
+    int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
+    int32_t nbw_hint, ct_hint, rows_hint; /* 0 = the launcher's choice; otherwise blocks of 16 output channels per wave (1..4), blocks per
+                                           * workgroup, rows per 3x3 tile (1..8): tile shapes for tests and tools/bench_conv2d.py */
+} MvConv2dsDesc;
+int mv_conv2ds_forward(const MvConv2dsDesc* d, mv_stream_t stream);
+/* the first conv and the pooling with S16 maps on the map side */
+int mv_conv2d_first_s16(const float* feats, void* out, const float* w, const float* bias, int32_t B, int32_t T, int32_t F,
+                        int32_t C, mv_stream_t stream);
+int mv_tstp_s16(const void* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream);
 
 /* pack [Cout][Cin][k] fp32 (nn.Conv1d layout) -> fp16 [Cout_pad][k][Cin_pad]; returns element count */
 int64_t mv_conv1d_packed_elems(int32_t cout, int32_t cin, int32_t k);

@@ -271,6 +271,137 @@ CONV2D_CASES = [
 ]
 
 
+def s16_split(cdll, t, device):
+    """fp32 channel-last tensor (last axis a multiple of 16) -> device buffer in the S16 form of conv2ds.hip"""
+    td = t.to(device).contiguous().float()
+    out = torch.zeros_like(td)
+    _hip.check(cdll.mv_map_split_f32(td.data_ptr(), out.data_ptr(), td.numel(), _stream(td)), cdll)
+    return out
+
+
+def s16_merge(cdll, buf):
+    out = torch.empty_like(buf)
+    _hip.check(cdll.mv_map_merge_f32(buf.data_ptr(), out.data_ptr(), buf.numel(), _stream(buf)), cdll)
+    if buf.device.type != 'cpu':
+        torch.cuda.synchronize()
+    return out.cpu()
+
+
+def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, concat=False, epi=0, with_res=False, with_sum=False,
+                 lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, x_scale=1.0):
+    """mv_conv2ds_forward (split-fp16 operands on S16 maps) against F.conv2d in fp64 on the SAME 22-bit inputs: the map round trip
+    (split -> merge) is what the layer sees, so the bar is the fp32 one of conv2d_case."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    r16 = lambda n: -(-n // 16) * 16
+    cin_a = cin if not concat else cin // 2            # concat: two operands of cin/2 channels each
+    lda = r16(cin_a) + 16
+    xa = rn(B, H, W, lda) * x_scale
+    xb = rn(B, H, W, lda) * x_scale if concat else None
+    w = rn(cout, cin, ks, ks) * (2.0 / (cin * ks * ks)) ** 0.5
+    bn_scale = torch.rand(cout, generator=g) + 0.5
+    bias = rn(cout) * 0.3
+    p = ks // 2
+    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // stride + 1
+    c16 = r16(cout)
+    ldy = c16 + 16
+    res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
+    res2 = rn(B, Ho, Wo, c16) if epi == 2 else None
+    add = rn(B, Ho, Wo, c16) if with_sum else None
+    dev = lambda t: None if t is None else t.to(device).contiguous()
+    sp = lambda t: None if t is None else s16_split(cdll, t, device)
+    xad, xbd, resd, res2d, addd = sp(xa), sp(xb), sp(res), sp(res2), sp(add)
+    # what the layer reads: the 22-bit values
+    mg = lambda t: None if t is None else s16_merge(cdll, t).double()
+    xa_q, xb_q, res_q, res2_q, add_q = mg(xad), mg(xbd), mg(resd), mg(res2d), mg(addd)
+    assert (xa_q - xa.double()).abs().max().item() <= 3e-7 * max(1.0, xa.abs().max().item()), 'S16 round trip is not 22-bit'
+    wd, sd = dev(w), dev(bn_scale)
+    if concat:
+        wfull = torch.zeros(cout, 2 * r16(cin_a), ks, ks)
+        wfull[:, :cin_a] = w[:, :cin_a]
+        wfull[:, r16(cin_a):r16(cin_a) + cin_a] = w[:, cin_a:]
+        wd = dev(wfull)
+        cin_k = 2 * r16(cin_a)
+    else:
+        cin_k = cin
+    n = cdll.mv_conv2ds_packed_elems(cout, cin_k, ks)
+    packed = torch.zeros(n, dtype=torch.float32, device=device)
+    osc = ctypes.c_float(0.0)
+    _hip.check(cdll.mv_conv2ds_pack_weight(wd.data_ptr(), sd.data_ptr(), cout, cin_k, ks, packed.data_ptr(), ctypes.byref(osc), _stream(wd)), cdll)
+    biasd = torch.zeros(c16, device=device)
+    biasd[:cout] = dev(bias)
+    fill = s16_split(cdll, torch.full((B, Ho, Wo, ldy), 7.0), device)
+    y = fill.clone()
+    y2 = fill.clone() if with_sum else None
+    d = _hip.MvConv2dsDesc()
+    d.x, d.ldx = xad.data_ptr(), lda
+    d.x2, d.ldx2, d.cin1 = (xbd.data_ptr() if concat else None), lda, (r16(cin_a) if concat else 0)
+    d.w, d.bias, d.oscale = packed.data_ptr(), biasd.data_ptr(), osc.value
+    d.res, d.ldres = (resd.data_ptr() if res is not None else None), c16
+    d.res2, d.ldres2 = (res2d.data_ptr() if res2 is not None else None), c16
+    d.add, d.ldadd = (addd.data_ptr() if add is not None else None), c16
+    d.y, d.ldy = y.data_ptr(), ldy
+    d.y2, d.ldy2 = (y2.data_ptr() if with_sum else None), ldy
+    d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
+    d.lo, d.hi = lo, hi
+    d.nbw_hint, d.ct_hint, d.rows_hint = nbw, ct, rows
+    _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(d), _stream(xad)), cdll)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+
+    xin = xa_q[..., :cin_a]
+    if concat:
+        xin = torch.cat([xin, xb_q[..., :cin_a]], dim=-1)
+    weff = (w * bn_scale.view(-1, 1, 1, 1)).double()
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias.double(), stride=stride, padding=p).permute(0, 2, 3, 1)
+    if epi == 0:
+        if with_res:
+            ref = ref + res_q[..., :cout]
+        ref = ref.clamp(lo, hi)
+    elif epi == 1:
+        ref = F.silu(ref)
+    else:
+        t = torch.tanh(ref)
+        ref = res_q[..., :cout] * (1 + t) + res2_q[..., :cout] * (1 - t)
+    got = s16_merge(cdll, y).double()
+    assert torch.all(got[..., c16:] == 7.0), 'kernel wrote outside its channel slice'
+    if c16 > cout and epi != 2:
+        assert torch.all(got[..., cout:c16] == (0.0 if epi != 0 else min(max(0.0, lo), hi))), 'padded channels must stay zero'
+    scale = max(1.0, ref.abs().max().item())
+    err = (got[..., :cout] - ref).abs().max().item()
+    tol = 2e-5 * scale
+    assert err < tol, f'conv2ds mismatch {err} (tol {tol})'
+    if with_sum:
+        got2 = s16_merge(cdll, y2).double()
+        err2 = (got2[..., :cout] - (got[..., :cout] + add_q[..., :cout])).abs().max().item()
+        assert err2 < 1e-6 * scale, f'conv2ds second output mismatch {err2}'
+        assert torch.all(got2[..., c16:] == 7.0)
+    return err
+
+
+CONV2DS_CASES = [
+    dict(),                                                                  # 3x3 16 -> 16
+    dict(cin=13, cout=13, with_sum=True),                                    # ERes2NetV2 width 13 (padded) + the "sp + spx[i]" second output
+    dict(cin=32, cout=32, ks=1, stride=2, H=8, W=41),                        # strided 1x1 (conv1 / shortcut of a stage's first block)
+    dict(cin=64, cout=128, ks=3, stride=2, H=9, W=150, hi=65504.0, lo=-65504.0),  # layer1_downsample: no BN / activation
+    dict(cin=32, cout=64, ks=1, with_res=True, W=300, H=3),                  # conv3 + bn3 + residual + ReLU20, 8 pixel tiles
+    dict(cin=128, cout=16, ks=1, concat=True, epi=1),                        # AFF local_att[0:3]: cat -> 1x1 -> BN -> SiLU
+    dict(cin=96, cout=16, ks=1, concat=True, epi=1),                         # concat of two 48-channel operands: a K chunk straddles the sources
+    dict(cin=16, cout=64, ks=1, epi=2),                                      # AFF local_att[3:5] + fusion
+    dict(cin=104, cout=104, ks=3, H=5, W=40, B=1),                           # width 104: an odd number of 16-channel units, 7 blocks
+    dict(cin=256, cout=512, ks=3, stride=2, H=6, W=20, B=1, hi=65504.0, lo=-65504.0),  # layer3_downsample: two channel tiles
+    dict(cin=48, cout=144, ks=3, H=3, W=20, B=1),                            # 9 blocks on waves of 2: the last wave has one
+    dict(cin=48, cout=208, ks=1, H=2, W=37, B=2, with_res=True),             # 1x1: 13 blocks, an odd number of K chunks
+    dict(cin=32, cout=48, ks=1, stride=2, H=5, W=37, B=2),                   # strided 1x1 on odd sizes: 5 x 37 -> 3 x 19
+    dict(cin=16, cout=32, ks=3, stride=2, H=5, W=33, B=1),                   # strided 3x3 on odd sizes
+    dict(cin=48, cout=48, ks=3, H=21, W=50, B=1, with_sum=True),             # 21 rows: tiles of 7 rows
+    dict(cin=80, cout=80, ks=3, H=10, W=20, B=1, nbw=2),                     # forced two blocks per wave on 5 blocks
+    dict(cin=64, cout=256, ks=1, H=4, W=40, B=1, nbw=4, ct=8),               # four blocks per wave, two channel tiles
+    dict(cin=64, cout=192, ks=3, H=9, W=17, B=1, nbw=3, rows=3),             # three blocks per wave, tiles of 3 rows
+    dict(cin=32, cout=32, ks=3, H=6, W=18, B=1, x_scale=100.0, hi=65504.0, lo=-65504.0),   # large activations (|x| up to ~450; the split saturates at 1023.5)
+]
+
+
 def tstp_case(cdll, device, B=3, H=5, W=38, C=72, seed=0):
     g = torch.Generator().manual_seed(seed)
     ld = C + 8

@@ -23,6 +23,14 @@ def test_conv2d_emu(idx):
     lc.conv2d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV2D_CASES[idx])
 
 
+@pytest.mark.parametrize('idx', range(len(lc.CONV2DS_CASES)))
+def test_conv2ds_emu(idx):
+    """split-fp16 conv2d on S16 maps (conv2ds.hip): producer / consumer roles, patch geometry, swizzle, K tails, epilogues"""
+    if idx in (9,) and os.environ.get('MV_SLOW_EMU') != '1':
+        pytest.skip('slow under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
+    lc.conv2ds_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV2DS_CASES[idx])
+
+
 def test_tstp_and_first_conv_emu():
     lc.tstp_case(emu_cdll(), 'cpu')
     lc.conv2d_first_case(emu_cdll(), 'cpu')

@@ -28,7 +28,7 @@ def product_lib():
 def test_gpu_library_is_the_hip_build():
     from mvector import _hip
     lib = product_lib()
-    assert lib.mv_abi_version() == 2
+    assert lib.mv_abi_version() == 3
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 

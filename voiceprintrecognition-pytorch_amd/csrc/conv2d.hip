@@ -27,6 +27,7 @@
 // read of consecutive channels on both sides (the sum over K does not care about the order).  D[channel 4q+r][step j]:
 // a lane stores 4 consecutive channels (16 bytes) of one time step.
 #include "kernels.h"
+#include "s16map.h"
 
 namespace mv {
 
@@ -378,6 +379,8 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
 
 // ---- first conv of ERes2Net (eres2net.py:196-201, 250): one input map = the fp32 features [B, T, F] read transposed,
 // 3x3, zero padding, BatchNorm folded, plain ReLU.  K = 9 -> VALU; a lane produces 8 output maps of one position.
+// S16: the output map in the split-fp16 form of conv2ds.hip (s16map.h) instead of fp32
+template <bool S16>
 __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, float* out, const float* w, const float* bias,
                                                            int B, int T, int F, int C) {
     MV_DYN_SMEM(smem);
@@ -410,8 +413,14 @@ __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, f
             for (int j = 0; j < 9; ++j) acc += sw[co * 9 + j] * x[j];
             o[e] = fmaxf(acc, 0.0f);
         }
-        *reinterpret_cast<float4v*>(out + pix * C + cg * 8) = float4v{o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<float4v*>(out + pix * C + cg * 8 + 4) = float4v{o[4], o[5], o[6], o[7]};
+        if (S16) {
+            half_t* unit = reinterpret_cast<half_t*>(out) + (pix * C + (cg >> 1) * 16) * 2 + (cg & 1) * 8;
+            s16_store4(unit, float4v{o[0], o[1], o[2], o[3]});
+            s16_store4(unit + 4, float4v{o[4], o[5], o[6], o[7]});
+        } else {
+            *reinterpret_cast<float4v*>(out + pix * C + cg * 8) = float4v{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<float4v*>(out + pix * C + cg * 8 + 4) = float4v{o[4], o[5], o[6], o[7]};
+        }
     }
 }
 
@@ -421,13 +430,24 @@ int conv2d_first_launch(const float* feats, float* out, const float* w, const fl
     MV_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024, "conv2d_first: output maps must be a multiple of 8");
     const int64_t total = (int64_t)B * F * T * (C / 8);
     const int grid = (int)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
-    MV_LAUNCH(conv2d_first_kernel, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, out, w, bias, B, T, F, C);
+    MV_LAUNCH(conv2d_first_kernel<false>, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, out, w, bias, B, T, F, C);
+    return check_launch("conv2d_first_kernel");
+}
+
+int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream) {
+    MV_REQUIRE(feats != nullptr && out != nullptr && w != nullptr && bias != nullptr, "conv2d_first_s16: null pointer");
+    MV_REQUIRE(C > 0 && C % 16 == 0 && C <= 1024, "conv2d_first_s16: output maps must be a multiple of 16");
+    const int64_t total = (int64_t)B * F * T * (C / 8);
+    const int grid = (int)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
+    MV_LAUNCH(conv2d_first_kernel<true>, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, reinterpret_cast<float*>(out), w, bias, B,
+              T, F, C);
     return check_launch("conv2d_first_kernel");
 }
 
 // ---- temporal statistics pooling (mvector/models/pooling.py:130-148) over channel-last maps [B, H, W, C]:
 // stats[b, c*H + h] = mean over W, stats[b, C*H + c*H + h] = sqrt(unbiased var + 1e-8) -- the reference flattens [B, C, H].
 // One workgroup per (utterance, frequency row); moments about the first time step (see time_stats_kernel).
+template <bool S16>
 __global__ __launch_bounds__(256) void tstp_kernel(const float* x, int64_t ld, int H, int W, int C, int Creal, float* stats) {
     __shared__ float red[2][256];
     const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
@@ -436,9 +456,10 @@ __global__ __launch_bounds__(256) void tstp_kernel(const float* x, int64_t ld, i
         const int c = c0 + (tid & 63), ph = tid >> 6;
         float s1 = 0.0f, s2 = 0.0f, k = 0.0f;
         if (c < Creal) {
-            k = xr[c];
+            const half_t* xh = reinterpret_cast<const half_t*>(xr);
+            k = S16 ? s16_load1(xh, 0, c) : xr[c];
             for (int w = ph; w < W; w += 4) {
-                const float d = xr[(int64_t)w * ld + c] - k;
+                const float d = (S16 ? s16_load1(xh, (int64_t)w * ld, c) : xr[(int64_t)w * ld + c]) - k;
                 s1 += d;
                 s2 = fmaf(d, d, s2);
             }
@@ -462,7 +483,14 @@ __global__ __launch_bounds__(256) void tstp_kernel(const float* x, int64_t ld, i
 int tstp_launch(const float* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream) {
     MV_REQUIRE(x != nullptr && stats != nullptr && B > 0 && H > 0 && W > 1 && C > 0 && ld >= C, "tstp: bad argument");
     MV_REQUIRE(H <= 65535 && B <= 65535, "tstp: grid too large");
-    MV_LAUNCH(tstp_kernel, ((unsigned)H, (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, H, W, (int)ld, C, stats);
+    MV_LAUNCH(tstp_kernel<false>, ((unsigned)H, (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, H, W, (int)ld, C, stats);
+    return check_launch("tstp_kernel");
+}
+
+int tstp_s16_launch(const half_t* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && stats != nullptr && B > 0 && H > 0 && W > 1 && C > 0 && ld >= C && ld % 16 == 0, "tstp_s16: bad argument");
+    MV_REQUIRE(H <= 65535 && B <= 65535, "tstp_s16: grid too large");
+    MV_LAUNCH(tstp_kernel<true>, ((unsigned)H, (unsigned)B, 1), (256, 1, 1), 0, stream, reinterpret_cast<const float*>(x), ld, H, W, (int)ld, C, stats);
     return check_launch("tstp_kernel");
 }
 
@@ -510,6 +538,15 @@ int mv_conv2d_first(const float* feats, float* out, const float* w, const float*
 
 int mv_tstp_f32(const float* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream) {
     return mv::tstp_launch(x, ld, B, H, W, C, stats, static_cast<hipStream_t>(stream));
+}
+
+int mv_conv2d_first_s16(const float* feats, void* out, const float* w, const float* bias, int32_t B, int32_t T, int32_t F, int32_t C,
+                        mv_stream_t stream) {
+    return mv::conv2d_first_s16_launch(feats, static_cast<half_t*>(out), w, bias, B, T, F, C, static_cast<hipStream_t>(stream));
+}
+
+int mv_tstp_s16(const void* x, int64_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* stats, mv_stream_t stream) {
+    return mv::tstp_s16_launch(static_cast<const half_t*>(x), ld, B, H, W, C, stats, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,557 @@
+// 2-D convolutions of the ERes2Net family (mvector/models/eres2net.py:23-30) on the fp16 matrix pipe with fp32-grade operands
+// ("split" form, round 4).  conv2d.hip evaluates the same layers with fp32 maps and weights on v_mfma_f32_16x16x4_f32, 1/16 of the fp16
+// MFMA rate; the family does not tolerate 11-bit operands, but it does tolerate 22-bit ones:
+//
+//   every operand value v is carried as a pair of fp16 numbers  hi = fp16(V), lo = fp16(V - hi)  of the scaled value V = v * 2^k, and a
+//   product sum is evaluated as  sum Whi.Xhi + Whi.Xlo + Wlo.Xhi  in ONE fp32 accumulator (three v_mfma_f32_16x16x32_f16 per 32 channels:
+//   3/16 of the fp32 pipe's time); the dropped Wlo.Xlo term is 2^-22 of the product.  Activations are scaled by 2^6 (a map value of
+//   2e-3 still has a normal lo part; fp16 overflows at |v| = 1023.5, the split saturates there), the weights of a layer by the power of two
+//   that puts their largest magnitude into [512, 1024); the epilogue multiplies the accumulator by 2^-(6 + s) -- exact.  Emulated on the
+//   oracle (every conv of the seeded models evaluated this way, products in fp64): 1 - cos 4e-9 on the m32 models against the 1e-6 of the goldens.
+//
+// Map format "S16": channel-last like conv2d.hip's fp32 maps and with the same 4 bytes per channel, so pointers, leading dimensions and
+// channel slices (multiples of 16) are what they are there -- but a unit of 16 channels is stored as [16 x hi | 16 x lo] fp16.  A pixel's
+// 32-channel K chunk is then 128 contiguous bytes = 8 granules of 16 bytes (unit 0 hi ch 0-7, hi ch 8-15, lo ch 0-7, lo ch 8-15, unit 1 ...)
+// that LDS-DMA moves without touching a register, and lane group q of an MFMA operand reads granule (q >> 1) * 4 + (q & 1) for its hi half
+// and the granule two further for lo.  Weights are packed the same way per (output channel, tap): [cout16][taps][2 * nchunks units][32].
+//
+// Kernel: workgroup = (utterance, pixel tile of 8 segments of 16 output pixels, tile of CT blocks of 16 output channels).
+//   3x3: the segments are R <= 8 consecutive rows of one 16-column strip, so the input patch is (R - 1) * stride + 3 rows of 15 * stride + 3
+//        (padded to a multiple of 8) columns -- 1.4 x the output pixels where a flat list of segments reads 3.4 x;
+//   1x1: 128 consecutive pixels of the flattened utterance plane (no column padding of narrow maps).
+//   One or more PRODUCER waves keep the patch of the next K stage (3x3: one 32-channel chunk; 1x1: two) travelling into the other half of a
+//   double-buffered LDS area (global_load_lds, zero padding and the channel concatenation of AFF = the source address of a granule); they wait for
+//   their own transfers and meet the consumers at one barrier per stage.  The CONSUMER waves split the output channels (NBW blocks each) and
+//   share the pixels: every wave reads the B fragments (pixels) of all 8 segments from LDS -- bank-conflict free through the granule ^ (entry & 7)
+//   swizzle applied on the source side -- and its own A fragments (weights) straight from global memory / L2, one step ahead, so no weight byte
+//   is fetched twice by a workgroup.  Accumulators: 8 x NBW x 4 registers.
+//   Epilogue: scale, bias, clamp [+ residual] | SiLU | AFF mix, optionally a second output  y2 = y + add  (the "sp + spx[i]" input of the next
+//   3x3 conv of a Res2Net block, eres2net.py:92, so that its loader stays a plain copy), split and stored as two 8-byte halves per lane.
+#include <vector>
+
+#include "kernels.h"
+#include "s16map.h"
+
+namespace mv {
+
+constexpr int CS_SEGS = 8;             // 16-pixel segments per workgroup
+constexpr int CS_PI_MAX = 32;          // LDS-DMA instructions of one K chunk a producer wave may own
+constexpr int CS_CHUNK1_BYTES = CS_SEGS * 16 * 128;  // 1x1: one 32-channel chunk of the 128 pixels
+constexpr int CS_KCH1 = 2;                           // 1x1: chunks per stage
+
+__device__ __attribute__((aligned(256))) const unsigned char g_cs_zero_page[256] = {0};
+
+struct Conv2dsArgs {
+    const half_t* x;
+    const half_t* x2;    // second source of the channel concatenation (units >= cin1u)
+    const half_t* w;     // [cout16][taps][wunits][32]
+    const float* bias;   // [cout16]
+    const half_t* res;   // epi 0: optional residual; epi 2: first AFF operand
+    const half_t* res2;  // epi 2: second AFF operand
+    const half_t* add;   // optional: y2 = y + add
+    half_t* y;
+    half_t* y2;
+    int64_t ldx, ldx2, ldres, ldres2, ldadd, ldy, ldy2;  // channels (= 4-byte elements) between pixels
+    int cin1u, cinu, nchunks, wunits, cout16;
+    int H, W, Ho, Wo, sh, sw, epi;
+    float lo, hi, oscale;
+    int R, ncs, tiles, CT, ncons, nprod;   // rows per 3x3 tile, column strips, pixel tiles per utterance, blocks per channel tile, wave roles
+    int pc, pcv;                            // 3x3: allocated / valid patch columns
+};
+
+template <int KS, int NBW, int MAXT>
+__global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
+    MV_DYN_SMEM(smem);
+    constexpr int TAPS = KS * KS;
+    constexpr int KCH = KS == 3 ? 1 : CS_KCH1;            // K chunks per stage
+    constexpr int G = NBW >= 2 ? 2 : 4;                   // segments per MFMA group: >= 4 independent accumulators between dependent MFMAs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = MV_UNIFORM(tid >> 6);
+    const int b = blockIdx.y;
+    const int t = blockIdx.x % a.tiles, ct = blockIdx.x / a.tiles;
+    const int nst = (a.nchunks + KCH - 1) / KCH;
+    // tile origin
+    int ho0 = 0, wo0 = 0, p0 = 0;
+    if (KS == 3) {
+        ho0 = (t / a.ncs) * a.R;
+        wo0 = (t % a.ncs) * 16;
+    } else {
+        p0 = t * (CS_SEGS * 16);
+    }
+    const int chunk_bytes = KS == 3 ? ((a.R - 1) * a.sh + 3) * a.pc * 128 : CS_CHUNK1_BYTES;
+    const int stage_bytes = chunk_bytes * KCH;
+    const unsigned lds0 = lds_addr(smem);
+
+    if (wave >= a.ncons) {
+        // ---------------- producer ----------------
+        const int pw = wave - a.ncons;
+        const int psel = lane >> 3, slot = lane & 7;
+        const int g = slot ^ psel;                  // granule of the 128-byte chunk row this lane fetches (entry & 7 == psel: rows of 8k entries)
+        const int usel = g >> 2, inner = (g & 3) * 8;  // unit of the chunk, halves inside the unit
+        const int ni = chunk_bytes >> 10;           // transfers per chunk
+        int pidx[CS_PI_MAX];                        // input pixel of this lane's entry per owned transfer, -1 = zero
+#pragma unroll
+        for (int i = 0; i < CS_PI_MAX; ++i) {
+            const int k = i * a.nprod + pw;
+            int v = -1;
+            if (k < ni) {
+                const int entry = k * 8 + psel;
+                if (KS == 3) {
+                    const int pr = entry / a.pc, pcc = entry - pr * a.pc;
+                    const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + pcc;
+                    if (pcc < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) v = hi * a.W + wi;
+                } else {
+                    const int p = p0 + entry;
+                    if (p < a.Ho * a.Wo) {
+                        const int ho = p / a.Wo, wo = p - ho * a.Wo;
+                        v = ho * a.sh * a.W + wo * a.sw;
+                    }
+                }
+            }
+            pidx[i] = v;
+        }
+        const half_t* xb = a.x + (int64_t)b * a.H * a.W * a.ldx * 2;
+        const half_t* x2b = a.x2 != nullptr ? a.x2 + (int64_t)b * a.H * a.W * a.ldx2 * 2 : nullptr;
+        const half_t* zero = reinterpret_cast<const half_t*>(g_cs_zero_page);
+        auto issue_stage = [&](int c) {
+            const unsigned base = lds0 + (unsigned)((c & 1) * stage_bytes);
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                const int u = 2 * (c * KCH + kc) + usel;
+#pragma unroll
+                for (int i = 0; i < CS_PI_MAX; ++i) {
+                    const int k = i * a.nprod + pw;
+                    if (k < ni) {  // uniform
+                        const half_t* src = zero;
+                        if (pidx[i] >= 0 && u < a.cinu) {
+                            src = u < a.cin1u ? xb + ((int64_t)pidx[i] * a.ldx + 16 * u) * 2 + inner
+                                              : x2b + ((int64_t)pidx[i] * a.ldx2 + 16 * (u - a.cin1u)) * 2 + inner;
+                        }
+                        glds16_untracked(src, base + (unsigned)(kc * chunk_bytes + k * 1024));
+                    }
+                }
+            }
+        };
+        issue_stage(0);
+        wait_vm<0>();
+        lds_barrier();
+#pragma unroll 1
+        for (int c = 0; c < nst; ++c) {
+            if (c + 1 < nst) issue_stage(c + 1);
+            wait_vm<0>();
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ---------------- consumer ----------------
+    const int j16 = lane & 15, q = lane >> 4;
+    const int ghi = (q >> 1) * 4 + (q & 1);
+    const int nblk_total = a.cout16 >> 4;
+    const int blk0 = ct * a.CT + wave * NBW;                 // this wave's first block of 16 output channels
+    int nb = nblk_total - blk0;                              // blocks of this wave that exist
+    {
+        const int in_tile = a.CT - wave * NBW;
+        nb = nb < in_tile ? nb : in_tile;
+        nb = nb < NBW ? nb : NBW;
+    }
+    nb = MV_UNIFORM(nb);
+    int nvalid;                                              // segments of this tile that exist
+    if (KS == 3) {
+        const int rows = a.Ho - ho0;
+        nvalid = rows < a.R ? rows : a.R;
+    } else {
+        const int left = a.Ho * a.Wo - p0;
+        nvalid = left >= CS_SEGS * 16 ? CS_SEGS : (left + 15) >> 4;
+    }
+    nvalid = MV_UNIFORM(nvalid);
+
+    float4v acc[CS_SEGS][NBW];
+#pragma unroll
+    for (int u = 0; u < CS_SEGS; ++u)
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[u][i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // A fragments: lane (row j16 of a block, K group q) reads 16 bytes of hi and the 16 bytes 32 further of lo
+    const int64_t wrow_halves = (int64_t)TAPS * a.wunits * 32;
+    const half_t* wrow[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int blk = i < nb ? blk0 + i : (blk0 < nblk_total ? blk0 : 0);   // clamped: loaded, never used
+        wrow[i] = a.w + ((int64_t)blk * 16 + j16) * wrow_halves + ghi * 8;
+    }
+    // step j of stage c: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j
+    constexpr int SPS = KS == 3 ? TAPS : KCH;
+    auto a_offset = [&](int c, int j) -> int64_t {
+        if (KS == 3) return ((int64_t)j * a.wunits + 2 * c) * 32;
+        const int ch = c * KCH + j;
+        return (int64_t)(ch < a.nchunks ? ch : a.nchunks - 1) * 64;
+    };
+    half8v ah[NBW], al[NBW], nh[NBW], nl[NBW];
+    auto load_a = [&](int c, int j) {
+        const int64_t off = a_offset(c, j);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            nh[i] = *reinterpret_cast<const half8v*>(wrow[i] + off);
+            nl[i] = *reinterpret_cast<const half8v*>(wrow[i] + off + 16);
+        }
+    };
+    load_a(0, 0);
+    // B fragments: entry e of the patch at e * 128, granule g at ((g ^ (e & 7)) << 4); rows of a 3x3 patch are a multiple of 8 entries
+    // apart, so segment u is a constant further than segment 0
+    const int seg_stride = KS == 3 ? a.sh * a.pc * 128 : 16 * 128;
+
+    lds_barrier();  // stage 0 has landed
+#pragma unroll 1
+    for (int c = 0; c < nst; ++c) {
+        const char* buf = smem + (c & 1) * stage_bytes;
+#pragma unroll 1
+        for (int j = 0; j < SPS; ++j) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                ah[i] = nh[i];
+                al[i] = nl[i];
+            }
+            {   // the next step's weights
+                int cn = c, jn = j + 1;
+                if (jn == SPS) {
+                    jn = 0;
+                    cn = c + 1 < nst ? c + 1 : c;
+                }
+                load_a(cn, jn);
+            }
+            const bool live = KS == 3 || c * KCH + j < a.nchunks;  // uniform: the chunk behind the last one of an odd count does not exist
+            if (live && nb > 0) {
+                int e0;
+                const char* cb;
+                if (KS == 3) {
+                    const int kh = j / 3, kw = j - kh * 3;
+                    e0 = kh * a.pc + j16 * a.sw + kw;
+                    cb = buf;
+                } else {
+                    e0 = j16;
+                    cb = buf + j * chunk_bytes;
+                }
+                const char* ph = cb + e0 * 128 + ((ghi ^ (e0 & 7)) << 4);
+                const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4);
+#pragma unroll
+                for (int u0 = 0; u0 < CS_SEGS; u0 += G) {
+                    if (u0 < nvalid) {  // uniform
+                        half8v bh[G], bl[G];
+#pragma unroll
+                        for (int u = 0; u < G; ++u) {
+                            bh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
+                            bl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[u], acc[u0 + u][i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[u], acc[u0 + u][i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[u], acc[u0 + u][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        lds_barrier();  // every wave is done with this buffer; the next stage has landed
+    }
+
+    // ---------------- epilogue: D[channel 4q + r][pixel j16] ----------------
+    const int HWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int u = 0; u < CS_SEGS; ++u) {
+        if (u >= nvalid) break;  // uniform
+        int64_t pix;
+        bool ok;
+        if (KS == 3) {
+            const int wo = wo0 + j16;
+            ok = wo < a.Wo;
+            pix = (int64_t)b * HWo + (int64_t)(ho0 + u) * a.Wo + wo;
+        } else {
+            const int p = p0 + u * 16 + j16;
+            ok = p < HWo;
+            pix = (int64_t)b * HWo + p;
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (i >= nb) break;  // uniform
+            const int co = (blk0 + i) * 16 + q * 4;
+            const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
+            const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
+            float4v v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[u][i][r] * a.oscale + bias[r];
+            if (a.epi == 0) {
+                if (a.res != nullptr) {
+                    const float4v rv = s16_load4(a.res + pix * a.ldres * 2 + coff);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
+            } else if (a.epi == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            } else {
+                const float4v xa = s16_load4(a.res + pix * a.ldres * 2 + coff);
+                const float4v ya = s16_load4(a.res2 + pix * a.ldres2 * 2 + coff);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float th = tanhf(v[r]);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
+                    v[r] = xa[r] * (1.0f + th) + ya[r] * (1.0f - th);
+                }
+            }
+            s16_store4(a.y + pix * a.ldy * 2 + coff, v);
+            if (a.y2 != nullptr) {
+                const float4v av = s16_load4(a.add + pix * a.ldadd * 2 + coff);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += av[r];
+                s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);
+            }
+        }
+    }
+}
+
+// ---- launch ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct CsPlan {
+    int nbw, CT, ctiles, ncons, nprod, R, ncs, tiles, pc, pcv, maxt;
+    size_t lds;
+};
+
+// rows per 3x3 tile: the value in 4..8 that wastes the fewest rows (ties: the larger)
+int cs_rows(int Ho, int stride) {
+    if (stride == 2) return 2;
+    if (Ho <= 8) return Ho;
+    int best = 8, waste = (int)(ceil_div(Ho, 8) * 8 - Ho);
+    for (int r = 7; r >= 4; --r) {
+        const int w = (int)(ceil_div(Ho, r) * r - Ho);
+        if (w < waste) {
+            waste = w;
+            best = r;
+        }
+    }
+    return best;
+}
+
+int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
+    const int nblk = d.cout16 / 16;
+    int nbw = d.nbw_hint;
+    if (nbw == 0) nbw = nblk <= 7 ? 1 : 2;
+    MV_REQUIRE(nbw >= 1 && nbw <= 4, "conv2ds: blocks per wave must be 1..4");
+    const int max_waves = nbw <= 2 ? 12 : 8;        // 168 / 256 registers per lane
+    const int nprod_want = d.ks == 1 ? 4 : 2;
+    const int max_cons = nbw <= 2 ? 8 : max_waves - nprod_want;
+    int CT = d.ct_hint;
+    if (CT == 0) {
+        const int cap = max_cons * nbw;
+        const int ctiles = (int)ceil_div(nblk, cap);
+        CT = (int)round_up(ceil_div(nblk, ctiles), nbw);
+    }
+    MV_REQUIRE(CT >= 1 && ceil_div(CT, nbw) <= max_cons, "conv2ds: channel tile too wide");
+    p->nbw = nbw;
+    p->CT = CT;
+    p->ctiles = (int)ceil_div(nblk, CT);
+    p->ncons = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
+    p->maxt = max_waves * 64;
+    if (d.ks == 3) {
+        p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride);
+        MV_REQUIRE(p->R >= 1 && p->R <= CS_SEGS, "conv2ds: rows per tile must be 1..8");
+        p->ncs = (int)ceil_div(Wo, 16);
+        p->tiles = (int)ceil_div(Ho, p->R) * p->ncs;
+        p->pcv = 15 * sw + 3;
+        p->pc = (int)round_up(p->pcv, 8);
+        const int chunk = ((p->R - 1) * d.stride + 3) * p->pc * 128;
+        p->lds = (size_t)2 * chunk;
+        const int ni = chunk / 1024;
+        p->nprod = nprod_want;
+        while ((int)ceil_div(ni, p->nprod) > CS_PI_MAX) ++p->nprod;
+    } else {
+        p->R = CS_SEGS;
+        p->ncs = 0;
+        p->tiles = (int)ceil_div((int64_t)Ho * Wo, CS_SEGS * 16);
+        p->pc = p->pcv = 0;
+        p->lds = (size_t)2 * CS_KCH1 * CS_CHUNK1_BYTES;
+        p->nprod = nprod_want;
+    }
+    MV_REQUIRE(p->ncons + p->nprod <= max_waves, "conv2ds: too many waves for one workgroup");
+    MV_REQUIRE(p->lds <= 160 * 1024, "conv2ds: patch does not fit the LDS");
+    return MV_OK;
+}
+
+template <int KS, int NBW, int MAXT>
+int cs_launch(const Conv2dsArgs& a, const CsPlan& p, int B, hipStream_t stream) {
+    static DeviceOnce smem_set;
+    int slot;
+    if (device_once_pending(smem_set, &slot)) {
+        if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, MAXT>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
+        device_once_done(smem_set, slot);
+    }
+    MV_LAUNCH((conv2ds_kernel<KS, NBW, MAXT>), ((unsigned)(p.tiles * p.ctiles), (unsigned)B, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds,
+              stream, a);
+    return MV_OK;
+}
+
+}  // namespace
+
+int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
+    MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2ds: null pointer");
+    MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.B <= 65535, "conv2ds: empty input or batch too large for one launch");
+    MV_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv2ds: kernel 1 or 3, stride 1 or 2");
+    MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2ds: channels must be padded to 16");
+    MV_REQUIRE(d.ldx % 16 == 0 && d.ldy % 16 == 0, "conv2ds: leading dimensions must be multiples of 16 channels");
+    MV_REQUIRE(d.x2 == nullptr || (d.cin1 > 0 && d.cin1 % 16 == 0 && d.cin1 < d.cin16 && d.ldx2 % 16 == 0), "conv2ds: concat split");
+    MV_REQUIRE(d.epi >= 0 && d.epi <= 2, "conv2ds: epilogue mode");
+    if (d.epi == 2) MV_REQUIRE(d.res != nullptr && d.res2 != nullptr && d.ldres % 16 == 0 && d.ldres2 % 16 == 0, "conv2ds: AFF mix needs both operands");
+    if (d.res != nullptr) MV_REQUIRE(d.ldres % 16 == 0, "conv2ds: residual leading dimension");
+    MV_REQUIRE((d.y2 == nullptr) == (d.add == nullptr), "conv2ds: the second output needs its addend");
+    if (d.y2 != nullptr) MV_REQUIRE(d.ldy2 % 16 == 0 && d.ldadd % 16 == 0, "conv2ds: second output leading dimensions");
+    MV_REQUIRE(d.oscale > 0.0f, "conv2ds: output scale of the packed weights missing");
+    MV_REQUIRE((int64_t)d.H * d.W * d.ldx < (int64_t)1 << 31 && (d.x2 == nullptr || (int64_t)d.H * d.W * d.ldx2 < (int64_t)1 << 31),
+               "conv2ds: one utterance's map too large");
+    const int p = d.ks / 2;
+    const int Ho = (d.H + 2 * p - d.ks) / d.stride + 1, Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
+    CsPlan plan;
+    int rc = cs_plan(d, Ho, Wo, d.stride, &plan);
+    if (rc != MV_OK) return rc;
+    Conv2dsArgs a;
+    a.x = static_cast<const half_t*>(d.x); a.x2 = static_cast<const half_t*>(d.x2); a.w = static_cast<const half_t*>(d.w); a.bias = d.bias;
+    a.res = static_cast<const half_t*>(d.res); a.res2 = static_cast<const half_t*>(d.res2); a.add = static_cast<const half_t*>(d.add);
+    a.y = static_cast<half_t*>(d.y); a.y2 = static_cast<half_t*>(d.y2);
+    a.ldx = d.ldx; a.ldx2 = d.ldx2; a.ldres = d.ldres; a.ldres2 = d.ldres2; a.ldadd = d.ldadd; a.ldy = d.ldy; a.ldy2 = d.ldy2;
+    a.cinu = d.cin16 / 16;
+    a.cin1u = d.x2 != nullptr ? d.cin1 / 16 : a.cinu;
+    a.nchunks = (a.cinu + 1) / 2;
+    a.wunits = 2 * a.nchunks;
+    a.cout16 = d.cout16;
+    a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = d.stride; a.epi = d.epi;
+    a.lo = d.lo; a.hi = d.hi; a.oscale = d.oscale;
+    a.R = plan.R; a.ncs = plan.ncs; a.tiles = plan.tiles; a.CT = plan.CT; a.ncons = plan.ncons; a.nprod = plan.nprod;
+    a.pc = plan.pc; a.pcv = plan.pcv;
+    const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * Ho * Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
+                                                (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
+    if (d.ks == 3) {
+        switch (plan.nbw) {
+            case 1: rc = cs_launch<3, 1, 768>(a, plan, d.B, stream); break;
+            case 2: rc = cs_launch<3, 2, 768>(a, plan, d.B, stream); break;
+            case 3: rc = cs_launch<3, 3, 512>(a, plan, d.B, stream); break;
+            default: rc = cs_launch<3, 4, 512>(a, plan, d.B, stream); break;
+        }
+    } else {
+        switch (plan.nbw) {
+            case 1: rc = cs_launch<1, 1, 768>(a, plan, d.B, stream); break;
+            case 2: rc = cs_launch<1, 2, 768>(a, plan, d.B, stream); break;
+            case 3: rc = cs_launch<1, 3, 512>(a, plan, d.B, stream); break;
+            default: rc = cs_launch<1, 4, 512>(a, plan, d.B, stream); break;
+        }
+    }
+    prof_end(prof, stream);
+    if (rc != MV_OK) return rc;
+    return check_launch("conv2ds_kernel");
+}
+
+// ---- weights: fp32 [cout16][taps][cin16] (BatchNorm folded) -> split fp16 [cout16][taps][wunits][hi 16 | lo 16], scaled by 2^s -------------
+int64_t conv2ds_packed_floats(int cout16, int cin16, int ks) { return (int64_t)cout16 * ks * ks * round_up(cin16, 32); }
+
+float conv2ds_pack_host(const float* w, int cout16, int cin16, int ks, half_t* out) {
+    const int taps = ks * ks, wunits = (int)round_up(cin16, 32) / 16;
+    const size_t n = (size_t)cout16 * taps * cin16;
+    float mx = 0.0f;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    int s = 0;
+    if (mx > 0.0f && std::isfinite(mx)) {
+        int e;
+        frexpf(mx, &e);   // mx = f * 2^e, f in [0.5, 1)
+        s = 10 - e;       // mx * 2^s in [512, 1024)
+    }
+    const float ws = ldexpf(1.0f, s);
+    memset(out, 0, (size_t)cout16 * taps * wunits * 32 * sizeof(half_t));
+    for (int co = 0; co < cout16; ++co)
+        for (int tp = 0; tp < taps; ++tp)
+            for (int ci = 0; ci < cin16; ++ci) {
+                const float V = w[((size_t)co * taps + tp) * cin16 + ci] * ws;
+                const half_t h = (half_t)V;
+                const half_t l = (half_t)(V - (float)h);
+                half_t* unit = out + (((size_t)co * taps + tp) * wunits + ci / 16) * 32;
+                unit[ci % 16] = h;
+                unit[16 + ci % 16] = l;
+            }
+    return ldexpf(1.0f, -s) * CS_XSCALE_INV;
+}
+
+// ---- fp32 <-> S16 maps (stem output, interchange with fp32 code, tests): n_units units of 16 consecutive channels ----------------------------
+__global__ void map_split_kernel(const float* x, half_t* y, int64_t n_units) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_units * 4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4v v = *reinterpret_cast<const float4v*>(x + i * 4);
+        s16_store4(y + (i >> 2) * 32 + (i & 3) * 4, v);
+    }
+}
+__global__ void map_merge_kernel(const half_t* x, float* y, int64_t n_units) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_units * 4; i += (int64_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<float4v*>(y + i * 4) = s16_load4(x + (i >> 2) * 32 + (i & 3) * 4);
+}
+
+int map_split_launch(const float* x, void* y, int64_t n, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && y != nullptr && n > 0 && n % 16 == 0, "map_split: needs whole units of 16 channels");
+    const int64_t work = n / 4;
+    const int grid = (int)(ceil_div(work, 256) < 8192 ? ceil_div(work, 256) : 8192);
+    MV_LAUNCH(map_split_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, x, static_cast<half_t*>(y), n / 16);
+    return check_launch("map_split_kernel");
+}
+int map_merge_launch(const void* x, float* y, int64_t n, hipStream_t stream) {
+    MV_REQUIRE(x != nullptr && y != nullptr && n > 0 && n % 16 == 0, "map_merge: needs whole units of 16 channels");
+    const int64_t work = n / 4;
+    const int grid = (int)(ceil_div(work, 256) < 8192 ? ceil_div(work, 256) : 8192);
+    MV_LAUNCH(map_merge_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, static_cast<const half_t*>(x), y, n / 16);
+    return check_launch("map_merge_kernel");
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int64_t mv_conv2ds_packed_elems(int32_t cout, int32_t cin, int32_t ks) {
+    return mv::conv2ds_packed_floats((int)mv::round_up(cout, 16), (int)mv::round_up(cin, 16), ks);
+}
+
+int mv_conv2ds_pack_weight(const float* w, const float* out_scale, int32_t cout, int32_t cin, int32_t ks, void* packed, float* oscale,
+                           mv_stream_t stream) {
+    MV_REQUIRE(w != nullptr && packed != nullptr && oscale != nullptr && cout > 0 && cin > 0 && (ks == 1 || ks == 3), "mv_conv2ds_pack_weight: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int taps = ks * ks, cout16 = (int)mv::round_up(cout, 16), cin16 = (int)mv::round_up(cin, 16);
+    std::vector<float> hw((size_t)cout * cin * taps), hs;
+    MV_HIP_OK(hipMemcpyAsync(hw.data(), w, hw.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (out_scale != nullptr) {
+        hs.resize((size_t)cout);
+        MV_HIP_OK(hipMemcpyAsync(hs.data(), out_scale, hs.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    MV_HIP_OK(hipStreamSynchronize(st));
+    std::vector<float> dense((size_t)cout16 * taps * cin16, 0.0f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tp = 0; tp < taps; ++tp)
+                dense[((size_t)co * taps + tp) * cin16 + ci] = hw[((size_t)co * cin + ci) * taps + tp] * (hs.empty() ? 1.0f : hs[co]);
+    std::vector<half_t> out((size_t)mv::conv2ds_packed_floats(cout16, cin16, ks) * 2);
+    *oscale = mv::conv2ds_pack_host(dense.data(), cout16, cin16, ks, out.data());
+    MV_HIP_OK(hipMemcpyAsync(packed, out.data(), out.size() * sizeof(half_t), hipMemcpyHostToDevice, st));
+    MV_HIP_OK(hipStreamSynchronize(st));
+    return MV_OK;
+}
+
+int mv_conv2ds_forward(const MvConv2dsDesc* d, mv_stream_t stream) {
+    MV_REQUIRE(d != nullptr, "mv_conv2ds_forward: null descriptor");
+    return mv::conv2ds_launch(*d, static_cast<hipStream_t>(stream));
+}
+
+int mv_map_split_f32(const float* x, void* y, int64_t n, mv_stream_t stream) { return mv::map_split_launch(x, y, n, static_cast<hipStream_t>(stream)); }
+int mv_map_merge_f32(const void* x, float* y, int64_t n, mv_stream_t stream) { return mv::map_merge_launch(x, y, n, static_cast<hipStream_t>(stream)); }
+
+}  // extern "C"

@@ -25,6 +25,15 @@ int conv2d_first_launch(const float* feats, float* out, const float* w, const fl
                         hipStream_t stream);
 int tstp_launch(const float* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);
 
+// split-fp16 form of the same layers on S16 maps (conv2ds.hip)
+int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream);
+int64_t conv2ds_packed_floats(int cout16, int cin16, int ks);
+float conv2ds_pack_host(const float* w_dense, int cout16, int cin16, int ks, half_t* out);  // [cout16][taps][cin16] fp32 -> split; returns oscale
+int map_split_launch(const float* x, void* y, int64_t n, hipStream_t stream);
+int map_merge_launch(const void* x, float* y, int64_t n, hipStream_t stream);
+int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream);
+int tstp_s16_launch(const half_t* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);
+
 int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
                       int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream);
 

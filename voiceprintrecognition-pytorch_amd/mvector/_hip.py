@@ -61,6 +61,15 @@ class MvConv2dDesc(ctypes.Structure):
                 ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32)]
 
 
+class MvConv2dsDesc(ctypes.Structure):
+    _fields_ = [('x', c_vp), ('x2', c_vp), ('cin1', c_i32), ('ldx', c_i64), ('ldx2', c_i64), ('w', c_vp), ('bias', c_vp),
+                ('oscale', c_f32), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64), ('add', c_vp),
+                ('ldadd', c_i64), ('y', c_vp), ('ldy', c_i64), ('y2', c_vp), ('ldy2', c_i64), ('B', c_i32), ('H', c_i32),
+                ('W', c_i32), ('cin16', c_i32), ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32),
+                ('lo', c_f32), ('hi', c_f32), ('cin_alg', c_i32), ('cout_alg', c_i32), ('nbw_hint', c_i32),
+                ('ct_hint', c_i32), ('rows_hint', c_i32)]
+
+
 class MvTdnnCfg(ctypes.Structure):
     _fields_ = [('input_size', c_i32), ('channels', c_i32), ('embd_dim', c_i32)]
 
@@ -103,6 +112,13 @@ _SIGNATURES = {
     'mv_conv2d_forward': (c_i32, [ctypes.POINTER(MvConv2dDesc), c_vp]),
     'mv_conv2d_first': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'mv_tstp_f32': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'mv_conv2ds_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
+    'mv_conv2ds_pack_weight': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, ctypes.POINTER(c_f32), c_vp]),
+    'mv_conv2ds_forward': (c_i32, [ctypes.POINTER(MvConv2dsDesc), c_vp]),
+    'mv_map_split_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    'mv_map_merge_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    'mv_conv2d_first_s16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'mv_tstp_s16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_model_destroy': (c_i32, [c_vp]),
     'mv_model_embd_dim': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     'mv_model_info': (c_i32, [c_vp, c_i32, ctypes.POINTER(c_f32)]),
@@ -169,7 +185,7 @@ def lib():
                 f'{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` or '
                 f'`python voiceprintrecognition-pytorch_amd/build_native.py`). There is no non-HIP device path.')
         cdll = bind(ctypes.CDLL(LIB_PATH))
-        if cdll.mv_abi_version() != 2:
+        if cdll.mv_abi_version() != 3:
             raise RuntimeError('libmvector_hip.so ABI version mismatch')
         _lib = cdll
     return _lib
