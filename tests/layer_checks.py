@@ -402,14 +402,19 @@ CONV2DS_CASES = [
 ]
 
 
-def tstp_case(cdll, device, B=3, H=5, W=38, C=72, seed=0):
+def tstp_case(cdll, device, B=3, H=5, W=38, C=72, seed=0, s16=False):
     g = torch.Generator().manual_seed(seed)
     ld = C + 8
     x = torch.randn(B, H, W, ld, generator=g) * 2 + 1
     x[0, 0, :, 3] = 1.5   # constant channel: std = sqrt(1e-8)
     xd = x.to(device)
     out = torch.full((B, 2 * C * H), float('nan'), device=device)
-    _hip.check(cdll.mv_tstp_f32(xd.data_ptr(), ld, B, H, W, C, out.data_ptr(), _stream(xd)), cdll)
+    if s16:   # the map in the split form of conv2ds.hip (1.5 * 64 is exact there too)
+        xs = s16_split(cdll, x, device)
+        x = s16_merge(cdll, xs)
+        _hip.check(cdll.mv_tstp_s16(xs.data_ptr(), ld, B, H, W, C, out.data_ptr(), _stream(xd)), cdll)
+    else:
+        _hip.check(cdll.mv_tstp_f32(xd.data_ptr(), ld, B, H, W, C, out.data_ptr(), _stream(xd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
     xr = x.float()[..., :C].permute(0, 3, 1, 2)            # [B, C, H, W] as the reference holds it
@@ -419,14 +424,18 @@ def tstp_case(cdll, device, B=3, H=5, W=38, C=72, seed=0):
     return err
 
 
-def conv2d_first_case(cdll, device, B=2, T=50, F_=16, C=32, seed=0):
+def conv2d_first_case(cdll, device, B=2, T=50, F_=16, C=32, seed=0, s16=False):
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, T, F_, generator=g)
     w = torch.randn(C, 9, generator=g) * 0.3
     bias = torch.randn(C, generator=g) * 0.1
     fd, wd, bd = feats.to(device), w.to(device), bias.to(device)
     out = torch.empty(B, F_, T, C, dtype=torch.float32, device=device)
-    _hip.check(cdll.mv_conv2d_first(fd.data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, T, F_, C, _stream(fd)), cdll)
+    if s16:
+        _hip.check(cdll.mv_conv2d_first_s16(fd.data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, T, F_, C, _stream(fd)), cdll)
+        out = s16_merge(cdll, out)
+    else:
+        _hip.check(cdll.mv_conv2d_first(fd.data_ptr(), out.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, T, F_, C, _stream(fd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
     ref = torch.relu(F.conv2d(feats.permute(0, 2, 1).unsqueeze(1), w.view(C, 1, 3, 3), bias, padding=1)).permute(0, 2, 3, 1)

@@ -34,6 +34,8 @@ def test_conv2ds_emu(idx):
 def test_tstp_and_first_conv_emu():
     lc.tstp_case(emu_cdll(), 'cpu')
     lc.conv2d_first_case(emu_cdll(), 'cpu')
+    lc.tstp_case(emu_cdll(), 'cpu', s16=True)
+    lc.conv2d_first_case(emu_cdll(), 'cpu', s16=True)
 
 
 @pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=1, T=150, cout=256, tile=256)])

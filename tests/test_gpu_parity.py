@@ -37,9 +37,26 @@ def test_conv2d(idx):
     lc.conv2d_case(product_lib(), DEV, seed=idx, **lc.CONV2D_CASES[idx])
 
 
+@pytest.mark.parametrize('idx', range(len(lc.CONV2DS_CASES)))
+def test_conv2ds(idx):
+    """the split-fp16 form of the ERes2Net conv layers on S16 maps, through the C ABI"""
+    lc.conv2ds_case(product_lib(), DEV, seed=idx, **lc.CONV2DS_CASES[idx])
+
+
+def test_conv2ds_full_size_layers():
+    """stage-1 / stage-4 shapes of the 54.9 M ERes2NetV2 (LDS-DMA rings under real latencies: many tiles, long K loops)"""
+    lc.conv2ds_case(product_lib(), DEV, B=2, H=80, W=298, cin=48, cout=48, ks=3, with_sum=True, seed=30)
+    lc.conv2ds_case(product_lib(), DEV, B=2, H=80, W=298, cin=192, cout=192, ks=1, with_res=True, seed=31)
+    lc.conv2ds_case(product_lib(), DEV, B=3, H=10, W=38, cin=1280, cout=1536, ks=1, with_res=True, seed=32)
+    lc.conv2ds_case(product_lib(), DEV, B=3, H=10, W=38, cin=320, cout=320, ks=3, seed=33)
+    lc.conv2ds_case(product_lib(), DEV, B=2, H=20, W=75, cin=768, cout=1536, ks=3, stride=2, lo=-65504.0, hi=65504.0, seed=34)
+
+
 def test_tstp_and_first_conv():
     lc.tstp_case(product_lib(), DEV)
     lc.conv2d_first_case(product_lib(), DEV, B=3, T=298, F_=80, C=32)
+    lc.tstp_case(product_lib(), DEV, s16=True)
+    lc.conv2d_first_case(product_lib(), DEV, B=3, T=298, F_=80, C=32, s16=True)
 
 
 @pytest.mark.parametrize('cfg', [dict(B=2, T=70, cout=64), dict(B=3, T=300, cout=512), dict(B=5, T=298, cout=1024, F_=128, tile=256)])

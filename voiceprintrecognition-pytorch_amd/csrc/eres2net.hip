@@ -2,12 +2,14 @@
 //
 // create(): reads the reference-layout fp32 state_dict, folds every eval-mode BatchNorm into the conv in front of it
 // (BN follows each conv directly: eres2net.py:86-87, 96, 101-102; AFF eres2net.py:39-45), pads the channel groups to
-// multiples of 16 and packs fp32 [cout16][tap][cin16] weights for conv2d_kernel (fp32 maps and weights: see conv2d.hip).  The two width-sized channel groups that
+// multiples of 16 and packs the weights for conv2ds_kernel: split fp16 pairs with a per-layer power-of-two scale, maps in the S16 form (conv2ds.hip;
+// the fp32 kernels of conv2d.hip remain the CAM++ fp32 head's).  The two width-sized channel groups that
 // torch.split / torch.cat move around (eres2net.py:89, 99) are fixed slices of two buffers instead:
 //   A  = conv1 output   [.., scale * wpad]   group i = spx[i]
 //   Bc = "cat" buffer   [.., scale * wpad]   group i = relu(bn_i(conv_i(.)))
-// so a 3x3 conv reads slice i of A (plus slice i-1 of Bc through the loader's add, or the AFF of both) and writes slice
-// i of Bc; conv3 reads Bc whole.  Padded channels carry exact zeros through every layer.
+// so a 3x3 conv writes slice i of Bc -- and, in the plain blocks, "its output + slice i+1 of A" (eres2net.py:92) as a second output into
+// a width-sized temporary that the next 3x3 conv reads (its loader is a plain copy); the AFF blocks fuse (slice i-1 of Bc, slice i of A) first;
+// conv3 reads Bc whole.  Padded channels carry exact zeros through every layer.
 // forward(): a fixed sequence of launches on the caller's stream over the caller's workspace.
 #include <memory>
 #include <vector>
@@ -20,8 +22,9 @@ namespace mv {
 namespace {
 
 struct C2Layer {
-    float* w = nullptr;
+    half_t* w = nullptr;   // split-packed (conv2ds_pack_host)
     float* bias = nullptr;
+    float oscale = 0.0f;
     int cin16 = 0, cout16 = 0, ks = 1, stride = 1;
     int cin = 0, cout = 0;  // the layer's own channel counts (algorithmic FLOP accounting)
 };
@@ -84,10 +87,12 @@ struct Eres2Model : MvModelBase {
                     packed[((size_t)out_pos[co] * taps + t) * cin16 + in_pos[ci]] = w[((size_t)co * cin + ci) * taps + t] * s;
                 }
         }
-        L->w = static_cast<float*>(dev_alloc(packed.size() * sizeof(float)));
+        std::vector<half_t> split((size_t)conv2ds_packed_floats(cout16, cin16, ks) * 2);
+        L->oscale = conv2ds_pack_host(packed.data(), cout16, cin16, ks, split.data());
+        L->w = static_cast<half_t*>(dev_alloc(split.size() * sizeof(half_t)));
         L->bias = upload(bias);
         if (L->w == nullptr || L->bias == nullptr) return fail(MV_ERR_HIP, "eres2net create: out of device memory");
-        MV_HIP_OK(hipMemcpy(L->w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        MV_HIP_OK(hipMemcpy(L->w, split.data(), split.size() * sizeof(half_t), hipMemcpyHostToDevice));
         L->cin16 = cin16;
         L->cout16 = cout16;
         L->cin = cin;
@@ -230,7 +235,7 @@ struct Eres2Model : MvModelBase {
 
     // ---- workspace ---------------------------------------------------------------------------------------------
     struct Ws {
-        float *ping[2], *a, *bc, *r, *t, *hh, *out[4], *dsb, *fuse[2];
+        float *ping[2], *a, *bc, *r, *t, *t2, *hh, *out[4], *dsb, *fuse[2];   // maps: S16 form, 4 bytes per channel
         float *stats, *emb_a;
         size_t bytes;
     };
@@ -268,6 +273,7 @@ struct Eres2Model : MvModelBase {
         s.bc = c.take<float>(max_a + slack);
         s.r = c.take<float>(max_r + slack);
         s.t = c.take<float>(max_t + slack);
+        s.t2 = c.take<float>(max_t + slack);
         s.hh = c.take<float>(max_h + slack);
         for (int l = 0; l < 4; ++l) s.out[l] = c.take<float>((size_t)B * H[l] * W[l] * layers[l].back().out_c16 + slack);
         size_t max_ds = 0, max_f = 0;
@@ -292,24 +298,26 @@ struct Eres2Model : MvModelBase {
     }
 
     // ---- launches ----------------------------------------------------------------------------------------------
-    static int conv(const C2Layer& L, const float* x, int64_t ldx, const float* x2, int64_t ldx2, int x2_mode, int cin1, float* y,
-                    int64_t ldy, int B, int H, int W, int epi, float lo, float hi, const float* res, int64_t ldres, const float* res2,
-                    int64_t ldres2, hipStream_t st) {
-        Conv2dDesc d{};
-        d.x = x; d.x2 = x2; d.x2_mode = x2_mode; d.cin1 = cin1; d.ldx = ldx; d.ldx2 = ldx2;
-        d.w = L.w; d.bias = L.bias; d.res = res; d.res2 = res2; d.ldres = ldres; d.ldres2 = ldres2;
+    // x2 != nullptr: the channels behind the first cin1 come from x2 (AFF concatenation); y2 != nullptr: second output y + add
+    static int conv(const C2Layer& L, const float* x, int64_t ldx, const float* x2, int64_t ldx2, int cin1, float* y, int64_t ldy, int B, int H,
+                    int W, int epi, float lo, float hi, const float* res, int64_t ldres, const float* res2, int64_t ldres2, hipStream_t st,
+                    const float* add = nullptr, int64_t ldadd = 0, float* y2 = nullptr, int64_t ldy2 = 0) {
+        MvConv2dsDesc d{};
+        d.x = x; d.x2 = x2; d.cin1 = cin1; d.ldx = ldx; d.ldx2 = ldx2;
+        d.w = L.w; d.bias = L.bias; d.oscale = L.oscale; d.res = res; d.res2 = res2; d.ldres = ldres; d.ldres2 = ldres2;
+        d.add = add; d.ldadd = ldadd; d.y2 = y2; d.ldy2 = ldy2;
         d.y = y; d.ldy = ldy; d.B = B; d.H = H; d.W = W; d.cin16 = L.cin16; d.cout16 = L.cout16; d.ks = L.ks; d.stride = L.stride;
         d.epi = epi; d.lo = lo; d.hi = hi;
         d.cin_alg = L.cin; d.cout_alg = L.cout;
-        return conv2d_launch(d, st);
+        return conv2ds_launch(d, st);
     }
 
     // out = xa * (1 + tanh(att)) + ya * (1 - tanh(att)),  att = BN(conv(SiLU(BN(conv(cat(xa, ya))))))   (eres2net.py:47-52)
     static int aff(const AffLayer& A, const float* xa, int64_t ldxa, const float* ya, int64_t ldya, float* hidden, float* out,
                    int64_t ldo, int B, int H, int W, hipStream_t st) {
-        int rc = conv(A.att1, xa, ldxa, ya, ldya, 2, A.chp, hidden, A.inter16, B, H, W, MV_EPI_SILU, 0.0f, 0.0f, nullptr, 0, nullptr, 0, st);
+        int rc = conv(A.att1, xa, ldxa, ya, ldya, A.chp, hidden, A.inter16, B, H, W, MV_EPI_SILU, 0.0f, 0.0f, nullptr, 0, nullptr, 0, st);
         if (rc != MV_OK) return rc;
-        return conv(A.att2, hidden, A.inter16, nullptr, 0, 0, 0, out, ldo, B, H, W, MV_EPI_AFF, 0.0f, 0.0f, xa, ldxa, ya, ldya, st);
+        return conv(A.att2, hidden, A.inter16, nullptr, 0, 0, out, ldo, B, H, W, MV_EPI_AFF, 0.0f, 0.0f, xa, ldxa, ya, ldya, st);
     }
 
     int run_block(const Block& b, const float* x, float* y, const Ws& s, int B, int Hin, int Win, hipStream_t st) const {
@@ -318,31 +326,35 @@ struct Eres2Model : MvModelBase {
         const int64_t lda = (int64_t)scale * b.wpad;
         int rc;
         // out = relu(bn1(conv1(x)))   (eres2net.py:86-88)
-        if ((rc = conv(b.conv1, x, b.in_c16, nullptr, 0, 0, 0, s.a, lda, B, Hin, Win, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st)))
+        if ((rc = conv(b.conv1, x, b.in_c16, nullptr, 0, 0, s.a, lda, B, Hin, Win, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st)))
             return rc;
+        float* const sums[2] = {s.t, s.t2};
         for (int i = 0; i < scale; ++i) {
             const float* spx = s.a + (int64_t)i * b.wpad;
             float* dst = s.bc + (int64_t)i * b.wpad;
-            if (i == 0) {
-                rc = conv(b.convs[0], spx, lda, nullptr, 0, 0, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st);
-            } else if (b.fuse.empty()) {  // sp = sp + spx[i]   (eres2net.py:92)
-                rc = conv(b.convs[i], spx, lda, dst - b.wpad, lda, 1, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st);
+            if (b.fuse.empty()) {
+                // sp = sp + spx[i] (eres2net.py:92) was formed by the previous conv's second output; this one forms the next
+                const bool more = i + 1 < scale;
+                rc = conv(b.convs[i], i == 0 ? spx : sums[(i - 1) & 1], i == 0 ? lda : b.wpad, nullptr, 0, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f,
+                          nullptr, 0, nullptr, 0, st, more ? spx + b.wpad : nullptr, lda, more ? sums[i & 1] : nullptr, b.wpad);
+            } else if (i == 0) {
+                rc = conv(b.convs[0], spx, lda, nullptr, 0, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st);
             } else {                      // sp = fuse_models[i-1](sp, spx[i])   (eres2net.py:152)
                 if ((rc = aff(b.fuse[i - 1], dst - b.wpad, lda, spx, lda, s.hh, s.t, b.wpad, B, Ho, Wo, st))) return rc;
-                rc = conv(b.convs[i], s.t, b.wpad, nullptr, 0, 0, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st);
+                rc = conv(b.convs[i], s.t, b.wpad, nullptr, 0, 0, dst, lda, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, nullptr, 0, nullptr, 0, st);
             }
             if (rc != MV_OK) return rc;
         }
         const float* resid = x;
         int64_t ldr = b.in_c16;
         if (b.has_shortcut) {
-            if ((rc = conv(b.shortcut, x, b.in_c16, nullptr, 0, 0, 0, s.r, b.out_c16, B, Hin, Win, MV_EPI_CLAMP, NEG, POS, nullptr, 0, nullptr, 0, st)))
+            if ((rc = conv(b.shortcut, x, b.in_c16, nullptr, 0, 0, s.r, b.out_c16, B, Hin, Win, MV_EPI_CLAMP, NEG, POS, nullptr, 0, nullptr, 0, st)))
                 return rc;
             resid = s.r;
             ldr = b.out_c16;
         }
         // relu(bn3(conv3(cat)) + residual)   (eres2net.py:101-106)
-        return conv(b.conv3, s.bc, lda, nullptr, 0, 0, 0, y, b.out_c16, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, resid, ldr, nullptr, 0, st);
+        return conv(b.conv3, s.bc, lda, nullptr, 0, 0, y, b.out_c16, B, Ho, Wo, MV_EPI_CLAMP, 0.0f, 20.0f, resid, ldr, nullptr, 0, st);
     }
 
     int forward(const float* feats, int B, int T, float* emb, void* ws, size_t ws_bytes, hipStream_t st) const override {
@@ -355,7 +367,7 @@ struct Eres2Model : MvModelBase {
         int H = cfg.input_size, W = T;
         int Hs[4], Wsz[4];
         // x.permute(0, 2, 1).unsqueeze(1) -> relu(bn1(conv1(x)))   (eres2net.py:267-270)
-        if ((rc = conv2d_first_launch(feats, s.ping[0], stem_w, stem_b, B, T, cfg.input_size, m, st))) return rc;
+        if ((rc = conv2d_first_s16_launch(feats, reinterpret_cast<half_t*>(s.ping[0]), stem_w, stem_b, B, T, cfg.input_size, m, st))) return rc;
         const float* cur = s.ping[0];
         int pp = 1;
         for (int l = 0; l < 4; ++l) {
@@ -381,7 +393,7 @@ struct Eres2Model : MvModelBase {
             const float* prev = s.out[0];
             int64_t prev_ld = layers[0].back().out_c16;
             for (int i = 0; i < 3; ++i) {
-                if ((rc = conv(ds[i], prev, prev_ld, nullptr, 0, 0, 0, s.dsb, ds[i].cout16, B, Hs[i], Wsz[i], MV_EPI_CLAMP, NEG, POS, nullptr, 0,
+                if ((rc = conv(ds[i], prev, prev_ld, nullptr, 0, 0, s.dsb, ds[i].cout16, B, Hs[i], Wsz[i], MV_EPI_CLAMP, NEG, POS, nullptr, 0,
                                nullptr, 0, st)))
                     return rc;
                 float* fo = s.fuse[i & 1];
@@ -395,7 +407,7 @@ struct Eres2Model : MvModelBase {
             pooled_ld = prev_ld;
         } else {
             // fuse34(out4, layer3_ds(out3))   (eres2net.py:446-447)
-            if ((rc = conv(ds[2], s.out[2], layers[2].back().out_c16, nullptr, 0, 0, 0, s.dsb, ds[2].cout16, B, Hs[2], Wsz[2], MV_EPI_CLAMP, NEG,
+            if ((rc = conv(ds[2], s.out[2], layers[2].back().out_c16, nullptr, 0, 0, s.dsb, ds[2].cout16, B, Hs[2], Wsz[2], MV_EPI_CLAMP, NEG,
                            POS, nullptr, 0, nullptr, 0, st)) ||
                 (rc = aff(top_fuse[2], s.out[3], layers[3].back().out_c16, s.dsb, ds[2].cout16, s.hh, s.fuse[0], top_fuse[2].chp, B, Hs[3],
                           Wsz[3], st)))
@@ -404,7 +416,7 @@ struct Eres2Model : MvModelBase {
             pooled_ld = top_fuse[2].chp;
         }
         MV_REQUIRE(Hs[3] == final_h, "eres2net forward: unexpected frequency size after the four stages");
-        if ((rc = tstp_launch(pooled, pooled_ld, B, Hs[3], Wsz[3], final_c, s.stats, st))) return rc;
+        if ((rc = tstp_s16_launch(reinterpret_cast<const half_t*>(pooled), pooled_ld, B, Hs[3], Wsz[3], final_c, s.stats, st))) return rc;
         const int K = 2 * final_c * final_h;
         if (!cfg.two_emb_layer)
             return linear_f32_launch(s.stats, K, seg1_w, K, seg1_b, MV_ACT_NONE, emb, cfg.embd_dim, B, K, cfg.embd_dim, 0, st);
