@@ -288,7 +288,7 @@ def s16_merge(cdll, buf):
 
 
 def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, concat=False, epi=0, with_res=False, with_sum=False,
-                 lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, x_scale=1.0):
+                 lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, ring=0, wgs=0, x_scale=1.0):
     """mv_conv2ds_forward (split-fp16 operands on S16 maps) against F.conv2d in fp64 on the SAME 22-bit inputs: the map round trip
     (split -> merge) is what the layer sees, so the bar is the fp32 one of conv2d_case."""
     g = torch.Generator().manual_seed(seed)
@@ -344,7 +344,7 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     d.y2, d.ldy2 = (y2.data_ptr() if with_sum else None), ldy
     d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
     d.lo, d.hi = lo, hi
-    d.nbw_hint, d.ct_hint, d.rows_hint = nbw, ct, rows
+    d.nbw_hint, d.ct_hint, d.rows_hint, d.ring_hint, d.wgs_hint = nbw, ct, rows, ring, wgs
     _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(d), _stream(xad)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
@@ -396,8 +396,11 @@ CONV2DS_CASES = [
     dict(cin=16, cout=32, ks=3, stride=2, H=5, W=33, B=1),                   # strided 3x3 on odd sizes
     dict(cin=48, cout=48, ks=3, H=21, W=50, B=1, with_sum=True),             # 21 rows: tiles of 7 rows
     dict(cin=80, cout=80, ks=3, H=10, W=20, B=1, nbw=2),                     # forced two blocks per wave on 5 blocks
-    dict(cin=64, cout=256, ks=1, H=4, W=40, B=1, nbw=4, ct=8),               # four blocks per wave, two channel tiles
+    dict(cin=64, cout=256, ks=1, H=4, W=40, B=1, nbw=3, ct=6),               # three blocks per wave, three channel tiles (the last with 4 blocks)
     dict(cin=64, cout=192, ks=3, H=9, W=17, B=1, nbw=3, rows=3),             # three blocks per wave, tiles of 3 rows
+    dict(cin=64, cout=64, ks=3, H=24, W=40, B=2, ring=2, wgs=1),             # shortest ring, many tiles per workgroup
+    dict(cin=96, cout=48, ks=1, H=30, W=40, B=2, ring=2, wgs=2),             # 1x1, two workgroups per CU with a ring of two
+    dict(cin=160, cout=48, ks=1, H=30, W=40, B=2, ring=3, wgs=1),            # 1x1, ring of three
     dict(cin=32, cout=32, ks=3, H=6, W=18, B=1, x_scale=100.0, hi=65504.0, lo=-65504.0),   # large activations (|x| up to ~450; the split saturates at 1023.5)
 ]
 

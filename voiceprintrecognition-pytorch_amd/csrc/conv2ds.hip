@@ -35,7 +35,7 @@
 namespace mv {
 
 constexpr int CS_SEGS = 8;             // 16-pixel segments per workgroup
-constexpr int CS_PI_MAX = 32;          // LDS-DMA instructions of one K chunk a producer wave may own
+constexpr int CS_P_MAX = 16;           // LDS-DMA transfers of one stage a producer wave may own
 constexpr int CS_CHUNK1_BYTES = CS_SEGS * 16 * 128;  // 1x1: one 32-channel chunk of the 128 pixels
 constexpr int CS_KCH1 = 2;                           // 1x1: chunks per stage
 
@@ -53,12 +53,34 @@ struct Conv2dsArgs {
     half_t* y2;
     int64_t ldx, ldx2, ldres, ldres2, ldadd, ldy, ldy2;  // channels (= 4-byte elements) between pixels
     int cin1u, cinu, nchunks, wunits, cout16;
-    int H, W, Ho, Wo, sh, sw, epi;
+    int B, H, W, Ho, Wo, sh, sw, epi;
     float lo, hi, oscale;
     int R, ncs, tiles, CT, ncons, nprod;   // rows per 3x3 tile, column strips, pixel tiles per utterance, blocks per channel tile, wave roles
-    int pc, pcv;                            // 3x3: allocated / valid patch columns
+    int pc, pcv, pc_magic;                  // 3x3: allocated / valid patch columns, 65536 / pc rounded up
+    int ns, pp, wg_per_ct;                  // ring stages, transfers per producer wave and stage (padded), workgroups per channel tile
 };
 
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {
+#define MV_CS_W(N) case N: wait_vm<N>(); break;
+        MV_CS_W(0) MV_CS_W(1) MV_CS_W(2) MV_CS_W(3) MV_CS_W(4) MV_CS_W(5) MV_CS_W(6) MV_CS_W(7) MV_CS_W(8) MV_CS_W(9) MV_CS_W(10) MV_CS_W(11)
+        MV_CS_W(12) MV_CS_W(13) MV_CS_W(14) MV_CS_W(15) MV_CS_W(16) MV_CS_W(17) MV_CS_W(18) MV_CS_W(19) MV_CS_W(20) MV_CS_W(21) MV_CS_W(22)
+        MV_CS_W(23) MV_CS_W(24) MV_CS_W(25) MV_CS_W(26) MV_CS_W(27) MV_CS_W(28) MV_CS_W(29) MV_CS_W(30) MV_CS_W(31) MV_CS_W(32) MV_CS_W(33)
+        MV_CS_W(34) MV_CS_W(35) MV_CS_W(36) MV_CS_W(37) MV_CS_W(38) MV_CS_W(39) MV_CS_W(40) MV_CS_W(41) MV_CS_W(42) MV_CS_W(43) MV_CS_W(44)
+        MV_CS_W(45) MV_CS_W(46) MV_CS_W(47) MV_CS_W(48)
+#undef MV_CS_W
+        default: wait_vm<0>(); break;
+    }
+}
+
+// Persistent workgroups: workgroup (channel tile ct, index widx) walks the pixel tiles widx, widx + wg_per_ct, ... of all utterances; its sequence of
+// K stages (tiles x stages per tile) runs through ONE ring of `ns` LDS slots, so the producers are ns - 1 stages ahead across tile boundaries -- the
+// patch of the next tile travels while the consumers finish this one and store it.  One barrier per stage:
+//   producer:  [issue stages 0 .. ns-2]   for g: wait until stage g has landed (the younger stages may stay in flight: counted wait, every producer
+//              wave issues exactly pp transfers per stage -- the padding ones read the zero page into a dump KiB); barrier g; issue stage g + ns - 1
+//              into the slot of stage g - 1, which every consumer has left when it arrives at barrier g
+//   consumer:  for g: barrier g; MFMAs of stage g (weights two steps ahead in registers); after a tile's last stage its epilogue
 template <int KS, int NBW, int MAXT>
 __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     MV_DYN_SMEM(smem);
@@ -67,79 +89,98 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     constexpr int G = NBW >= 2 ? 2 : 4;                   // segments per MFMA group: >= 4 independent accumulators between dependent MFMAs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = MV_UNIFORM(tid >> 6);
-    const int b = blockIdx.y;
-    const int t = blockIdx.x % a.tiles, ct = blockIdx.x / a.tiles;
+    const int ct = blockIdx.x / a.wg_per_ct, widx = blockIdx.x - ct * a.wg_per_ct;
     const int nst = (a.nchunks + KCH - 1) / KCH;
-    // tile origin
-    int ho0 = 0, wo0 = 0, p0 = 0;
-    if (KS == 3) {
-        ho0 = (t / a.ncs) * a.R;
-        wo0 = (t % a.ncs) * 16;
-    } else {
-        p0 = t * (CS_SEGS * 16);
-    }
+    const int ptiles = a.B * a.tiles;                                                  // pixel tiles of the launch
+    const int my_tiles = widx < ptiles ? (ptiles - widx + a.wg_per_ct - 1) / a.wg_per_ct : 0;
+    const int nstages = my_tiles * nst;
     const int chunk_bytes = KS == 3 ? ((a.R - 1) * a.sh + 3) * a.pc * 128 : CS_CHUNK1_BYTES;
     const int stage_bytes = chunk_bytes * KCH;
     const unsigned lds0 = lds_addr(smem);
+    const int HWo = a.Ho * a.Wo;
 
     if (wave >= a.ncons) {
         // ---------------- producer ----------------
         const int pw = wave - a.ncons;
         const int psel = lane >> 3, slot = lane & 7;
-        const int g = slot ^ psel;                  // granule of the 128-byte chunk row this lane fetches (entry & 7 == psel: rows of 8k entries)
+        const int g = slot ^ psel;                  // granule of the 128-byte chunk row this lane fetches (entry & 7 == psel: rows are 8k entries)
         const int usel = g >> 2, inner = (g & 3) * 8;  // unit of the chunk, halves inside the unit
-        const int ni = chunk_bytes >> 10;           // transfers per chunk
-        int pidx[CS_PI_MAX];                        // input pixel of this lane's entry per owned transfer, -1 = zero
-#pragma unroll
-        for (int i = 0; i < CS_PI_MAX; ++i) {
-            const int k = i * a.nprod + pw;
-            int v = -1;
-            if (k < ni) {
-                const int entry = k * 8 + psel;
-                if (KS == 3) {
-                    const int pr = entry / a.pc, pcc = entry - pr * a.pc;
-                    const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + pcc;
-                    if (pcc < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) v = hi * a.W + wi;
-                } else {
-                    const int p = p0 + entry;
-                    if (p < a.Ho * a.Wo) {
-                        const int ho = p / a.Wo, wo = p - ho * a.Wo;
-                        v = ho * a.sh * a.W + wo * a.sw;
-                    }
-                }
-            }
-            pidx[i] = v;
-        }
-        const half_t* xb = a.x + (int64_t)b * a.H * a.W * a.ldx * 2;
-        const half_t* x2b = a.x2 != nullptr ? a.x2 + (int64_t)b * a.H * a.W * a.ldx2 * 2 : nullptr;
+        const int ni = stage_bytes >> 10;           // transfers per stage
+        const unsigned dump = lds0 + (unsigned)(a.ns * stage_bytes + pw * 1024);
         const half_t* zero = reinterpret_cast<const half_t*>(g_cs_zero_page);
-        auto issue_stage = [&](int c) {
-            const unsigned base = lds0 + (unsigned)((c & 1) * stage_bytes);
-#pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) {
-                const int u = 2 * (c * KCH + kc) + usel;
-#pragma unroll
-                for (int i = 0; i < CS_PI_MAX; ++i) {
-                    const int k = i * a.nprod + pw;
-                    if (k < ni) {  // uniform
-                        const half_t* src = zero;
-                        if (pidx[i] >= 0 && u < a.cinu) {
-                            src = u < a.cin1u ? xb + ((int64_t)pidx[i] * a.ldx + 16 * u) * 2 + inner
-                                              : x2b + ((int64_t)pidx[i] * a.ldx2 + 16 * (u - a.cin1u)) * 2 + inner;
-                        }
-                        glds16_untracked(src, base + (unsigned)(kc * chunk_bytes + k * 1024));
-                    }
-                }
+        // issue state: stage gi = (tile ti of this workgroup, stage ci of the tile)
+        int ti = 0, ci = 0, b = 0, ho0 = 0, wo0 = 0, p0 = 0;
+        auto decode = [&](int tile_index) {
+            const int pt = widx + tile_index * a.wg_per_ct;
+            b = pt / a.tiles;
+            const int t = pt - b * a.tiles;
+            if (KS == 3) {
+                const int rt = t / a.ncs;
+                ho0 = rt * a.R;
+                wo0 = (t - rt * a.ncs) * 16;
+            } else {
+                p0 = t * (CS_SEGS * 16);
             }
         };
-        issue_stage(0);
-        wait_vm<0>();
-        lds_barrier();
+        decode(0);
+        auto issue_stage = [&](int gi) {
+            const unsigned base = lds0 + (unsigned)((gi % a.ns) * stage_bytes);
+            const half_t* xb = a.x + (int64_t)b * a.H * a.W * a.ldx * 2;
+            const half_t* x2b = a.x2 != nullptr ? a.x2 + (int64_t)b * a.H * a.W * a.ldx2 * 2 : nullptr;
+#pragma unroll
+            for (int j = 0; j < CS_P_MAX; ++j) {
+                if (j < a.pp) {  // uniform
+                    const int k = j * a.nprod + pw;   // transfer of the stage
+                    const half_t* src = zero;
+                    unsigned dst = dump;
+                    if (k < ni) {  // uniform
+                        int kc = 0, kk = k;   // chunk of the stage, transfer of the chunk
+                        if (KS == 1 && kk >= (CS_CHUNK1_BYTES >> 10)) {
+                            kc = 1;
+                            kk -= CS_CHUNK1_BYTES >> 10;
+                        }
+                        int pix = -1;
+                        if (KS == 3) {
+                            const int pr = (kk * 8 * a.pc_magic) >> 16, col = kk * 8 - pr * a.pc + psel;
+                            const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + col;
+                            if (col < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) pix = hi * a.W + wi;
+                        } else {
+                            const int p = p0 + kk * 8 + psel;
+                            if (p < HWo) {
+                                if (a.sh == 1 && a.sw == 1) {
+                                    pix = p;
+                                } else {
+                                    const int ho = p / a.Wo, wo = p - ho * a.Wo;
+                                    pix = ho * a.sh * a.W + wo * a.sw;
+                                }
+                            }
+                        }
+                        const int u = 2 * (ci * KCH + kc) + usel;
+                        if (pix >= 0 && u < a.cinu) {
+                            src = u < a.cin1u ? xb + ((int64_t)pix * a.ldx + 16 * u) * 2 + inner
+                                              : x2b + ((int64_t)pix * a.ldx2 + 16 * (u - a.cin1u)) * 2 + inner;
+                        }
+                        dst = base + (unsigned)(k * 1024);
+                    }
+                    glds16_untracked(src, dst);
+                }
+            }
+            if (++ci == nst) {
+                ci = 0;
+                ++ti;
+                if (ti < my_tiles) decode(ti);
+            }
+        };
+        int issued = 0;
+        for (; issued < a.ns - 1 && issued < nstages; ++issued) issue_stage(issued);
 #pragma unroll 1
-        for (int c = 0; c < nst; ++c) {
-            if (c + 1 < nst) issue_stage(c + 1);
-            wait_vm<0>();
+        for (int gs = 0; gs < nstages; ++gs) {
+            wait_vm_dyn((issued - gs - 1) * a.pp);
             lds_barrier();
+            if (issued < nstages) {
+                issue_stage(issued);
+                ++issued;
+            }
         }
         return;
     }
@@ -154,23 +195,9 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         const int in_tile = a.CT - wave * NBW;
         nb = nb < in_tile ? nb : in_tile;
         nb = nb < NBW ? nb : NBW;
+        nb = nb > 0 ? nb : 0;
     }
     nb = MV_UNIFORM(nb);
-    int nvalid;                                              // segments of this tile that exist
-    if (KS == 3) {
-        const int rows = a.Ho - ho0;
-        nvalid = rows < a.R ? rows : a.R;
-    } else {
-        const int left = a.Ho * a.Wo - p0;
-        nvalid = left >= CS_SEGS * 16 ? CS_SEGS : (left + 15) >> 4;
-    }
-    nvalid = MV_UNIFORM(nvalid);
-
-    float4v acc[CS_SEGS][NBW];
-#pragma unroll
-    for (int u = 0; u < CS_SEGS; ++u)
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) acc[u][i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 
     // A fragments: lane (row j16 of a block, K group q) reads 16 bytes of hi and the 16 bytes 32 further of lo
     const int64_t wrow_halves = (int64_t)TAPS * a.wunits * 32;
@@ -180,46 +207,76 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         const int blk = i < nb ? blk0 + i : (blk0 < nblk_total ? blk0 : 0);   // clamped: loaded, never used
         wrow[i] = a.w + ((int64_t)blk * 16 + j16) * wrow_halves + ghi * 8;
     }
-    // step j of stage c: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j
+    // step j of stage c of a tile: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j.  The weights do not depend on the pixel tile.
     constexpr int SPS = KS == 3 ? TAPS : KCH;
     auto a_offset = [&](int c, int j) -> int64_t {
         if (KS == 3) return ((int64_t)j * a.wunits + 2 * c) * 32;
         const int ch = c * KCH + j;
         return (int64_t)(ch < a.nchunks ? ch : a.nchunks - 1) * 64;
     };
-    half8v ah[NBW], al[NBW], nh[NBW], nl[NBW];
-    auto load_a = [&](int c, int j) {
-        const int64_t off = a_offset(c, j);
+    half8v ah[NBW], al[NBW], n1h[NBW], n1l[NBW], n2h[NBW], n2l[NBW];
+    int pc_c = 0, pc_j = 0;   // (stage, step) the next weight request is for
+    auto load_next = [&]() {
+        const int64_t off = a_offset(pc_c, pc_j);
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            nh[i] = *reinterpret_cast<const half8v*>(wrow[i] + off);
-            nl[i] = *reinterpret_cast<const half8v*>(wrow[i] + off + 16);
+            n2h[i] = *reinterpret_cast<const half8v*>(wrow[i] + off);
+            n2l[i] = *reinterpret_cast<const half8v*>(wrow[i] + off + 16);
+        }
+        if (++pc_j == SPS) {
+            pc_j = 0;
+            if (++pc_c == nst) pc_c = 0;
         }
     };
-    load_a(0, 0);
+    load_next();
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        n1h[i] = n2h[i];
+        n1l[i] = n2l[i];
+    }
+    load_next();
     // B fragments: entry e of the patch at e * 128, granule g at ((g ^ (e & 7)) << 4); rows of a 3x3 patch are a multiple of 8 entries
     // apart, so segment u is a constant further than segment 0
     const int seg_stride = KS == 3 ? a.sh * a.pc * 128 : 16 * 128;
 
-    lds_barrier();  // stage 0 has landed
+    float4v acc[CS_SEGS][NBW];
+    int c = 0, tile_index = 0;
 #pragma unroll 1
-    for (int c = 0; c < nst; ++c) {
-        const char* buf = smem + (c & 1) * stage_bytes;
+    for (int gs = 0; gs < nstages; ++gs) {
+        // ---- this tile ----
+        const int pt = widx + tile_index * a.wg_per_ct;
+        const int b = pt / a.tiles, t = pt - b * a.tiles;
+        int ho0 = 0, wo0 = 0, p0 = 0, nvalid;
+        if (KS == 3) {
+            const int rt = t / a.ncs;
+            ho0 = rt * a.R;
+            wo0 = (t - rt * a.ncs) * 16;
+            const int rows = a.Ho - ho0;
+            nvalid = rows < a.R ? rows : a.R;
+        } else {
+            p0 = t * (CS_SEGS * 16);
+            const int left = HWo - p0;
+            nvalid = left >= CS_SEGS * 16 ? CS_SEGS : (left + 15) >> 4;
+        }
+        nvalid = MV_UNIFORM(nvalid);
+        if (c == 0) {
+#pragma unroll
+            for (int u = 0; u < CS_SEGS; ++u)
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) acc[u][i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next
+        const char* buf = smem + (gs % a.ns) * stage_bytes;
 #pragma unroll 1
         for (int j = 0; j < SPS; ++j) {
 #pragma unroll
             for (int i = 0; i < NBW; ++i) {
-                ah[i] = nh[i];
-                al[i] = nl[i];
+                ah[i] = n1h[i];
+                al[i] = n1l[i];
+                n1h[i] = n2h[i];
+                n1l[i] = n2l[i];
             }
-            {   // the next step's weights
-                int cn = c, jn = j + 1;
-                if (jn == SPS) {
-                    jn = 0;
-                    cn = c + 1 < nst ? c + 1 : c;
-                }
-                load_a(cn, jn);
-            }
+            load_next();
             const bool live = KS == 3 || c * KCH + j < a.nchunks;  // uniform: the chunk behind the last one of an odd count does not exist
             if (live && nb > 0) {
                 int e0;
@@ -259,61 +316,62 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                 }
             }
         }
-        lds_barrier();  // every wave is done with this buffer; the next stage has landed
-    }
+        if (++c < nst) continue;
+        c = 0;
+        ++tile_index;
 
-    // ---------------- epilogue: D[channel 4q + r][pixel j16] ----------------
-    const int HWo = a.Ho * a.Wo;
+        // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16] ----------------
 #pragma unroll
-    for (int u = 0; u < CS_SEGS; ++u) {
-        if (u >= nvalid) break;  // uniform
-        int64_t pix;
-        bool ok;
-        if (KS == 3) {
-            const int wo = wo0 + j16;
-            ok = wo < a.Wo;
-            pix = (int64_t)b * HWo + (int64_t)(ho0 + u) * a.Wo + wo;
-        } else {
-            const int p = p0 + u * 16 + j16;
-            ok = p < HWo;
-            pix = (int64_t)b * HWo + p;
-        }
-        if (!ok) continue;
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            if (i >= nb) break;  // uniform
-            const int co = (blk0 + i) * 16 + q * 4;
-            const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
-            const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
-            float4v v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[u][i][r] * a.oscale + bias[r];
-            if (a.epi == 0) {
-                if (a.res != nullptr) {
-                    const float4v rv = s16_load4(a.res + pix * a.ldres * 2 + coff);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
-            } else if (a.epi == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+        for (int u = 0; u < CS_SEGS; ++u) {
+            if (u >= nvalid) break;  // uniform
+            int64_t pix;
+            bool ok;
+            if (KS == 3) {
+                const int wo = wo0 + j16;
+                ok = wo < a.Wo;
+                pix = (int64_t)b * HWo + (int64_t)(ho0 + u) * a.Wo + wo;
             } else {
-                const float4v xa = s16_load4(a.res + pix * a.ldres * 2 + coff);
-                const float4v ya = s16_load4(a.res2 + pix * a.ldres2 * 2 + coff);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float th = tanhf(v[r]);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
-                    v[r] = xa[r] * (1.0f + th) + ya[r] * (1.0f - th);
-                }
+                const int p = p0 + u * 16 + j16;
+                ok = p < HWo;
+                pix = (int64_t)b * HWo + p;
             }
-            s16_store4(a.y + pix * a.ldy * 2 + coff, v);
-            if (a.y2 != nullptr) {
-                const float4v av = s16_load4(a.add + pix * a.ldadd * 2 + coff);
+            if (!ok) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += av[r];
-                s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);
+            for (int i = 0; i < NBW; ++i) {
+                if (i >= nb) break;  // uniform
+                const int co = (blk0 + i) * 16 + q * 4;
+                const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
+                const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
+                float4v v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[u][i][r] * a.oscale + bias[r];
+                if (a.epi == 0) {
+                    if (a.res != nullptr) {
+                        const float4v rv = s16_load4(a.res + pix * a.ldres * 2 + coff);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
+                } else if (a.epi == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+                } else {
+                    const float4v xa = s16_load4(a.res + pix * a.ldres * 2 + coff);
+                    const float4v ya = s16_load4(a.res2 + pix * a.ldres2 * 2 + coff);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float th = tanhf(v[r]);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
+                        v[r] = xa[r] * (1.0f + th) + ya[r] * (1.0f - th);
+                    }
+                }
+                s16_store4(a.y + pix * a.ldy * 2 + coff, v);
+                if (a.y2 != nullptr) {
+                    const float4v av = s16_load4(a.add + pix * a.ldadd * 2 + coff);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += av[r];
+                    s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);
+                }
             }
         }
     }
@@ -323,16 +381,16 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 namespace {
 
 struct CsPlan {
-    int nbw, CT, ctiles, ncons, nprod, R, ncs, tiles, pc, pcv, maxt;
+    int nbw, CT, ctiles, ncons, nprod, R, ncs, tiles, pc, pcv, ns, pp, wg_per_ct, wgs_per_cu;
     size_t lds;
 };
 
 // rows per 3x3 tile: the value in 4..8 that wastes the fewest rows (ties: the larger)
 int cs_rows(int Ho, int stride) {
-    if (stride == 2) return 2;
-    if (Ho <= 8) return Ho;
-    int best = 8, waste = (int)(ceil_div(Ho, 8) * 8 - Ho);
-    for (int r = 7; r >= 4; --r) {
+    const int cap = stride == 2 ? 4 : CS_SEGS;
+    if (Ho <= cap) return Ho;
+    int best = cap, waste = (int)(ceil_div(Ho, cap) * cap - Ho);
+    for (int r = cap - 1; r >= (cap + 1) / 2; --r) {
         const int w = (int)(ceil_div(Ho, r) * r - Ho);
         if (w < waste) {
             waste = w;
@@ -346,7 +404,7 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     const int nblk = d.cout16 / 16;
     int nbw = d.nbw_hint;
     if (nbw == 0) nbw = nblk <= 7 ? 1 : 2;
-    MV_REQUIRE(nbw >= 1 && nbw <= 4, "conv2ds: blocks per wave must be 1..4");
+    MV_REQUIRE(nbw >= 1 && nbw <= 3, "conv2ds: blocks per wave must be 1..3");
     const int max_waves = nbw <= 2 ? 12 : 8;        // 168 / 256 registers per lane
     const int nprod_want = d.ks == 1 ? 4 : 2;
     const int max_cons = nbw <= 2 ? 8 : max_waves - nprod_want;
@@ -361,7 +419,8 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     p->CT = CT;
     p->ctiles = (int)ceil_div(nblk, CT);
     p->ncons = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
-    p->maxt = max_waves * 64;
+    p->nprod = nprod_want;
+    int stage;
     if (d.ks == 3) {
         p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride);
         MV_REQUIRE(p->R >= 1 && p->R <= CS_SEGS, "conv2ds: rows per tile must be 1..8");
@@ -369,34 +428,46 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
         p->tiles = (int)ceil_div(Ho, p->R) * p->ncs;
         p->pcv = 15 * sw + 3;
         p->pc = (int)round_up(p->pcv, 8);
-        const int chunk = ((p->R - 1) * d.stride + 3) * p->pc * 128;
-        p->lds = (size_t)2 * chunk;
-        const int ni = chunk / 1024;
-        p->nprod = nprod_want;
-        while ((int)ceil_div(ni, p->nprod) > CS_PI_MAX) ++p->nprod;
+        stage = ((p->R - 1) * d.stride + 3) * p->pc * 128;
     } else {
         p->R = CS_SEGS;
         p->ncs = 0;
         p->tiles = (int)ceil_div((int64_t)Ho * Wo, CS_SEGS * 16);
         p->pc = p->pcv = 0;
-        p->lds = (size_t)2 * CS_KCH1 * CS_CHUNK1_BYTES;
-        p->nprod = nprod_want;
+        stage = CS_KCH1 * CS_CHUNK1_BYTES;
     }
+    const int ni = stage / 1024;
+    while ((int)ceil_div(ni, p->nprod) > CS_P_MAX) ++p->nprod;
+    p->pp = (int)ceil_div(ni, p->nprod);
     MV_REQUIRE(p->ncons + p->nprod <= max_waves, "conv2ds: too many waves for one workgroup");
-    MV_REQUIRE(p->lds <= 160 * 1024, "conv2ds: patch does not fit the LDS");
+    // workgroups per CU: two while the waves and a ring of >= 3 stages fit twice, else one with the deepest ring (<= 4 stages)
+    const int waves = p->ncons + p->nprod;
+    int wgs = d.wgs_hint > 0 ? d.wgs_hint : ((2 * waves <= max_waves && 2 * (3 * (size_t)stage + p->nprod * 1024) <= 160 * 1024) ? 2 : 1);
+    MV_REQUIRE(wgs == 1 || wgs == 2, "conv2ds: one or two workgroups per CU");
+    const size_t budget = (size_t)160 * 1024 / wgs - (size_t)p->nprod * 1024;
+    int ns = d.ring_hint > 0 ? d.ring_hint : (int)(budget / stage < 4 ? budget / stage : 4);
+    MV_REQUIRE(ns >= 2 && (size_t)ns * stage <= budget, "conv2ds: the ring does not fit the LDS");
+    MV_REQUIRE((ns - 2) * p->pp <= 48, "conv2ds: too many transfers in flight for a counted wait");
+    p->ns = ns;
+    p->wgs_per_cu = wgs;
+    p->lds = (size_t)ns * stage + (size_t)p->nprod * 1024;
+    const int64_t ptiles = (int64_t)d.B * p->tiles;
+    MV_REQUIRE(ptiles < ((int64_t)1 << 30), "conv2ds: too many pixel tiles");
+    int64_t per_ct = (int64_t)device_cu_count() * wgs / p->ctiles;
+    if (per_ct < 1) per_ct = 1;
+    p->wg_per_ct = (int)(per_ct < ptiles ? per_ct : ptiles);
     return MV_OK;
 }
 
 template <int KS, int NBW, int MAXT>
-int cs_launch(const Conv2dsArgs& a, const CsPlan& p, int B, hipStream_t stream) {
+int cs_launch(const Conv2dsArgs& a, const CsPlan& p, hipStream_t stream) {
     static DeviceOnce smem_set;
     int slot;
     if (device_once_pending(smem_set, &slot)) {
         if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, MAXT>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
         device_once_done(smem_set, slot);
     }
-    MV_LAUNCH((conv2ds_kernel<KS, NBW, MAXT>), ((unsigned)(p.tiles * p.ctiles), (unsigned)B, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds,
-              stream, a);
+    MV_LAUNCH((conv2ds_kernel<KS, NBW, MAXT>), ((unsigned)(p.wg_per_ct * p.ctiles), 1, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds, stream, a);
     return MV_OK;
 }
 
@@ -404,7 +475,7 @@ int cs_launch(const Conv2dsArgs& a, const CsPlan& p, int B, hipStream_t stream) 
 
 int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2ds: null pointer");
-    MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.B <= 65535, "conv2ds: empty input or batch too large for one launch");
+    MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0, "conv2ds: empty input");
     MV_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv2ds: kernel 1 or 3, stride 1 or 2");
     MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2ds: channels must be padded to 16");
     MV_REQUIRE(d.ldx % 16 == 0 && d.ldy % 16 == 0, "conv2ds: leading dimensions must be multiples of 16 channels");
@@ -432,25 +503,24 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     a.nchunks = (a.cinu + 1) / 2;
     a.wunits = 2 * a.nchunks;
     a.cout16 = d.cout16;
-    a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = d.stride; a.epi = d.epi;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = d.stride; a.epi = d.epi;
     a.lo = d.lo; a.hi = d.hi; a.oscale = d.oscale;
     a.R = plan.R; a.ncs = plan.ncs; a.tiles = plan.tiles; a.CT = plan.CT; a.ncons = plan.ncons; a.nprod = plan.nprod;
-    a.pc = plan.pc; a.pcv = plan.pcv;
+    a.pc = plan.pc; a.pcv = plan.pcv; a.pc_magic = plan.pc > 0 ? 65536 / plan.pc + 1 : 0;
+    a.ns = plan.ns; a.pp = plan.pp; a.wg_per_ct = plan.wg_per_ct;
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * Ho * Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
                                                 (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
     if (d.ks == 3) {
         switch (plan.nbw) {
-            case 1: rc = cs_launch<3, 1, 768>(a, plan, d.B, stream); break;
-            case 2: rc = cs_launch<3, 2, 768>(a, plan, d.B, stream); break;
-            case 3: rc = cs_launch<3, 3, 512>(a, plan, d.B, stream); break;
-            default: rc = cs_launch<3, 4, 512>(a, plan, d.B, stream); break;
+            case 1: rc = cs_launch<3, 1, 768>(a, plan, stream); break;
+            case 2: rc = cs_launch<3, 2, 768>(a, plan, stream); break;
+            default: rc = cs_launch<3, 3, 512>(a, plan, stream); break;
         }
     } else {
         switch (plan.nbw) {
-            case 1: rc = cs_launch<1, 1, 768>(a, plan, d.B, stream); break;
-            case 2: rc = cs_launch<1, 2, 768>(a, plan, d.B, stream); break;
-            case 3: rc = cs_launch<1, 3, 512>(a, plan, d.B, stream); break;
-            default: rc = cs_launch<1, 4, 512>(a, plan, d.B, stream); break;
+            case 1: rc = cs_launch<1, 1, 768>(a, plan, stream); break;
+            case 2: rc = cs_launch<1, 2, 768>(a, plan, stream); break;
+            default: rc = cs_launch<1, 3, 512>(a, plan, stream); break;
         }
     }
     prof_end(prof, stream);
