@@ -396,10 +396,10 @@ CONV2DS_CASES = [
     dict(cin=16, cout=32, ks=3, stride=2, H=5, W=33, B=1),                   # strided 3x3 on odd sizes
     dict(cin=48, cout=48, ks=3, H=21, W=50, B=1, with_sum=True),             # 21 rows: tiles of 7 rows
     dict(cin=80, cout=80, ks=3, H=10, W=20, B=1, nbw=2),                     # forced two blocks per wave on 5 blocks
-    dict(cin=64, cout=256, ks=1, H=4, W=40, B=1, nbw=3, ct=6),               # three blocks per wave, three channel tiles (the last with 4 blocks)
-    dict(cin=64, cout=192, ks=3, H=9, W=17, B=1, nbw=3, rows=3),             # three blocks per wave, tiles of 3 rows
+    dict(cin=64, cout=256, ks=1, H=4, W=40, B=1, nbw=2, ct=6),               # two blocks per wave, three channel tiles (the last with 4 blocks)
+    dict(cin=64, cout=192, ks=3, H=9, W=17, B=1, nbw=2, rows=3),             # two blocks per wave on 12 blocks, tiles of 3 rows
     dict(cin=64, cout=64, ks=3, H=24, W=40, B=2, ring=2, wgs=1),             # shortest ring, many tiles per workgroup
-    dict(cin=96, cout=48, ks=1, H=30, W=40, B=2, ring=2, wgs=2),             # 1x1, two workgroups per CU with a ring of two
+    dict(cin=96, cout=48, ks=1, H=30, W=40, B=2, ring=2, wgs=1),             # 1x1, a ring of two
     dict(cin=160, cout=48, ks=1, H=30, W=40, B=2, ring=3, wgs=1),            # 1x1, ring of three
     dict(cin=32, cout=32, ks=3, H=6, W=18, B=1, x_scale=100.0, hi=65504.0, lo=-65504.0),   # large activations (|x| up to ~450; the split saturates at 1023.5)
 ]

@@ -28,15 +28,15 @@ def build():
         '#define CS_T(role, st, ev) do { if (blockIdx.x == 37 && lane == 0 && (st) < %d) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); '
         'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_cs_trace[((role) * %d + (st)) * 4 + (ev)] = t_; } } while (0)\nconstexpr int CS_SEGS = 8;' % (NST, NST, NST))
     # producer (first producer wave only): before the wait, after the wait, after the barrier, after the issue
-    rep('            wait_vm_dyn((issued - gs - 1) * a.pp);\n            lds_barrier();\n            if (issued < nstages) {\n                issue_stage(issued);\n                ++issued;\n            }\n',
+    rep('            wait_vm_dyn((issued - gs - 1) * a.pp);\n            lds_barrier();\n            if (issued < nstages) {\n                issue_stage();\n                ++issued;\n            }\n',
         '            if (pw == 0) CS_T(1, gs, 0);\n            wait_vm_dyn((issued - gs - 1) * a.pp);\n            if (pw == 0) CS_T(1, gs, 1);\n            lds_barrier();\n            if (pw == 0) CS_T(1, gs, 2);\n'
-        '            if (issued < nstages) {\n                issue_stage(issued);\n                ++issued;\n            }\n            if (pw == 0) CS_T(1, gs, 3);\n')
+        '            if (issued < nstages) {\n                issue_stage();\n                ++issued;\n            }\n            if (pw == 0) CS_T(1, gs, 3);\n')
     # consumer wave 0: before the barrier, after it, after the MFMAs, after the epilogue (tile ends only)
     rep('        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n',
         '        if (wave == 0) CS_T(0, gs, 0);\n        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n        if (wave == 0) CS_T(0, gs, 1);\n')
     rep('        if (++c < nst) continue;\n', '        if (wave == 0) CS_T(0, gs, 2);\n        if (++c < nst) continue;\n')
-    rep("                    s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);\n                }\n            }\n        }\n    }\n}\n",
-        "                    s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);\n                }\n            }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n}\n")
+    rep("                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n    }\n}\n",
+        "                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n}\n")
     rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
         'extern "C" int mv_conv2ds_trace_clear() { static unsigned long long z[2 * %d * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), z, sizeof(z)); }\n}  // namespace mv\n\nextern "C" {' % NST)
     open(p, 'w').write(s)
@@ -94,8 +94,8 @@ def run():
         buf = (ctypes.c_ulonglong * (2 * NST * 4))()
         lib.mv_conv2ds_trace_read(buf)
         t0 = min(v for v in buf if v)
-        us = lambda v: '%7.2f' % ((v - t0) / 100.0) if v else '      -'    # s_memtime: 100 MHz
-        print('== %s (B=%d): consumer wave 0 [arrive, barrier passed, MFMAs done, epilogue done] | producer 0 [before wait, landed, barrier passed, issued]  (us)' % (name, B))
+        us = lambda v: '%7.2f' % ((v - t0) / 100.0) if v else '      -'    # unit: 100 ticks of s_memtime (r12q: the kernel's 167 us are 412 k ticks)
+        print('== %s (B=%d): consumer wave 0 [arrive, barrier passed, MFMAs done, epilogue done] | producer 0 [before wait, landed, barrier passed, issued]  (units of 100 s_memtime ticks ~ 0.04 us)' % (name, B))
         for sidx in range(NST):
             c = [buf[(0 * NST + sidx) * 4 + k] for k in range(4)]
             pr = [buf[(1 * NST + sidx) * 4 + k] for k in range(4)]

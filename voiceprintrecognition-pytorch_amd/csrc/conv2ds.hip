@@ -19,8 +19,8 @@
 //   3x3: the segments are R <= 8 consecutive rows of one 16-column strip, so the input patch is (R - 1) * stride + 3 rows of 15 * stride + 3
 //        (padded to a multiple of 8) columns -- 1.4 x the output pixels where a flat list of segments reads 3.4 x;
 //   1x1: 128 consecutive pixels of the flattened utterance plane (no column padding of narrow maps).
-//   One or more PRODUCER waves keep the patch of the next K stage (3x3: one 32-channel chunk; 1x1: two) travelling into the other half of a
-//   double-buffered LDS area (global_load_lds, zero padding and the channel concatenation of AFF = the source address of a granule); they wait for
+//   One or more PRODUCER waves keep the patches of the next K stages (3x3: one 32-channel chunk each; 1x1: three) travelling into a ring
+//   of LDS slots (global_load_lds, zero padding and the channel concatenation of AFF = the source address of a granule); they wait for
 //   their own transfers and meet the consumers at one barrier per stage.  The CONSUMER waves split the output channels (NBW blocks each) and
 //   share the pixels: every wave reads the B fragments (pixels) of all 8 segments from LDS -- bank-conflict free through the granule ^ (entry & 7)
 //   swizzle applied on the source side -- and its own A fragments (weights) straight from global memory / L2, one step ahead, so no weight byte
@@ -35,9 +35,9 @@
 namespace mv {
 
 constexpr int CS_SEGS = 8;             // 16-pixel segments per workgroup
-constexpr int CS_P_MAX = 16;           // LDS-DMA transfers of one stage a producer wave may own
+constexpr int CS_P_MAX = 32;           // LDS-DMA transfers of one stage a producer wave may own
 constexpr int CS_CHUNK1_BYTES = CS_SEGS * 16 * 128;  // 1x1: one 32-channel chunk of the 128 pixels
-constexpr int CS_KCH1 = 2;                           // 1x1: chunks per stage
+constexpr int CS_KCH1 = 3;                           // 1x1: chunks per stage (three steps: the weight register sets rotate with period 3)
 
 __device__ __attribute__((aligned(256))) const unsigned char g_cs_zero_page[256] = {0};
 
@@ -101,19 +101,24 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 
     if (wave >= a.ncons) {
         // ---------------- producer ----------------
+        // Per transfer: source = base of (utterance, source tensor, chunk, this lane's granule) + pixel * bytes per pixel -- one 64-bit
+        // multiply-add -- or the zero page; the pixel of every owned transfer is worked out once per tile.
         const int pw = wave - a.ncons;
         const int psel = lane >> 3, slot = lane & 7;
         const int g = slot ^ psel;                  // granule of the 128-byte chunk row this lane fetches (entry & 7 == psel: rows are 8k entries)
-        const int usel = g >> 2, inner = (g & 3) * 8;  // unit of the chunk, halves inside the unit
+        const int usel = g >> 2;                    // unit of the chunk
+        const unsigned lane_off = (unsigned)((g & 3) * 16);   // bytes inside the unit
         const int ni = stage_bytes >> 10;           // transfers per stage
+        constexpr int NI_CHUNK = CS_CHUNK1_BYTES >> 10;
         const unsigned dump = lds0 + (unsigned)(a.ns * stage_bytes + pw * 1024);
-        const half_t* zero = reinterpret_cast<const half_t*>(g_cs_zero_page);
-        // issue state: stage gi = (tile ti of this workgroup, stage ci of the tile)
-        int ti = 0, ci = 0, b = 0, ho0 = 0, wo0 = 0, p0 = 0;
-        auto decode = [&](int tile_index) {
+        const char* zero = reinterpret_cast<const char*>(g_cs_zero_page);
+        int pixv[CS_P_MAX];                         // pixel (inside the utterance's input plane) behind this lane's entry of transfer j; -1: zero
+        int ti = 0, ci = 0, b = 0, slot_i = 0;
+        auto enter_tile = [&](int tile_index) __attribute__((always_inline)) {
             const int pt = widx + tile_index * a.wg_per_ct;
             b = pt / a.tiles;
             const int t = pt - b * a.tiles;
+            int ho0 = 0, wo0 = 0, p0 = 0;
             if (KS == 3) {
                 const int rt = t / a.ncs;
                 ho0 = rt * a.R;
@@ -121,64 +126,83 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
             } else {
                 p0 = t * (CS_SEGS * 16);
             }
+#pragma unroll
+            for (int j = 0; j < CS_P_MAX; ++j) {
+                int pix = -1;
+                const int k = j * a.nprod + pw;
+                if (j < a.pp && k < ni) {  // uniform
+                    const int kk = KS == 1 ? k % NI_CHUNK : k;   // 1x1: the chunks of a stage cover the same pixels
+                    if (KS == 3) {
+                        const int pr = (kk * 8 * a.pc_magic) >> 16, col = kk * 8 - pr * a.pc + psel;
+                        const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + col;
+                        if (col < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) pix = hi * a.W + wi;
+                    } else {
+                        const int p = p0 + kk * 8 + psel;
+                        if (p < HWo) {
+                            if (a.sh == 1 && a.sw == 1) {
+                                pix = p;
+                            } else {
+                                const int ho = p / a.Wo, wo = p - ho * a.Wo;
+                                pix = ho * a.sh * a.W + wo * a.sw;
+                            }
+                        }
+                    }
+                }
+                pixv[j] = pix;
+            }
         };
-        decode(0);
-        auto issue_stage = [&](int gi) {
-            const unsigned base = lds0 + (unsigned)((gi % a.ns) * stage_bytes);
-            const half_t* xb = a.x + (int64_t)b * a.H * a.W * a.ldx * 2;
-            const half_t* x2b = a.x2 != nullptr ? a.x2 + (int64_t)b * a.H * a.W * a.ldx2 * 2 : nullptr;
+        enter_tile(0);
+        auto issue_stage = [&]() __attribute__((always_inline)) {
+            const unsigned base = lds0 + (unsigned)(slot_i * stage_bytes);
+            if (++slot_i == a.ns) slot_i = 0;
+            // this lane's source per chunk of the stage: tensor, bytes per pixel, or nothing (a unit behind the last one)
+            const char* sb[KCH];
+            unsigned ldb[KCH];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                const int u = 2 * (ci * KCH + kc) + usel;
+                if (u < a.cin1u) {
+                    sb[kc] = reinterpret_cast<const char*>(a.x) + ((int64_t)b * a.H * a.W * a.ldx + 16 * u) * 4 + lane_off;
+                    ldb[kc] = (unsigned)(a.ldx * 4);
+                } else if (u < a.cinu) {
+                    sb[kc] = reinterpret_cast<const char*>(a.x2) + ((int64_t)b * a.H * a.W * a.ldx2 + 16 * (u - a.cin1u)) * 4 + lane_off;
+                    ldb[kc] = (unsigned)(a.ldx2 * 4);
+                } else {
+                    sb[kc] = nullptr;
+                    ldb[kc] = 0;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < CS_P_MAX; ++j) {
                 if (j < a.pp) {  // uniform
                     const int k = j * a.nprod + pw;   // transfer of the stage
-                    const half_t* src = zero;
-                    unsigned dst = dump;
-                    if (k < ni) {  // uniform
-                        int kc = 0, kk = k;   // chunk of the stage, transfer of the chunk
-                        if (KS == 1 && kk >= (CS_CHUNK1_BYTES >> 10)) {
-                            kc = 1;
-                            kk -= CS_CHUNK1_BYTES >> 10;
+                    const int kc = KS == 1 ? k / NI_CHUNK : 0;   // uniform
+                    const char* cbase = sb[0];   // (selected by comparisons: a dynamically indexed array would live in scratch memory)
+                    unsigned cld = ldb[0];
+#pragma unroll
+                    for (int z = 1; z < KCH; ++z)
+                        if (kc == z) {
+                            cbase = sb[z];
+                            cld = ldb[z];
                         }
-                        int pix = -1;
-                        if (KS == 3) {
-                            const int pr = (kk * 8 * a.pc_magic) >> 16, col = kk * 8 - pr * a.pc + psel;
-                            const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + col;
-                            if (col < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) pix = hi * a.W + wi;
-                        } else {
-                            const int p = p0 + kk * 8 + psel;
-                            if (p < HWo) {
-                                if (a.sh == 1 && a.sw == 1) {
-                                    pix = p;
-                                } else {
-                                    const int ho = p / a.Wo, wo = p - ho * a.Wo;
-                                    pix = ho * a.sh * a.W + wo * a.sw;
-                                }
-                            }
-                        }
-                        const int u = 2 * (ci * KCH + kc) + usel;
-                        if (pix >= 0 && u < a.cinu) {
-                            src = u < a.cin1u ? xb + ((int64_t)pix * a.ldx + 16 * u) * 2 + inner
-                                              : x2b + ((int64_t)pix * a.ldx2 + 16 * (u - a.cin1u)) * 2 + inner;
-                        }
-                        dst = base + (unsigned)(k * 1024);
-                    }
-                    glds16_untracked(src, dst);
+                    const char* src = (pixv[j] >= 0 && cbase != nullptr) ? cbase + (uint64_t)(unsigned)pixv[j] * cld : zero;
+                    glds16_untracked(src, k < ni ? base + (unsigned)(k * 1024) : dump);
                 }
             }
             if (++ci == nst) {
                 ci = 0;
                 ++ti;
-                if (ti < my_tiles) decode(ti);
+                if (ti < my_tiles) enter_tile(ti);
             }
         };
         int issued = 0;
-        for (; issued < a.ns - 1 && issued < nstages; ++issued) issue_stage(issued);
+        for (; issued < a.ns - 1 && issued < nstages; ++issued) issue_stage();
 #pragma unroll 1
         for (int gs = 0; gs < nstages; ++gs) {
             wait_vm_dyn((issued - gs - 1) * a.pp);
             lds_barrier();
             if (issued < nstages) {
-                issue_stage(issued);
+                issue_stage();
                 ++issued;
             }
         }
@@ -202,81 +226,79 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     // A fragments: lane (row j16 of a block, K group q) reads 16 bytes of hi and the 16 bytes 32 further of lo
     const int64_t wrow_halves = (int64_t)TAPS * a.wunits * 32;
     const half_t* wrow[NBW];
+    float4v bias64[NBW];   // 64 * bias of this lane's four channels per block: the epilogue works on the stored (scaled) values
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int blk = i < nb ? blk0 + i : (blk0 < nblk_total ? blk0 : 0);   // clamped: loaded, never used
         wrow[i] = a.w + ((int64_t)blk * 16 + j16) * wrow_halves + ghi * 8;
+        const float4v bv = *reinterpret_cast<const float4v*>(a.bias + blk * 16 + q * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias64[i][r] = bv[r] * CS_XSCALE;
     }
+    const float osc64 = a.oscale * CS_XSCALE;
+    const float lo64 = fminf(fmaxf(a.lo * CS_XSCALE, -65504.0f), 65504.0f), hi64 = fminf(fmaxf(a.hi * CS_XSCALE, -65504.0f), 65504.0f);
     // step j of stage c of a tile: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j.  The weights do not depend on the pixel tile.
     constexpr int SPS = KS == 3 ? TAPS : KCH;
-    auto a_offset = [&](int c, int j) -> int64_t {
+    static_assert(SPS % 3 == 0, "the weight register sets rotate with period 3");
+    auto a_offset = [&](int c, int j) __attribute__((always_inline)) -> int64_t {
         if (KS == 3) return ((int64_t)j * a.wunits + 2 * c) * 32;
         const int ch = c * KCH + j;
         return (int64_t)(ch < a.nchunks ? ch : a.nchunks - 1) * 64;
     };
-    half8v ah[NBW], al[NBW], n1h[NBW], n1l[NBW], n2h[NBW], n2l[NBW];
+    // three register sets of weights: the set of step s is s % 3 (3x3: nine steps per stage, the roles are compile-time inside a stage);
+    // the request for step s + 2 goes into the set step s - 1 has left
+    half8v wh[3][NBW], wl[3][NBW];
     int pc_c = 0, pc_j = 0;   // (stage, step) the next weight request is for
-    auto load_next = [&]() {
+    auto request = [&](int set) __attribute__((always_inline)) {
         const int64_t off = a_offset(pc_c, pc_j);
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            n2h[i] = *reinterpret_cast<const half8v*>(wrow[i] + off);
-            n2l[i] = *reinterpret_cast<const half8v*>(wrow[i] + off + 16);
+            wh[set][i] = *reinterpret_cast<const half8v*>(wrow[i] + off);
+            wl[set][i] = *reinterpret_cast<const half8v*>(wrow[i] + off + 16);
         }
         if (++pc_j == SPS) {
             pc_j = 0;
             if (++pc_c == nst) pc_c = 0;
         }
     };
-    load_next();
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-        n1h[i] = n2h[i];
-        n1l[i] = n2l[i];
-    }
-    load_next();
+    request(0);
+    request(1);
     // B fragments: entry e of the patch at e * 128, granule g at ((g ^ (e & 7)) << 4); rows of a 3x3 patch are a multiple of 8 entries
     // apart, so segment u is a constant further than segment 0
     const int seg_stride = KS == 3 ? a.sh * a.pc * 128 : 16 * 128;
 
     float4v acc[CS_SEGS][NBW];
-    int c = 0, tile_index = 0;
+    int c = 0, tile_index = 0, slot_c = 0;
+    int b = 0, ho0 = 0, wo0 = 0, p0 = 0, nvalid = 0;
 #pragma unroll 1
     for (int gs = 0; gs < nstages; ++gs) {
-        // ---- this tile ----
-        const int pt = widx + tile_index * a.wg_per_ct;
-        const int b = pt / a.tiles, t = pt - b * a.tiles;
-        int ho0 = 0, wo0 = 0, p0 = 0, nvalid;
-        if (KS == 3) {
-            const int rt = t / a.ncs;
-            ho0 = rt * a.R;
-            wo0 = (t - rt * a.ncs) * 16;
-            const int rows = a.Ho - ho0;
-            nvalid = rows < a.R ? rows : a.R;
-        } else {
-            p0 = t * (CS_SEGS * 16);
-            const int left = HWo - p0;
-            nvalid = left >= CS_SEGS * 16 ? CS_SEGS : (left + 15) >> 4;
-        }
-        nvalid = MV_UNIFORM(nvalid);
         if (c == 0) {
+            // ---- a new tile ----
+            const int pt = widx + tile_index * a.wg_per_ct;
+            b = pt / a.tiles;
+            const int t = pt - b * a.tiles;
+            if (KS == 3) {
+                const int rt = t / a.ncs;
+                ho0 = rt * a.R;
+                wo0 = (t - rt * a.ncs) * 16;
+                const int rows = a.Ho - ho0;
+                nvalid = rows < a.R ? rows : a.R;
+            } else {
+                p0 = t * (CS_SEGS * 16);
+                const int left = HWo - p0;
+                nvalid = left >= CS_SEGS * 16 ? CS_SEGS : (left + 15) >> 4;
+            }
+            nvalid = MV_UNIFORM(nvalid);
 #pragma unroll
             for (int u = 0; u < CS_SEGS; ++u)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i) acc[u][i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
         lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next
-        const char* buf = smem + (gs % a.ns) * stage_bytes;
-#pragma unroll 1
-        for (int j = 0; j < SPS; ++j) {
-#pragma unroll
-            for (int i = 0; i < NBW; ++i) {
-                ah[i] = n1h[i];
-                al[i] = n1l[i];
-                n1h[i] = n2h[i];
-                n1l[i] = n2l[i];
-            }
-            load_next();
+        const char* buf = smem + slot_c * stage_bytes;
+        if (++slot_c == a.ns) slot_c = 0;
+        // one step: the MFMAs of (tap | chunk) j on weight set SET
+        auto step = [&](int j, const half8v (&ah)[NBW], const half8v (&al)[NBW]) __attribute__((always_inline)) {
             const bool live = KS == 3 || c * KCH + j < a.nchunks;  // uniform: the chunk behind the last one of an odd count does not exist
             if (live && nb > 0) {
                 int e0;
@@ -315,64 +337,116 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                     }
                 }
             }
+        };
+        // sets 0, 1, 2 in turn: a stage starts on set 0 because its step count (9 taps | 3 chunks) is a multiple of 3
+#pragma unroll 1
+        for (int jj = 0; jj < SPS; jj += 3) {
+            request(2);
+            step(jj, wh[0], wl[0]);
+            request(0);
+            step(jj + 1, wh[1], wl[1]);
+            request(1);
+            step(jj + 2, wh[2], wl[2]);
         }
         if (++c < nst) continue;
         c = 0;
         ++tile_index;
 
-        // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16] ----------------
+        // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16], in the scaled domain X = 64 * value ----------------
+        // Batches of EB segments: all operand loads of a batch are requested before the first is used (clamped addresses instead of branches:
+        // only the stores are predicated), so a tile pays the memory latency once per batch.
+        constexpr int EB = NBW == 1 ? 4 : 2;
 #pragma unroll
-        for (int u = 0; u < CS_SEGS; ++u) {
-            if (u >= nvalid) break;  // uniform
-            int64_t pix;
-            bool ok;
-            if (KS == 3) {
-                const int wo = wo0 + j16;
-                ok = wo < a.Wo;
-                pix = (int64_t)b * HWo + (int64_t)(ho0 + u) * a.Wo + wo;
-            } else {
-                const int p = p0 + u * 16 + j16;
-                ok = p < HWo;
-                pix = (int64_t)b * HWo + p;
-            }
-            if (!ok) continue;
+        for (int u0 = 0; u0 < CS_SEGS; u0 += EB) {
+            if (u0 >= nvalid) break;  // uniform
+            int64_t pixo[EB];
+            bool ok[EB];
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
-                if (i >= nb) break;  // uniform
-                const int co = (blk0 + i) * 16 + q * 4;
-                const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
-                const float4v bias = *reinterpret_cast<const float4v*>(a.bias + co);
-                float4v v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[u][i][r] * a.oscale + bias[r];
-                if (a.epi == 0) {
-                    if (a.res != nullptr) {
-                        const float4v rv = s16_load4(a.res + pix * a.ldres * 2 + coff);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], a.lo), a.hi);
-                } else if (a.epi == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));
+            for (int u = 0; u < EB; ++u) {
+                const int uu = u0 + u < nvalid ? u0 + u : nvalid - 1;   // clamped row: loaded, not stored
+                if (KS == 3) {
+                    const int wo = wo0 + j16;
+                    ok[u] = u0 + u < nvalid && wo < a.Wo;
+                    pixo[u] = (int64_t)b * HWo + (int64_t)(ho0 + uu) * a.Wo + (wo < a.Wo ? wo : a.Wo - 1);
                 } else {
-                    const float4v xa = s16_load4(a.res + pix * a.ldres * 2 + coff);
-                    const float4v ya = s16_load4(a.res2 + pix * a.ldres2 * 2 + coff);
+                    const int p = p0 + uu * 16 + j16;
+                    ok[u] = u0 + u < nvalid && p < HWo;
+                    pixo[u] = (int64_t)b * HWo + (p < HWo ? p : HWo - 1);
+                }
+            }
+            half4v r1h[EB][NBW], r1l[EB][NBW], r2h[EB][NBW], r2l[EB][NBW];
+            const bool has1 = a.res != nullptr, has2 = a.epi == 2, has3 = a.y2 != nullptr;   // uniform
+#pragma unroll
+            for (int u = 0; u < EB; ++u)
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) {
+                    const int64_t coff = (int64_t)(i < nb ? blk0 + i : blk0) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
+                    if (has1) {
+                        const half_t* rp = a.res + pixo[u] * a.ldres * 2 + coff;
+                        r1h[u][i] = *reinterpret_cast<const half4v*>(rp);
+                        r1l[u][i] = *reinterpret_cast<const half4v*>(rp + 16);
+                    }
+                    if (has2 || has3) {
+                        const half_t* rp = has2 ? a.res2 + pixo[u] * a.ldres2 * 2 + coff : a.add + pixo[u] * a.ldadd * 2 + coff;
+                        r2h[u][i] = *reinterpret_cast<const half4v*>(rp);
+                        r2l[u][i] = *reinterpret_cast<const half4v*>(rp + 16);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < EB; ++u)
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) {
+                    if (i >= nb) break;  // uniform
+                    const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;
+                    float4v X;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[r] = acc[u0 + u][i][r] * osc64 + bias64[i][r];
+                    if (a.epi == 0) {
+                        if (has1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) X[r] += (float)r1h[u][i][r] + (float)r1l[u][i][r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r], lo64), hi64);
+                    } else if (a.epi == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = X[r] * CS_XSCALE_INV;
+                            X[r] = fminf(fmaxf(v / (1.0f + expf(-v)) * CS_XSCALE, -65504.0f), 65504.0f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float th = tanhf(X[r] * CS_XSCALE_INV);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
+                            const float xa = (float)r1h[u][i][r] + (float)r1l[u][i][r], ya = (float)r2h[u][i][r] + (float)r2l[u][i][r];
+                            X[r] = fminf(fmaxf(xa * (1.0f + th) + ya * (1.0f - th), -65504.0f), 65504.0f);
+                        }
+                    }
+                    half4v h, l;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float th = tanhf(v[r]);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
-                        v[r] = xa[r] * (1.0f + th) + ya[r] * (1.0f - th);
+                        h[r] = (half_t)X[r];
+                        l[r] = (half_t)(X[r] - (float)h[r]);
+                    }
+                    if (ok[u]) {
+                        half_t* yp = a.y + pixo[u] * a.ldy * 2 + coff;
+                        *reinterpret_cast<half4v*>(yp) = h;
+                        *reinterpret_cast<half4v*>(yp + 16) = l;
+                    }
+                    if (has3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float S = fminf(fmaxf(X[r] + (float)r2h[u][i][r] + (float)r2l[u][i][r], -65504.0f), 65504.0f);
+                            h[r] = (half_t)S;
+                            l[r] = (half_t)(S - (float)h[r]);
+                        }
+                        if (ok[u]) {
+                            half_t* yp = a.y2 + pixo[u] * a.ldy2 * 2 + coff;
+                            *reinterpret_cast<half4v*>(yp) = h;
+                            *reinterpret_cast<half4v*>(yp + 16) = l;
+                        }
                     }
                 }
-                s16_store4(a.y + pix * a.ldy * 2 + coff, v);
-                if (a.y2 != nullptr) {
-                    const float4v av = s16_load4(a.add + pix * a.ldadd * 2 + coff);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += av[r];
-                    s16_store4(a.y2 + pix * a.ldy2 * 2 + coff, v);
-                }
-            }
         }
     }
 }
@@ -404,10 +478,10 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     const int nblk = d.cout16 / 16;
     int nbw = d.nbw_hint;
     if (nbw == 0) nbw = nblk <= 7 ? 1 : 2;
-    MV_REQUIRE(nbw >= 1 && nbw <= 3, "conv2ds: blocks per wave must be 1..3");
-    const int max_waves = nbw <= 2 ? 12 : 8;        // 168 / 256 registers per lane
-    const int nprod_want = d.ks == 1 ? 4 : 2;
-    const int max_cons = nbw <= 2 ? 8 : max_waves - nprod_want;
+    MV_REQUIRE(nbw >= 1 && nbw <= 2, "conv2ds: blocks per wave must be 1 or 2");
+    const int max_waves = nbw == 1 ? 12 : 8;        // 168 / 256 registers per lane
+    const int nprod_want = 2;
+    const int max_cons = nbw == 1 ? 8 : 6;
     int CT = d.ct_hint;
     if (CT == 0) {
         const int cap = max_cons * nbw;
@@ -419,7 +493,6 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     p->CT = CT;
     p->ctiles = (int)ceil_div(nblk, CT);
     p->ncons = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
-    p->nprod = nprod_want;
     int stage;
     if (d.ks == 3) {
         p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride);
@@ -437,20 +510,30 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
         stage = CS_KCH1 * CS_CHUNK1_BYTES;
     }
     const int ni = stage / 1024;
-    while ((int)ceil_div(ni, p->nprod) > CS_P_MAX) ++p->nprod;
-    p->pp = (int)ceil_div(ni, p->nprod);
-    MV_REQUIRE(p->ncons + p->nprod <= max_waves, "conv2ds: too many waves for one workgroup");
-    // workgroups per CU: two while the waves and a ring of >= 3 stages fit twice, else one with the deepest ring (<= 4 stages)
-    const int waves = p->ncons + p->nprod;
-    int wgs = d.wgs_hint > 0 ? d.wgs_hint : ((2 * waves <= max_waves && 2 * (3 * (size_t)stage + p->nprod * 1024) <= 160 * 1024) ? 2 : 1);
-    MV_REQUIRE(wgs == 1 || wgs == 2, "conv2ds: one or two workgroups per CU");
-    const size_t budget = (size_t)160 * 1024 / wgs - (size_t)p->nprod * 1024;
-    int ns = d.ring_hint > 0 ? d.ring_hint : (int)(budget / stage < 4 ? budget / stage : 4);
-    MV_REQUIRE(ns >= 2 && (size_t)ns * stage <= budget, "conv2ds: the ring does not fit the LDS");
-    MV_REQUIRE((ns - 2) * p->pp <= 48, "conv2ds: too many transfers in flight for a counted wait");
-    p->ns = ns;
-    p->wgs_per_cu = wgs;
-    p->lds = (size_t)ns * stage + (size_t)p->nprod * 1024;
+    // workgroups per CU, producer waves, ring depth: two workgroups (r12o: 3x3 layers with few consumer waves gain 1.4 - 1.7 x from the second
+    // workgroup's MFMAs under the first one's epilogue) while the waves and a ring of two fit twice -- with one producer wave if two do not fit --,
+    // else one workgroup with the deepest ring (<= 4 stages, <= 48 transfers per wave in flight behind the awaited stage)
+    bool found = false;
+    for (int wgs = 2; wgs >= 1 && !found; --wgs) {
+        if (d.wgs_hint > 0 && wgs != d.wgs_hint) continue;
+        for (int nprod = nprod_want; nprod >= 1 && !found; --nprod) {
+            const int pp = (int)ceil_div(ni, nprod);
+            if ((p->ncons + nprod) * wgs > max_waves || pp > CS_P_MAX) continue;
+            const size_t budget = (size_t)160 * 1024 / wgs - (size_t)nprod * 1024;
+            int ns = (int)(budget / stage < 4 ? budget / stage : 4);
+            if (d.ring_hint > 0) ns = d.ring_hint <= ns ? d.ring_hint : 0;
+            if (ns > 2 && (ns - 2) * pp > 48) ns = 2 + 48 / pp;
+            if (ns < 2) continue;
+            p->wgs_per_cu = wgs;
+            p->nprod = nprod;
+            p->pp = pp;
+            p->ns = ns;
+            found = true;
+        }
+    }
+    MV_REQUIRE(found, "conv2ds: no launch shape fits (waves, LDS ring)");
+    p->lds = (size_t)p->ns * stage + (size_t)p->nprod * 1024;
+    const int wgs = p->wgs_per_cu;
     const int64_t ptiles = (int64_t)d.B * p->tiles;
     MV_REQUIRE(ptiles < ((int64_t)1 << 30), "conv2ds: too many pixel tiles");
     int64_t per_ct = (int64_t)device_cu_count() * wgs / p->ctiles;
@@ -486,8 +569,8 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     MV_REQUIRE((d.y2 == nullptr) == (d.add == nullptr), "conv2ds: the second output needs its addend");
     if (d.y2 != nullptr) MV_REQUIRE(d.ldy2 % 16 == 0 && d.ldadd % 16 == 0, "conv2ds: second output leading dimensions");
     MV_REQUIRE(d.oscale > 0.0f, "conv2ds: output scale of the packed weights missing");
-    MV_REQUIRE((int64_t)d.H * d.W * d.ldx < (int64_t)1 << 31 && (d.x2 == nullptr || (int64_t)d.H * d.W * d.ldx2 < (int64_t)1 << 31),
-               "conv2ds: one utterance's map too large");
+    MV_REQUIRE((int64_t)d.H * d.W * d.ldx < (int64_t)1 << 30 && (d.x2 == nullptr || (int64_t)d.H * d.W * d.ldx2 < (int64_t)1 << 30),
+               "conv2ds: one utterance's map too large (4 GiB)");
     const int p = d.ks / 2;
     const int Ho = (d.H + 2 * p - d.ks) / d.stride + 1, Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
     CsPlan plan;
@@ -513,14 +596,12 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     if (d.ks == 3) {
         switch (plan.nbw) {
             case 1: rc = cs_launch<3, 1, 768>(a, plan, stream); break;
-            case 2: rc = cs_launch<3, 2, 768>(a, plan, stream); break;
-            default: rc = cs_launch<3, 3, 512>(a, plan, stream); break;
+            default: rc = cs_launch<3, 2, 512>(a, plan, stream); break;
         }
     } else {
         switch (plan.nbw) {
             case 1: rc = cs_launch<1, 1, 768>(a, plan, stream); break;
-            case 2: rc = cs_launch<1, 2, 768>(a, plan, stream); break;
-            default: rc = cs_launch<1, 3, 512>(a, plan, stream); break;
+            default: rc = cs_launch<1, 2, 512>(a, plan, stream); break;
         }
     }
     prof_end(prof, stream);
