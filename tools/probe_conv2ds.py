@@ -37,7 +37,12 @@ def build():
     rep('        if (++c < nst) continue;\n', '        if (wave == 0) CS_T(0, gs, 2);\n        if (++c < nst) continue;\n')
     rep("                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n    }\n}\n",
         "                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n}\n")
-    rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
+    rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_occupancy(int ks, int nbw, int threads, int lds) { int n = -1; hipError_t e;\n'
+        '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 768>, threads, (size_t)lds);\n'
+        '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 512>, threads, (size_t)lds);\n'
+        '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 768>, threads, (size_t)lds);\n'
+        '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 512>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
+        'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
         'extern "C" int mv_conv2ds_trace_clear() { static unsigned long long z[2 * %d * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), z, sizeof(z)); }\n}  // namespace mv\n\nextern "C" {' % NST)
     open(p, 'w').write(s)
     obj = d + '/cs.o'
@@ -58,6 +63,8 @@ def run():
     cdll = _hip.bind(lib)
     _hip._lib = cdll
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    for ks, nbw, threads, lds_ in [(3, 1, 320, 63488), (3, 1, 320, 40000), (3, 1, 256, 63488), (3, 1, 384, 63488), (3, 1, 448, 63488), (3, 2, 448, 63488), (1, 2, 512, 149504), (1, 1, 320, 63488)]:
+        print('occupancy: ks %d nbw %d threads %d lds %d -> %d workgroups per CU' % (ks, nbw, threads, lds_, lib.mv_conv2ds_occupancy(ks, nbw, threads, lds_)))
     import importlib.util
     spec = importlib.util.spec_from_file_location('bc', os.path.join(REPO, 'tools', 'bench_conv2d.py'))
     src = open(os.path.join(REPO, 'tools', 'bench_conv2d.py')).read()

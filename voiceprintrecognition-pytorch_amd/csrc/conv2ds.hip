@@ -374,40 +374,37 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                     pixo[u] = (int64_t)b * HWo + (p < HWo ? p : HWo - 1);
                 }
             }
-            half4v r1h[EB][NBW], r1l[EB][NBW], r2h[EB][NBW], r2l[EB][NBW];
+            // A lane's four channels are 8 bytes of hi and 8 bytes of lo, 32 bytes apart.  Memory sees 16 bytes per lane instead: lane group q = 0 / 1 / 2 / 3
+            // moves the hi halves of channels 0-7, the lo halves of 0-7, hi of 8-15, lo of 8-15 of the unit, and v_permlane16_swap trades the
+            // odd / even 16-lane rows of the register pairs on the way (the same exchange in both directions): 64 contiguous bytes per pixel
+            // and instruction instead of two times 32.
+            const int64_t qoff = (q & 1) * 16 + (q >> 1) * 8;   // halves inside the unit: (q & 1) * 32 + (q >> 1) * 16 bytes
+            uint4v r1[EB][NBW], r2[EB][NBW];
             const bool has1 = a.res != nullptr, has2 = a.epi == 2, has3 = a.y2 != nullptr;   // uniform
 #pragma unroll
             for (int u = 0; u < EB; ++u)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i) {
-                    const int64_t coff = (int64_t)(i < nb ? blk0 + i : blk0) * 32 + q * 4;   // halves inside a pixel: unit base + position of the hi quadruple
-                    if (has1) {
-                        const half_t* rp = a.res + pixo[u] * a.ldres * 2 + coff;
-                        r1h[u][i] = *reinterpret_cast<const half4v*>(rp);
-                        r1l[u][i] = *reinterpret_cast<const half4v*>(rp + 16);
-                    }
-                    if (has2 || has3) {
-                        const half_t* rp = has2 ? a.res2 + pixo[u] * a.ldres2 * 2 + coff : a.add + pixo[u] * a.ldadd * 2 + coff;
-                        r2h[u][i] = *reinterpret_cast<const half4v*>(rp);
-                        r2l[u][i] = *reinterpret_cast<const half4v*>(rp + 16);
-                    }
+                    const int64_t coff = (int64_t)(i < nb ? blk0 + i : blk0) * 32 + qoff;   // halves inside a pixel
+                    if (has1) r1[u][i] = *reinterpret_cast<const uint4v*>(a.res + pixo[u] * a.ldres * 2 + coff);
+                    if (has2 || has3)
+                        r2[u][i] = *reinterpret_cast<const uint4v*>(has2 ? a.res2 + pixo[u] * a.ldres2 * 2 + coff : a.add + pixo[u] * a.ldadd * 2 + coff);
                 }
 #pragma unroll
             for (int u = 0; u < EB; ++u)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i) {
                     if (i >= nb) break;  // uniform
-                    const int64_t coff = (int64_t)(blk0 + i) * 32 + q * 4;
+                    const int64_t coff = (int64_t)(blk0 + i) * 32 + qoff;
+                    float4v o1 = {0.0f, 0.0f, 0.0f, 0.0f}, o2 = {0.0f, 0.0f, 0.0f, 0.0f};   // the operands' values (scaled) of this lane's four channels
+                    if (has1) o1 = s16_unswap4(r1[u][i]);
+                    if (has2 || has3) o2 = s16_unswap4(r2[u][i]);
                     float4v X;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[r] = acc[u0 + u][i][r] * osc64 + bias64[i][r];
                     if (a.epi == 0) {
-                        if (has1) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) X[r] += (float)r1h[u][i][r] + (float)r1l[u][i][r];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r], lo64), hi64);
+                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r] + o1[r], lo64), hi64);
                     } else if (a.epi == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -418,33 +415,16 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float th = tanhf(X[r] * CS_XSCALE_INV);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
-                            const float xa = (float)r1h[u][i][r] + (float)r1l[u][i][r], ya = (float)r2h[u][i][r] + (float)r2l[u][i][r];
-                            X[r] = fminf(fmaxf(xa * (1.0f + th) + ya * (1.0f - th), -65504.0f), 65504.0f);
+                            X[r] = fminf(fmaxf(o1[r] * (1.0f + th) + o2[r] * (1.0f - th), -65504.0f), 65504.0f);
                         }
                     }
-                    half4v h, l;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        h[r] = (half_t)X[r];
-                        l[r] = (half_t)(X[r] - (float)h[r]);
-                    }
-                    if (ok[u]) {
-                        half_t* yp = a.y + pixo[u] * a.ldy * 2 + coff;
-                        *reinterpret_cast<half4v*>(yp) = h;
-                        *reinterpret_cast<half4v*>(yp + 16) = l;
-                    }
+                    const uint4v w1 = s16_swap4(X);
+                    if (ok[u]) *reinterpret_cast<uint4v*>(a.y + pixo[u] * a.ldy * 2 + coff) = w1;
                     if (has3) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float S = fminf(fmaxf(X[r] + (float)r2h[u][i][r] + (float)r2l[u][i][r], -65504.0f), 65504.0f);
-                            h[r] = (half_t)S;
-                            l[r] = (half_t)(S - (float)h[r]);
-                        }
-                        if (ok[u]) {
-                            half_t* yp = a.y2 + pixo[u] * a.ldy2 * 2 + coff;
-                            *reinterpret_cast<half4v*>(yp) = h;
-                            *reinterpret_cast<half4v*>(yp + 16) = l;
-                        }
+                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r] + o2[r], -65504.0f), 65504.0f);
+                        const uint4v w2 = s16_swap4(X);
+                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;
                     }
                 }
         }

@@ -27,6 +27,33 @@ __device__ __forceinline__ void s16_store4(half_t* p, const float4v& v) {
     *reinterpret_cast<half4v*>(p) = h;
     *reinterpret_cast<half4v*>(p + 16) = l;
 }
+// Wave-level forms for MFMA epilogues (lane = (pixel j16, channel quadruple q = lane / 16) of a unit): X = the four scaled values of the lane.
+// s16_swap4 splits them and trades register halves between the odd and even 16-lane rows (v_permlane16_swap) so that every lane holds 16
+// contiguous bytes of the unit -- q = 0: hi of channels 0-7, 1: lo of 0-7, 2: hi of 8-15, 3: lo of 8-15, i.e. byte (q & 1) * 32 + (q >> 1) * 16;
+// s16_unswap4 is the way back (the exchange is its own inverse): the sum hi + lo of the lane's own four channels, still scaled.
+// Every lane of the wave has to call them.
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4v s16_swap4(const float4v& X) {
+    half4v h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h[r] = (half_t)X[r];
+        l[r] = (half_t)(X[r] - (float)h[r]);
+    }
+    unsigned h0 = __builtin_bit_cast(unsigned, half2v{h[0], h[1]}), h1 = __builtin_bit_cast(unsigned, half2v{h[2], h[3]});
+    unsigned l0 = __builtin_bit_cast(unsigned, half2v{l[0], l[1]}), l1 = __builtin_bit_cast(unsigned, half2v{l[2], l[3]});
+    row_swap_odd_even(h0, l0);
+    row_swap_odd_even(h1, l1);
+    return uint4v{h0, h1, l0, l1};
+}
+__device__ __forceinline__ float4v s16_unswap4(const uint4v& w) {
+    unsigned h0 = w[0], h1 = w[1], l0 = w[2], l1 = w[3];
+    row_swap_odd_even(h0, l0);
+    row_swap_odd_even(h1, l1);
+    const half2v a = __builtin_bit_cast(half2v, h0), b = __builtin_bit_cast(half2v, h1), c = __builtin_bit_cast(half2v, l0), d = __builtin_bit_cast(half2v, l1);
+    return float4v{(float)a[0] + (float)c[0], (float)a[1] + (float)c[1], (float)b[0] + (float)d[0], (float)b[1] + (float)d[1]};
+}
+
 // one channel (scalar code paths: pooling)
 __device__ __forceinline__ float s16_load1(const half_t* map, int64_t pixel_ld_offset, int c) {
     const half_t* u = map + (pixel_ld_offset + (c & ~15)) * 2 + (c & 15);
