@@ -24,7 +24,7 @@ def build():
         nonlocal s
         assert s.count(a) == 1, (a[:70], s.count(a))
         s = s.replace(a, b)
-    rep('constexpr int CS_SEGS = 8;', '__device__ unsigned long long g_cs_trace[2 * %d * 4];\n'
+    rep('constexpr int CS_SEGS = 8;', '__device__ unsigned long long g_cs_trace[2 * %d * 4];\n__device__ unsigned long long g_cs_wg[1024][2];\n'
         '#define CS_T(role, st, ev) do { if (blockIdx.x == 37 && lane == 0 && (st) < %d) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); '
         'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_cs_trace[((role) * %d + (st)) * 4 + (ev)] = t_; } } while (0)\nconstexpr int CS_SEGS = 8;' % (NST, NST, NST))
     # producer (first producer wave only): before the wait, after the wait, after the barrier, after the issue
@@ -35,14 +35,17 @@ def build():
     rep('        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n',
         '        if (wave == 0) CS_T(0, gs, 0);\n        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n        if (wave == 0) CS_T(0, gs, 1);\n')
     rep('        if (++c < nst) continue;\n', '        if (wave == 0) CS_T(0, gs, 2);\n        if (++c < nst) continue;\n')
-    rep("                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n    }\n}\n",
-        "                            *reinterpret_cast<half4v*>(yp + 16) = l;\n                        }\n                    }\n                }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n}\n")
+    rep("                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;\n                    }\n                }\n        }\n    }\n}\n",
+        "                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;\n                    }\n                }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n"
+        "    if (tid == 0) g_cs_wg[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memtime();\n}\n")
+    rep("    const int HWo = a.Ho * a.Wo;\n\n    if (wave >= a.ncons) {", "    const int HWo = a.Ho * a.Wo;\n    if (tid == 0) g_cs_wg[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memtime();\n\n    if (wave >= a.ncons) {")
     rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_occupancy(int ks, int nbw, int threads, int lds) { int n = -1; hipError_t e;\n'
         '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 768>, threads, (size_t)lds);\n'
         '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 512>, threads, (size_t)lds);\n'
         '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 768>, threads, (size_t)lds);\n'
         '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 512>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
         'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
+        'extern "C" int mv_conv2ds_wg_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_wg), sizeof(g_cs_wg)); }\n'
         'extern "C" int mv_conv2ds_trace_clear() { static unsigned long long z[2 * %d * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), z, sizeof(z)); }\n}  // namespace mv\n\nextern "C" {' % NST)
     open(p, 'w').write(s)
     obj = d + '/cs.o'
@@ -100,6 +103,15 @@ def run():
         torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * (2 * NST * 4))()
         lib.mv_conv2ds_trace_read(buf)
+        wg = (ctypes.c_ulonglong * 2048)()
+        lib.mv_conv2ds_wg_read(wg)
+        starts = sorted(wg[2 * i] for i in range(1024) if wg[2 * i + 1])
+        ends = sorted(wg[2 * i + 1] for i in range(1024) if wg[2 * i + 1])
+        if starts:
+            k0 = starts[0]
+            q = lambda a, f: (a[min(len(a) - 1, int(f * len(a)))] - k0) / 100.0
+            print('   workgroups %d: start min / median / max %.1f / %.1f / %.1f, end min / median / max %.1f / %.1f / %.1f (same units, from the first start)' %
+                  (len(starts), q(starts, 0), q(starts, 0.5), q(starts, 0.9999), q(ends, 0), q(ends, 0.5), q(ends, 0.9999)))
         t0 = min(v for v in buf if v)
         us = lambda v: '%7.2f' % ((v - t0) / 100.0) if v else '      -'    # unit: 100 ticks of s_memtime (r12q: the kernel's 167 us are 412 k ticks)
         print('== %s (B=%d): consumer wave 0 [arrive, barrier passed, MFMAs done, epilogue done] | producer 0 [before wait, landed, barrier passed, issued]  (units of 100 s_memtime ticks ~ 0.04 us)' % (name, B))

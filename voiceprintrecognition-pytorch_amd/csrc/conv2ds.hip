@@ -101,94 +101,107 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 
     if (wave >= a.ncons) {
         // ---------------- producer ----------------
-        // Per transfer: source = base of (utterance, source tensor, chunk, this lane's granule) + pixel * bytes per pixel -- one 64-bit
-        // multiply-add -- or the zero page; the pixel of every owned transfer is worked out once per tile.
+        // Rolled loops over the transfers of a stage with scalar bookkeeping: source = base of (utterance, source tensor, chunk, this lane's
+        // granule) + pixel * bytes per pixel -- one 64-bit multiply-add -- or the zero page.  (The first form, an unrolled loop over a register
+        // array of pixels, compiled to ~50 instructions per transfer with scalar registers spilled into lanes: the producers, not the matrix
+        // pipe, set the pace of the 1x1 layers, r12t timeline.)
         const int pw = wave - a.ncons;
         const int psel = lane >> 3, slot = lane & 7;
         const int g = slot ^ psel;                  // granule of the 128-byte chunk row this lane fetches (entry & 7 == psel: rows are 8k entries)
         const int usel = g >> 2;                    // unit of the chunk
         const unsigned lane_off = (unsigned)((g & 3) * 16);   // bytes inside the unit
         const int ni = stage_bytes >> 10;           // transfers per stage
-        constexpr int NI_CHUNK = CS_CHUNK1_BYTES >> 10;
-        const unsigned dump = lds0 + (unsigned)(a.ns * stage_bytes + pw * 1024);
+        const int nprod = a.nprod, pp = a.pp, ns = a.ns;
+        const unsigned dump = lds0 + (unsigned)(ns * stage_bytes + pw * 1024);
         const char* zero = reinterpret_cast<const char*>(g_cs_zero_page);
-        int pixv[CS_P_MAX];                         // pixel (inside the utterance's input plane) behind this lane's entry of transfer j; -1: zero
-        int ti = 0, ci = 0, b = 0, slot_i = 0;
+        const int cpr = KS == 3 ? a.pc >> 3 : 16;   // transfers per patch row | per chunk
+        int ti = 0, ci = 0, slot_i = 0;
+        int b = 0;
+        int h0 = 0, wlane = 0;                      // 3x3: input row of patch row 0; this lane's input column of column group 0
+        unsigned cmask = 0;                         // 3x3: column groups in which this lane's column exists (inside the patch and the map)
+        int p0 = 0;                                 // 1x1: first pixel of the tile
         auto enter_tile = [&](int tile_index) __attribute__((always_inline)) {
             const int pt = widx + tile_index * a.wg_per_ct;
             b = pt / a.tiles;
             const int t = pt - b * a.tiles;
-            int ho0 = 0, wo0 = 0, p0 = 0;
             if (KS == 3) {
                 const int rt = t / a.ncs;
-                ho0 = rt * a.R;
-                wo0 = (t - rt * a.ncs) * 16;
+                h0 = rt * a.R * a.sh - 1;
+                const int w0 = (t - rt * a.ncs) * 16 * a.sw - 1;
+                wlane = w0 + psel;
+                cmask = 0;
+                for (int cg = 0; cg < cpr; ++cg) {
+                    const int col = cg * 8 + psel, wi = w0 + col;
+                    if (col < a.pcv && wi >= 0 && wi < a.W) cmask |= 1u << cg;
+                }
             } else {
                 p0 = t * (CS_SEGS * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < CS_P_MAX; ++j) {
-                int pix = -1;
-                const int k = j * a.nprod + pw;
-                if (j < a.pp && k < ni) {  // uniform
-                    const int kk = KS == 1 ? k % NI_CHUNK : k;   // 1x1: the chunks of a stage cover the same pixels
-                    if (KS == 3) {
-                        const int pr = (kk * 8 * a.pc_magic) >> 16, col = kk * 8 - pr * a.pc + psel;
-                        const int hi = ho0 * a.sh - 1 + pr, wi = wo0 * a.sw - 1 + col;
-                        if (col < a.pcv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) pix = hi * a.W + wi;
-                    } else {
-                        const int p = p0 + kk * 8 + psel;
-                        if (p < HWo) {
-                            if (a.sh == 1 && a.sw == 1) {
-                                pix = p;
-                            } else {
-                                const int ho = p / a.Wo, wo = p - ho * a.Wo;
-                                pix = ho * a.sh * a.W + wo * a.sw;
-                            }
-                        }
-                    }
-                }
-                pixv[j] = pix;
             }
         };
         enter_tile(0);
         auto issue_stage = [&]() __attribute__((always_inline)) {
             const unsigned base = lds0 + (unsigned)(slot_i * stage_bytes);
-            if (++slot_i == a.ns) slot_i = 0;
-            // this lane's source per chunk of the stage: tensor, bytes per pixel, or nothing (a unit behind the last one)
-            const char* sb[KCH];
+            if (++slot_i == ns) slot_i = 0;
+            // this lane's source per chunk of the stage: address of pixel 0 (its unit and granule included) and bytes per pixel; 0 = nothing
+            // (a unit behind the last one)
+            uint64_t sb[KCH];
             unsigned ldb[KCH];
 #pragma unroll
             for (int kc = 0; kc < KCH; ++kc) {
                 const int u = 2 * (ci * KCH + kc) + usel;
+                sb[kc] = 0;
+                ldb[kc] = 0;
                 if (u < a.cin1u) {
-                    sb[kc] = reinterpret_cast<const char*>(a.x) + ((int64_t)b * a.H * a.W * a.ldx + 16 * u) * 4 + lane_off;
+                    sb[kc] = (uint64_t)(reinterpret_cast<const char*>(a.x) + ((int64_t)b * a.H * a.W * a.ldx + 16 * u) * 4 + lane_off);
                     ldb[kc] = (unsigned)(a.ldx * 4);
                 } else if (u < a.cinu) {
-                    sb[kc] = reinterpret_cast<const char*>(a.x2) + ((int64_t)b * a.H * a.W * a.ldx2 + 16 * (u - a.cin1u)) * 4 + lane_off;
+                    sb[kc] = (uint64_t)(reinterpret_cast<const char*>(a.x2) + ((int64_t)b * a.H * a.W * a.ldx2 + 16 * (u - a.cin1u)) * 4 + lane_off);
                     ldb[kc] = (unsigned)(a.ldx2 * 4);
-                } else {
-                    sb[kc] = nullptr;
-                    ldb[kc] = 0;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < CS_P_MAX; ++j) {
-                if (j < a.pp) {  // uniform
-                    const int k = j * a.nprod + pw;   // transfer of the stage
-                    const int kc = KS == 1 ? k / NI_CHUNK : 0;   // uniform
-                    const char* cbase = sb[0];   // (selected by comparisons: a dynamically indexed array would live in scratch memory)
-                    unsigned cld = ldb[0];
+            int count = 0;
+            if (KS == 3) {
+                int pr = pw / cpr, cg = pw - pr * cpr;   // patch row and column group of transfer k
+#pragma unroll 1
+                for (int k = pw; k < ni; k += nprod) {
+                    const int hi = h0 + pr;
+                    const bool ok = (unsigned)hi < (unsigned)a.H && ((cmask >> cg) & 1u) != 0 && sb[0] != 0;
+                    const unsigned pix = (unsigned)(hi * a.W + wlane + cg * 8);   // (meaningless where !ok)
+                    const uint64_t src = ok ? sb[0] + (uint64_t)pix * ldb[0] : (uint64_t)zero;
+                    glds16_untracked(reinterpret_cast<const void*>(src), base + (unsigned)(k * 1024));
+                    ++count;
+                    cg += nprod;
+                    while (cg >= cpr) {
+                        cg -= cpr;
+                        ++pr;
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int k = pw; k < ni; k += nprod) {
+                    const int kc = k >> 4, kk = k & 15;   // chunk of the stage, transfer of the chunk (the chunks cover the same pixels)
+                    uint64_t cb = sb[0];
+                    unsigned cl = ldb[0];
 #pragma unroll
                     for (int z = 1; z < KCH; ++z)
-                        if (kc == z) {
-                            cbase = sb[z];
-                            cld = ldb[z];
+                        if (kc == z) {  // uniform
+                            cb = sb[z];
+                            cl = ldb[z];
                         }
-                    const char* src = (pixv[j] >= 0 && cbase != nullptr) ? cbase + (uint64_t)(unsigned)pixv[j] * cld : zero;
-                    glds16_untracked(src, k < ni ? base + (unsigned)(k * 1024) : dump);
+                    const int p = p0 + kk * 8 + psel;
+                    unsigned pix = (unsigned)p;
+                    if (a.sh != 1) {  // uniform: strided 1x1 (first block of a stage)
+                        const int ho = p / a.Wo, wo = p - ho * a.Wo;
+                        pix = (unsigned)(ho * a.sh * a.W + wo * a.sw);
+                    }
+                    const bool ok = p < HWo && cb != 0;
+                    const uint64_t src = ok ? cb + (uint64_t)pix * cl : (uint64_t)zero;
+                    glds16_untracked(reinterpret_cast<const void*>(src), base + (unsigned)(k * 1024));
+                    ++count;
                 }
             }
+#pragma unroll 1
+            for (; count < pp; ++count) glds16_untracked(zero, dump);   // every producer wave issues exactly pp transfers per stage (counted waits)
             if (++ci == nst) {
                 ci = 0;
                 ++ti;
@@ -196,10 +209,10 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
             }
         };
         int issued = 0;
-        for (; issued < a.ns - 1 && issued < nstages; ++issued) issue_stage();
+        for (; issued < ns - 1 && issued < nstages; ++issued) issue_stage();
 #pragma unroll 1
         for (int gs = 0; gs < nstages; ++gs) {
-            wait_vm_dyn((issued - gs - 1) * a.pp);
+            wait_vm_dyn((issued - gs - 1) * pp);
             lds_barrier();
             if (issued < nstages) {
                 issue_stage();
