@@ -28,8 +28,8 @@ def build():
         '#define CS_T(role, st, ev) do { if (blockIdx.x == 37 && lane == 0 && (st) < %d) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); '
         'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_cs_trace[((role) * %d + (st)) * 4 + (ev)] = t_; } } while (0)\nconstexpr int CS_SEGS = 8;' % (NST, NST, NST))
     # producer (first producer wave only): before the wait, after the wait, after the barrier, after the issue
-    rep('            wait_vm_dyn((issued - gs - 1) * a.pp);\n            lds_barrier();\n            if (issued < nstages) {\n                issue_stage();\n                ++issued;\n            }\n',
-        '            if (pw == 0) CS_T(1, gs, 0);\n            wait_vm_dyn((issued - gs - 1) * a.pp);\n            if (pw == 0) CS_T(1, gs, 1);\n            lds_barrier();\n            if (pw == 0) CS_T(1, gs, 2);\n'
+    rep('            wait_vm_dyn((issued - gs - 1) * pp);\n            lds_barrier();\n            if (issued < nstages) {\n                issue_stage();\n                ++issued;\n            }\n',
+        '            if (pw == 0) CS_T(1, gs, 0);\n            wait_vm_dyn((issued - gs - 1) * pp);\n            if (pw == 0) CS_T(1, gs, 1);\n            lds_barrier();\n            if (pw == 0) CS_T(1, gs, 2);\n'
         '            if (issued < nstages) {\n                issue_stage();\n                ++issued;\n            }\n            if (pw == 0) CS_T(1, gs, 3);\n')
     # consumer wave 0: before the barrier, after it, after the MFMAs, after the epilogue (tile ends only)
     rep('        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n',
