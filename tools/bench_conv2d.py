@@ -25,6 +25,10 @@ SHAPES = [
     ('s4 3x3 320->320', 10, 38, 320, 320, 3, 1, False),
     ('s4 conv3 1280->1536+res', 10, 38, 1280, 1536, 1, 1, True),
     ('ds 3x3 768->1536 /2', 20, 75, 768, 1536, 3, 2, False),
+    ('m32 s1 conv1 64->32', 80, 298, 64, 32, 1, 1, False),
+    ('m32 s1 3x3 16->16', 80, 298, 16, 16, 3, 1, False),
+    ('m32 s1 conv3 32->64+res', 80, 298, 32, 64, 1, 1, True),
+    ('m32 s2 3x3 32->32', 40, 149, 32, 32, 3, 1, False),
 ]
 only = os.environ.get('MV_BENCH_SHAPES')
 if only:
@@ -77,22 +81,24 @@ for name, H, W, cin, cout, ks, stride, with_res in SHAPES:
     e.x, e.ldx, e.w, e.bias, e.oscale, e.y, e.ldy = xs.data_ptr(), cin, pks.data_ptr(), bias.data_ptr(), osc.value, ys.data_ptr(), cout
     e.res, e.ldres = (rs.data_ptr() if with_res else None), cout
     e.B, e.H, e.W, e.cin16, e.cout16, e.ks, e.stride, e.epi, e.lo, e.hi = B, H, W, cin, cout, ks, stride, 0, 0.0, 20.0
-    hints = [(0, 0, 0, 0, 0)]   # nbw, ct, rows, ring, wgs
+    hints = [(0, 0, 0, 0, 0, 0)]   # nbw, ct, rows, ring, wgs, spw
     if os.environ.get('MV_BENCH_SWEEP') == '1':
-        hints += [(1, 0, 0, 0, 0), (2, 0, 0, 0, 0), (0, 0, 0, 2, 0), (0, 0, 0, 0, 1), (0, 0, 0, 0, 2)]
+        hints += [(1, 0, 0, 0, 0, 0), (2, 0, 0, 0, 0, 0), (0, 0, 0, 0, 1, 0), (0, 0, 0, 0, 2, 0)]
+        if cout <= 64:
+            hints += [(1, 0, 0, 0, 0, 8), (1, 0, 0, 0, 0, 4), (1, 0, 0, 0, 0, 2)]
         if ks == 3 and stride == 1:
-            hints += [(0, 0, 4, 0, 0), (0, 0, 5, 0, 0)]
+            hints += [(0, 0, 4, 0, 0, 0)]
     out = dict(layer=name, B=B, gflop=round(gflop, 1), mbytes=round(mbytes, 1), f32_us=round(t32, 1), f32_tflops=round(gflop / t32 * 1e3, 1))
-    for nbw, ct, rows, ring, wgs in hints:
-        e.nbw_hint, e.ct_hint, e.rows_hint, e.ring_hint, e.wgs_hint = nbw, ct, rows, ring, wgs
-        key = 'split' if (nbw, ct, rows, ring, wgs) == (0, 0, 0, 0, 0) else 'nbw%d_rows%d_ring%d_wgs%d' % (nbw, rows, ring, wgs)
+    for nbw, ct, rows, ring, wgs, spw in hints:
+        e.nbw_hint, e.ct_hint, e.rows_hint, e.ring_hint, e.wgs_hint, e.spw_hint = nbw, ct, rows, ring, wgs, spw
+        key = 'split' if (nbw, ct, rows, ring, wgs, spw) == (0, 0, 0, 0, 0, 0) else 'nbw%d_rows%d_ring%d_wgs%d_spw%d' % (nbw, rows, ring, wgs, spw)
         try:
             ts = timed(lambda: _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(e), st()), cdll))
         except RuntimeError as ex:
             out[key] = 'n/a'
             continue
         out[key + '_us'] = round(ts, 1)
-        if (nbw, ct, rows, ring, wgs) == (0, 0, 0, 0, 0):
+        if (nbw, ct, rows, ring, wgs, spw) == (0, 0, 0, 0, 0, 0):
             ym = torch.empty_like(ys)
             _hip.check(cdll.mv_map_merge_f32(ys.data_ptr(), ym.data_ptr(), ys.numel(), st()), cdll)
             torch.cuda.synchronize()

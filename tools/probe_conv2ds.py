@@ -40,10 +40,10 @@ def build():
         "    if (tid == 0) g_cs_wg[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memtime();\n}\n")
     rep("    const int HWo = a.Ho * a.Wo;\n\n    if (wave >= a.ncons) {", "    const int HWo = a.Ho * a.Wo;\n    if (tid == 0) g_cs_wg[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memtime();\n\n    if (wave >= a.ncons) {")
     rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_occupancy(int ks, int nbw, int threads, int lds) { int n = -1; hipError_t e;\n'
-        '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 768>, threads, (size_t)lds);\n'
-        '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 512>, threads, (size_t)lds);\n'
-        '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 768>, threads, (size_t)lds);\n'
-        '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 512>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
+        '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 8, 768>, threads, (size_t)lds);\n'
+        '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 8, 512>, threads, (size_t)lds);\n'
+        '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 8, 768>, threads, (size_t)lds);\n'
+        '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 8, 512>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
         'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
         'extern "C" int mv_conv2ds_wg_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_wg), sizeof(g_cs_wg)); }\n'
         'extern "C" int mv_conv2ds_trace_clear() { static unsigned long long z[2 * %d * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), z, sizeof(z)); }\n}  // namespace mv\n\nextern "C" {' % NST)
@@ -93,7 +93,7 @@ def run():
         e.x, e.ldx, e.w, e.bias, e.oscale, e.y, e.ldy = xs.data_ptr(), cin, pks.data_ptr(), bias.data_ptr(), osc.value, ys.data_ptr(), cout
         e.res, e.ldres = (rs.data_ptr() if with_res else None), cout
         e.B, e.H, e.W, e.cin16, e.cout16, e.ks, e.stride, e.epi, e.lo, e.hi = B, H, W, cin, cout, ks, stride, 0, 0.0, 20.0
-        for k in ('nbw', 'rows', 'ring', 'wgs'):
+        for k in ('nbw', 'rows', 'ring', 'wgs', 'spw'):
             setattr(e, k + '_hint', int(os.environ.get('MV_PROBE_' + k.upper(), '0')))
         for _ in range(2):
             _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(e), st()), cdll)

@@ -81,12 +81,17 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 //              wave issues exactly pp transfers per stage -- the padding ones read the zero page into a dump KiB); barrier g; issue stage g + ns - 1
 //              into the slot of stage g - 1, which every consumer has left when it arrives at barrier g
 //   consumer:  for g: barrier g; MFMAs of stage g (weights two steps ahead in registers); after a tile's last stage its epilogue
-template <int KS, int NBW, int MAXT>
+// SPW = segments per consumer wave: 8 (the waves split the output channels and share all pixels) or, for layers with few output channels, 4 / 2 / 1
+// (consumer wave w works on segments (w % PG) * SPW ..., PG = 8 / SPW, of channel group w / PG: more waves on the matrix pipe where one or two
+// blocks of 16 channels would leave three SIMDs idle; the small weight slices are then read by PG waves)
+template <int KS, int NBW, int SPW, int MAXT>
 __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     MV_DYN_SMEM(smem);
     constexpr int TAPS = KS * KS;
     constexpr int KCH = KS == 3 ? 1 : CS_KCH1;            // K chunks per stage
-    constexpr int G = NBW >= 2 ? 2 : 4;                   // segments per MFMA group: >= 4 independent accumulators between dependent MFMAs
+    constexpr int G0 = NBW >= 2 ? 2 : 4;                  // segments per MFMA group: >= 4 independent accumulators between dependent MFMAs
+    constexpr int G = G0 < SPW ? G0 : SPW;
+    constexpr int PG = CS_SEGS / SPW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = MV_UNIFORM(tid >> 6);
     const int ct = blockIdx.x / a.wg_per_ct, widx = blockIdx.x - ct * a.wg_per_ct;
@@ -226,10 +231,11 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     const int j16 = lane & 15, q = lane >> 4;
     const int ghi = (q >> 1) * 4 + (q & 1);
     const int nblk_total = a.cout16 >> 4;
-    const int blk0 = ct * a.CT + wave * NBW;                 // this wave's first block of 16 output channels
+    const int cgrp = wave / PG, useg0 = (wave - cgrp * PG) * SPW;   // channel group and first segment of this wave
+    const int blk0 = ct * a.CT + cgrp * NBW;                 // this wave's first block of 16 output channels
     int nb = nblk_total - blk0;                              // blocks of this wave that exist
     {
-        const int in_tile = a.CT - wave * NBW;
+        const int in_tile = a.CT - cgrp * NBW;
         nb = nb < in_tile ? nb : in_tile;
         nb = nb < NBW ? nb : NBW;
         nb = nb > 0 ? nb : 0;
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     // apart, so segment u is a constant further than segment 0
     const int seg_stride = KS == 3 ? a.sh * a.pc * 128 : 16 * 128;
 
-    float4v acc[CS_SEGS][NBW];
+    float4v acc[SPW][NBW];
     int c = 0, tile_index = 0, slot_c = 0;
     int b = 0, ho0 = 0, wo0 = 0, p0 = 0, nvalid = 0;
 #pragma unroll 1
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
             }
             nvalid = MV_UNIFORM(nvalid);
 #pragma unroll
-            for (int u = 0; u < CS_SEGS; ++u)
+            for (int u = 0; u < SPW; ++u)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i) acc[u][i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
@@ -324,11 +330,11 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                     e0 = j16;
                     cb = buf + j * chunk_bytes;
                 }
-                const char* ph = cb + e0 * 128 + ((ghi ^ (e0 & 7)) << 4);
-                const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4);
+                const char* ph = cb + e0 * 128 + ((ghi ^ (e0 & 7)) << 4) + useg0 * seg_stride;
+                const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4) + useg0 * seg_stride;
 #pragma unroll
-                for (int u0 = 0; u0 < CS_SEGS; u0 += G) {
-                    if (u0 < nvalid) {  // uniform
+                for (int u0 = 0; u0 < SPW; u0 += G) {
+                    if (useg0 + u0 < nvalid) {  // uniform
                         half8v bh[G], bl[G];
 #pragma unroll
                         for (int u = 0; u < G; ++u) {
@@ -368,22 +374,24 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16], in the scaled domain X = 64 * value ----------------
         // Batches of EB segments: all operand loads of a batch are requested before the first is used (clamped addresses instead of branches:
         // only the stores are predicated), so a tile pays the memory latency once per batch.
-        constexpr int EB = NBW == 1 ? 4 : 2;
+        constexpr int EB0 = NBW == 1 ? 4 : 2;
+        constexpr int EB = EB0 < SPW ? EB0 : SPW;
 #pragma unroll
-        for (int u0 = 0; u0 < CS_SEGS; u0 += EB) {
-            if (u0 >= nvalid) break;  // uniform
+        for (int u0 = 0; u0 < SPW; u0 += EB) {
+            if (useg0 + u0 >= nvalid) break;  // uniform
             int64_t pixo[EB];
             bool ok[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
-                const int uu = u0 + u < nvalid ? u0 + u : nvalid - 1;   // clamped row: loaded, not stored
+                const int su = useg0 + u0 + u;                           // segment of the tile
+                const int uu = su < nvalid ? su : nvalid - 1;           // clamped row: loaded, not stored
                 if (KS == 3) {
                     const int wo = wo0 + j16;
-                    ok[u] = u0 + u < nvalid && wo < a.Wo;
+                    ok[u] = su < nvalid && wo < a.Wo;
                     pixo[u] = (int64_t)b * HWo + (int64_t)(ho0 + uu) * a.Wo + (wo < a.Wo ? wo : a.Wo - 1);
                 } else {
                     const int p = p0 + uu * 16 + j16;
-                    ok[u] = u0 + u < nvalid && p < HWo;
+                    ok[u] = su < nvalid && p < HWo;
                     pixo[u] = (int64_t)b * HWo + (p < HWo ? p : HWo - 1);
                 }
             }
@@ -448,13 +456,13 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 namespace {
 
 struct CsPlan {
-    int nbw, CT, ctiles, ncons, nprod, R, ncs, tiles, pc, pcv, ns, pp, wg_per_ct, wgs_per_cu;
+    int nbw, spw, CT, ctiles, ncons, nprod, R, ncs, tiles, pc, pcv, ns, pp, wg_per_ct, wgs_per_cu;
     size_t lds;
 };
 
 // rows per 3x3 tile: the value in 4..8 that wastes the fewest rows (ties: the larger)
 int cs_rows(int Ho, int stride) {
-    const int cap = stride == 2 ? 4 : CS_SEGS;
+    const int cap = stride == 2 ? 5 : CS_SEGS;   // (stride 2: 11 patch rows of 40 columns = 55 KiB per stage, a ring of two)
     if (Ho <= cap) return Ho;
     int best = cap, waste = (int)(ceil_div(Ho, cap) * cap - Ho);
     for (int r = cap - 1; r >= (cap + 1) / 2; --r) {
@@ -485,7 +493,19 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     p->nbw = nbw;
     p->CT = CT;
     p->ctiles = (int)ceil_div(nblk, CT);
-    p->ncons = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
+    const int cgroups = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
+    // few channel groups: the consumer waves also split the pixels (as many waves as 8 allow)
+    int pg = 1;
+    if (nbw == 1)
+        while (pg < CS_SEGS && 2 * pg * cgroups <= max_cons) pg *= 2;
+    if (d.spw_hint > 0) {
+        MV_REQUIRE((d.spw_hint == 1 || d.spw_hint == 2 || d.spw_hint == 4 || d.spw_hint == 8) && (d.spw_hint == 8 || nbw == 1) &&
+                       (CS_SEGS / d.spw_hint) * cgroups <= max_cons,
+                   "conv2ds: segments per wave must be 1, 2, 4 or 8 (below 8: one block per wave, at most 8 consumer waves)");
+        pg = CS_SEGS / d.spw_hint;
+    }
+    p->spw = CS_SEGS / pg;
+    p->ncons = pg * cgroups;
     int stage;
     if (d.ks == 3) {
         p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride);
@@ -506,12 +526,13 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     // workgroups per CU, producer waves, ring depth: two workgroups (r12o: 3x3 layers with few consumer waves gain 1.4 - 1.7 x from the second
     // workgroup's MFMAs under the first one's epilogue) while the waves and a ring of two fit twice -- with one producer wave if two do not fit --,
     // else one workgroup with the deepest ring (<= 4 stages, <= 48 transfers per wave in flight behind the awaited stage)
+    const int wave_cap = nbw == 2 ? 8 : (p->spw <= 2 ? 16 : 12);   // waves per CU at the variant's register count (<= 256 | <= 104 | <= 168 per lane)
     bool found = false;
     for (int wgs = 2; wgs >= 1 && !found; --wgs) {
         if (d.wgs_hint > 0 && wgs != d.wgs_hint) continue;
         for (int nprod = nprod_want; nprod >= 1 && !found; --nprod) {
             const int pp = (int)ceil_div(ni, nprod);
-            if ((p->ncons + nprod) * wgs > max_waves || pp > CS_P_MAX) continue;
+            if ((p->ncons + nprod) * wgs > wave_cap || p->ncons + nprod > max_waves || pp > CS_P_MAX) continue;
             const size_t budget = (size_t)160 * 1024 / wgs - (size_t)nprod * 1024;
             int ns = (int)(budget / stage < 4 ? budget / stage : 4);
             if (d.ring_hint > 0) ns = d.ring_hint <= ns ? d.ring_hint : 0;
@@ -535,15 +556,15 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     return MV_OK;
 }
 
-template <int KS, int NBW, int MAXT>
+template <int KS, int NBW, int SPW, int MAXT>
 int cs_launch(const Conv2dsArgs& a, const CsPlan& p, hipStream_t stream) {
     static DeviceOnce smem_set;
     int slot;
     if (device_once_pending(smem_set, &slot)) {
-        if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, MAXT>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
+        if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, SPW, MAXT>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
         device_once_done(smem_set, slot);
     }
-    MV_LAUNCH((conv2ds_kernel<KS, NBW, MAXT>), ((unsigned)(p.wg_per_ct * p.ctiles), 1, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds, stream, a);
+    MV_LAUNCH((conv2ds_kernel<KS, NBW, SPW, MAXT>), ((unsigned)(p.wg_per_ct * p.ctiles), 1, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds, stream, a);
     return MV_OK;
 }
 
@@ -587,15 +608,17 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * Ho * Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
                                                 (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
     if (d.ks == 3) {
-        switch (plan.nbw) {
-            case 1: rc = cs_launch<3, 1, 768>(a, plan, stream); break;
-            default: rc = cs_launch<3, 2, 512>(a, plan, stream); break;
-        }
+        if (plan.nbw == 2) rc = cs_launch<3, 2, 8, 512>(a, plan, stream);
+        else if (plan.spw == 8) rc = cs_launch<3, 1, 8, 768>(a, plan, stream);
+        else if (plan.spw == 4) rc = cs_launch<3, 1, 4, 768>(a, plan, stream);
+        else if (plan.spw == 2) rc = cs_launch<3, 1, 2, 768>(a, plan, stream);
+        else rc = cs_launch<3, 1, 1, 768>(a, plan, stream);
     } else {
-        switch (plan.nbw) {
-            case 1: rc = cs_launch<1, 1, 768>(a, plan, stream); break;
-            default: rc = cs_launch<1, 2, 512>(a, plan, stream); break;
-        }
+        if (plan.nbw == 2) rc = cs_launch<1, 2, 8, 512>(a, plan, stream);
+        else if (plan.spw == 8) rc = cs_launch<1, 1, 8, 768>(a, plan, stream);
+        else if (plan.spw == 4) rc = cs_launch<1, 1, 4, 768>(a, plan, stream);
+        else if (plan.spw == 2) rc = cs_launch<1, 1, 2, 768>(a, plan, stream);
+        else rc = cs_launch<1, 1, 1, 768>(a, plan, stream);
     }
     prof_end(prof, stream);
     if (rc != MV_OK) return rc;
