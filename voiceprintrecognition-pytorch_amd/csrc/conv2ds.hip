@@ -332,27 +332,39 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                 }
                 const char* ph = cb + e0 * 128 + ((ghi ^ (e0 & 7)) << 4) + useg0 * seg_stride;
                 const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4) + useg0 * seg_stride;
+                // groups of G segments, the fragment reads of group g + 1 requested before the MFMAs of group g (the uniform branches on the
+                // segment count end basic blocks: left to the compiler every group waited for its own reads, r12w: 49 % of the MFMA rate in a stage)
+                constexpr int NG = SPW / G;
+                constexpr int NBUF = NBW >= 2 ? 2 : 1;   // (one block per wave: 4-segment groups, a second fragment set does not fit 168 registers)
+                half8v bh[NBUF][G], bl[NBUF][G];
+                auto read_group = [&](int u0, half8v (&rh)[G], half8v (&rl)[G]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u0 = 0; u0 < SPW; u0 += G) {
+                    for (int u = 0; u < G; ++u) {
+                        rh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
+                        rl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
+                    }
+                };
+                if (NBUF == 2 && useg0 < nvalid) read_group(0, bh[0], bl[0]);  // uniform
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int u0 = gi * G;
+                    if (NBUF == 2 && gi + 1 < NG && useg0 + u0 + G < nvalid) read_group(u0 + G, bh[(gi + 1) % NBUF], bl[(gi + 1) % NBUF]);  // uniform
                     if (useg0 + u0 < nvalid) {  // uniform
-                        half8v bh[G], bl[G];
-#pragma unroll
-                        for (int u = 0; u < G; ++u) {
-                            bh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
-                            bl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
-                        }
+                        if (NBUF == 1) read_group(u0, bh[0], bl[0]);
+                        const half8v(&ch)[G] = bh[gi % NBUF];
+                        const half8v(&cl)[G] = bl[gi % NBUF];
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], ch[u], acc[u0 + u][i], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], cl[u], acc[u0 + u][i], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], ch[u], acc[u0 + u][i], 0, 0, 0);
                     }
                 }
             }
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16], in the scaled domain X = 64 * value ----------------
         // Batches of EB segments: all operand loads of a batch are requested before the first is used (clamped addresses instead of branches:
         // only the stores are predicated), so a tile pays the memory latency once per batch.
-        constexpr int EB0 = NBW == 1 ? 4 : 2;
+        constexpr int EB0 = 4;
         constexpr int EB = EB0 < SPW ? EB0 : SPW;
 #pragma unroll
         for (int u0 = 0; u0 < SPW; u0 += EB) {
@@ -494,10 +506,10 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     p->CT = CT;
     p->ctiles = (int)ceil_div(nblk, CT);
     const int cgroups = (int)ceil_div(CT < nblk ? CT : nblk, nbw);
-    // few channel groups: the consumer waves also split the pixels (as many waves as 8 allow)
+    // few channel groups: two groups of consumer waves split the pixels (r12w, 16 -> 16 channels 3x3 at 16 x 80 x 298: 8 segments per wave 38.7 us,
+    // 4: 28.1, 2: 34.4, 1: 62 -- one segment per wave is a chain of dependent MFMAs)
     int pg = 1;
-    if (nbw == 1)
-        while (pg < CS_SEGS && 2 * pg * cgroups <= max_cons) pg *= 2;
+    if (nbw == 1 && 2 * cgroups <= max_cons) pg = 2;
     if (d.spw_hint > 0) {
         MV_REQUIRE((d.spw_hint == 1 || d.spw_hint == 2 || d.spw_hint == 4 || d.spw_hint == 8) && (d.spw_hint == 8 || nbw == 1) &&
                        (CS_SEGS / d.spw_hint) * cgroups <= max_cons,
