@@ -312,9 +312,9 @@ typedef struct MvConv2dsDesc {
     int32_t B, H, W, cin16, cout16, ks, stride, epi;
     float lo, hi;
     int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
-    int32_t nbw_hint, ct_hint, rows_hint, ring_hint, wgs_hint, spw_hint; /* 0 = the launcher's choice; otherwise blocks of 16 output channels per wave
-                                           * (1 | 2), blocks per workgroup, rows per 3x3 tile (1..8), LDS ring stages (>= 2), workgroups per CU
-                                           * (1 | 2), segments per consumer wave (8 | 4 | 2 | 1): launch shapes for tests and tools/bench_conv2d.py (never the bits of a result) */
+    int32_t nbw_hint, ct_hint, rows_hint, ring_hint, wgs_hint, spw_hint, nprod_hint; /* 0 = the launcher's choice; otherwise blocks of 16 output channels per wave
+                                           * (1..3), blocks per workgroup, rows per 3x3 tile (1..8), LDS ring stages (>= 2), workgroups per CU
+                                           * (1 | 2), segments per consumer wave (8 | 4 | 2 | 1), producer waves: launch shapes for tests and tools/bench_conv2d.py (never the bits of a result) */
 } MvConv2dsDesc;
 int mv_conv2ds_forward(const MvConv2dsDesc* d, mv_stream_t stream);
 /* the first conv and the pooling with S16 maps on the map side */

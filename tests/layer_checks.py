@@ -288,7 +288,7 @@ def s16_merge(cdll, buf):
 
 
 def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, concat=False, epi=0, with_res=False, with_sum=False,
-                 lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, ring=0, wgs=0, spw=0, x_scale=1.0):
+                 lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, ring=0, wgs=0, spw=0, nprod=0, x_scale=1.0):
     """mv_conv2ds_forward (split-fp16 operands on S16 maps) against F.conv2d in fp64 on the SAME 22-bit inputs: the map round trip
     (split -> merge) is what the layer sees, so the bar is the fp32 one of conv2d_case."""
     g = torch.Generator().manual_seed(seed)
@@ -344,7 +344,7 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     d.y2, d.ldy2 = (y2.data_ptr() if with_sum else None), ldy
     d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
     d.lo, d.hi = lo, hi
-    d.nbw_hint, d.ct_hint, d.rows_hint, d.ring_hint, d.wgs_hint, d.spw_hint = nbw, ct, rows, ring, wgs, spw
+    d.nbw_hint, d.ct_hint, d.rows_hint, d.ring_hint, d.wgs_hint, d.spw_hint, d.nprod_hint = nbw, ct, rows, ring, wgs, spw, nprod
     _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(d), _stream(xad)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
@@ -401,6 +401,9 @@ CONV2DS_CASES = [
     dict(cin=64, cout=64, ks=3, H=24, W=40, B=2, ring=2, wgs=1),             # shortest ring, many tiles per workgroup
     dict(cin=96, cout=48, ks=1, H=30, W=40, B=2, ring=2, wgs=1),             # 1x1, a ring of two
     dict(cin=160, cout=48, ks=1, H=30, W=40, B=2, ring=3, wgs=1),            # 1x1, ring of three
+    dict(cin=64, cout=160, ks=3, H=10, W=20, B=1),                           # 10 blocks on four waves of <= 3 (3, 3, 2, 2), four producer waves
+    dict(cin=96, cout=192, ks=1, H=6, W=50, B=1, with_res=True),             # residual + short K: two blocks on six consumer waves, two producers
+    dict(cin=320, cout=192, ks=1, H=6, W=50, B=1, with_res=True),            # the same layer with four K stages ... and one more (12 blocks on 4 x 3)
     dict(cin=48, cout=48, ks=3, H=13, W=40, B=1, spw=8),                     # three blocks, the waves do not split the pixels
     dict(cin=32, cout=16, ks=1, H=9, W=50, B=1, spw=2, with_res=True),       # one block, four pixel groups
     dict(cin=32, cout=32, ks=3, H=11, W=30, B=1, spw=2, with_sum=True),      # two blocks, four pixel groups of two segments

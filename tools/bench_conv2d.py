@@ -81,24 +81,25 @@ for name, H, W, cin, cout, ks, stride, with_res in SHAPES:
     e.x, e.ldx, e.w, e.bias, e.oscale, e.y, e.ldy = xs.data_ptr(), cin, pks.data_ptr(), bias.data_ptr(), osc.value, ys.data_ptr(), cout
     e.res, e.ldres = (rs.data_ptr() if with_res else None), cout
     e.B, e.H, e.W, e.cin16, e.cout16, e.ks, e.stride, e.epi, e.lo, e.hi = B, H, W, cin, cout, ks, stride, 0, 0.0, 20.0
-    hints = [(0, 0, 0, 0, 0, 0)]   # nbw, ct, rows, ring, wgs, spw
+    hints = [(0, 0, 0, 0, 0, 0, 0)]   # nbw, ct, rows, ring, wgs, spw, nprod
     if os.environ.get('MV_BENCH_SWEEP') == '1':
-        hints += [(1, 0, 0, 0, 0, 0), (2, 0, 0, 0, 0, 0), (0, 0, 0, 0, 1, 0), (0, 0, 0, 0, 2, 0)]
+        if cout >= 128:
+            hints += [(2, 0, 0, 0, 0, 0, 2), (2, 0, 0, 0, 0, 0, 4), (3, 0, 0, 0, 0, 0, 4), (3, 0, 0, 0, 0, 0, 2)]
         if cout <= 64:
-            hints += [(1, 0, 0, 0, 0, 8), (1, 0, 0, 0, 0, 4), (1, 0, 0, 0, 0, 2)]
-        if ks == 3 and stride == 1:
-            hints += [(0, 0, 4, 0, 0, 0)]
+            hints += [(1, 0, 0, 0, 0, 8, 0), (1, 0, 0, 0, 0, 4, 0)]
+        if ks == 3 and stride == 1 and cout >= 128:
+            hints += [(0, 0, 4, 0, 0, 0, 0)]
     out = dict(layer=name, B=B, gflop=round(gflop, 1), mbytes=round(mbytes, 1), f32_us=round(t32, 1), f32_tflops=round(gflop / t32 * 1e3, 1))
-    for nbw, ct, rows, ring, wgs, spw in hints:
-        e.nbw_hint, e.ct_hint, e.rows_hint, e.ring_hint, e.wgs_hint, e.spw_hint = nbw, ct, rows, ring, wgs, spw
-        key = 'split' if (nbw, ct, rows, ring, wgs, spw) == (0, 0, 0, 0, 0, 0) else 'nbw%d_rows%d_ring%d_wgs%d_spw%d' % (nbw, rows, ring, wgs, spw)
+    for nbw, ct, rows, ring, wgs, spw, nprod in hints:
+        e.nbw_hint, e.ct_hint, e.rows_hint, e.ring_hint, e.wgs_hint, e.spw_hint, e.nprod_hint = nbw, ct, rows, ring, wgs, spw, nprod
+        key = 'split' if (nbw, ct, rows, ring, wgs, spw, nprod) == (0, 0, 0, 0, 0, 0, 0) else 'nbw%d_rows%d_spw%d_prod%d' % (nbw, rows, spw, nprod)
         try:
             ts = timed(lambda: _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(e), st()), cdll))
         except RuntimeError as ex:
             out[key] = 'n/a'
             continue
         out[key + '_us'] = round(ts, 1)
-        if (nbw, ct, rows, ring, wgs, spw) == (0, 0, 0, 0, 0, 0):
+        if (nbw, ct, rows, ring, wgs, spw, nprod) == (0, 0, 0, 0, 0, 0, 0):
             ym = torch.empty_like(ys)
             _hip.check(cdll.mv_map_merge_f32(ys.data_ptr(), ym.data_ptr(), ys.numel(), st()), cdll)
             torch.cuda.synchronize()

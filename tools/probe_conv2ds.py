@@ -93,7 +93,7 @@ def run():
         e.x, e.ldx, e.w, e.bias, e.oscale, e.y, e.ldy = xs.data_ptr(), cin, pks.data_ptr(), bias.data_ptr(), osc.value, ys.data_ptr(), cout
         e.res, e.ldres = (rs.data_ptr() if with_res else None), cout
         e.B, e.H, e.W, e.cin16, e.cout16, e.ks, e.stride, e.epi, e.lo, e.hi = B, H, W, cin, cout, ks, stride, 0, 0.0, 20.0
-        for k in ('nbw', 'rows', 'ring', 'wgs', 'spw'):
+        for k in ('nbw', 'rows', 'ring', 'wgs', 'spw', 'nprod'):
             setattr(e, k + '_hint', int(os.environ.get('MV_PROBE_' + k.upper(), '0')))
         for _ in range(2):
             _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(e), st()), cdll)

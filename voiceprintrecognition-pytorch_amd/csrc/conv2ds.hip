@@ -232,15 +232,13 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     const int ghi = (q >> 1) * 4 + (q & 1);
     const int nblk_total = a.cout16 >> 4;
     const int cgrp = wave / PG, useg0 = (wave - cgrp * PG) * SPW;   // channel group and first segment of this wave
-    const int blk0 = ct * a.CT + cgrp * NBW;                 // this wave's first block of 16 output channels
-    int nb = nblk_total - blk0;                              // blocks of this wave that exist
-    {
-        const int in_tile = a.CT - cgrp * NBW;
-        nb = nb < in_tile ? nb : in_tile;
-        nb = nb < NBW ? nb : NBW;
-        nb = nb > 0 ? nb : 0;
-    }
-    nb = MV_UNIFORM(nb);
+    // the blocks of this channel tile, spread evenly over its channel groups (10 blocks on 4 waves: 3, 3, 2, 2)
+    const int ncg = a.ncons / PG;
+    int tile_blocks = nblk_total - ct * a.CT;
+    tile_blocks = tile_blocks < a.CT ? tile_blocks : a.CT;
+    const int base_nb = tile_blocks / ncg, rem_nb = tile_blocks - base_nb * ncg;
+    const int blk0 = ct * a.CT + cgrp * base_nb + (cgrp < rem_nb ? cgrp : rem_nb);   // this wave's first block of 16 output channels
+    const int nb = MV_UNIFORM(base_nb + (cgrp < rem_nb ? 1 : 0));                     // ... and how many (<= NBW)
 
     // A fragments: lane (row j16 of a block, K group q) reads 16 bytes of hi and the 16 bytes 32 further of lo
     const int64_t wrow_halves = (int64_t)TAPS * a.wunits * 32;
@@ -264,9 +262,11 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         const int ch = c * KCH + j;
         return (int64_t)(ch < a.nchunks ? ch : a.nchunks - 1) * 64;
     };
-    // three register sets of weights: the set of step s is s % 3 (3x3: nine steps per stage, the roles are compile-time inside a stage);
-    // the request for step s + 2 goes into the set step s - 1 has left
-    half8v wh[3][NBW], wl[3][NBW];
+    // three register sets of weights: the set of step s is s % 3 (a stage has 9 or 3 steps, so it always starts on set 0 and the roles are
+    // compile-time inside it); the request for step s + 2 goes into the set step s - 1 has left.  (Two sets with three blocks per wave -- a step
+    // of 72 MFMAs covers an L2 round trip -- need the step sequence twice, once per stage parity: that form spilled 300 - 500 registers.)
+    constexpr int NSET = 3;
+    half8v wh[NSET][NBW], wl[NSET][NBW];
     int pc_c = 0, pc_j = 0;   // (stage, step) the next weight request is for
     auto request = [&](int set) __attribute__((always_inline)) {
         const int64_t off = a_offset(pc_c, pc_j);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                 // groups of G segments, the fragment reads of group g + 1 requested before the MFMAs of group g (the uniform branches on the
                 // segment count end basic blocks: left to the compiler every group waited for its own reads, r12w: 49 % of the MFMA rate in a stage)
                 constexpr int NG = SPW / G;
-                constexpr int NBUF = NBW >= 2 ? 2 : 1;   // (one block per wave: 4-segment groups, a second fragment set does not fit 168 registers)
+                constexpr int NBUF = 1;   // (requesting the reads of group g + 1 before the MFMAs of group g measured slower, r12x: 3x3 160 -> 160 81 -> 89 us)
                 half8v bh[NBUF][G], bl[NBUF][G];
                 auto read_group = [&](int u0, half8v (&rh)[G], half8v (&rl)[G]) __attribute__((always_inline)) {
 #pragma unroll
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         // ---------------- epilogue of the tile: D[channel 4q + r][pixel j16], in the scaled domain X = 64 * value ----------------
         // Batches of EB segments: all operand loads of a batch are requested before the first is used (clamped addresses instead of branches:
         // only the stores are predicated), so a tile pays the memory latency once per batch.
-        constexpr int EB0 = 4;
+        constexpr int EB0 = NBW <= 2 ? 4 : 1;   // (three blocks per wave: 253 registers with one segment's operands in flight)
         constexpr int EB = EB0 < SPW ? EB0 : SPW;
 #pragma unroll
         for (int u0 = 0; u0 < SPW; u0 += EB) {
@@ -489,17 +489,36 @@ int cs_rows(int Ho, int stride) {
 
 int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     const int nblk = d.cout16 / 16;
-    int nbw = d.nbw_hint;
-    if (nbw == 0) nbw = nblk <= 7 ? 1 : 2;
-    MV_REQUIRE(nbw >= 1 && nbw <= 2, "conv2ds: blocks per wave must be 1 or 2");
+    // Wave roles.  Up to 7 blocks: one block per consumer wave (<= 168 registers, 12 waves per CU).  From 8 blocks on: FOUR consumer waves -- one per
+    // SIMD, so no two of them share a matrix pipe (five or six waves leave one SIMD with twice the work: the barrier of a stage waits for it, r12w
+    // timeline) -- with the blocks of a channel tile of <= 12 spread evenly over them (2 or 3 per wave, <= 256 registers, 8 waves per CU), and four
+    // producer waves: one transfer costs a producer wave ~270 cycles, so two of them bound a 1x1 stage before the matrix pipe does (r12x timeline).
+    // ... except where the epilogue dominates: a layer with operands to read back (residual, second output, AFF) and few K stages per tile keeps
+    // two blocks per wave on up to six consumer waves (four segments' operands in flight per batch instead of one; such layers are HBM-bound and a
+    // second channel tile would read the input twice).
+    int nbw = d.nbw_hint, CT = d.ct_hint;
+    const int stages_per_tile = (int)ceil_div(ceil_div(d.cin16, 32), d.ks == 3 ? 1 : CS_KCH1);
+    const bool epilogue_bound = (d.res != nullptr || d.y2 != nullptr || d.epi == 2) && stages_per_tile <= 4;
+    if (nbw == 0) {
+        if (nblk <= 7) {
+            nbw = 1;
+        } else if (epilogue_bound) {
+            nbw = 2;
+        } else {
+            const int ctb = CT > 0 ? CT : (int)ceil_div(nblk, ceil_div(nblk, 12));
+            nbw = (int)ceil_div(ctb, 4);
+            nbw = nbw < 2 ? 2 : nbw;
+        }
+    }
+    MV_REQUIRE(nbw >= 1 && nbw <= 3, "conv2ds: blocks per wave must be 1..3");
     const int max_waves = nbw == 1 ? 12 : 8;        // 168 / 256 registers per lane
-    const int nprod_want = 2;
-    const int max_cons = nbw == 1 ? 8 : 6;
-    int CT = d.ct_hint;
+    const bool six = nbw == 2 && (epilogue_bound || d.nprod_hint == 2);   // six consumer + two producer waves
+    const int nprod_want = d.nprod_hint > 0 ? d.nprod_hint : (nbw == 1 || six ? 2 : 4);
+    const int max_cons = nbw == 1 ? 8 : max_waves - nprod_want;
     if (CT == 0) {
         const int cap = max_cons * nbw;
         const int ctiles = (int)ceil_div(nblk, cap);
-        CT = (int)round_up(ceil_div(nblk, ctiles), nbw);
+        CT = (int)ceil_div(nblk, ctiles);
     }
     MV_REQUIRE(CT >= 1 && ceil_div(CT, nbw) <= max_cons, "conv2ds: channel tile too wide");
     p->nbw = nbw;
@@ -538,7 +557,7 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     // workgroups per CU, producer waves, ring depth: two workgroups (r12o: 3x3 layers with few consumer waves gain 1.4 - 1.7 x from the second
     // workgroup's MFMAs under the first one's epilogue) while the waves and a ring of two fit twice -- with one producer wave if two do not fit --,
     // else one workgroup with the deepest ring (<= 4 stages, <= 48 transfers per wave in flight behind the awaited stage)
-    const int wave_cap = nbw == 2 ? 8 : (p->spw <= 2 ? 16 : 12);   // waves per CU at the variant's register count (<= 256 | <= 104 | <= 168 per lane)
+    const int wave_cap = nbw >= 2 ? 8 : (p->spw <= 2 ? 16 : 12);   // waves per CU at the variant's register count (<= 256 | <= 104 | <= 168 per lane)
     bool found = false;
     for (int wgs = 2; wgs >= 1 && !found; --wgs) {
         if (d.wgs_hint > 0 && wgs != d.wgs_hint) continue;
@@ -620,13 +639,15 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * Ho * Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
                                                 (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
     if (d.ks == 3) {
-        if (plan.nbw == 2) rc = cs_launch<3, 2, 8, 512>(a, plan, stream);
+        if (plan.nbw == 3) rc = cs_launch<3, 3, 8, 512>(a, plan, stream);
+        else if (plan.nbw == 2) rc = cs_launch<3, 2, 8, 512>(a, plan, stream);
         else if (plan.spw == 8) rc = cs_launch<3, 1, 8, 768>(a, plan, stream);
         else if (plan.spw == 4) rc = cs_launch<3, 1, 4, 768>(a, plan, stream);
         else if (plan.spw == 2) rc = cs_launch<3, 1, 2, 768>(a, plan, stream);
         else rc = cs_launch<3, 1, 1, 768>(a, plan, stream);
     } else {
-        if (plan.nbw == 2) rc = cs_launch<1, 2, 8, 512>(a, plan, stream);
+        if (plan.nbw == 3) rc = cs_launch<1, 3, 8, 512>(a, plan, stream);
+        else if (plan.nbw == 2) rc = cs_launch<1, 2, 8, 512>(a, plan, stream);
         else if (plan.spw == 8) rc = cs_launch<1, 1, 8, 768>(a, plan, stream);
         else if (plan.spw == 4) rc = cs_launch<1, 1, 4, 768>(a, plan, stream);
         else if (plan.spw == 2) rc = cs_launch<1, 1, 2, 768>(a, plan, stream);
