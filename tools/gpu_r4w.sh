@@ -18,4 +18,4 @@ for m in eres2netv2 eres2net; do
   timeout 300 python bench.py --model $m --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/bench_$m.log 2>&1; echo "$m rc=$?"; grep "^{" $OUT/bench_$m.log | cut -c1-330
 done
 timeout 300 python bench.py --model eres2netv2_w96s4 --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_w96s4_b64.log 2>&1; echo "w96s4 rc=$?"; grep "^{" $OUT/bench_w96s4_b64.log | cut -c1-330
-MV_BENCH_SHAPES="s3 3x3,s4 conv3" timeout 200 python tools/probe_conv2ds.py run 16 > $OUT/timeline.log 2>&1; grep -v "stage [2-9][0-9]\|occupancy\|workgroups" $OUT/timeline.log | head -50 | cut -c1-150
+MV_BENCH_SHAPES="s4 conv1" timeout 200 python tools/probe_conv2ds.py run 16 > $OUT/timeline.log 2>&1; grep -v "stage [2-9][0-9]\|occupancy\|workgroups" $OUT/timeline.log | head -50 | cut -c1-150
