@@ -198,7 +198,8 @@ int mv_eres2net_create(const MvEres2Cfg* cfg, const MvTensorRef* tensors, int32_
 int mv_model_destroy(MvModel* m);
 int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
 /* Model-specific facts (tests, logs).  Keys:
- *   MV_INFO_CAMPP_HEAD_F32     1.0 when the CAM++ handle evaluates its FCM head on fp32 maps (conv2d kernels), 0.0 for the fp16 head;
+ *   MV_INFO_CAMPP_HEAD_F32     1.0 when the CAM++ handle evaluates its FCM head in the exact form (since ABI 3: hi + lo fp16 operand pairs through the
+ *                              conv2ds kernels; before: fp32 maps through the conv2d kernels), 0.0 for the fp16 head;
  *   MV_INFO_CAMPP_CALIBRATION  largest 1 - cos between the embeddings of the two heads over the handle's three probe utterances
  *                              (mv_campp_create; -1 when MvCamppCfg.head_precision pinned the head);
  *   MV_INFO_CAMPP_PROBE0 + p   the figure of probe p = 0..2 (white uniform / white bell-shaped / smooth voiced-like). */
@@ -312,6 +313,8 @@ typedef struct MvConv2dsDesc {
     int32_t B, H, W, cin16, cout16, ks, stride, epi;
     float lo, hi;
     int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
+    int32_t stride_w;          /* stride along W when it differs from `stride` (then the stride along H); 0 = same (the CAM++ head strides the
+                                * frequency axis only, campplus.py:221-292) */
     int32_t nbw_hint, ct_hint, rows_hint, ring_hint, wgs_hint, spw_hint, nprod_hint; /* 0 = the launcher's choice; otherwise blocks of 16 output channels per wave
                                            * (1..3), blocks per workgroup, rows per 3x3 tile (1..8), LDS ring stages (>= 2), workgroups per CU
                                            * (1 | 2), segments per consumer wave (8 | 4 | 2 | 1), producer waves: launch shapes for tests and tools/bench_conv2d.py (never the bits of a result) */

@@ -287,7 +287,7 @@ def s16_merge(cdll, buf):
     return out.cpu()
 
 
-def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, concat=False, epi=0, with_res=False, with_sum=False,
+def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, stride_w=0, concat=False, epi=0, with_res=False, with_sum=False,
                  lo=0.0, hi=20.0, seed=0, nbw=0, ct=0, rows=0, ring=0, wgs=0, spw=0, nprod=0, x_scale=1.0):
     """mv_conv2ds_forward (split-fp16 operands on S16 maps) against F.conv2d in fp64 on the SAME 22-bit inputs: the map round trip
     (split -> merge) is what the layer sees, so the bar is the fp32 one of conv2d_case."""
@@ -302,7 +302,8 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     bn_scale = torch.rand(cout, generator=g) + 0.5
     bias = rn(cout) * 0.3
     p = ks // 2
-    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // stride + 1
+    sw = stride_w or stride
+    Ho, Wo = (H + 2 * p - ks) // stride + 1, (W + 2 * p - ks) // sw + 1
     c16 = r16(cout)
     ldy = c16 + 16
     res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
@@ -344,6 +345,7 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     d.y2, d.ldy2 = (y2.data_ptr() if with_sum else None), ldy
     d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi = B, H, W, r16(cin_k), c16, ks, stride, epi
     d.lo, d.hi = lo, hi
+    d.stride_w = stride_w
     d.nbw_hint, d.ct_hint, d.rows_hint, d.ring_hint, d.wgs_hint, d.spw_hint, d.nprod_hint = nbw, ct, rows, ring, wgs, spw, nprod
     _hip.check(cdll.mv_conv2ds_forward(ctypes.byref(d), _stream(xad)), cdll)
     if device != 'cpu':
@@ -353,7 +355,7 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     if concat:
         xin = torch.cat([xin, xb_q[..., :cin_a]], dim=-1)
     weff = (w * bn_scale.view(-1, 1, 1, 1)).double()
-    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias.double(), stride=stride, padding=p).permute(0, 2, 3, 1)
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), weff, bias.double(), stride=(stride, sw), padding=p).permute(0, 2, 3, 1)
     if epi == 0:
         if with_res:
             ref = ref + res_q[..., :cout]
@@ -408,7 +410,10 @@ CONV2DS_CASES = [
     dict(cin=32, cout=16, ks=1, H=9, W=50, B=1, spw=2, with_res=True),       # one block, four pixel groups
     dict(cin=32, cout=32, ks=3, H=11, W=30, B=1, spw=2, with_sum=True),      # two blocks, four pixel groups of two segments
     dict(cin=16, cout=16, ks=3, H=11, W=30, B=2, spw=1),                     # one block, eight waves of one segment
-    dict(cin=32, cout=32, ks=3, H=6, W=18, B=1, x_scale=100.0, hi=65504.0, lo=-65504.0),   # large activations (|x| up to ~450; the split saturates at 1023.5)
+    dict(cin=32, cout=32, ks=3, stride=2, stride_w=1, H=9, W=45, B=2, hi=65504.0),   # CAM++ head (exact form): stride on the frequency axis only
+    dict(cin=32, cout=32, ks=1, stride=2, stride_w=1, H=8, W=37, B=2, hi=65504.0, lo=-65504.0),  # its 1x1 shortcut conv
+    dict(cin=32, cout=32, ks=3, stride=2, stride_w=1, H=80, W=150, B=1, with_res=False, hi=65504.0),  # the head's first block at full height
+    dict(cin=32, cout=32, ks=3, H=6, W=18, B=1, x_scale=60.0, hi=65504.0, lo=-65504.0),    # large activations (|x| up to ~270, outputs up to ~600; the split saturates at 1023.5)
 ]
 
 

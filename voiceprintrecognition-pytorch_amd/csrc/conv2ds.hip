@@ -195,7 +195,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                         }
                     const int p = p0 + kk * 8 + psel;
                     unsigned pix = (unsigned)p;
-                    if (a.sh != 1) {  // uniform: strided 1x1 (first block of a stage)
+                    if (a.sh != 1 || a.sw != 1) {  // uniform: strided 1x1 (first block of a stage)
                         const int ho = p / a.Wo, wo = p - ho * a.Wo;
                         pix = (unsigned)(ho * a.sh * a.W + wo * a.sw);
                     }
@@ -605,6 +605,8 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     MV_REQUIRE(d.x != nullptr && d.w != nullptr && d.bias != nullptr && d.y != nullptr, "conv2ds: null pointer");
     MV_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0, "conv2ds: empty input");
     MV_REQUIRE((d.ks == 1 || d.ks == 3) && (d.stride == 1 || d.stride == 2), "conv2ds: kernel 1 or 3, stride 1 or 2");
+    MV_REQUIRE(d.stride_w == 0 || d.stride_w == 1 || d.stride_w == 2, "conv2ds: stride_w must be 0 (= stride), 1 or 2");
+    const int sw = d.stride_w == 0 ? d.stride : d.stride_w;
     MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2ds: channels must be padded to 16");
     MV_REQUIRE(d.ldx % 16 == 0 && d.ldy % 16 == 0, "conv2ds: leading dimensions must be multiples of 16 channels");
     MV_REQUIRE(d.x2 == nullptr || (d.cin1 > 0 && d.cin1 % 16 == 0 && d.cin1 < d.cin16 && d.ldx2 % 16 == 0), "conv2ds: concat split");
@@ -617,9 +619,9 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     MV_REQUIRE((int64_t)d.H * d.W * d.ldx < (int64_t)1 << 30 && (d.x2 == nullptr || (int64_t)d.H * d.W * d.ldx2 < (int64_t)1 << 30),
                "conv2ds: one utterance's map too large (4 GiB)");
     const int p = d.ks / 2;
-    const int Ho = (d.H + 2 * p - d.ks) / d.stride + 1, Wo = (d.W + 2 * p - d.ks) / d.stride + 1;
+    const int Ho = (d.H + 2 * p - d.ks) / d.stride + 1, Wo = (d.W + 2 * p - d.ks) / sw + 1;
     CsPlan plan;
-    int rc = cs_plan(d, Ho, Wo, d.stride, &plan);
+    int rc = cs_plan(d, Ho, Wo, sw, &plan);
     if (rc != MV_OK) return rc;
     Conv2dsArgs a;
     a.x = static_cast<const half_t*>(d.x); a.x2 = static_cast<const half_t*>(d.x2); a.w = static_cast<const half_t*>(d.w); a.bias = d.bias;
@@ -631,7 +633,7 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     a.nchunks = (a.cinu + 1) / 2;
     a.wunits = 2 * a.nchunks;
     a.cout16 = d.cout16;
-    a.B = d.B; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = d.stride; a.epi = d.epi;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = sw; a.epi = d.epi;
     a.lo = d.lo; a.hi = d.hi; a.oscale = d.oscale;
     a.R = plan.R; a.ncs = plan.ncs; a.tiles = plan.tiles; a.CT = plan.CT; a.ncons = plan.ncons; a.nprod = plan.nprod;
     a.pc = plan.pc; a.pcv = plan.pcv; a.pc_magic = plan.pc > 0 ? 65536 / plan.pc + 1 : 0;

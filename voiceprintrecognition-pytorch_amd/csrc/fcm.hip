@@ -8,6 +8,7 @@
 // whole kernel, each wave produces 32 positions x 32 maps.  The residual branch is fused: either the strided 1x1
 // shortcut conv (+BN) as a tenth tap on the block input, or the identity add in the epilogue, then ReLU.
 #include "kernels.h"
+#include "s16map.h"
 
 namespace mv {
 
@@ -392,6 +393,8 @@ __global__ __launch_bounds__(256) void fcm_band_kernel(FcmConvArgs a, int n_ttil
 }
 
 // fp32 head (campplus.hip): [B, F8, T, 32] fp32 -> [B, T, F8, 32] fp16; thread = 8 maps of one (b, f, t)
+// S16: the maps in the split-fp16 form of conv2ds.hip (s16map.h) instead of fp32
+template <bool S16>
 __global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* maps, half_t* rows, int64_t n8, int T, int F8) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
@@ -401,7 +404,15 @@ __global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* map
     p /= T;
     const int f = (int)(p % F8);
     const int64_t b = p / F8;
-    const float4v lo = *reinterpret_cast<const float4v*>(maps + i * 8), hi = *reinterpret_cast<const float4v*>(maps + i * 8 + 4);
+    float4v lo, hi;
+    if (S16) {   // eight channels c8 * 8 ... of a pixel: unit c8 / 2, quadruples 2 * (c8 & 1) and 2 * (c8 & 1) + 1
+        const half_t* unit = reinterpret_cast<const half_t*>(maps) + ((i >> 2) * 32 + (c8 >> 1) * 16) * 2 + (c8 & 1) * 8;
+        lo = s16_load4(unit);
+        hi = s16_load4(unit + 4);
+    } else {
+        lo = *reinterpret_cast<const float4v*>(maps + i * 8);
+        hi = *reinterpret_cast<const float4v*>(maps + i * 8 + 4);
+    }
     half8v o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -415,7 +426,15 @@ int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int 
     MV_REQUIRE(maps != nullptr && rows != nullptr && B > 0 && T > 0 && F8 > 0, "fcm_rows_from_f32: bad argument");
     const int64_t n8 = (int64_t)B * F8 * T * 4;
     MV_REQUIRE(ceil_div(n8, 256) < ((int64_t)1 << 31), "fcm_rows_from_f32: grid too large");
-    MV_LAUNCH(fcm_rows_from_f32_kernel, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, maps, rows, n8, T, F8);
+    MV_LAUNCH(fcm_rows_from_f32_kernel<false>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, maps, rows, n8, T, F8);
+    return check_launch("fcm_rows_from_f32_kernel");
+}
+
+int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream) {
+    MV_REQUIRE(maps != nullptr && rows != nullptr && B > 0 && T > 0 && F8 > 0, "fcm_rows_from_s16: bad argument");
+    const int64_t n8 = (int64_t)B * F8 * T * 4;
+    MV_REQUIRE(ceil_div(n8, 256) < ((int64_t)1 << 31), "fcm_rows_from_s16: grid too large");
+    MV_LAUNCH(fcm_rows_from_f32_kernel<true>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, reinterpret_cast<const float*>(maps), rows, n8, T, F8);
     return check_launch("fcm_rows_from_f32_kernel");
 }
 

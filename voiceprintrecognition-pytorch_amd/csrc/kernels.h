@@ -47,6 +47,8 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
                        hipStream_t stream);
 // fp32 head of CAM++: maps fp32 [B, F8, T, 32] -> the TDNN's input rows fp16 [B, T, F8, 32] (saturating at +-65504)
 int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int F8, hipStream_t stream);
+// the same from S16 maps (the split-fp16 head)
+int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream);
 // one BasicResBlock of the FCM head (campplus.py:221-254) as one launch, intermediate map kept in LDS (fcmblock.hip)
 bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin);
 // feats != nullptr (then x == nullptr, sf == 2): the block input is head.conv1 + bn1 + ReLU of the fp32 features [B, T, Fin], evaluated inside

@@ -66,7 +66,7 @@ class MvConv2dsDesc(ctypes.Structure):
                 ('oscale', c_f32), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64), ('add', c_vp),
                 ('ldadd', c_i64), ('y', c_vp), ('ldy', c_i64), ('y2', c_vp), ('ldy2', c_i64), ('B', c_i32), ('H', c_i32),
                 ('W', c_i32), ('cin16', c_i32), ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32),
-                ('lo', c_f32), ('hi', c_f32), ('cin_alg', c_i32), ('cout_alg', c_i32), ('nbw_hint', c_i32),
+                ('lo', c_f32), ('hi', c_f32), ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32), ('nbw_hint', c_i32),
                 ('ct_hint', c_i32), ('rows_hint', c_i32), ('ring_hint', c_i32), ('wgs_hint', c_i32), ('spw_hint', c_i32), ('nprod_hint', c_i32)]
 
 
