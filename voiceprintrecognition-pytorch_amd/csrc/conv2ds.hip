@@ -472,15 +472,23 @@ struct CsPlan {
     size_t lds;
 };
 
-// rows per 3x3 tile: the value in 4..8 that wastes the fewest rows (ties: the larger)
-int cs_rows(int Ho, int stride) {
+// Rows per 3x3 tile, by a cost model of one launch: rounds of tiles over the workgroup slots x cycles per tile.  A tile costs its K steps (the MFMAs of
+// the segments the wave computes -- whole groups of G -- at ~60 % of the issue rate plus ~300 cycles per step of reads, waits and requests), an
+// epilogue per row and a fixed part; few tall tiles leave CUs idle on small launches (16 x 20 x 75 at 160 channels: tiles of 4 rows 65 us, of 5 rows
+// 81 us, r12u), many flat ones pay the per-step overhead more often (16 x 10 x 38 at 320 channels: 4 rows 115 us, 5 rows 78 us).  Never changes bits.
+int cs_rows(int Ho, int stride, int64_t strips, int ctiles, int slots, int steps_per_tile, int nbw, int spw) {
     const int cap = stride == 2 ? 5 : CS_SEGS;   // (stride 2: 11 patch rows of 40 columns = 55 KiB per stage, a ring of two)
-    if (Ho <= cap) return Ho;
-    int best = cap, waste = (int)(ceil_div(Ho, cap) * cap - Ho);
-    for (int r = cap - 1; r >= (cap + 1) / 2; --r) {
-        const int w = (int)(ceil_div(Ho, r) * r - Ho);
-        if (w < waste) {
-            waste = w;
+    const int g = nbw >= 2 ? 2 : (spw < 4 ? spw : 4);
+    int best = 1;
+    double best_cost = 0.0;
+    for (int r = cap < Ho ? cap : Ho; r >= 1; --r) {
+        const int segs = (int)round_up((int64_t)ceil_div(r, CS_SEGS / spw), g);   // segments a consumer wave computes per step
+        const double step = segs * nbw * 3 * 16 / 0.6 + 300.0;
+        const double tile = steps_per_tile * step + r * nbw * 400.0 + 3000.0;
+        const int64_t tiles = ceil_div(Ho, r) * strips * ctiles;
+        const double cost = (double)ceil_div(tiles, slots) * tile;
+        if (best_cost == 0.0 || cost < best_cost * 0.9) {   // (ties and near-ties: the taller tile -- less patch overlap, and the model is coarse)
+            best_cost = cost;
             best = r;
         }
     }
@@ -539,7 +547,9 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     p->ncons = pg * cgroups;
     int stage;
     if (d.ks == 3) {
-        p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride);
+        const int64_t strips = (int64_t)d.B * ceil_div(Wo, 16);
+        const int steps_per_tile = (int)ceil_div(d.cin16, 32) * 9;
+        p->R = d.rows_hint > 0 ? d.rows_hint : cs_rows(Ho, d.stride, strips, p->ctiles, device_cu_count() * (p->ncons + nprod_want <= max_waves / 2 ? 2 : 1), steps_per_tile, nbw, p->spw);
         MV_REQUIRE(p->R >= 1 && p->R <= CS_SEGS, "conv2ds: rows per tile must be 1..8");
         p->ncs = (int)ceil_div(Wo, 16);
         p->tiles = (int)ceil_div(Ho, p->R) * p->ncs;
