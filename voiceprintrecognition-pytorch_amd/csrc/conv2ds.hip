@@ -15,7 +15,8 @@
 // that LDS-DMA moves without touching a register, and lane group q of an MFMA operand reads granule (q >> 1) * 4 + (q & 1) for its hi half
 // and the granule two further for lo.  Weights are packed the same way per (output channel, tap): [cout16][taps][2 * nchunks units][32].
 //
-// Kernel: workgroup = (utterance, pixel tile of 8 segments of 16 output pixels, tile of CT blocks of 16 output channels).
+// Kernel: persistent workgroups; a unit of work = (utterance, pixel tile of 8 segments of 16 output pixels) of one tile of CT <= 12 blocks of 16
+// output channels.
 //   3x3: the segments are R <= 8 consecutive rows of one 16-column strip, so the input patch is (R - 1) * stride + 3 rows of 15 * stride + 3
 //        (padded to a multiple of 8) columns -- 1.4 x the output pixels where a flat list of segments reads 3.4 x;
 //   1x1: 128 consecutive pixels of the flattened utterance plane (no column padding of narrow maps).
@@ -23,10 +24,14 @@
 //   of LDS slots (global_load_lds, zero padding and the channel concatenation of AFF = the source address of a granule); they wait for
 //   their own transfers and meet the consumers at one barrier per stage.  The CONSUMER waves split the output channels (NBW blocks each) and
 //   share the pixels: every wave reads the B fragments (pixels) of all 8 segments from LDS -- bank-conflict free through the granule ^ (entry & 7)
-//   swizzle applied on the source side -- and its own A fragments (weights) straight from global memory / L2, one step ahead, so no weight byte
-//   is fetched twice by a workgroup.  Accumulators: 8 x NBW x 4 registers.
-//   Epilogue: scale, bias, clamp [+ residual] | SiLU | AFF mix, optionally a second output  y2 = y + add  (the "sp + spx[i]" input of the next
-//   3x3 conv of a Res2Net block, eres2net.py:92, so that its loader stays a plain copy), split and stored as two 8-byte halves per lane.
+//   swizzle applied on the source side -- and its own A fragments (weights) straight from global memory / L2, two steps ahead in three rotating
+//   register sets, so no weight byte is fetched twice by a workgroup (layers with few output channels: two groups of consumer waves also split the
+//   pixels).  Accumulators: segments x NBW x 4 registers.
+//   Epilogue (in the scaled domain of the stored values): scale, bias, clamp [+ residual] | SiLU | AFF mix, optionally a second output
+//   y2 = y + add  (the "sp + spx[i]" input of the next 3x3 conv of a Res2Net block, eres2net.py:92, so that its loader stays a plain copy); operands
+//   requested per batch of segments, 16 bytes per lane in both directions (v_permlane16_swap trades the hi / lo halves between lane rows).
+//   Launch shapes (cs_plan below: blocks per wave, wave roles, rows per tile, ring depth, workgroups per CU) follow the layer; none changes a bit of
+//   the result -- every output element is the same K-ordered sum in every shape.
 #include <vector>
 
 #include "kernels.h"
@@ -332,39 +337,32 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                 }
                 const char* ph = cb + e0 * 128 + ((ghi ^ (e0 & 7)) << 4) + useg0 * seg_stride;
                 const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4) + useg0 * seg_stride;
-                // groups of G segments, the fragment reads of group g + 1 requested before the MFMAs of group g (the uniform branches on the
-                // segment count end basic blocks: left to the compiler every group waited for its own reads, r12w: 49 % of the MFMA rate in a stage)
+                // groups of G segments.  Every group waits for its own fragment reads (the uniform branches on the segment count end basic blocks):
+                // the MFMA phase of a stage runs at 50 - 60 % of the issue rate (r12w / r12y timelines).  Requesting the reads of group g + 1 before
+                // the MFMAs of group g measured slower (r12x: 3x3 160 -> 160 at 16 x 20 x 75 81 -> 89 us).
                 constexpr int NG = SPW / G;
-                constexpr int NBUF = 1;   // (requesting the reads of group g + 1 before the MFMAs of group g measured slower, r12x: 3x3 160 -> 160 81 -> 89 us)
-                half8v bh[NBUF][G], bl[NBUF][G];
-                auto read_group = [&](int u0, half8v (&rh)[G], half8v (&rl)[G]) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int u = 0; u < G; ++u) {
-                        rh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
-                        rl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
-                    }
-                };
-                if (NBUF == 2 && useg0 < nvalid) read_group(0, bh[0], bl[0]);  // uniform
+                half8v bh[G], bl[G];
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     const int u0 = gi * G;
-                    if (NBUF == 2 && gi + 1 < NG && useg0 + u0 + G < nvalid) read_group(u0 + G, bh[(gi + 1) % NBUF], bl[(gi + 1) % NBUF]);  // uniform
                     if (useg0 + u0 < nvalid) {  // uniform
-                        if (NBUF == 1) read_group(u0, bh[0], bl[0]);
-                        const half8v(&ch)[G] = bh[gi % NBUF];
-                        const half8v(&cl)[G] = bl[gi % NBUF];
+#pragma unroll
+                        for (int u = 0; u < G; ++u) {
+                            bh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
+                            bl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
+                        }
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], ch[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[u], acc[u0 + u][i], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], cl[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[u], acc[u0 + u][i], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], ch[u], acc[u0 + u][i], 0, 0, 0);
+                            for (int u = 0; u < G; ++u) acc[u0 + u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[u], acc[u0 + u][i], 0, 0, 0);
                     }
                 }
             }
