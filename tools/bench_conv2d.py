@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd')]
 import torch
 from mvector import _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-cdll = _hip.lib()
+cdll = _hip.bind(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else _hip.lib()   # (a probe / baseline build of the library for an A/B inside one call)
 st = lambda: _hip.current_stream(torch.empty(1, device='cuda'))
 r16 = lambda n: -(-n // 16) * 16
 # (name, H, W, cin, cout, ks, stride, with_res)

@@ -339,7 +339,8 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                 const char* pl = cb + e0 * 128 + (((ghi + 2) ^ (e0 & 7)) << 4) + useg0 * seg_stride;
                 // groups of G segments.  Every group waits for its own fragment reads (the uniform branches on the segment count end basic blocks):
                 // the MFMA phase of a stage runs at 50 - 60 % of the issue rate (r12w / r12y timelines).  Requesting the reads of group g + 1 before
-                // the MFMAs of group g measured slower (r12x: 3x3 160 -> 160 at 16 x 20 x 75 81 -> 89 us).
+                // the MFMAs of group g measured slower (r12x: 3x3 160 -> 160 at 16 x 20 x 75 81 -> 89 us), and so did a branch-free copy of this loop
+                // for full tiles that the scheduler interleaves by itself (r12ac, same call: 3x3 80 -> 80 75.5 -> 87 us, 16 -> 16 29 -> 32).
                 constexpr int NG = SPW / G;
                 half8v bh[G], bl[G];
 #pragma unroll
