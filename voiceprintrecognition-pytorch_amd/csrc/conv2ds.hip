@@ -537,9 +537,9 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     int pg = 1;
     if (nbw == 1 && 2 * cgroups <= max_cons) pg = 2;
     if (d.spw_hint > 0) {
-        MV_REQUIRE((d.spw_hint == 1 || d.spw_hint == 2 || d.spw_hint == 4 || d.spw_hint == 8) && (d.spw_hint == 8 || nbw == 1) &&
+        MV_REQUIRE((d.spw_hint == 1 || d.spw_hint == 2 || d.spw_hint == 4 || d.spw_hint == 8) && (d.spw_hint != 1 || nbw == 1) &&
                        (CS_SEGS / d.spw_hint) * cgroups <= max_cons,
-                   "conv2ds: segments per wave must be 1, 2, 4 or 8 (below 8: one block per wave, at most 8 consumer waves)");
+                   "conv2ds: segments per wave must be 8, 4, 2 (or 1 with one block per wave), consumer waves within the workgroup's limit");
         pg = CS_SEGS / d.spw_hint;
     }
     p->spw = CS_SEGS / pg;
@@ -649,21 +649,26 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     a.ns = plan.ns; a.pp = plan.pp; a.wg_per_ct = plan.wg_per_ct;
     const int prof = prof_begin(MV_PROF_CONV2D, 2.0 * d.B * Ho * Wo * (double)(d.cin_alg > 0 ? d.cin_alg : d.cin16) *
                                                 (d.cout_alg > 0 ? d.cout_alg : d.cout16) * d.ks * d.ks, stream);
-    if (d.ks == 3) {
-        if (plan.nbw == 3) rc = cs_launch<3, 3, 8, 512>(a, plan, stream);
-        else if (plan.nbw == 2) rc = cs_launch<3, 2, 8, 512>(a, plan, stream);
-        else if (plan.spw == 8) rc = cs_launch<3, 1, 8, 768>(a, plan, stream);
-        else if (plan.spw == 4) rc = cs_launch<3, 1, 4, 768>(a, plan, stream);
-        else if (plan.spw == 2) rc = cs_launch<3, 1, 2, 768>(a, plan, stream);
-        else rc = cs_launch<3, 1, 1, 768>(a, plan, stream);
-    } else {
-        if (plan.nbw == 3) rc = cs_launch<1, 3, 8, 512>(a, plan, stream);
-        else if (plan.nbw == 2) rc = cs_launch<1, 2, 8, 512>(a, plan, stream);
-        else if (plan.spw == 8) rc = cs_launch<1, 1, 8, 768>(a, plan, stream);
-        else if (plan.spw == 4) rc = cs_launch<1, 1, 4, 768>(a, plan, stream);
-        else if (plan.spw == 2) rc = cs_launch<1, 1, 2, 768>(a, plan, stream);
-        else rc = cs_launch<1, 1, 1, 768>(a, plan, stream);
-    }
+#define MV_CS_DISPATCH(KS)                                                                       \
+    do {                                                                                         \
+        if (plan.nbw == 3) {                                                                     \
+            if (plan.spw == 8) rc = cs_launch<KS, 3, 8, 512>(a, plan, stream);                   \
+            else if (plan.spw == 4) rc = cs_launch<KS, 3, 4, 512>(a, plan, stream);              \
+            else rc = cs_launch<KS, 3, 2, 512>(a, plan, stream);                                 \
+        } else if (plan.nbw == 2) {                                                              \
+            if (plan.spw == 8) rc = cs_launch<KS, 2, 8, 512>(a, plan, stream);                   \
+            else if (plan.spw == 4) rc = cs_launch<KS, 2, 4, 512>(a, plan, stream);              \
+            else rc = cs_launch<KS, 2, 2, 512>(a, plan, stream);                                 \
+        } else {                                                                                 \
+            if (plan.spw == 8) rc = cs_launch<KS, 1, 8, 768>(a, plan, stream);                   \
+            else if (plan.spw == 4) rc = cs_launch<KS, 1, 4, 768>(a, plan, stream);              \
+            else if (plan.spw == 2) rc = cs_launch<KS, 1, 2, 768>(a, plan, stream);              \
+            else rc = cs_launch<KS, 1, 1, 768>(a, plan, stream);                                 \
+        }                                                                                        \
+    } while (0)
+    if (d.ks == 3) MV_CS_DISPATCH(3);
+    else MV_CS_DISPATCH(1);
+#undef MV_CS_DISPATCH
     prof_end(prof, stream);
     if (rc != MV_OK) return rc;
     return check_launch("conv2ds_kernel");
