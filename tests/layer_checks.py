@@ -410,6 +410,8 @@ CONV2DS_CASES = [
     dict(cin=80, cout=80, ks=3, H=10, W=20, B=1, nbw=3, spw=4),              # five blocks as 3 + 2 on two pixel groups: four consumer waves
     dict(cin=32, cout=32, ks=3, H=11, W=30, B=2, nbw=2, spw=2),              # two blocks per wave, four pixel groups of two segments
     dict(cin=64, cout=64, ks=1, H=7, W=50, B=1, nbw=2, spw=4, with_res=True),  # 1x1: 2 x 2 blocks on two pixel groups
+    dict(cin=64, cout=32, ks=1, H=9, W=70, B=2),                             # 1x1 with two blocks and no operands: both blocks in each of four waves of two segments (the default)
+    dict(cin=80, cout=80, ks=3, H=12, W=30, B=1),                            # five blocks: the default is 2 + 2 + 1 on three consumer waves
     dict(cin=48, cout=48, ks=3, H=13, W=40, B=1, spw=8),                     # three blocks, the waves do not split the pixels
     dict(cin=32, cout=16, ks=1, H=9, W=50, B=1, spw=2, with_res=True),       # one block, four pixel groups
     dict(cin=32, cout=32, ks=3, H=11, W=30, B=1, spw=2, with_sum=True),      # two blocks, four pixel groups of two segments

@@ -506,8 +506,13 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     int nbw = d.nbw_hint, CT = d.ct_hint;
     const int stages_per_tile = (int)ceil_div(ceil_div(d.cin16, 32), d.ks == 3 ? 1 : CS_KCH1);
     const bool epilogue_bound = (d.res != nullptr || d.y2 != nullptr || d.epi == 2) && stages_per_tile <= 4;
+    const bool operands = d.res != nullptr || d.y2 != nullptr || d.epi == 2;
     if (nbw == 0) {
-        if (nblk <= 7) {
+        if (nblk == 5 && d.ks == 3) {
+            nbw = 2;   // (r12ag, 3x3 80 -> 80 at 16 x 40 x 149: three consumer waves of 2 + 2 + 1 blocks 66.5 us, five of one block 75)
+        } else if (nblk == 2 && d.ks == 1 && !operands) {
+            nbw = 2;   // (r12ag, 1x1 64 -> 32 at 16 x 80 x 298: both blocks in each of four waves of two segments 33.8 us, one block per wave 45)
+        } else if (nblk <= 7) {
             nbw = 1;
         } else if (epilogue_bound) {
             nbw = 2;
@@ -536,6 +541,7 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     // 4: 28.1, 2: 34.4, 1: 62 -- one segment per wave is a chain of dependent MFMAs)
     int pg = 1;
     if (nbw == 1 && 2 * cgroups <= max_cons) pg = 2;
+    if (nbw == 2 && nblk == 2 && d.ks == 1 && d.nbw_hint == 0) pg = 4;
     if (d.spw_hint > 0) {
         MV_REQUIRE((d.spw_hint == 1 || d.spw_hint == 2 || d.spw_hint == 4 || d.spw_hint == 8) && (d.spw_hint != 1 || nbw == 1) &&
                        (CS_SEGS / d.spw_hint) * cgroups <= max_cons,
