@@ -13,6 +13,13 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+// 12 bytes, as the device's global_load_dwordx3 (a host load of the 3-vector type would read 16)
+inline float3u load_f32x3(const float* p) {
+    float3u v;
+    memcpy(&v, p, 12);
+    return v;
+}
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 #define MV_LAUNCH(kernel, grid, block, shmem, stream, ...) emu::launch(dim3 grid, dim3 block, (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -1,5 +1,6 @@
 """Build tests/emu/build/libmvector_emu.so: the csrc/*.hip kernels compiled for the HOST against
 hip_emu.h (SIMT emulator).  Test infrastructure only -- see hip_emu.h."""
+import fcntl
 import glob
 import hashlib
 import os
@@ -13,7 +14,19 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
 def build(verbose=False):
+    # MV_EMU_SANITIZE=address: the same sources with AddressSanitizer (own build directory; the process that loads the library must have
+    # the sanitizer runtime preloaded -- tools/emu_check.py does that)
+    sanitize = os.environ.get('MV_EMU_SANITIZE', '')
+    assert sanitize in ('', 'address'), sanitize
+    OUT = os.path.join(HERE, 'build_asan' if sanitize else 'build')
+    extra = ['-fsanitize=address', '-shared-libsan', '-fno-omit-frame-pointer', '-g1'] if sanitize else ['-g0']
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'lock'), 'w') as lock:   # pytest-xdist workers arrive here together: one builds, the others find the stamp
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(OUT, extra, sanitize, verbose)
+
+
+def _build_locked(OUT, extra, sanitize, verbose):
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
     deps = srcs + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, 'hip_emu.h'), os.path.join(HERE, 'arch', 'gfx950.h'),
                                                                    os.path.join(ROOT, 'include', 'mvector_hip.h')]
@@ -29,7 +42,7 @@ def build(verbose=False):
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s) + '.o')
         # tests/emu in front of csrc on the include path: <arch/gfx950.h> resolves to the emulator's host spellings
-        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-I', HERE, '-I', CSRC, '-include',
+        cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-fPIC'] + extra + [ '-I', HERE, '-I', CSRC, '-include',
                os.path.join(HERE, 'hip_emu.h'), '-Wno-unused-value', '-c', s, '-o', o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
@@ -39,7 +52,7 @@ def build(verbose=False):
             raise RuntimeError('emu build failed:\n' + ' '.join(cmd) + '\n' + out.decode())
         if verbose and out:
             print(out.decode())
-    subprocess.check_call([CLANG, '-shared', '-o', lib] + objs)
+    subprocess.check_call([CLANG, '-shared', '-o', lib] + ([f'-fsanitize={sanitize}', '-shared-libsan'] if sanitize else []) + objs)
     open(stamp, 'w').write(h.hexdigest())
     return lib
 

@@ -13,8 +13,23 @@
 //   mfma_f32_32x32x16_f16 : A[i=lane&31][k=8*(lane>>5)+e], B[k][j=lane&31],
 //                           D[row=(r&3)+8*(r>>2)+4*(lane>>5)][col=lane&31]
 //   mfma_f32_16x16x4f32   : A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D as 16x16 above
+//
+// Checking modes (tools/emu_check.py drives them; the default suite runs the plain forward order):
+//   MV_EMU_SCHED = forward | reverse | waves-reverse | random:<seed>   order in which the threads of a block are resumed between
+//       barriers.  A thread runs until its next block / wave barrier, so a cross-thread dependency through LDS or global memory
+//       that no barrier orders (read-after-write or write-after-read) gives a wrong result in the forward or in the reverse
+//       order; the random orders (reshuffled at every sweep) add the mixed cases.  The tests' expected values are the detector.
+//   -fsanitize=address (build_emu.py, MV_EMU_SANITIZE=address): every global buffer is a heap block and the dynamic LDS of a
+//       block is a heap block of exactly the launch's size, so an index that leaves its buffer -- also one that a GPU page
+//       would silently absorb -- is reported; the fibers announce their stack switches to the sanitizer.
 #pragma once
 #include <ucontext.h>
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define MV_EMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -64,10 +79,12 @@ struct State {
     std::vector<int> wave_count;
     std::vector<int> wave_live;
     unsigned long progress = 0;
-    std::vector<char> dyn_smem;
+    char* dyn_smem = nullptr;            // the current block's dynamic LDS: its own heap block of exactly the launch's size, 64-byte aligned
     std::function<void()> body;
     // wave scratch for collectives: 64 lanes x 64 bytes x 2 operands
     std::vector<unsigned char> scratch;
+    const void* sched_stack = nullptr;   // (sanitizer builds) the scheduler's stack, learnt when the first fiber starts
+    size_t sched_stack_size = 0;
 };
 
 inline State& S() {
@@ -77,10 +94,28 @@ inline State& S() {
 
 static const size_t kStack = 256 * 1024;
 
-inline void yield() {
-    State& s = S();
-    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+// ---- stack switches, announced to AddressSanitizer when it is compiled in ----
+inline void to_fiber(State& s, Fiber& f);
+inline void fiber_entered(State& s) {
+#ifdef MV_EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &s.sched_stack, &s.sched_stack_size);
+#else
+    (void)s;
+#endif
 }
+inline void to_scheduler(State& s, bool last) {
+#ifdef MV_EMU_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(last ? nullptr : &fake, s.sched_stack, s.sched_stack_size);   // last: the fiber's fake stack is released
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+    (void)last;
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+#endif
+}
+
+inline void yield() { to_scheduler(S(), false); }
 
 inline int flat_tid() {
     State& s = S();
@@ -120,10 +155,70 @@ inline unsigned char* wave_slot(int operand, int lane) {
 
 inline void trampoline() {
     State& s = S();
+    fiber_entered(s);
     s.body();
     s.fibers[s.cur].done = true;
     s.progress++;
-    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+    to_scheduler(s, true);
+}
+
+inline void to_fiber(State& s, Fiber& f) {
+#ifdef MV_EMU_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, f.stack, kStack);
+    swapcontext(&s.sched, &f.ctx);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+    swapcontext(&s.sched, &f.ctx);
+#endif
+}
+
+// MV_EMU_SCHED (see the file header): the order of one sweep over the threads of a block
+struct SchedMode {
+    int kind = 0;   // 0 forward, 1 reverse, 2 waves-reverse, 3 random
+    unsigned long long seed = 0;
+};
+inline SchedMode sched_mode() {
+    SchedMode m;
+    const char* e = getenv("MV_EMU_SCHED");
+    if (e == nullptr || *e == 0 || strcmp(e, "forward") == 0) return m;
+    if (strcmp(e, "reverse") == 0) {
+        m.kind = 1;
+    } else if (strcmp(e, "waves-reverse") == 0) {
+        m.kind = 2;
+    } else if (strncmp(e, "random:", 7) == 0) {
+        m.kind = 3;
+        m.seed = strtoull(e + 7, nullptr, 10);
+    } else {
+        fprintf(stderr, "hip_emu: MV_EMU_SCHED=%s not understood (forward | reverse | waves-reverse | random:<seed>)\n", e);
+        abort();
+    }
+    return m;
+}
+inline void sweep_order(const SchedMode& m, int nthreads, unsigned long long salt, std::vector<int>& order) {
+    order.resize(nthreads);
+    for (int t = 0; t < nthreads; ++t) order[t] = t;
+    if (m.kind == 1) {
+        for (int t = 0; t < nthreads; ++t) order[t] = nthreads - 1 - t;
+    } else if (m.kind == 2) {
+        const int nwaves = (nthreads + 63) / 64;
+        int k = 0;
+        for (int w = nwaves - 1; w >= 0; --w)
+            for (int t = w * 64; t < nthreads && t < (w + 1) * 64; ++t) order[k++] = t;
+    } else if (m.kind == 3) {
+        unsigned long long x = (m.seed + 1) * 0x9E3779B97F4A7C15ull + salt * 0xBF58476D1CE4E5B9ull;
+        for (int t = nthreads - 1; t > 0; --t) {   // Fisher-Yates on a splitmix-style stream
+            x += 0x9E3779B97F4A7C15ull;
+            unsigned long long z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const int j = (int)(z % (unsigned long long)(t + 1));
+            const int tmp = order[t];
+            order[t] = order[j];
+            order[j] = tmp;
+        }
+    }
 }
 
 inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<void()> body) {
@@ -139,11 +234,20 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
         for (size_t i = old; i < s.fibers.size(); ++i) s.fibers[i].stack = (char*)malloc(kStack);
     }
     s.scratch.assign((size_t)nwaves * 2 * 64 * 64, 0);
+    const SchedMode mode = sched_mode();
+    std::vector<int> order;
+    unsigned long long sweep = 0;
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 s.blockIdx = emu_dim3(bx, by, bz);
-                s.dyn_smem.assign(shmem + 64, 0);
+                // (a fresh heap block of exactly shmem bytes per block: sanitizer builds see the end of the block's LDS, and nothing is
+                // inherited from the block before)
+                free(s.dyn_smem);
+                void* lds = nullptr;
+                if (posix_memalign(&lds, 64, shmem ? shmem : 1) != 0) abort();
+                memset(lds, 0, shmem ? shmem : 1);
+                s.dyn_smem = static_cast<char*>(lds);
                 s.bar_count = 0;
                 s.wave_gen.assign(nwaves, 0);
                 s.wave_count.assign(nwaves, 0);
@@ -162,11 +266,13 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
                 while (live > 0) {
                     unsigned long before = s.progress;
                     live = 0;
-                    for (int t = 0; t < s.nthreads; ++t) {
+                    sweep_order(mode, s.nthreads, sweep++, order);
+                    for (int k = 0; k < s.nthreads; ++k) {
+                        const int t = order[k];
                         if (s.fibers[t].done) continue;
                         s.cur = t;
                         s.threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                        swapcontext(&s.sched, &s.fibers[t].ctx);
+                        to_fiber(s, s.fibers[t]);
                         if (!s.fibers[t].done) live++;
                     }
                     if (live > 0 && s.progress == before) {
@@ -376,4 +482,4 @@ inline hipError_t hipGetDevice(int* d) {
     return 0;
 }
 
-#define MV_EMU_DYN_SMEM() (reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(emu::S().dyn_smem.data()) + 63) & ~uintptr_t(63)))
+#define MV_EMU_DYN_SMEM() (emu::S().dyn_smem)

@@ -1,0 +1,60 @@
+// Self-test of the emulator's checking modes (tests/emu/hip_emu.h header): two deliberately broken kernels show that the modes detect what
+// they are for.  TEST INFRASTRUCTURE ONLY; built and run by tests/test_emu_detectors.py.
+//   detectors race <barrier 0|1>   a cross-wave exchange through LDS; without the barrier the forward thread order happens to give the right
+//                                  answer (the producer thread runs first), the reverse order does not.  Prints the number of wrong values.
+//   detectors lds_oob <n>          reads one int n elements behind a 1 KiB dynamic LDS block (n = 0: the last element inside); the
+//                                  AddressSanitizer build must stop at n > 0.
+//   detectors global_oob <n>       the same behind a heap buffer of 256 ints.
+#include <arch/gfx950.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+__global__ void exchange_kernel(int* out, int with_barrier) {
+    MV_DYN_SMEM(smem);
+    int* v = reinterpret_cast<int*>(smem);
+    const int t = threadIdx.x;
+    v[t] = t + 1;
+    if (with_barrier) __syncthreads();
+    out[t] = t >= 64 ? v[t - 64] : v[t];   // the value of the same lane one wave below
+}
+
+__global__ void lds_read_kernel(int* out, int index) {
+    MV_DYN_SMEM(smem);
+    int* v = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) out[0] = v[index];
+}
+
+__global__ void global_read_kernel(const int* in, int* out, int index) {
+    if (threadIdx.x == 0) out[0] = in[index];
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    const int n = atoi(argv[2]);
+    if (strcmp(argv[1], "race") == 0) {
+        std::vector<int> out(256, 0);
+        int* outp = out.data();   // (the launch macro's closure copies what it names)
+        MV_LAUNCH(exchange_kernel, (1, 1, 1), (256, 1, 1), 256 * sizeof(int), nullptr, outp, n);
+        int wrong = 0;
+        for (int t = 0; t < 256; ++t) wrong += out[t] != (t >= 64 ? t - 64 : t) + 1;
+        printf("wrong=%d\n", wrong);
+        return 0;
+    }
+    int result = 0;
+    int* resp = &result;
+    if (strcmp(argv[1], "lds_oob") == 0) {
+        MV_LAUNCH(lds_read_kernel, (1, 1, 1), (64, 1, 1), 1024, nullptr, resp, 255 + n);
+    } else if (strcmp(argv[1], "global_oob") == 0) {
+        int* in = static_cast<int*>(malloc(256 * sizeof(int)));
+        memset(in, 0, 256 * sizeof(int));
+        MV_LAUNCH(global_read_kernel, (1, 1, 1), (64, 1, 1), 0, nullptr, in, resp, 255 + n);
+        free(in);
+    } else {
+        return 2;
+    }
+    printf("read=%d\n", result);
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""The emulator's checking modes detect what they are for (tests/emu/hip_emu.h header; tools/emu_check.py runs the whole emulator suite
+under them): a missing barrier that the forward thread order hides shows in the reverse / random orders, and the AddressSanitizer build
+stops at an index one element behind the dynamic LDS block or a global buffer."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, 'emu')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+SRC = os.path.join(EMU, 'selftest', 'detectors.cpp')
+
+
+def build(tmp_path, asan):
+    exe = str(tmp_path / ('detectors_asan' if asan else 'detectors'))
+    cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-I', EMU, '-include', os.path.join(EMU, 'hip_emu.h'), '-Wno-unused-value', SRC, '-o', exe]
+    if asan:
+        cmd[1:1] = ['-fsanitize=address', '-fno-omit-frame-pointer', '-g1']
+    subprocess.check_call(cmd)
+    return exe
+
+
+def run(exe, *args, sched=None):
+    env = dict(os.environ)
+    env.pop('MV_EMU_SCHED', None)
+    if sched:
+        env['MV_EMU_SCHED'] = sched
+    env['ASAN_OPTIONS'] = 'detect_leaks=0'
+    return subprocess.run([exe] + [str(a) for a in args], env=env, capture_output=True, text=True)
+
+
+@pytest.fixture(scope='module')
+def exe(tmp_path_factory):
+    return build(tmp_path_factory.mktemp('emu_detectors'), asan=False)
+
+
+@pytest.fixture(scope='module')
+def exe_asan(tmp_path_factory):
+    return build(tmp_path_factory.mktemp('emu_detectors_asan'), asan=True)
+
+
+def test_missing_barrier_is_hidden_by_the_forward_order_and_shown_by_the_others(exe):
+    assert run(exe, 'race', 0).stdout.strip() == 'wrong=0'              # the hidden race: producer threads happen to run first
+    assert run(exe, 'race', 0, sched='forward').stdout.strip() == 'wrong=0'
+    assert run(exe, 'race', 0, sched='reverse').stdout.strip() == 'wrong=192'
+    assert run(exe, 'race', 0, sched='waves-reverse').stdout.strip() == 'wrong=192'
+    wrong = [int(run(exe, 'race', 0, sched=f'random:{s}').stdout.strip().split('=')[1]) for s in (1, 2, 3)]
+    assert all(0 < w < 192 for w in wrong), wrong
+    for sched in (None, 'reverse', 'waves-reverse', 'random:1', 'random:2'):   # with the barrier every order is right
+        assert run(exe, 'race', 1, sched=sched).stdout.strip() == 'wrong=0'
+
+
+def test_unknown_schedule_is_refused(exe):
+    r = run(exe, 'race', 1, sched='sideways')
+    assert r.returncode != 0 and 'MV_EMU_SCHED' in r.stderr
+
+
+@pytest.mark.parametrize('what', ['lds_oob', 'global_oob'])
+def test_address_sanitizer_build_stops_one_element_behind_a_buffer(exe_asan, what):
+    ok = run(exe_asan, what, 0)
+    assert ok.returncode == 0 and ok.stdout.strip() == 'read=0', ok.stderr
+    bad = run(exe_asan, what, 1)
+    assert bad.returncode != 0 and 'heap-buffer-overflow' in bad.stderr, bad.stderr[-2000:]
+    for sched in ('reverse', 'random:1'):   # the fibers' stack switches are announced in every order
+        assert run(exe_asan, what, 0, sched=sched).returncode == 0

@@ -16,6 +16,9 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+// three consecutive floats at any 4-byte aligned address as ONE global_load_dwordx3 (12 bytes: nothing behind p[2] is touched)
+__device__ __forceinline__ float3u load_f32x3(const float* p) { return *reinterpret_cast<const float3u*>(p); }
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 #define MV_LAUNCH(kernel, grid, block, shmem, stream, ...) \

@@ -290,6 +290,10 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     // B fragments: entry e of the patch at e * 128, granule g at ((g ^ (e & 7)) << 4); rows of a 3x3 patch are a multiple of 8 entries
     // apart, so segment u is a constant further than segment 0
     const int seg_stride = KS == 3 ? a.sh * a.pc * 128 : 16 * 128;
+    // 3x3: the patch holds the rows of R segments.  A group of G segments that starts inside the tile may reach behind them (R = 5 in groups of
+    // two: segment 5) -- such a segment is never stored, and its fragment reads are pointed at the last one that exists, so that no read leaves
+    // the stage (in the last ring slot: the workgroup's LDS).  Relative to this wave's first segment; scalar.
+    const int seg_last = MV_UNIFORM((KS == 3 ? a.R : CS_SEGS) - 1 - useg0);
 
     float4v acc[SPW][NBW];
     int c = 0, tile_index = 0, slot_c = 0;
@@ -349,8 +353,9 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                     if (useg0 + u0 < nvalid) {  // uniform
 #pragma unroll
                         for (int u = 0; u < G; ++u) {
-                            bh[u] = *reinterpret_cast<const half8v*>(ph + (u0 + u) * seg_stride);
-                            bl[u] = *reinterpret_cast<const half8v*>(pl + (u0 + u) * seg_stride);
+                            const int su = KS == 3 && u0 + u > seg_last ? seg_last : u0 + u;   // uniform
+                            bh[u] = *reinterpret_cast<const half8v*>(ph + su * seg_stride);
+                            bl[u] = *reinterpret_cast<const half8v*>(pl + su * seg_stride);
                         }
 #pragma unroll
                         for (int i = 0; i < NBW; ++i)

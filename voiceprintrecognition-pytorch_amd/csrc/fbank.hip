@@ -459,7 +459,6 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     // they are.  (Loading the pair and the previous sample as separate values made the compiler merge them into the same
     // 12-byte load and then copy the components out right behind it: a full-latency wait directly after the prefetch was
     // issued, which is why prefetching showed no gain in r03c.)
-    typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
     auto load_quad = [&](int q, float3u (&r)[NG]) {
         const int f_raw = q * 4 + fs;
         const int f = f_raw < T ? f_raw : T - 1;  // surplus slots recompute the last frame; nothing of theirs is kept
@@ -476,7 +475,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
             // (one 12-byte load like every other lane: a lane-dependent {x[0], x[0], x[1]} assembled from two loads made the compiler copy
             // the components out right behind the prefetch, i.e. wait for it)
             const int jl = (n1 == 0 && j == 0) ? 1 : j;
-            r[n1] = *reinterpret_cast<const float3u*>(fp + jl - 1);
+            r[n1] = load_f32x3(fp + jl - 1);
         }
     };
     // The next quad's samples are requested as soon as this quad's have been consumed (window stage): their HBM latency runs
