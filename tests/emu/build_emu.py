@@ -17,9 +17,13 @@ def build(verbose=False):
     # MV_EMU_SANITIZE=address: the same sources with AddressSanitizer (own build directory; the process that loads the library must have
     # the sanitizer runtime preloaded -- tools/emu_check.py does that)
     sanitize = os.environ.get('MV_EMU_SANITIZE', '')
-    assert sanitize in ('', 'address'), sanitize
-    OUT = os.path.join(HERE, 'build_asan' if sanitize else 'build')
-    extra = ['-fsanitize=address', '-shared-libsan', '-fno-omit-frame-pointer', '-g1'] if sanitize else ['-g0']
+    assert sanitize in ('', 'address', 'undefined'), sanitize
+    OUT = os.path.join(HERE, {'': 'build', 'address': 'build_asan', 'undefined': 'build_ubsan'}[sanitize])
+    # undefined: the integer checks that matter for index arithmetic (alignment is left out: the device's vector loads need none)
+    checks = 'address' if sanitize == 'address' else 'signed-integer-overflow,shift,integer-divide-by-zero,bounds,null,float-cast-overflow'
+    extra = [f'-fsanitize={checks}', '-shared-libsan', '-fno-omit-frame-pointer', '-g1'] if sanitize else ['-g0']
+    if sanitize == 'undefined':
+        extra.append(f'-fno-sanitize-recover={checks}')
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, 'lock'), 'w') as lock:   # pytest-xdist workers arrive here together: one builds, the others find the stamp
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -52,7 +56,7 @@ def _build_locked(OUT, extra, sanitize, verbose):
             raise RuntimeError('emu build failed:\n' + ' '.join(cmd) + '\n' + out.decode())
         if verbose and out:
             print(out.decode())
-    subprocess.check_call([CLANG, '-shared', '-o', lib] + ([f'-fsanitize={sanitize}', '-shared-libsan'] if sanitize else []) + objs)
+    subprocess.check_call([CLANG, '-shared', '-o', lib] + ([e for e in extra if e.startswith('-fsanitize') or e == '-shared-libsan'] if sanitize else []) + objs)
     open(stamp, 'w').write(h.hexdigest())
     return lib
 

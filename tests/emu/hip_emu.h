@@ -19,6 +19,8 @@
 //       barriers.  A thread runs until its next block / wave barrier, so a cross-thread dependency through LDS or global memory
 //       that no barrier orders (read-after-write or write-after-read) gives a wrong result in the forward or in the reverse
 //       order; the random orders (reshuffled at every sweep) add the mixed cases.  The tests' expected values are the detector.
+//   MV_EMU_POISON = 1   a block's dynamic LDS and every hipMalloc block start as 0xFF bytes (NaN as fp16 / fp32, -1 as an integer) instead of
+//       zeros: on the device both hold what the previous owner left, so a result that depends on storage nobody wrote shows up as a NaN.
 //   -fsanitize=address (build_emu.py, MV_EMU_SANITIZE=address): every global buffer is a heap block and the dynamic LDS of a
 //       block is a heap block of exactly the launch's size, so an index that leaves its buffer -- also one that a GPU page
 //       would silently absorb -- is reported; the fibers announce their stack switches to the sanitizer.
@@ -221,6 +223,11 @@ inline void sweep_order(const SchedMode& m, int nthreads, unsigned long long sal
     }
 }
 
+inline int poison_byte() {
+    const char* e = getenv("MV_EMU_POISON");
+    return e != nullptr && *e == '1' ? 0xFF : 0;
+}
+
 inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<void()> body) {
     State& s = S();
     s.gridDim = grid;
@@ -246,7 +253,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
                 free(s.dyn_smem);
                 void* lds = nullptr;
                 if (posix_memalign(&lds, 64, shmem ? shmem : 1) != 0) abort();
-                memset(lds, 0, shmem ? shmem : 1);
+                memset(lds, poison_byte(), shmem ? shmem : 1);
                 s.dyn_smem = static_cast<char*>(lds);
                 s.bar_count = 0;
                 s.wave_gen.assign(nwaves, 0);
@@ -455,6 +462,7 @@ inline emu_float4 emu_mfma_f32_16x16x4f32(float a, float b, emu_float4 c) {
 // ---- tiny runtime shim (device memory == host memory) ---------------------------------------------
 inline hipError_t hipMalloc(void** p, size_t n) {
     *p = malloc(n ? n : 1);
+    if (*p && emu::poison_byte()) memset(*p, 0xFF, n ? n : 1);
     return *p ? 0 : 2;
 }
 inline hipError_t hipFree(void* p) {

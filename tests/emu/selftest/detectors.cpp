@@ -5,6 +5,7 @@
 //   detectors lds_oob <n>          reads one int n elements behind a 1 KiB dynamic LDS block (n = 0: the last element inside); the
 //                                  AddressSanitizer build must stop at n > 0.
 //   detectors global_oob <n>       the same behind a heap buffer of 256 ints.
+//   detectors uninit 0             reads dynamic LDS and a hipMalloc block that nobody wrote: zeros by default, -1 under MV_EMU_POISON=1.
 #include <arch/gfx950.h>
 
 #include <cstdio>
@@ -45,6 +46,14 @@ int main(int argc, char** argv) {
     }
     int result = 0;
     int* resp = &result;
+    if (strcmp(argv[1], "uninit") == 0) {
+        int* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), 1024) != hipSuccess) return 3;
+        MV_LAUNCH(lds_read_kernel, (1, 1, 1), (64, 1, 1), 1024, nullptr, resp, 17);
+        printf("lds=%d global=%d\n", result, fresh[17]);
+        hipFree(fresh);
+        return 0;
+    }
     if (strcmp(argv[1], "lds_oob") == 0) {
         MV_LAUNCH(lds_read_kernel, (1, 1, 1), (64, 1, 1), 1024, nullptr, resp, 255 + n);
     } else if (strcmp(argv[1], "global_oob") == 0) {

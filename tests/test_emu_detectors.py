@@ -21,9 +21,12 @@ def build(tmp_path, asan):
     return exe
 
 
-def run(exe, *args, sched=None):
+def run(exe, *args, sched=None, poison=False):
     env = dict(os.environ)
     env.pop('MV_EMU_SCHED', None)
+    env.pop('MV_EMU_POISON', None)
+    if poison:
+        env['MV_EMU_POISON'] = '1'
     if sched:
         env['MV_EMU_SCHED'] = sched
     env['ASAN_OPTIONS'] = 'detect_leaks=0'
@@ -64,3 +67,8 @@ def test_address_sanitizer_build_stops_one_element_behind_a_buffer(exe_asan, wha
     assert bad.returncode != 0 and 'heap-buffer-overflow' in bad.stderr, bad.stderr[-2000:]
     for sched in ('reverse', 'random:1'):   # the fibers' stack switches are announced in every order
         assert run(exe_asan, what, 0, sched=sched).returncode == 0
+
+
+def test_poison_mode_fills_unwritten_lds_and_device_blocks(exe):
+    assert run(exe, 'uninit', 0).stdout.strip() == 'lds=0 global=0'
+    assert run(exe, 'uninit', 0, poison=True).stdout.strip() == 'lds=-1 global=-1'

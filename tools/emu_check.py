@@ -1,12 +1,16 @@
 """Race / memory-safety sweep of the kernels on the SIMT emulator (no GPU): runs tests/test_emu_kernels.py -- every kernel family, the
 tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prints one summary line per mode.
 
-    python tools/emu_check.py                       # all modes: asan, reverse, waves-reverse, random:1, random:2
+    python tools/emu_check.py                       # all modes: asan, ubsan, poison, reverse, waves-reverse, random:1, random:2
     python tools/emu_check.py asan random:7         # chosen modes
     python tools/emu_check.py -k conv2ds asan       # a subset of the cases (pytest -k)
 
   asan            the emulator build with -fsanitize=address (tests/emu/build_asan): every global buffer and every block's dynamic LDS is a
                   heap block of exactly its size, so an index that leaves its buffer is reported -- also one the GPU would absorb silently.
+  ubsan           -fsanitize=signed-integer-overflow,shift,integer-divide-by-zero,bounds,null,float-cast-overflow (tests/emu/build_ubsan,
+                  no recovery): index and size arithmetic that overflows, on the host side and in the kernels.
+  poison          MV_EMU_POISON=1: dynamic LDS and hipMalloc blocks start as 0xFF bytes (NaN) instead of zeros -- a result that depends on
+                  storage nobody wrote (the device leaves the previous owner's bytes there) turns into a NaN.
   reverse | waves-reverse | random:<seed>
                   MV_EMU_SCHED: the order in which a block's threads run between barriers; a dependency no barrier orders gives a wrong result
                   in one of them and the tests' expected values catch it (tests/test_emu_detectors.py shows both detectors at work).
@@ -24,18 +28,27 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASAN_RT = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+UBSAN_RT = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so')
 
 
 def run_mode(mode, k, workers):
     env = dict(os.environ)
     env.pop('MV_EMU_SCHED', None)
     env.pop('MV_EMU_SANITIZE', None)
+    env.pop('MV_EMU_POISON', None)
     logdir = None
     if mode == 'asan':
         assert ASAN_RT, 'no AddressSanitizer runtime under /opt/rocm/lib/llvm'
         logdir = tempfile.mkdtemp(prefix='emu_asan_')
         env.update(MV_EMU_SANITIZE='address', LD_PRELOAD=ASAN_RT[0], ASAN_SYMBOLIZER_PATH='/opt/rocm/lib/llvm/bin/llvm-symbolizer',
                    ASAN_OPTIONS=f'detect_leaks=0:verify_asan_link_order=0:halt_on_error=1:log_path={logdir}/log')
+    elif mode == 'ubsan':
+        assert UBSAN_RT, 'no UndefinedBehaviorSanitizer runtime under /opt/rocm/lib/llvm'
+        logdir = tempfile.mkdtemp(prefix='emu_ubsan_')
+        env.update(MV_EMU_SANITIZE='undefined', LD_PRELOAD=UBSAN_RT[0], UBSAN_SYMBOLIZER_PATH='/opt/rocm/lib/llvm/bin/llvm-symbolizer',
+                   UBSAN_OPTIONS=f'print_stacktrace=1:halt_on_error=1:log_path={logdir}/log')
+    elif mode == 'poison':
+        env['MV_EMU_POISON'] = '1'
     else:
         env['MV_EMU_SCHED'] = mode
     # build first, in this process' environment (the workers then find the stamp)
@@ -55,18 +68,18 @@ def run_mode(mode, k, workers):
         sites = {}
         for f in glob.glob(os.path.join(logdir, 'log*')):
             for l in open(f):
-                if l.startswith('SUMMARY'):
+                if l.startswith('SUMMARY') or 'runtime error' in l:
                     sites[l.strip()] = sites.get(l.strip(), 0) + 1
         for s, n in sorted(sites.items()):
             print(f'    {n} x {s}')
         if not sites:
-            print('    no AddressSanitizer report')
+            print('    no sanitizer report')
     return r.returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('modes', nargs='*', default=['asan', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
+    ap.add_argument('modes', nargs='*', default=['asan', 'ubsan', 'poison', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
     ap.add_argument('-k', default='')
     ap.add_argument('-n', type=int, default=min(8, os.cpu_count() or 1))
     args = ap.parse_args()
