@@ -27,6 +27,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define MV_SET_MAX_SMEM(kernel, bytes) hipSuccess
 #define MV_WAVE_FENCE() emu::wave_sync()
 #define MV_LOCKSTEP_POINT() emu::wave_sync()
+#define MV_VM_LOADS(n) emu::dma_note(n)
 #define MV_AS_LDS(T, p) ((T*)(p))
 #define MV_AS_GLOBAL(T, p) ((T*)(p))
 #define MV_GLOBAL_PTR(T, p) reinterpret_cast<const T*>(p)
@@ -110,14 +111,14 @@ inline lds_half_ptr lds_opaque_half_ptr(const half_t* p) { return p; }
 inline half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *reinterpret_cast<const half8v*>(p + elem_off); }
 inline void glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16); }
 template <int N>
-inline void wait_vm() {}
-inline void lds_barrier() { __syncthreads(); }
-inline void barrier_only() { __syncthreads(); }
+inline void wait_vm() { emu::dma_retire(N); }
+inline void lds_barrier() { emu::syncthreads(); }   // (no drain of transfers in flight: s_waitcnt lgkmcnt(0) + s_barrier)
+inline void barrier_only() { emu::syncthreads(); }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
-    memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc, 16);
+    emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc);
 }
 inline void glds16_untracked_so(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
-    memcpy(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(sbase) + voff, 16);
+    emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(sbase) + voff);
 }
 inline void lds_read1(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr)); }
 template <int N>

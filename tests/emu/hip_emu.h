@@ -21,6 +21,15 @@
 //       order; the random orders (reshuffled at every sweep) add the mixed cases.  The tests' expected values are the detector.
 //   MV_EMU_POISON = 1   a block's dynamic LDS and every hipMalloc block start as 0xFF bytes (NaN as fp16 / fp32, -1 as an integer) instead of
 //       zeros: on the device both hold what the previous owner left, so a result that depends on storage nobody wrote shows up as a NaN.
+//   MV_EMU_DMA = lazy | lazy-sync   the untracked LDS-DMA transfers (glds16_untracked*: global_load_lds the compiler does not see, ordered by the
+//       kernels' own counted s_waitcnt vmcnt) land as LATE as the hardware allows: the source is read at issue, the 16 bytes reach LDS only when
+//       the issuing thread's wait_vm<N>() retires them (the N youngest stay in flight; in order, as the counter is) -- never otherwise.  A
+//       fragment read that no counted wait + barrier covers sees the slot's old (or poisoned) content.  The default -- every transfer lands at
+//       issue -- is the other extreme (a slot refilled while it is still being read).  lazy: __syncthreads() retires nothing (only counted
+//       waits do); lazy-sync: __syncthreads() also drains the calling thread's transfers (the fence in front of the barrier).  Conservative where
+//       a wave mixes these transfers with other vector-memory operations (those are not counted here, so fewer transfers count as landed than on
+//       the device) -- a failure in this mode is a lead to check against the ISA, not a verdict.
+//       Where a kernel's counted wait includes tracked loads, the source says so with MV_VM_LOADS(n) and they are counted here too.
 //   -fsanitize=address (build_emu.py, MV_EMU_SANITIZE=address): every global buffer is a heap block and the dynamic LDS of a
 //       block is a heap block of exactly the launch's size, so an index that leaves its buffer -- also one that a GPU page
 //       would silently absorb -- is reported; the fibers announce their stack switches to the sanitizer.
@@ -63,10 +72,17 @@ typedef void* hipStream_t;
 
 namespace emu {
 
+struct PendingDma {
+    char* dst;
+    unsigned char data[16];
+};
+
 struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
+    std::vector<PendingDma> dma;   // MV_EMU_DMA=lazy: this thread's transfers in flight, oldest first from dma_head
+    size_t dma_head = 0;
 };
 
 struct State {
@@ -85,6 +101,7 @@ struct State {
     std::function<void()> body;
     // wave scratch for collectives: 64 lanes x 64 bytes x 2 operands
     std::vector<unsigned char> scratch;
+    int dma_mode = 0;
     const void* sched_stack = nullptr;   // (sanitizer builds) the scheduler's stack, learnt when the first fiber starts
     size_t sched_stack_size = 0;
 };
@@ -124,6 +141,46 @@ inline int flat_tid() {
     return s.threadIdx.x + s.blockDim.x * (s.threadIdx.y + s.blockDim.y * s.threadIdx.z);
 }
 
+// ---- MV_EMU_DMA (see the file header) ----
+inline int dma_mode() {   // 0 eager, 1 lazy, 2 lazy-sync
+    const char* e = getenv("MV_EMU_DMA");
+    if (e == nullptr || *e == 0 || strcmp(e, "eager") == 0) return 0;
+    if (strcmp(e, "lazy") == 0) return 1;
+    if (strcmp(e, "lazy-sync") == 0) return 2;
+    fprintf(stderr, "hip_emu: MV_EMU_DMA=%s not understood (eager | lazy | lazy-sync)\n", e);
+    abort();
+}
+inline void dma_retire(size_t keep) {   // all but the `keep` youngest transfers of the calling thread land, oldest first
+    Fiber& f = S().fibers[S().cur];
+    while (f.dma.size() - f.dma_head > keep) {
+        const PendingDma& p = f.dma[f.dma_head++];
+        if (p.dst != nullptr) memcpy(p.dst, p.data, 16);
+    }
+    if (f.dma_head == f.dma.size()) {
+        f.dma.clear();
+        f.dma_head = 0;
+    }
+}
+inline void dma_issue(char* dst, const void* src) {
+    State& s = S();
+    if (s.dma_mode == 0) {
+        memcpy(dst, src, 16);
+        return;
+    }
+    PendingDma p;
+    p.dst = dst;
+    memcpy(p.data, src, 16);
+    s.fibers[s.cur].dma.push_back(p);
+}
+
+inline void dma_note(int n) {   // MV_VM_LOADS: n tracked loads take their places in the counter's order
+    State& s = S();
+    if (s.dma_mode == 0) return;
+    PendingDma p;
+    p.dst = nullptr;
+    for (int i = 0; i < n; ++i) s.fibers[s.cur].dma.push_back(p);
+}
+
 inline void syncthreads() {
     State& s = S();
     unsigned long gen = s.bar_gen;
@@ -159,6 +216,7 @@ inline void trampoline() {
     State& s = S();
     fiber_entered(s);
     s.body();
+    // (transfers a thread leaves in flight when it ends are dropped, not landed: LDS dies with the block, and nobody may have counted on them)
     s.fibers[s.cur].done = true;
     s.progress++;
     to_scheduler(s, true);
@@ -242,6 +300,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
     }
     s.scratch.assign((size_t)nwaves * 2 * 64 * 64, 0);
     const SchedMode mode = sched_mode();
+    s.dma_mode = dma_mode();
     std::vector<int> order;
     unsigned long long sweep = 0;
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -263,6 +322,8 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
                 for (int t = 0; t < s.nthreads; ++t) {
                     Fiber& f = s.fibers[t];
                     f.done = false;
+                    f.dma.clear();
+                    f.dma_head = 0;
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = kStack;
@@ -311,7 +372,10 @@ inline T shfl_from(T v, int src_lane) {
 #define gridDim (emu::S().gridDim)
 #define warpSize 64
 
-inline void __syncthreads() { emu::syncthreads(); }
+inline void __syncthreads() {
+    if (emu::S().dma_mode == 2) emu::dma_retire(0);
+    emu::syncthreads();
+}
 
 template <typename T>
 inline T __shfl_xor(T v, int mask, int width = 64) {

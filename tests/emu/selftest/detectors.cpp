@@ -5,6 +5,9 @@
 //   detectors lds_oob <n>          reads one int n elements behind a 1 KiB dynamic LDS block (n = 0: the last element inside); the
 //                                  AddressSanitizer build must stop at n > 0.
 //   detectors global_oob <n>       the same behind a heap buffer of 256 ints.
+//   detectors dma <waited 0|1>     wave 0 fetches 1 KiB into LDS with an untracked LDS-DMA transfer and every wave reads it behind an LDS-only
+//                                  barrier; without the counted wait the default emulator (transfers land at issue) still gives the right
+//                                  answer, MV_EMU_DMA=lazy does not.  Prints the number of wrong values.
 //   detectors uninit 0             reads dynamic LDS and a hipMalloc block that nobody wrote: zeros by default, -1 under MV_EMU_POISON=1.
 #include <arch/gfx950.h>
 
@@ -20,6 +23,17 @@ __global__ void exchange_kernel(int* out, int with_barrier) {
     v[t] = t + 1;
     if (with_barrier) __syncthreads();
     out[t] = t >= 64 ? v[t - 64] : v[t];   // the value of the same lane one wave below
+}
+
+__global__ void dma_kernel(const int* src, int* out, int waited) {
+    MV_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        mv::glds16_untracked(reinterpret_cast<const char*>(src) + lane * 16, mv::lds_addr(smem));
+        if (waited) mv::wait_vm<0>();
+    }
+    mv::lds_barrier();
+    out[threadIdx.x] = reinterpret_cast<const int*>(smem)[threadIdx.x];
 }
 
 __global__ void lds_read_kernel(int* out, int index) {
@@ -41,6 +55,17 @@ int main(int argc, char** argv) {
         MV_LAUNCH(exchange_kernel, (1, 1, 1), (256, 1, 1), 256 * sizeof(int), nullptr, outp, n);
         int wrong = 0;
         for (int t = 0; t < 256; ++t) wrong += out[t] != (t >= 64 ? t - 64 : t) + 1;
+        printf("wrong=%d\n", wrong);
+        return 0;
+    }
+    if (strcmp(argv[1], "dma") == 0) {
+        std::vector<int> src(256), out(256, 0);
+        for (int t = 0; t < 256; ++t) src[t] = 1000 + t;
+        const int* srcp = src.data();
+        int* outp = out.data();
+        MV_LAUNCH(dma_kernel, (1, 1, 1), (256, 1, 1), 1024, nullptr, srcp, outp, n);
+        int wrong = 0;
+        for (int t = 0; t < 256; ++t) wrong += out[t] != 1000 + t;
         printf("wrong=%d\n", wrong);
         return 0;
     }

@@ -21,8 +21,11 @@ def build(tmp_path, asan):
     return exe
 
 
-def run(exe, *args, sched=None, poison=False):
+def run(exe, *args, sched=None, poison=False, dma=None):
     env = dict(os.environ)
+    env.pop('MV_EMU_DMA', None)
+    if dma:
+        env['MV_EMU_DMA'] = dma
     env.pop('MV_EMU_SCHED', None)
     env.pop('MV_EMU_POISON', None)
     if poison:
@@ -72,3 +75,13 @@ def test_address_sanitizer_build_stops_one_element_behind_a_buffer(exe_asan, wha
 def test_poison_mode_fills_unwritten_lds_and_device_blocks(exe):
     assert run(exe, 'uninit', 0).stdout.strip() == 'lds=0 global=0'
     assert run(exe, 'uninit', 0, poison=True).stdout.strip() == 'lds=-1 global=-1'
+
+
+def test_missing_counted_wait_is_hidden_by_eager_transfers_and_shown_by_lazy_ones(exe):
+    assert run(exe, 'dma', 0).stdout.strip() == 'wrong=0'                       # the default: every transfer lands at issue
+    assert run(exe, 'dma', 0, dma='lazy').stdout.strip() == 'wrong=256'         # as late as the hardware allows: nothing has landed
+    assert run(exe, 'dma', 0, dma='lazy', sched='reverse').stdout.strip() == 'wrong=256'
+    for dma in (None, 'lazy', 'lazy-sync'):
+        assert run(exe, 'dma', 1, dma=dma).stdout.strip() == 'wrong=0'          # with wait_vm<0>() in front of the barrier
+    r = run(exe, 'dma', 1, dma='sometimes')
+    assert r.returncode != 0 and 'MV_EMU_DMA' in r.stderr

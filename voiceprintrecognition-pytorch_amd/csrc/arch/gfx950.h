@@ -41,6 +41,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 // point at which lanes of one wave hand data to each other through LDS without a barrier: the lanes of a wave run in lockstep, so
 // there is nothing to do (the test-suite's SIMT emulator runs lanes as fibres and makes them meet here)
 #define MV_LOCKSTEP_POINT() do { } while (0)
+// "n compiler-tracked vector-memory loads of this wave were just issued, and a counted wait_vm<N>() further down includes them in its N":
+// nothing to do on the device (the counter counts them by itself); the test-suite's emulator counts them beside the untracked transfers
+#define MV_VM_LOADS(n) do { } while (0)
 #define MV_AS_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define MV_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define MV_GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 const int row = (cw * 2 + mi) * 16 + fr;
                 dst[kk][mi] = *MV_GLOBAL_PTR(half8v, wj + ((int64_t)row * a.k + tap) * a.kpad + c0 + (kk * 4 + fg) * 8);
             }
+        MV_VM_LOADS(4);   // (the direct form's r2_wait_vm<4>() behind the last stage counts these four)
     };
     // weight fragments of the stage that runs `ahead` stages after stage s of step j (possibly in the next step; nothing after the last)
     auto load_ahead = [&](int j, int s, half8v (&dst)[2][2]) {
