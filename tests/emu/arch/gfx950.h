@@ -109,7 +109,9 @@ inline const char* lds_ptr(unsigned addr) { return MV_EMU_DYN_SMEM() + addr; }
 typedef const half_t* lds_half_ptr;
 inline lds_half_ptr lds_opaque_half_ptr(const half_t* p) { return p; }
 inline half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *reinterpret_cast<const half8v*>(p + elem_off); }
-inline void glds16(const void* gsrc, char* lds_wave_base) { memcpy(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc, 16); }
+// (the compiler-tracked transfer: cross-wave visibility is the kernel's business too -- a counted wait in front of the barrier -- so the lazy
+// mode queues it like the untracked ones)
+inline void glds16(const void* gsrc, char* lds_wave_base) { emu::dma_issue(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc); }
 template <int N>
 inline void wait_vm() { emu::dma_retire(N); }
 inline void lds_barrier() { emu::syncthreads(); }   // (no drain of transfers in flight: s_waitcnt lgkmcnt(0) + s_barrier)

@@ -1,7 +1,7 @@
 """Race / memory-safety sweep of the kernels on the SIMT emulator (no GPU): runs tests/test_emu_kernels.py -- every kernel family, the
 tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prints one summary line per mode.
 
-    python tools/emu_check.py                       # all modes: asan, ubsan, poison, lazy-dma, reverse, waves-reverse, random:1, random:2
+    python tools/emu_check.py                       # all modes: asan, ubsan, poison, lazy-dma, lazy-dma+reverse, reverse, waves-reverse, random:1, random:2
     python tools/emu_check.py asan random:7         # chosen modes
     python tools/emu_check.py -k conv2ds asan       # a subset of the cases (pytest -k)
 
@@ -11,7 +11,8 @@ tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prin
                   no recovery): index and size arithmetic that overflows, on the host side and in the kernels.
   poison          MV_EMU_POISON=1: dynamic LDS and hipMalloc blocks start as 0xFF bytes (NaN) instead of zeros -- a result that depends on
                   storage nobody wrote (the device leaves the previous owner's bytes there) turns into a NaN.
-  lazy-dma        MV_EMU_DMA=lazy (+ poison): the untracked LDS-DMA transfers land as late as the kernels' counted s_waitcnt vmcnt allow (the N
+  lazy-dma[+<order>]
+                  MV_EMU_DMA=lazy (+ poison, optionally with a thread order): the LDS-DMA transfers land as late as the kernels' counted s_waitcnt vmcnt allow (the N
                   youngest of a wait_vm<N>() stay in flight, only counted waits retire anything) -- a fragment read that no counted wait +
                   barrier covers sees NaNs.  The default emulator lets every transfer land at issue (the other extreme).
   reverse | waves-reverse | random:<seed>
@@ -55,9 +56,11 @@ def run_mode(mode, k, workers, slow):
                    UBSAN_OPTIONS=f'print_stacktrace=1:halt_on_error=1:log_path={logdir}/log')
     elif mode == 'poison':
         env['MV_EMU_POISON'] = '1'
-    elif mode == 'lazy-dma':
+    elif mode.startswith('lazy-dma'):   # lazy-dma | lazy-dma+reverse | lazy-dma+random:<seed>
         env['MV_EMU_POISON'] = '1'
         env['MV_EMU_DMA'] = 'lazy'
+        if '+' in mode:
+            env['MV_EMU_SCHED'] = mode.split('+', 1)[1]
     else:
         env['MV_EMU_SCHED'] = mode
     # build first, in this process' environment (the workers then find the stamp)
@@ -88,7 +91,7 @@ def run_mode(mode, k, workers, slow):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('modes', nargs='*', default=['asan', 'ubsan', 'poison', 'lazy-dma', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
+    ap.add_argument('modes', nargs='*', default=['asan', 'ubsan', 'poison', 'lazy-dma', 'lazy-dma+reverse', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
     ap.add_argument('-k', default='')
     ap.add_argument('--slow', action='store_true', help='also the cases behind MV_SLOW_EMU=1 (CAM++ end to end, the largest conv2d cases)')
     ap.add_argument('-n', type=int, default=min(8, os.cpu_count() or 1))
