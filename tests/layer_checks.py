@@ -847,7 +847,7 @@ def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=N
     else:
         cfg = _hip.MvCamppCfg()
         cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 512)
-        cfg.growth_rate, cfg.bn_size, cfg.init_channels = 32, 4, 128
+        cfg.growth_rate, cfg.bn_size, cfg.init_channels = kw.get('growth_rate', 32), kw.get('bn_size', 4), kw.get('init_channels', 128)
         cfg.head_precision = head   # MV_CAMPP_HEAD_AUTO (0) / _F16 (1) / _F32 (2)
         kind = 'campp'
     sd_dev = {k: v.to(device) for k, v in sd.items()}

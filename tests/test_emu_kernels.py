@@ -187,6 +187,14 @@ def test_emu_campp_short_end_to_end():
     assert info[1] == 1.0 and cd32 < 1e-5
 
 
+@pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~50 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_native_model_matches_reference_golden[campp_c64])')
+def test_emu_campp_64_initial_channels_runs_the_per_layer_dense_kernel():
+    """CAMPPlus(init_channels=64): block 1 is 64 -> 448 channels wide, below what cam_dense_block_kernel takes, so its twelve layers run
+    cam_dense_layer_kernel (camdense.hip); blocks 2 / 3 (224 -> 992, 496 -> 1008: channel counts that are no multiples of 64) the block kernel"""
+    cd, rel = lc.model_case(emu_cdll(), 'cpu', 'campp_c64', head=1)
+    assert cd < 2e-5 and rel < 1e-2, (cd, rel)
+
+
 def test_emu_melspec_fft_kernel_and_dft_kernel():
     """default geometry (n_fft 400, 128 mels) = melspec_tile_kernel: edge frames with reflect padding, a masked row, feature
     rows beyond the LDS block (T = 241 > 212 rows) and fewer; every n_fft that is neither 400 nor a power of two runs the dense-DFT kernels"""

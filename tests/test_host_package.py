@@ -16,7 +16,7 @@ from oracle import frontend, models as omodels, scoring
 FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
-@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'campp', 'tdnn', 'eres2net_tiny',
+@pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_c1024', 'ecapa_mel128', 'campp', 'campp_c64', 'tdnn', 'eres2net_tiny',
                                   'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32', 'eres2netv2_w96s4'])
 def test_state_dict_layout_equals_reference_manifest(case):
     import mvector.models as M

@@ -14,7 +14,7 @@ FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
 @pytest.mark.parametrize('case', ['ecapa_tiny', 'ecapa_c512', 'ecapa_mel128', 'campp_short', 'tdnn', 'eres2net_tiny',
-                                  'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32', 'eres2netv2_w96s4', 'ecapa_stress', 'campp_stress', 'campp_mid_a', 'campp_mid_b'])
+                                  'eres2netv2_tiny', 'eres2net_m32', 'eres2netv2_m32', 'eres2netv2_w96s4', 'ecapa_stress', 'campp_stress', 'campp_mid_a', 'campp_mid_b', 'campp_c64'])
 def test_oracle_models_match_reference_golden(case):
     man, sd, x, emb_ref, _ = load_case(case)
     emb = omodels.FORWARDS[man['model']](sd, x)

@@ -1,0 +1,270 @@
+"""Random launch geometries through the kernels on the SIMT emulator (no GPU), each checked against the same fp32 / fp64 evaluation the layer
+tests use (tests/layer_checks.py) -- the hand-picked emulator cases cover the shapes somebody thought of, this covers the ones nobody did:
+odd sizes around tile / ring / chunk boundaries, single rows and columns, ragged channel counts, operand combinations.
+
+    python tools/emu_fuzz.py conv2ds 200                  # 200 random conv2ds cases, plain emulator
+    python tools/emu_fuzz.py all 60 --mode lazy-dma       # every family, 60 cases each, under a checking mode of tools/emu_check.py
+    python tools/emu_fuzz.py conv1d 100 --mode asan --seed 7 --jobs 8
+    python tools/emu_fuzz.py conv2ds --replay "dict(B=1, H=3, ...)"      # one case again (the line a failure prints)
+
+A case the launcher REFUSES (RuntimeError carrying the library's message) counts as "refused", not as a failure: refusing loudly is the contract
+(include/mvector_hip.h); wrong values, NaNs, sanitizer reports, deadlocks and crashes are failures.  Modes: see tools/emu_check.py.
+"""
+import argparse
+import glob
+import os
+import random
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'tests'), ROOT, os.path.join(ROOT, 'voiceprintrecognition-pytorch_amd')]
+
+
+# ---- generators: one random kwargs dict for the family's case function --------------------------------------------------------------------
+def g_conv2ds(r):
+    ks = r.choice([1, 3, 3])
+    stride = r.choice([1, 1, 2])
+    ch = lambda: r.choice([13, 16, 26, 32, 39, 48, 64, 80, 96, 104, 128, 160, 208])
+    kw = dict(B=r.choice([1, 1, 2, 3]), H=r.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 16, 17, 21, 24]), W=r.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 40, 50, 65]),
+              cin=ch(), cout=ch(), ks=ks, stride=stride, seed=r.randrange(1000))
+    if stride == 2 and r.random() < 0.3:
+        kw['stride_w'] = 1
+    mode = r.random()
+    if mode < 0.2:
+        kw['with_res'] = True
+    elif mode < 0.35:
+        kw['with_sum'] = True
+    elif mode < 0.45 and ks == 1:
+        kw['epi'] = r.choice([1, 2])
+    elif mode < 0.55 and ks == 1:
+        kw.update(concat=True, epi=1, cin=2 * r.choice([16, 32, 48, 64]))
+    if r.random() < 0.2:
+        kw.update(hi=65504.0, lo=-65504.0)
+    if r.random() < 0.15:
+        kw['ring'] = r.choice([2, 3])
+        kw['wgs'] = 1
+    if r.random() < 0.15 and ks == 3:
+        kw['rows'] = r.choice([1, 2, 3, 5, 8])
+    if r.random() < 0.15:
+        kw['spw'] = r.choice([2, 4, 8])
+    if r.random() < 0.1:
+        kw['nbw'] = r.choice([1, 2, 3])
+    return kw
+
+
+def g_conv2d(r):
+    ks = r.choice([1, 3])
+    kw = dict(B=r.choice([1, 2, 3]), H=r.choice([1, 2, 3, 5, 8, 9, 10, 16]), W=r.choice([1, 2, 7, 15, 16, 17, 33, 40, 50]), cin=r.choice([13, 16, 32, 48, 64, 104]),
+              cout=r.choice([13, 16, 32, 48, 64, 104, 128]), ks=ks, stride=r.choice([1, 1, 2]), seed=r.randrange(1000))
+    if r.random() < 0.3:
+        kw['with_res'] = True
+    return kw
+
+
+def g_conv1d(r):
+    k = r.choice([1, 1, 3, 5])
+    kw = dict(B=r.choice([1, 2, 3, 5, 7]), T=r.choice([1, 2, 9, 31, 37, 63, 64, 65, 100, 127, 129, 160, 161, 200, 298, 305]), cin=r.choice([8, 16, 24, 64, 72, 80, 128, 136, 192, 320]),
+              cout=r.choice([8, 16, 20, 40, 64, 128, 200, 256, 512]), k=k, dil=r.choice([1, 2, 3, 4]) if k > 1 else 1, seed=r.randrange(1000))
+    if k > 1 and r.random() < 0.3:
+        kw['pad_mode'] = 'zero'
+        if r.random() < 0.4:
+            kw['valid'] = True
+    if r.random() < 0.2:
+        kw.update(stride=2, pad_mode='zero')
+    if r.random() < 0.2:
+        kw['x_f32'] = True
+    if r.random() < 0.2:
+        kw['y_f32'] = True
+    if r.random() < 0.15:
+        kw['with_x2'] = True
+    if r.random() < 0.2:
+        kw.update(in_affine=True, pre_act=0)
+    if r.random() < 0.2:
+        kw.update(affine=False, pre_act=0)
+    if r.random() < 0.2:
+        kw.update(row_bias=True, post_act=2)
+    if r.random() < 0.15:
+        kw['gate_seg'] = r.choice([10, 25, 100])
+    if r.random() < 0.35:
+        kw['tile'] = r.choice([160, 256, 256])
+    if kw.get('tile') == 256 and k == 1 and r.random() < 0.4:
+        kw['stats'] = r.choice([1, 2])
+    if k == 1 and 'tile' not in kw and r.random() < 0.15:
+        kw.update(in_stats=True, y_f32=True, pre_act=0, affine=False)
+    if r.random() < 0.2:
+        kw['extra_ld'] = r.choice([0, 8, 56])
+    # reflect padding needs T > pad (F.pad's rule, and the reference's)
+    pad = kw['dil'] * (k - 1) // 2
+    if kw.get('pad_mode', 'reflect') == 'reflect' and kw['T'] <= pad:
+        kw['T'] = pad + 1 + r.randrange(5)
+    if kw.get('valid') and kw['T'] <= kw['dil'] * (k - 1):
+        kw['T'] = kw['dil'] * (k - 1) + 1 + r.randrange(5)
+    return kw
+
+
+def g_res2(r):
+    width = r.choice([64, 128])
+    dil = r.choice([2, 3, 4])
+    return dict(B=r.choice([1, 2, 3]), T=r.choice([9, 17, 33, 45, 75, 100, 150, 160, 161, 170, 200]), width=width, dil=dil, groups=8, seed=r.randrange(1000),
+                alone_rows=r.choice([0, 0, 1]))
+
+
+def g_asp(r):
+    kw = dict(B=r.choice([1, 2, 3, 5]), T=r.choice([1, 2, 9, 45, 64, 65, 100, 160, 161, 298]), C=r.choice([72, 192, 256, 384]), A=r.choice([64, 128]), seed=r.randrange(1000))
+    if r.random() < 0.3:
+        kw['online'] = True
+    if r.random() < 0.3:
+        kw['ldx'] = kw['C'] + 8
+    if r.random() < 0.3:
+        kw['centred'] = False
+    return kw
+
+
+def g_time_stats(r):
+    C = r.choice([8, 72, 520, 1024])
+    return dict(B=r.choice([1, 2, 3, 7]), T=r.choice([1, 2, 29, 64, 150, 298]), C=C, ld=C + r.choice([0, 8]), unbiased=r.choice([0, 1]), eps=r.choice([1e-12, 0.0]),
+                seed=r.randrange(1000))
+
+
+def g_linear(r):
+    return dict(B=r.choice([1, 2, 5, 17, 33, 150]), K=r.choice([1, 7, 64, 100, 1024, 2100, 4100]), O=r.choice([1, 3, 16, 37, 128, 192]), act=r.choice([0, 1, 2, 3]), seed=r.randrange(1000))
+
+
+def g_fbank(r):
+    # samples per utterance around the frame / quad / chunk boundaries (25 ms window = 400, shift 160); a few utterances, ragged ratios or none
+    n = r.choice([400, 401, 559, 560, 561, 1040, 4000, 8000, 16000, 16001, 24080, 48000, 52000])
+    B = r.choice([1, 2, 3])
+    return dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 40, 23]), seed=r.randrange(1000))
+
+
+FAMILIES = {'conv2ds': g_conv2ds, 'conv2d': g_conv2d, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
+            'fbank': g_fbank}
+
+
+def run_case(family, kw):
+    import torch
+    import layer_checks as lc
+    from emu_lib import emu_cdll
+    cdll = emu_cdll()
+    if family == 'conv2ds':
+        lc.conv2ds_case(cdll, 'cpu', **kw)
+    elif family == 'conv2d':
+        lc.conv2d_case(cdll, 'cpu', **kw)
+    elif family == 'conv1d':
+        lc.conv1d_case(cdll, 'cpu', **kw)
+    elif family == 'res2':
+        lc.res2_chain_case(cdll, 'cpu', **kw)
+    elif family == 'asp_pool':
+        lc.asp_pool_case(cdll, 'cpu', **kw)
+    elif family == 'time_stats':
+        lc.time_stats_case(cdll, 'cpu', **kw)
+    elif family == 'linear':
+        lc.linear_case(cdll, 'cpu', **kw)
+    elif family == 'fbank':
+        from oracle import frontend
+        wav = frontend.synth_waveforms(kw['B'], kw['L'], seed=kw['seed'])
+        ratio = None
+        if kw['ragged'] and kw['B'] > 1:
+            g = torch.Generator().manual_seed(kw['seed'])
+            ratio = torch.rand(kw['B'], generator=g) * 0.8 + 0.2
+            ratio[0] = 1.0
+        lc.fbank_case(cdll, 'cpu', wav, ratio, dict(sample_frequency=16000, num_mel_bins=kw['bins']))
+    else:
+        raise SystemExit(f'unknown family {family}')
+
+
+def worker(family, n, seed):
+    r = random.Random(seed)
+    ok = refused = 0
+    failures = []
+    for _ in range(n):
+        kw = FAMILIES[family](r)
+        try:
+            run_case(family, kw)
+            ok += 1
+        except RuntimeError as ex:
+            msg = str(ex)
+            if 'mv_' in msg or family.split('_')[0] in msg or 'unsupported' in msg or 'must' in msg:
+                refused += 1
+            else:
+                failures.append((kw, f'RuntimeError: {msg[:200]}'))
+        except AssertionError as ex:
+            failures.append((kw, f'AssertionError: {str(ex)[:200]}'))
+        except Exception as ex:  # noqa: BLE001  (whatever a case throws is a finding)
+            failures.append((kw, f'{type(ex).__name__}: {str(ex)[:200]}'))
+    print(f'RESULT {family} seed {seed}: {ok} ok, {refused} refused, {len(failures)} FAILED', flush=True)
+    for kw, why in failures:
+        print(f'  FAIL {family} "dict({", ".join(f"{k}={v!r}" for k, v in kw.items())})"  {why}', flush=True)
+    return len(failures)
+
+
+def mode_env(mode):
+    env = dict(os.environ)
+    for k in ('MV_EMU_SCHED', 'MV_EMU_SANITIZE', 'MV_EMU_POISON', 'MV_EMU_DMA'):
+        env.pop(k, None)
+    llvm = '/opt/rocm/lib/llvm'
+    if mode == 'asan':
+        rt = glob.glob(llvm + '/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')[0]
+        env.update(MV_EMU_SANITIZE='address', LD_PRELOAD=rt, ASAN_SYMBOLIZER_PATH=llvm + '/bin/llvm-symbolizer',
+                   ASAN_OPTIONS='detect_leaks=0:verify_asan_link_order=0:halt_on_error=1')
+    elif mode == 'ubsan':
+        rt = glob.glob(llvm + '/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so')[0]
+        env.update(MV_EMU_SANITIZE='undefined', LD_PRELOAD=rt, UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    elif mode == 'poison':
+        env['MV_EMU_POISON'] = '1'
+    elif mode.startswith('lazy-dma'):
+        env.update(MV_EMU_POISON='1', MV_EMU_DMA='lazy')
+        if '+' in mode:
+            env['MV_EMU_SCHED'] = mode.split('+', 1)[1]
+    elif mode != 'plain':
+        env['MV_EMU_SCHED'] = mode
+    return env
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('family', choices=sorted(FAMILIES) + ['all'])
+    ap.add_argument('n', type=int, nargs='?', default=50)
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--mode', default='plain')
+    ap.add_argument('--jobs', type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument('--replay', default='')
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.replay:
+        run_case(args.family, eval(args.replay))  # noqa: S307  (a developer's own command line)
+        print('ok')
+        return
+    if args.worker:
+        sys.exit(1 if worker(args.family, args.n, args.seed) else 0)
+    env = mode_env(args.mode)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'build_emu.py')], env={**env, 'LD_PRELOAD': ''}, stdout=subprocess.DEVNULL)
+    fams = sorted(FAMILIES) if args.family == 'all' else [args.family]
+    t0 = time.time()
+    bad = 0
+    for fam in fams:
+        per = -(-args.n // args.jobs)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker'], env=env, cwd=ROOT,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j in range(args.jobs)]
+        ok = refused = failed = crashed = 0
+        for p in procs:
+            out, _ = p.communicate()
+            res = [l for l in out.splitlines() if l.startswith('RESULT')]
+            if not res:   # the worker died (sanitizer report, deadlock abort, crash): show the tail
+                crashed += 1
+                print(f'  CRASH {fam} worker rc={p.returncode}:\n    ' + '\n    '.join(out.splitlines()[-25:]), flush=True)
+                continue
+            w = res[-1].split(':')[1].split(',')
+            ok += int(w[0].split()[0]); refused += int(w[1].split()[0]); failed += int(w[2].split()[0])
+            for l in out.splitlines():
+                if l.startswith('  FAIL'):
+                    print(l, flush=True)
+        print(f'{args.mode:16s} {fam:10s} {ok} ok, {refused} refused, {failed} failed, {crashed} workers crashed   ({time.time() - t0:.0f} s)', flush=True)
+        bad += failed + crashed
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
