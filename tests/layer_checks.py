@@ -194,6 +194,9 @@ def conv2d_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1, 
     ldy = c16 + 4
     res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
     res2 = rn(B, Ho, Wo, c16) if epi == 2 else None
+    for t in (res, res2):   # operands are maps of the same model: their padded channels are zero
+        if t is not None:
+            t[..., cout:] = 0.0
     dev = lambda t: None if t is None else t.to(device).contiguous()
     xad, xbd, resd, res2d = dev(xa), dev(xb), dev(res), dev(res2)
     wd, sd = dev(w), dev(bn_scale)
@@ -309,6 +312,9 @@ def conv2ds_case(cdll, device, B=2, H=10, W=37, cin=16, cout=16, ks=3, stride=1,
     res = rn(B, Ho, Wo, c16) if (with_res or epi == 2) else None
     res2 = rn(B, Ho, Wo, c16) if epi == 2 else None
     add = rn(B, Ho, Wo, c16) if with_sum else None
+    for t in (res, res2, add):   # operands are maps of the same model: their padded channels are zero (eres2net.hip pads weights with zero rows)
+        if t is not None:
+            t[..., cout:] = 0.0
     dev = lambda t: None if t is None else t.to(device).contiguous()
     sp = lambda t: None if t is None else s16_split(cdll, t, device)
     xad, xbd, resd, res2d, addd = sp(xa), sp(xb), sp(res), sp(res2), sp(add)
@@ -871,7 +877,7 @@ def melspec_case(cdll, device, wav, ratio, method_args, rtol=2e-4):
     scale = ref.abs().max().item()
     err = (out - ref).abs().max().item()
     assert err <= rtol * scale + 1e-6, (err, scale)
-    return err / scale
+    return err / scale if scale > 0.0 else err   # (a single frame: the time mean takes everything away)
 
 
 def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0, alone_rows=0):

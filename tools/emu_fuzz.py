@@ -6,6 +6,7 @@ odd sizes around tile / ring / chunk boundaries, single rows and columns, ragged
     python tools/emu_fuzz.py all 60 --mode lazy-dma       # every family, 60 cases each, under a checking mode of tools/emu_check.py
     python tools/emu_fuzz.py conv1d 100 --mode asan --seed 7 --jobs 8
     python tools/emu_fuzz.py conv2ds --replay "dict(B=1, H=3, ...)"      # one case again (the line a failure prints)
+    python tools/emu_fuzz.py all 300 --device gpu --jobs 1 # the same generators against the product library on cuda:0 (a GPU box)
 
 A case the launcher REFUSES (RuntimeError carrying the library's message) counts as "refused", not as a failure: refusing loudly is the contract
 (include/mvector_hip.h); wrong values, NaNs, sanitizer reports, deadlocks and crashes are failures.  Modes: see tools/emu_check.py.
@@ -23,12 +24,27 @@ sys.path[:0] = [os.path.join(ROOT, 'tests'), ROOT, os.path.join(ROOT, 'voiceprin
 
 
 # ---- generators: one random kwargs dict for the family's case function --------------------------------------------------------------------
+BIG = False   # --device gpu: also the sizes the emulator would take minutes for (full-height maps, 10 s utterances, batches that fill the chip)
+
+
+def _pick(r, small, big):
+    return r.choice(small + big) if BIG else r.choice(small)
+
+
 def g_conv2ds(r):
+    for _ in range(100):
+        kw = _g_conv2ds(r)
+        if kw['B'] * kw['H'] * kw['W'] * kw['cin'] * kw['cout'] * kw['ks'] ** 2 <= 3e9:   # (the fp64 reference runs on the host)
+            return kw
+    return kw
+
+
+def _g_conv2ds(r):
     ks = r.choice([1, 3, 3])
     stride = r.choice([1, 1, 2])
     ch = lambda: r.choice([13, 16, 26, 32, 39, 48, 64, 80, 96, 104, 128, 160, 208])
-    kw = dict(B=r.choice([1, 1, 2, 3]), H=r.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 16, 17, 21, 24]), W=r.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 40, 50, 65]),
-              cin=ch(), cout=ch(), ks=ks, stride=stride, seed=r.randrange(1000))
+    kw = dict(B=_pick(r, [1, 1, 2, 3], [4, 16, 33]), H=_pick(r, [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 16, 17, 21, 24], [40, 41, 80]),
+              W=_pick(r, [1, 2, 7, 15, 16, 17, 31, 32, 33, 40, 50, 65], [75, 149, 298, 301]), cin=ch(), cout=ch(), ks=ks, stride=stride, seed=r.randrange(1000))
     if stride == 2 and r.random() < 0.3:
         kw['stride_w'] = 1
     mode = r.random()
@@ -56,7 +72,7 @@ def g_conv2ds(r):
 
 def g_conv2d(r):
     ks = r.choice([1, 3])
-    kw = dict(B=r.choice([1, 2, 3]), H=r.choice([1, 2, 3, 5, 8, 9, 10, 16]), W=r.choice([1, 2, 7, 15, 16, 17, 33, 40, 50]), cin=r.choice([13, 16, 32, 48, 64, 104]),
+    kw = dict(B=_pick(r, [1, 2, 3], [8]), H=_pick(r, [1, 2, 3, 5, 8, 9, 10, 16], [40, 80]), W=_pick(r, [1, 2, 7, 15, 16, 17, 33, 40, 50], [149, 298]), cin=r.choice([13, 16, 32, 48, 64, 104]),
               cout=r.choice([13, 16, 32, 48, 64, 104, 128]), ks=ks, stride=r.choice([1, 1, 2]), seed=r.randrange(1000))
     if r.random() < 0.3:
         kw['with_res'] = True
@@ -65,7 +81,8 @@ def g_conv2d(r):
 
 def g_conv1d(r):
     k = r.choice([1, 1, 3, 5])
-    kw = dict(B=r.choice([1, 2, 3, 5, 7]), T=r.choice([1, 2, 9, 31, 37, 63, 64, 65, 100, 127, 129, 160, 161, 200, 298, 305]), cin=r.choice([8, 16, 24, 64, 72, 80, 128, 136, 192, 320]),
+    kw = dict(B=_pick(r, [1, 2, 3, 5, 7], [16, 64, 130]), T=_pick(r, [1, 2, 9, 31, 37, 63, 64, 65, 100, 127, 129, 160, 161, 200, 298, 305], [600, 998, 1501]),
+              cin=r.choice([8, 16, 24, 64, 72, 80, 128, 136, 192, 320]),
               cout=r.choice([8, 16, 20, 40, 64, 128, 200, 256, 512]), k=k, dil=r.choice([1, 2, 3, 4]) if k > 1 else 1, seed=r.randrange(1000))
     if k > 1 and r.random() < 0.3:
         kw['pad_mode'] = 'zero'
@@ -95,6 +112,14 @@ def g_conv1d(r):
         kw.update(in_stats=True, y_f32=True, pre_act=0, affine=False)
     if r.random() < 0.2:
         kw['extra_ld'] = r.choice([0, 8, 56])
+    if 'tile' in kw:   # the forced wide tiles belong to the plain fp16 path (anything else is refused -- loudly, but it would not test a kernel)
+        for key in ('x_f32', 'with_x2', 'in_affine', 'in_stats'):
+            kw.pop(key, None)
+        if kw['tile'] == 256:
+            kw['cout'] = r.choice([256, 512, 768])
+    if kw.get('in_stats'):
+        kw['cout'] = r.choice([64, 128])
+        kw.pop('stride', None)
     # reflect padding needs T > pad (F.pad's rule, and the reference's)
     pad = kw['dil'] * (k - 1) // 2
     if kw.get('pad_mode', 'reflect') == 'reflect' and kw['T'] <= pad:
@@ -107,24 +132,27 @@ def g_conv1d(r):
 def g_res2(r):
     width = r.choice([64, 128])
     dil = r.choice([2, 3, 4])
-    return dict(B=r.choice([1, 2, 3]), T=r.choice([9, 17, 33, 45, 75, 100, 150, 160, 161, 170, 200]), width=width, dil=dil, groups=8, seed=r.randrange(1000),
+    return dict(B=_pick(r, [1, 2, 3], [8, 40, 130]), T=_pick(r, [9, 17, 33, 45, 75, 100, 150, 160, 161, 170, 200], [298, 304, 305, 320, 321, 400, 998]), width=width, dil=dil, groups=8,
+                seed=r.randrange(1000),
                 alone_rows=r.choice([0, 0, 1]))
 
 
 def g_asp(r):
-    kw = dict(B=r.choice([1, 2, 3, 5]), T=r.choice([1, 2, 9, 45, 64, 65, 100, 160, 161, 298]), C=r.choice([72, 192, 256, 384]), A=r.choice([64, 128]), seed=r.randrange(1000))
+    kw = dict(B=_pick(r, [1, 2, 3, 5], [16, 130]), T=_pick(r, [1, 2, 9, 45, 64, 65, 100, 160, 161, 298], [600, 998, 1501]), C=_pick(r, [72, 192, 256, 384], [1536, 3072]), A=r.choice([64, 128]),
+              seed=r.randrange(1000))
     if r.random() < 0.3:
         kw['online'] = True
     if r.random() < 0.3:
         kw['ldx'] = kw['C'] + 8
-    if r.random() < 0.3:
-        kw['centred'] = False
+    if r.random() < 0.3 and kw['T'] >= 9:
+        kw['centred'] = False   # (the uncentred moments are the option for callers without a global mean; on one or two frames E[x^2] - mean^2 cancels to
+        #                          ~1e-3 where the centred form gives the clamp -- the models always pass the mean, and never pool fewer than 9 frames)
     return kw
 
 
 def g_time_stats(r):
     C = r.choice([8, 72, 520, 1024])
-    return dict(B=r.choice([1, 2, 3, 7]), T=r.choice([1, 2, 29, 64, 150, 298]), C=C, ld=C + r.choice([0, 8]), unbiased=r.choice([0, 1]), eps=r.choice([1e-12, 0.0]),
+    return dict(B=_pick(r, [1, 2, 3, 7], [64, 256]), T=_pick(r, [1, 2, 29, 64, 150, 298], [998, 3001]), C=C, ld=C + r.choice([0, 8]), unbiased=r.choice([0, 1]), eps=r.choice([1e-12, 0.0]),
                 seed=r.randrange(1000))
 
 
@@ -134,34 +162,94 @@ def g_linear(r):
 
 def g_fbank(r):
     # samples per utterance around the frame / quad / chunk boundaries (25 ms window = 400, shift 160); a few utterances, ragged ratios or none
-    n = r.choice([400, 401, 559, 560, 561, 1040, 4000, 8000, 16000, 16001, 24080, 48000, 52000])
-    B = r.choice([1, 2, 3])
+    n = _pick(r, [400, 401, 559, 560, 561, 1040, 4000, 8000, 16000, 16001, 24080, 48000, 52000], [112000, 160000, 480000])
+    B = _pick(r, [1, 2, 3], [8, 40, 130, 256])
+    if B * n > 16e6:
+        B = 3
     return dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 40, 23]), seed=r.randrange(1000))
 
 
+def g_melspec(r):
+    # torchaudio.transforms.MelSpectrogram(**method_args) geometries (featurizer.py:41-42): the n_fft = 400 FFT kernel, the power-of-two FFT kernel
+    # (n_fft <= 1024), the dense DFT for everything else; windows shorter than n_fft, hops, mel counts and band edges, centre on / off
+    n_fft = r.choice([128, 200, 256, 320, 400, 400, 512, 512, 600, 1024])
+    args = dict(n_fft=n_fft)
+    if r.random() < 0.4:
+        args['win_length'] = r.choice([n_fft, n_fft // 2, max(16, n_fft - 56)])
+    if r.random() < 0.6:
+        args['hop_length'] = r.choice([80, 100, 128, 160, 200, 320])
+    if r.random() < 0.5:
+        args['n_mels'] = r.choice([23, 32, 40, 64, 80, 128])
+    if r.random() < 0.3:
+        args.update(f_min=r.choice([0.0, 20.0, 50.0]), f_max=r.choice([3800.0, 7000.0, 8000.0, 14000.0]))
+    if r.random() < 0.2:
+        args['center'] = False
+    if r.random() < 0.2:
+        args['power'] = r.choice([1.0, 2.0])
+    L = _pick(r, [n_fft, n_fft + 1, 1500, 2000, 3333, 5003, 9000], [48000, 160000])
+    if L < n_fft:
+        L = n_fft
+    return dict(B=_pick(r, [1, 2, 3], [8, 64, 256]) if L < 100000 else 2, L=L, ragged=r.random() < 0.4, args=args, seed=r.randrange(1000))
+
+
+def g_fcm_block(r):
+    sf = r.choice([1, 2])
+    kw = dict(B=_pick(r, [1, 2, 3, 9], [32, 256]), Fin=r.choice([1, 2, 3, 4, 5, 6, 9, 12, 20]), T=_pick(r, [5, 16, 33, 45, 62, 70, 100, 318, 319, 330], [298, 998]), sf=sf,
+              seed=r.randrange(1000))
+    if sf == 2 and r.random() < 0.3:
+        kw['strided_out'] = True
+    return kw
+
+
+def _budget(gen, cost, limit):
+    """resample until the host-side reference of the case is affordable"""
+    def g(r):
+        for _ in range(200):
+            kw = gen(r)
+            if cost(kw) <= limit:
+                break
+        return kw
+    return g
+
+
+g_conv2d = _budget(g_conv2d, lambda k: k['B'] * k['H'] * k['W'] * k['cin'] * k['cout'] * k['ks'] ** 2, 3e9)
+g_conv1d = _budget(g_conv1d, lambda k: k['B'] * k['T'] * k['cin'] * k['cout'] * k['k'], 4e9)
+g_res2 = _budget(g_res2, lambda k: k['B'] * k['T'] * k['width'] ** 2 * 3 * 7, 6e9)
+g_asp = _budget(g_asp, lambda k: k['B'] * k['T'] * k['C'] * k['A'], 3e9)
+g_time_stats = _budget(g_time_stats, lambda k: k['B'] * k['T'] * k['C'], 3e8)
+g_fcm_block = _budget(g_fcm_block, lambda k: k['B'] * k['T'] * k['Fin'] * 32 * 32 * 9 * 2, 4e9)
+g_melspec = _budget(g_melspec, lambda k: k['B'] * k['L'], 4e6)
+
 FAMILIES = {'conv2ds': g_conv2ds, 'conv2d': g_conv2d, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
-            'fbank': g_fbank}
+            'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block}
+
+
+DEVICE = 'cpu'   # 'cpu' = the emulator build of the kernels; 'cuda' = the product library on the GPU
 
 
 def run_case(family, kw):
     import torch
     import layer_checks as lc
-    from emu_lib import emu_cdll
-    cdll = emu_cdll()
+    if DEVICE == 'cpu':
+        from emu_lib import emu_cdll
+        cdll = emu_cdll()
+    else:
+        from mvector import _hip
+        cdll = _hip.lib()
     if family == 'conv2ds':
-        lc.conv2ds_case(cdll, 'cpu', **kw)
+        lc.conv2ds_case(cdll, DEVICE, **kw)
     elif family == 'conv2d':
-        lc.conv2d_case(cdll, 'cpu', **kw)
+        lc.conv2d_case(cdll, DEVICE, **kw)
     elif family == 'conv1d':
-        lc.conv1d_case(cdll, 'cpu', **kw)
+        lc.conv1d_case(cdll, DEVICE, **kw)
     elif family == 'res2':
-        lc.res2_chain_case(cdll, 'cpu', **kw)
+        lc.res2_chain_case(cdll, DEVICE, **kw)
     elif family == 'asp_pool':
-        lc.asp_pool_case(cdll, 'cpu', **kw)
+        lc.asp_pool_case(cdll, DEVICE, **kw)
     elif family == 'time_stats':
-        lc.time_stats_case(cdll, 'cpu', **kw)
+        lc.time_stats_case(cdll, DEVICE, **kw)
     elif family == 'linear':
-        lc.linear_case(cdll, 'cpu', **kw)
+        lc.linear_case(cdll, DEVICE, **kw)
     elif family == 'fbank':
         from oracle import frontend
         wav = frontend.synth_waveforms(kw['B'], kw['L'], seed=kw['seed'])
@@ -170,7 +258,18 @@ def run_case(family, kw):
             g = torch.Generator().manual_seed(kw['seed'])
             ratio = torch.rand(kw['B'], generator=g) * 0.8 + 0.2
             ratio[0] = 1.0
-        lc.fbank_case(cdll, 'cpu', wav, ratio, dict(sample_frequency=16000, num_mel_bins=kw['bins']))
+        lc.fbank_case(cdll, DEVICE, wav, ratio, dict(sample_frequency=16000, num_mel_bins=kw['bins']))
+    elif family == 'melspec':
+        from oracle import frontend
+        wav = frontend.synth_waveforms(kw['B'], kw['L'], seed=kw['seed'])
+        ratio = None
+        if kw['ragged'] and kw['B'] > 1:
+            g = torch.Generator().manual_seed(kw['seed'])
+            ratio = torch.rand(kw['B'], generator=g) * 0.8 + 0.2
+            ratio[0] = 1.0
+        lc.melspec_case(cdll, DEVICE, wav, ratio, kw['args'])
+    elif family == 'fcm_block':
+        lc.fcm_block_case(cdll, DEVICE, **kw)
     else:
         raise SystemExit(f'unknown family {family}')
 
@@ -188,6 +287,8 @@ def worker(family, n, seed):
             msg = str(ex)
             if 'mv_' in msg or family.split('_')[0] in msg or 'unsupported' in msg or 'must' in msg:
                 refused += 1
+                if os.environ.get('MV_FUZZ_VERBOSE'):
+                    print(f'  refused: {msg[:160]}   {kw}', flush=True)
             else:
                 failures.append((kw, f'RuntimeError: {msg[:200]}'))
         except AssertionError as ex:
@@ -230,9 +331,13 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--mode', default='plain')
     ap.add_argument('--jobs', type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument('--device', default='emu', choices=['emu', 'gpu'])
     ap.add_argument('--replay', default='')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global DEVICE, BIG
+    DEVICE = 'cuda' if args.device == 'gpu' else 'cpu'
+    BIG = args.device == 'gpu'
     if args.replay:
         run_case(args.family, eval(args.replay))  # noqa: S307  (a developer's own command line)
         print('ok')
@@ -240,13 +345,14 @@ def main():
     if args.worker:
         sys.exit(1 if worker(args.family, args.n, args.seed) else 0)
     env = mode_env(args.mode)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'build_emu.py')], env={**env, 'LD_PRELOAD': ''}, stdout=subprocess.DEVNULL)
+    if args.device == 'emu':
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'build_emu.py')], env={**env, 'LD_PRELOAD': ''}, stdout=subprocess.DEVNULL)
     fams = sorted(FAMILIES) if args.family == 'all' else [args.family]
     t0 = time.time()
     bad = 0
     for fam in fams:
         per = -(-args.n // args.jobs)
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker'], env=env, cwd=ROOT,
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker', '--device', args.device], env=env, cwd=ROOT,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j in range(args.jobs)]
         ok = refused = failed = crashed = 0
         for p in procs:
