@@ -8,6 +8,7 @@ odd sizes around tile / ring / chunk boundaries, single rows and columns, ragged
     python tools/emu_fuzz.py conv2ds --replay "dict(B=1, H=3, ...)"      # one case again (the line a failure prints)
     python tools/emu_fuzz.py all 300 --device gpu --jobs 1 # the same generators against the product library on cuda:0 (a GPU box)
 
+MV_FUZZ_STREAM=1: the workers print their own RESULT / FAIL / progress lines instead of the per-family summary (for runs under a time limit).
 A case the launcher REFUSES (RuntimeError carrying the library's message) counts as "refused", not as a failure: refusing loudly is the contract
 (include/mvector_hip.h); wrong values, NaNs, sanitizer reports, deadlocks and crashes are failures.  Modes: see tools/emu_check.py.
 """
@@ -280,6 +281,8 @@ def worker(family, n, seed):
     failures = []
     for _ in range(n):
         kw = FAMILIES[family](r)
+        if (ok + refused + len(failures)) % 10 == 0 and ok + refused + len(failures) > 0:
+            print(f'  progress {family} seed {seed}: {ok} ok, {refused} refused, {len(failures)} failed so far', file=sys.stderr, flush=True)
         try:
             run_case(family, kw)
             ok += 1
@@ -352,8 +355,19 @@ def main():
     bad = 0
     for fam in fams:
         per = -(-args.n // args.jobs)
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker', '--device', args.device], env=env, cwd=ROOT,
+        # (each worker's host-side references on a few threads: a dozen torch processes with one thread per core each thrash the box -- the first
+        # GPU run of this tool, r13c, spent its whole time limit that way and printed nothing)
+        if os.environ.get('MV_FUZZ_STREAM'):
+            wenv = {**env, 'OMP_NUM_THREADS': str(max(1, min(8, (os.cpu_count() or 8) // max(1, args.jobs)))), 'PYTHONUNBUFFERED': '1'}
+            ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker', '--device', args.device], env=wenv, cwd=ROOT)
+                  for j in range(args.jobs)]
+            bad += sum(1 for q in ps if q.wait() != 0)
+            continue
+        wenv = {**env, 'OMP_NUM_THREADS': str(max(1, min(8, (os.cpu_count() or 8) // max(1, args.jobs)))), 'PYTHONUNBUFFERED': '1'}
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), fam, str(per), '--seed', str(args.seed * 1000 + j), '--worker', '--device', args.device], env=wenv, cwd=ROOT,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j in range(args.jobs)]
+        if os.environ.get('MV_FUZZ_STREAM'):   # (a run under somebody's time limit: let the workers talk themselves -- a cut-off run keeps what they said)
+            raise SystemExit('MV_FUZZ_STREAM is handled before the workers are started')
         ok = refused = failed = crashed = 0
         for p in procs:
             out, _ = p.communicate()
