@@ -95,4 +95,4 @@ def test_fuzzer_runs_random_geometries_of_every_family_clean():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'emu_fuzz.py'), 'all', '4', '--jobs', '4', '--seed', '11'], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if ' ok, ' in l]
-    assert len(lines) == 10 and all(' 0 failed, 0 workers crashed' in l for l in lines), r.stdout
+    assert len(lines) == 11 and all(' 0 failed, 0 workers crashed' in l for l in lines), r.stdout

@@ -202,6 +202,14 @@ def g_fcm_block(r):
     return kw
 
 
+def g_model(r):
+    # whole tiny backbones on one utterance of a random length against the oracle: the host side's choices (tile shapes, chunk forms, fused or
+    # stand-alone statistics, ring / direct Res2Net forms) all follow the frame count
+    case = r.choice(['ecapa_tiny', 'ecapa_tiny', 'tdnn', 'eres2net_tiny', 'eres2netv2_tiny'])
+    T = _pick(r, [20, 23, 31, 33, 47, 64, 65, 97, 100, 127, 128, 129, 159, 160, 161, 163, 200, 257], [298, 305, 321, 640, 998])
+    return dict(case=case, frames=T)
+
+
 def _budget(gen, cost, limit):
     """resample until the host-side reference of the case is affordable"""
     def g(r):
@@ -222,7 +230,7 @@ g_fcm_block = _budget(g_fcm_block, lambda k: k['B'] * k['T'] * k['Fin'] * 32 * 3
 g_melspec = _budget(g_melspec, lambda k: k['B'] * k['L'], 4e6)
 
 FAMILIES = {'conv2ds': g_conv2ds, 'conv2d': g_conv2d, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
-            'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block}
+            'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block, 'model': g_model}
 
 
 DEVICE = 'cpu'   # 'cpu' = the emulator build of the kernels; 'cuda' = the product library on the GPU
@@ -271,6 +279,8 @@ def run_case(family, kw):
         lc.melspec_case(cdll, DEVICE, wav, ratio, kw['args'])
     elif family == 'fcm_block':
         lc.fcm_block_case(cdll, DEVICE, **kw)
+    elif family == 'model':
+        lc.model_case(cdll, DEVICE, kw['case'], frames=kw['frames'])
     else:
         raise SystemExit(f'unknown family {family}')
 
