@@ -329,3 +329,14 @@ def test_emu_fbank_long_utterance_chunked_and_single_workgroup_forms():
         assert torch.equal(fb(wav3[:nb]), full[:nb])
     nsamp = torch.tensor([48000, 48000, 48000])
     assert torch.equal(fb(wav3[:3], num_samples=nsamp), fb(wav3[:3], torch.ones(3), workspace=False))   # the variable-length entry sums the same way
+
+
+def test_emu_fbank_without_time_mean_is_the_reference_kaldi_fbank_module():
+    """KaldiFbank.forward (featurizer.py:114-132 of the reference): kaldi.fbank per utterance, no mean subtraction -- the kernel with
+    subtract_time_mean off, in the one-workgroup form, with rows beyond the LDS block (T > 292) and in the several-workgroups form"""
+    fb = lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80), subtract_time_mean=False, cdll=emu_cdll())
+    for B, L, ws in ((2, 4000, True), (1, 52000, True), (1, 52000, False), (3, 16001, True)):
+        wav = frontend.synth_waveforms(B, L, seed=40 + B)
+        ref = torch.stack([frontend.kaldi_fbank(row.unsqueeze(0), sample_frequency=16000, num_mel_bins=80) for row in wav])
+        out = fb(wav, workspace=ws)
+        assert out.shape == ref.shape and (out - ref).abs().max() < 2e-3, (B, L, ws, (out - ref).abs().max())

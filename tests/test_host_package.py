@@ -111,6 +111,22 @@ def test_cpu_featurizer_matches_oracle_and_contract():
         AudioFeaturizer('Fbank', method_args=dict(not_an_argument=1))
 
 
+def test_cpu_kaldi_fbank_module_matches_oracle():
+    """the reference's KaldiFbank (featurizer.py:114-132): [Batch, Length] -> [Batch, Feature, Length], kaldi.fbank per row, no CMN"""
+    from mvector.data_utils.featurizer import KaldiFbank
+    m = KaldiFbank(**FB)
+    wav = frontend.synth_waveforms(3, 16000, seed=12)
+    out = m(wav)
+    ref = torch.stack([frontend.kaldi_fbank(row.unsqueeze(0), **FB).transpose(0, 1) for row in wav])
+    assert out.shape == (3, 80, 98) and (out - ref).abs().max() < 1e-4
+    assert torch.equal(m(wav.unsqueeze(1)), out)      # rows as [1, Length]
+    assert KaldiFbank(sample_frequency=16000)(wav[:1]).shape == (1, 23, 98)   # torchaudio's default 23 bins
+    with pytest.raises(TypeError):
+        KaldiFbank(not_an_argument=1)
+    with pytest.raises(ValueError):
+        m(wav[0])
+
+
 def _write_model_and_audio(tmp_path):
     import scipy.io.wavfile as wavfile
     man, sd, _, _, _ = load_case('tdnn')

@@ -116,3 +116,48 @@ def test_reference_infer_recognition_runs_unchanged(tmp_path):
     assert '识别说话的为' in out
     assert os.path.exists(str(tmp_path / 'audio_db' / 'audio_indexes.bin'))
     assert os.path.isdir(str(tmp_path / 'audio_db' / 'alice')) and not os.path.isdir(str(tmp_path / 'audio_db' / 'bob'))
+
+
+def _public_api(path):
+    """{name: argument names} of the top-level functions, classes and their public methods of a source file (no import: AST)"""
+    import ast
+    out = {}
+    for n in ast.parse(open(path).read()).body:
+        if isinstance(n, ast.ClassDef):
+            out[n.name] = None
+            for m in n.body:
+                if isinstance(m, ast.FunctionDef) and (not m.name.startswith('_') or m.name == '__init__'):
+                    out[f'{n.name}.{m.name}'] = [a.arg for a in m.args.args + m.args.kwonlyargs]
+        elif isinstance(n, ast.FunctionDef) and not n.name.startswith('_'):
+            out[n.name] = [a.arg for a in n.args.args]
+    return out
+
+
+def test_public_names_and_arguments_of_the_path_exist_here():
+    """every top-level name, public method and argument name the reference defines in the files of the embedding path
+    exists in this package's file of the same name (extra arguments with defaults are allowed; training-only names are listed apart)"""
+    files = ['mvector/predict.py', 'mvector/data_utils/featurizer.py', 'mvector/metric/metrics.py', 'mvector/models/ecapa_tdnn.py', 'mvector/models/tdnn.py',
+             'mvector/models/pooling.py', 'mvector/models/utils.py', 'mvector/utils/utils.py', 'mvector/utils/record.py', 'mvector/data_utils/collate_fn.py']
+    missing = []
+    for rel in files:
+        ref, ours = _public_api(os.path.join(REF, rel)), _public_api(os.path.join(PKG, rel))
+        for name, args in ref.items():
+            if name not in ours:
+                if name.endswith('.__init__') and name.rsplit('.', 1)[0] in ours:
+                    continue   # (a constructor without arguments that the class here inherits)
+                missing.append(f'{rel}: {name}')
+            elif args and ours[name] is not None:
+                lost = [a for a in args if a not in ours[name]]
+                if lost:
+                    missing.append(f'{rel}: {name} lacks {lost}')
+    assert not missing, missing
+    # the model files define the classes users construct (the reference's internal building blocks of CAM++ / ERes2Net are laid out differently here;
+    # the state_dict contract is what test_state_dict_layout_equals_reference_manifest pins)
+    for rel, names in (('mvector/models/campplus.py', ['CAMPPlus']), ('mvector/models/eres2net.py', ['ERes2Net', 'ERes2NetV2']),
+                       ('mvector/trainer.py', ['MVectorTrainer', 'MVectorTrainer.evaluate', 'MVectorTrainer.train', 'MVectorTrainer.export', 'MVectorTrainer.extract_features'])):
+        ref, ours = _public_api(os.path.join(REF, rel)), _public_api(os.path.join(PKG, rel))
+        for name in names:
+            assert name in ref and name in ours, (rel, name)
+        for cls in [n for n in names if '.' not in n]:
+            lost = [a for a in ref[f'{cls}.__init__'] if a not in ours[f'{cls}.__init__']]
+            assert not lost, (rel, cls, lost)

@@ -103,3 +103,40 @@ class AudioFeaturizer(nn.Module):
             return self._method_args.get('num_mel_bins', 23)
         else:
             raise Exception('没有{}预处理方法'.format(self._feature_method))
+
+
+class KaldiFbank(nn.Module):
+    """The reference's Fbank module (featurizer.py:114-132: ``Kaldi.fbank(waveform, **kwargs)`` per utterance, stacked):
+    ``[Batch, Length]`` -> ``[Batch, Feature, Length]`` log-mel energies, no mean subtraction.  ``AudioFeaturizer`` does not go through it
+    here (its Fbank, time mean and mask are one launch); the class exists for code that uses it directly.  CUDA tensors run the same HIP
+    kernel with the time-mean subtraction switched off, CPU tensors the batched torch restatement -- like ``AudioFeaturizer``."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.kwargs = kwargs
+        _cpu_frontend.validate_args('Fbank', self.kwargs)
+        self._native = {}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_native'] = {}
+        return state
+
+    def forward(self, waveforms):
+        if waveforms.dim() == 3 and waveforms.size(1) == 1:   # rows given as [1, Length] (the reference unsqueezes 1-D rows to that)
+            waveforms = waveforms[:, 0]
+        if waveforms.dim() != 2:
+            raise ValueError(f'KaldiFbank expects [Batch, Length] waveforms, got {tuple(waveforms.shape)}')
+        if waveforms.dtype != torch.float32:
+            waveforms = waveforms.float()
+        if waveforms.is_cuda:
+            key = waveforms.device.index if waveforms.device.index is not None else torch.cuda.current_device()
+            with torch.cuda.device(key):
+                h = self._native.get(key)
+                if h is None:
+                    from mvector import _hip
+                    h = self._native[key] = _hip.Fbank(self.kwargs, subtract_time_mean=False)
+                feats = h(waveforms)
+        else:
+            feats = _cpu_frontend.fbank_batch(waveforms, self.kwargs)
+        return feats.transpose(1, 2)

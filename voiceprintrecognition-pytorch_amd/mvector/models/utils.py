@@ -16,6 +16,16 @@ def length_to_mask(length, max_len=None, dtype=None, device=None):
                            device=length.device if device is None else device)
 
 
+def get_padding_elem(L_in, stride, kernel_size, dilation):
+    """[left, right] padding that keeps the length ('same'), as the reference computes it (models/utils.py:28-36): half the kernel on a strided
+    conv, half of what the dilated kernel takes away otherwise.  ``Conv1d.forward`` below applies the same rule."""
+    if stride > 1:
+        p = kernel_size // 2
+    else:
+        p = (L_in - ((L_in - dilation * (kernel_size - 1) - 1) // stride + 1)) // 2
+    return [p, p]
+
+
 class Conv1d(nn.Module):
     """nn.Conv1d with 'same' (reflect by default) / 'causal' / 'valid' padding done outside the conv."""
 
@@ -29,12 +39,7 @@ class Conv1d(nn.Module):
 
     def forward(self, x):
         if self.padding == 'same':
-            if self.stride > 1:
-                p = self.kernel_size // 2
-            else:
-                L = x.shape[-1]
-                p = (L - ((L - self.dilation * (self.kernel_size - 1) - 1) // self.stride + 1)) // 2
-            x = F.pad(x, (p, p), mode=self.padding_mode)
+            x = F.pad(x, tuple(get_padding_elem(x.shape[-1], self.stride, self.kernel_size, self.dilation)), mode=self.padding_mode)
         elif self.padding == 'causal':
             x = F.pad(x, ((self.kernel_size - 1) * self.dilation, 0))
         elif self.padding != 'valid':
