@@ -1485,6 +1485,11 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (d.pad_mode == MV_PAD_REFLECT) MV_REQUIRE(d.pad < d.T_in, "conv1d: reflect padding needs pad < T_in");
     MV_REQUIRE(d.x_dtype == MV_DT_F16 || d.x_dtype == MV_DT_F32, "conv1d: x dtype");
     MV_REQUIRE(d.y_dtype == MV_DT_F16 || d.y_dtype == MV_DT_F32, "conv1d: y dtype");
+    MV_REQUIRE(d.pad_mode == MV_PAD_ZERO || d.pad_mode == MV_PAD_REFLECT, "conv1d: padding mode");
+    MV_REQUIRE(d.pre_act >= MV_ACT_NONE && d.pre_act <= MV_ACT_SIGMOID && d.post_act >= MV_ACT_NONE && d.post_act <= MV_ACT_SIGMOID, "conv1d: activation code");
+    // (a row may be SHORTER than cin -- the first block's window form reads 5 overlapping 80-channel rows as one of 400 -- but never of no or negative length)
+    MV_REQUIRE(d.ldx > 0 && d.ldy > 0 && (d.x2 == nullptr || d.ldx2 > 0) && (d.sum_dst == nullptr || (d.ld_add > 0 && d.ld_sum > 0)),
+               "conv1d: leading dimensions must be positive");
     MV_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr), "conv1d: in_scale/in_shift go together");
     MV_REQUIRE((d.scale == nullptr) == (d.shift == nullptr), "conv1d: scale/shift go together");
     // vector-access contract of the loader / epilogue

@@ -312,6 +312,9 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
     const int stride_w = d.stride_w == 0 ? d.stride : d.stride_w;
     MV_REQUIRE(d.cin16 > 0 && d.cin16 % 16 == 0 && d.cout16 > 0 && d.cout16 % 16 == 0, "conv2d: channels must be padded to 16");
     MV_REQUIRE(d.ldx % 4 == 0 && d.ldy % 4 == 0, "conv2d: leading dimensions");
+    MV_REQUIRE(d.ldx > 0 && d.ldy > 0 && (d.x2_mode == 0 || d.ldx2 > 0) && (d.res == nullptr || d.ldres > 0) && (d.res2 == nullptr || d.ldres2 > 0),
+               "conv2d: leading dimensions must be positive");
+    MV_REQUIRE((d.res == nullptr || d.ldres % 4 == 0) && (d.res2 == nullptr || d.ldres2 % 4 == 0), "conv2d: operand leading dimensions (16-byte rows)");
     MV_REQUIRE(d.x2_mode >= 0 && d.x2_mode <= 2 && (d.x2_mode == 0 || (d.x2 != nullptr && d.ldx2 % 4 == 0)), "conv2d: second input");
     if (d.x2_mode == 2) MV_REQUIRE(d.cin1 > 0 && d.cin1 % 4 == 0 && d.cin1 < d.cin16, "conv2d: concat split");
     MV_REQUIRE(d.epi >= 0 && d.epi <= 2, "conv2d: epilogue mode");

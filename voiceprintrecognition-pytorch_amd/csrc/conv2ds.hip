@@ -635,7 +635,10 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     if (d.res != nullptr) MV_REQUIRE(d.ldres % 16 == 0, "conv2ds: residual leading dimension");
     MV_REQUIRE((d.y2 == nullptr) == (d.add == nullptr), "conv2ds: the second output needs its addend");
     if (d.y2 != nullptr) MV_REQUIRE(d.ldy2 % 16 == 0 && d.ldadd % 16 == 0, "conv2ds: second output leading dimensions");
-    MV_REQUIRE(d.oscale > 0.0f, "conv2ds: output scale of the packed weights missing");
+    MV_REQUIRE(d.ldx > 0 && d.ldy > 0 && (d.x2 == nullptr || d.ldx2 > 0) && (d.res == nullptr || d.ldres > 0) && (d.res2 == nullptr || d.ldres2 > 0) &&
+                   (d.y2 == nullptr || (d.ldy2 > 0 && d.ldadd > 0)),
+               "conv2ds: leading dimensions must be positive");
+    MV_REQUIRE(d.oscale > 0.0f && d.oscale < 3.0e38f, "conv2ds: output scale of the packed weights missing");
     MV_REQUIRE((int64_t)d.H * d.W * d.ldx < (int64_t)1 << 30 && (d.x2 == nullptr || (int64_t)d.H * d.W * d.ldx2 < (int64_t)1 << 30),
                "conv2ds: one utterance's map too large (4 GiB)");
     const int p = d.ks / 2;
