@@ -108,7 +108,7 @@ def test_tampered_descriptors_are_refused_or_harmless_never_a_crash():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     summary = [l for l in r.stdout.splitlines() if 'SUMMARY' in l][0]
     n, rejected = int(summary.split()[2]), int(summary.split()[5])
-    assert n > 300 and rejected > 250 and ' 0 crashed' in summary, summary
+    assert n > 400 and rejected > 330 and ' 0 crashed' in summary, summary
     accepted = [l for l in r.stdout.splitlines() if 'ACCEPTED' in l][0]
     for must_reject in ('pre_act=99', 'post_act=-1', 'pad_mode=99', 'mv_conv2d_forward.ldres=-1', 'mv_conv1d_forward.ldx=', 'mv_conv1d_forward.ldy=', 'x=None', 'y=None', 'oscale'):
         assert must_reject not in accepted, must_reject

@@ -1,4 +1,5 @@
-"""Bad descriptors at the C ABI (no GPU): every field of MvConv1dDesc / MvConv2dDesc / MvConv2dsDesc of a VALID layer call is replaced, one at a
+"""Bad arguments at the C ABI (no GPU): every field of MvConv1dDesc / MvConv2dDesc / MvConv2dsDesc of a VALID layer call -- and every pointer / integer
+argument of the positional entry points (linear, time statistics, ASP pooling, Res2Net chain, BN + ReLU rows, TSTP, wave preparation, cosine) -- is replaced, one at a
 time, by values a caller can get wrong -- a null pointer, 0, -1, a huge size, an enum out of range, a leading dimension smaller than the row --
 and the entry point is called on the emulator build.  The contract (include/mvector_hip.h): a call the library cannot run returns an error code
 and a message; it never crashes and never touches memory outside the caller's buffers.
@@ -46,6 +47,38 @@ def candidates(name, typ, value):
     return []
 
 
+class TamperArgs:
+    """the same for entry points with positional arguments: every pointer argument that was given becomes null, every integer 0 and -1 -- the
+    LAST argument (the stream) excepted.  A null pointer for an OPTIONAL operand is a valid call; it shows up under ACCEPTED."""
+
+    def __init__(self, cdll, fn_name, log):
+        from mvector import _hip
+        self._cdll, self._fn, self._log = cdll, fn_name, log
+        self._argtypes = _hip._SIGNATURES[fn_name][1]
+
+    def __getattr__(self, name):
+        real = getattr(self._cdll, name)
+        if name != self._fn:
+            return real
+
+        def call(*args):
+            for i, (typ, val) in enumerate(zip(self._argtypes[:-1], args[:-1])):
+                if typ is POINTER_T:
+                    bads = [None] if val else []
+                elif typ in (ctypes.c_int32, ctypes.c_int64):
+                    bads = [v for v in (0, -1) if v != val]
+                else:
+                    bads = []
+                for bad in bads:
+                    print(f'CALL {self._fn} arg{i} = {bad!r}', flush=True)
+                    rc = real(*(args[:i] + (bad,) + args[i + 1:]))
+                    msg = self._cdll.mv_last_error().decode() if rc != 0 else ''
+                    self._log.append((self._fn, f'arg{i}', bad, rc, msg))
+                    print(f'  -> {"accepted" if rc == 0 else "rejected: " + msg[:120]}', flush=True)
+            return real(*args)
+        return call
+
+
 class Tamper:
     """stands in for the bound library: the named entry point is first called with every tampered copy of its descriptor"""
 
@@ -85,6 +118,17 @@ def worker():
     lc.conv2d_case(Tamper(cdll, 'mv_conv2d_forward', _hip.MvConv2dDesc, log), 'cpu', B=1, H=5, W=9, cin=16, cout=32, ks=3, with_res=True)
     lc.conv2ds_case(Tamper(cdll, 'mv_conv2ds_forward', _hip.MvConv2dsDesc, log), 'cpu', B=1, H=5, W=9, cin=16, cout=32, ks=3, with_res=True, with_sum=True)
     lc.conv2ds_case(Tamper(cdll, 'mv_conv2ds_forward', _hip.MvConv2dsDesc, log), 'cpu', B=1, H=4, W=9, cin=64, cout=16, ks=1, concat=True, epi=1)
+    import torch
+    lc.linear_case(TamperArgs(cdll, 'mv_linear_f32', log), 'cpu', B=3, K=40, O=12)
+    lc.time_stats_case(TamperArgs(cdll, 'mv_time_stats_f16', log), 'cpu', B=2, T=9, C=72, ld=80)
+    lc.asp_pool_case(TamperArgs(cdll, 'mv_asp_pool_f16', log), 'cpu', B=2, T=20, C=72, A=64)
+    lc.res2_chain_case(TamperArgs(cdll, 'mv_res2net_chain_f16', log), 'cpu', B=1, T=20, width=64, dil=2)
+    lc.bn_relu_rows_case(TamperArgs(cdll, 'mv_bn_relu_rows_f16', log), 'cpu', rows=9, C=72, ldx=80, ldy=88)
+    lc.tstp_case(TamperArgs(cdll, 'mv_tstp_f32', log), 'cpu', B=2, H=3, W=10, C=16)
+    lc.wave_prepare_case(TamperArgs(cdll, 'mv_wave_prepare_i16', log), 'cpu', B=2, L=300)
+    a, b = torch.randn(5, 16), torch.randn(7, 16)
+    lc.cosine_case(TamperArgs(cdll, 'mv_cosine_f32', log), 'cpu', a.numpy(), b.numpy(),
+                   (torch.nn.functional.normalize(a, dim=1) @ torch.nn.functional.normalize(b, dim=1).t()).numpy())
     rej = sum(1 for e in log if e[3] != 0)
     print(f'SUMMARY {len(log)} tampered calls: {rej} rejected, {len(log) - rej} accepted, 0 crashed', flush=True)
     acc = sorted({(e[0], e[1], e[2]) for e in log if e[3] == 0})

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
 int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
                       int unbiased, float clamp_eps, hipStream_t stream, const float* in_scale, const float* in_shift) {
     MV_REQUIRE(x != nullptr && mean != nullptr && B > 0 && T > 0 && C > 0, "time_stats: bad argument");
-    MV_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
+    MV_REQUIRE(ld > 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
     if (ceil_div(C, 128) * (int64_t)B <= 1024) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const half_t* x, int6
 int bn_relu_rows_launch(const half_t* x, int64_t ldx, const float* scale, const float* shift, half_t* y, int64_t ldy, int64_t n_rows, int C,
                         hipStream_t stream) {
     MV_REQUIRE(x != nullptr && y != nullptr && scale != nullptr && shift != nullptr, "bn_relu_rows: null tensor");
-    MV_REQUIRE(n_rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    MV_REQUIRE(n_rows > 0 && C > 0 && C % 8 == 0 && ldx > 0 && ldy > 0 && ldx % 8 == 0 && ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(shift) & 15) == 0,
                "bn_relu_rows: rows and parameters must be 16-byte aligned, channels a multiple of 8");
     const int64_t total = n_rows * (C / 8);
@@ -809,6 +809,7 @@ int asp_pool_launch(const half_t* h, const half_t* w2_packed, const half_t* x, i
     MV_REQUIRE(B > 0 && T > 0 && C > 0 && A > 0, "asp_pool: bad geometry");
     MV_REQUIRE(A % 8 == 0 && A <= 256, "asp_pool: attention width must be a multiple of 8 and <= 256");
     MV_REQUIRE(ldx % 4 == 0 && C % 4 == 0, "asp_pool: channels must be a multiple of 4");
+    MV_REQUIRE(ldx > 0 && (gmean == nullptr || gmean_ld >= 0), "asp_pool: leading dimensions must not be negative");
     AspArgs a;
     a.h = h;
     a.w2 = w2_packed;
