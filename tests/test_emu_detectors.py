@@ -88,14 +88,14 @@ def test_missing_counted_wait_is_hidden_by_eager_transfers_and_shown_by_lazy_one
 
 
 def test_fuzzer_runs_random_geometries_of_every_family_clean():
-    """tools/emu_fuzz.py: a handful of seeded random launch geometries per kernel family against the layer checks (the long runs and the
+    """tools/emu_fuzz.py: a handful of seeded random launch geometries of five kernel families (the tool knows eleven) against the layer checks (the long runs and the
     checking modes are a tool, profiles/r13a_emu_check.log); a refused geometry is fine, a wrong value is not"""
     import sys
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'emu_fuzz.py'), 'all', '4', '--jobs', '4', '--seed', '11'], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'emu_fuzz.py'), 'conv2ds,conv1d,fbank,melspec,model', '4', '--jobs', '4', '--seed', '11'], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if ' ok, ' in l]
-    assert len(lines) == 11 and all(' 0 failed, 0 workers crashed' in l for l in lines), r.stdout
+    assert len(lines) == 5 and all(' 0 failed, 0 workers crashed' in l for l in lines), r.stdout
 
 
 def test_tampered_descriptors_are_refused_or_harmless_never_a_crash():

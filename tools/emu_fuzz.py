@@ -339,7 +339,7 @@ def mode_env(mode):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('family', choices=sorted(FAMILIES) + ['all'])
+    ap.add_argument('family', help='one of ' + ', '.join(sorted(FAMILIES)) + ', a comma-separated list of them, or all')
     ap.add_argument('n', type=int, nargs='?', default=50)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--mode', default='plain')
@@ -360,7 +360,8 @@ def main():
     env = mode_env(args.mode)
     if args.device == 'emu':
         subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'emu', 'build_emu.py')], env={**env, 'LD_PRELOAD': ''}, stdout=subprocess.DEVNULL)
-    fams = sorted(FAMILIES) if args.family == 'all' else [args.family]
+    fams = sorted(FAMILIES) if args.family == 'all' else args.family.split(',')
+    assert all(f in FAMILIES for f in fams), fams
     t0 = time.time()
     bad = 0
     for fam in fams:
