@@ -114,7 +114,10 @@ inline half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *reinterpret
 inline void glds16(const void* gsrc, char* lds_wave_base) { emu::dma_issue(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc); }
 template <int N>
 inline void wait_vm() { emu::dma_retire(N); }
-inline void lds_barrier() { emu::syncthreads(); }   // (no drain of transfers in flight: s_waitcnt lgkmcnt(0) + s_barrier)
+inline void lds_barrier() {   // (no drain of transfers in flight: s_waitcnt lgkmcnt(0) + s_barrier)
+    emu::lds_read_retire(0);
+    emu::syncthreads();
+}
 inline void barrier_only() { emu::syncthreads(); }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc);
@@ -122,37 +125,39 @@ inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
 inline void glds16_untracked_so(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
     emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(sbase) + voff);
 }
-inline void lds_read1(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr)); }
+inline void lds_read1(half8v& d, unsigned addr) { emu::lds_read_issue(&d, lds_ptr(addr)); }
 template <int N>
-inline void lds_wait(half8v&, half8v&) {}
+inline void lds_wait(half8v&, half8v&) { emu::lds_read_retire(N); }
 template <int N>
-inline void lds_wait(half8v&) {}
+inline void lds_wait(half8v&) { emu::lds_read_retire(N); }
 template <int N>
-inline void lds_wait(half8v&, half8v&, half8v&) {}
+inline void lds_wait(half8v&, half8v&, half8v&) { emu::lds_read_retire(N); }
 template <int N>
-inline void lds_wait(half8v&, half8v&, half8v&, half8v&) {}
+inline void lds_wait(half8v&, half8v&, half8v&, half8v&) { emu::lds_read_retire(N); }
 template <int OFF>
-inline void lds_read1_off(half8v& d, unsigned addr) { d = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF)); }
+inline void lds_read1_off(half8v& d, unsigned addr) { emu::lds_read_issue(&d, lds_ptr(addr + OFF)); }
 
 template <int WAIT>
 inline void mfma8_step(float4v (&c0)[4], float4v (&c1)[4], const half8v& a0, const half8v& a1, const half8v (&b)[4]) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < 4; ++i) c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
     for (int i = 0; i < 4; ++i) c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
 }
 template <int OFF0, int OFF1>
 inline void lds_read2(half8v& d0, half8v& d1, unsigned addr) {
-    d0 = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF0));
-    d1 = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF1));
+    emu::lds_read_issue(&d0, lds_ptr(addr + OFF0));
+    emu::lds_read_issue(&d1, lds_ptr(addr + OFF1));
 }
 inline void lds_read4(half8v (&d)[4], unsigned addr) {
-    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 2048 * i));
+    for (int i = 0; i < 4; ++i) emu::lds_read_issue(&d[i], lds_ptr(addr + 2048 * i));
 }
 template <int OFF, int STRIDE>
 inline void lds_read5(half8v (&d)[5], unsigned addr) {
-    for (int i = 0; i < 5; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + OFF + i * STRIDE));
+    for (int i = 0; i < 5; ++i) emu::lds_read_issue(&d[i], lds_ptr(addr + OFF + i * STRIDE));
 }
 template <int WAIT>
 inline void mfma10_step(float4v* c0, float4v* c1, const half8v& a0, const half8v& a1, const half8v (&b)[5]) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < 5; ++i) {
         c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
         c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
@@ -160,10 +165,11 @@ inline void mfma10_step(float4v* c0, float4v* c1, const half8v& a0, const half8v
 }
 template <int N>
 inline void lds_read_tiles(half8v (&d)[N], unsigned addr) {
-    for (int i = 0; i < N; ++i) d[i] = *reinterpret_cast<const half8v*>(lds_ptr(addr + 1024 * i));
+    for (int i = 0; i < N; ++i) emu::lds_read_issue(&d[i], lds_ptr(addr + 1024 * i));
 }
 template <int N, int WAIT>
 inline void mfma_tiles2(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N]) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < N; ++i) {
         c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], c0[i]);
         c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], c1[i]);
@@ -171,11 +177,13 @@ inline void mfma_tiles2(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, co
 }
 template <int N, int WAIT>
 inline void mfma_tiles1(float4v (&c)[N], const half8v& a, const half8v (&b)[N]) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < N; ++i) c[i] = emu_mfma_f32_16x16x32_f16(a, b[i], c[i]);
 }
 template <int N, int WAIT>
 inline void mfma_tiles2_init(float4v (&c0)[N], float4v (&c1)[N], const half8v& a0, const half8v& a1, const half8v (&b)[N], const float4v& i0,
                              const float4v& i1) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < N; ++i) {
         c0[i] = emu_mfma_f32_16x16x32_f16(a0, b[i], i0);
         c1[i] = emu_mfma_f32_16x16x32_f16(a1, b[i], i1);
@@ -183,6 +191,7 @@ inline void mfma_tiles2_init(float4v (&c0)[N], float4v (&c1)[N], const half8v& a
 }
 template <int N, int WAIT>
 inline void mfma_tiles1_init(float4v (&c)[N], const half8v& a, const half8v (&b)[N], const float4v& init) {
+    emu::lds_read_retire(WAIT);
     for (int i = 0; i < N; ++i) c[i] = emu_mfma_f32_16x16x32_f16(a, b[i], init);
 }
 inline void glds16_untracked_so_fresh(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) { glds16_untracked_so(sbase, voff, lds_wave_base_addr); }

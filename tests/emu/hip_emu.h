@@ -30,6 +30,8 @@
 //       a wave mixes these transfers with other vector-memory operations (those are not counted here, so fewer transfers count as landed than on
 //       the device) -- a failure in this mode is a lead to check against the ISA, not a verdict.
 //       Where a kernel's counted wait includes tracked loads, the source says so with MV_VM_LOADS(n) and they are counted here too.
+//   MV_EMU_LDS = lazy   the hand-issued LDS fragment reads (inline-assembly ds_read_b128 behind the kernels' own counted s_waitcnt lgkmcnt) deliver
+//       their data only when a counted wait of the issuing thread retires them; until then the destination register holds NaNs (see lds_read_issue).
 //   -fsanitize=address (build_emu.py, MV_EMU_SANITIZE=address): every global buffer is a heap block and the dynamic LDS of a
 //       block is a heap block of exactly the launch's size, so an index that leaves its buffer -- also one that a GPU page
 //       would silently absorb -- is reported; the fibers announce their stack switches to the sanitizer.
@@ -83,6 +85,8 @@ struct Fiber {
     bool done = false;
     std::vector<PendingDma> dma;   // MV_EMU_DMA=lazy: this thread's transfers in flight, oldest first from dma_head
     size_t dma_head = 0;
+    std::vector<PendingDma> ldsq;  // MV_EMU_LDS=lazy: this thread's hand-issued LDS fragment reads in flight (dst = the destination register)
+    size_t ldsq_head = 0;
 };
 
 struct State {
@@ -102,6 +106,7 @@ struct State {
     // wave scratch for collectives: 64 lanes x 64 bytes x 2 operands
     std::vector<unsigned char> scratch;
     int dma_mode = 0;
+    int lds_mode = 0;
     const void* sched_stack = nullptr;   // (sanitizer builds) the scheduler's stack, learnt when the first fiber starts
     size_t sched_stack_size = 0;
 };
@@ -171,6 +176,43 @@ inline void dma_issue(char* dst, const void* src) {
     p.dst = dst;
     memcpy(p.data, src, 16);
     s.fibers[s.cur].dma.push_back(p);
+}
+
+// ---- MV_EMU_LDS = lazy: the hand-issued LDS fragment reads (ds_read_b128 in inline assembly, ordered by the kernels' own counted
+// s_waitcnt lgkmcnt inside lds_wait<N>() and the MFMA groups) deliver their 16 bytes only when a counted wait of the issuing thread retires them
+// (in order, the N youngest stay in flight); until then the destination register holds NaNs.  A group of MFMAs that starts on a fragment its wait
+// count does not cover computes NaNs.  LDS-only barriers (s_waitcnt lgkmcnt(0) + s_barrier) and __syncthreads() retire everything.
+inline int lds_mode_env() {
+    const char* e = getenv("MV_EMU_LDS");
+    if (e == nullptr || *e == 0 || strcmp(e, "eager") == 0) return 0;
+    if (strcmp(e, "lazy") == 0) return 1;
+    fprintf(stderr, "hip_emu: MV_EMU_LDS=%s not understood (eager | lazy)\n", e);
+    abort();
+}
+inline void lds_read_issue(void* dst_reg, const void* src) {
+    State& s = S();
+    if (s.lds_mode == 0) {
+        memcpy(dst_reg, src, 16);
+        return;
+    }
+    PendingDma p;
+    p.dst = static_cast<char*>(dst_reg);
+    memcpy(p.data, src, 16);
+    memset(dst_reg, 0xFF, 16);
+    s.fibers[s.cur].ldsq.push_back(p);
+}
+inline void lds_read_retire(size_t keep) {
+    State& s = S();
+    if (s.lds_mode == 0) return;
+    Fiber& f = s.fibers[s.cur];
+    while (f.ldsq.size() - f.ldsq_head > keep) {
+        const PendingDma& p = f.ldsq[f.ldsq_head++];
+        memcpy(p.dst, p.data, 16);
+    }
+    if (f.ldsq_head == f.ldsq.size()) {
+        f.ldsq.clear();
+        f.ldsq_head = 0;
+    }
 }
 
 inline void dma_note(int n) {   // MV_VM_LOADS: n tracked loads take their places in the counter's order
@@ -301,6 +343,7 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
     s.scratch.assign((size_t)nwaves * 2 * 64 * 64, 0);
     const SchedMode mode = sched_mode();
     s.dma_mode = dma_mode();
+    s.lds_mode = lds_mode_env();
     std::vector<int> order;
     unsigned long long sweep = 0;
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -324,6 +367,8 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t shmem, std::function<vo
                     f.done = false;
                     f.dma.clear();
                     f.dma_head = 0;
+                    f.ldsq.clear();
+                    f.ldsq_head = 0;
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = kStack;
@@ -374,6 +419,7 @@ inline T shfl_from(T v, int src_lane) {
 
 inline void __syncthreads() {
     if (emu::S().dma_mode == 2) emu::dma_retire(0);
+    emu::lds_read_retire(0);
     emu::syncthreads();
 }
 

@@ -8,6 +8,8 @@
 //   detectors dma <waited 0|1>     wave 0 fetches 1 KiB into LDS with an untracked LDS-DMA transfer and every wave reads it behind an LDS-only
 //                                  barrier; without the counted wait the default emulator (transfers land at issue) still gives the right
 //                                  answer, MV_EMU_DMA=lazy does not.  Prints the number of wrong values.
+//   detectors ldsread <waited 0|1> every thread issues a hand-scheduled LDS fragment read (lds_read1) of data it wrote itself and uses the register with or without
+//                                  the counted wait (lds_wait<0>): right either way on the default emulator, NaNs without the wait under MV_EMU_LDS=lazy.
 //   detectors uninit 0             reads dynamic LDS and a hipMalloc block that nobody wrote: zeros by default, -1 under MV_EMU_POISON=1.
 #include <arch/gfx950.h>
 
@@ -36,6 +38,22 @@ __global__ void dma_kernel(const int* src, int* out, int waited) {
     out[threadIdx.x] = reinterpret_cast<const int*>(smem)[threadIdx.x];
 }
 
+__global__ void lds_fragment_kernel(float* out, int waited) {
+    MV_DYN_SMEM(smem);
+    half8v* v = reinterpret_cast<half8v*>(smem);
+    const int t = threadIdx.x;
+    half8v mine;
+    for (int e = 0; e < 8; ++e) mine[e] = (half_t)(t + e);
+    v[t] = mine;
+    __syncthreads();
+    half8v got;
+    mv::lds_read1(got, mv::lds_addr(v + t));
+    if (waited) mv::lds_wait<0>(got);
+    float sum = 0.0f;
+    for (int e = 0; e < 8; ++e) sum += (float)got[e];
+    out[t] = sum;
+}
+
 __global__ void lds_read_kernel(int* out, int index) {
     MV_DYN_SMEM(smem);
     int* v = reinterpret_cast<int*>(smem);
@@ -55,6 +73,15 @@ int main(int argc, char** argv) {
         MV_LAUNCH(exchange_kernel, (1, 1, 1), (256, 1, 1), 256 * sizeof(int), nullptr, outp, n);
         int wrong = 0;
         for (int t = 0; t < 256; ++t) wrong += out[t] != (t >= 64 ? t - 64 : t) + 1;
+        printf("wrong=%d\n", wrong);
+        return 0;
+    }
+    if (strcmp(argv[1], "ldsread") == 0) {
+        std::vector<float> out(64, 0.0f);
+        float* outp = out.data();
+        MV_LAUNCH(lds_fragment_kernel, (1, 1, 1), (64, 1, 1), 1024, nullptr, outp, n);
+        int wrong = 0;
+        for (int t = 0; t < 64; ++t) wrong += !(out[t] == 8.0f * t + 28.0f);
         printf("wrong=%d\n", wrong);
         return 0;
     }

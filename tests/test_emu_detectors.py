@@ -21,9 +21,12 @@ def build(tmp_path, asan):
     return exe
 
 
-def run(exe, *args, sched=None, poison=False, dma=None):
+def run(exe, *args, sched=None, poison=False, dma=None, lds=None):
     env = dict(os.environ)
     env.pop('MV_EMU_DMA', None)
+    env.pop('MV_EMU_LDS', None)
+    if lds:
+        env['MV_EMU_LDS'] = lds
     if dma:
         env['MV_EMU_DMA'] = dma
     env.pop('MV_EMU_SCHED', None)
@@ -85,6 +88,13 @@ def test_missing_counted_wait_is_hidden_by_eager_transfers_and_shown_by_lazy_one
         assert run(exe, 'dma', 1, dma=dma).stdout.strip() == 'wrong=0'          # with wait_vm<0>() in front of the barrier
     r = run(exe, 'dma', 1, dma='sometimes')
     assert r.returncode != 0 and 'MV_EMU_DMA' in r.stderr
+
+
+def test_missing_lgkmcnt_wait_is_hidden_by_eager_fragment_reads_and_shown_by_lazy_ones(exe):
+    assert run(exe, 'ldsread', 0).stdout.strip() == 'wrong=0'                  # the default: a hand-issued LDS read delivers at once
+    assert run(exe, 'ldsread', 0, lds='lazy').stdout.strip() == 'wrong=64'     # only a counted wait delivers: the register still holds NaNs
+    assert run(exe, 'ldsread', 1, lds='lazy').stdout.strip() == 'wrong=0'
+    assert run(exe, 'ldsread', 1, lds='lazy', sched='reverse', dma='lazy').stdout.strip() == 'wrong=0'
 
 
 def test_fuzzer_runs_random_geometries_of_every_family_clean():

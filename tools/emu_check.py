@@ -1,7 +1,7 @@
 """Race / memory-safety sweep of the kernels on the SIMT emulator (no GPU): runs tests/test_emu_kernels.py -- every kernel family, the
 tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prints one summary line per mode.
 
-    python tools/emu_check.py                       # all modes: asan, ubsan, poison, lazy-dma, lazy-dma+reverse, reverse, waves-reverse, random:1, random:2
+    python tools/emu_check.py                       # all modes: asan, ubsan, poison, lazy-dma, lazy-dma+reverse, lazy-lds, lazy-all+random:1, reverse, waves-reverse, random:1, random:2
     python tools/emu_check.py asan random:7         # chosen modes
     python tools/emu_check.py -k conv2ds asan       # a subset of the cases (pytest -k)
 
@@ -15,6 +15,11 @@ tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prin
                   MV_EMU_DMA=lazy (+ poison, optionally with a thread order): the LDS-DMA transfers land as late as the kernels' counted s_waitcnt vmcnt allow (the N
                   youngest of a wait_vm<N>() stay in flight, only counted waits retire anything) -- a fragment read that no counted wait +
                   barrier covers sees NaNs.  The default emulator lets every transfer land at issue (the other extreme).
+  lazy-lds[+<order>]
+                  MV_EMU_LDS=lazy (+ poison): the hand-issued LDS fragment reads (inline-assembly ds_read_b128) deliver only when a counted
+                  s_waitcnt lgkmcnt of the issuing thread (lds_wait<N>, the WAIT of the MFMA groups) retires them; until then the destination
+                  register holds NaNs -- an MFMA group that starts on a fragment its wait count does not cover computes NaNs.
+  lazy-all[+<order>]  lazy-dma and lazy-lds together.
   reverse | waves-reverse | random:<seed>
                   MV_EMU_SCHED: the order in which a block's threads run between barriers; a dependency no barrier orders gives a wrong result
                   in one of them and the tests' expected values catch it (tests/test_emu_detectors.py shows both detectors at work).
@@ -41,6 +46,7 @@ def run_mode(mode, k, workers, slow):
     env.pop('MV_EMU_SANITIZE', None)
     env.pop('MV_EMU_POISON', None)
     env.pop('MV_EMU_DMA', None)
+    env.pop('MV_EMU_LDS', None)
     if slow:
         env['MV_SLOW_EMU'] = '1'
     logdir = None
@@ -56,6 +62,13 @@ def run_mode(mode, k, workers, slow):
                    UBSAN_OPTIONS=f'print_stacktrace=1:halt_on_error=1:log_path={logdir}/log')
     elif mode == 'poison':
         env['MV_EMU_POISON'] = '1'
+    elif mode.startswith('lazy-lds') or mode.startswith('lazy-all'):   # [+<order>]
+        env['MV_EMU_POISON'] = '1'
+        env['MV_EMU_LDS'] = 'lazy'
+        if mode.startswith('lazy-all'):
+            env['MV_EMU_DMA'] = 'lazy'
+        if '+' in mode:
+            env['MV_EMU_SCHED'] = mode.split('+', 1)[1]
     elif mode.startswith('lazy-dma'):   # lazy-dma | lazy-dma+reverse | lazy-dma+random:<seed>
         env['MV_EMU_POISON'] = '1'
         env['MV_EMU_DMA'] = 'lazy'
@@ -91,7 +104,7 @@ def run_mode(mode, k, workers, slow):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('modes', nargs='*', default=['asan', 'ubsan', 'poison', 'lazy-dma', 'lazy-dma+reverse', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
+    ap.add_argument('modes', nargs='*', default=['asan', 'ubsan', 'poison', 'lazy-dma', 'lazy-dma+reverse', 'lazy-lds', 'lazy-all+random:1', 'reverse', 'waves-reverse', 'random:1', 'random:2'])
     ap.add_argument('-k', default='')
     ap.add_argument('--slow', action='store_true', help='also the cases behind MV_SLOW_EMU=1 (CAM++ end to end, the largest conv2d cases)')
     ap.add_argument('-n', type=int, default=min(8, os.cpu_count() or 1))

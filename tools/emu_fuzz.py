@@ -316,7 +316,7 @@ def worker(family, n, seed):
 
 def mode_env(mode):
     env = dict(os.environ)
-    for k in ('MV_EMU_SCHED', 'MV_EMU_SANITIZE', 'MV_EMU_POISON', 'MV_EMU_DMA'):
+    for k in ('MV_EMU_SCHED', 'MV_EMU_SANITIZE', 'MV_EMU_POISON', 'MV_EMU_DMA', 'MV_EMU_LDS'):
         env.pop(k, None)
     llvm = '/opt/rocm/lib/llvm'
     if mode == 'asan':
@@ -328,6 +328,12 @@ def mode_env(mode):
         env.update(MV_EMU_SANITIZE='undefined', LD_PRELOAD=rt, UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
     elif mode == 'poison':
         env['MV_EMU_POISON'] = '1'
+    elif mode.startswith('lazy-lds') or mode.startswith('lazy-all'):
+        env.update(MV_EMU_POISON='1', MV_EMU_LDS='lazy')
+        if mode.startswith('lazy-all'):
+            env['MV_EMU_DMA'] = 'lazy'
+        if '+' in mode:
+            env['MV_EMU_SCHED'] = mode.split('+', 1)[1]
     elif mode.startswith('lazy-dma'):
         env.update(MV_EMU_POISON='1', MV_EMU_DMA='lazy')
         if '+' in mode:
