@@ -197,7 +197,13 @@ inline void mfma_tiles1_init(float4v (&c)[N], const half8v& a, const half8v (&b)
 inline void glds16_untracked_so_fresh(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) { glds16_untracked_so(sbase, voff, lds_wave_base_addr); }
 inline void mfma_hazard_pad() {}
 
-inline int device_cu_count() { return 8; }
+// compute units of the emulated chip: 8 by default; MV_EMU_CUS = 256 makes every test batch a sub-chip one (the chunk / small-batch launch forms the
+// real chip takes for a few utterances), MV_EMU_CUS = 1 a chip-filling one (persistent workgroups walking many tiles) -- the host side's plans follow it
+inline int device_cu_count() {
+    const char* e = getenv("MV_EMU_CUS");
+    const int n = e != nullptr ? atoi(e) : 0;
+    return n > 0 ? n : 8;
+}
 struct DeviceOnce { bool flag = false; };
 inline bool device_once_pending(DeviceOnce& o, int* slot) { *slot = 0; return !o.flag; }
 inline void device_once_done(DeviceOnce& o, int) { o.flag = true; }
