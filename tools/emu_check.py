@@ -24,8 +24,8 @@ tiny models end to end -- once per checking mode of tests/emu/hip_emu.h and prin
                   MV_EMU_SCHED: the order in which a block's threads run between barriers; a dependency no barrier orders gives a wrong result
                   in one of them and the tests' expected values catch it (tests/test_emu_detectors.py shows both detectors at work).
 MV_EMU_CUS=<n> in the environment sets the emulated chip's compute units (default 8): 256 = every batch a sub-chip one, 1 = a chip-filling one.
-The emulator does not model the memory counters (s_waitcnt) or asynchronous LDS-DMA: those are covered on the device by
-tools/stress_determinism.py and the bit-identity tests.
+What no mode models is time itself (how long a wait takes, MFMA-to-register hazards inside the assembly groups): that stays with the device-side
+detectors, tools/stress_determinism.py and the bit-identity tests.
 """
 import argparse
 import glob
