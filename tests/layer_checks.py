@@ -592,7 +592,9 @@ def bn_relu_rows_case(cdll, device, rows=77, C=520, ldx=528, ldy=544, seed=0):
     ref64 = torch.clamp(torch.relu(x.double()[:, :C] * sc.double() + sh.double()), max=65504.0)
     out = y.cpu()
     err = (out[:, :C].double() - ref64).abs()
-    tol = ref64.abs() * 2.0 ** -11 * 1.001 + 2.0 ** -25   # half an fp16 ulp of the exact value (subnormals: 2^-25)
+    # half an fp16 ulp of the exact value (subnormals: 2^-25) + one fp32 rounding of the product (the emulator's host build multiplies and adds
+    # separately where the device fuses: visible where x * scale and shift cancel)
+    tol = ref64.abs() * 2.0 ** -11 * 1.001 + 2.0 ** -25 + (x.double()[:, :C] * sc.double()).abs() * 2.0 ** -23
     assert bool((err <= tol).all()), (err - tol).max()
     assert bool((out[:, C:] == -7.0).all())
     assert out[0, 0] == 65504.0 and out[0, 1] == 0.0
@@ -740,7 +742,7 @@ FCM_BLOCK_C1_CASES = [
 ]
 
 
-def fcm_block_c1_case(cdll, device, B, F, T, seed=0, scale=4.0):
+def fcm_block_c1_case(cdll, device, B, F, T, seed=0, scale=4.0, outlier=True):
     """head.conv1 + bn1 + ReLU (campplus.py:262-264,283) and the first BasicResBlock in one launch (mv_fcm_block_c1_f16).  Reference in
     fp64: the conv of the fp32 features with the fp16-rounded folded weights, rounded to fp16 (the map the block's MFMAs read), then
     the block as in fcm_block_case."""
@@ -749,7 +751,9 @@ def fcm_block_c1_case(cdll, device, B, F, T, seed=0, scale=4.0):
     g = torch.Generator().manual_seed(seed)
     Fout = (F - 1) // 2 + 1
     feats = torch.randn(B, T, F, generator=g) * scale
-    feats[0, T // 2, F // 2] = 20000.0                    # far beyond fp16 precision of the hi part alone; exact as hi + lo
+    if outlier:   # (random-seed sweeps switch it off: where the outlier's large terms cancel in an output, the fp16 ulp of the intermediate maps -- the
+        #            reference's too -- is 1e-2 of that output: a property of the metric below, seed-dependent)
+        feats[0, T // 2, F // 2] = 20000.0                # far beyond fp16 precision of the hi part alone; exact as hi + lo
     c1w = torch.randn(32, 3, 3, generator=g) * 0.3        # [co][df][dt]
     c1b = torch.randn(32, generator=g) * 0.1
     w1 = (torch.randn(9, 32, 32, generator=g) * 0.08).half()

@@ -210,6 +210,44 @@ def g_model(r):
     return dict(case=case, frames=T)
 
 
+def g_fcm_conv(r):
+    # the single 3x3 FCM convs (band kernel): plain / strided in frequency, with the strided 1x1 shortcut tap or the identity residual
+    mode2 = r.choice([0, 0, 1, 2])
+    kw = dict(B=_pick(r, [1, 2, 3], [32]), Fin=r.choice([1, 2, 3, 5, 6, 9, 12, 20]), T=_pick(r, [5, 16, 33, 45, 70, 100, 319, 320, 321, 330], [298, 998]), sf=r.choice([1, 2]) if mode2 == 0 else 1,
+              mode2=mode2, seed=r.randrange(1000))
+    if mode2 == 1:
+        kw['sf2'] = r.choice([1, 2])
+    if mode2 == 0 and kw['sf'] == 2 and r.random() < 0.4:
+        kw['strided_out'] = True
+    return kw
+
+
+def g_fcm_c1(r):
+    return dict(B=_pick(r, [1, 2, 3], [64]), F=r.choice([3, 5, 9, 12, 40, 80]), T=_pick(r, [5, 16, 45, 70, 131, 319, 330], [298, 998]), seed=r.randrange(1000), outlier=False)
+
+
+def g_window(r):
+    kw = dict(B=_pick(r, [1, 2, 3], [64]), T=_pick(r, [9, 33, 70, 150, 300], [298, 998]), F_=r.choice([16, 40, 80]), k=5, cout=r.choice([64, 256, 512]), seed=r.randrange(1000))
+    if kw['cout'] % 256 == 0 and r.random() < 0.5:
+        kw['tile'] = 256
+    return kw
+
+
+def g_small(r):
+    # the small element-wise / reduction kernels of the paths: TSTP, the ERes2Net stem, BN + ReLU rows, int16 wave preparation
+    what = r.choice(['tstp', 'first', 'bn_relu', 'wave'])
+    if what == 'tstp':
+        s16 = r.random() < 0.5   # (the S16 map needs rows of whole 16-channel units: the case's ld is C + 8)
+        return dict(what=what, B=r.choice([1, 2, 3]), H=r.choice([1, 2, 5, 10]), W=_pick(r, [2, 3, 17, 38, 75], [298]), C=r.choice([24, 72, 120]) if s16 else r.choice([16, 72, 128]), s16=s16,
+                    seed=r.randrange(1000))
+    if what == 'first':
+        return dict(what=what, B=r.choice([1, 2]), T=_pick(r, [9, 33, 50, 131], [298]), F_=r.choice([16, 80]), C=r.choice([16, 32]), s16=r.random() < 0.5, seed=r.randrange(1000))
+    if what == 'bn_relu':
+        C = r.choice([8, 72, 520, 1024])
+        return dict(what=what, rows=_pick(r, [1, 5, 77, 300], [76288]), C=C, ldx=C + r.choice([0, 8]), ldy=C + r.choice([0, 24]), seed=r.randrange(1000))
+    return dict(what=what, B=r.choice([2, 3, 5]), L=_pick(r, [1, 7, 300, 5000, 16001], [480000]), normalize=r.random() < 0.5, seed=r.randrange(1000))
+
+
 def _budget(gen, cost, limit):
     """resample until the host-side reference of the case is affordable"""
     def g(r):
@@ -230,7 +268,8 @@ g_fcm_block = _budget(g_fcm_block, lambda k: k['B'] * k['T'] * k['Fin'] * 32 * 3
 g_melspec = _budget(g_melspec, lambda k: k['B'] * k['L'], 4e6)
 
 FAMILIES = {'conv2ds': g_conv2ds, 'conv2d': g_conv2d, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
-            'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block, 'model': g_model}
+            'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block, 'model': g_model, 'fcm_conv': g_fcm_conv, 'fcm_c1': g_fcm_c1, 'window': g_window,
+            'small': g_small}
 
 
 DEVICE = 'cpu'   # 'cpu' = the emulator build of the kernels; 'cuda' = the product library on the GPU
@@ -279,6 +318,16 @@ def run_case(family, kw):
         lc.melspec_case(cdll, DEVICE, wav, ratio, kw['args'])
     elif family == 'fcm_block':
         lc.fcm_block_case(cdll, DEVICE, **kw)
+    elif family == 'fcm_conv':
+        lc.fcm_conv_case(cdll, DEVICE, **kw)
+    elif family == 'fcm_c1':
+        lc.fcm_block_c1_case(cdll, DEVICE, **kw)
+    elif family == 'window':
+        lc.conv1d_window_case(cdll, DEVICE, **kw)
+    elif family == 'small':
+        kw = dict(kw)
+        what = kw.pop('what')
+        {'tstp': lc.tstp_case, 'first': lc.conv2d_first_case, 'bn_relu': lc.bn_relu_rows_case, 'wave': lc.wave_prepare_case}[what](cdll, DEVICE, **kw)
     elif family == 'model':
         lc.model_case(cdll, DEVICE, kw['case'], frames=kw['frames'])
     else:
@@ -298,7 +347,7 @@ def worker(family, n, seed):
             ok += 1
         except RuntimeError as ex:
             msg = str(ex)
-            if 'mv_' in msg or family.split('_')[0] in msg or 'unsupported' in msg or 'must' in msg:
+            if msg.startswith('libmvector_hip:') or 'mv_' in msg or family.split('_')[0] in msg or 'unsupported' in msg or 'must' in msg:
                 refused += 1
                 if os.environ.get('MV_FUZZ_VERBOSE'):
                     print(f'  refused: {msg[:160]}   {kw}', flush=True)
