@@ -98,7 +98,7 @@ def test_missing_lgkmcnt_wait_is_hidden_by_eager_fragment_reads_and_shown_by_laz
 
 
 def test_fuzzer_runs_random_geometries_of_every_family_clean():
-    """tools/emu_fuzz.py: a handful of seeded random launch geometries of five kernel families (the tool knows eleven) against the layer checks (the long runs and the
+    """tools/emu_fuzz.py: a handful of seeded random launch geometries of five kernel families (the tool knows fifteen) against the layer checks (the long runs and the
     checking modes are a tool, profiles/r13a_emu_check.log); a refused geometry is fine, a wrong value is not"""
     import sys
     root = os.path.dirname(HERE)
