@@ -340,3 +340,27 @@ def test_emu_fbank_without_time_mean_is_the_reference_kaldi_fbank_module():
         ref = torch.stack([frontend.kaldi_fbank(row.unsqueeze(0), sample_frequency=16000, num_mel_bins=80) for row in wav])
         out = fb(wav, workspace=ws)
         assert out.shape == ref.shape and (out - ref).abs().max() < 2e-3, (B, L, ws, (out - ref).abs().max())
+
+
+def test_emu_ecapa_without_global_context():
+    """EcapaTdnn(global_context=False) (ecapa_tdnn.py:159, pooling.py:105): the attention conv sees the frames alone (C instead of 3C input channels, no
+    per-utterance bias from the global mean / std) -- a constructor argument no golden uses; reference = the oracle's restatement of that branch"""
+    import mvector.models as M
+    from oracle import weights, models as omodels
+    from helpers import cos_dist
+    kw = dict(input_size=80, channels=[64, 64, 64, 64, 192], global_context=False)
+    m = M.EcapaTdnn(**kw)
+    sd = weights.make_state_dict(weights.shapes_of(m.state_dict()), 7)
+    x = torch.randn(2, 50, 80, generator=torch.Generator().manual_seed(3)) * 2
+    ref = omodels.ecapa_tdnn(sd, x, global_context=False)
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        assert cos_dist(m(x), ref).max().item() < 1e-10      # the host package's torch forward
+    cfg = lc._hip.MvEcapaCfg()
+    cfg.input_size, cfg.embd_dim = 80, 192
+    for i in range(5):
+        cfg.channels[i], cfg.kernel_sizes[i], cfg.dilations[i] = kw['channels'][i], [5, 3, 3, 3, 1][i], [1, 2, 3, 4, 1][i]
+    cfg.attention_channels, cfg.res2net_scale, cfg.se_channels, cfg.global_context = 128, 8, 128, 0
+    emb = lc._hip.Model('ecapa', cfg, sd, cdll=emu_cdll()).forward(x).cpu()
+    assert cos_dist(emb, ref).max().item() < 1e-5
