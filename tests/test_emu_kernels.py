@@ -364,3 +364,41 @@ def test_emu_ecapa_without_global_context():
     cfg.attention_channels, cfg.res2net_scale, cfg.se_channels, cfg.global_context = 128, 8, 128, 0
     emb = lc._hip.Model('ecapa', cfg, sd, cdll=emu_cdll()).forward(x).cpu()
     assert cos_dist(emb, ref).max().item() < 1e-5
+
+
+@pytest.mark.parametrize('cls,kw,T', [
+    ('EcapaTdnn', dict(input_size=80, channels=[64, 64, 64, 64, 192], res2net_scale=4, attention_channels=64, se_channels=64, embd_dim=256), 50),
+    ('EcapaTdnn', dict(input_size=40, channels=[64, 64, 64, 64, 192], kernel_sizes=[5, 5, 3, 3, 1], dilations=[1, 2, 2, 2, 1]), 50),
+    ('TDNN', dict(input_size=40, channels=256, embd_dim=128), 60),
+    ('ERes2Net', dict(input_size=16, m_channels=16, num_blocks=[1, 1, 1, 1], embd_dim=128), 41),
+    ('ERes2NetV2', dict(input_size=16, m_channels=16, num_blocks=[1, 1, 1, 1], embd_dim=64, base_width=32, scale=4), 41),
+])
+def test_emu_models_with_other_constructor_arguments(cls, kw, T):
+    """constructor arguments the goldens do not use (widths, Res2Net scale, kernel sizes / dilations, embedding size, base width): the native
+    handle built from the module's own configuration against the host package's torch forward of the same module (that forward and the
+    state_dict layout are pinned to the reference at the goldens' arguments)"""
+    import mvector.models as M
+    from oracle import weights
+    from helpers import cos_dist
+    m = getattr(M, cls)(**kw)
+    sd = weights.make_state_dict(weights.shapes_of(m.state_dict()), 9)
+    x = torch.randn(2, T, kw['input_size'], generator=torch.Generator().manual_seed(4)) * 2
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        ref = m(x)
+    ok, why = m._native_supported()
+    assert ok, why
+    kind = {'EcapaTdnn': 'ecapa', 'TDNN': 'tdnn', 'ERes2Net': 'eres2net', 'ERes2NetV2': 'eres2net'}[cls]
+    emb = lc._hip.Model(kind, m._native_cfg(), sd, cdll=emu_cdll()).forward(x).cpu()
+    assert cos_dist(emb, ref).max().item() < 1e-5
+
+
+def test_unsupported_constructor_arguments_are_named_not_approximated():
+    """what the native path does not build says so (and the CUDA forward raises NotImplementedError with that text): other pooling types, other
+    CAM++ growth rates"""
+    import mvector.models as M
+    ok, why = M.EcapaTdnn(input_size=80, channels=[64, 64, 64, 64, 192], pooling_type='TSP')._native_supported()
+    assert not ok and 'pooling_type' in why
+    ok, why = M.CAMPPlus(input_size=80, growth_rate=16)._native_supported()
+    assert not ok and 'growth_rate' in why
