@@ -402,3 +402,16 @@ def test_unsupported_constructor_arguments_are_named_not_approximated():
     assert not ok and 'pooling_type' in why
     ok, why = M.CAMPPlus(input_size=80, growth_rate=16)._native_supported()
     assert not ok and 'growth_rate' in why
+
+
+@pytest.mark.parametrize('frame_length', [20.0, 24.0, 25.0, 26.0, 27.0, 28.0, 30.0])
+def test_emu_fbank_other_frame_lengths_with_80_bins(frame_length):
+    """kaldi.fbank's frame_length is a method argument (featurizer.py:128).  Windows of 385 .. 416 samples (25 / 26 ms at 16 kHz) run fbank_tile_kernel, every other
+    one fbank_kernel -- the tile kernel's 16-group instantiation gave wrong features for windows of <= 384 samples (20 ms: 9.9 off; found by tools/emu_fuzz.py) and is
+    not selected any more"""
+    args = dict(sample_frequency=16000, num_mel_bins=80, frame_length=frame_length)
+    fb = lc._hip.Fbank(args, cdll=emu_cdll())
+    assert fb.info()['tile_kernel'] == (frame_length in (25.0, 26.0))
+    wav = frontend.synth_waveforms(2, 24080, seed=3)
+    ratio = torch.tensor([1.0, 0.6])
+    lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, args)

@@ -167,7 +167,27 @@ def g_fbank(r):
     B = _pick(r, [1, 2, 3], [8, 40, 130, 256])
     if B * n > 16e6:
         B = 3
-    return dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 40, 23]), seed=r.randrange(1000))
+    kw = dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 40, 23]), seed=r.randrange(1000))
+    if r.random() < 0.4:   # kaldi.fbank arguments other than the defaults (featurizer.py:128 passes method_args through): the generic kernel's geometries
+        extra = {}
+        if r.random() < 0.5:
+            extra['frame_length'] = r.choice([20.0, 25.0, 32.0])
+        if r.random() < 0.5:
+            extra['frame_shift'] = r.choice([8.0, 10.0, 12.5, 16.0])
+        if r.random() < 0.4:
+            extra['low_freq'] = r.choice([0.0, 20.0, 100.0])
+        if r.random() < 0.4:
+            extra['high_freq'] = r.choice([0.0, -400.0, 7600.0])
+        if r.random() < 0.3:
+            extra['preemphasis_coefficient'] = r.choice([0.0, 0.9])
+        if r.random() < 0.3:
+            extra['remove_dc_offset'] = False
+        if r.random() < 0.2:
+            extra['use_power'] = False
+        if r.random() < 0.2:
+            extra['use_log_fbank'] = False
+        kw['extra'] = extra
+    return kw
 
 
 def g_melspec(r):
@@ -306,7 +326,17 @@ def run_case(family, kw):
             g = torch.Generator().manual_seed(kw['seed'])
             ratio = torch.rand(kw['B'], generator=g) * 0.8 + 0.2
             ratio[0] = 1.0
-        lc.fbank_case(cdll, DEVICE, wav, ratio, dict(sample_frequency=16000, num_mel_bins=kw['bins']))
+        args = dict(sample_frequency=16000, num_mel_bins=kw['bins'], **kw.get('extra', {}))
+        if args.get('use_log_fbank', True) and kw['L'] >= 16 * args.get('frame_length', 25.0):
+            lc.fbank_case(cdll, DEVICE, wav, ratio, args)
+        else:   # linear mel energies (the layer check's absolute bars are those of log features), or no frame at all: relative to the block's scale
+            from mvector import _hip
+            out = _hip.Fbank(args, cdll=cdll)(wav.to(DEVICE), None if ratio is None else ratio.to(DEVICE)).cpu()
+            ref = frontend.audio_featurizer(wav, ratio, 'Fbank', args)
+            assert out.shape == ref.shape, (out.shape, ref.shape)
+            if ref.numel():
+                err, scale = (out - ref).abs().max().item(), ref.abs().max().item()
+                assert err <= 2e-4 * scale + 1e-6, (err, scale)
     elif family == 'melspec':
         from oracle import frontend
         wav = frontend.synth_waveforms(kw['B'], kw['L'], seed=kw['seed'])

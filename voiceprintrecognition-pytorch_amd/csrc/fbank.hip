@@ -837,7 +837,11 @@ constexpr int FBT_G0 = 7, FBT_G1 = 3;
 static bool fbank_tile_geometry_ok(const MvFbank* h) {
     const mv::FbankTables& t = h->tab;
     return t.passes == 2 && t.pass_steps[0] == 4 * FBT_G0 && t.pass_steps[1] == 4 * FBT_G1 && t.pass_split[0] == 1 &&
-           (h->nbins & 3) == 0 && h->nbins <= 128 && h->win <= mv::FBT_WIN_FLOATS && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
+           (h->nbins & 3) == 0 && h->nbins <= 128 && h->win > 12 * 32 && h->win <= 13 * 32 && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
+    // (windows of 385 .. 416 samples -- 25 ms at 16 kHz is 400 -- are the 13-group instantiation, the one every shipped configuration runs and every
+    // GPU test covers.  The 16-group instantiation for other windows gives WRONG features for windows of <= 384 samples (20 ms: max error 9.9
+    // against the oracle, found by tools/emu_fuzz.py at the end of round 4 with no GPU minutes left to debug it on the device): those geometries
+    // run fbank_kernel, which is right for them, until the tile kernel's short-window path is fixed and measured.)
 }
 
 static size_t fbank_tile_fixed_lds_bytes() {
