@@ -510,6 +510,10 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         const float npre = -a.preemph;
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
+            if (32 * n1 >= FBT_WIN_FLOATS) {   // (NG = 16: the LDS table holds FBT_WIN_FLOATS taps -- groups 14 and 15 lie behind every window this kernel takes; reading
+                z[n1] = cmake(0.0f, 0.0f);     //  "their" weights read the twiddle table that follows: the wrong features of windows <= 384 samples, section 8 of DESIGN.md)
+                continue;
+            }
             const float2v w2 = lds_load_unmerged(reinterpret_cast<const float2v*>(cwin + 32 * n1));
             const float y0 = fmaf(npre, r[n1][0], x0[n1]) - dc;   // taps beyond the window meet a zero weight
             const float y1 = fmaf(npre, x0[n1], x1[n1]) - dc;
@@ -839,9 +843,10 @@ static bool fbank_tile_geometry_ok(const MvFbank* h) {
     return t.passes == 2 && t.pass_steps[0] == 4 * FBT_G0 && t.pass_steps[1] == 4 * FBT_G1 && t.pass_split[0] == 1 &&
            (h->nbins & 3) == 0 && h->nbins <= 128 && h->win > 12 * 32 && h->win <= 13 * 32 && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
     // (windows of 385 .. 416 samples -- 25 ms at 16 kHz is 400 -- are the 13-group instantiation, the one every shipped configuration runs and every
-    // GPU test covers.  The 16-group instantiation for other windows gives WRONG features for windows of <= 384 samples (20 ms: max error 9.9
-    // against the oracle, found by tools/emu_fuzz.py at the end of round 4 with no GPU minutes left to debug it on the device): those geometries
-    // run fbank_kernel, which is right for them, until the tile kernel's short-window path is fixed and measured.)
+    // GPU test covers.  The 16-group instantiation for other windows gave WRONG features (20 ms: max error 9.9 against the oracle, found by
+    // tools/emu_fuzz.py at the end of round 4): its groups 14 and 15 read "window taps" behind the 448-tap LDS table.  The kernel is repaired (those
+    // groups are zero; 20 / 24 ms then agree with the oracle to 1.8e-4 on the emulator), but no GPU minutes were left to run it on the device, so
+    // those geometries keep running fbank_kernel until a device test re-admits them.)
 }
 
 static size_t fbank_tile_fixed_lds_bytes() {
