@@ -35,7 +35,7 @@ extern "C" {
 #define MV_ERR_WORKSPACE (-4)
 #define MV_ERR_MISSING_TENSOR (-5)
 
-#define MV_ABI_VERSION 3
+#define MV_ABI_VERSION 4
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -60,14 +60,27 @@ typedef struct MvFbankCfg {
     int32_t use_power;            /* 1 */
     int32_t use_log_fbank;        /* 1 */
     int32_t subtract_time_mean;   /* 1: featurizer.py:79 (mean over ALL frames, padded ones included) */
+    /* ---- since ABI 4: the further kaldi.fbank keyword arguments featurizer.py:128 forwards (**kwargs) ---- */
+    int32_t window_type;          /* MV_WINDOW_POVEY (0) | HAMMING | HANNING | RECTANGULAR | BLACKMAN */
+    float blackman_coeff;         /* 0.42 (window_type BLACKMAN only) */
+    int32_t snip_edges;           /* 1: frames lie inside the signal.  0: T = (L + shift / 2) / shift frames, the signal mirrored at both ends
+                                   * (needs the caller workspace of mv_fbank_forward_ws: the mirrored rows are written there first) */
+    int32_t subtract_mean;        /* 0.  kaldi.fbank's own subtract_mean: column means over the utterance's frames, BEFORE the wrapper's mean */
+    float min_duration;           /* 0 s: shorter signals give no frames */
+    int32_t kernel;               /* MV_FBANK_KERNEL_AUTO (0) | MV_FBANK_KERNEL_GENERIC (fbank_kernel) | MV_FBANK_KERNEL_TILE (fbank_tile_kernel;
+                                   * create fails when the mel geometry has no instantiation).  Both kernels implement the same contract; the
+                                   * field exists so that tests and tools/bench_fbank.py can run either on any geometry. */
 } MvFbankCfg;
+
+enum { MV_WINDOW_POVEY = 0, MV_WINDOW_HAMMING = 1, MV_WINDOW_HANNING = 2, MV_WINDOW_RECTANGULAR = 3, MV_WINDOW_BLACKMAN = 4 };
+enum { MV_FBANK_KERNEL_AUTO = 0, MV_FBANK_KERNEL_GENERIC = 1, MV_FBANK_KERNEL_TILE = 2 };
 
 typedef struct MvFbank MvFbank;
 
 void mv_fbank_default_cfg(MvFbankCfg* cfg);
 int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out);
 int mv_fbank_destroy(MvFbank* h);
-/* T = 1 + (L - window) / shift, or 0 when L < window (snip_edges=True) */
+/* T = 1 + (L - window) / shift, or 0 when L < window (snip_edges = 1); (L + shift / 2) / shift (snip_edges = 0); 0 below min_duration */
 int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_frames);
 /* which kernel this handle launches: *tile_kernel = 1 for fbank_tile_kernel (mel geometry of the reference configurations:
  * 80 bins / 16 kHz / 512-point FFT), 0 for the generic fbank_kernel; pass_steps[2] = FFT bins each mel MFMA pass walks */
@@ -95,6 +108,9 @@ int mv_fbank_forward_ws(const MvFbank* h, const float* wav, int32_t B, int64_t L
  * and zero-pads the features (collate_fn.py:11-19). */
 int mv_fbank_forward_varlen(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                             const int64_t* num_samples, float* out, mv_stream_t stream);
+/* the same with the caller workspace of mv_fbank_workspace_bytes(h, B, L): what snip_edges = 0 handles need (the mirrored rows) */
+int mv_fbank_forward_varlen_ws(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const int64_t* num_samples,
+                               float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Front-end 2: MelSpectrogram (power STFT, centre/reflect padding, HTK mel filterbank, NO log) +

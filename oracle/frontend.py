@@ -68,97 +68,120 @@ def povey_window(n):
     return torch.hann_window(n, periodic=False).pow(0.85)
 
 
-def kaldi_fbank(waveform, **kwargs):
-    """waveform: fp32 tensor [1, L] or [L] -> [m, num_mel_bins] log-mel energies."""
+def kaldi_window(window_type, n, blackman_coeff=0.42, dtype=torch.float32):
+    """torchaudio.compliance.kaldi._feature_window_function: symmetric (periodic=False) windows."""
+    if window_type == 'hanning':
+        return torch.hann_window(n, periodic=False, dtype=dtype)
+    if window_type == 'hamming':
+        return torch.hamming_window(n, periodic=False, alpha=0.54, beta=0.46, dtype=dtype)
+    if window_type == 'povey':
+        return torch.hann_window(n, periodic=False, dtype=dtype).pow(0.85)
+    if window_type == 'rectangular':
+        return torch.ones(n, dtype=dtype)
+    if window_type == 'blackman':
+        a = 2 * math.pi / (n - 1)
+        i = torch.arange(n, dtype=dtype)
+        return blackman_coeff - 0.5 * torch.cos(a * i) + (0.5 - blackman_coeff) * torch.cos(2 * a * i)
+    raise Exception('Invalid window type ' + window_type)
+
+
+def kaldi_strided_frames(w, size, shift, snip_edges):
+    """torchaudio.compliance.kaldi._get_strided: [L] -> [m, size].  snip_edges=False: m = (L + shift // 2) // shift frames over the signal with
+    its reversed copy attached to both ends (the last pad = size // 2 - shift // 2 samples of it in front; a negative pad trims the front)."""
+    L = w.shape[0]
+    if snip_edges:
+        if L < size:
+            return w.new_empty((0, size))
+        m = 1 + (L - size) // shift
+    else:
+        rev = torch.flip(w, [0])
+        m = (L + (shift // 2)) // shift
+        pad = size // 2 - shift // 2
+        if pad > 0:
+            w = torch.cat((rev[-pad:], w, rev), dim=0)
+        else:
+            w = torch.cat((w[-pad:], rev), dim=0)
+    return w.contiguous().as_strided((m, size), (shift, 1)).clone()   # (raises when the frames reach beyond the mirrored signal, like torchaudio)
+
+
+def _kaldi_fbank_impl(waveform, kwargs, dtype):
+    """torchaudio.compliance.kaldi.fbank (2.4.0) restated; dtype float32 = the oracle, float64 = the arbiter (same fp32 samples in)."""
     a = dict(FBANK_DEFAULTS)
     unknown = set(kwargs) - set(a)
     if unknown:
         raise TypeError(f'unexpected fbank arguments {sorted(unknown)}')
     a.update(kwargs)
-    for k, v in (('window_type', 'povey'), ('use_energy', False), ('vtln_warp', 1.0), ('dither', 0.0),
-                 ('snip_edges', True), ('subtract_mean', False), ('htk_compat', False)):
+    for k, v in (('vtln_warp', 1.0), ('dither', 0.0), ('round_to_power_of_two', True)):
         if a[k] != v:
             raise NotImplementedError(f'oracle restates only {k}={v!r}')
     w = torch.as_tensor(waveform, dtype=torch.float32)
     if w.dim() == 2:
         w = w[max(a['channel'], 0)]
+    w = w.to(dtype)
     sf = a['sample_frequency']
     shift = int(sf * a['frame_shift'] * 0.001)
     size = int(sf * a['frame_length'] * 0.001)
-    padded = _next_pow2(size) if a['round_to_power_of_two'] else size
+    padded = _next_pow2(size)
     L = w.shape[0]
     nbins = a['num_mel_bins']
-    if L < a['min_duration'] * sf or L < size:
-        return torch.empty(0, nbins)
-    m = 1 + (L - size) // shift
-    frames = w.as_strided((m, size), (shift, 1)).clone()
+    eps = torch.tensor(EPS_F32, dtype=dtype)
+    if L < a['min_duration'] * sf:
+        return torch.empty(0, dtype=dtype)
+    frames = kaldi_strided_frames(w, size, shift, a['snip_edges'])
+    if frames.shape[0] == 0:
+        return torch.empty(0, nbins + int(bool(a['use_energy'])), dtype=dtype)
+
+    def log_energy(fr):
+        le = torch.max(fr.pow(2).sum(1), eps).log()
+        return le if a['energy_floor'] == 0.0 else torch.max(le, torch.tensor(math.log(a['energy_floor']), dtype=dtype))
     if a['remove_dc_offset']:
         frames = frames - frames.mean(dim=1, keepdim=True)
+    if a['raw_energy']:
+        energy = log_energy(frames)
     pc = a['preemphasis_coefficient']
     if pc != 0.0:
         prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)  # replicate-pad on the left
         frames = frames - pc * prev
-    frames = frames * povey_window(size).unsqueeze(0)
+    frames = frames * kaldi_window(a['window_type'], size, a['blackman_coeff'], dtype).unsqueeze(0)
     if padded != size:
         frames = F.pad(frames, (0, padded - size))
+    if not a['raw_energy']:
+        energy = log_energy(frames)
     spec = torch.fft.rfft(frames).abs()
     if a['use_power']:
         spec = spec.pow(2.0)
-    banks = kaldi_mel_banks(nbins, padded, sf, a['low_freq'], a['high_freq'])
-    banks = F.pad(banks, (0, 1))
+    if dtype == torch.float32:
+        banks = kaldi_mel_banks(nbins, padded, sf, a['low_freq'], a['high_freq'])
+    else:
+        high = a['high_freq'] + 0.5 * sf if a['high_freq'] <= 0.0 else a['high_freq']
+        mel_lo = 1127.0 * math.log(1.0 + a['low_freq'] / 700.0)
+        mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
+        delta = (mel_hi - mel_lo) / (nbins + 1)
+        b = torch.arange(nbins, dtype=dtype).unsqueeze(1)
+        left, center, right = mel_lo + b * delta, mel_lo + (b + 1.0) * delta, mel_lo + (b + 2.0) * delta
+        mel_f = (1127.0 * (1.0 + ((sf / padded) * torch.arange(padded // 2, dtype=dtype)) / 700.0).log()).unsqueeze(0)
+        banks = torch.clamp(torch.min((mel_f - left) / (center - left), (right - mel_f) / (right - center)), min=0.0)
+    banks = F.pad(banks, (0, 1))   # zero weight on the Nyquist bin
     mel = torch.mm(spec, banks.T)
     if a['use_log_fbank']:
-        mel = torch.max(mel, torch.tensor(EPS_F32)).log()
+        mel = torch.max(mel, eps).log()
+    if a['use_energy']:
+        mel = torch.cat((mel, energy.unsqueeze(1)), dim=1) if a['htk_compat'] else torch.cat((energy.unsqueeze(1), mel), dim=1)
+    if a['subtract_mean']:
+        mel = mel - mel.mean(dim=0, keepdim=True)
     return mel
+
+
+def kaldi_fbank(waveform, **kwargs):
+    """waveform: fp32 tensor [1, L] or [L] -> [m, num_mel_bins] log-mel energies."""
+    return _kaldi_fbank_impl(waveform, kwargs, torch.float32)
 
 
 def kaldi_fbank_f64(waveform, **kwargs):
     """fp64 ARBITER of kaldi_fbank: the same steps on the same fp32 samples with every intermediate (window, filterbank, DC removal,
     pre-emphasis, FFT, power, mel sums, log) in float64.  Neither torchaudio nor the kernel computes this; it says which of two fp32
     evaluations that disagree on a near-floor log energy is the closer one (tests: |HIP - f64| against |oracle32 - f64|)."""
-    a = dict(FBANK_DEFAULTS)
-    a.update(kwargs)
-    w = torch.as_tensor(waveform, dtype=torch.float32)
-    if w.dim() == 2:
-        w = w[max(a['channel'], 0)]
-    w = w.double()
-    sf = a['sample_frequency']
-    shift = int(sf * a['frame_shift'] * 0.001)
-    size = int(sf * a['frame_length'] * 0.001)
-    padded = _next_pow2(size) if a['round_to_power_of_two'] else size
-    L = w.shape[0]
-    nbins = a['num_mel_bins']
-    if L < a['min_duration'] * sf or L < size:
-        return torch.empty(0, nbins, dtype=torch.float64)
-    m = 1 + (L - size) // shift
-    frames = w.as_strided((m, size), (shift, 1)).clone()
-    if a['remove_dc_offset']:
-        frames = frames - frames.mean(dim=1, keepdim=True)
-    pc = a['preemphasis_coefficient']
-    if pc != 0.0:
-        prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)
-        frames = frames - pc * prev
-    frames = frames * torch.hann_window(size, periodic=False, dtype=torch.float64).pow(0.85).unsqueeze(0)
-    if padded != size:
-        frames = F.pad(frames, (0, padded - size))
-    spec = torch.fft.rfft(frames).abs()
-    if a['use_power']:
-        spec = spec.pow(2.0)
-    num_fft_bins = padded // 2
-    nyquist = 0.5 * sf
-    high = a['high_freq'] + nyquist if a['high_freq'] <= 0.0 else a['high_freq']
-    mel_lo = 1127.0 * math.log(1.0 + a['low_freq'] / 700.0)
-    mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
-    delta = (mel_hi - mel_lo) / (nbins + 1)
-    b = torch.arange(nbins, dtype=torch.float64).unsqueeze(1)
-    left, center, right = mel_lo + b * delta, mel_lo + (b + 1.0) * delta, mel_lo + (b + 2.0) * delta
-    mel_f = (1127.0 * (1.0 + ((sf / padded) * torch.arange(num_fft_bins, dtype=torch.float64)) / 700.0).log()).unsqueeze(0)
-    banks = torch.clamp(torch.min((mel_f - left) / (center - left), (right - mel_f) / (right - center)), min=0.0)
-    banks = F.pad(banks, (0, 1))
-    mel = torch.mm(spec, banks.T)
-    if a['use_log_fbank']:
-        mel = torch.clamp(mel, min=EPS_F32).log()
-    return mel
+    return _kaldi_fbank_impl(waveform, kwargs, torch.float64)
 
 
 def audio_featurizer_fbank_f64(waveforms, input_lens_ratio=None, method_args=None):

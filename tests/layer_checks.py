@@ -797,23 +797,89 @@ def wave_prepare_case(cdll, device, B=5, L=5000, normalize=True, seed=0):
     return err
 
 
-def fbank_case(cdll, device, wav, ratio, method_args):
+# kaldi.fbank keyword arguments (featurizer.py:128 forwards **kwargs) x launch options, shared by the emulator and the device sweep.
+# (args, options): options = kernel ('auto' | 'generic' | 'tile'), cmn (False = bare kaldi.fbank rows, KaldiFbank), varlen (num_samples entry point)
+_FB80 = dict(sample_frequency=16000, num_mel_bins=80)
+FBANK_ARG_CASES = (
+    [(dict(_FB80, frame_length=fl), dict(kernel='tile')) for fl in (20, 24, 25, 30)] +          # fbank_tile_kernel<16> (20 / 24 / 30 ms) and <13> (25 ms)
+    [(dict(_FB80, frame_length=fl), dict(kernel='generic')) for fl in (20, 24, 25, 30, 32)] +   # fbank_kernel on the same geometries
+    [(dict(_FB80, frame_shift=12.5), dict(kernel='tile')), (dict(_FB80, frame_shift=12.5, frame_length=20), dict(kernel='generic'))] +
+    [(dict(sample_frequency=16000, num_mel_bins=nb), {}) for nb in (23, 40, 64, 128)] +
+    [(dict(sample_frequency=16000), {})] +                                                     # num_mel_bins default (23)
+    [(dict(sample_frequency=8000, num_mel_bins=nb), {}) for nb in (23, 40, 64)] +               # 200-sample window: kaldi's 256-point FFT
+    [(dict(sample_frequency=8000, num_mel_bins=40, frame_length=fl, frame_shift=fs), {}) for fl, fs in ((20, 10), (30, 12.5))] +
+    [(dict(sample_frequency=22050, num_mel_bins=64, frame_length=20), {}), (dict(sample_frequency=11025, num_mel_bins=40), {})] +  # odd window (275)
+    [(dict(_FB80, low_freq=100, high_freq=-400), {}), (dict(_FB80, high_freq=7000), {}), (dict(_FB80, low_freq=0), {}),
+     (dict(sample_frequency=8000, num_mel_bins=40, low_freq=60, high_freq=3800), {})] +
+    [(dict(_FB80, use_power=False), {}), (dict(_FB80, use_log_fbank=False), {}), (dict(_FB80, use_power=False, use_log_fbank=False), {}),
+     (dict(_FB80, remove_dc_offset=False), {}), (dict(_FB80, preemphasis_coefficient=0.0), {}),
+     (dict(_FB80, remove_dc_offset=False, preemphasis_coefficient=0.0), dict(kernel='generic')),
+     (dict(sample_frequency=16000, num_mel_bins=40, remove_dc_offset=False, preemphasis_coefficient=0.5), {})] +
+    [(dict(_FB80, window_type=w), {}) for w in ('hamming', 'hanning', 'rectangular', 'blackman')] +
+    [(dict(sample_frequency=16000, num_mel_bins=40, window_type='blackman', blackman_coeff=0.4), {})] +
+    [(dict(_FB80, snip_edges=False), {}), (dict(_FB80, snip_edges=False, frame_shift=30.0), {}), (dict(_FB80, snip_edges=False), dict(varlen=True)),
+     (dict(sample_frequency=8000, num_mel_bins=23, snip_edges=False), dict(cmn=False))] +
+    [(dict(_FB80, subtract_mean=True), {}), (dict(_FB80, subtract_mean=True), dict(cmn=False)), (dict(_FB80, min_duration=0.3), dict(varlen=True))] +
+    [(dict(_FB80), dict(cmn=False)), (dict(_FB80), dict(cmn=False, kernel='generic')), (dict(_FB80), dict(varlen=True, kernel='generic')),
+     (dict(sample_frequency=16000, num_mel_bins=23), dict(cmn=False))])
+
+
+def fbank_arguments_case(cdll, device, idx, B=3, seconds=0.5, seed=None):
+    """one entry of FBANK_ARG_CASES on B utterances of `seconds`: a fixed-length batch with a length mask (or bare rows / ragged true lengths)"""
+    args, opt = FBANK_ARG_CASES[idx]
     from oracle import frontend
-    fb = _hip.Fbank(method_args, cdll=cdll)
-    out = fb(wav.to(device), None if ratio is None else ratio.to(device)).cpu()
-    ref = frontend.audio_featurizer(wav, ratio, 'Fbank', method_args)
-    assert out.shape == ref.shape
-    d = (out - ref).abs()
+    sf = int(args.get('sample_frequency', 16000))
+    L = int(sf * seconds) + 37
+    wav = frontend.synth_waveforms(B, L, seed=100 + idx if seed is None else seed)
+    cmn = opt.get('cmn', True)
+    if opt.get('varlen'):
+        ns = torch.tensor([L, int(0.62 * L), int(0.45 * L), L - 1, int(0.8 * L)] * (B // 5 + 1))[:B]
+        return fbank_case(cdll, device, wav, None, args, kernel=opt.get('kernel', 'auto'), cmn=cmn, num_samples=ns)
+    ratio = torch.tensor([1.0, 0.61, 0.8, 0.33, 0.5] * (B // 5 + 1))[:B] if cmn else None
+    return fbank_case(cdll, device, wav, ratio, args, kernel=opt.get('kernel', 'auto'), cmn=cmn)
+
+
+def fbank_case(cdll, device, wav, ratio, method_args, kernel='auto', cmn=True, num_samples=None):
+    """HIP Fbank (+ time mean + mask) against the fp32 oracle AND the fp64 arbiter of the same algorithm.  `kernel`: 'auto' | 'generic' | 'tile'
+    (MvFbankCfg.kernel).  cmn=False: the bare kaldi.fbank rows (KaldiFbank, featurizer.py:114-132).  num_samples: the variable-length entry point
+    (every row on its own length, zero rows behind it).  Log energies are compared in absolute terms (the stated 1e-3); linear ones
+    (use_log_fbank=False) relative to the largest energy of the batch."""
+    from oracle import frontend
+    fb = _hip.Fbank(method_args, cdll=cdll, kernel=kernel, subtract_time_mean=cmn)
+    out = fb(wav.to(device), None if ratio is None else ratio.to(device), None if num_samples is None else num_samples.to(device)).cpu()
+
+    def oracle(fn):
+        if num_samples is not None:
+            rows = []
+            for w, n in zip(wav, num_samples.tolist()):
+                f = fn(w[:n].unsqueeze(0), **method_args)
+                f = f.reshape(-1, out.shape[2]) if f.numel() else f.new_zeros((0, out.shape[2]))
+                if cmn and f.shape[0]:
+                    f = f - f.mean(0, keepdim=True)
+                rows.append(torch.cat([f, f.new_zeros((out.shape[1] - f.shape[0], out.shape[2]))]))
+            return torch.stack(rows)
+        if not cmn:
+            assert ratio is None
+            return torch.stack([fn(w.unsqueeze(0), **method_args) for w in wav])
+        if fn is frontend.kaldi_fbank:
+            return frontend.audio_featurizer(wav, ratio, 'Fbank', method_args)
+        return frontend.audio_featurizer_fbank_f64(wav, ratio, method_args)
+    if out.numel() == 0:   # no frames (shorter than a window, or than min_duration -- where kaldi.fbank returns a bare empty tensor the reference's
+        assert wav.shape[0] == 0 or all(frontend.kaldi_fbank(w.unsqueeze(0), **method_args).numel() == 0 for w in wav)   # wrapper cannot stack)
+        return 0.0
+    ref = oracle(frontend.kaldi_fbank)
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    ref64 = oracle(frontend.kaldi_fbank_f64)
+    scale = 1.0 if dict(method_args).get('use_log_fbank', True) else max(float(ref64.abs().max()), 1e-30)
+    d = (out - ref).abs() / scale
     # Two fp32 evaluations of a near-floor log energy (a small difference of fp32 spectra) differ by more than either differs from the exact
     # value, so the STATED bar (SURVEY 8(c) / BASELINE.md 3: max-abs <= 1e-3) is asserted against the fp64 arbiter of the same algorithm, next
     # to the fp32 oracle's own distance from it; kernel vs fp32 oracle keeps the looser 2e-3.
     assert d.max().item() < 2e-3, d.max().item()
     assert d.mean().item() < 2e-5, d.mean().item()
-    if wav.numel() and out.numel():
-        ref64 = frontend.audio_featurizer_fbank_f64(wav, ratio, method_args)
-        e_hip, e_o32 = (out.double() - ref64).abs(), (ref.double() - ref64).abs()
-        assert e_hip.max().item() <= 1e-3, (e_hip.max().item(), e_o32.max().item())
-        assert e_hip.mean().item() <= 1e-5, e_hip.mean().item()
+    e_hip, e_o32 = (out.double() - ref64).abs() / scale, (ref.double() - ref64).abs() / scale
+    assert e_hip.max().item() <= 1e-3, (e_hip.max().item(), e_o32.max().item())
+    assert e_hip.mean().item() <= 1e-5, e_hip.mean().item()
     return d.max().item()
 
 

@@ -106,8 +106,21 @@ def test_emu_fbank_edge_cases():
     w = frontend.synth_waveforms(1, 4000, seed=9)
     ref = frontend.audio_featurizer(w, None, 'Fbank', dict(sample_frequency=16000))
     assert (fb23(w) - ref).abs().max() < 2e-3
-    with pytest.raises(RuntimeError, match='512-point'):
-        lc._hip.Fbank(dict(sample_frequency=8000, num_mel_bins=40), cdll=emu_cdll())
+    with pytest.raises(RuntimeError, match='512 points'):   # 40 ms at 16 kHz = 640 samples: kaldi pads to 1024
+        lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40, frame_length=40), cdll=emu_cdll())
+    with pytest.raises(RuntimeError, match='fbank_tile_kernel is instantiated'):
+        lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40), cdll=emu_cdll(), kernel='tile')
+    for bad in (dict(dither=1.0), dict(use_energy=True), dict(vtln_warp=1.1), dict(round_to_power_of_two=False)):
+        with pytest.raises(NotImplementedError):
+            lc._hip.Fbank(dict(FB, **bad), cdll=emu_cdll())
+    with pytest.raises(TypeError):
+        lc._hip.Fbank(dict(FB, n_fft=512), cdll=emu_cdll())
+    with pytest.raises(Exception, match='Invalid window type'):
+        lc._hip.Fbank(dict(FB, window_type='kaiser'), cdll=emu_cdll())
+    snip = lc._hip.Fbank(dict(FB, snip_edges=False), cdll=emu_cdll())
+    assert snip.num_frames(16000) == 100 and snip.num_frames(79) == 0 and snip.num_frames(80) == 1
+    with pytest.raises(RuntimeError, match='too short to be mirrored'):   # (torchaudio raises on these as well: its mirrored signal ends)
+        snip(torch.zeros(1, 100))
 
 
 @pytest.mark.skipif(os.environ.get('MV_SLOW_EMU') != '1', reason='~3 min under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_backbones_long_and_short_utterances)')
@@ -404,14 +417,23 @@ def test_unsupported_constructor_arguments_are_named_not_approximated():
     assert not ok and 'growth_rate' in why
 
 
-@pytest.mark.parametrize('frame_length', [20.0, 24.0, 25.0, 26.0, 27.0, 28.0, 30.0])
+@pytest.mark.parametrize('frame_length', [20.0, 24.0, 25.0, 26.0, 27.0, 28.0, 30.0, 32.0])
 def test_emu_fbank_other_frame_lengths_with_80_bins(frame_length):
-    """kaldi.fbank's frame_length is a method argument (featurizer.py:128).  Windows of 385 .. 416 samples (25 / 26 ms at 16 kHz) run fbank_tile_kernel, every other
-    one fbank_kernel -- the tile kernel's 16-group instantiation gave wrong features for windows of <= 384 samples (20 ms: 9.9 off; found by tools/emu_fuzz.py) and is
-    not selected any more"""
+    """kaldi.fbank's frame_length is a method argument (featurizer.py:128).  Windows of 385 .. 416 samples (25 / 26 ms at 16 kHz) run the 13-group instantiation of
+    fbank_tile_kernel, every other even window the 16-group one -- which gave wrong features for windows of <= 384 samples until round 5 (20 ms: 9.9 off; its LDS window
+    table was 448 taps, groups 14 / 15 read behind it; found by tools/emu_fuzz.py).  Both kernels, every window, against the oracle."""
     args = dict(sample_frequency=16000, num_mel_bins=80, frame_length=frame_length)
-    fb = lc._hip.Fbank(args, cdll=emu_cdll())
-    assert fb.info()['tile_kernel'] == (frame_length in (25.0, 26.0))
+    assert lc._hip.Fbank(args, cdll=emu_cdll()).info()['tile_kernel']
+    assert not lc._hip.Fbank(args, cdll=emu_cdll(), kernel='generic').info()['tile_kernel']
     wav = frontend.synth_waveforms(2, 24080, seed=3)
     ratio = torch.tensor([1.0, 0.6])
     lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, args)
+    lc.fbank_case(emu_cdll(), 'cpu', wav, ratio, args, kernel='generic')
+
+
+@pytest.mark.parametrize('idx', range(len(lc.FBANK_ARG_CASES)))
+def test_emu_fbank_arguments(idx):
+    """the kaldi.fbank keyword arguments featurizer.py:128 forwards (frame length / shift, bin counts, sample rates incl. kaldi's 256-point FFT at 8 kHz, band edges,
+    magnitude / linear outputs, DC / pre-emphasis switches, the five window types, snip_edges=False, subtract_mean, min_duration) x (kernel, bare rows, true lengths):
+    tests/layer_checks.py::FBANK_ARG_CASES, the list the device sweep (test_gpu_fbank_arguments) runs at 3 s"""
+    lc.fbank_arguments_case(emu_cdll(), 'cpu', idx)

@@ -28,7 +28,7 @@ def product_lib():
 def test_gpu_library_is_the_hip_build():
     from mvector import _hip
     lib = product_lib()
-    assert lib.mv_abi_version() == 3
+    assert lib.mv_abi_version() == 4
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
@@ -174,6 +174,130 @@ def test_gpu_fbank_one_handle_two_streams_is_reentrant():
 def test_gpu_bn_relu_rows():
     lc.bn_relu_rows_case(product_lib(), DEV)
     lc.bn_relu_rows_case(product_lib(), DEV, rows=38144, C=1024, ldx=1024, ldy=1024, seed=3)
+
+
+def test_gpu_fbank_golden_fixed_and_ragged():
+    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    out = fb(wav.to(DEV)).cpu().numpy()
+    d = np.abs(out - z['fbank'])
+    assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+    lens = z['lens']
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(lens):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    outv = fb(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy()
+    dv = np.abs(outv - z['fbank_var'])
+    assert dv.max() < 2e-3 and dv.mean() < 2e-5, (dv.max(), dv.mean())
+    for i, n in enumerate(lens):  # frames beyond round_half_even(ratio*T) are exactly zero (Q2/Q3)
+        ml = int(torch.round(torch.tensor(n / 48000, dtype=torch.float32) * 298).item())
+        assert np.all(outv[i, ml:] == 0) and np.any(outv[i, ml - 1] != 0)
+
+
+def test_gpu_featurizer_matches_reference_wrapper_golden():
+    """AudioFeaturizer.forward on the HIP path against tests/golden/featurizer_ref.npz = the REFERENCE's own featurizer.py wrapper
+    (KaldiFbank loop, transposes, CMN, torch.round mask) run by oracle/make_golden.py under a stub torchaudio (a3 pin)."""
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    z = np.load(os.path.join(GOLDEN, 'featurizer_ref.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(z['lens']):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    ratio, half = torch.from_numpy(z['ratio']).to(DEV), torch.from_numpy(z['half']).to(DEV)
+    fz = AudioFeaturizer('Fbank', method_args=FB)
+
+    def close(got, want):
+        d = np.abs(got - want)
+        assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+        # masked frames are exactly zero, frame by frame, on both sides (Q3: the edge sits where torch.round puts it)
+        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
+    out = fz(wav[:2].to(DEV))
+    assert out.is_cuda and out.dtype == torch.float32
+    close(out.cpu().numpy(), z['fbank'])
+    close(fz(wav_var.to(DEV), ratio).cpu().numpy(), z['fbank_var'])
+    close(fz(wav_var.to(DEV), half).cpu().numpy()[:, :24], z['fbank_half'])
+    close(fz(wav[1, :16000].to(DEV)).cpu().numpy(), z['fbank_1d'])  # 1-D input is unsqueezed (featurizer.py:63-64)
+    mz = AudioFeaturizer('MelSpectrogram', method_args={})
+    scale = float(np.abs(z['mel']).max())
+    for got, want in ((mz(wav[:2].to(DEV)), z['mel']), (mz(wav_var.to(DEV), ratio)[2:], z['mel_var']),
+                      (mz(wav_var[:1].to(DEV), half[:1]), z['mel_half'])):
+        got = got.cpu().numpy()
+        assert np.abs(got - want).max() < 2e-4 * scale
+        assert np.array_equal(np.all(got == 0, axis=-1), np.all(want == 0, axis=-1))
+    readme = dict(sample_rate=16000, n_fft=1024, win_length=1024, hop_length=320, f_min=50, f_max=14000, n_mels=64)
+    got = AudioFeaturizer('MelSpectrogram', method_args=readme)(wav[:1].to(DEV)).cpu().numpy()
+    assert np.abs(got - z['mel_readme']).max() < 2e-4 * float(np.abs(z['mel_readme']).max())
+
+
+def test_gpu_fbank_ragged_strides_and_edges():
+    wav = frontend.synth_waveforms(3, 16000 + 37, seed=3)
+    wav[2, 9000:] = 0
+    lc.fbank_case(product_lib(), DEV, wav, torch.tensor([1.0, 0.61, 9000 / 16037]), FB)
+    from mvector import _hip
+    fb = _hip.Fbank(FB)
+    assert fb(torch.zeros(2, 399, device=DEV)).shape == (2, 0, 80)
+    assert fb(torch.zeros(1, 1200, device=DEV)).abs().max().item() < 1e-5
+    z = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    real = torch.from_numpy(z['pcm16'].astype(np.float32) / 32768.0).to(DEV)
+    assert np.abs(fb(real).cpu().numpy() - z['fbank']).max() < 2e-3
+
+
+@pytest.mark.parametrize('kernel', ['generic', 'tile'])
+def test_gpu_fbank_both_kernels_on_the_committed_goldens(kernel):
+    """fbank_kernel and fbank_tile_kernel (MvFbankCfg.kernel) each against the committed fixtures: frontend.npz (fixed + ragged), the real-audio
+    golden, and the full 256 x 3 s batch against the fp64 arbiter at the stated 1e-3"""
+    from mvector import _hip
+    fb = _hip.Fbank(FB, kernel=kernel)
+    assert fb.info()['tile_kernel'] == (kernel == 'tile')
+    z = np.load(os.path.join(GOLDEN, 'frontend.npz'))
+    wav = frontend.synth_waveforms(4, 48000)
+    d = np.abs(fb(wav.to(DEV)).cpu().numpy() - z['fbank'])
+    assert d.max() < 2e-3 and d.mean() < 2e-5, (d.max(), d.mean())
+    wav_var = torch.zeros(4, 48000)
+    for i, n in enumerate(z['lens']):
+        wav_var[i, :n] = wav[i, :n] * (1e-4 if i == 3 else 1.0)
+    dv = np.abs(fb(wav_var.to(DEV), torch.from_numpy(z['ratio']).to(DEV)).cpu().numpy() - z['fbank_var'])
+    assert dv.max() < 2e-3 and dv.mean() < 2e-5, (dv.max(), dv.mean())
+    zr = np.load(os.path.join(GOLDEN, 'real_audio.npz'))
+    real = torch.from_numpy(zr['pcm16'].astype(np.float32) / 32768.0).to(DEV)
+    assert np.abs(fb(real).cpu().numpy() - zr['fbank']).max() < 2e-3
+    big = frontend.synth_waveforms(256, 48000)
+    out = fb(big.to(DEV)).cpu()
+    ref64 = frontend.audio_featurizer_fbank_f64(big, None, FB)
+    e = (out.double() - ref64).abs()
+    print(f'{kernel}: 256 x 3 s |HIP - f64| max {e.max().item():.3e} mean {e.mean().item():.3e}')
+    assert e.max().item() <= 1e-3 and e.mean().item() <= 1e-5
+
+
+@pytest.mark.parametrize('idx', range(len(lc.FBANK_ARG_CASES)))
+def test_gpu_fbank_arguments(idx):
+    """HIP vs the fp32 oracle AND the fp64 arbiter over the kaldi.fbank keyword arguments featurizer.py:128 forwards (tests/layer_checks.py::
+    FBANK_ARG_CASES: frame_length 20 / 24 / 25 / 30 / 32 ms on BOTH kernels -- fbank_tile_kernel<13> and <16>, fbank_kernel --, frame_shift 10 / 12.5,
+    23 / 40 / 64 / 80 / 128 bins, 8 / 11.025 / 16 / 22.05 kHz, band edges, use_power / use_log_fbank / remove_dc_offset / preemphasis switches,
+    the five window types, snip_edges=False, subtract_mean, min_duration; bare kaldi.fbank rows and true-length batches): 5 x 3 s with a ragged
+    mask, and 260 x 0.5 s (more utterances than CUs)"""
+    lc.fbank_arguments_case(product_lib(), DEV, idx, B=5, seconds=3.0)
+    lc.fbank_arguments_case(product_lib(), DEV, idx, B=260, seconds=0.5, seed=7)
+
+
+def test_gpu_kaldi_fbank_module_matches_oracle():
+    """KaldiFbank (featurizer.py:114-132: kaldi.fbank per utterance, [B, F, T], NO time mean) on CUDA tensors against oracle.frontend.kaldi_fbank;
+    [B, 1, L] rows as the reference's own caller passes them; the default 23 bins (generic kernel) and 80 bins (tile kernel)"""
+    from mvector.data_utils.featurizer import KaldiFbank
+    wav = frontend.synth_waveforms(6, 48000, seed=41)
+    for kwargs in (FB, dict(sample_frequency=16000), dict(sample_frequency=8000, num_mel_bins=40, frame_length=30)):
+        mod = KaldiFbank(**kwargs)
+        out = mod(wav.to(DEV))
+        F_ = kwargs.get('num_mel_bins', 23)
+        ref = torch.stack([frontend.kaldi_fbank(w.unsqueeze(0), **kwargs).t() for w in wav])
+        ref64 = torch.stack([frontend.kaldi_fbank_f64(w.unsqueeze(0), **kwargs).t() for w in wav])
+        assert out.is_cuda and out.shape == ref.shape == (6, F_, ref.shape[2])
+        assert (out.cpu() - ref).abs().max().item() < 2e-3
+        assert (out.cpu().double() - ref64).abs().max().item() <= 1e-3
+        assert torch.equal(mod(wav.to(DEV).unsqueeze(1)), out)
+        assert torch.allclose(mod(wav), ref, atol=1e-4)   # CPU tensors: the batched torch restatement
 
 
 def test_gpu_fbank_full_batch_properties():

@@ -26,7 +26,7 @@ def test_library_built_and_exports_every_declared_symbol():
     from mvector import _hip
     assert set(_hip.EXPORTED_SYMBOLS) == set(syms)
     _hip.bind(cdll)
-    assert cdll.mv_abi_version() == 3
+    assert cdll.mv_abi_version() == 4
     assert cdll.mv_conv1d_packed_elems(192, 80, 5) == 192 * 5 * 128
 
 

@@ -167,11 +167,26 @@ def g_fbank(r):
     B = _pick(r, [1, 2, 3], [8, 40, 130, 256])
     if B * n > 16e6:
         B = 3
-    kw = dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 40, 23]), seed=r.randrange(1000))
-    if r.random() < 0.4:   # kaldi.fbank arguments other than the defaults (featurizer.py:128 passes method_args through): the generic kernel's geometries
+    kw = dict(B=B, L=n, ragged=r.random() < 0.5, bins=r.choice([80, 80, 80, 40, 23, 64, 128, 17]), seed=r.randrange(1000))
+    kw['kernel'] = r.choice(['auto', 'auto', 'generic'])   # (80 bins at 16 kHz: auto = fbank_tile_kernel)
+    if r.random() < 0.15:
+        kw['cmn'] = False     # bare kaldi.fbank rows (KaldiFbank)
+    elif r.random() < 0.15:
+        kw['varlen'] = True   # true lengths per row (the evaluation path)
+    if r.random() < 0.5:   # kaldi.fbank arguments other than the defaults (featurizer.py:128 passes method_args through)
         extra = {}
         if r.random() < 0.5:
-            extra['frame_length'] = r.choice([20.0, 25.0, 32.0])
+            extra['frame_length'] = r.choice([10.0, 20.0, 24.0, 25.0, 26.0, 30.0, 32.0])
+        if r.random() < 0.2:
+            extra['sample_frequency'] = r.choice([8000, 11025, 16000, 22050])
+        if r.random() < 0.3:
+            extra['window_type'] = r.choice(['hamming', 'hanning', 'rectangular', 'blackman', 'povey'])
+        if r.random() < 0.2:
+            extra['snip_edges'] = False
+        if r.random() < 0.15:
+            extra['subtract_mean'] = True
+        if r.random() < 0.1:
+            extra['min_duration'] = r.choice([0.02, 0.5, 1.0])
         if r.random() < 0.5:
             extra['frame_shift'] = r.choice([8.0, 10.0, 12.5, 16.0])
         if r.random() < 0.4:
@@ -326,17 +341,24 @@ def run_case(family, kw):
             g = torch.Generator().manual_seed(kw['seed'])
             ratio = torch.rand(kw['B'], generator=g) * 0.8 + 0.2
             ratio[0] = 1.0
-        args = dict(sample_frequency=16000, num_mel_bins=kw['bins'], **kw.get('extra', {}))
-        if args.get('use_log_fbank', True) and kw['L'] >= 16 * args.get('frame_length', 25.0):
-            lc.fbank_case(cdll, DEVICE, wav, ratio, args)
-        else:   # linear mel energies (the layer check's absolute bars are those of log features), or no frame at all: relative to the block's scale
-            from mvector import _hip
-            out = _hip.Fbank(args, cdll=cdll)(wav.to(DEVICE), None if ratio is None else ratio.to(DEVICE)).cpu()
-            ref = frontend.audio_featurizer(wav, ratio, 'Fbank', args)
-            assert out.shape == ref.shape, (out.shape, ref.shape)
-            if ref.numel():
-                err, scale = (out - ref).abs().max().item(), ref.abs().max().item()
-                assert err <= 2e-4 * scale + 1e-6, (err, scale)
+        args = dict(dict(sample_frequency=16000, num_mel_bins=kw['bins']), **kw.get('extra', {}))
+        cmn, ns = kw.get('cmn', True), None
+        if kw.get('varlen'):
+            g = torch.Generator().manual_seed(kw['seed'] + 1)
+            ns = (torch.rand(kw['B'], generator=g) * kw['L']).long().clamp(min=1)
+            ns[0] = kw['L']
+            ratio = None
+        if not cmn:
+            ratio = None
+        if not args.get('snip_edges', True):   # rows the reference raises on (its mirrored signal ends before the last frame): refused / zero rows here
+            size, shift = int(args['sample_frequency'] * args.get('frame_length', 25.0) * 0.001), int(args['sample_frequency'] * args.get('frame_shift', 10.0) * 0.001)
+
+            def mirrors(n):
+                m, pad = (n + shift // 2) // shift, size // 2 - shift // 2
+                return m == 0 or (pad <= n and (m - 1) * shift - pad + size <= 2 * n)
+            if not all(mirrors(int(n)) for n in (ns.tolist() if ns is not None else [kw['L']])):
+                raise RuntimeError('mv_fbank_forward: (fuzzer) snip_edges=False on a signal too short to mirror')
+        lc.fbank_case(cdll, DEVICE, wav, ratio, args, kernel=kw.get('kernel', 'auto'), cmn=cmn, num_samples=ns)
     elif family == 'melspec':
         from oracle import frontend
         wav = frontend.synth_waveforms(kw['B'], kw['L'], seed=kw['seed'])

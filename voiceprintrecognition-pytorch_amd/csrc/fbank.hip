@@ -65,6 +65,7 @@ struct FbankArgs {
     float inv_win;
     int remove_dc, use_power, use_log, cmn;
     int64_t L;
+    int64_t min_len;  // rows of fewer samples have no frames (the window, or min_duration when that is longer)
     int tile_rows;    // fbank_tile_kernel: the first tile_rows (multiple of 4) frames of the utterance's [T, nbins] block stay in LDS
                       // until the time mean is known; later frames take the write / re-read / rewrite route through global memory
     // fbank_tile_kernel: the time sum of an utterance has ONE order whatever the launch form, so a row's bits depend on its own length only,
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
     int T = a.T;
     if (a.num_samples != nullptr) {
         const int64_t ns = a.num_samples[b];
-        const int64_t tb = ns < a.win ? 0 : 1 + (ns - a.win) / a.shift;
+        const int64_t tb = ns < a.min_len ? 0 : 1 + (ns - a.win) / a.shift;
         T = (int)(tb < a.T ? tb : a.T);
     }
     const int nbins = a.nbins;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
 constexpr int FBT_WAVES = 8;
 constexpr int FBT_ROW = 65;                      // complex elements per transpose row: [4 frames][16] + 1 pad
 constexpr int FBT_SLOT_FLOATS = 16 * FBT_ROW * 2;  // 2080 floats = 8320 B per wave
-constexpr int FBT_WIN_FLOATS = 448;              // window taps kept in LDS (the taps the 13 / 14 sample groups of a <= 448-sample window touch)
+constexpr int fbt_win_floats(int ng) { return 32 * ng; }   // window taps kept in LDS: the taps the NG sample groups touch
 constexpr int FBT_PSTR = 292;                    // floats between the power rows of the wave's four frames (36 banks apart)
 
 template <int NG, bool VEC2, int G0, int G1>
@@ -391,8 +392,9 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     constexpr int THREADS = FBT_WAVES * 64;
     MV_DYN_SMEM(smem);
     float* xbuf = reinterpret_cast<float*>(smem);                  // [FBT_WAVES][FBT_SLOT_FLOATS]
-    float* lwin = xbuf + FBT_WAVES * FBT_SLOT_FLOATS;              // [FBT_WIN_FLOATS] 0.5 * window
-    float* ltw1 = lwin + FBT_WIN_FLOATS;                           // [16 k1][16 n2][2] stage twiddles
+    constexpr int WINF = fbt_win_floats(NG);
+    float* lwin = xbuf + FBT_WAVES * FBT_SLOT_FLOATS;              // [32 NG] 0.5 * window
+    float* ltw1 = lwin + WINF;                                     // [16 k1][16 n2][2] stage twiddles
     float* tile = ltw1 + 512;                                      // [tile_rows][nbins]
     float* colsum = xbuf;                                          // [FBT_WAVES][128] then mean[128], after the frame loop
 
@@ -407,13 +409,13 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
     int T = a.T;
     if (a.num_samples != nullptr) {
         const int64_t ns = a.num_samples[b];
-        const int64_t tb = ns < a.win ? 0 : 1 + (ns - a.win) / a.shift;
+        const int64_t tb = ns < a.min_len ? 0 : 1 + (ns - a.win) / a.shift;
         T = (int)(tb < a.T ? tb : a.T);
     }
     const int nbins = a.nbins;
 
     // ---- per-lane constants (registers) ----
-    for (int i = tid; i < FBT_WIN_FLOATS; i += THREADS) lwin[i] = a.tab.window_half[i];
+    for (int i = tid; i < WINF; i += THREADS) lwin[i] = a.tab.window_half[i];
     const float* cwin = lwin + 2 * l16;  // 0.5 * window at samples 32 n1 + 2 l16 (+1): one 8-byte LDS read per group
     for (int i = tid; i < 512; i += THREADS) ltw1[i] = a.tab.tw256[i];
     const float* ctw1 = ltw1 + 2 * l16;  // W256^(l16 k1) as (cos, sin) at + 32 k1: one 8-byte LDS read per twiddle
@@ -510,10 +512,6 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
         const float npre = -a.preemph;
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
-            if (32 * n1 >= FBT_WIN_FLOATS) {   // (NG = 16: the LDS table holds FBT_WIN_FLOATS taps -- groups 14 and 15 lie behind every window this kernel takes; reading
-                z[n1] = cmake(0.0f, 0.0f);     //  "their" weights read the twiddle table that follows: the wrong features of windows <= 384 samples, section 8 of DESIGN.md)
-                continue;
-            }
             const float2v w2 = lds_load_unmerged(reinterpret_cast<const float2v*>(cwin + 32 * n1));
             const float y0 = fmaf(npre, r[n1][0], x0[n1]) - dc;   // taps beyond the window meet a zero weight
             const float y1 = fmaf(npre, x0[n1], x1[n1]) - dc;
@@ -746,6 +744,36 @@ __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const
     }
 }
 
+// snip_edges = False (torchaudio.compliance.kaldi._get_strided): T = (n + shift / 2) / shift frames over the signal mirrored at both ends --
+// frame f covers the samples f * shift - pad ... + win - 1 with pad = win / 2 - shift / 2, index -1 - j reads x[j], index n + j reads x[n - 1 - j].
+// This pre-pass writes the mirrored row [0, (T - 1) * shift + win) to the caller workspace (one extra pass over the waveform for a non-default
+// argument); the frames of that row are then plain snip_edges = True frames, so fbank_kernel / fbank_tile_kernel run unchanged on it.
+// lens_out (variable-length batches): the length of row b's mirrored signal, 0 when it has no frames.
+__global__ __launch_bounds__(256) void fbank_mirror_kernel(const float* wav, int64_t wav_stride, const int64_t* num_samples, int64_t L, float* dst,
+                                                           int64_t dst_stride, int64_t Lp, int64_t* lens_out, int win, int shift, int64_t min_samples) {
+    const int b = blockIdx.y;
+    int64_t n = num_samples != nullptr ? num_samples[b] : L;
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const int64_t pad = win / 2 - shift / 2;
+    int64_t T = n < min_samples ? 0 : (n + shift / 2) / shift;
+    // the mirror reaches one signal length to either side (torchaudio concatenates the reversed signal once): a row too short for its
+    // frames (n < pad, or the last frame beyond 2 n) has no frames here -- the reference raises on such a row
+    if (T > 0 && (pad > n || (T - 1) * shift - pad + win > 2 * n)) T = 0;
+    const int64_t own = T > 0 ? (T - 1) * shift + win : 0;
+    if (lens_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) lens_out[b] = own;
+    const float* src = wav + (int64_t)b * wav_stride;
+    float* d = dst + (int64_t)b * dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < (int64_t)(blockIdx.x + 1) * 1024 && i < dst_stride; i += 256) {
+        float v = 0.0f;
+        if (i < own) {
+            int64_t j = i - pad;
+            j = j < 0 ? -1 - j : (j >= n ? 2 * n - 1 - j : j);
+            v = src[j];
+        }
+        d[i] = v;
+    }
+}
+
 }  // namespace mv
 
 // ------------------------------------------------------------------------------------------ host side
@@ -753,6 +781,8 @@ __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const
 struct MvFbank {
     MvFbankCfg cfg;
     int win, shift, nbins;
+    int padded = 512;          // kaldi's FFT size: the window rounded up to a power of two (<= 512)
+    int64_t min_samples = 0;   // min_duration in samples
     float* d_window = nullptr;
     float* d_window_half = nullptr;
     float* d_tw256 = nullptr;
@@ -841,16 +871,16 @@ constexpr int FBT_G0 = 7, FBT_G1 = 3;
 static bool fbank_tile_geometry_ok(const MvFbank* h) {
     const mv::FbankTables& t = h->tab;
     return t.passes == 2 && t.pass_steps[0] == 4 * FBT_G0 && t.pass_steps[1] == 4 * FBT_G1 && t.pass_split[0] == 1 &&
-           (h->nbins & 3) == 0 && h->nbins <= 128 && h->win > 12 * 32 && h->win <= 13 * 32 && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
-    // (windows of 385 .. 416 samples -- 25 ms at 16 kHz is 400 -- are the 13-group instantiation, the one every shipped configuration runs and every
-    // GPU test covers.  The 16-group instantiation for other windows gave WRONG features (20 ms: max error 9.9 against the oracle, found by
-    // tools/emu_fuzz.py at the end of round 4): its groups 14 and 15 read "window taps" behind the 448-tap LDS table.  The kernel is repaired (those
-    // groups are zero; 20 / 24 ms then agree with the oracle to 1.8e-4 on the emulator), but no GPU minutes were left to run it on the device, so
-    // those geometries keep running fbank_kernel until a device test re-admits them.)
+           (h->nbins & 3) == 0 && h->nbins <= 128 && h->win >= 4 && (h->win & 1) == 0 && h->cfg.use_power && h->cfg.use_log_fbank;  // log power spectra only
+    // (windows of 385 .. 416 samples -- 25 ms at 16 kHz is 400 -- run the 13-group instantiation, every other even window the 16-group one, whose
+    // LDS window table holds all 512 taps since round 5: in rounds 2 - 4 it held 448, and groups 14 / 15 read the twiddle table behind it -- the
+    // wrong features of 20 / 24 ms windows.  tests/test_gpu_parity.py::test_gpu_fbank_arguments runs both instantiations against the oracle.)
 }
 
-static size_t fbank_tile_fixed_lds_bytes() {
-    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::FBT_WIN_FLOATS + 512) * sizeof(float);
+static bool fbank_tile_ng13(int win) { return win > 12 * 32 && win <= 13 * 32; }
+
+static size_t fbank_tile_fixed_lds_bytes(int win) {
+    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::fbt_win_floats(fbank_tile_ng13(win) ? 13 : 16) + 512) * sizeof(float);
 }
 
 template <int NG, bool V>
@@ -859,7 +889,7 @@ static hipError_t fbank_tile_set_smem() {
 }
 
 static void fbank_tile_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, bool vec2) {
-    const bool ng13 = a.win > 12 * 32 && a.win <= 13 * 32;
+    const bool ng13 = fbank_tile_ng13(a.win);
     const dim3 grid(B, 1, 1), block(mv::FBT_WAVES * 64, 1, 1);
     if (ng13 && vec2) {
         MV_LAUNCH((mv::fbank_tile_kernel<13, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
@@ -888,6 +918,12 @@ void mv_fbank_default_cfg(MvFbankCfg* cfg) {
     cfg->use_power = 1;
     cfg->use_log_fbank = 1;
     cfg->subtract_time_mean = 1;
+    cfg->window_type = MV_WINDOW_POVEY;
+    cfg->blackman_coeff = 0.42f;
+    cfg->snip_edges = 1;
+    cfg->subtract_mean = 0;
+    cfg->min_duration = 0.0f;
+    cfg->kernel = MV_FBANK_KERNEL_AUTO;
 }
 
 int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
@@ -897,22 +933,33 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     MV_REQUIRE(shift >= 1, "mv_fbank_create: frame shift must be at least one sample");
     MV_REQUIRE(cfg->num_mel_bins >= 1 && cfg->num_mel_bins <= 64 * mv::FB_MAX_PASSES,
                "mv_fbank_create: num_mel_bins must be in [1, 128]");
-    if (win <= mv::FB_NFFT / 2 || win > mv::FB_NFFT)
+    if (win < 2 || win > mv::FB_NFFT)
         return mv::fail(MV_ERR_UNSUPPORTED,
-                        "mv_fbank_create: only frame lengths that pad to a 512-point FFT (257..512 samples, e.g. 25 ms "
-                        "at 16 kHz) are implemented on gfx950");
+                        "mv_fbank_create: only frame lengths of 2 .. 512 samples (an FFT of up to 512 points, e.g. 25 ms at 16 kHz) are "
+                        "implemented on gfx950");
+    MV_REQUIRE(cfg->window_type >= MV_WINDOW_POVEY && cfg->window_type <= MV_WINDOW_BLACKMAN, "mv_fbank_create: unknown window_type");
+    MV_REQUIRE(cfg->kernel >= MV_FBANK_KERNEL_AUTO && cfg->kernel <= MV_FBANK_KERNEL_TILE, "mv_fbank_create: unknown kernel selector");
+    MV_REQUIRE(cfg->min_duration >= 0.0f, "mv_fbank_create: negative min_duration");
     MvFbank* h = new MvFbank();
     h->cfg = *cfg;
     h->win = win;
     h->shift = shift;
     h->nbins = cfg->num_mel_bins;
+    h->padded = 2;
+    while (h->padded < win) h->padded *= 2;   // round_to_power_of_two=True (the only form implemented)
+    h->min_samples = (int64_t)ceil((double)cfg->min_duration * (double)cfg->sample_frequency);   // len < min_duration * sf  <=>  len < ceil(...)
 
     const double pi = 3.14159265358979323846;
     std::vector<float> window(512, 0.0f), window_half(512, 0.0f), tw256(512), tw512(512);
     for (int i = 0; i < win; ++i) {
-        // povey: hann(win, periodic=False) ** 0.85
-        const double hann = 0.5 - 0.5 * cos(2.0 * pi * i / (win - 1));
-        window[i] = (float)pow(hann, 0.85);
+        // torchaudio.compliance.kaldi._feature_window_function (all symmetric, periodic=False)
+        const double a = 2.0 * pi / (win - 1);
+        double w = 1.0;                                                                       // rectangular
+        if (cfg->window_type == MV_WINDOW_POVEY) w = pow(0.5 - 0.5 * cos(a * i), 0.85);       // hann ** 0.85
+        if (cfg->window_type == MV_WINDOW_HANNING) w = 0.5 - 0.5 * cos(a * i);
+        if (cfg->window_type == MV_WINDOW_HAMMING) w = 0.54 - 0.46 * cos(a * i);
+        if (cfg->window_type == MV_WINDOW_BLACKMAN) w = cfg->blackman_coeff - 0.5 * cos(a * i) + (0.5 - cfg->blackman_coeff) * cos(2.0 * a * i);
+        window[i] = (float)w;
         window_half[i] = 0.5f * window[i];  // exact: the halved spectrum squares to |X|^2 without a final scale
     }
     for (int m = 0; m < 256; ++m) {
@@ -922,7 +969,16 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         tw512[2 * m] = (float)cos(2.0 * pi * m / 512.0);
         tw512[2 * m + 1] = (float)sin(2.0 * pi * m / 512.0);
     }
-    auto banks = kaldi_mel_banks(h->nbins, mv::FB_NFFT, cfg->sample_frequency, cfg->low_freq, cfg->high_freq);
+    // Windows that round up to an FFT of P < 512 points (8 kHz: 25 ms = 200 samples, P = 256): the kernels still transform the frame zero-padded to
+    // 512 points; bin k of the P-point transform of a zero-padded frame IS bin k * 512 / P of the 512-point one, so kaldi's filter weights (built
+    // for P) are placed on those bins and the bins in between carry zero weight.
+    auto banks_p = kaldi_mel_banks(h->nbins, h->padded, cfg->sample_frequency, cfg->low_freq, cfg->high_freq);
+    std::vector<std::vector<float>> banks(h->nbins, std::vector<float>(mv::FB_NFFT / 2, 0.0f));
+    {
+        const int stride = mv::FB_NFFT / h->padded;
+        for (int m = 0; m < h->nbins; ++m)
+            for (int k = 0; k < h->padded / 2; ++k) banks[m][k * stride] = banks_p[m][k];
+    }
     // Mel stage tables (frontend_common.h::build_mel_plan): passes of 16 blocks x (4 frames x 4 adjacent filters), every block
     // walking only the bins its triangles cover, inside the 256 bins of a power row
     mv::FbankTables& tab = h->tab;
@@ -964,7 +1020,12 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         mv_fbank_destroy(h);
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_kernel");
     }
-    h->tile_kernel = fbank_tile_geometry_ok(h);
+    h->tile_kernel = fbank_tile_geometry_ok(h) && cfg->kernel != MV_FBANK_KERNEL_GENERIC;
+    if (cfg->kernel == MV_FBANK_KERNEL_TILE && !h->tile_kernel) {
+        mv_fbank_destroy(h);
+        return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: fbank_tile_kernel is instantiated for log power spectra on the mel geometry of 80 bins / 16 kHz / "
+                                            "512-point FFT (mel passes of 28 + 12 bins) with an even window; this configuration runs fbank_kernel");
+    }
     if (h->tile_kernel && (fbank_tile_set_smem<13, true>() != hipSuccess || fbank_tile_set_smem<13, false>() != hipSuccess ||
                            fbank_tile_set_smem<16, true>() != hipSuccess || fbank_tile_set_smem<16, false>() != hipSuccess)) {
         mv_fbank_destroy(h);
@@ -987,7 +1048,13 @@ int mv_fbank_destroy(MvFbank* h) {
 
 int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_frames) {
     MV_REQUIRE(h != nullptr && num_frames != nullptr, "mv_fbank_num_frames: null argument");
-    *num_frames = num_samples < h->win ? 0 : 1 + (num_samples - h->win) / h->shift;
+    if (num_samples < h->min_samples) {
+        *num_frames = 0;
+    } else if (h->cfg.snip_edges) {
+        *num_frames = num_samples < h->win ? 0 : 1 + (num_samples - h->win) / h->shift;
+    } else {
+        *num_frames = (num_samples + h->shift / 2) / h->shift;
+    }
     return MV_OK;
 }
 
@@ -1006,14 +1073,25 @@ struct FbankPlan {
     int64_t T = 0, fit = 0, need = 0;
     int nch = 1, chunk_quads = 0;
     bool chunk_form = false;   // B * nch workgroups + the finish pass; needs the caller's workspace
+    // snip_edges = 0: the mirrored rows [B][mirror_stride] and their lengths [B] come first in the workspace (mirror_bytes, a multiple of 256)
+    int64_t mirror_len = 0, mirror_stride = 0;
+    size_t mirror_bytes = 0;
+    size_t chunk_bytes = 0;
     size_t workspace_bytes = 0;
 };
 
 static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
     FbankPlan p;
     mv_fbank_num_frames(h, L, &p.T);
-    if (!h->tile_kernel || B <= 0 || p.T <= 0) return p;
-    p.fit = (int64_t)((160 * 1024 - fbank_tile_fixed_lds_bytes()) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
+    if (B <= 0 || p.T <= 0) return p;
+    if (!h->cfg.snip_edges) {
+        p.mirror_len = (p.T - 1) * h->shift + h->win;
+        p.mirror_stride = mv::round_up(p.mirror_len, (int64_t)4);
+        p.mirror_bytes = (size_t)mv::round_up((int64_t)B * p.mirror_stride * (int64_t)sizeof(float) + (int64_t)B * (int64_t)sizeof(int64_t), (int64_t)256);
+        p.workspace_bytes = p.mirror_bytes;
+    }
+    if (!h->tile_kernel) return p;
+    p.fit = (int64_t)((160 * 1024 - fbank_tile_fixed_lds_bytes(h->win)) / ((size_t)h->nbins * sizeof(float))) & ~(int64_t)3;
     p.need = (p.T + 3) & ~(int64_t)3;
     const int cus = mv::device_cu_count();
     const int nquads = (int)(p.need / 4);
@@ -1025,7 +1103,8 @@ static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
         p.nch = (int)mv::ceil_div(nquads, p.chunk_quads);
         p.chunk_form = p.nch > 1;
     }
-    if (p.chunk_form) p.workspace_bytes = (size_t)B * p.nch * p.chunk_quads * 128 * sizeof(float);
+    if (p.chunk_form) p.chunk_bytes = (size_t)B * p.nch * p.chunk_quads * 128 * sizeof(float);
+    p.workspace_bytes += p.chunk_bytes;
     return p;
 }
 
@@ -1054,6 +1133,12 @@ int mv_fbank_forward_varlen(const MvFbank* h, const float* wav, int32_t B, int64
     return fbank_forward_impl(h, wav, B, L, wav_stride, nullptr, num_samples, out, nullptr, 0, stream);
 }
 
+int mv_fbank_forward_varlen_ws(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const int64_t* num_samples,
+                               float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream) {
+    MV_REQUIRE(num_samples != nullptr, "mv_fbank_forward_varlen_ws: null length array");
+    return fbank_forward_impl(h, wav, B, L, wav_stride, nullptr, num_samples, out, workspace, workspace_bytes, stream);
+}
+
 static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride, const float* lens_ratio,
                               const int64_t* num_samples, float* out, void* workspace, size_t workspace_bytes, mv_stream_t stream) {
     MV_REQUIRE(h != nullptr, "mv_fbank_forward: null handle");
@@ -1080,27 +1165,55 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     a.remove_dc = h->cfg.remove_dc_offset;
     a.use_power = h->cfg.use_power;
     a.use_log = h->cfg.use_log_fbank;
-    a.cmn = h->cfg.subtract_time_mean;
+    // kaldi.fbank's own subtract_mean (column means over the utterance's frames) followed by the wrapper's time mean over the same frames
+    // subtracts (a rounding of) zero the second time: one subtraction serves both
+    a.cmn = h->cfg.subtract_time_mean || h->cfg.subtract_mean;
     a.L = L;
+    a.min_len = h->min_samples > h->win ? h->min_samples : h->win;
     a.tile_rows = 0;
     a.chunked = 0;
     a.nchunks = 1;
     a.chunk_quads = 0;
     a.part = nullptr;
     a.tab = h->tab;
+    void* chunk_ws = workspace;
+    size_t chunk_ws_bytes = workspace_bytes;
+    if (!h->cfg.snip_edges) {
+        if (workspace == nullptr || workspace_bytes < plan.mirror_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+            return mv::fail(MV_ERR_WORKSPACE, "mv_fbank_forward: snip_edges=False writes the mirrored signal to the caller workspace "
+                                            "(mv_fbank_workspace_bytes, 16-byte aligned; mv_fbank_forward_ws / mv_fbank_forward_varlen_ws)");
+        if (num_samples == nullptr) {   // (torchaudio concatenates the reversed signal once to either side: shorter signals make it raise)
+            const int64_t pad = h->win / 2 - h->shift / 2;
+            if (pad > L || (T - 1) * h->shift - pad + h->win > 2 * L)
+                return mv::fail(MV_ERR_INVALID_ARGUMENT, "mv_fbank_forward: snip_edges=False: the signal is too short to be mirrored over its frames");
+        }
+        float* mw = static_cast<float*>(workspace);
+        int64_t* mlens = reinterpret_cast<int64_t*>(mw + (int64_t)B * plan.mirror_stride);
+        const int64_t xb = mv::ceil_div(plan.mirror_stride, (int64_t)1024);
+        MV_REQUIRE(B <= 65535, "mv_fbank_forward: snip_edges=False takes at most 65535 rows per call");
+        MV_LAUNCH(mv::fbank_mirror_kernel, ((unsigned)xb, (unsigned)B, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), wav, wav_stride, num_samples, L, mw,
+                  plan.mirror_stride, plan.mirror_len, num_samples != nullptr ? mlens : nullptr, h->win, h->shift, h->min_samples);
+        a.wav = wav = mw;
+        a.wav_stride = wav_stride = plan.mirror_stride;
+        a.L = plan.mirror_len;
+        a.min_len = h->win;
+        if (num_samples != nullptr) a.num_samples = num_samples = mlens;
+        chunk_ws = static_cast<char*>(workspace) + plan.mirror_bytes;
+        chunk_ws_bytes = workspace_bytes - plan.mirror_bytes;
+    }
     const bool vec2 = (reinterpret_cast<uintptr_t>(wav) & 7) == 0 && (wav_stride & 1) == 0 && (h->shift & 1) == 0 && (h->win & 1) == 0;
     const int prof = mv::prof_begin(MV_PROF_FBANK, (double)B * (4.0 * (double)L + 4.0 * (double)T * h->nbins), static_cast<hipStream_t>(stream));
     if (h->tile_kernel) {
-        const size_t fixed = fbank_tile_fixed_lds_bytes();
+        const size_t fixed = fbank_tile_fixed_lds_bytes(h->win);
         // The chunk form and the one-workgroup form give the same bits (FbankArgs), so taking it is a matter of time only.  It needs scratch for
         // the chunks' per-wave sums, which belongs to the CALL, not to the handle: without the caller's workspace (mv_fbank_forward, the
         // variable-length entry point) every utterance runs on one workgroup.
-        if (plan.chunk_form && num_samples == nullptr && workspace != nullptr && workspace_bytes >= plan.workspace_bytes &&
-            (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+        if (plan.chunk_form && num_samples == nullptr && chunk_ws != nullptr && chunk_ws_bytes >= plan.chunk_bytes &&
+            (reinterpret_cast<uintptr_t>(chunk_ws) & 15) == 0) {
             a.chunked = 1;
             a.nchunks = plan.nch;
             a.chunk_quads = plan.chunk_quads;
-            a.part = static_cast<float*>(workspace);
+            a.part = static_cast<float*>(chunk_ws);
             fbank_tile_launch(B * plan.nch, fixed, static_cast<hipStream_t>(stream), a, vec2);
             if (a.cmn || lens_ratio != nullptr) {
                 const int row_blocks = (int)mv::ceil_div(T, mv::FBF_ROWS);

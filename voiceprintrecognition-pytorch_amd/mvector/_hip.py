@@ -23,7 +23,8 @@ class MvFbankCfg(ctypes.Structure):
     _fields_ = [('sample_frequency', c_f32), ('frame_length_ms', c_f32), ('frame_shift_ms', c_f32),
                 ('num_mel_bins', c_i32), ('low_freq', c_f32), ('high_freq', c_f32),
                 ('preemphasis_coefficient', c_f32), ('remove_dc_offset', c_i32), ('use_power', c_i32),
-                ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32)]
+                ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32), ('window_type', c_i32), ('blackman_coeff', c_f32),
+                ('snip_edges', c_i32), ('subtract_mean', c_i32), ('min_duration', c_f32), ('kernel', c_i32)]
 
 
 class MvMelSpecCfg(ctypes.Structure):
@@ -94,6 +95,7 @@ _SIGNATURES = {
     'mv_fbank_num_frames': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     'mv_fbank_forward': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'mv_fbank_forward_varlen': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'mv_fbank_forward_varlen_ws': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     'mv_fbank_workspace_bytes': (c_i32, [c_vp, c_i32, c_i64, ctypes.POINTER(ctypes.c_size_t)]),
     'mv_fbank_forward_ws': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     'mv_melspec_default_cfg': (None, [ctypes.POINTER(MvMelSpecCfg)]),
@@ -185,7 +187,7 @@ def lib():
                 f'{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` or '
                 f'`python voiceprintrecognition-pytorch_amd/build_native.py`). There is no non-HIP device path.')
         cdll = bind(ctypes.CDLL(LIB_PATH))
-        if cdll.mv_abi_version() != 3:
+        if cdll.mv_abi_version() != 4:
             raise RuntimeError('libmvector_hip.so ABI version mismatch')
         _lib = cdll
     return _lib
@@ -210,7 +212,12 @@ def _ptr(t):
 class Fbank:
     """Handle of the fused Fbank + CMN + mask kernel (mv_fbank_*)."""
 
-    def __init__(self, method_args=None, subtract_time_mean=True, cdll=None):
+    WINDOW_TYPES = {'povey': 0, 'hamming': 1, 'hanning': 2, 'rectangular': 3, 'blackman': 4}
+    KERNELS = {'auto': 0, 'generic': 1, 'tile': 2}
+
+    def __init__(self, method_args=None, subtract_time_mean=True, cdll=None, kernel='auto'):
+        """``method_args``: the keyword arguments of torchaudio.compliance.kaldi.fbank (featurizer.py:128 forwards them).  ``kernel``:
+        'auto' | 'generic' (fbank_kernel) | 'tile' (fbank_tile_kernel; refused when the geometry has no instantiation) -- tests / tools."""
         self._cdll = cdll or lib()
         cfg = MvFbankCfg()
         self._cdll.mv_fbank_default_cfg(ctypes.byref(cfg))
@@ -218,24 +225,33 @@ class Fbank:
         mapping = {'sample_frequency': 'sample_frequency', 'frame_length': 'frame_length_ms',
                    'frame_shift': 'frame_shift_ms', 'num_mel_bins': 'num_mel_bins', 'low_freq': 'low_freq',
                    'high_freq': 'high_freq', 'preemphasis_coefficient': 'preemphasis_coefficient',
-                   'remove_dc_offset': 'remove_dc_offset', 'use_power': 'use_power', 'use_log_fbank': 'use_log_fbank'}
-        fixed = {'dither': 0.0, 'window_type': 'povey', 'snip_edges': True, 'use_energy': False, 'vtln_warp': 1.0,
-                 'subtract_mean': False, 'htk_compat': False, 'round_to_power_of_two': True, 'channel': (-1, 0),
-                 'min_duration': 0.0, 'raw_energy': True, 'energy_floor': (0.0, 1.0), 'blackman_coeff': 0.42,
-                 'vtln_low': 100.0, 'vtln_high': -500.0}
+                   'remove_dc_offset': 'remove_dc_offset', 'use_power': 'use_power', 'use_log_fbank': 'use_log_fbank',
+                   'blackman_coeff': 'blackman_coeff', 'snip_edges': 'snip_edges', 'subtract_mean': 'subtract_mean',
+                   'min_duration': 'min_duration'}
+        # arguments whose other values are not implemented (dither draws random numbers; use_energy adds a column that
+        # AudioFeaturizer.feature_dim, featurizer.py:110-111, does not count; VTLN warping; non-power-of-two FFT sizes) and arguments
+        # that only matter together with those (raw_energy, energy_floor, htk_compat: use_energy; vtln_low / vtln_high: vtln_warp)
+        fixed = {'dither': 0.0, 'use_energy': False, 'vtln_warp': 1.0, 'round_to_power_of_two': True, 'channel': (-1, 0)}
+        ignored = ('raw_energy', 'energy_floor', 'htk_compat', 'vtln_low', 'vtln_high')
         for k, v in args.items():
             if k in mapping:
                 field = mapping[k]
                 typ = dict(MvFbankCfg._fields_)[field]
                 setattr(cfg, field, int(v) if typ is c_i32 else float(v))
+            elif k == 'window_type':
+                if v not in self.WINDOW_TYPES:
+                    raise Exception('Invalid window type ' + str(v))   # torchaudio's own message
+                cfg.window_type = self.WINDOW_TYPES[v]
             elif k in fixed:
                 allowed = fixed[k] if isinstance(fixed[k], tuple) else (fixed[k],)
                 if v not in allowed:
                     raise NotImplementedError(f'Fbank argument {k}={v!r} is not implemented by the HIP kernel')
-            else:
+            elif k not in ignored:
                 raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
         cfg.subtract_time_mean = 1 if subtract_time_mean else 0
+        cfg.kernel = self.KERNELS[kernel]
         self.num_mel_bins = cfg.num_mel_bins
+        self._snip_edges = bool(cfg.snip_edges)
         self._h = c_vp()
         check(self._cdll.mv_fbank_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
 
@@ -263,18 +279,23 @@ class Fbank:
         out = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=wav.device)
         if B == 0 or T == 0:
             return out
+        # per-call scratch (the several-workgroups-per-utterance form of long utterances / batches smaller than the chip; the mirrored signal
+        # of snip_edges=False): from torch's stream-aware caching allocator, so concurrent forwards on other streams never share it (the handle
+        # owns no mutable state)
+        need = ctypes.c_size_t()
+        check(self._cdll.mv_fbank_workspace_bytes(self._h, B, L, ctypes.byref(need)), self._cdll)
+        ws = torch.empty(need.value, dtype=torch.uint8, device=wav.device) if need.value and (workspace or not self._snip_edges) else None
         if num_samples is not None:
             num_samples = num_samples.to(device=wav.device, dtype=torch.int64).contiguous()
-            check(self._cdll.mv_fbank_forward_varlen(self._h, wav.data_ptr(), B, L, wav.stride(0), num_samples.data_ptr(), out.data_ptr(),
-                                                     current_stream(wav)), self._cdll)
+            if ws is None:
+                check(self._cdll.mv_fbank_forward_varlen(self._h, wav.data_ptr(), B, L, wav.stride(0), num_samples.data_ptr(), out.data_ptr(),
+                                                         current_stream(wav)), self._cdll)
+            else:
+                check(self._cdll.mv_fbank_forward_varlen_ws(self._h, wav.data_ptr(), B, L, wav.stride(0), num_samples.data_ptr(), out.data_ptr(),
+                                                            _ptr(ws), need.value, current_stream(wav)), self._cdll)
             return out
         if lens_ratio is not None:
             lens_ratio = lens_ratio.to(device=wav.device, dtype=torch.float32).contiguous()
-        # per-call scratch of the several-workgroups-per-utterance form (long utterances, batch smaller than the chip): from torch's
-        # stream-aware caching allocator, so concurrent forwards on other streams never share it (the handle owns no mutable state)
-        need = ctypes.c_size_t()
-        check(self._cdll.mv_fbank_workspace_bytes(self._h, B, L, ctypes.byref(need)), self._cdll)
-        ws = torch.empty(need.value, dtype=torch.uint8, device=wav.device) if need.value and workspace else None
         check(self._cdll.mv_fbank_forward_ws(self._h, wav.data_ptr(), B, L, wav.stride(0), _ptr(lens_ratio), out.data_ptr(), _ptr(ws),
                                              need.value if ws is not None else 0, current_stream(wav)), self._cdll)
         return out

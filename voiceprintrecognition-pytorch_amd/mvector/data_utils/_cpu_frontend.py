@@ -12,11 +12,14 @@ import torch
 
 _FBANK_KEYS = {'sample_frequency': 16000.0, 'frame_length': 25.0, 'frame_shift': 10.0, 'num_mel_bins': 23,
                'low_freq': 20.0, 'high_freq': 0.0, 'preemphasis_coefficient': 0.97, 'remove_dc_offset': True,
-               'use_power': True, 'use_log_fbank': True}
-_FBANK_FIXED = {'dither': (0.0,), 'window_type': ('povey',), 'snip_edges': (True,), 'use_energy': (False,),
-                'vtln_warp': (1.0,), 'subtract_mean': (False,), 'htk_compat': (False,),
-                'round_to_power_of_two': (True,), 'channel': (-1, 0), 'min_duration': (0.0,), 'raw_energy': (True,),
-                'energy_floor': (0.0, 1.0), 'blackman_coeff': (0.42,), 'vtln_low': (100.0,), 'vtln_high': (-500.0,)}
+               'use_power': True, 'use_log_fbank': True, 'window_type': 'povey', 'blackman_coeff': 0.42, 'snip_edges': True,
+               'subtract_mean': False, 'min_duration': 0.0}
+# not implemented beyond these values: dither draws random numbers, use_energy adds a column AudioFeaturizer.feature_dim does not count
+# (featurizer.py:110-111), VTLN warping, FFT sizes that are not powers of two
+_FBANK_FIXED = {'dither': (0.0,), 'use_energy': (False,), 'vtln_warp': (1.0,), 'round_to_power_of_two': (True,), 'channel': (-1, 0)}
+# arguments that only act together with use_energy / vtln_warp
+_FBANK_IGNORED = ('raw_energy', 'energy_floor', 'htk_compat', 'vtln_low', 'vtln_high')
+_WINDOWS = ('povey', 'hamming', 'hanning', 'rectangular', 'blackman')
 _MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
              'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale'}
 
@@ -24,7 +27,9 @@ _MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max
 def validate_args(method, args):
     if method == 'Fbank':
         for k, v in args.items():
-            if k in _FBANK_KEYS:
+            if k == 'window_type' and v not in _WINDOWS:
+                raise Exception('Invalid window type ' + str(v))
+            if k in _FBANK_KEYS or k in _FBANK_IGNORED:
                 continue
             if k in _FBANK_FIXED:
                 if v not in _FBANK_FIXED[k]:
@@ -41,12 +46,26 @@ def validate_args(method, args):
             raise NotImplementedError('MelSpectrogram option not implemented')
 
 
+def _window(window_type, size, blackman_coeff):
+    if window_type == 'povey':
+        return torch.hann_window(size, periodic=False).pow(0.85)
+    if window_type == 'hanning':
+        return torch.hann_window(size, periodic=False)
+    if window_type == 'hamming':
+        return torch.hamming_window(size, periodic=False, alpha=0.54, beta=0.46)
+    if window_type == 'rectangular':
+        return torch.ones(size)
+    a = 2 * math.pi / (size - 1)
+    i = torch.arange(size, dtype=torch.float32)
+    return blackman_coeff - 0.5 * torch.cos(a * i) + (0.5 - blackman_coeff) * torch.cos(2 * a * i)
+
+
 @functools.lru_cache(maxsize=8)
-def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high):
+def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high, window_type, blackman_coeff):
     size = int(sf * frame_length * 0.001)
     shift = int(sf * frame_shift * 0.001)
-    padded = 1 << (size - 1).bit_length()
-    window = torch.hann_window(size, periodic=False).pow(0.85)
+    padded = max(2, 1 << (size - 1).bit_length())
+    window = _window(window_type, size, blackman_coeff)
     nfft_bins = padded // 2
     high = high + 0.5 * sf if high <= 0.0 else high
     mel_lo = 1127.0 * math.log(1.0 + low / 700.0)
@@ -66,10 +85,21 @@ def fbank_batch(wav, args):
     a.update({k: v for k, v in args.items() if k in _FBANK_KEYS})
     size, shift, padded, window, banks_t = _fbank_tables(float(a['sample_frequency']), float(a['frame_length']),
                                                           float(a['frame_shift']), int(a['num_mel_bins']),
-                                                          float(a['low_freq']), float(a['high_freq']))
+                                                          float(a['low_freq']), float(a['high_freq']), a['window_type'],
+                                                          float(a['blackman_coeff']))
     B, L = wav.shape
-    if L < size:
+    if L < float(a['min_duration']) * float(a['sample_frequency']) or (a['snip_edges'] and L < size):
         return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
+    if not a['snip_edges']:  # (L + shift // 2) // shift frames over the signal mirrored at both ends (kaldi._get_strided)
+        m = (L + shift // 2) // shift
+        pad = size // 2 - shift // 2
+        rev = torch.flip(wav, [1])
+        wav = torch.cat((rev[:, L - pad:], wav, rev), dim=1) if pad > 0 else torch.cat((wav[:, -pad:], rev), dim=1)
+        if m == 0:
+            return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
+        if (m - 1) * shift + size > wav.shape[1] or pad > L:
+            raise RuntimeError('snip_edges=False: the signal is too short to be mirrored over its frames')
+        wav = wav[:, :(m - 1) * shift + size]
     frames = wav.unfold(1, size, shift)  # [B, m, size]
     if a['remove_dc_offset']:
         frames = frames - frames.mean(dim=2, keepdim=True)
@@ -83,6 +113,8 @@ def fbank_batch(wav, args):
     mel = spec @ banks_t
     if a['use_log_fbank']:
         mel = torch.clamp(mel, min=torch.finfo(torch.float32).eps).log()
+    if a['subtract_mean']:
+        mel = mel - mel.mean(dim=1, keepdim=True)
     return mel
 
 
