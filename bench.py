@@ -1,6 +1,12 @@
 """Benchmark of the embedding-extraction hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (the driver's command; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment) every rank runs main() directly.  Started plainly (``python bench.py --gpus N``, no WORLD_SIZE in the
+environment) the script launches those N ranks itself (torch.distributed.run, 127.0.0.1, a free port -- the launcher habit of the reference's
+README_en.md:204) and passes rank 0's JSON line through.  The ranks first rendezvous on a gloo group and compare device counts: a node with fewer than
+N devices ends with a clear message AFTER the rendezvous, not with an assert.  ``--dry-launch`` stops there (no GPU needed: tests/test_host_package.py).
 
 One "step" = one pass of the hot path over one batch of synthetic waveforms already resident in HBM:
     waveforms [B, 48000] fp32 -> HIP Fbank-80 + CMN -> native backbone forward -> embeddings [B, 192]
@@ -363,6 +369,54 @@ def two_stream_run(name, dev, wav, steps, ref):
             'note': 'front-end + backbone of two 128-utterance halves on two HIP streams, no cosine block; an option of the caller, not the headline'}
 
 
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: re-exec under torch.distributed.run with N ranks on this node and hand its exit code back"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MV_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL needs between the ranks of one node on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous(args, rank, local_rank, world):
+    """N > 1, two stages.  (1) Every rank joins a gloo group (needs no device) and the ranks exchange their device counts: a node that cannot seat all
+    ranks says so on rank 0 and every rank leaves with exit code 2 -- after the rendezvous, with no device touched.  (2) That group is closed and the
+    ranks meet again on nccl (= RCCL), the group the step's all-gather runs on (--dry-launch: on gloo again, one more exchange, then exit 0 -- the same
+    two-stage sequence without a device).  Returns the ranks seen."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    seen = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank, local_rank, ndev], dtype=torch.int64))
+    ranks = sorted(int(t[0]) for t in seen)
+    assert ranks == list(range(world)), ranks
+    short = [int(t[2]) for t in seen if int(t[2]) <= int(t[1])]
+    dist.barrier()
+    dist.destroy_process_group()
+    if short and not args.dry_launch:
+        if rank == 0:
+            print(f'bench.py --gpus {args.gpus}: all {world} ranks met, but this node has {min(short)} visible device(s) and every rank needs its own '
+                  f'(LOCAL_RANK < device count): run with --gpus <= the device count.', file=sys.stderr, flush=True)
+        sys.exit(2)
+    dist.init_process_group('gloo' if args.dry_launch else 'nccl', rank=rank, world_size=world)
+    if args.dry_launch:
+        again = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(again, torch.tensor([rank], dtype=torch.int64))
+        if rank == 0:
+            print(json.dumps({'dry_launch': True, 'n_gpus': args.gpus, 'ranks_seen': ranks, 'ranks_seen_second_group': sorted(int(t) for t in again),
+                              'devices_per_rank': [int(t[2]) for t in seen],
+                              'launcher': 'self' if os.environ.get('MV_BENCH_SELF_LAUNCHED') else 'torch.distributed.run'}), flush=True)
+        dist.destroy_process_group()
+        sys.exit(0)
+    return ranks
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -374,18 +428,22 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true', help='skip the CAM++ / MelSpectrogram / bucketed ERes2NetV2 legs')
     ap.add_argument('--cpu-sample', type=int, default=256, help='utterances timed on the CPU oracle (~10-20 s of CPU work)')
     ap.add_argument('--cpu-threads', type=int, default=32, help='cap on the torch CPU threads of the oracle baseline')
+    ap.add_argument('--dry-launch', action='store_true', help='N ranks rendezvous (gloo), rank 0 prints what it saw, nothing runs on a device')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it with --nproc-per-node {args.gpus} '
+                 f'(or plainly as `python bench.py --gpus {args.gpus}`, which launches the ranks itself)')
+    ranks_seen = rendezvous(args, rank, local_rank, world) if world > 1 or args.dry_launch else [0]
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs MI355X GPUs (torch.cuda.is_available() is False)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
 
     from mvector import _hip
     _hip.lib()  # fail loudly if the HIP library is missing
@@ -506,6 +564,8 @@ def main():
             'vs_baseline': None, 'dtype': SPLIT_DTYPE if f32_family else 'f16', 'data': 'synthetic',
             'config': {'workload': label, 'batch_per_gpu': B, 'global_batch': world * B, 'samples_per_utt': SAMPLES,
                        'frames': T, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
+            'ranks': {'seen_at_rendezvous': len(ranks_seen), 'rccl_world_size': dist.get_world_size() if world > 1 else 1,
+                      'launcher': 'self' if os.environ.get('MV_BENCH_SELF_LAUNCHED') else ('torch.distributed.run' if world > 1 else 'none')},
             'stage_ms': {'frontend_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
                          'all_gather': round(stage_ms[2], 4), 'cosine': round(stage_ms[3], 4)},
             'roofline': roof_conv,

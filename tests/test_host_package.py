@@ -415,3 +415,40 @@ def test_embed_stream_cpu_applies_the_reference_db_normalisation():
     assert torch.allclose(out, expect, atol=1e-5) and torch.isfinite(out).all()
     (plain,) = list(parallel.embed_stream(fz, m, [pcm], device='cpu'))
     assert not torch.allclose(plain[:2], expect[:2], atol=1e-3)   # the gain matters for these rows
+
+
+def _bench(*argv, launcher=False):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    cmd = [sys.executable]
+    if launcher:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd += ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    return subprocess.run(cmd + [os.path.join(ROOT, 'bench.py')] + list(argv), env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+
+
+def test_bench_launches_its_own_ranks_and_fails_clearly_without_devices():
+    """`python bench.py --gpus 2` with no launcher (the form of the driver's N = 1 command): the script starts 2 ranks itself; both rendezvous (gloo),
+    meet again on a second group, and rank 0 prints ONE JSON line (--dry-launch: no device needed).  Without --dry-launch on a node with fewer than 2
+    devices the run ends AFTER the rendezvous with a message that says so -- not with an assert.  Under torch.distributed.run
+    (the driver's N > 1 command) the same ranks run main() directly."""
+    r = _bench('--gpus', '2', '--dry-launch')
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {'dry_launch': True, 'n_gpus': 2, 'ranks_seen': [0, 1], 'ranks_seen_second_group': [0, 1],
+                 'devices_per_rank': d['devices_per_rank'], 'launcher': 'self'}
+    r = _bench('--gpus', '2', '--dry-launch', launcher=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['launcher'] == 'torch.distributed.run' and d['ranks_seen'] == [0, 1]
+    if torch.cuda.device_count() < 2:
+        r = _bench('--gpus', '2', '--steps', '1', '--warmup', '0')
+        assert r.returncode != 0
+        assert 'all 2 ranks met' in r.stderr and 'visible device(s)' in r.stderr, r.stderr[-2000:]
+        assert 'AssertionError' not in r.stderr
+    r = _bench('--gpus', '3', '--dry-launch', launcher=True)   # launcher and flag disagree: said in words
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
