@@ -450,6 +450,9 @@ def main():
 
     cls, kwargs, method, margs, gflop_per_utt, label, _ = MODELS[args.model]
     featurizer, model, state_cpu = build(args.model, dev)
+    if world > 1:   # checkpoint-derived choices of the native handles (CAM++ head precision): rank 0's, pinned on every rank, once
+        from mvector import parallel
+        parallel.sync_native_choices(model, device=dev)
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)

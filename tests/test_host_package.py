@@ -452,3 +452,50 @@ def test_bench_launches_its_own_ranks_and_fails_clearly_without_devices():
         assert 'AssertionError' not in r.stderr
     r = _bench('--gpus', '3', '--dry-launch', launcher=True)   # launcher and flag disagree: said in words
     assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+
+
+SYNC_WORKER = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path[:0] = [sys.argv[1], os.path.join(sys.argv[1], "tests"), os.path.join(sys.argv[1], "voiceprintrecognition-pytorch_amd")]
+from mvector.models import CAMPPlus, EcapaTdnn
+from mvector import parallel
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+torch.manual_seed(0)
+campp = torch.nn.Sequential(CAMPPlus(input_size=80, embd_dim=32)).eval()
+if rank == 0:
+    campp[0].head_precision = "f32"          # what rank 0's handle decided (here: pinned; no device in this container)
+x = torch.randn(2, 60, 80)
+n_fwd = 3 if rank == 0 else 0               # rank 1 has an empty shard / does not evaluate: forwards must not be collective
+for _ in range(n_fwd):
+    campp(x)
+pinned = parallel.sync_native_choices(campp)  # the explicit, once-per-job collective
+ecapa = torch.nn.Sequential(EcapaTdnn(input_size=80, channels=[64, 64, 64, 64, 192])).eval()
+none = parallel.sync_native_choices(ecapa)    # nothing to agree on: no collective issued, returns {}
+dist.barrier()
+json.dump({"pinned": pinned, "head": campp[0].head_precision, "none": none}, open(sys.argv[2] + f"/sync_rank{rank}.json", "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_campp_head_choice_is_synchronised_explicitly_not_from_forward(tmp_path):
+    """ADVICE r4 (medium): CAMPPlus.forward issued a dist.broadcast whenever a native handle was built -- ranks running different numbers of
+    forwards (an empty shard, rank-0-only evaluation as in the reference's trainer.py:376) blocked each other.  Now: forward never touches the
+    process group (rank 0 runs three forwards here, rank 1 none, nobody hangs), and parallel.sync_native_choices -- one explicit collective
+    every rank calls -- pins rank 0's choice on all ranks."""
+    import inspect
+    from mvector.models import CAMPPlus
+    from mvector.models._native import NativeBackbone
+    assert CAMPPlus._native_created is NativeBackbone._native_created          # the build hook is the no-op again
+    assert 'dist.' not in inspect.getsource(CAMPPlus.forward) and 'dist.' not in inspect.getsource(NativeBackbone._native_handle_on)
+    script = tmp_path / 'sync_worker.py'
+    script.write_text(SYNC_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29633', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()
+    for r in range(2):
+        d = json.load(open(tmp_path / f'sync_rank{r}.json'))
+        assert d == {'pinned': {'0': 'f32'}, 'head': 'f32', 'none': {}}, (r, d)

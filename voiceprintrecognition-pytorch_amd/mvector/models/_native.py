@@ -78,23 +78,32 @@ class NativeBackbone:
         return True  # (parameters require grad by default and the reference's predictor never enters no_grad, predict.py:228,262:
         #               that alone must not take inference off the HIP path)
 
-    def _native_forward(self, x):
-        ok, why = self._native_supported()
-        if not ok:
-            raise NotImplementedError(f'{type(self).__name__}: {why} is not implemented on the MI355X path')
-        from mvector import _hip
+    def _native_handle_on(self, key):
+        """the native handle of CUDA device ``key`` (the caller has made it current), built from the live parameters when there is none or they
+        have changed"""
         handles = self.__dict__.setdefault('_native_handles', {})
+        h, built_at, tensors = handles.get(key, (None, None, None))
+        if h is None or built_at != self._params_version(tensors):
+            ok, why = self._native_supported()
+            if not ok:
+                raise NotImplementedError(f'{type(self).__name__}: {why} is not implemented on the MI355X path')
+            from mvector import _hip
+            live = self.state_dict(keep_vars=True)
+            tensors = self._forward_tensors(live)
+            for v in tensors:
+                if v.device.type != 'cuda' or (v.device.index if v.device.index is not None else key) != key:
+                    raise RuntimeError(f'{type(self).__name__} parameters are on {v.device} but the input is on cuda:{key}')
+            build = lambda: _hip.Model(self._native_kind, self._native_cfg(), {k: v.detach() for k, v in live.items()})
+            h = self._native_created(build(), build)
+            handles[key] = (h, self._params_version(tensors), tensors)
+        return h
+
+    def _native_handle(self, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(key):
+            return self._native_handle_on(key)
+
+    def _native_forward(self, x):
         key = x.device.index if x.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(key):
-            h, built_at, tensors = handles.get(key, (None, None, None))
-            if h is None or built_at != self._params_version(tensors):
-                live = self.state_dict(keep_vars=True)
-                tensors = self._forward_tensors(live)
-                for v in tensors:
-                    if v.device != x.device:
-                        raise RuntimeError(f'{type(self).__name__} parameters are on {v.device} but the input is on '
-                                           f'{x.device}')
-                build = lambda: _hip.Model(self._native_kind, self._native_cfg(), {k: v.detach() for k, v in live.items()})
-                h = self._native_created(build(), build)
-                handles[key] = (h, self._params_version(tensors), tensors)
-            return h.forward(x if x.dtype == torch.float32 else x.float())
+            return self._native_handle_on(key).forward(x if x.dtype == torch.float32 else x.float())

@@ -131,7 +131,8 @@ class CAMPPlus(NativeBackbone, nn.Module):
         self.memory_efficient = memory_efficient  # activation checkpointing of the reference's training path: not used here
         # MI355X path: 'auto' lets the native handle pick the FCM head's precision from three probe utterances when it is built (fp16 maps, or
         # fp32 maps for a checkpoint whose head amplifies the fp16 rounding); 'f16' / 'f32' pin it.  Not a constructor argument: the reference's
-        # signature stays.  In a torch.distributed job rank 0's choice is broadcast, so every rank embeds with the same numerics.
+        # signature stays.  In a torch.distributed job every rank calls sync_native_head() once (mvector.parallel.sync_native_choices): rank 0's
+        # choice is then pinned on all of them.  forward() itself never issues a collective.
         self.head_precision = 'auto'
         self.head = _head(32, input_size)
         bottleneck = bn_size * growth_rate
@@ -171,22 +172,29 @@ class CAMPPlus(NativeBackbone, nn.Module):
         cfg.head_precision = {'auto': 0, 'f16': 1, 'f32': 2}[self.head_precision]
         return cfg
 
-    def _native_created(self, handle, build):
-        """rank 0's automatic head choice for every rank (enrol and verify embeddings must come out of one numerics)"""
+    def sync_native_head(self, device=None, group=None, src=0):
+        """COLLECTIVE (every rank of ``group`` calls it, once, after the weights are loaded and the module is in eval mode on its device): rank
+        ``src``'s FCM head choice becomes every rank's pinned ``head_precision``, so enrol and verify embeddings of a job come out of one numerics.
+        The automatic choice is a deterministic function of the checkpoint (fixed probe utterances, deterministic kernels), so ranks on identical
+        devices agree anyway; this call makes that a guarantee.  It is NOT issued from ``forward`` (round 4 did that: a rank that skips a forward --
+        an empty shard in ``parallel.embed_bucketed``, rank-0-only evaluation as in the reference's trainer.py:376 -- left the others blocked in a
+        broadcast).  Returns the pinned value ('f16' / 'f32'), or 'auto' when ``src`` has nothing to decide with (CPU module, no native handle)."""
         import torch.distributed as dist
-        if self.head_precision != 'auto' or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return handle
-        dev = next(self.parameters()).device
-        flag = torch.tensor([1 if handle.campp_head()['head'] == 'f32' else 0], dtype=torch.int32, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.broadcast(flag, 0)
-        want = 'f32' if int(flag.item()) else 'f16'
-        if want == handle.campp_head()['head']:
-            return handle
-        self.head_precision = want
-        try:
-            return build()
-        finally:
-            self.head_precision = 'auto'
+        codes = {'auto': 0, 'f16': 1, 'f32': 2}
+        mine = codes[self.head_precision]
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if mine == 0 and dev.type == 'cuda' and not self.training and self._native_supported()[0]:
+            mine = codes[self._native_handle(dev).campp_head()['head']]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            on_device = dist.get_backend(group) == 'nccl'
+            flag = torch.tensor([mine], dtype=torch.int32, device=dev if on_device else 'cpu')
+            dist.broadcast(flag, src, group=group)
+            mine = int(flag.item())
+        want = {v: k for k, v in codes.items()}[mine]
+        if want != self.head_precision:
+            self.head_precision = want
+            self.invalidate_native()   # (a handle built under 'auto' that chose the same head is rebuilt pinned: same kernels, same bits)
+        return want
 
     def native_head(self):
         """{'head', 'calibration', 'probes'} of the native handle on the current device (None before the first CUDA forward)"""

@@ -31,6 +31,17 @@ def all_gather_embeddings(emb_local, out=None, always=False):
     return out
 
 
+def sync_native_choices(model, device=None, group=None, src=0):
+    """COLLECTIVE, once per job after the weights are loaded (every rank calls it): choices a native handle makes from the checkpoint are taken from
+    rank ``src`` and pinned on every rank -- today the CAM++ FCM head precision (``CAMPPlus.sync_native_head``).  The forwards themselves never issue a
+    collective, so ranks may run different numbers of forwards (empty shards, rank-0-only evaluation).  Returns {module name: pinned value}."""
+    out = {}
+    for name, m in model.named_modules():
+        if hasattr(m, 'sync_native_head'):
+            out[name] = m.sync_native_head(device=device, group=group, src=src)
+    return out
+
+
 def cosine_block(emb_local, emb_all):
     """Rows of this rank against all rows: HIP kernel on CUDA tensors, torch on CPU tensors (gloo tests)."""
     if emb_local.is_cuda:
