@@ -8,7 +8,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 48000
 import ctypes
 cdll = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else None
-fb_h = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80), cdll=cdll)
+KERNEL = os.environ.get('MV_BENCH_KERNEL', 'auto')                    # auto | generic | tile (MvFbankCfg.kernel)
+FL = float(os.environ.get('MV_BENCH_FRAME_LENGTH', '25'))             # ms: 25 = fbank_tile_kernel<13>, 20 / 30 = <16>
+fb_h = _hip.Fbank(dict(sample_frequency=16000, num_mel_bins=80, frame_length=FL), cdll=cdll, kernel=KERNEL)
 T = fb_h.num_frames(L)
 _out = torch.empty((B, T, 80), dtype=torch.float32, device='cuda')
 
@@ -35,5 +37,5 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / n * 1e3
-print(json.dumps(dict(info=fb.info(), lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), impl=os.environ.get('MV_FBANK_IMPL', 'tile'), waves=os.environ.get('MV_FBANK_WAVES', 'default'), B=B, L=L, us=round(us, 2),
-                      GBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3, 1), frac_of_8TBps=round(B * (L * 4 + (1 + (L - 400) // 160) * 320) / us / 1e3 / 8000, 4))))
+print(json.dumps(dict(info=fb.info(), lib=os.path.basename(os.environ.get('MV_PROBE_LIB', 'product')), kernel=KERNEL, frame_length_ms=FL, B=B, L=L, us=round(us, 2),
+                      GBps=round(B * (L * 4 + T * 320) / us / 1e3, 1), frac_of_8TBps=round(B * (L * 4 + T * 320) / us / 1e3 / 8000, 4))))
