@@ -222,6 +222,16 @@ int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
 #define MV_INFO_CAMPP_HEAD_F32 1
 #define MV_INFO_CAMPP_CALIBRATION 2
 #define MV_INFO_CAMPP_PROBE0 3
+/* since ABI 4 -- the range of the exact head.  Its S16 maps hold 64 * gain * value in fp16 pairs (|.| <= 65504); gain = 2^k (k <= 0) is chosen at
+ * create so that the probes' largest map value sits 16 x below that bound (the head is positively homogeneous, so the gain is exact).
+ *   MV_INFO_CAMPP_HEAD_GAIN_LOG2  k
+ *   MV_INFO_CAMPP_PROBE_PEAK      largest map value over the probes (real units)
+ *   MV_INFO_CAMPP_HEAD_PEAK       largest map value the exact head has wanted to store on the caller's inputs since create (real units; waits for the device)
+ *   MV_INFO_CAMPP_HEAD_SATURATED  1.0 when one of them exceeded the range and was clamped (the embedding of that call is not to be trusted) */
+#define MV_INFO_CAMPP_HEAD_GAIN_LOG2 6
+#define MV_INFO_CAMPP_PROBE_PEAK 7
+#define MV_INFO_CAMPP_HEAD_PEAK 8
+#define MV_INFO_CAMPP_HEAD_SATURATED 9
 int mv_model_info(const MvModel* m, int32_t key, float* value);
 int mv_model_workspace_bytes(const MvModel* m, int32_t B, int32_t T, size_t* bytes);
 /* feats: [B, T, F] fp32 (the AudioFeaturizer output layout); emb: [B, embd_dim] fp32. */
@@ -331,6 +341,8 @@ typedef struct MvConv2dsDesc {
     int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
     int32_t stride_w;          /* stride along W when it differs from `stride` (then the stride along H); 0 = same (the CAM++ head strides the
                                 * frequency axis only, campplus.py:221-292) */
+    uint32_t* peak;            /* optional device word (since ABI 4): the kernel max-es in the bits of the largest |64 * value| it wanted to store BEFORE the
+                                * clamp to the fp16 range (positive floats order like unsigned integers); >= 65504.0f means the S16 split saturated */
     int32_t nbw_hint, ct_hint, rows_hint, ring_hint, wgs_hint, spw_hint, nprod_hint; /* 0 = the launcher's choice; otherwise blocks of 16 output channels per wave
                                            * (1..3), blocks per workgroup, rows per 3x3 tile (1..8), LDS ring stages (>= 2), workgroups per CU
                                            * (1 | 2), segments per consumer wave (8 | 4 | 2 | 1), producer waves: launch shapes for tests and tools/bench_conv2d.py (never the bits of a result) */

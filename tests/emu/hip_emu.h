@@ -465,6 +465,12 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) {
     return o;
 }
 
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned o = *p;
+    *p = o > v ? o : v;
+    return o;
+}
+
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
@@ -586,6 +592,10 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) {
     memmove(d, s, n);
     return 0;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+    memset(d, v, n);
+    return hipSuccess;
 }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
     memset(d, v, n);

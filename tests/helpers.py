@@ -18,6 +18,12 @@ def load_case(case):
     for k in z.files:  # calibrated BatchNorm statistics of the stress cases travel in the fixture
         if k.startswith('bn:'):
             sd[k[3:].replace('/', '.')] = torch.from_numpy(z[k])
+    if man.get('hot_head_log2'):   # oracle/make_golden.py::hot_head_state_dict: FCM head maps 2^k times larger, the same network otherwise
+        g = float(2 ** man['hot_head_log2'])
+        for name in list(sd):
+            stem, _, leaf = name.rpartition('.')
+            if name.startswith('head.') and stem != 'head.bn2' and (stem + '.running_mean') in sd and leaf in ('weight', 'bias'):
+                sd[name] = sd[name] * g
     return man, sd, torch.from_numpy(z['x']), torch.from_numpy(z['emb']), z
 
 

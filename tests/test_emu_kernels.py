@@ -437,3 +437,20 @@ def test_emu_fbank_arguments(idx):
     magnitude / linear outputs, DC / pre-emphasis switches, the five window types, snip_edges=False, subtract_mean, min_duration) x (kernel, bare rows, true lengths):
     tests/layer_checks.py::FBANK_ARG_CASES, the list the device sweep (test_gpu_fbank_arguments) runs at 3 s"""
     lc.fbank_arguments_case(emu_cdll(), 'cpu', idx)
+
+
+S16_RANGE_CASES = [
+    dict(cin=32, cout=32, ks=3, H=6, W=20, B=1, lo=0.0, hi=3.0e38, peak=True),                                   # peak below the range: reported exactly
+    dict(cin=32, cout=32, ks=3, H=6, W=20, B=1, lo=0.0, hi=3.0e38, peak=True, x_scale=200.0, seed=2),            # outputs beyond 1023.5: clamped AND reported
+    dict(cin=32, cout=48, ks=1, H=6, W=20, B=2, lo=-3.0e38, hi=3.0e38, peak=True, x_scale=200.0, with_res=True, seed=3),
+    dict(cin=16, cout=16, ks=3, H=6, W=20, B=1, lo=0.0, hi=3.0e38, nan_at=(0, 2, 5, 3)),                          # a NaN input reaches its 9 x 16 outputs as NaN
+    dict(cin=32, cout=32, ks=1, H=6, W=20, B=1, epi=1, nan_at=(0, 2, 5, 3), peak=True),
+    dict(cin=32, cout=16, ks=1, H=4, W=20, B=1, epi=2, nan_at=(0, 1, 7, 30), peak=True),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(S16_RANGE_CASES)))
+def test_emu_conv2ds_reports_its_peak_and_keeps_nans(idx):
+    """S16 maps saturate at |value| = 1023.5 and the clamps turned NaNs into finite bounds.  MvConv2dsDesc.peak reports the largest
+    value a launch wanted to store (the CAM++ handle picks its exact head's gain from it and exposes saturation on real inputs); NaNs travel on."""
+    lc.conv2ds_case(emu_cdll(), 'cpu', **S16_RANGE_CASES[idx])

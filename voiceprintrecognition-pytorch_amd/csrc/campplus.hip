@@ -33,6 +33,7 @@
 
 #include "kernels.h"
 #include "model.h"
+#include "s16map.h"
 
 namespace mv {
 
@@ -52,6 +53,7 @@ struct CamppModel : MvModelBase {
         half_t *w32 = nullptr, *sc_w32 = nullptr;
         float *b32 = nullptr, *sc_b32 = nullptr;
         float osc32 = 0.0f, sc_osc32 = 0.0f;
+        std::vector<float> b32_host, sc_b32_host;   // unscaled (set_exact_gain uploads them times the head gain)
     };
     struct ResBlock {
         Conv2d conv1, conv2;  // conv2 carries the shortcut tap when the block has one
@@ -80,6 +82,16 @@ struct CamppModel : MvModelBase {
     float *out_s = nullptr, *out_t = nullptr;
     float *dense_w = nullptr, *dense_b = nullptr;
     int F8 = 0, bn_ch = 0, cfin = 0;
+    // Range of the exact head.  S16 maps hold 64 * value in fp16 pairs and saturate at |value| = 1023.5 -- 64 x less than the fp16 head's maps, on
+    // exactly the checkpoints (large BatchNorm gains) the exact head exists for.  The head is positively homogeneous (conv + folded BN + ReLU,
+    // residual sums): run on gain * x with every bias times gain it produces gain * maps, exactly for a power of two.  create() measures the
+    // largest stored value on the probe utterances (MvConv2dsDesc.peak) and picks gain = 2^-k so that it sits 16 x below the saturation point;
+    // the first conv's weights / bias and the biases of the exact head carry the gain, the rows handed to the TDNN are multiplied by 2^k.
+    int head_gain_k = 0;
+    float *c1_w32 = nullptr, *c1_b32 = nullptr;   // head.conv1 (+ bn1) of the exact head: c1_w / c1_b times the gain
+    std::vector<float> c1_w_host, c1_b_host;
+    unsigned* d_peak = nullptr;     // device word: largest |64 * gain * value| an exact-head launch wanted to store (float bits; sticky, diagnostic only)
+    float probe_peak = 0.0f;        // the largest head activation over the probe utterances (real units), what the gain was chosen from
     bool head_f32 = false;          // which head forward() runs (decided in create())
     float calibration = -1.0f;      // largest 1 - cos between the two heads over the probe utterances (-1: forced by MvCamppCfg.head_precision)
     float probe_calibration[3] = {-1.0f, -1.0f, -1.0f};
@@ -123,10 +135,12 @@ struct CamppModel : MvModelBase {
             };
             if (!upload_split(w32, 3, &out->w32, &out->osc32)) return fail(MV_ERR_HIP, "campp create: upload failed");
             out->b32 = upload(t);
+            out->b32_host = t;
             if (sc) {
                 scw.assign(packed.begin() + (size_t)9 * 32 * 32, packed.end());  // [co][ci]
                 if (!upload_split(scw, 1, &out->sc_w32, &out->sc_osc32)) return fail(MV_ERR_HIP, "campp create: upload failed");
                 out->sc_b32 = upload(ts);
+                out->sc_b32_host = ts;
             }
         }
         return out->bias && out->w32 && out->b32 ? MV_OK : fail(MV_ERR_HIP, "campp create: upload failed");
@@ -149,6 +163,13 @@ struct CamppModel : MvModelBase {
                 for (int j = 0; j < 9; ++j) W[co * 9 + j] *= s[co];
             c1_w = upload(W);
             c1_b = upload(t);
+            c1_w32 = upload(W);
+            c1_b32 = upload(t);
+            c1_w_host = W;
+            c1_b_host = t;
+            d_peak = static_cast<unsigned*>(dev_alloc(sizeof(unsigned)));
+            if (c1_w32 == nullptr || c1_b32 == nullptr || d_peak == nullptr) return fail(MV_ERR_HIP, "campp create: out of device memory");
+            MV_HIP_OK(hipMemset(d_peak, 0, sizeof(unsigned)));
             std::vector<half_t> frag(2 * 64 * 8);
             fcm_c1_pack(W.data(), frag.data());
             c1_a = static_cast<half_t*>(dev_alloc(frag.size() * sizeof(half_t)));
@@ -246,13 +267,56 @@ struct CamppModel : MvModelBase {
             *value = probe_calibration[key - MV_INFO_CAMPP_PROBE0];
             return MV_OK;
         }
+        if (key == MV_INFO_CAMPP_HEAD_GAIN_LOG2) {
+            *value = (float)-head_gain_k;
+            return MV_OK;
+        }
+        if (key == MV_INFO_CAMPP_PROBE_PEAK) {
+            *value = probe_peak;
+            return MV_OK;
+        }
+        if (key == MV_INFO_CAMPP_HEAD_PEAK || key == MV_INFO_CAMPP_HEAD_SATURATED) {   // (waits for the device: a diagnostic, not a hot-path call)
+            float v = 0.0f;
+            MV_HIP_OK(hipDeviceSynchronize());
+            if (read_peak(&v) != MV_OK) return MV_ERR_HIP;
+            *value = key == MV_INFO_CAMPP_HEAD_PEAK ? ldexpf(v, head_gain_k) / CS_XSCALE : (v >= 65504.0f ? 1.0f : 0.0f);
+            return MV_OK;
+        }
         return MvModelBase::info(key, value);
     }
 
-    // Three fixed probe utterances through both heads; the largest 1 - cos between the two embeddings decides (header comment).
+    int read_peak(float* v) const {   // largest scaled value the exact head wanted to store since the word was last cleared
+        unsigned bits = 0;
+        MV_HIP_OK(hipMemcpy(&bits, d_peak, sizeof(bits), hipMemcpyDeviceToHost));
+        *v = __builtin_bit_cast(float, bits);
+        return MV_OK;
+    }
+
+    // the exact head's first conv and biases times gain = 2^-k (see head_gain_k)
+    int set_exact_gain(int k) {
+        head_gain_k = k;
+        const float g = ldexpf(1.0f, -k);
+        auto put = [&](float* dst, const std::vector<float>& src) {
+            if (dst == nullptr || src.empty()) return MV_OK;
+            std::vector<float> v(src);
+            for (float& x : v) x *= g;
+            MV_HIP_OK(hipMemcpy(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+            return MV_OK;
+        };
+        int rc;
+        if ((rc = put(c1_w32, c1_w_host)) || (rc = put(c1_b32, c1_b_host))) return rc;
+        for (int i = 0; i < 4; ++i)
+            if ((rc = put(res[i].conv1.b32, res[i].conv1.b32_host)) || (rc = put(res[i].conv2.b32, res[i].conv2.b32_host)) ||
+                (rc = put(res[i].conv2.sc_b32, res[i].conv2.sc_b32_host)))
+                return rc;
+        return put(head_out.b32, head_out.b32_host);
+    }
+
+    // Three fixed probe utterances: they set the exact head's gain (largest stored value 16 x below the S16 saturation point) and, through both
+    // heads, the largest 1 - cos between the two embeddings decides which head forward() runs (header comment).
     int choose_head() {
-        if (cfg.head_precision == MV_CAMPP_HEAD_F16 || cfg.head_precision == MV_CAMPP_HEAD_F32) {
-            head_f32 = cfg.head_precision == MV_CAMPP_HEAD_F32;
+        if (cfg.head_precision == MV_CAMPP_HEAD_F16) {
+            head_f32 = false;
             return MV_OK;
         }
         const int F = cfg.input_size, D = cfg.embd_dim;
@@ -304,6 +368,31 @@ struct CamppModel : MvModelBase {
         MV_HIP_OK(hipMalloc(reinterpret_cast<void**>(&sc.dfe), (size_t)probe_T[NPROBE - 1] * F * sizeof(float)));
         MV_HIP_OK(hipMalloc(reinterpret_cast<void**>(&sc.demb), (size_t)2 * D * sizeof(float)));
         MV_HIP_OK(hipMalloc(&sc.ws, wsb));
+        // ---- the exact head's gain: the probes' largest stored value, 16 x below the saturation point (the measurement repeats at the new gain: a map
+        //      clamped upstream makes everything downstream of it read low) ----
+        for (int round = 0; round < 8; ++round) {
+            MV_HIP_OK(hipMemset(d_peak, 0, sizeof(unsigned)));
+            for (int p = 0; p < NPROBE; ++p) {
+                MV_HIP_OK(hipMemcpy(sc.dfe, feats[p].data(), feats[p].size() * sizeof(float), hipMemcpyHostToDevice));
+                const int rc = forward_impl(sc.dfe, 1, probe_T[p], sc.demb, sc.ws, wsb, nullptr, true);
+                if (rc != MV_OK) return rc;
+            }
+            MV_HIP_OK(hipDeviceSynchronize());
+            float v = 0.0f;
+            if (read_peak(&v) != MV_OK) return MV_ERR_HIP;
+            probe_peak = ldexpf(v, head_gain_k) / CS_XSCALE;
+            if (!(v > 65504.0f / 16.0f) || head_gain_k >= 96) break;   // (an infinite or NaN peak: nothing a gain repairs)
+            int e2 = 0;
+            frexpf(v / (65504.0f / 16.0f), &e2);   // v / limit = f * 2^e2, f in [0.5, 1): 2^-e2 brings it to or below the limit
+            const int step = std::isfinite(v) ? (e2 > 0 ? e2 : 1) : 16;
+            const int rc = set_exact_gain(head_gain_k + step);
+            if (rc != MV_OK) return rc;
+        }
+        MV_HIP_OK(hipMemset(d_peak, 0, sizeof(unsigned)));   // from here on the word reports what real inputs do
+        if (cfg.head_precision == MV_CAMPP_HEAD_F32) {
+            head_f32 = true;
+            return MV_OK;
+        }
         float worst = 0.0f;
         std::vector<float> e((size_t)2 * D);
         for (int p = 0; p < NPROBE; ++p) {
@@ -326,6 +415,7 @@ struct CamppModel : MvModelBase {
         }
         calibration = worst;
         head_f32 = !(calibration <= CAMPP_HEAD_THRESHOLD);  // also taken when the fp16 head produced a non-finite embedding
+        MV_HIP_OK(hipMemset(d_peak, 0, sizeof(unsigned)));
         return MV_OK;
     }
 
@@ -397,7 +487,7 @@ struct CamppModel : MvModelBase {
     int head_fp32(const float* feats, int B, int T, const Ws& s, hipStream_t st) const {
         const int F = cfg.input_size;
         int rc;
-        if ((rc = conv2d_first_s16_launch(feats, reinterpret_cast<half_t*>(s.f0), c1_w, c1_b, B, T, F, 32, st))) return rc;
+        if ((rc = conv2d_first_s16_launch(feats, reinterpret_cast<half_t*>(s.f0), c1_w32, c1_b32, B, T, F, 32, st, d_peak))) return rc;
         auto conv = [&](const float* x, int H, const half_t* w, float osc, const float* bias, int ks, int stride, const float* res, bool relu, float* y) {
             MvConv2dsDesc d{};
             d.x = x;
@@ -419,6 +509,7 @@ struct CamppModel : MvModelBase {
             d.epi = 0;
             d.lo = relu ? 0.0f : -FLT_MAX;
             d.hi = FLT_MAX;
+            d.peak = d_peak;
             return conv2ds_launch(d, st);
         };
         const float* cur = s.f0;
@@ -442,7 +533,7 @@ struct CamppModel : MvModelBase {
         }
         MV_REQUIRE((Fc - 1) / 2 + 1 == F8, "campp forward: unexpected frequency size after the head");
         if ((rc = conv(cur, Fc, head_out.w32, head_out.osc32, head_out.b32, 3, 2, nullptr, true, s.fa))) return rc;
-        return fcm_rows_from_s16_launch(reinterpret_cast<const half_t*>(s.fa), s.rows, B, T, F8, st);
+        return fcm_rows_from_s16_launch(reinterpret_cast<const half_t*>(s.fa), s.rows, B, T, F8, st, ldexpf(1.0f, head_gain_k));
     }
 
     int forward_impl(const float* feats, int B, int T, float* emb, void* ws, size_t ws_bytes, hipStream_t st, bool f32) const {

@@ -385,7 +385,7 @@ int conv2d_launch(const Conv2dDesc& d, hipStream_t stream) {
 // S16: the output map in the split-fp16 form of conv2ds.hip (s16map.h) instead of fp32
 template <bool S16>
 __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, float* out, const float* w, const float* bias,
-                                                           int B, int T, int F, int C) {
+                                                           int B, int T, int F, int C, unsigned* peak) {
     MV_DYN_SMEM(smem);
     float* sw = reinterpret_cast<float*>(smem);  // [C][9] weights, then [C] bias
     for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, f
     __syncthreads();
     const int groups = C >> 3;
     const int64_t total = (int64_t)B * F * T * groups;
+    float pk = 0.0f;   // S16: largest scaled value this lane stores (s16map.h)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(i % groups);
         const int64_t pix = i / groups;  // (b*F + f)*T + t
@@ -420,11 +421,13 @@ __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* feats, f
             half_t* unit = reinterpret_cast<half_t*>(out) + (pix * C + (cg >> 1) * 16) * 2 + (cg & 1) * 8;
             s16_store4(unit, float4v{o[0], o[1], o[2], o[3]});
             s16_store4(unit + 4, float4v{o[4], o[5], o[6], o[7]});
+            pk = s16_peak_of(s16_peak_of(pk, float4v{o[0], o[1], o[2], o[3]}), float4v{o[4], o[5], o[6], o[7]});
         } else {
             *reinterpret_cast<float4v*>(out + pix * C + cg * 8) = float4v{o[0], o[1], o[2], o[3]};
             *reinterpret_cast<float4v*>(out + pix * C + cg * 8 + 4) = float4v{o[4], o[5], o[6], o[7]};
         }
     }
+    if (S16 && peak != nullptr) s16_peak_commit(peak, pk * CS_XSCALE);   // (uniform condition: every lane arrives)
 }
 
 int conv2d_first_launch(const float* feats, float* out, const float* w, const float* bias, int B, int T, int F, int C,
@@ -433,17 +436,17 @@ int conv2d_first_launch(const float* feats, float* out, const float* w, const fl
     MV_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024, "conv2d_first: output maps must be a multiple of 8");
     const int64_t total = (int64_t)B * F * T * (C / 8);
     const int grid = (int)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
-    MV_LAUNCH(conv2d_first_kernel<false>, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, out, w, bias, B, T, F, C);
+    MV_LAUNCH(conv2d_first_kernel<false>, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, out, w, bias, B, T, F, C, static_cast<unsigned*>(nullptr));
     return check_launch("conv2d_first_kernel");
 }
 
-int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream) {
+int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream, unsigned* peak) {
     MV_REQUIRE(feats != nullptr && out != nullptr && w != nullptr && bias != nullptr, "conv2d_first_s16: null pointer");
     MV_REQUIRE(C > 0 && C % 16 == 0 && C <= 1024, "conv2d_first_s16: output maps must be a multiple of 16");
     const int64_t total = (int64_t)B * F * T * (C / 8);
     const int grid = (int)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
     MV_LAUNCH(conv2d_first_kernel<true>, (grid, 1, 1), (256, 1, 1), (size_t)C * 10 * sizeof(float), stream, feats, reinterpret_cast<float*>(out), w, bias, B,
-              T, F, C);
+              T, F, C, peak);
     return check_launch("conv2d_first_kernel");
 }
 

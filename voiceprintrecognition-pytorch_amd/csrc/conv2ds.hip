@@ -56,6 +56,7 @@ struct Conv2dsArgs {
     const half_t* add;   // optional: y2 = y + add
     half_t* y;
     half_t* y2;
+    unsigned* peak;      // optional: largest |stored value * 64| before the clamp, as float bits (s16map.h)
     int64_t ldx, ldx2, ldres, ldres2, ldadd, ldy, ldy2;  // channels (= 4-byte elements) between pixels
     int cin1u, cinu, nchunks, wunits, cout16;
     int B, H, W, Ho, Wo, sh, sw, epi;
@@ -259,6 +260,8 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     }
     const float osc64 = a.oscale * CS_XSCALE;
     const float lo64 = fminf(fmaxf(a.lo * CS_XSCALE, -65504.0f), 65504.0f), hi64 = fminf(fmaxf(a.hi * CS_XSCALE, -65504.0f), 65504.0f);
+    const bool track = a.peak != nullptr;   // uniform
+    float pk = 0.0f;
     // step j of stage c of a tile: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j.  The weights do not depend on the pixel tile.
     constexpr int SPS = KS == 3 ? TAPS : KCH;
     static_assert(SPS % 3 == 0, "the weight register sets rotate with period 3");
@@ -441,31 +444,44 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
                     for (int r = 0; r < 4; ++r) X[r] = acc[u0 + u][i][r] * osc64 + bias64[i][r];
                     if (a.epi == 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r] + o1[r], lo64), hi64);
+                        for (int r = 0; r < 4; ++r) X[r] += o1[r];
+                        if (track && ok[u]) pk = s16_peak_of(pk, float4v{fmaxf(X[0], a.lo * CS_XSCALE), fmaxf(X[1], a.lo * CS_XSCALE), fmaxf(X[2], a.lo * CS_XSCALE), fmaxf(X[3], a.lo * CS_XSCALE)});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r], lo64, hi64);
                     } else if (a.epi == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = X[r] * CS_XSCALE_INV;
-                            X[r] = fminf(fmaxf(v / (1.0f + expf(-v)) * CS_XSCALE, -65504.0f), 65504.0f);
+                            X[r] = v / (1.0f + expf(-v)) * CS_XSCALE;
                         }
+                        if (track && ok[u]) pk = s16_peak_of(pk, X);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float th = tanhf(X[r] * CS_XSCALE_INV);  // x_att = 1 + th;  out = x * x_att + y * (2 - x_att)
-                            X[r] = fminf(fmaxf(o1[r] * (1.0f + th) + o2[r] * (1.0f - th), -65504.0f), 65504.0f);
+                            X[r] = o1[r] * (1.0f + th) + o2[r] * (1.0f - th);
                         }
+                        if (track && ok[u]) pk = s16_peak_of(pk, X);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r]);
                     }
                     const uint4v w1 = s16_swap4(X);
                     if (ok[u]) *reinterpret_cast<uint4v*>(a.y + pixo[u] * a.ldy * 2 + coff) = w1;
                     if (has3) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) X[r] = fminf(fmaxf(X[r] + o2[r], -65504.0f), 65504.0f);
+                        for (int r = 0; r < 4; ++r) X[r] += o2[r];
+                        if (track && ok[u]) pk = s16_peak_of(pk, X);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r]);
                         const uint4v w2 = s16_swap4(X);
                         if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;
                     }
                 }
         }
     }
+    if (track) s16_peak_commit(a.peak, pk);   // (every lane of the consumer wave is here)
 }
 
 // ---- launch ------------------------------------------------------------------------------------------------------------------------------
@@ -658,6 +674,7 @@ int conv2ds_launch(const MvConv2dsDesc& d, hipStream_t stream) {
     a.cout16 = d.cout16;
     a.B = d.B; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.sh = d.stride; a.sw = sw; a.epi = d.epi;
     a.lo = d.lo; a.hi = d.hi; a.oscale = d.oscale;
+    a.peak = d.peak;
     a.R = plan.R; a.ncs = plan.ncs; a.tiles = plan.tiles; a.CT = plan.CT; a.ncons = plan.ncons; a.nprod = plan.nprod;
     a.pc = plan.pc; a.pcv = plan.pcv; a.pc_magic = plan.pc > 0 ? 65536 / plan.pc + 1 : 0;
     a.ns = plan.ns; a.pp = plan.pp; a.wg_per_ct = plan.wg_per_ct;

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void fcm_band_kernel(FcmConvArgs a, int n_ttil
 // fp32 head (campplus.hip): [B, F8, T, 32] fp32 -> [B, T, F8, 32] fp16; thread = 8 maps of one (b, f, t)
 // S16: the maps in the split-fp16 form of conv2ds.hip (s16map.h) instead of fp32
 template <bool S16>
-__global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* maps, half_t* rows, int64_t n8, int T, int F8) {
+__global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* maps, half_t* rows, int64_t n8, int T, int F8, float scale) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const int c8 = (int)(i & 3);
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256) void fcm_rows_from_f32_kernel(const float* map
     half8v o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        o[e] = (half_t)fmed3(lo[e], -65504.0f, 65504.0f);
-        o[4 + e] = (half_t)fmed3(hi[e], -65504.0f, 65504.0f);
+        o[e] = (half_t)s16_clamp(lo[e] * scale);   // saturates at the fp16 range like the fp16 head's maps; a NaN stays a NaN
+        o[4 + e] = (half_t)s16_clamp(hi[e] * scale);
     }
     *reinterpret_cast<half8v*>(rows + ((b * T + t) * F8 + f) * FCM_C + c8 * 8) = o;
 }
@@ -426,15 +426,15 @@ int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int 
     MV_REQUIRE(maps != nullptr && rows != nullptr && B > 0 && T > 0 && F8 > 0, "fcm_rows_from_f32: bad argument");
     const int64_t n8 = (int64_t)B * F8 * T * 4;
     MV_REQUIRE(ceil_div(n8, 256) < ((int64_t)1 << 31), "fcm_rows_from_f32: grid too large");
-    MV_LAUNCH(fcm_rows_from_f32_kernel<false>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, maps, rows, n8, T, F8);
+    MV_LAUNCH(fcm_rows_from_f32_kernel<false>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, maps, rows, n8, T, F8, 1.0f);
     return check_launch("fcm_rows_from_f32_kernel");
 }
 
-int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream) {
+int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream, float scale) {
     MV_REQUIRE(maps != nullptr && rows != nullptr && B > 0 && T > 0 && F8 > 0, "fcm_rows_from_s16: bad argument");
     const int64_t n8 = (int64_t)B * F8 * T * 4;
     MV_REQUIRE(ceil_div(n8, 256) < ((int64_t)1 << 31), "fcm_rows_from_s16: grid too large");
-    MV_LAUNCH(fcm_rows_from_f32_kernel<true>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, reinterpret_cast<const float*>(maps), rows, n8, T, F8);
+    MV_LAUNCH(fcm_rows_from_f32_kernel<true>, ((unsigned)ceil_div(n8, 256), 1, 1), (256, 1, 1), 0, stream, reinterpret_cast<const float*>(maps), rows, n8, T, F8, scale);
     return check_launch("fcm_rows_from_f32_kernel");
 }
 

@@ -31,7 +31,8 @@ int64_t conv2ds_packed_floats(int cout16, int cin16, int ks);
 float conv2ds_pack_host(const float* w_dense, int cout16, int cin16, int ks, half_t* out);  // [cout16][taps][cin16] fp32 -> split; returns oscale
 int map_split_launch(const float* x, void* y, int64_t n, hipStream_t stream);
 int map_merge_launch(const void* x, float* y, int64_t n, hipStream_t stream);
-int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream);
+// peak (optional device word): largest |64 * value| stored, as float bits (s16map.h)
+int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream, unsigned* peak = nullptr);
 int tstp_s16_launch(const half_t* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);
 
 int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
@@ -48,7 +49,7 @@ int fcm_conv3x3_launch(const half_t* x, int Fin, int sf, const half_t* x2, int F
 // fp32 head of CAM++: maps fp32 [B, F8, T, 32] -> the TDNN's input rows fp16 [B, T, F8, 32] (saturating at +-65504)
 int fcm_rows_from_f32_launch(const float* maps, half_t* rows, int B, int T, int F8, hipStream_t stream);
 // the same from S16 maps (the split-fp16 head)
-int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream);
+int fcm_rows_from_s16_launch(const half_t* maps, half_t* rows, int B, int T, int F8, hipStream_t stream, float scale = 1.0f);   // rows = maps * scale
 // one BasicResBlock of the FCM head (campplus.py:221-254) as one launch, intermediate map kept in LDS (fcmblock.hip)
 bool fcm_block_supported(const half_t* y, int64_t y_sB, int64_t y_sF, int64_t y_sT, int T, int Fin);
 // feats != nullptr (then x == nullptr, sf == 2): the block input is head.conv1 + bn1 + ReLU of the fp32 features [B, T, Fin], evaluated inside

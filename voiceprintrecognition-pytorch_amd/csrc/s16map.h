@@ -8,6 +8,22 @@ namespace mv {
 constexpr float CS_XSCALE = 64.0f;
 constexpr float CS_XSCALE_INV = 1.0f / 64.0f;
 
+// Stored values are clamped to the fp16 range (|V| <= 65504, i.e. |value| <= 1023.5 at the scale of 64): the split SATURATES there.  A NaN is not a
+// number to clamp -- fminf / fmaxf would turn it into a bound and hide it -- so it travels on.  Kernels that store S16 maps can report the largest
+// |V| they wanted to store (before the clamp) to a device word (s16_peak_*: the float's bits, monotonic under an unsigned max), which is how a
+// handle learns that its maps need a smaller scale (campplus.hip: the exact head's gain) and how saturation on real inputs becomes visible.
+__device__ __forceinline__ float s16_clamp(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float s16_clamp(float v) { return s16_clamp(v, -65504.0f, 65504.0f); }
+__device__ __forceinline__ float s16_peak_of(float pk, const float4v& X) {   // (fmaxf drops NaNs: they are reported by the data itself)
+    return fmaxf(fmaxf(pk, fmaxf(fabsf(X[0]), fabsf(X[1]))), fmaxf(fabsf(X[2]), fabsf(X[3])));
+}
+// every lane of the wave calls it with its running peak; one atomic per wave
+__device__ __forceinline__ void s16_peak_commit(unsigned* dst, float pk) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) pk = fmaxf(pk, __shfl_xor(pk, off));
+    if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(dst, __builtin_bit_cast(unsigned, pk));
+}
+
 // p = position of the hi quadruple: unit base + 4 * (channel quadruple inside the unit)
 __device__ __forceinline__ float4v s16_load4(const half_t* p) {
     const half4v h = *reinterpret_cast<const half4v*>(p), l = *reinterpret_cast<const half4v*>(p + 16);
@@ -20,7 +36,7 @@ __device__ __forceinline__ void s16_store4(half_t* p, const float4v& v) {
     half4v h, l;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float X = fminf(fmaxf(v[r] * CS_XSCALE, -65504.0f), 65504.0f);
+        const float X = s16_clamp(v[r] * CS_XSCALE);
         h[r] = (half_t)X;
         l[r] = (half_t)(X - (float)h[r]);
     }

@@ -67,7 +67,7 @@ class MvConv2dsDesc(ctypes.Structure):
                 ('oscale', c_f32), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64), ('add', c_vp),
                 ('ldadd', c_i64), ('y', c_vp), ('ldy', c_i64), ('y2', c_vp), ('ldy2', c_i64), ('B', c_i32), ('H', c_i32),
                 ('W', c_i32), ('cin16', c_i32), ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32),
-                ('lo', c_f32), ('hi', c_f32), ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32), ('nbw_hint', c_i32),
+                ('lo', c_f32), ('hi', c_f32), ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32), ('peak', c_vp), ('nbw_hint', c_i32),
                 ('ct_hint', c_i32), ('rows_hint', c_i32), ('ring_hint', c_i32), ('wgs_hint', c_i32), ('spw_hint', c_i32), ('nprod_hint', c_i32)]
 
 
@@ -421,7 +421,10 @@ class Model:
     def campp_head(self):
         """CAM++ handles: {'head': 'f16' | 'f32', 'calibration': largest probe figure (-1 when pinned), 'probes': the three figures} -- the
         FCM head the handle chose at create (include/mvector_hip.h, MvCamppCfg.head_precision)"""
-        return {'head': 'f32' if self.info(1) == 1.0 else 'f16', 'calibration': self.info(2), 'probes': tuple(self.info(3 + p) for p in range(3))}
+        d = {'head': 'f32' if self.info(1) == 1.0 else 'f16', 'calibration': self.info(2), 'probes': tuple(self.info(3 + p) for p in range(3))}
+        if d['head'] == 'f32':   # the exact head's range (include/mvector_hip.h, MV_INFO_CAMPP_HEAD_*): gain 2^k, probe peak, peak / saturation on real inputs
+            d.update(gain_log2=int(self.info(6)), probe_peak=self.info(7), peak=self.info(8), saturated=self.info(9) == 1.0)
+        return d
 
     def forward(self, feats):
         assert feats.dim() == 3 and feats.dtype == torch.float32
