@@ -79,7 +79,9 @@ struct FbankArgs {
     FbankTables tab;
 };
 
-// NG = groups of 32 samples that cover the window (13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512);
+// NG = groups of 32 samples that cover the window (fbank_kernel: 13 when 384 < win <= 416, e.g. 25 ms at 16 kHz; 16 = any window up to 512.
+// fbank_tile_kernel: 10 / 12 / 13 / 15 for windows of 289..320 / 353..384 / 385..416 / 449..480 samples -- 20 / 24 / 25 / 30 ms at 16 kHz --, whose
+// groups 0 .. NG - 2 are full at compile time; 16 for every other window);
 // VEC2: rows and frames start on 8-byte boundaries, samples are fetched as float2
 template <int NG, bool VEC2, int FB_WAVES>
 __global__ __launch_bounds__(FB_WAVES * 64) void fbank_kernel(FbankArgs a) {
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
-            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            const bool full = NG < 16 ? n1 < NG - 1 : 32 * n1 + 32 <= a.win;   // NG < 16 is launched for 32 (NG - 1) < win <= 32 NG only
             // first group: x[-1] := x[0] (replicate); groups that reach beyond the window: clamped (the row may end with the
             // frame), their surplus taps are zeroed when the group is consumed
             int j = idx;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(FBT_WAVES * 64) void fbank_tile_kernel(FbankArgs a)
 #pragma unroll
         for (int n1 = 0; n1 < NG; ++n1) {
             const int idx = 32 * n1 + 2 * l16;
-            const bool full = NG == 13 ? n1 < 12 : 32 * n1 + 32 <= a.win;
+            const bool full = NG < 16 ? n1 < NG - 1 : 32 * n1 + 32 <= a.win;   // NG < 16 is launched for 32 (NG - 1) < win <= 32 NG only
             x0[n1] = full || idx < a.win ? r[n1][1] : 0.0f;
             x1[n1] = full || idx + 1 < a.win ? r[n1][2] : 0.0f;
         }
@@ -877,10 +879,14 @@ static bool fbank_tile_geometry_ok(const MvFbank* h) {
     // wrong features of 20 / 24 ms windows.  tests/test_gpu_parity.py::test_gpu_fbank_arguments runs both instantiations against the oracle.)
 }
 
-static bool fbank_tile_ng13(int win) { return win > 12 * 32 && win <= 13 * 32; }
+// sample groups of the instantiation a window runs: its own count when that is instantiated (20 / 24 / 25 / 30 ms at 16 kHz), else 16
+static int fbank_tile_ng(int win) {
+    const int ng = (win + 31) / 32;
+    return (ng == 10 || ng == 12 || ng == 13 || ng == 15) ? ng : 16;
+}
 
 static size_t fbank_tile_fixed_lds_bytes(int win) {
-    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::fbt_win_floats(fbank_tile_ng13(win) ? 13 : 16) + 512) * sizeof(float);
+    return ((size_t)mv::FBT_WAVES * mv::FBT_SLOT_FLOATS + mv::fbt_win_floats(fbank_tile_ng(win)) + 512) * sizeof(float);
 }
 
 template <int NG, bool V>
@@ -888,20 +894,29 @@ static hipError_t fbank_tile_set_smem() {
     return MV_SET_MAX_SMEM((mv::fbank_tile_kernel<NG, V, FBT_G0, FBT_G1>), 160 * 1024);
 }
 
-static void fbank_tile_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, bool vec2) {
-    const bool ng13 = fbank_tile_ng13(a.win);
-    const dim3 grid(B, 1, 1), block(mv::FBT_WAVES * 64, 1, 1);
-    if (ng13 && vec2) {
-        MV_LAUNCH((mv::fbank_tile_kernel<13, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
-    } else if (ng13) {
-        MV_LAUNCH((mv::fbank_tile_kernel<13, false, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
-    } else if (vec2) {
-        MV_LAUNCH((mv::fbank_tile_kernel<16, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+template <int NG>
+static void fbank_tile_launch_ng(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, bool vec2) {
+    if (vec2) {
+        MV_LAUNCH((mv::fbank_tile_kernel<NG, true, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
     } else {
-        MV_LAUNCH((mv::fbank_tile_kernel<16, false, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
+        MV_LAUNCH((mv::fbank_tile_kernel<NG, false, FBT_G0, FBT_G1>), (B, 1, 1), (mv::FBT_WAVES * 64, 1, 1), smem, st, a);
     }
-    (void)grid;
-    (void)block;
+}
+
+static void fbank_tile_launch(int B, size_t smem, hipStream_t st, const mv::FbankArgs& a, bool vec2) {
+    switch (fbank_tile_ng(a.win)) {
+        case 10: return fbank_tile_launch_ng<10>(B, smem, st, a, vec2);
+        case 12: return fbank_tile_launch_ng<12>(B, smem, st, a, vec2);
+        case 13: return fbank_tile_launch_ng<13>(B, smem, st, a, vec2);
+        case 15: return fbank_tile_launch_ng<15>(B, smem, st, a, vec2);
+        default: return fbank_tile_launch_ng<16>(B, smem, st, a, vec2);
+    }
+}
+
+template <int NG>
+static hipError_t fbank_tile_set_smem_ng() {
+    hipError_t e = fbank_tile_set_smem<NG, true>();
+    return e == hipSuccess ? fbank_tile_set_smem<NG, false>() : e;
 }
 
 extern "C" {
@@ -1026,8 +1041,8 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
         return mv::fail(MV_ERR_UNSUPPORTED, "mv_fbank_create: fbank_tile_kernel is instantiated for log power spectra on the mel geometry of 80 bins / 16 kHz / "
                                             "512-point FFT (mel passes of 28 + 12 bins) with an even window; this configuration runs fbank_kernel");
     }
-    if (h->tile_kernel && (fbank_tile_set_smem<13, true>() != hipSuccess || fbank_tile_set_smem<13, false>() != hipSuccess ||
-                           fbank_tile_set_smem<16, true>() != hipSuccess || fbank_tile_set_smem<16, false>() != hipSuccess)) {
+    if (h->tile_kernel && (fbank_tile_set_smem_ng<10>() != hipSuccess || fbank_tile_set_smem_ng<12>() != hipSuccess || fbank_tile_set_smem_ng<13>() != hipSuccess ||
+                           fbank_tile_set_smem_ng<15>() != hipSuccess || fbank_tile_set_smem_ng<16>() != hipSuccess)) {
         mv_fbank_destroy(h);
         return mv::fail(MV_ERR_HIP, "mv_fbank_create: cannot reserve dynamic LDS for fbank_tile_kernel");
     }
