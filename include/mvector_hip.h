@@ -125,10 +125,19 @@ typedef struct MvMelSpecCfg {
     float f_min;         /* 0 */
     float f_max;         /* sample_rate / 2 */
     int32_t n_mels;      /* 128 */
-    float power;         /* 2.0 (1.0 also supported) */
+    float power;         /* 2.0; any positive exponent of |X| (the FFT kernels take 2, the dense-DFT kernel every other one) */
     int32_t center;      /* 1 */
     int32_t subtract_time_mean;
+    /* ---- since ABI 4: further MelSpectrogram(**method_args) keyword arguments (featurizer.py:41-42), all of them tables ---- */
+    int32_t mel_scale;   /* MV_MEL_HTK (0) | MV_MEL_SLANEY */
+    int32_t norm;        /* 0 = None | MV_MEL_NORM_SLANEY (1): filter j times 2 / (f[j + 2] - f[j]) */
+    int32_t normalized;  /* 0 = False | MV_STFT_NORM_WINDOW (1; True): spectrum / sqrt(sum window^2) | MV_STFT_NORM_FRAME_LENGTH (2): / sqrt(n_fft) */
+    const float* window; /* NULL = periodic Hann | HOST array [win_length]: what window_fn(win_length, **wkwargs) returned (copied at create) */
 } MvMelSpecCfg;
+
+enum { MV_MEL_HTK = 0, MV_MEL_SLANEY = 1 };
+enum { MV_MEL_NORM_NONE = 0, MV_MEL_NORM_SLANEY = 1 };
+enum { MV_STFT_NORM_NONE = 0, MV_STFT_NORM_WINDOW = 1, MV_STFT_NORM_FRAME_LENGTH = 2 };
 
 typedef struct MvMelSpec MvMelSpec;
 

@@ -32,7 +32,7 @@ FBANK_DEFAULTS = dict(
 MELSPEC_DEFAULTS = dict(
     sample_rate=16000, n_fft=400, win_length=None, hop_length=None, f_min=0.0, f_max=None,
     pad=0, n_mels=128, power=2.0, normalized=False, center=True, pad_mode='reflect',
-    onesided=None, norm=None, mel_scale='htk')
+    onesided=None, norm=None, mel_scale='htk', window_fn=None, wkwargs=None)
 
 EPS_F32 = float(torch.finfo(torch.float32).eps)  # 1.1920929e-07, the Kaldi log floor
 
@@ -196,39 +196,87 @@ def audio_featurizer_fbank_f64(waveforms, input_lens_ratio=None, method_args=Non
     return feats
 
 
-def htk_mel_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
-    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
+def _hz_to_mel(freq, mel_scale='htk'):
+    """torchaudio.functional.functional._hz_to_mel"""
+    if mel_scale == 'htk':
+        return 2595.0 * math.log10(1.0 + (freq / 700.0))
+    f_min, f_sp = 0.0, 200.0 / 3
+    mels = (freq - f_min) / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = (min_log_hz - f_min) / f_sp
+    logstep = math.log(6.4) / 27.0
+    if freq >= min_log_hz:
+        mels = min_log_mel + math.log(freq / min_log_hz) / logstep
+    return mels
+
+
+def _mel_to_hz(mels, mel_scale='htk'):
+    """torchaudio.functional.functional._mel_to_hz"""
+    if mel_scale == 'htk':
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_min, f_sp = 0.0, 200.0 / 3
+    freqs = f_min + f_sp * mels
+    min_log_hz = 1000.0
+    min_log_mel = (min_log_hz - f_min) / f_sp
+    logstep = math.log(6.4) / 27.0
+    log_t = mels >= min_log_mel
+    freqs[log_t] = min_log_hz * torch.exp(logstep * (mels[log_t] - min_log_mel))
+    return freqs
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale='htk'):
+    """torchaudio.functional.melscale_fbanks -> [n_freqs, n_mels] (triangles in Hz; norm='slaney': filter j times 2 / (f[j+2] - f[j]))."""
+    if norm is not None and norm != 'slaney':
+        raise ValueError('norm must be one of None or "slaney"')
+    if mel_scale not in ('htk', 'slaney'):
+        raise ValueError('mel_scale should be one of "htk" or "slaney".')
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
-    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
-    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_min = _hz_to_mel(f_min, mel_scale)
+    m_max = _hz_to_mel(f_max, mel_scale)
     m_pts = torch.linspace(m_min, m_max, n_mels + 2)
-    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_pts = _mel_to_hz(m_pts, mel_scale)
     f_diff = f_pts[1:] - f_pts[:-1]
     slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
     down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return torch.max(torch.zeros(1), torch.min(down, up))
+    fb = torch.max(torch.zeros(1), torch.min(down, up))
+    if norm == 'slaney':
+        enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+        fb = fb * enorm.unsqueeze(0)
+    return fb
+
+
+def htk_mel_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
+    return melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate)
 
 
 def mel_spectrogram(waveforms, **kwargs):
-    """waveforms fp32 [B, L] -> [B, n_mels, 1 + L // hop] raw-power mel spectrogram."""
+    """waveforms fp32 [B, L] -> [B, n_mels, 1 + L // hop] mel spectrogram (torchaudio.transforms.MelSpectrogram = Spectrogram + MelScale;
+    torchaudio.functional.spectrogram for the normalisation modes: "frame_length" is torch.stft(normalized=True), "window" / True divides the
+    complex spectrum by sqrt(sum window^2))."""
     a = dict(MELSPEC_DEFAULTS)
     unknown = set(kwargs) - set(a)
     if unknown:
         raise TypeError(f'unexpected MelSpectrogram arguments {sorted(unknown)}')
     a.update(kwargs)
-    if a['mel_scale'] != 'htk' or a['norm'] is not None or a['pad'] != 0 or a['normalized']:
-        raise NotImplementedError('oracle restates only the htk / un-normalised MelSpectrogram')
+    if a['pad'] != 0 or a['power'] is None or a['onesided'] not in (None, True):
+        raise NotImplementedError('oracle restates MelSpectrogram without signal padding, with a real exponent, one-sided')
+    if a['normalized'] not in (False, True, 'window', 'frame_length'):
+        raise ValueError(f"Invalid normalized parameter: {a['normalized']}")
     n_fft = a['n_fft']
     win = a['win_length'] if a['win_length'] is not None else n_fft
     hop = a['hop_length'] if a['hop_length'] is not None else win // 2
     sr = a['sample_rate']
     f_max = a['f_max'] if a['f_max'] is not None else float(sr // 2)
     x = torch.as_tensor(waveforms, dtype=torch.float32)
-    spec = torch.stft(x, n_fft, hop, win, torch.hann_window(win), center=a['center'],
-                      pad_mode=a['pad_mode'], normalized=False, onesided=True, return_complex=True)
+    window = a['window_fn'](win, **(a['wkwargs'] or {})) if a['window_fn'] is not None else torch.hann_window(win)
+    spec = torch.stft(x, n_fft, hop, win, window, center=a['center'], pad_mode=a['pad_mode'], normalized=a['normalized'] == 'frame_length',
+                      onesided=True, return_complex=True)
+    if a['normalized'] in (True, 'window'):
+        spec = spec / window.pow(2.0).sum().sqrt()
     spec = spec.abs() if a['power'] == 1.0 else spec.abs().pow(a['power'])
-    fb = htk_mel_fbanks(n_fft // 2 + 1, a['f_min'], f_max, a['n_mels'], sr)
+    fb = melscale_fbanks(n_fft // 2 + 1, a['f_min'], f_max, a['n_mels'], sr, a['norm'], a['mel_scale'])
     return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
 
 

@@ -994,6 +994,30 @@ def melspec_case(cdll, device, wav, ratio, method_args, rtol=2e-4):
     return err / scale if scale > 0.0 else err   # (a single frame: the time mean takes everything away)
 
 
+# MelSpectrogram(**method_args) keyword arguments beyond the shipped configurations (featurizer.py:41-42), shared by the emulator and the device sweep;
+# every FFT kernel (n_fft 400: melspec_tile_kernel, powers of two: melspec_pow2_kernel) and the dense-DFT path meets each table option
+MELSPEC_ARG_CASES = [
+    dict(mel_scale='slaney'), dict(norm='slaney'), dict(mel_scale='slaney', norm='slaney'),
+    dict(normalized=True), dict(normalized='window', n_fft=512), dict(normalized='frame_length'), dict(normalized='frame_length', n_fft=480, n_mels=64),
+    dict(window_fn=torch.hamming_window), dict(window_fn=torch.blackman_window, wkwargs=dict(periodic=False), n_fft=1024, hop_length=320, n_mels=64),
+    dict(window_fn=torch.kaiser_window, wkwargs=dict(periodic=True, beta=8.0), n_fft=320, win_length=300, hop_length=100, n_mels=40),
+    dict(power=1.0), dict(power=1.5, n_fft=512), dict(power=3.0, n_mels=64), dict(power=1.0, n_fft=256, mel_scale='slaney', norm='slaney', n_mels=40),
+    dict(center=False), dict(center=False, n_fft=512, hop_length=160, norm='slaney'),
+    dict(sample_rate=8000, n_fft=256, n_mels=40, f_min=60.0, f_max=3800.0, mel_scale='slaney'),
+    dict(sample_rate=22050, n_fft=1024, hop_length=256, n_mels=80, f_min=0.0, f_max=8000.0, norm='slaney', mel_scale='slaney'),   # librosa-style
+    dict(n_fft=400, win_length=320, hop_length=160, n_mels=80, normalized=True, window_fn=torch.hann_window, wkwargs=dict(periodic=False)),
+]
+
+
+def melspec_arguments_case(cdll, device, idx, B=3, seconds=0.5):
+    from oracle import frontend
+    args = MELSPEC_ARG_CASES[idx]
+    L = int(args.get('sample_rate', 16000) * seconds) + 37
+    wav = frontend.synth_waveforms(B, L, seed=200 + idx)
+    ratio = torch.tensor([1.0, 0.61, 0.8, 0.33, 0.5] * (B // 5 + 1))[:B]
+    return melspec_case(cdll, device, wav, ratio, args)
+
+
 def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0, alone_rows=0):
     """Fused Res2Net chain vs a torch fp32 evaluation that rounds to fp16 exactly where the kernel does."""
     g = torch.Generator().manual_seed(seed)

@@ -454,3 +454,11 @@ def test_emu_conv2ds_reports_its_peak_and_keeps_nans(idx):
     """S16 maps saturate at |value| = 1023.5 and the clamps turned NaNs into finite bounds.  MvConv2dsDesc.peak reports the largest
     value a launch wanted to store (the CAM++ handle picks its exact head's gain from it and exposes saturation on real inputs); NaNs travel on."""
     lc.conv2ds_case(emu_cdll(), 'cpu', **S16_RANGE_CASES[idx])
+
+
+@pytest.mark.parametrize('idx', range(len(lc.MELSPEC_ARG_CASES)))
+def test_emu_melspec_arguments(idx):
+    """MelSpectrogram(**method_args) beyond the shipped configurations (featurizer.py:41-42): Slaney mel scale / area normalisation, the three
+    `normalized` modes, window_fn (+ wkwargs) evaluated once like torchaudio does, any positive power, centre off, other rates -- all of them tables
+    of the same kernels (tests/layer_checks.py::MELSPEC_ARG_CASES; the device runs the list at 3 s: test_gpu_melspec_arguments)"""
+    lc.melspec_arguments_case(emu_cdll(), 'cpu', idx)

@@ -1006,3 +1006,12 @@ def test_gpu_campp_hot_head_golden_runs_the_exact_head_inside_its_range():
     info0 = {6: None, 7: None}
     lc.model_case(product_lib(), DEV, 'campp_stress', tol=1e-4, info=info0, head=2)
     assert info0[6] == 0.0 and info0[7] < 1023.5 / 16.0 * 1.0001, info0   # an ordinary checkpoint keeps the scale of 64
+
+
+@pytest.mark.parametrize('idx', range(len(lc.MELSPEC_ARG_CASES)))
+def test_gpu_melspec_arguments(idx):
+    """HIP MelSpectrogram vs the oracle over the keyword arguments beyond the shipped configurations (tests/layer_checks.py::MELSPEC_ARG_CASES):
+    Slaney mel scale / norm (the oracle's filterbanks agree with transformers' independent ones to 2e-7), normalized = True / "window" /
+    "frame_length", window_fn + wkwargs, power 1 / 1.5 / 3, centre off, 8 / 22.05 kHz -- on 5 x 3 s with a ragged mask and 260 x 0.5 s"""
+    lc.melspec_arguments_case(product_lib(), DEV, idx, B=5, seconds=3.0)
+    lc.melspec_arguments_case(product_lib(), DEV, idx, B=260, seconds=0.5)

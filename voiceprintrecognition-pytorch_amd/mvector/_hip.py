@@ -30,7 +30,7 @@ class MvFbankCfg(ctypes.Structure):
 class MvMelSpecCfg(ctypes.Structure):
     _fields_ = [('sample_rate', c_i32), ('n_fft', c_i32), ('win_length', c_i32), ('hop_length', c_i32),
                 ('f_min', c_f32), ('f_max', c_f32), ('n_mels', c_i32), ('power', c_f32), ('center', c_i32),
-                ('subtract_time_mean', c_i32)]
+                ('subtract_time_mean', c_i32), ('mel_scale', c_i32), ('norm', c_i32), ('normalized', c_i32), ('window', c_vp)]
 
 
 class MvTensorRef(ctypes.Structure):
@@ -317,14 +317,20 @@ class MelSpec:
         self._cdll.mv_melspec_default_cfg(ctypes.byref(cfg))
         a = dict(method_args or {})
         allowed = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
-                   'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale'}
+                   'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale', 'window_fn', 'wkwargs'}
         for k in a:
             if k not in allowed:
                 raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
-        if a.get('pad', 0) != 0 or a.get('normalized', False) or a.get('norm') is not None or \
-                a.get('mel_scale', 'htk') != 'htk' or a.get('pad_mode', 'reflect') != 'reflect' or \
-                a.get('onesided') not in (None, True):
+        # not implemented: zero padding of the signal (pad), padding modes of the centred frames other than reflect, two-sided spectra
+        # (torchaudio's own MelScale refuses their bin count), power=None (a complex spectrogram has no mel scale)
+        if a.get('pad', 0) != 0 or a.get('pad_mode', 'reflect') != 'reflect' or a.get('onesided') not in (None, True) or a.get('power', 2.0) is None:
             raise NotImplementedError('MelSpectrogram option not implemented by the HIP kernel')
+        if a.get('norm') not in (None, 'slaney'):
+            raise ValueError('norm must be one of None or "slaney"')          # torchaudio.functional.melscale_fbanks' own messages
+        if a.get('mel_scale', 'htk') not in ('htk', 'slaney'):
+            raise ValueError('mel_scale should be one of "htk" or "slaney".')
+        if a.get('normalized', False) not in (False, True, 'window', 'frame_length'):
+            raise ValueError(f"Invalid normalized parameter: {a.get('normalized')}")
         cfg.sample_rate = int(a.get('sample_rate', 16000))
         cfg.n_fft = int(a.get('n_fft', 400))
         win = a.get('win_length')
@@ -338,6 +344,15 @@ class MelSpec:
         cfg.power = float(a.get('power', 2.0))
         cfg.center = 1 if a.get('center', True) else 0
         cfg.subtract_time_mean = 1 if subtract_time_mean else 0
+        cfg.mel_scale = 1 if a.get('mel_scale', 'htk') == 'slaney' else 0
+        cfg.norm = 1 if a.get('norm') == 'slaney' else 0
+        cfg.normalized = {False: 0, True: 1, 'window': 1, 'frame_length': 2}[a.get('normalized', False)]
+        win_host = None
+        if a.get('window_fn') is not None:   # torchaudio evaluates window_fn(win_length, **wkwargs) once, at construction: so does this
+            win_host = a['window_fn'](cfg.win_length, **(a.get('wkwargs') or {})).detach().to(device='cpu', dtype=torch.float32).contiguous()
+            if win_host.shape != (cfg.win_length,):
+                raise ValueError(f'window_fn returned {tuple(win_host.shape)}, expected ({cfg.win_length},)')
+            cfg.window = win_host.data_ptr()
         self.n_mels = cfg.n_mels
         self._h = c_vp()
         check(self._cdll.mv_melspec_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)

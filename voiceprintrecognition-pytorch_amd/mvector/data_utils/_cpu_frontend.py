@@ -21,7 +21,7 @@ _FBANK_FIXED = {'dither': (0.0,), 'use_energy': (False,), 'vtln_warp': (1.0,), '
 _FBANK_IGNORED = ('raw_energy', 'energy_floor', 'htk_compat', 'vtln_low', 'vtln_high')
 _WINDOWS = ('povey', 'hamming', 'hanning', 'rectangular', 'blackman')
 _MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
-             'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale'}
+             'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale', 'window_fn', 'wkwargs'}
 
 
 def validate_args(method, args):
@@ -40,10 +40,15 @@ def validate_args(method, args):
         for k in args:
             if k not in _MEL_KEYS:
                 raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
-        if args.get('pad', 0) != 0 or args.get('normalized', False) or args.get('norm') is not None or \
-                args.get('mel_scale', 'htk') != 'htk' or args.get('pad_mode', 'reflect') != 'reflect' or \
-                args.get('onesided') not in (None, True):
+        if args.get('pad', 0) != 0 or args.get('pad_mode', 'reflect') != 'reflect' or args.get('onesided') not in (None, True) or \
+                args.get('power', 2.0) is None:
             raise NotImplementedError('MelSpectrogram option not implemented')
+        if args.get('norm') not in (None, 'slaney'):
+            raise ValueError('norm must be one of None or "slaney"')
+        if args.get('mel_scale', 'htk') not in ('htk', 'slaney'):
+            raise ValueError('mel_scale should be one of "htk" or "slaney".')
+        if args.get('normalized', False) not in (False, True, 'window', 'frame_length'):
+            raise ValueError(f"Invalid normalized parameter: {args.get('normalized')}")
 
 
 def _window(window_type, size, blackman_coeff):
@@ -118,19 +123,41 @@ def fbank_batch(wav, args):
     return mel
 
 
+def _hz_to_mel(f, slaney):
+    if not slaney:
+        return 2595.0 * math.log10(1.0 + f / 700.0)
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0
+    return min_log_hz / f_sp + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+
+def _mel_to_hz(m, slaney):
+    if not slaney:
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    f = f_sp * m
+    log_t = m >= min_log_mel
+    f[log_t] = min_log_hz * torch.exp(logstep * (m[log_t] - min_log_mel))
+    return f
+
+
 @functools.lru_cache(maxsize=8)
-def _mel_tables(sr, n_fft, win, f_min, f_max, n_mels):
+def _mel_fbank(sr, n_fft, f_min, f_max, n_mels, mel_scale, norm):
+    """torchaudio.functional.melscale_fbanks: [n_fft // 2 + 1, n_mels]"""
+    slaney = mel_scale == 'slaney'
     all_freqs = torch.linspace(0, sr // 2, n_fft // 2 + 1)
-    m_pts = torch.linspace(2595.0 * math.log10(1.0 + f_min / 700.0), 2595.0 * math.log10(1.0 + f_max / 700.0), n_mels + 2)
-    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    m_pts = torch.linspace(_hz_to_mel(f_min, slaney), _hz_to_mel(f_max, slaney), n_mels + 2)
+    f_pts = _mel_to_hz(m_pts, slaney)
     f_diff = f_pts[1:] - f_pts[:-1]
     slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
     fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
-    return torch.hann_window(win), fb
+    if norm == 'slaney':
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb
 
 
 def melspec_batch(wav, args):
-    """[B, L] -> [B, frames, n_mels] raw-power mel spectrogram (no log, no CMN)."""
+    """[B, L] -> [B, frames, n_mels] mel spectrogram (no log, no CMN): torchaudio.transforms.MelSpectrogram(**args)"""
     sr = int(args.get('sample_rate', 16000))
     n_fft = int(args.get('n_fft', 400))
     win = args.get('win_length')
@@ -140,9 +167,14 @@ def melspec_batch(wav, args):
     f_max = args.get('f_max')
     f_max = float(f_max if f_max is not None else sr // 2)
     power = float(args.get('power', 2.0))
-    window, fb = _mel_tables(sr, n_fft, win, float(args.get('f_min', 0.0)), f_max, int(args.get('n_mels', 128)))
+    fb = _mel_fbank(sr, n_fft, float(args.get('f_min', 0.0)), f_max, int(args.get('n_mels', 128)), args.get('mel_scale', 'htk'), args.get('norm'))
+    window = args['window_fn'](win, **(args.get('wkwargs') or {})).float() if args.get('window_fn') is not None else torch.hann_window(win)
+    normalized = args.get('normalized', False)
     spec = torch.stft(wav, n_fft, hop, win, window, center=bool(args.get('center', True)), pad_mode='reflect',
-                      normalized=False, onesided=True, return_complex=True).abs()
+                      normalized=normalized == 'frame_length', onesided=True, return_complex=True)
+    if normalized in (True, 'window'):
+        spec = spec / window.pow(2.0).sum().sqrt()
+    spec = spec.abs()
     if power != 1.0:
         spec = spec.pow(power)
     return spec.transpose(1, 2) @ fb
