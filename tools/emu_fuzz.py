@@ -204,12 +204,12 @@ def g_fbank(r):
         # more mel bins than a quarter of the transform's bins: filters narrower than two FFT bins, where a log energy IS one bin's power and the
         # per-bin rounding of a 512-point fp32 transform shows undamped (device fuzz r14b: 128 bins on kaldi's 128-point FFT at 8 kHz / 10 ms,
         # 29 of 832 k values 1e-3 .. 3e-3 from the fp64 arbiter where torch's 128-point fp32 transform stays within 7.4e-4) -- not a
-        # configuration anybody featurises with; the generator keeps to filters of two bins and more
+        # configuration anybody featurises with; the generator keeps to at most half as many filters as bins
         sf = extra.get('sample_frequency', 16000)
         size = int(sf * extra.get('frame_length', 25.0) * 0.001)
         padded = 1 << max(1, (size - 1).bit_length())
-        if kw['bins'] > padded // 8:
-            kw['bins'] = max(4, padded // 8 // 4 * 4)
+        if kw['bins'] > padded // 4:   # (at most half as many filters as the transform has bins)
+            kw['bins'] = max(4, padded // 4 // 4 * 4)
         kw['extra'] = extra
     return kw
 
