@@ -405,6 +405,9 @@ typedef struct MvConv1dDesc {
      * k = 1, stride 1, no padding, T_out == T_in, cout <= 128, no x2 / in_scale.  Finish with mv_conv1d_in_stats_finish. */
     float* in_stat_sum;
     float* in_stat_sq;
+    int32_t persist_blocks_hint;  /* 0 = one resident workgroup per CU; otherwise that many (rounded up to 8) workgroups walk the tiles of the
+                                   * persistent kernels -- tests make small problems walk several tiles per workgroup; never the bits of a result
+                                   * (since ABI 4; replaces the MV_CONV_PERSIST_BLOCKS environment hook: no getenv is left in the library) */
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
 /* floats in one partial-statistics buffer, and the reduction of the partial rows to per-utterance mean[b, c] (and

@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -73,6 +73,7 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     d.dilation, d.stride, d.pad = dil, stride, pad
     d.pad_mode = _hip.MV_PAD_REFLECT if pad_mode == 'reflect' else _hip.MV_PAD_ZERO
     d.tile = tile
+    d.persist_blocks_hint = persist_blocks
     if stats:  # fused per-utterance time statistics of y (mean; mean + std)
         nstat = cdll.mv_conv1d_stats_elems(B, T_out, cout)
         psum = torch.full((nstat,), float('nan'), device=device)

@@ -70,19 +70,15 @@ def test_gpu_conv1d(idx):
 
 
 def test_gpu_conv1d_persistent_walks_many_tiles():
-    """MV_CONV_PERSIST_BLOCKS=8 (test hook, read once per process -> subprocess): eight resident workgroups walk 5-10 tiles each (full tiles, a
-    ragged last one, 2-3 channel tiles), so the tile-boundary machinery of the persistent kernels (epilogue inside the next tile's first stage,
-    transfers requested ahead of the output stores and the counted wait behind them, parameter reload when the channel tile changes) runs on the
-    device: dense 1x1 layers on the ring kernel, a k = 3 layer on the double-buffer kernel."""
-    code = ("import sys; sys.path[:0] = %r\n"
-            "import layer_checks as lc\nfrom mvector import _hip\n"
-            "for seed, cfg in enumerate([dict(k=1, dil=1, cin=256, cout=512, T=298, B=16, tile=256),\n"
-            "                            dict(k=1, dil=1, cin=1024, cout=768, T=300, B=11, tile=256),\n"
-            "                            dict(k=3, dil=2, cin=256, cout=512, T=298, B=16, tile=256),\n"
-            "                            dict(k=1, dil=1, cin=128, cout=256, T=64, B=40, tile=256, affine=False)]):\n"
-            "    lc.conv1d_case(_hip.lib(), 'cuda', seed=seed, **cfg)\n") % (sys.path,)
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MV_CONV_PERSIST_BLOCKS='8'), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
+    """MvConv1dDesc.persist_blocks_hint = 8: eight resident workgroups walk 5-10 tiles each (full tiles, a ragged last one, 2-3 channel tiles), so
+    the tile-boundary machinery of the persistent kernels (epilogue inside the next tile's first stage, transfers requested ahead of the output
+    stores and the counted wait behind them, parameter reload when the channel tile changes) runs on the device: dense 1x1 layers on the ring
+    kernel, a k = 3 layer on the double-buffer kernel."""
+    for seed, cfg in enumerate([dict(k=1, dil=1, cin=256, cout=512, T=298, B=16, tile=256),
+                                dict(k=1, dil=1, cin=1024, cout=768, T=300, B=11, tile=256),
+                                dict(k=3, dil=2, cin=256, cout=512, T=298, B=16, tile=256),
+                                dict(k=1, dil=1, cin=128, cout=256, T=64, B=40, tile=256, affine=False)]):
+        lc.conv1d_case(product_lib(), DEV, seed=seed, persist_blocks=8, **cfg)
 
 
 def test_gpu_conv1d_input_statistics_two_launch_forms_agree():

@@ -1465,15 +1465,10 @@ static int cu_count() {
 }
 
 // Resident workgroups of the persistent kernel: one per CU (a multiple of 8 keeps  id mod 8 == XCD  across the walk).
-// MV_CONV_PERSIST_BLOCKS overrides it (tests walk several tiles per workgroup on small problems; 0 disables the kernel).
-static int persistent_blocks() {
-    static int n = -1;
-    if (n < 0) {
-        const char* e = getenv("MV_CONV_PERSIST_BLOCKS");
-        const int v = e != nullptr ? atoi(e) : cu_count();
-        n = v > 0 ? (int)round_up(v, 8) : 0;
-    }
-    return n;
+// MvConv1dDesc.persist_blocks_hint overrides it (tests walk several tiles per workgroup on small problems; never the bits of a result).
+static int persistent_blocks(const MvConv1dDesc& d) {
+    const int v = d.persist_blocks_hint > 0 ? d.persist_blocks_hint : cu_count();
+    return (int)round_up(v, 8);
 }
 
 int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
@@ -1573,7 +1568,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool persist = big && d.y_dtype == MV_DT_F16 && d.sum_dst == nullptr && d.row_bias == nullptr && d.gate == nullptr &&
                          d.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(d.y) & 15) == 0 &&
                          (d.pre_act == MV_ACT_NONE || d.pre_act == MV_ACT_RELU) &&
-                         (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) && persistent_blocks() > 0 &&
+                         (d.post_act == MV_ACT_NONE || d.post_act == MV_ACT_RELU) &&
                          (int64_t)d.k * conv1d_cin_pad(d.cin) >= 2 * CV_BK;  // at least two K stages per tile
     // 128 x 160 tile of the direct path: two workgroups per CU = 2 * CUs slots; taken when it saves a whole round of
     // workgroups (B*T = 76 288 rows x 128 channels: 477 tiles in one round instead of 596 tiles in two)
@@ -1652,7 +1647,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const int prof = prof_begin(MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
-        const int pgrid = (int)(tiles < persistent_blocks() ? round_up(tiles, 8) : persistent_blocks());
+        const int pgrid = (int)(tiles < persistent_blocks(d) ? round_up(tiles, 8) : persistent_blocks(d));
         const bool simple = d.k == 1 && d.cin % CV_BK == 0;
         // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
         const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
