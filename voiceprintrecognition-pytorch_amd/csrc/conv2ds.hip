@@ -90,7 +90,10 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 // SPW = segments per consumer wave: 8 (the waves split the output channels and share all pixels) or, for layers with few output channels, 4 / 2 / 1
 // (consumer wave w works on segments (w % PG) * SPW ..., PG = 8 / SPW, of channel group w / PG: more waves on the matrix pipe where one or two
 // blocks of 16 channels would leave three SIMDs idle; the small weight slices are then read by PG waves)
-template <int KS, int NBW, int SPW, int MAXT>
+// TRACK: the instantiation that reports the largest stored value to a.peak (MvConv2dsDesc.peak; the CAM++ exact head).  A template parameter, not a
+// branch: the running maximum and its operands cost 9-18 VGPRs in every shape (r14c: the 54.9 M ERes2NetV2 692 -> 517 utt/s with the tracking code
+// compiled into the one kernel, although its branch was never taken), so launches without a peak word run the kernel without that code.
+template <int KS, int NBW, int SPW, int MAXT, bool TRACK>
 __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     MV_DYN_SMEM(smem);
     constexpr int TAPS = KS * KS;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
     }
     const float osc64 = a.oscale * CS_XSCALE;
     const float lo64 = fminf(fmaxf(a.lo * CS_XSCALE, -65504.0f), 65504.0f), hi64 = fminf(fmaxf(a.hi * CS_XSCALE, -65504.0f), 65504.0f);
-    const bool track = a.peak != nullptr;   // uniform
+    constexpr bool track = TRACK;
     float pk = 0.0f;
     // step j of stage c of a tile: 3x3 -> tap j of chunk c; 1x1 -> chunk c * KCH + j.  The weights do not depend on the pixel tile.
     constexpr int SPS = KS == 3 ? TAPS : KCH;
@@ -623,16 +626,21 @@ int cs_plan(const MvConv2dsDesc& d, int Ho, int Wo, int sw, CsPlan* p) {
     return MV_OK;
 }
 
-template <int KS, int NBW, int SPW, int MAXT>
-int cs_launch(const Conv2dsArgs& a, const CsPlan& p, hipStream_t stream) {
+template <int KS, int NBW, int SPW, int MAXT, bool TRACK>
+int cs_launch_t(const Conv2dsArgs& a, const CsPlan& p, hipStream_t stream) {
     static DeviceOnce smem_set;
     int slot;
     if (device_once_pending(smem_set, &slot)) {
-        if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, SPW, MAXT>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
+        if (MV_SET_MAX_SMEM((conv2ds_kernel<KS, NBW, SPW, MAXT, TRACK>), 160 * 1024) != hipSuccess) return fail(MV_ERR_HIP, "conv2ds: cannot reserve dynamic LDS");
         device_once_done(smem_set, slot);
     }
-    MV_LAUNCH((conv2ds_kernel<KS, NBW, SPW, MAXT>), ((unsigned)(p.wg_per_ct * p.ctiles), 1, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds, stream, a);
+    MV_LAUNCH((conv2ds_kernel<KS, NBW, SPW, MAXT, TRACK>), ((unsigned)(p.wg_per_ct * p.ctiles), 1, 1), ((unsigned)((p.ncons + p.nprod) * 64), 1, 1), p.lds, stream, a);
     return MV_OK;
+}
+
+template <int KS, int NBW, int SPW, int MAXT>
+int cs_launch(const Conv2dsArgs& a, const CsPlan& p, hipStream_t stream) {
+    return a.peak != nullptr ? cs_launch_t<KS, NBW, SPW, MAXT, true>(a, p, stream) : cs_launch_t<KS, NBW, SPW, MAXT, false>(a, p, stream);
 }
 
 }  // namespace
