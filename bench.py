@@ -392,10 +392,12 @@ def self_launch(args):
 
 
 def rendezvous(args, rank, local_rank, world):
-    """N > 1, two stages.  (1) Every rank joins a gloo group (needs no device) and the ranks exchange their device counts: a node that cannot seat all
-    ranks says so on rank 0 and every rank leaves with exit code 2 -- after the rendezvous, with no device touched.  (2) That group is closed and the
-    ranks meet again on nccl (= RCCL), the group the step's all-gather runs on (--dry-launch: on gloo again, one more exchange, then exit 0 -- the same
-    two-stage sequence without a device).  Returns the ranks seen."""
+    """N > 1, two stages on ONE store.  (1) Every rank joins the default process group on gloo (needs no device) and the ranks exchange their device
+    counts: a node that cannot seat all ranks says so on rank 0 and every rank leaves with exit code 2 -- after the rendezvous, with no device
+    touched.  (2) `dist.new_group(backend="nccl")` (= RCCL) over the same ranks is the group the step's all-gather, barriers and max-reduce run on
+    (--dry-launch: a second gloo group, one more exchange, then exit 0 -- the same sequence without a device).  The first group is NOT closed and
+    re-opened: a second init_process_group on the same store reads the first one's stale keys (seen as "connection refused" with gloo and possible
+    as a hang with an old ncclUniqueId); new_group prefixes its keys.  Returns (ranks seen, the second group)."""
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -404,24 +406,27 @@ def rendezvous(args, rank, local_rank, world):
     ranks = sorted(int(t[0]) for t in seen)
     assert ranks == list(range(world)), ranks
     short = [int(t[2]) for t in seen if int(t[2]) <= int(t[1])]
-    dist.barrier()
-    dist.destroy_process_group()
     if short and not args.dry_launch:
+        dist.barrier()
         if rank == 0:
             print(f'bench.py --gpus {args.gpus}: all {world} ranks met, but this node has {min(short)} visible device(s) and every rank needs its own '
                   f'(LOCAL_RANK < device count): run with --gpus <= the device count.', file=sys.stderr, flush=True)
+        dist.destroy_process_group()
         sys.exit(2)
-    dist.init_process_group('gloo' if args.dry_launch else 'nccl', rank=rank, world_size=world)
+    if not args.dry_launch:
+        torch.cuda.set_device(local_rank)   # (the nccl group binds to the current device)
+    group = dist.new_group(backend='gloo' if args.dry_launch else 'nccl')
     if args.dry_launch:
         again = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(again, torch.tensor([rank], dtype=torch.int64))
+        dist.all_gather(again, torch.tensor([rank], dtype=torch.int64), group=group)
         if rank == 0:
             print(json.dumps({'dry_launch': True, 'n_gpus': args.gpus, 'ranks_seen': ranks, 'ranks_seen_second_group': sorted(int(t) for t in again),
                               'devices_per_rank': [int(t[2]) for t in seen],
                               'launcher': 'self' if os.environ.get('MV_BENCH_SELF_LAUNCHED') else 'torch.distributed.run'}), flush=True)
+        dist.barrier()
         dist.destroy_process_group()
         sys.exit(0)
-    return ranks
+    return ranks, group
 
 
 def main():
@@ -446,7 +451,10 @@ def main():
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it with --nproc-per-node {args.gpus} '
                  f'(or plainly as `python bench.py --gpus {args.gpus}`, which launches the ranks itself)')
-    ranks_seen = rendezvous(args, rank, local_rank, world) if world > 1 or args.dry_launch else [0]
+    # under a launcher (WORLD_SIZE set) the ranks always rendezvous and the step's collectives run on the second group -- also for ONE rank, so that a
+    # 1-GPU box can exercise the RCCL path of the N > 1 runs (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`); plain `python bench.py`
+    # (the driver's N = 1 command) touches no process group
+    ranks_seen, group = rendezvous(args, rank, local_rank, world) if 'WORLD_SIZE' in os.environ or args.dry_launch else ([0], None)
     if not torch.cuda.is_available():
         sys.exit('bench.py needs MI355X GPUs (torch.cuda.is_available() is False)')
     torch.cuda.set_device(local_rank)
@@ -457,9 +465,9 @@ def main():
 
     cls, kwargs, method, margs, gflop_per_utt, label, _ = MODELS[args.model]
     featurizer, model, state_cpu = build(args.model, dev)
-    if world > 1:   # checkpoint-derived choices of the native handles (CAM++ head precision): rank 0's, pinned on every rank, once
+    if group is not None:   # checkpoint-derived choices of the native handles (CAM++ head precision): rank 0's, pinned on every rank, once
         from mvector import parallel
-        parallel.sync_native_choices(model, device=dev)
+        parallel.sync_native_choices(model, device=dev, group=group)
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
@@ -475,8 +483,8 @@ def main():
         emb = model(feats)
         if events is not None:
             events[2].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, emb)
+        if group is not None:
+            dist.all_gather_into_tensor(gathered, emb, group=group)
             allemb = gathered
         else:
             allemb = emb
@@ -499,8 +507,8 @@ def main():
         for _ in range(args.warmup):
             step()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-        if world > 1:
-            dist.barrier()
+        if group is not None:
+            dist.barrier(group=group)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -509,14 +517,14 @@ def main():
             cdll.mv_profile_enable(1 if i % 4 == 0 else 0)
             emb, scores, T = step(evs[i])
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if group is not None:
+            dist.barrier(group=group)
         elapsed = time.perf_counter() - t0
 
     cdll.mv_profile_enable(0)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if group is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     elapsed = t.item()
 
     stage_ms = [sum(evs[i][j].elapsed_time(evs[i][j + 1]) for i in range(args.steps)) / args.steps for j in range(4)]
@@ -574,8 +582,8 @@ def main():
             'vs_baseline': None, 'dtype': SPLIT_DTYPE if f32_family else 'f16', 'data': 'synthetic',
             'config': {'workload': label, 'batch_per_gpu': B, 'global_batch': world * B, 'samples_per_utt': SAMPLES,
                        'frames': T, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of embeddings' if world > 1 else '')},
-            'ranks': {'seen_at_rendezvous': len(ranks_seen), 'rccl_world_size': dist.get_world_size() if world > 1 else 1,
-                      'launcher': 'self' if os.environ.get('MV_BENCH_SELF_LAUNCHED') else ('torch.distributed.run' if world > 1 else 'none')},
+            'ranks': {'seen_at_rendezvous': len(ranks_seen), 'rccl_world_size': dist.get_world_size(group) if group is not None else 0,
+                      'launcher': 'self' if os.environ.get('MV_BENCH_SELF_LAUNCHED') else ('torch.distributed.run' if group is not None else 'none')},
             'stage_ms': {'frontend_cmn': round(stage_ms[0], 4), 'backbone': round(stage_ms[1], 4),
                          'all_gather': round(stage_ms[2], 4), 'cosine': round(stage_ms[3], 4)},
             'roofline': roof_conv,
@@ -688,7 +696,7 @@ def main():
                 except Exception as ex:
                     out['two_streams'] = {'error': f'{type(ex).__name__}: {ex}'}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 
