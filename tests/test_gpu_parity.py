@@ -1011,3 +1011,22 @@ def test_gpu_melspec_arguments(idx):
     "frame_length", window_fn + wkwargs, power 1 / 1.5 / 3, centre off, 8 / 22.05 kHz -- on 5 x 3 s with a ragged mask and 260 x 0.5 s"""
     lc.melspec_arguments_case(product_lib(), DEV, idx, B=5, seconds=3.0)
     lc.melspec_arguments_case(product_lib(), DEV, idx, B=260, seconds=0.5)
+
+
+def test_gpu_bench_under_a_launcher_runs_its_collectives_on_the_rccl_group():
+    """bench.py under torch.distributed.run with ONE rank: gloo rendezvous group + device-count exchange, `new_group(backend='nccl')`, and the step's
+    all-gather / barriers / max-reduce on that group -- the N > 1 code path of the driver's SCALE runs on a 1-GPU box (the 8-GPU curve itself has
+    never been measured)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='16')   # (the launcher's default of one OpenMP thread would slow the 4-row oracle check)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-other-configs'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['ranks'] == {'seen_at_rendezvous': 1, 'rccl_world_size': 1, 'launcher': 'torch.distributed.run'}
+    assert d['value'] > 10000 and d['parity']['max_one_minus_cos'] < 1e-4
