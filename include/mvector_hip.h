@@ -271,8 +271,9 @@ int mv_l2_normalize_f32(float* x, int32_t n, int32_t dim, mv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 2-D convolution layer of the ERes2Net family (eres2net.py:23-30: conv1x1 / conv3x3, zero padding k/2, no conv
- * bias) on channel-last fp32 maps [B, H = frequency, W = time, C], channels padded to multiples of 16 (fp32 operands on
- * v_mfma_f32_16x16x4_f32: the family is too deep for fp16 operands at the 1e-4 cosine bar, see csrc/conv2d.hip):
+ * bias) on channel-last maps [B, H = frequency, W = time, C], channels padded to multiples of 16 -- the semantics of
+ * mv_conv2ds_forward below (split fp16 operands on S16 maps: the family is too deep for plain fp16 operands at the 1e-4 cosine
+ * bar) and of the fp32-operand yard-stick tools/yardstick/conv2d_f32.hip:
  *   y = epi( sum_taps W . in + bias ),  in = x | x + x2 (eres2net.py:92) | cat(x, x2) (AFF, eres2net.py:49)
  *   epi 0: clamp(v [+ res], lo, hi)   -- BatchNorm folded into W / bias, ReLU(0..20) eres2net.py:12-15, residual :103-105
  *   epi 1: SiLU (AFF local_att, eres2net.py:41)
@@ -281,30 +282,8 @@ int mv_l2_normalize_f32(float* x, int32_t n, int32_t dim, mv_stream_t stream);
 #define MV_EPI_CLAMP 0
 #define MV_EPI_SILU 1
 #define MV_EPI_AFF 2
-/* pack [Cout][Cin][k][k] fp32 (nn.Conv2d layout) times an optional per-output-channel scale -> fp32 [cout16][k*k][cin16] */
-int64_t mv_conv2d_packed_elems(int32_t cout, int32_t cin, int32_t ks);
-int mv_conv2d_pack_weight(const float* w, const float* out_scale, int32_t cout, int32_t cin, int32_t ks, float* packed,
-                          mv_stream_t stream);
-typedef struct MvConv2dDesc {
-    const float* x;      /* [B, H, W, ldx] */
-    const float* x2;     /* optional second input */
-    int32_t x2_mode;     /* 0 none, 1 added, 2 concatenated behind the first cin1 channels */
-    int32_t cin1;
-    int64_t ldx, ldx2;
-    const float* w;      /* packed [cout16][ks*ks][cin16] */
-    const float* bias;   /* [cout16] */
-    const float* res;    /* epi 0: optional residual; epi 2: first AFF operand; [B, Ho, Wo, ldres] */
-    const float* res2;   /* epi 2: second AFF operand */
-    int64_t ldres, ldres2;
-    float* y;            /* [B, Ho, Wo, ldy], Ho = (H + 2*(ks/2) - ks)/stride + 1, Wo likewise with stride_w */
-    int64_t ldy;
-    int32_t B, H, W, cin16, cout16, ks, stride, epi;
-    float lo, hi;
-    int32_t cin_alg, cout_alg; /* channel counts of the layer before padding (0: same as cin16 / cout16): profile accounting only */
-    int32_t stride_w;          /* stride along W when it differs from `stride` (then the stride along H); 0 = same.  The CAM++ head
-                                * (campplus.py:221-292) strides the frequency axis only: stride 2, stride_w 1 */
-} MvConv2dDesc;
-int mv_conv2d_forward(const MvConv2dDesc* d, mv_stream_t stream);
+/* (The fp32-operand form of these layers -- MvConv2dDesc, mv_conv2d_pack_weight / _packed_elems / _forward, ABI 1-3 -- left the library with ABI 4: no
+ * model handle had run it since round 4; it is the exact-fp32 yard-stick under tools/yardstick/.) */
 /* first ERes2Net conv: features fp32 [B, T, F] -> fp32 [B, F, T, C] = relu(conv3x3(1 -> C) + bias), w fp32 [C][9] */
 int mv_conv2d_first(const float* feats, float* out, const float* w, const float* bias, int32_t B, int32_t T, int32_t F,
                     int32_t C, mv_stream_t stream);

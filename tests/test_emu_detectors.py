@@ -109,7 +109,7 @@ def test_fuzzer_runs_random_geometries_of_every_family_clean():
 
 
 def test_tampered_descriptors_are_refused_or_harmless_never_a_crash():
-    """tools/emu_bad_args.py: every field of a valid MvConv1dDesc / MvConv2dDesc / MvConv2dsDesc replaced by a value a caller can get wrong (null
+    """tools/emu_bad_args.py: every field of a valid MvConv1dDesc / MvConv2dsDesc replaced by a value a caller can get wrong (null
     tensor, 0, -1, a row length that is no multiple of the vector width, an enum out of range): the entry point returns an error code with a
     message or runs a call that is valid in itself -- the process survives all of them (include/mvector_hip.h: fail loudly, never crash)"""
     import sys
@@ -118,7 +118,7 @@ def test_tampered_descriptors_are_refused_or_harmless_never_a_crash():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     summary = [l for l in r.stdout.splitlines() if 'SUMMARY' in l][0]
     n, rejected = int(summary.split()[2]), int(summary.split()[5])
-    assert n > 400 and rejected > 330 and ' 0 crashed' in summary, summary
+    assert n > 380 and rejected > 300 and ' 0 crashed' in summary, summary   # (round 5: one descriptor fewer -- the fp32 conv2d form left the library)
     accepted = [l for l in r.stdout.splitlines() if 'ACCEPTED' in l][0]
-    for must_reject in ('pre_act=99', 'post_act=-1', 'pad_mode=99', 'mv_conv2d_forward.ldres=-1', 'mv_conv1d_forward.ldx=', 'mv_conv1d_forward.ldy=', 'x=None', 'y=None', 'oscale'):
+    for must_reject in ('pre_act=99', 'post_act=-1', 'pad_mode=99', 'mv_conv1d_forward.ldx=', 'mv_conv1d_forward.ldy=', 'x=None', 'y=None', 'oscale'):
         assert must_reject not in accepted, must_reject

@@ -16,13 +16,6 @@ from oracle import frontend
 FB = dict(sample_frequency=16000, num_mel_bins=80)
 
 
-@pytest.mark.parametrize('idx', range(len(lc.CONV2D_CASES)))
-def test_conv2d_emu(idx):
-    if idx == 8 and os.environ.get('MV_SLOW_EMU') != '1':
-        pytest.skip('~40 s under the emulator; set MV_SLOW_EMU=1 (covered on the GPU by test_gpu_parity)')
-    lc.conv2d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV2D_CASES[idx])
-
-
 @pytest.mark.parametrize('idx', range(len(lc.CONV2DS_CASES)))
 def test_conv2ds_emu(idx):
     """split-fp16 conv2d on S16 maps (conv2ds.hip): producer / consumer roles, patch geometry, swizzle, K tails, epilogues"""

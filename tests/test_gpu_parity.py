@@ -32,11 +32,6 @@ def test_gpu_library_is_the_hip_build():
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
-@pytest.mark.parametrize('idx', range(len(lc.CONV2D_CASES)))
-def test_conv2d(idx):
-    lc.conv2d_case(product_lib(), DEV, seed=idx, **lc.CONV2D_CASES[idx])
-
-
 @pytest.mark.parametrize('idx', range(len(lc.CONV2DS_CASES)))
 def test_conv2ds(idx):
     """the split-fp16 form of the ERes2Net conv layers on S16 maps, through the C ABI"""

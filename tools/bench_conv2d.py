@@ -1,4 +1,4 @@
-"""ERes2Net conv layers alone, fp32 form (mv_conv2d_forward, conv2d.hip) beside the split-fp16 form (mv_conv2ds_forward, conv2ds.hip), HIP events.
+"""ERes2Net conv layers alone, fp32 form (mv_conv2d_forward of the yard-stick library, tools/yardstick/) beside the split-fp16 form (mv_conv2ds_forward, conv2ds.hip), HIP events.
 usage: python tools/bench_conv2d.py [B]     MV_BENCH_SWEEP=1 also runs the tile-shape hints of the split form
 Shapes: the 54.9 M ERes2NetV2 (m_channels 96, base_width 26, scale 4; widths 39 / 78 / 156 / 312 padded to 48 / 80 / 160 / 320) at 3 s."""
 import ctypes, json, os, sys
@@ -8,6 +8,9 @@ import torch
 from mvector import _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 cdll = _hip.bind(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else _hip.lib()   # (a probe / baseline build of the library for an A/B inside one call)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from yardstick import binding as ybinding
+ycdll = ybinding.load()
 st = lambda: _hip.current_stream(torch.empty(1, device='cuda'))
 r16 = lambda n: -(-n // 16) * 16
 # (name, H, W, cin, cout, ks, stride, with_res)
@@ -59,15 +62,15 @@ for name, H, W, cin, cout, ks, stride, with_res in SHAPES:
     y = torch.empty(B, Ho, Wo, cout, device='cuda')
     gflop = 2.0 * B * Ho * Wo * cin * cout * ks * ks / 1e9
     mbytes = 4.0 * (x.numel() + y.numel() + (res.numel() if with_res else 0)) / 1e6
-    # fp32 form
-    n = cdll.mv_conv2d_packed_elems(cout, cin, ks)
+    # fp32 form (the yard-stick: not in the product library)
+    n = ycdll.mv_conv2d_packed_elems(cout, cin, ks)
     pk = torch.zeros(n, device='cuda')
-    _hip.check(cdll.mv_conv2d_pack_weight(w.data_ptr(), None, cout, cin, ks, pk.data_ptr(), st()), cdll)
-    d = _hip.MvConv2dDesc()
+    _hip.check(ycdll.mv_conv2d_pack_weight(w.data_ptr(), None, cout, cin, ks, pk.data_ptr(), st()), ycdll)
+    d = ybinding.MvConv2dDesc()
     d.x, d.ldx, d.w, d.bias, d.y, d.ldy = x.data_ptr(), cin, pk.data_ptr(), bias.data_ptr(), y.data_ptr(), cout
     d.res, d.ldres = (res.data_ptr() if with_res else None), cout
     d.B, d.H, d.W, d.cin16, d.cout16, d.ks, d.stride, d.epi, d.lo, d.hi = B, H, W, cin, cout, ks, stride, 0, 0.0, 20.0
-    t32 = timed(lambda: _hip.check(cdll.mv_conv2d_forward(ctypes.byref(d), st()), cdll))
+    t32 = timed(lambda: _hip.check(ycdll.mv_conv2d_forward(ctypes.byref(d), st()), ycdll))
     y32 = y.clone()
     # split form
     sp = lambda t: None if t is None else (lambda o: (_hip.check(cdll.mv_map_split_f32(t.data_ptr(), o.data_ptr(), t.numel(), st()), cdll), o)[1])(torch.empty_like(t))

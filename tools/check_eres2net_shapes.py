@@ -7,13 +7,15 @@ from mvector import _hip
 from oracle import weights, models as om
 from helpers import cos_dist
 import layer_checks as lc
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from yardstick import binding as ybinding, check_conv2d
 lib = _hip.lib()
 for cfg in [dict(cin=48, cout=48, ks=3, H=5, W=40, B=1), dict(cin=80, cout=80, ks=3, H=5, W=40, B=1), dict(cin=160, cout=160, ks=3, H=5, W=40, B=1),
             dict(cin=320, cout=320, ks=3, H=5, W=40, B=1), dict(cin=192, cout=192, ks=1, H=5, W=40, B=1), dict(cin=1280, cout=1536, ks=1, H=3, W=20, B=1, with_res=True),
             dict(cin=320, cout=48, ks=1, x2_mode=2, epi=1, H=5, W=40, B=1), dict(cin=48, cout=160, ks=1, epi=2, H=5, W=40, B=1),
             dict(cin=768, cout=1536, ks=3, stride=2, H=6, W=20, B=1, lo=-3e38, hi=3e38)]:
     try:
-        print('layer', cfg, lc.conv2d_case(lib, 'cuda', **cfg), flush=True)
+        print('layer', cfg, check_conv2d.conv2d_case(ybinding.load(), 'cuda', **cfg), flush=True)
     except AssertionError as e:
         print('layer', cfg, 'FAIL', e, flush=True)
 torch.set_num_threads(32)

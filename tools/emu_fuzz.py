@@ -71,15 +71,6 @@ def _g_conv2ds(r):
     return kw
 
 
-def g_conv2d(r):
-    ks = r.choice([1, 3])
-    kw = dict(B=_pick(r, [1, 2, 3], [8]), H=_pick(r, [1, 2, 3, 5, 8, 9, 10, 16], [40, 80]), W=_pick(r, [1, 2, 7, 15, 16, 17, 33, 40, 50], [149, 298]), cin=r.choice([13, 16, 32, 48, 64, 104]),
-              cout=r.choice([13, 16, 32, 48, 64, 104, 128]), ks=ks, stride=r.choice([1, 1, 2]), seed=r.randrange(1000))
-    if r.random() < 0.3:
-        kw['with_res'] = True
-    return kw
-
-
 def g_conv1d(r):
     k = r.choice([1, 1, 3, 5])
     kw = dict(B=_pick(r, [1, 2, 3, 5, 7], [16, 64, 130]), T=_pick(r, [1, 2, 9, 31, 37, 63, 64, 65, 100, 127, 129, 160, 161, 200, 298, 305], [600, 998, 1501]),
@@ -303,7 +294,6 @@ def _budget(gen, cost, limit):
     return g
 
 
-g_conv2d = _budget(g_conv2d, lambda k: k['B'] * k['H'] * k['W'] * k['cin'] * k['cout'] * k['ks'] ** 2, 3e9)
 g_conv1d = _budget(g_conv1d, lambda k: k['B'] * k['T'] * k['cin'] * k['cout'] * k['k'], 4e9)
 g_res2 = _budget(g_res2, lambda k: k['B'] * k['T'] * k['width'] ** 2 * 3 * 7, 6e9)
 g_asp = _budget(g_asp, lambda k: k['B'] * k['T'] * k['C'] * k['A'], 3e9)
@@ -311,7 +301,7 @@ g_time_stats = _budget(g_time_stats, lambda k: k['B'] * k['T'] * k['C'], 3e8)
 g_fcm_block = _budget(g_fcm_block, lambda k: k['B'] * k['T'] * k['Fin'] * 32 * 32 * 9 * 2, 4e9)
 g_melspec = _budget(g_melspec, lambda k: k['B'] * k['L'], 4e6)
 
-FAMILIES = {'conv2ds': g_conv2ds, 'conv2d': g_conv2d, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
+FAMILIES = {'conv2ds': g_conv2ds, 'conv1d': g_conv1d, 'res2': g_res2, 'asp_pool': g_asp, 'time_stats': g_time_stats, 'linear': g_linear,
             'fbank': g_fbank, 'melspec': g_melspec, 'fcm_block': g_fcm_block, 'model': g_model, 'fcm_conv': g_fcm_conv, 'fcm_c1': g_fcm_c1, 'window': g_window,
             'small': g_small}
 
@@ -330,8 +320,6 @@ def run_case(family, kw):
         cdll = _hip.lib()
     if family == 'conv2ds':
         lc.conv2ds_case(cdll, DEVICE, **kw)
-    elif family == 'conv2d':
-        lc.conv2d_case(cdll, DEVICE, **kw)
     elif family == 'conv1d':
         lc.conv1d_case(cdll, DEVICE, **kw)
     elif family == 'res2':

@@ -19,8 +19,6 @@ int bn_relu_rows_launch(const half_t* x, int64_t ldx, const float* scale, const 
                         hipStream_t stream);
 int asp_hidden_act_launch(half_t* zh, const float* row_bias, const float* scale, const float* shift, int B, int T, int A, hipStream_t stream);
 
-typedef MvConv2dDesc Conv2dDesc;
-int conv2d_launch(const Conv2dDesc& d, hipStream_t stream);
 int conv2d_first_launch(const float* feats, float* out, const float* w, const float* bias, int B, int T, int F, int C,
                         hipStream_t stream);
 int tstp_launch(const float* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);

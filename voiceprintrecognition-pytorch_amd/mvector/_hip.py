@@ -54,14 +54,6 @@ class MvEres2Cfg(ctypes.Structure):
                 ('scale', c_i32), ('two_emb_layer', c_i32)]
 
 
-class MvConv2dDesc(ctypes.Structure):
-    _fields_ = [('x', c_vp), ('x2', c_vp), ('x2_mode', c_i32), ('cin1', c_i32), ('ldx', c_i64), ('ldx2', c_i64),
-                ('w', c_vp), ('bias', c_vp), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64),
-                ('y', c_vp), ('ldy', c_i64), ('B', c_i32), ('H', c_i32), ('W', c_i32), ('cin16', c_i32),
-                ('cout16', c_i32), ('ks', c_i32), ('stride', c_i32), ('epi', c_i32), ('lo', c_f32), ('hi', c_f32),
-                ('cin_alg', c_i32), ('cout_alg', c_i32), ('stride_w', c_i32)]
-
-
 class MvConv2dsDesc(ctypes.Structure):
     _fields_ = [('x', c_vp), ('x2', c_vp), ('cin1', c_i32), ('ldx', c_i64), ('ldx2', c_i64), ('w', c_vp), ('bias', c_vp),
                 ('oscale', c_f32), ('res', c_vp), ('res2', c_vp), ('ldres', c_i64), ('ldres2', c_i64), ('add', c_vp),
@@ -110,9 +102,6 @@ _SIGNATURES = {
     'mv_campp_create': (c_i32, [ctypes.POINTER(MvCamppCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
     'mv_tdnn_create': (c_i32, [ctypes.POINTER(MvTdnnCfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
     'mv_eres2net_create': (c_i32, [ctypes.POINTER(MvEres2Cfg), ctypes.POINTER(MvTensorRef), c_i32, ctypes.POINTER(c_vp)]),
-    'mv_conv2d_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
-    'mv_conv2d_pack_weight': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    'mv_conv2d_forward': (c_i32, [ctypes.POINTER(MvConv2dDesc), c_vp]),
     'mv_conv2d_first': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'mv_tstp_f32': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'mv_conv2ds_packed_elems': (c_i64, [c_i32, c_i32, c_i32]),
