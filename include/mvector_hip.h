@@ -67,6 +67,8 @@ typedef struct MvFbankCfg {
                                    * (needs the caller workspace of mv_fbank_forward_ws: the mirrored rows are written there first) */
     int32_t subtract_mean;        /* 0.  kaldi.fbank's own subtract_mean: column means over the utterance's frames, BEFORE the wrapper's mean */
     float min_duration;           /* 0 s: shorter signals give no frames */
+    float vtln_warp;              /* 1.0 = no vocal-tract-length warp of the filter edges; otherwise kaldi's 3-piece linear warp between */
+    float vtln_low, vtln_high;    /* 100, -500 (negative: + Nyquist) */
     int32_t kernel;               /* MV_FBANK_KERNEL_AUTO (0) | MV_FBANK_KERNEL_GENERIC (fbank_kernel) | MV_FBANK_KERNEL_TILE (fbank_tile_kernel;
                                    * create fails when the mel geometry has no instantiation).  Both kernels implement the same contract; the
                                    * field exists so that tests and tools/bench_fbank.py can run either on any geometry. */

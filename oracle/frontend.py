@@ -41,10 +41,43 @@ def _next_pow2(n):
     return 1 if n == 0 else 2 ** (n - 1).bit_length()
 
 
-def kaldi_mel_banks(num_bins, padded, sample_freq, low_freq, high_freq):
-    """Kaldi triangular filters, triangles in MEL space, no normalisation.
+def _mel_scale(freq):
+    return 1127.0 * (1.0 + freq / 700.0).log()
 
-    Returns [num_bins, padded//2] fp32 (the caller appends the zero Nyquist column).
+
+def _inverse_mel_scale(mel_freq):
+    return 700.0 * ((mel_freq / 1127.0).exp() - 1.0)
+
+
+def vtln_warp_freq(vtln_low_cutoff, vtln_high_cutoff, low_freq, high_freq, vtln_warp_factor, freq):
+    """torchaudio.compliance.kaldi.vtln_warp_freq: the 3-piece linear warp of Kaldi's VTLN (identity outside [low_freq, high_freq])."""
+    assert vtln_low_cutoff > low_freq, 'be sure to set the vtln_low option higher than low_freq'
+    assert vtln_high_cutoff < high_freq, 'be sure to set the vtln_high option lower than high_freq [or negative]'
+    l = vtln_low_cutoff * max(1.0, vtln_warp_factor)
+    h = vtln_high_cutoff * min(1.0, vtln_warp_factor)
+    scale = 1.0 / vtln_warp_factor
+    Fl = scale * l
+    Fh = scale * h
+    assert l > low_freq and h < high_freq
+    scale_left = (Fl - low_freq) / (l - low_freq)
+    scale_right = (high_freq - Fh) / (high_freq - h)
+    res = torch.empty_like(freq)
+    outside_low_high_freq = torch.lt(freq, low_freq) | torch.gt(freq, high_freq)
+    before_l = torch.lt(freq, l)
+    before_h = torch.lt(freq, h)
+    after_h = torch.ge(freq, h)
+    res[after_h] = high_freq + scale_right * (freq[after_h] - high_freq)
+    res[before_h] = scale * freq[before_h]
+    res[before_l] = low_freq + scale_left * (freq[before_l] - low_freq)
+    res[outside_low_high_freq] = freq[outside_low_high_freq]
+    return res
+
+
+def kaldi_mel_banks(num_bins, padded, sample_freq, low_freq, high_freq, vtln_low=100.0, vtln_high=-500.0, vtln_warp=1.0, dtype=torch.float32):
+    """torchaudio.compliance.kaldi.get_mel_banks: Kaldi triangular filters, triangles in MEL space, no normalisation; vtln_warp != 1 moves the
+    filter edges through the VTLN warp (and then the half-open comparisons of the warped branch decide the weights).
+
+    Returns [num_bins, padded//2] (the caller appends the zero Nyquist column).
     """
     num_fft_bins = padded // 2
     nyquist = 0.5 * sample_freq
@@ -54,14 +87,28 @@ def kaldi_mel_banks(num_bins, padded, sample_freq, low_freq, high_freq):
     mel_lo = 1127.0 * math.log(1.0 + low_freq / 700.0)
     mel_hi = 1127.0 * math.log(1.0 + high_freq / 700.0)
     delta = (mel_hi - mel_lo) / (num_bins + 1)
-    b = torch.arange(num_bins).unsqueeze(1)
+    if vtln_high < 0.0:
+        vtln_high += nyquist
+    assert vtln_warp == 1.0 or ((low_freq < vtln_low < high_freq) and (0.0 < vtln_high < high_freq) and (vtln_low < vtln_high)), \
+        f'Bad values in options: vtln-low {vtln_low} and vtln-high {vtln_high}, versus low-freq {low_freq} and high-freq {high_freq}'
+    b = torch.arange(num_bins, dtype=dtype).unsqueeze(1)
     left = mel_lo + b * delta
     center = mel_lo + (b + 1.0) * delta
     right = mel_lo + (b + 2.0) * delta
-    mel = (1127.0 * (1.0 + (fft_bin_width * torch.arange(num_fft_bins)) / 700.0).log()).unsqueeze(0)
+    if vtln_warp != 1.0:
+        warp = lambda m: _mel_scale(vtln_warp_freq(vtln_low, vtln_high, low_freq, high_freq, vtln_warp, _inverse_mel_scale(m)))
+        left, center, right = warp(left), warp(center), warp(right)
+    mel = _mel_scale(fft_bin_width * torch.arange(num_fft_bins, dtype=dtype)).unsqueeze(0)
     up = (mel - left) / (center - left)
     down = (right - mel) / (right - center)
-    return torch.max(torch.zeros(1), torch.min(up, down))
+    if vtln_warp == 1.0:
+        return torch.max(torch.zeros(1, dtype=dtype), torch.min(up, down))
+    bins = torch.zeros_like(up)
+    up_idx = torch.gt(mel, left) & torch.le(mel, center)
+    down_idx = torch.gt(mel, center) & torch.lt(mel, right)
+    bins[up_idx] = up[up_idx]
+    bins[down_idx] = down[down_idx]
+    return bins
 
 
 def povey_window(n):
@@ -111,7 +158,7 @@ def _kaldi_fbank_impl(waveform, kwargs, dtype):
     if unknown:
         raise TypeError(f'unexpected fbank arguments {sorted(unknown)}')
     a.update(kwargs)
-    for k, v in (('vtln_warp', 1.0), ('dither', 0.0), ('round_to_power_of_two', True)):
+    for k, v in (('dither', 0.0), ('round_to_power_of_two', True)):
         if a[k] != v:
             raise NotImplementedError(f'oracle restates only {k}={v!r}')
     w = torch.as_tensor(waveform, dtype=torch.float32)
@@ -150,17 +197,7 @@ def _kaldi_fbank_impl(waveform, kwargs, dtype):
     spec = torch.fft.rfft(frames).abs()
     if a['use_power']:
         spec = spec.pow(2.0)
-    if dtype == torch.float32:
-        banks = kaldi_mel_banks(nbins, padded, sf, a['low_freq'], a['high_freq'])
-    else:
-        high = a['high_freq'] + 0.5 * sf if a['high_freq'] <= 0.0 else a['high_freq']
-        mel_lo = 1127.0 * math.log(1.0 + a['low_freq'] / 700.0)
-        mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
-        delta = (mel_hi - mel_lo) / (nbins + 1)
-        b = torch.arange(nbins, dtype=dtype).unsqueeze(1)
-        left, center, right = mel_lo + b * delta, mel_lo + (b + 1.0) * delta, mel_lo + (b + 2.0) * delta
-        mel_f = (1127.0 * (1.0 + ((sf / padded) * torch.arange(padded // 2, dtype=dtype)) / 700.0).log()).unsqueeze(0)
-        banks = torch.clamp(torch.min((mel_f - left) / (center - left), (right - mel_f) / (right - center)), min=0.0)
+    banks = kaldi_mel_banks(nbins, padded, sf, a['low_freq'], a['high_freq'], a['vtln_low'], a['vtln_high'], a['vtln_warp'], dtype)
     banks = F.pad(banks, (0, 1))   # zero weight on the Nyquist bin
     mel = torch.mm(spec, banks.T)
     if a['use_log_fbank']:

@@ -745,6 +745,8 @@ FBANK_ARG_CASES = (
     [(dict(_FB80, snip_edges=False), {}), (dict(_FB80, snip_edges=False, frame_shift=30.0), {}), (dict(_FB80, snip_edges=False), dict(varlen=True)),
      (dict(sample_frequency=8000, num_mel_bins=23, snip_edges=False), dict(cmn=False))] +
     [(dict(_FB80, subtract_mean=True), {}), (dict(_FB80, subtract_mean=True), dict(cmn=False)), (dict(_FB80, min_duration=0.3), dict(varlen=True))] +
+    [(dict(_FB80, vtln_warp=1.1), {}), (dict(_FB80, vtln_warp=0.9), dict(cmn=False)), (dict(sample_frequency=16000, num_mel_bins=40, vtln_warp=1.2, vtln_low=300.0, vtln_high=-800.0), {}),
+     (dict(sample_frequency=8000, num_mel_bins=23, vtln_warp=0.85, vtln_high=-300.0), dict(varlen=True))] +    # kaldi's VTLN warp of the filter edges
     [(dict(_FB80), dict(cmn=False)), (dict(_FB80), dict(cmn=False, kernel='generic')), (dict(_FB80), dict(varlen=True, kernel='generic')),
      (dict(sample_frequency=16000, num_mel_bins=23), dict(cmn=False))])
 

@@ -103,9 +103,11 @@ def test_emu_fbank_edge_cases():
         lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40, frame_length=40), cdll=emu_cdll())
     with pytest.raises(RuntimeError, match='fbank_tile_kernel is instantiated'):
         lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40), cdll=emu_cdll(), kernel='tile')
-    for bad in (dict(dither=1.0), dict(use_energy=True), dict(vtln_warp=1.1), dict(round_to_power_of_two=False)):
+    for bad in (dict(dither=1.0), dict(use_energy=True), dict(round_to_power_of_two=False)):
         with pytest.raises(NotImplementedError):
             lc._hip.Fbank(dict(FB, **bad), cdll=emu_cdll())
+    with pytest.raises(RuntimeError, match='bad VTLN options'):   # (torchaudio asserts on these)
+        lc._hip.Fbank(dict(FB, vtln_warp=1.1, vtln_low=10.0), cdll=emu_cdll())
     with pytest.raises(TypeError):
         lc._hip.Fbank(dict(FB, n_fft=512), cdll=emu_cdll())
     with pytest.raises(Exception, match='Invalid window type'):
@@ -427,7 +429,7 @@ def test_emu_fbank_other_frame_lengths_with_80_bins(frame_length):
 @pytest.mark.parametrize('idx', range(len(lc.FBANK_ARG_CASES)))
 def test_emu_fbank_arguments(idx):
     """the kaldi.fbank keyword arguments featurizer.py:128 forwards (frame length / shift, bin counts, sample rates incl. kaldi's 256-point FFT at 8 kHz, band edges,
-    magnitude / linear outputs, DC / pre-emphasis switches, the five window types, snip_edges=False, subtract_mean, min_duration) x (kernel, bare rows, true lengths):
+    magnitude / linear outputs, DC / pre-emphasis switches, the five window types, snip_edges=False, subtract_mean, min_duration, VTLN warps) x (kernel, bare rows, true lengths):
     tests/layer_checks.py::FBANK_ARG_CASES, the list the device sweep (test_gpu_fbank_arguments) runs at 3 s"""
     lc.fbank_arguments_case(emu_cdll(), 'cpu', idx)
 

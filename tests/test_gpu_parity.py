@@ -266,7 +266,7 @@ def test_gpu_fbank_arguments(idx):
     """HIP vs the fp32 oracle AND the fp64 arbiter over the kaldi.fbank keyword arguments featurizer.py:128 forwards (tests/layer_checks.py::
     FBANK_ARG_CASES: frame_length 20 / 24 / 25 / 30 / 32 ms on BOTH kernels -- fbank_tile_kernel<13> and <16>, fbank_kernel --, frame_shift 10 / 12.5,
     23 / 40 / 64 / 80 / 128 bins, 8 / 11.025 / 16 / 22.05 kHz, band edges, use_power / use_log_fbank / remove_dc_offset / preemphasis switches,
-    the five window types, snip_edges=False, subtract_mean, min_duration; bare kaldi.fbank rows and true-length batches): 5 x 3 s with a ragged
+    the five window types, snip_edges=False, subtract_mean, min_duration, VTLN warps; bare kaldi.fbank rows and true-length batches): 5 x 3 s with a ragged
     mask, and 260 x 0.5 s (more utterances than CUs)"""
     lc.fbank_arguments_case(product_lib(), DEV, idx, B=5, seconds=3.0)
     lc.fbank_arguments_case(product_lib(), DEV, idx, B=260, seconds=0.5, seed=7, check_rows=[0, 1, 2, 3, 4, 130, 255, 256, 257, 258, 259])

@@ -798,28 +798,57 @@ struct MvFbank {
 
 namespace {
 
-// Kaldi mel banks, triangles in mel space (oracle/frontend.py::kaldi_mel_banks), fp32 like torchaudio.
-std::vector<std::vector<float>> kaldi_mel_banks(int num_bins, int padded, float sample_freq, float low_freq,
-                                                float high_freq) {
+// Kaldi mel banks, triangles in mel space (oracle/frontend.py::kaldi_mel_banks = torchaudio.compliance.kaldi.get_mel_banks), fp32 like torchaudio.
+// vtln_warp != 1: the filter edges pass through Kaldi's 3-piece linear VTLN warp (vtln_warp_freq) and the weights follow the warped branch's
+// half-open comparisons.  Returns false for option values torchaudio asserts on.
+bool kaldi_mel_banks(int num_bins, int padded, float sample_freq, float low_freq, float high_freq, float vtln_low, float vtln_high, float vtln_warp,
+                     std::vector<std::vector<float>>* out) {
     const int num_fft_bins = padded / 2;
     const float nyquist = 0.5f * sample_freq;
     if (high_freq <= 0.0f) high_freq += nyquist;
+    if (vtln_high < 0.0f) vtln_high += nyquist;
+    const bool warp = vtln_warp != 1.0f;
+    if (warp && !(low_freq < vtln_low && vtln_low < high_freq && 0.0f < vtln_high && vtln_high < high_freq && vtln_low < vtln_high)) return false;
     const float fft_bin_width = sample_freq / padded;
     const float mel_lo = 1127.0f * logf(1.0f + low_freq / 700.0f);
     const float mel_hi = 1127.0f * logf(1.0f + high_freq / 700.0f);
     const float delta = (mel_hi - mel_lo) / (num_bins + 1);
-    std::vector<std::vector<float>> banks(num_bins, std::vector<float>(num_fft_bins, 0.0f));
+    // vtln_warp_mel_freq: mel -> Hz -> warped Hz -> mel
+    const float l = vtln_low * fmaxf(1.0f, vtln_warp), h = vtln_high * fminf(1.0f, vtln_warp), scale = 1.0f / vtln_warp;
+    if (warp && !(l > low_freq && h < high_freq)) return false;
+    const float scale_left = (scale * l - low_freq) / (l - low_freq), scale_right = (high_freq - scale * h) / (high_freq - h);
+    auto warp_mel = [&](float mel) {
+        const float f = 700.0f * (expf(mel / 1127.0f) - 1.0f);
+        float r;
+        if (f < low_freq || f > high_freq) r = f;
+        else if (f < l) r = low_freq + scale_left * (f - low_freq);
+        else if (f < h) r = scale * f;
+        else r = high_freq + scale_right * (f - high_freq);
+        return 1127.0f * logf(1.0f + r / 700.0f);
+    };
+    out->assign(num_bins, std::vector<float>(num_fft_bins, 0.0f));
     for (int b = 0; b < num_bins; ++b) {
-        const float left = mel_lo + b * delta, center = mel_lo + (b + 1.0f) * delta, right = mel_lo + (b + 2.0f) * delta;
+        float left = mel_lo + b * delta, center = mel_lo + (b + 1.0f) * delta, right = mel_lo + (b + 2.0f) * delta;
+        if (warp) {
+            left = warp_mel(left);
+            center = warp_mel(center);
+            right = warp_mel(right);
+        }
         for (int k = 0; k < num_fft_bins; ++k) {
             const float mel = 1127.0f * logf(1.0f + (fft_bin_width * k) / 700.0f);
             const float up = (mel - left) / (center - left);
             const float down = (right - mel) / (right - center);
-            const float w = fminf(up, down);
-            banks[b][k] = w > 0.0f ? w : 0.0f;
+            float w;
+            if (!warp) {
+                w = fminf(up, down);
+                w = w > 0.0f ? w : 0.0f;
+            } else {   // warping can move the order of left, center, right anywhere
+                w = (mel > left && mel <= center) ? up : ((mel > center && mel < right) ? down : 0.0f);
+            }
+            (*out)[b][k] = w;
         }
     }
-    return banks;
+    return true;
 }
 
 template <typename T>
@@ -939,6 +968,9 @@ void mv_fbank_default_cfg(MvFbankCfg* cfg) {
     cfg->subtract_mean = 0;
     cfg->min_duration = 0.0f;
     cfg->kernel = MV_FBANK_KERNEL_AUTO;
+    cfg->vtln_warp = 1.0f;
+    cfg->vtln_low = 100.0f;
+    cfg->vtln_high = -500.0f;
 }
 
 int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
@@ -955,6 +987,7 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     MV_REQUIRE(cfg->window_type >= MV_WINDOW_POVEY && cfg->window_type <= MV_WINDOW_BLACKMAN, "mv_fbank_create: unknown window_type");
     MV_REQUIRE(cfg->kernel >= MV_FBANK_KERNEL_AUTO && cfg->kernel <= MV_FBANK_KERNEL_TILE, "mv_fbank_create: unknown kernel selector");
     MV_REQUIRE(cfg->min_duration >= 0.0f, "mv_fbank_create: negative min_duration");
+    MV_REQUIRE(cfg->vtln_warp > 0.0f, "mv_fbank_create: vtln_warp must be positive");
     MvFbank* h = new MvFbank();
     h->cfg = *cfg;
     h->win = win;
@@ -987,7 +1020,11 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     // Windows that round up to an FFT of P < 512 points (8 kHz: 25 ms = 200 samples, P = 256): the kernels still transform the frame zero-padded to
     // 512 points; bin k of the P-point transform of a zero-padded frame IS bin k * 512 / P of the 512-point one, so kaldi's filter weights (built
     // for P) are placed on those bins and the bins in between carry zero weight.
-    auto banks_p = kaldi_mel_banks(h->nbins, h->padded, cfg->sample_frequency, cfg->low_freq, cfg->high_freq);
+    std::vector<std::vector<float>> banks_p;
+    if (!kaldi_mel_banks(h->nbins, h->padded, cfg->sample_frequency, cfg->low_freq, cfg->high_freq, cfg->vtln_low, cfg->vtln_high, cfg->vtln_warp, &banks_p)) {
+        delete h;
+        return mv::fail(MV_ERR_INVALID_ARGUMENT, "mv_fbank_create: bad VTLN options (need low_freq < vtln_low < vtln_high < high_freq, and the warped cut-offs inside the band)");
+    }
     std::vector<std::vector<float>> banks(h->nbins, std::vector<float>(mv::FB_NFFT / 2, 0.0f));
     {
         const int stride = mv::FB_NFFT / h->padded;

@@ -24,7 +24,8 @@ class MvFbankCfg(ctypes.Structure):
                 ('num_mel_bins', c_i32), ('low_freq', c_f32), ('high_freq', c_f32),
                 ('preemphasis_coefficient', c_f32), ('remove_dc_offset', c_i32), ('use_power', c_i32),
                 ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32), ('window_type', c_i32), ('blackman_coeff', c_f32),
-                ('snip_edges', c_i32), ('subtract_mean', c_i32), ('min_duration', c_f32), ('kernel', c_i32)]
+                ('snip_edges', c_i32), ('subtract_mean', c_i32), ('min_duration', c_f32), ('vtln_warp', c_f32), ('vtln_low', c_f32),
+                ('vtln_high', c_f32), ('kernel', c_i32)]
 
 
 class MvMelSpecCfg(ctypes.Structure):
@@ -217,12 +218,12 @@ class Fbank:
                    'high_freq': 'high_freq', 'preemphasis_coefficient': 'preemphasis_coefficient',
                    'remove_dc_offset': 'remove_dc_offset', 'use_power': 'use_power', 'use_log_fbank': 'use_log_fbank',
                    'blackman_coeff': 'blackman_coeff', 'snip_edges': 'snip_edges', 'subtract_mean': 'subtract_mean',
-                   'min_duration': 'min_duration'}
+                   'min_duration': 'min_duration', 'vtln_warp': 'vtln_warp', 'vtln_low': 'vtln_low', 'vtln_high': 'vtln_high'}
         # arguments whose other values are not implemented (dither draws random numbers; use_energy adds a column that
-        # AudioFeaturizer.feature_dim, featurizer.py:110-111, does not count; VTLN warping; non-power-of-two FFT sizes) and arguments
-        # that only matter together with those (raw_energy, energy_floor, htk_compat: use_energy; vtln_low / vtln_high: vtln_warp)
-        fixed = {'dither': 0.0, 'use_energy': False, 'vtln_warp': 1.0, 'round_to_power_of_two': True, 'channel': (-1, 0)}
-        ignored = ('raw_energy', 'energy_floor', 'htk_compat', 'vtln_low', 'vtln_high')
+        # AudioFeaturizer.feature_dim, featurizer.py:110-111, does not count -- the reference's own models would refuse the features;
+        # non-power-of-two FFT sizes) and arguments that only matter together with those (raw_energy, energy_floor, htk_compat: use_energy)
+        fixed = {'dither': 0.0, 'use_energy': False, 'round_to_power_of_two': True, 'channel': (-1, 0)}
+        ignored = ('raw_energy', 'energy_floor', 'htk_compat')
         for k, v in args.items():
             if k in mapping:
                 field = mapping[k]

@@ -13,12 +13,12 @@ import torch
 _FBANK_KEYS = {'sample_frequency': 16000.0, 'frame_length': 25.0, 'frame_shift': 10.0, 'num_mel_bins': 23,
                'low_freq': 20.0, 'high_freq': 0.0, 'preemphasis_coefficient': 0.97, 'remove_dc_offset': True,
                'use_power': True, 'use_log_fbank': True, 'window_type': 'povey', 'blackman_coeff': 0.42, 'snip_edges': True,
-               'subtract_mean': False, 'min_duration': 0.0}
+               'subtract_mean': False, 'min_duration': 0.0, 'vtln_warp': 1.0, 'vtln_low': 100.0, 'vtln_high': -500.0}
 # not implemented beyond these values: dither draws random numbers, use_energy adds a column AudioFeaturizer.feature_dim does not count
-# (featurizer.py:110-111), VTLN warping, FFT sizes that are not powers of two
-_FBANK_FIXED = {'dither': (0.0,), 'use_energy': (False,), 'vtln_warp': (1.0,), 'round_to_power_of_two': (True,), 'channel': (-1, 0)}
-# arguments that only act together with use_energy / vtln_warp
-_FBANK_IGNORED = ('raw_energy', 'energy_floor', 'htk_compat', 'vtln_low', 'vtln_high')
+# (featurizer.py:110-111), FFT sizes that are not powers of two
+_FBANK_FIXED = {'dither': (0.0,), 'use_energy': (False,), 'round_to_power_of_two': (True,), 'channel': (-1, 0)}
+# arguments that only act together with use_energy
+_FBANK_IGNORED = ('raw_energy', 'energy_floor', 'htk_compat')
 _WINDOWS = ('povey', 'hamming', 'hanning', 'rectangular', 'blackman')
 _MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
              'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale', 'window_fn', 'wkwargs'}
@@ -65,8 +65,22 @@ def _window(window_type, size, blackman_coeff):
     return blackman_coeff - 0.5 * torch.cos(a * i) + (0.5 - blackman_coeff) * torch.cos(2 * a * i)
 
 
+def _vtln_warp_mel(mel, low, high, vtln_low, vtln_high, warp):
+    """kaldi's vocal-tract-length warp of mel-scale filter edges (torchaudio.compliance.kaldi.vtln_warp_mel_freq): a 3-piece linear map of the
+    frequency axis, the identity outside [low, high]"""
+    f = 700.0 * ((mel / 1127.0).exp() - 1.0)
+    lo_cut, hi_cut, scale = vtln_low * max(1.0, warp), vtln_high * min(1.0, warp), 1.0 / warp
+    if not (lo_cut > low and hi_cut < high):
+        raise AssertionError('VTLN cut-offs must lie inside (low_freq, high_freq)')
+    left = low + (scale * lo_cut - low) / (lo_cut - low) * (f - low)
+    right = high + (high - scale * hi_cut) / (high - hi_cut) * (f - high)
+    r = torch.where(f < lo_cut, left, torch.where(f < hi_cut, scale * f, right))
+    r = torch.where((f < low) | (f > high), f, r)
+    return 1127.0 * (1.0 + r / 700.0).log()
+
+
 @functools.lru_cache(maxsize=8)
-def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high, window_type, blackman_coeff):
+def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high, window_type, blackman_coeff, vtln_warp=1.0, vtln_low=100.0, vtln_high=-500.0):
     size = int(sf * frame_length * 0.001)
     shift = int(sf * frame_shift * 0.001)
     padded = max(2, 1 << (size - 1).bit_length())
@@ -79,7 +93,16 @@ def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high, window_type, 
     idx = torch.arange(nbins).unsqueeze(1)
     left, center, right = mel_lo + idx * delta, mel_lo + (idx + 1.0) * delta, mel_lo + (idx + 2.0) * delta
     mel = (1127.0 * (1.0 + (sf / padded) * torch.arange(nfft_bins) / 700.0).log()).unsqueeze(0)
-    banks = torch.clamp(torch.min((mel - left) / (center - left), (right - mel) / (right - center)), min=0.0)
+    if vtln_warp == 1.0:
+        banks = torch.clamp(torch.min((mel - left) / (center - left), (right - mel) / (right - center)), min=0.0)
+    else:
+        vtln_high = vtln_high + 0.5 * sf if vtln_high < 0.0 else vtln_high
+        if not (low < vtln_low < high and 0.0 < vtln_high < high and vtln_low < vtln_high):
+            raise AssertionError(f'Bad values in options: vtln-low {vtln_low} and vtln-high {vtln_high}, versus low-freq {low} and high-freq {high}')
+        left, center, right = (_vtln_warp_mel(m, low, high, vtln_low, vtln_high, vtln_warp) for m in (left, center, right))
+        up, down = (mel - left) / (center - left), (right - mel) / (right - center)
+        zero = torch.zeros_like(up)
+        banks = torch.where((mel > left) & (mel <= center), up, torch.where((mel > center) & (mel < right), down, zero))
     banks = torch.nn.functional.pad(banks, (0, 1))  # zero weight on the Nyquist bin
     return size, shift, padded, window, banks.t().contiguous()
 
@@ -91,7 +114,7 @@ def fbank_batch(wav, args):
     size, shift, padded, window, banks_t = _fbank_tables(float(a['sample_frequency']), float(a['frame_length']),
                                                           float(a['frame_shift']), int(a['num_mel_bins']),
                                                           float(a['low_freq']), float(a['high_freq']), a['window_type'],
-                                                          float(a['blackman_coeff']))
+                                                          float(a['blackman_coeff']), float(a['vtln_warp']), float(a['vtln_low']), float(a['vtln_high']))
     B, L = wav.shape
     if L < float(a['min_duration']) * float(a['sample_frequency']) or (a['snip_edges'] and L < size):
         return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
