@@ -40,4 +40,13 @@ Pin status
   (the numpy code HuggingFace ships as the replacement for ``ta_kaldi.fbank``)
   and, for MelSpectrogram, ``torch.stft`` (the very op torchaudio calls) plus
   ``transformers.audio_utils.mel_filter_bank``.
+  Round 5 widened the restatement to the keyword arguments the reference forwards
+  (featurizer.py:42,128): kaldi.fbank's window types, ``snip_edges=False``,
+  ``subtract_mean``, ``use_energy`` / ``htk_compat`` / ``raw_energy`` /
+  ``energy_floor``, ``min_duration``, VTLN warping; MelSpectrogram's Slaney mel
+  points / area normalisation, ``normalized`` modes, ``window_fn`` / ``wkwargs``,
+  any real ``power`` -- written from the torchaudio 2.4.0 algorithms as recalled,
+  **equally unpinned**; the Slaney filterbanks are cross-checked against
+  ``transformers.audio_utils.mel_filter_bank(norm=..., mel_scale=...)``
+  (tests/test_oracle.py), the rest has no second implementation here.
 """

@@ -156,3 +156,64 @@ def test_product_cpu_featurizer_matches_reference_wrapper_golden():
     assert np.allclose(mz(wav[:2]).numpy(), z['mel'], rtol=1e-4, atol=1e-5)
     mv = mz(wav_var, ratio).numpy()[2:]
     assert np.allclose(mv, z['mel_var'], rtol=1e-4, atol=1e-5) and np.array_equal(np.all(mv == 0, -1), np.all(z['mel_var'] == 0, -1))
+
+
+def test_oracle_widened_front_end_arguments_against_independent_code_and_properties():
+    """Round 5: the restatements of the further kaldi.fbank / MelSpectrogram keyword arguments (oracle/__init__.py: unpinned against torchaudio)
+    against what IS available -- transformers' window functions, Kaldi port and Slaney filterbanks -- and through properties of the definitions."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    wav = frontend.synth_waveforms(2, 16000, seed=5)
+    # window types: transformers' symmetric windows; the whole Fbank through HF's Kaldi port with a hamming / hann window
+    for name, hf_name in (('hamming', 'hamming'), ('hanning', 'hann')):
+        w = frontend.kaldi_window(name, 400).numpy()
+        assert np.abs(w - window_function(400, hf_name, periodic=False)).max() < 1e-6
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            mf = mel_filter_bank(257, 80, 20, 8000, 16000, norm=None, mel_scale='kaldi', triangularize_in_mel_space=True)
+        hf = spectrogram(wav[0].numpy().astype(np.float64), w.astype(np.float64), frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False,
+                         preemphasis=0.97, mel_filters=mf, log_mel='log', mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+        d = np.abs(frontend.kaldi_fbank(wav[:1], window_type=name, **FB).numpy() - hf)
+        assert d.max() < 5e-4 and d.mean() < 1e-5, (name, d.max(), d.mean())
+    assert torch.equal(frontend.kaldi_window('rectangular', 7), torch.ones(7))
+    bl = frontend.kaldi_window('blackman', 9, 0.42)
+    assert abs(bl[4].item() - 1.0) < 1e-6 and abs(bl[0].item()) < 1e-6 and torch.allclose(bl, bl.flip(0), atol=1e-7)
+    # snip_edges=False: (L + shift / 2) / shift frames; an interior frame equals the snip_edges=True frame over the same samples (offset 120 = pad)
+    a = frontend.kaldi_fbank(wav[:1], snip_edges=False, **FB)
+    assert a.shape == (100, 80)
+    b = frontend.kaldi_fbank(wav[:1, 40:], **FB)          # frame f of b starts at 40 + 160 f = 160 (f + 1) - 120: frame f + 1 of a
+    assert torch.allclose(a[1:98], b[:97], atol=1e-5)
+    # subtract_mean: zero column means; the wrapper's time mean afterwards changes nothing
+    sm = frontend.kaldi_fbank(wav[:1], subtract_mean=True, **FB)
+    assert sm.mean(0).abs().max().item() < 1e-5
+    assert torch.allclose(frontend.audio_featurizer(wav, None, 'Fbank', dict(FB, subtract_mean=True)), frontend.audio_featurizer(wav, None, 'Fbank', FB), atol=2e-5)
+    # use_energy: one more column (first, or last with htk_compat) = log energy of the DC-removed frame, floored at log(energy_floor) = 0
+    e = frontend.kaldi_fbank(wav[:1], use_energy=True, **FB)
+    eh = frontend.kaldi_fbank(wav[:1], use_energy=True, htk_compat=True, **FB)
+    plain = frontend.kaldi_fbank(wav[:1], **FB)
+    assert e.shape == (98, 81) and torch.equal(e[:, 1:], plain) and torch.equal(eh[:, :80], plain) and torch.equal(eh[:, 80], e[:, 0])
+    fr = wav[0].unfold(0, 400, 160)
+    fr = fr - fr.mean(1, keepdim=True)
+    assert torch.allclose(e[:, 0], fr.pow(2).sum(1).log().clamp(min=0.0), atol=1e-5)
+    # VTLN: warp factor 1 is the plain filterbank; the warp is continuous in the factor; cut-offs outside the band are refused
+    b0 = frontend.kaldi_mel_banks(80, 512, 16000.0, 20.0, 0.0)
+    b1 = frontend.kaldi_mel_banks(80, 512, 16000.0, 20.0, 0.0, vtln_warp=1.0 + 1e-6)
+    assert (b0 - b1).abs().max().item() < 1e-3
+    f = torch.tensor([10.0, 20.0, 100.0, 1000.0, 5000.0, 7500.0, 8000.0, 9000.0])
+    wf = frontend.vtln_warp_freq(100.0, 7500.0, 20.0, 8000.0, 1.1, f)
+    assert wf[0] == 10.0 and wf[7] == 9000.0 and abs(wf[1].item() - 20.0) < 1e-4 and abs(wf[6].item() - 8000.0) < 1e-3   # identity outside, fixed ends
+    assert abs(wf[3].item() - 1000.0 / 1.1) < 1e-3 and torch.all(wf[1:7][1:] > wf[1:7][:-1])                             # scaled middle, monotonic
+    with pytest.raises(AssertionError):
+        frontend.kaldi_mel_banks(80, 512, 16000.0, 20.0, 0.0, vtln_low=10.0, vtln_warp=1.1)
+    # MelSpectrogram: Slaney mel points / norm against transformers' (librosa-style) filterbanks; normalisation modes as scalings
+    for ms, nm in (('slaney', 'slaney'), ('slaney', None), ('htk', 'slaney')):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref = mel_filter_bank(201, 128, 0.0, 8000.0, 16000, norm=nm, mel_scale=ms)
+        mine = frontend.melscale_fbanks(201, 0.0, 8000.0, 128, 16000, nm, ms).numpy()
+        assert np.abs(mine - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (ms, nm)
+    m0 = frontend.mel_spectrogram(wav)
+    win = torch.hann_window(400)
+    assert torch.allclose(frontend.mel_spectrogram(wav, normalized=True), m0 / win.pow(2).sum(), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(frontend.mel_spectrogram(wav, normalized='frame_length'), m0 / 400.0, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(frontend.mel_spectrogram(wav, window_fn=torch.hann_window), m0)
+    assert torch.allclose(frontend.mel_spectrogram(wav, power=1.0).pow(1.0), frontend.mel_spectrogram(wav, power=1.0))
