@@ -25,7 +25,16 @@ __device__ __forceinline__ float s16_peak_of(float pk, const float4v& X) {   // 
 __device__ __forceinline__ void s16_peak_commit(unsigned* dst, float pk) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) pk = fmaxf(pk, __shfl_xor(pk, off));
-    if ((threadIdx.x & 63) == 0 && pk > 0.0f) atomicMax(dst, __builtin_bit_cast(unsigned, pk));
+    // (a relaxed look at the word first: tens of thousands of waves of a launch report to ONE address, and same-address atomics serialise in L2 --
+    //  after the first few, a wave's maximum is almost never a new one)
+    if ((threadIdx.x & 63) == 0 && pk > 0.0f) {
+        const unsigned bits = __builtin_bit_cast(unsigned, pk);
+#ifdef MV_S16_UNGUARDED_PEAK   // A/B arm (tools/gpu_r5h.sh): every wave's atomic goes out
+        atomicMax(dst, bits);
+#else
+        if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
+#endif
+    }
 }
 
 // p = position of the hi quadruple: unit base + 4 * (channel quadruple inside the unit)
