@@ -473,6 +473,20 @@ def linear_case(cdll, device, B=5, K=100, O=37, act=1, seed=0):
     ref = ACT[act](x.double() @ w.double().t() + b.double()).float()
     err = (y.cpu() - ref).abs().max().item()
     assert err < 1e-5 * max(1.0, ref.abs().max().item()) + 1e-5, err
+    # the workspace form (long reductions over many rows: K slices + slice-ordered sum): same bar, rows independent of the batch they sit in
+    need = int(cdll.mv_linear_f32_workspace_floats(B, K, O))
+    if need:
+        ws = torch.full((need + 7,), float('nan'), device=device)
+        y2 = torch.full((B, O + 3), 5.0, device=device)
+        _hip.check(cdll.mv_linear_f32_ws(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), act, y2.data_ptr(), O + 3, B, K, O, ws.data_ptr(), need, _stream(xd)), cdll)
+        err2 = (y2.cpu()[:, :O] - ref).abs().max().item()
+        assert err2 < 1e-5 * max(1.0, ref.abs().max().item()) + 1e-5, err2
+        assert torch.all(y2[:, O:] == 5.0) and torch.isnan(ws[need:]).all(), 'wrote outside its output / workspace'
+        nb = max(32, B // 3)
+        y3 = torch.empty(nb, O, device=device)
+        _hip.check(cdll.mv_linear_f32_ws(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), act, y3.data_ptr(), O, nb, K, O, ws.data_ptr(), need, _stream(xd)), cdll)
+        assert torch.equal(y3.cpu(), y2.cpu()[:nb, :O]), 'a row\'s bits depend on the batch'
+        err = max(err, err2)
     return err
 
 

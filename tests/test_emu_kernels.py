@@ -52,7 +52,8 @@ def test_emu_conv1d_rejects_bad_arguments():
         lc.conv1d_case(emu_cdll(), 'cpu', T=3, k=3, dil=4)
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2), (3, 2100, 20, 0), (4, 4180, 18, 0), (150, 4100, 20, 0)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (33, 1024, 128, 2), (3, 2100, 20, 0), (4, 4180, 18, 0), (150, 4100, 20, 0),
+                                   (40, 6144, 192, 0), (33, 2500, 17, 2), (70, 2050, 40, 3)])   # (B >= 32 and K >= 2048: also the split-K workspace form)
 def test_emu_linear(shape):
     B, K, O, act = shape
     lc.linear_case(emu_cdll(), 'cpu', B, K, O, act)

@@ -82,7 +82,7 @@ def test_gpu_conv1d_input_statistics_two_launch_forms_agree():
     lc.in_stats_forms_case(product_lib(), DEV, B_big=72, T=161, cin=1536, seed=1)
 
 
-@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0), (250, 4180, 40, 0), (2048, 6144, 192, 0)])
+@pytest.mark.parametrize('shape', [(5, 100, 37, 1), (17, 64, 16, 0), (1, 7, 3, 3), (256, 6144, 192, 0), (256, 1024, 128, 2), (19, 4180, 40, 0), (250, 4180, 40, 0), (2048, 6144, 192, 0), (256, 6144, 128, 0), (300, 3072, 192, 1), (33, 2500, 17, 2)])
 def test_gpu_linear(shape):
     lc.linear_case(product_lib(), DEV, *shape)
 

@@ -30,4 +30,26 @@ for (B, K, O) in [(256, 6144, 128), (256, 6144, 192), (256, 1024, 128), (256, 12
         call()
     e1.record()
     torch.cuda.synchronize()
-    print(f'linear B={B} K={K} O={O}: cold {sorted(ts)[len(ts) // 2]:.1f} us  warm {e0.elapsed_time(e1) / 50 * 1e3:.1f} us  max err {err:.2e}', flush=True)
+    line = f'linear B={B} K={K} O={O}: direct cold {sorted(ts)[len(ts) // 2]:.1f} us  warm {e0.elapsed_time(e1) / 50 * 1e3:.1f} us  max err {err:.2e}'
+    need = int(lib.mv_linear_f32_workspace_floats(B, K, O)) if hasattr(lib, 'mv_linear_f32_workspace_floats') else 0
+    if need:   # the split-K workspace form (round 5)
+        ws = torch.empty(need, device='cuda')
+        y2 = torch.empty(B, O, device='cuda')
+        call2 = lambda: lib.mv_linear_f32_ws(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), 0, y2.data_ptr(), O, B, K, O, ws.data_ptr(), need, st)
+        _hip.check(call2(), lib)
+        err2 = (y2 - (x.double() @ w.double().T + bias.double()).float()).abs().max().item()
+        ts2 = []
+        for _ in range(10):
+            big.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); call2(); e1.record()
+            torch.cuda.synchronize()
+            ts2.append(e0.elapsed_time(e1) * 1e3)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            call2()
+        e1.record()
+        torch.cuda.synchronize()
+        line += f'  |  split-K cold {sorted(ts2)[len(ts2) // 2]:.1f} us  warm {e0.elapsed_time(e1) / 50 * 1e3:.1f} us  max err {err2:.2e}'
+    print(line, flush=True)

@@ -236,8 +236,8 @@ struct Eres2Model : MvModelBase {
     // ---- workspace ---------------------------------------------------------------------------------------------
     struct Ws {
         float *ping[2], *a, *bc, *r, *t, *t2, *hh, *out[4], *dsb, *fuse[2];   // maps: S16 form, 4 bytes per channel
-        float *stats, *emb_a;
-        size_t bytes;
+        float *stats, *emb_a, *lin_ws;
+        size_t bytes, lin_ws_floats;
     };
     static int down(int n) { return (n - 1) / 2 + 1; }
 
@@ -287,6 +287,8 @@ struct Eres2Model : MvModelBase {
         s.fuse[1] = c.take<float>(max_f + slack);
         s.stats = c.take<float>((size_t)B * 2 * final_c * final_h);
         s.emb_a = c.take<float>((size_t)B * cfg.embd_dim);
+        s.lin_ws_floats = linear_f32_splitk_floats(B, 2 * final_c * final_h, cfg.embd_dim);   // K slices of seg_1 (linear.hip)
+        s.lin_ws = c.take<float>(s.lin_ws_floats);
         s.bytes = c.total();
         return s;
     }
@@ -419,9 +421,9 @@ struct Eres2Model : MvModelBase {
         if ((rc = tstp_s16_launch(reinterpret_cast<const half_t*>(pooled), pooled_ld, B, Hs[3], Wsz[3], final_c, s.stats, st))) return rc;
         const int K = 2 * final_c * final_h;
         if (!cfg.two_emb_layer)
-            return linear_f32_launch(s.stats, K, seg1_w, K, seg1_b, MV_ACT_NONE, emb, cfg.embd_dim, B, K, cfg.embd_dim, 0, st);
+            return linear_f32_launch(s.stats, K, seg1_w, K, seg1_b, MV_ACT_NONE, emb, cfg.embd_dim, B, K, cfg.embd_dim, 0, st, s.lin_ws, s.lin_ws_floats);
         // embed_a -> relu -> seg_bn_1 (folded into seg_2) -> seg_2   (eres2net.py:285-288)
-        if ((rc = linear_f32_launch(s.stats, K, seg1_w, K, seg1_b, MV_ACT_RELU, s.emb_a, cfg.embd_dim, B, K, cfg.embd_dim, 0, st))) return rc;
+        if ((rc = linear_f32_launch(s.stats, K, seg1_w, K, seg1_b, MV_ACT_RELU, s.emb_a, cfg.embd_dim, B, K, cfg.embd_dim, 0, st, s.lin_ws, s.lin_ws_floats))) return rc;
         return linear_f32_launch(s.emb_a, cfg.embd_dim, seg2_w, cfg.embd_dim, seg2_b, MV_ACT_NONE, emb, cfg.embd_dim, B, cfg.embd_dim,
                                  cfg.embd_dim, 0, st);
     }

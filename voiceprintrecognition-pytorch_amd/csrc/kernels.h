@@ -33,8 +33,11 @@ int map_merge_launch(const void* x, float* y, int64_t n, hipStream_t stream);
 int conv2d_first_s16_launch(const float* feats, half_t* out, const float* w, const float* bias, int B, int T, int F, int C, hipStream_t stream, unsigned* peak = nullptr);
 int tstp_s16_launch(const half_t* x, int64_t ld, int B, int H, int W, int C, float* stats, hipStream_t stream);
 
+// splitk_ws (optional, linear_f32_splitk_floats(B, K, O) floats; 0 = the direct kernel is what runs): long reductions over many rows as K slices + a
+// slice-ordered sum (linear.hip)
 int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
-                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream);
+                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream, float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+size_t linear_f32_splitk_floats(int B, int K, int O);
 
 int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* mean, float* stdv, int64_t ld_out,
                       int unbiased, float clamp_eps, hipStream_t stream, const float* in_scale = nullptr,

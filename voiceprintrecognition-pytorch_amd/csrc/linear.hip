@@ -17,7 +17,7 @@
 // that x passes through one L2 instead of eight) changes nothing -- 24.3 / 24.7 us warm and 28 us behind a cache flush in both forms, and
 // [2048, 6144] x [192, 6144] takes 8 x the time of 256 rows: the launch is bound by the workgroup's own chain (three dependent load trips + 96
 // fp32 MFMAs per wave, four waves per SIMD), not by operand delivery through the fabric.
-#include "common.h"
+#include "kernels.h"
 
 namespace mv {
 
@@ -135,6 +135,86 @@ __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int
     }
 }
 
+// ---- long reductions with many rows (round 5): split K over workgroups ------------------------------------------------------------------
+// [256, 6144] x [192, 6144] on the kernel above is 192 workgroups of 16 x 16 outputs, each streaming its 16 + 16 rows of 6144 floats: 151 MB
+// through L2 for 0.6 GFLOP, three dependent load trips per wave -- 31 us per launch, twice per EcapaTdnn-1024 step (ASP context bias, final fc).
+// Here a workgroup of four waves owns 32 x 32 outputs of ONE K slice of 384: every wave loads two row fragments and two weight fragments per 16
+// K values for SIXTEEN MFMAs (2 x 2 register blocking: half the operand bytes per output), all of its loads in one trip; the slices' partial
+// sums go to a caller workspace [slices][B][O] and a second launch adds them in slice order (+ bias, activation) -- a fixed order, so a row's
+// bits depend on nothing but the row.  (Atomics into y would need no second launch and give a different sum every run.)
+constexpr int LSK_SLICE = 384;   // K values per slice: 4 waves x 6 blocks of 16
+constexpr int LSK_U = LSK_SLICE / 64;
+
+__global__ __launch_bounds__(256) void linear_f32_splitk_kernel(const float* x, int64_t ldx, const float* w, int64_t ldw, float* part, int B, int K, int O) {
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int kb = blockIdx.z * LSK_SLICE;
+    const int ke = kb + LSK_SLICE < K ? kb + LSK_SLICE : K;
+    const float* xrow[2];
+    const float* wrow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int br = b0 + 16 * m + i < B ? b0 + 16 * m + i : B - 1;   // clamp: duplicates are masked at the store
+        const int oc = o0 + 16 * m + i < O ? o0 + 16 * m + i : O - 1;
+        xrow[m] = x + (int64_t)br * ldx;
+        wrow[m] = w + (int64_t)oc * ldw;
+    }
+    const bool xvec = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool wvec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    float4v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    float4v xa[LSK_U][2], wb[LSK_U][2];
+#pragma unroll
+    for (int u = 0; u < LSK_U; ++u) {   // wave `wave` takes the blocks of 16 with index == wave (mod 4) of the slice: all loads of the wave in one trip
+        const int k = kb + (u * 4 + wave) * 16 + 4 * g;
+        const int kc = k < ke ? k : kb;   // blocks behind the slice's end: any valid (aligned) address, the values are zeroed below
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            xa[u][m] = load4_guard(xrow[m], kc, K, xvec);
+            wb[u][m] = load4_guard(wrow[m], kc, K, wvec);
+            if (k >= ke) xa[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < LSK_U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][m][e], wb[u][n][e], acc[m][n], 0, 0, 0);
+    // lane holds D[row = 16 m + 4 g + r][col = 16 n + i]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][16 * m + 4 * g + r][16 * n + i] = acc[m][n][r];
+    __syncthreads();
+    float* pz = part + (int64_t)blockIdx.z * B * O;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j, r = idx >> 5, c = idx & 31;
+        const int b = b0 + r, o = o0 + c;
+        if (b < B && o < O) pz[(int64_t)b * O + o] = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_f32_splitk_finish_kernel(const float* part, const float* bias, int act, float* y, int64_t ldy, int B, int O, int slices) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * O) return;
+    const int b = (int)(idx / O), o = (int)(idx - (int64_t)b * O);
+    float v = 0.0f;
+    for (int s = 0; s < slices; ++s) v += part[(int64_t)s * B * O + idx];   // slice order
+    if (bias != nullptr) v += bias[o];
+    y[(int64_t)b * ldy + o] = lin_act(v, act);
+}
+
 // inv[r] = 1 / max(|x_r|, tiny); optionally normalise in place
 __global__ __launch_bounds__(256) void row_inv_norm_kernel(float* x, int n, int dim, float* inv, int normalize) {
     const int lane = threadIdx.x & 63;
@@ -152,10 +232,29 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(float* x, int n, int 
         for (int k = lane; k < dim; k += 64) p[k] = p[k] / nrm;  // features / np.linalg.norm (predict.py:165-166)
 }
 
+// the split-K form pays when the reduction is long and there are rows enough to fill 32-row tiles; its workspace: [slices][B][O] floats
+size_t linear_f32_splitk_floats(int B, int K, int O) {
+#ifdef MV_LINEAR_NO_SPLITK   // A/B arm of tools/gpu_r5i.sh: every layer on the direct kernel
+    return 0;
+#endif
+    if (K < 2048 || B < 32 || O < 16 || B > 65535 * 32) return 0;
+    return (size_t)ceil_div(K, LSK_SLICE) * B * O;
+}
+
 int linear_f32_launch(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
-                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream) {
+                      int64_t ldy, int B, int K, int O, int cosine, hipStream_t stream, float* splitk_ws, size_t splitk_ws_floats) {
     MV_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "linear_f32: null tensor");
     MV_REQUIRE(B > 0 && K > 0 && O > 0 && ldx >= K && ldw >= K && ldy >= O, "linear_f32: bad geometry");
+    {
+        const size_t need = cosine ? 0 : linear_f32_splitk_floats(B, K, O);
+        if (need > 0 && splitk_ws != nullptr && splitk_ws_floats >= need) {
+            const int slices = (int)ceil_div(K, LSK_SLICE);
+            MV_LAUNCH(linear_f32_splitk_kernel, ((unsigned)ceil_div(O, 32), (unsigned)ceil_div(B, 32), (unsigned)slices), (256, 1, 1), 0, stream, x, ldx, w, ldw,
+                      splitk_ws, B, K, O);
+            MV_LAUNCH(linear_f32_splitk_finish_kernel, ((unsigned)ceil_div((int64_t)B * O, 256), 1, 1), (256, 1, 1), 0, stream, splitk_ws, bias, act, y, ldy, B, O, slices);
+            return check_launch("linear_f32_splitk_kernel");
+        }
+    }
     // grid.y holds at most 65535 row tiles: longer inputs (evaluation score matrices with > 1 M trial rows) go in row chunks
     constexpr int kMaxRows = 65535 * 16;
     if (B > kMaxRows) {
@@ -186,6 +285,13 @@ extern "C" {
 int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
                   int32_t B, int32_t K, int32_t O, mv_stream_t stream) {
     return mv::linear_f32_launch(x, ldx, w, K, bias, act, y, ldy, B, K, O, 0, static_cast<hipStream_t>(stream));
+}
+
+size_t mv_linear_f32_workspace_floats(int32_t B, int32_t K, int32_t O) { return mv::linear_f32_splitk_floats(B, K, O); }
+
+int mv_linear_f32_ws(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy, int32_t B, int32_t K, int32_t O,
+                     float* workspace, size_t workspace_floats, mv_stream_t stream) {
+    return mv::linear_f32_launch(x, ldx, w, K, bias, act, y, ldy, B, K, O, 0, static_cast<hipStream_t>(stream), workspace, workspace_floats);
 }
 
 int mv_cosine_f32(const float* a, int32_t n, const float* b, int32_t m, int32_t dim, float* scores, mv_stream_t stream) {

@@ -214,10 +214,11 @@ int AspLayer::create(MvModelBase* m, const Weights& w, const std::string& prefix
     return MV_OK;
 }
 
-// [B, 2C] global mean | std, [B, A] context bias, the two partial buffers of the hidden conv's fused input statistics
+// [B, 2C] global mean | std, [B, A] context bias, the two partial buffers of the hidden conv's fused input statistics, the K slices of the
+// context-bias layer (linear.hip, split-K form: [2C -> A] over B rows)
 size_t AspLayer::workspace_floats(int B, int T) const {
     (void)T;
-    return (size_t)B * (2 * C + A) + 2 * (size_t)conv_in_stats_elems(B, T, C);
+    return (size_t)B * (2 * C + A) + 2 * (size_t)conv_in_stats_elems(B, T, C) + linear_f32_splitk_floats(B, 2 * C, A);
 }
 
 // x: [B, T, ldx] fp16 -> pooled [B, 2C] fp32.  h: [B*T, A] fp16 scratch, fws: workspace_floats(B) fp32 scratch.
@@ -226,6 +227,8 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     int rc;
     float* gstats = fws;                     // [B, 2C]  mean | std
     float* ctxb = fws + (size_t)B * 2 * C;   // [B, A]
+    float* lin_ws = fws + (size_t)B * (2 * C + A) + 2 * (size_t)conv_in_stats_elems(B, T, C);
+    const size_t lin_ws_floats = linear_f32_splitk_floats(B, 2 * C, A);
     const float* gmean = nullptr;
     if (global_ctx && !have_gstats && A <= 128 && A % 8 == 0 && ldx % 8 == 0) {
         // x is streamed ONCE for the global statistics and the hidden layer: the 1x1 conv over x collects the time sums of its own x
@@ -254,7 +257,7 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
         d.in_stat_sq = psq;
         if ((rc = conv1d_launch(d, stream))) return rc;
         if ((rc = conv_in_stats_finish_launch(psum, psq, B, T, C, gstats, gstats + C, 2 * C, 1e-12f, stream))) return rc;
-        if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream))) return rc;
+        if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream, lin_ws, lin_ws_floats))) return rc;
         if ((rc = asp_hidden_act_launch(h, ctxb, bn_scale, bn_shift, B, T, A, stream))) return rc;
         return asp_pool_launch(h, conv.w, x, ldx, gstats, 2 * C, pooled, B, T, C, A, logit_bound_log2, stream);
     }
@@ -265,7 +268,7 @@ int AspLayer::forward(const half_t* x, int64_t ldx, int B, int T, half_t* h, flo
     const float* row_bias = nullptr;
     if (global_ctx) {
         // context bias = W[:, C:3C] . [mean; std] + b  (pooling.py:104-117 with the T-constant columns hoisted)
-        if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream)))
+        if ((rc = linear_f32_launch(gstats, 2 * C, wms, 2 * C, tdnn.bias, MV_ACT_NONE, ctxb, A, B, 2 * C, A, 0, stream, lin_ws, lin_ws_floats)))
             return rc;
         row_bias = ctxb;
     }
@@ -419,8 +422,8 @@ struct EcapaModel : MvModelBase {
 
     struct Ws {
         half_t *x16, *a0, *cat, *t1, *r2, *t2, *sc, *mfa, *h, *rs[2];
-        float *se_mean, *se_hid, *gate, *asp_f, *pooled;
-        size_t bytes;
+        float *se_mean, *se_hid, *gate, *asp_f, *pooled, *fc_ws;
+        size_t bytes, fc_ws_floats;
     };
 
     Ws carve(void* base, int B, int T) const {
@@ -443,6 +446,8 @@ struct EcapaModel : MvModelBase {
         s.gate = c.take<float>((size_t)B * cmax);
         s.asp_f = c.take<float>(asp.workspace_floats(B, T));
         s.pooled = c.take<float>((size_t)B * 2 * cfg.channels[4]);
+        s.fc_ws_floats = linear_f32_splitk_floats(B, 2 * cfg.channels[4], cfg.embd_dim);   // K slices of the final layer (linear.hip)
+        s.fc_ws = c.take<float>(s.fc_ws_floats);
         s.bytes = c.total();
         return s;
     }
@@ -555,7 +560,7 @@ struct EcapaModel : MvModelBase {
         if ((rc = asp.forward(s.mfa, Cm, B, T, s.h, s.asp_f, s.pooled, st))) return rc;
         // asp_bn folded into fc
         return linear_f32_launch(s.pooled, 2 * Cm, fc_w, 2 * Cm, fc_b, MV_ACT_NONE, emb, cfg.embd_dim, B, 2 * Cm, cfg.embd_dim, 0,
-                                 st);
+                                 st, s.fc_ws, s.fc_ws_floats);
     }
 };
 

@@ -129,6 +129,8 @@ _SIGNATURES = {
     'mv_res2net_chain_f16': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                              ctypes.POINTER(c_vp), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'mv_linear_f32': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'mv_linear_f32_workspace_floats': (c_sz, [c_i32, c_i32, c_i32]),
+    'mv_linear_f32_ws': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     'mv_profile_enable': (c_i32, [c_i32]),
     'mv_profile_read': (c_i32, [c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_i32]),
     'mv_wave_prepare_i16': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp]),
