@@ -414,7 +414,7 @@ int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, co
 /* y[b, o] = act( sum_k x[b, k] * w[o, k] + bias[o] ) in exact fp32 (f32 MFMA). */
 int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
                   int32_t B, int32_t K, int32_t O, mv_stream_t stream);
-/* The same layer with a caller workspace (ABI 4): long reductions over many rows (K >= 2048, B >= 32: the [256, 6144] x [192, 6144] final layer of
+/* The same layer with a caller workspace (ABI 4): long reductions (K >= 2048, any number of rows: the [256, 6144] x [192, 6144] final layer of
  * EcapaTdnn-1024) run as K slices of 384 on 32 x 32 output tiles + a second launch that adds the slices' partial sums in slice order -- a fixed order,
  * so a row's bits depend on the row only.  mv_linear_f32_workspace_floats = floats that form needs (0: the direct kernel runs either way); with a
  * NULL or short workspace the call is mv_linear_f32. */

@@ -482,7 +482,7 @@ def linear_case(cdll, device, B=5, K=100, O=37, act=1, seed=0):
         err2 = (y2.cpu()[:, :O] - ref).abs().max().item()
         assert err2 < 1e-5 * max(1.0, ref.abs().max().item()) + 1e-5, err2
         assert torch.all(y2[:, O:] == 5.0) and torch.isnan(ws[need:]).all(), 'wrote outside its output / workspace'
-        nb = max(32, B // 3)
+        nb = max(1, B // 3)
         y3 = torch.empty(nb, O, device=device)
         _hip.check(cdll.mv_linear_f32_ws(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), act, y3.data_ptr(), O, nb, K, O, ws.data_ptr(), need, _stream(xd)), cdll)
         assert torch.equal(y3.cpu(), y2.cpu()[:nb, :O]), 'a row\'s bits depend on the batch'
