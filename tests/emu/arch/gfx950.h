@@ -114,6 +114,8 @@ inline half8v lds_load_half8(lds_half_ptr p, int elem_off) { return *reinterpret
 inline void glds16(const void* gsrc, char* lds_wave_base) { emu::dma_issue(lds_wave_base + (emu::flat_tid() & 63) * 16, gsrc); }
 template <int N>
 inline void wait_vm() { emu::dma_retire(N); }
+template <int N>
+inline void wait_vm_seen() { emu::dma_retire(N); }
 inline void lds_barrier() {   // (no drain of transfers in flight: s_waitcnt lgkmcnt(0) + s_barrier)
     emu::lds_read_retire(0);
     emu::syncthreads();
@@ -122,6 +124,7 @@ inline void barrier_only() { emu::syncthreads(); }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc);
 }
+inline void global_store8_untracked(void* gdst, const half4v& v) { *reinterpret_cast<half4v*>(gdst) = v; }
 inline void glds16_untracked_so(const void* sbase, unsigned voff, unsigned lds_wave_base_addr) {
     emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(sbase) + voff);
 }

@@ -1,0 +1,69 @@
+"""Compile every csrc/*.hip to gfx950 assembly (hipcc -S, the product's flags) and report, per kernel, what tends to hide a codegen accident:
+FLAT memory instructions (a pointer that lost its address space: FLAT loads count on lgkmcnt as well, so the next LDS wait waits for L2), scratch
+(spill) instructions, VGPR / spill counts, and MFMAs that sit alone in a basic block (a uniform branch per MFMA: each one waits for its own operands).
+usage: python tools/isa_audit.py [file.hip ...]      (writes /tmp/isa_audit/<file>.s)"""
+import glob, os, re, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'voiceprintrecognition-pytorch_amd')
+sys.path.insert(0, PKG)
+import build_native
+
+OUT = '/tmp/isa_audit'
+os.makedirs(OUT, exist_ok=True)
+files = [os.path.join(PKG, 'csrc', f) for f in sys.argv[1:]] or sorted(glob.glob(os.path.join(PKG, 'csrc', '*.hip')))
+procs = []
+for src in files:
+    asm = os.path.join(OUT, os.path.basename(src) + '.s')
+    cmd = [build_native.HIPCC] + build_native.FLAGS + build_native._file_flags(src) + ['-Wno-inline-asm', '--cuda-device-only', '-S', '-x', 'hip', src, '-o', asm]
+    procs.append((src, asm, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+for src, asm, p in procs:
+    out, _ = p.communicate()
+    if p.returncode:
+        print(out.decode()[-2000:])
+        raise SystemExit(f'hipcc failed on {src}')
+    kernel, stats = None, {}
+    for line in open(asm):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            kernel = m.group(1)
+            stats[kernel] = dict(flat=0, scratch=0, mfma=0, lone=0, blocks=0, in_block=0)
+            continue
+        if kernel is None:
+            continue
+        st = stats[kernel]
+        t = line.strip()
+        if t.startswith('.LBB') or t.startswith('s_cbranch') or t.startswith('s_branch'):
+            if st['in_block'] == 1:
+                st['lone'] += 1
+            st['in_block'] = 0
+            continue
+        if t.startswith(('flat_load', 'flat_store', 'flat_atomic')):
+            st['flat'] += 1
+        elif t.startswith('scratch_'):
+            st['scratch'] += 1
+        elif t.startswith('v_mfma'):
+            st['mfma'] += 1
+            st['in_block'] += 1
+        m = re.match(r'\.(vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)', t)
+        if m:
+            pass
+    meta = {}
+    cur = None
+    for line in open(asm):
+        t = line.strip()
+        m = re.match(r'\.name:\s+(\S+)', t)
+        if m:
+            cur = m.group(1)
+            meta.setdefault(cur, {})
+        m = re.match(r'\.(vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)', t)
+        if m and cur:
+            meta[cur][m.group(1)] = int(m.group(2))
+    print(os.path.basename(src))
+    for k, st in stats.items():
+        if k not in meta:
+            continue
+        md = meta[k]
+        flag = ' <--' if st['flat'] or st['scratch'] or md.get('vgpr_spill_count') or st['lone'] > 2 else ''
+        name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().split('(')[0][:90]
+        print(f"  {name:90s} vgpr {md.get('vgpr_count', 0):3d} spill v{md.get('vgpr_spill_count', 0)} s{md.get('sgpr_spill_count', 0):<3d} flat {st['flat']:3d} scratch {st['scratch']:3d} "
+              f"mfma {st['mfma']:4d} (alone in a block: {st['lone']}){flag}")

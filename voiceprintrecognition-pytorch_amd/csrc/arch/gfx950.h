@@ -128,6 +128,12 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The same wait as an instruction the compiler's wait-count insertion SEES: its scoreboard of tracked loads moves on.  (Where tracked loads stay in
+// flight across a wait the compiler cannot see, it protects every register one of them might still write with an s_waitcnt vmcnt(0) of its own.)
+template <int N>
+__device__ __forceinline__ void wait_vm_seen() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));   // gfx9 encoding: vmcnt [3:0] + [15:14], expcnt and lgkmcnt not waited for
+}
 // The same transfer as inline assembly, invisible to the compiler's wait-count insertion.  With the builtin the compiler knows that
 // LDS is written behind its back: it puts s_waitcnt vmcnt(0) in front of every LDS load that may alias a transfer in flight and in
 // front of the first use of any global load that shares the counter with one (mixed event types are assumed to complete out of
@@ -135,6 +141,11 @@ __device__ __forceinline__ void wait_vm() {
 // once a later s_waitcnt vmcnt (the caller's, or the compiler's for a younger tracked load) has retired the transfer.
 __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base_addr) : "memory", "m0");
+}
+// an 8-byte global store the compiler's wait-count insertion does not see: a tracked store in flight beside tracked loads makes it treat the counter
+// as completing out of order (mixed event types), and every wait it then needs becomes s_waitcnt vmcnt(0).  The caller owns the ordering.
+__device__ __forceinline__ void global_store8_untracked(void* gdst, const half4v& v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gdst), "v"(v) : "memory");
 }
 // the same with the address as uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: a stream that advances by a
 // constant per stage costs one scalar add per stage instead of a 64-bit vector add per transfer

@@ -43,6 +43,16 @@ namespace mv {
 #ifndef MV_CB_INTERLEAVE
 #define MV_CB_INTERLEAVE 1  // 0: the stage as three phases (requests, MFMAs, transform), the form of rounds 2-3 (A/B arm)
 #endif
+#ifndef MV_CB_REGSUMS
+#define MV_CB_REGSUMS 1     // 1 (round 5): the context's column sums leave the h epilogue's registers (DPP row sums, [2 time halves][2 segments][128] partials);
+#endif                      // 0: h is read back from LDS by 32 row phases into a 32 KB scratch and summed by 256 threads (two more barriers; A/B arm)
+#ifndef MV_CB_EARLY_W
+#define MV_CB_EARLY_W 0     // 1: the next layer's W1 stages 0 / 1 are requested with its x stages at the start of the tail (the W ring is no scratch with MV_CB_REGSUMS)
+#endif
+#ifndef MV_CB_LAZY_STORES
+#define MV_CB_LAZY_STORES 1 // 1 (round 5): the layer entry leaves the previous layer's y stores and k = 3 weight requests in flight (counted wait); 0: s_waitcnt vmcnt(0)
+#endif
+static_assert(!MV_CB_EARLY_W || MV_CB_REGSUMS, "the early W1 requests need the W ring idle through the context phase");
 constexpr int CB_THREADS = 512;
 constexpr int CB_TT = 10;                           // time tiles of 16 frames: T2 <= 160
 constexpr int CB_ROWS = CB_TT * 16;
@@ -57,7 +67,8 @@ constexpr int CB_H_OFF = 2 * CB_XS_BYTES;           // h = x slots 2, 3: [160 ro
 static_assert(CB_ROWS * CB_BN * 2 == 2 * CB_XS_BYTES, "h fills exactly two x slots");
 constexpr int CB_F_OFF = CB_XRING * CB_XS_BYTES + CB_RING * CB_WS_BYTES;  // fp32 area behind the rings
 constexpr int CB_F_CTX = 0, CB_F_G1 = CB_F_CTX + CB_MAX_SEG * CB_BN, CB_F_GATE = CB_F_G1 + CB_MAX_SEG * 64,
-              CB_F_TAB = CB_F_GATE + CB_MAX_SEG * CB_G,               // [2 layers][scale | shift][CB_MAX_CIN]
+              CB_F_PART = CB_F_GATE + CB_MAX_SEG * CB_G,              // [2 time halves][CB_MAX_SEG][CB_BN] column sums of h
+              CB_F_TAB = CB_F_PART + 2 * CB_MAX_SEG * CB_BN,          // [2 layers][scale | shift][CB_MAX_CIN]
               CB_F_END = CB_F_TAB + 4 * CB_MAX_CIN;
 constexpr int CB_MAX_LAYERS = 24;
 constexpr size_t CB_DESC_OFF = CB_F_OFF + CB_F_END * sizeof(float) + 1024;   // behind the KiB that swallows the padding transfers
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
     float* ctx = fsm + CB_F_CTX;
     float* g1 = fsm + CB_F_G1;
     float* gate = fsm + CB_F_GATE;
+    float* hsum = fsm + CB_F_PART;
     float* tabs = fsm + CB_F_TAB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,18 +130,19 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
 
     // ---- operand requests of a layer: every wave issues exactly 3 x transfers and 2 W1 transfers per stage (stages beyond the last one
     // and the x transfers 20..23 read a constant page into the dump KiB), so the waits can be counted ----
-    auto issue_x = [&](int s, int nst) {
+    auto issue_x_from = [&](int s, int nst, int wave_uu, int lrow_, int kc_) {
         const bool real = s < nst;
         const unsigned dst = xs_addr + (unsigned)((s & (CB_XRING - 1)) * CB_XS_BYTES);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const int tr = wave_u + 8 * u;
-            int row = tr * 8 + lrow;
+            const int tr = wave_uu + 8 * u;
+            int row = tr * 8 + lrow_;
             row = row < T2 ? row : T2 - 1;
             const bool live = real && tr < CB_ROWS / 8;  // uniform
-            glds16_untracked(live ? xb + (int64_t)row * a.ldx + s * 64 + kc * 8 : zero, live ? dst + (unsigned)(tr * 1024) : dump_addr);
+            glds16_untracked(live ? xb + (int64_t)row * a.ldx + s * 64 + kc_ * 8 : zero, live ? dst + (unsigned)(tr * 1024) : dump_addr);
         }
     };
+    auto issue_x = [&](int s, int nst) { issue_x_from(s, nst, wave_u, lrow, kc); };
     auto issue_w = [&](int s, int nst, const half_t* w1, int cin_pad) {
         const bool real = s < nst;
         const unsigned dst = ws_addr + (unsigned)((s % CB_RING) * CB_WS_BYTES);
@@ -174,8 +187,8 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * CB_THREADS;
             const int ic = i < L.cin ? i : L.cin - 1;  // always a load, never a select on its result: the compiler waits where a value is first USED
-            ts[j] = L.bn1_s[ic];
-            tt[j] = L.bn1_t[ic];
+            ts[j] = *MV_GLOBAL_PTR(float, L.bn1_s + ic);   // (pointers out of the descriptors in LDS carry no address space: without the cast every parameter
+            tt[j] = *MV_GLOBAL_PTR(float, L.bn1_t + ic);   //  load is a FLAT load, which also counts on lgkmcnt -- the next LDS wait then waits for L2)
         }
     };
     auto store_tables = [&](int buf, int cin, const float (&ts)[2], const float (&tt)[2]) {
@@ -195,21 +208,22 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
     auto load_ctx_params = [&](const MvCamLayerDesc& L) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            e_bn2s[mi] = *reinterpret_cast<const float4v*>(L.bn2_s + (cw * 2 + mi) * 16 + 4 * fg);
-            e_bn2t[mi] = *reinterpret_cast<const float4v*>(L.bn2_t + (cw * 2 + mi) * 16 + 4 * fg);
+            e_bn2s[mi] = *MV_GLOBAL_PTR(float4v, L.bn2_s + (cw * 2 + mi) * 16 + 4 * fg);
+            e_bn2t[mi] = *MV_GLOBAL_PTR(float4v, L.bn2_t + (cw * 2 + mi) * 16 + 4 * fg);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e_wa[u] = *reinterpret_cast<const float4v*>(L.wa + (tid >> 3) * CB_BN + (tid & 7) * 16 + 4 * u);
-        e_wb = *reinterpret_cast<const float4v*>(L.wb + (tid >> 4) * 64 + (tid & 15) * 4);
-        e_ba = L.ba[tid >> 3];
-        e_bb = L.bb[tid >> 4];
+        for (int u = 0; u < 4; ++u) e_wa[u] = *MV_GLOBAL_PTR(float4v, L.wa + (tid >> 3) * CB_BN + (tid & 7) * 16 + 4 * u);
+        e_wb = *MV_GLOBAL_PTR(float4v, L.wb + (tid >> 4) * 64 + (tid & 15) * 4);
+        e_ba = *MV_GLOBAL_PTR(float, L.ba + (tid >> 3));
+        e_bb = *MV_GLOBAL_PTR(float, L.bb + (tid >> 4));
     };
     auto load_wl = [&](const MvCamLayerDesc& L) {
         const half_t* wrow = L.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CB_BN + 8 * fg;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) e_wl[tap][kk] = *reinterpret_cast<const half8v*>(wrow + tap * CB_BN + kk * 32);
+            for (int kk = 0; kk < 4; ++kk) e_wl[tap][kk] = *MV_GLOBAL_PTR(half8v, wrow + tap * CB_BN + kk * 32);
+        MV_VM_LOADS(12);   // (the layer entry's counted wait leaves these twelve and the y stores in flight)
     };
 
     // ---- first layer: the start-up of cam_dense_layer_kernel ----
@@ -236,24 +250,28 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         const float* lbn_t = lbn_s + CB_MAX_CIN;
         // ---- layer entry: x(0), x(1), W1(0), W1(1) have been requested (by the previous layer's tail or by the start-up); everything
         // this wave has in flight -- them, the parameter loads, the previous layer's y stores -- is waited for, then x(2) goes out ----
-        wait_vm<0>();
-        // the parameter loads of this layer are the only vector loads the compiler tracks; touching what they deliver puts ITS wait for them
-        // here, behind ours -- left where the values are first used (epilogue, context phase, k = 3 conv) it would be an s_waitcnt vmcnt(0)
-        // in the middle of the tail, draining the next layer's operand requests that have just gone out
+        // The youngest vector-memory operations of this wave are the previous layer's y stores and the twelve k = 3 weight requests behind them; what
+        // the entry needs -- x(0), x(1), W1(0), W1(1), the context parameters -- is older.  The stores have to be in L2 before ANY wave requests the x
+        // stage that holds the previous layer's 32 channels: that is the LAST stage, requested at stage nst - 4 behind that stage's counted wait (which
+        // covers everything older than the last five transfers) and barrier.  So with more than four stages the entry waits for all but those
+        // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.
+        const bool lazy = MV_CB_LAZY_STORES && l > 0 && nst > 4;   // uniform
+        if (lazy) {
+            int n_st = 0;   // y stores this wave issued: its time tiles with a frame below T2 (phase C)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            MV_OPAQUE(e_bn2s[mi]);
-            MV_OPAQUE(e_bn2t[mi]);
+            for (int j = 0; j < 3; ++j) n_st += ((wave_u >> 1) + 4 * j < CB_TT && ((wave_u >> 1) + 4 * j) * 16 < T2) ? 1 : 0;
+            if (n_st == 3) {   // (waits the compiler sees: it has the k = 3 weight and context parameter loads on its scoreboard)
+                wait_vm_seen<15>();
+            } else if (n_st == 2) {
+                wait_vm_seen<14>();
+            } else if (n_st == 1) {
+                wait_vm_seen<13>();
+            } else {
+                wait_vm_seen<12>();
+            }
+        } else {
+            wait_vm_seen<0>();
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) MV_OPAQUE(e_wa[u]);
-        MV_OPAQUE(e_wb);
-        MV_OPAQUE(e_ba);
-        MV_OPAQUE(e_bb);
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) MV_OPAQUE(e_wl[tap][kk]);
         __syncthreads();   // every wave's stores are in L2, the tables of this layer are in LDS, h (x slots 2, 3) is dead
         issue_x(2, nst);
         transform(0, L.cin, lbn_s, lbn_t);
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         for (int s = 0; s < nst; ++s) {
             // W1(s) and x(s+1) have landed: younger are x(s+2) [3 transfers] and, from stage 1 on, W1(s+1) [2]
             if (s == 0) {
-                wait_vm<3>();   // (W1(1) was requested before x(2) at the layer boundary: older than the three transfers that may stay)
+                if (!lazy) wait_vm<3>();   // (W1(1) was requested before x(2) at the layer boundary: older than the three transfers that may stay)
             } else {
                 wait_vm<5>();
             }
@@ -398,6 +416,23 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         }
 #endif
         wait_vm<0>();   // only padding transfers are left: nothing may still be landing when the rings are reused
+        // the parameter loads of this layer are the only vector loads the compiler tracks; touching what they deliver puts ITS wait for them
+        // here, behind ours -- left where the values are first used (epilogue, context phase, k = 3 conv) it would be an s_waitcnt vmcnt(0)
+        // in the middle of the tail, draining the next layer's operand requests that have just gone out
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            MV_OPAQUE(e_bn2s[mi]);
+            MV_OPAQUE(e_bn2t[mi]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) MV_OPAQUE(e_wa[u]);
+        MV_OPAQUE(e_wb);
+        MV_OPAQUE(e_ba);
+        MV_OPAQUE(e_bb);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) MV_OPAQUE(e_wl[tap][kk]);
         lds_barrier();  // every wave is done with both rings
         // The tail's per-thread LDS / global addresses are derived from a thread id the optimiser must treat as new in every layer:
         // otherwise it hoists all of them out of the layer loop (they are loop-invariant) into ~130 long-lived registers and spills.
@@ -412,30 +447,77 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         if (more) {
             Ln = layer_desc(l + 1);
             const int nstn = Ln.cin_pad / 64;
-            issue_x(0, nstn);
-            issue_x(1, nstn);
-            load_tables(Ln, nts, ntt);   // (its W1 stages follow the context phase: the idle W ring is that phase's scratch)
-        }
+            const int lrow_t = lane_t >> 3, wave_ut = MV_UNIFORM(wave_t);   // (row addresses from the per-layer thread id: hoisted out of the layer loop they were spilled,
+            issue_x_from(0, nstn, wave_ut, lrow_t, (lane_t & 7) ^ lrow_t);   //  and the reload's s_waitcnt vmcnt(0) sat behind the first of these requests)
+            issue_x_from(1, nstn, wave_ut, lrow_t, (lane_t & 7) ^ lrow_t);
+#if MV_CB_EARLY_W
+            issue_w(0, nstn, Ln.w1, Ln.cin_pad);
+            issue_w(1, nstn, Ln.w1, Ln.cin_pad);
+#endif
+        }   // (MV_CB_REGSUMS 0: its W1 stages follow the context phase: the idle W ring is that phase's scratch)
+        // UNCONDITIONAL (the last layer fetches its own tables again, into the idle buffer): loaded under `if (more)` and stored under a second
+        // `if (more)`, the compiler's wait-count insertion sees a path on which the four loads are never waited for, carries their registers as
+        // pending around the layer loop, and protects the fragment read that reuses one of them with an s_waitcnt vmcnt(0) in every stage
+        load_tables(Ln, nts, ntt);
         // epilogue A: BN2 + ReLU -> h (fp16, swizzled 16-byte chunks: chunk ^= row & 15); frames >= T2 are zero
         for (int i = T2 * CB_BN * 2 + tid_t * 16; i < CB_ROWS * CB_BN * 2; i += CB_THREADS * 16)
             *reinterpret_cast<float4v*>(hbuf + i) = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#if MV_CB_REGSUMS
+        // column sums of h for the context, taken from the values on their way to LDS (before their rounding to fp16): per lane over its five time
+        // tiles, split at the segment boundary by 0 / 1 weights, then over the 16 frames of a tile with DPP row sums; frames >= T2 do not count
+        float m0[5], m1[5];
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) {
+            const int t = (th_t * 5 + ni) * 16 + fr_t;
+            m0[ni] = t < T2 && t < a.seg_len ? 1.0f : 0.0f;
+            m1[ni] = t < T2 && t >= a.seg_len ? 1.0f : 0.0f;
+        }
+#endif
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int co = (cw_t * 2 + mi) * 16 + 4 * fg_t;
             const float4v sc = e_bn2s[mi], sh = e_bn2t[mi];
+#if MV_CB_REGSUMS
+            float4v cs0 = float4v{0.0f, 0.0f, 0.0f, 0.0f}, cs1 = cs0;
+#endif
 #pragma unroll
             for (int ni = 0; ni < 5; ++ni) {
                 const int t = (th_t * 5 + ni) * 16 + fr_t;
                 half4v hv;
+                float4v hf;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+                for (int r = 0; r < 4; ++r) {
+                    hf[r] = fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+                    hv[r] = (half_t)hf[r];
+                }
                 if (t < T2) *reinterpret_cast<half4v*>(hbuf + h_off(t, co >> 3) + (co & 7) * 2) = hv;
+#if MV_CB_REGSUMS
+                cs0 += hf * m0[ni];   // (the fp32 value: the reference's context is the mean of an unrounded h)
+                cs1 += hf * m1[ni];
+#endif
             }
+#if MV_CB_REGSUMS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cs0[r] = row16_sum(cs0[r]);
+                cs1[r] = row16_sum(cs1[r]);
+            }
+            if (fr_t == 0) {
+                *reinterpret_cast<float4v*>(hsum + (th_t * CB_MAX_SEG + 0) * CB_BN + co) = cs0;
+                *reinterpret_cast<float4v*>(hsum + (th_t * CB_MAX_SEG + 1) * CB_BN + co) = cs1;
+            }
+#endif
         }
         __syncthreads();
 
         // ---- phase B: context gate per 100-frame segment ----
         {
+#if MV_CB_REGSUMS
+            const float inv_t = 1.0f / (float)T2;
+            const int len0 = a.seg_len < T2 ? a.seg_len : T2, len1 = T2 - len0;
+            const float inv_len[CB_MAX_SEG] = {1.0f / (float)len0, len1 > 0 ? 1.0f / (float)len1 : 0.0f};
+            const float has_seg[CB_MAX_SEG] = {1.0f, len1 > 0 ? 1.0f : 0.0f};   // a segment without frames has context 0 (no rows of y read its gate)
+#else
             // partial sums: thread = (8-channel chunk, 32 row phases); scratch [32][2][128] floats in the idle W ring
             float* part = reinterpret_cast<float*>(ws);
             const int cg = tid_t & 15, rp = tid_t >> 4;
@@ -472,15 +554,27 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 ctx[sg * CB_BN + c] = len > 0 ? (v + other) / (float)T2 + v / (float)len : 0.0f;
             }
             __syncthreads();
+#endif
             {   // g1 = ReLU(Wa ctx + ba): 8 threads per output row, both segments
                 const int j = tid_t >> 3, part8 = tid_t & 7;
 #pragma unroll
                 for (int sg = 0; sg < CB_MAX_SEG; ++sg) {
-                    const float* cx = ctx + sg * CB_BN + part8 * 16;
                     float v = 0.0f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float4v c4 = *reinterpret_cast<const float4v*>(cx + 4 * u);
+#if MV_CB_REGSUMS
+                        // ctx = mean over the utterance + mean over the segment, from the four partial sums of a channel
+                        const int c = part8 * 16 + 4 * u;
+                        const float4v own = *reinterpret_cast<const float4v*>(hsum + (0 * CB_MAX_SEG + sg) * CB_BN + c) +
+                                            *reinterpret_cast<const float4v*>(hsum + (1 * CB_MAX_SEG + sg) * CB_BN + c);
+                        const float4v oth = *reinterpret_cast<const float4v*>(hsum + (0 * CB_MAX_SEG + 1 - sg) * CB_BN + c) +
+                                            *reinterpret_cast<const float4v*>(hsum + (1 * CB_MAX_SEG + 1 - sg) * CB_BN + c);
+                        float4v c4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c4[e] = has_seg[sg] * fmaf(own[e] + oth[e], inv_t, own[e] * inv_len[sg]);
+#else
+                        const float4v c4 = *reinterpret_cast<const float4v*>(ctx + sg * CB_BN + part8 * 16 + 4 * u);
+#endif
                         v = fmaf(e_wa[u][0], c4[0], v);
                         v = fmaf(e_wa[u][1], c4[1], v);
                         v = fmaf(e_wa[u][2], c4[2], v);
@@ -512,16 +606,29 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // layer's first two W1 stages.  (These fifteen vector-memory instructions double the k = 3 phase that follows -- 10.4 k ticks against
         // 4.8 k in cam_dense_layer_kernel, r08b timeline: every workgroup of the launch is in the same phase at the same moment with its x
         // prefetch in flight -- but requested behind that phase instead they lengthen the layer entry by more, r08c.)
+        // the next layer's BN1 tables (requested at the start of this tail, read by its transform() behind the entry barrier) go to LDS HERE: behind
+        // the k = 3 phase the compiler's wait for them was an s_waitcnt vmcnt(0) that drained this layer's y stores and the twelve k = 3 weight
+        // requests at the end of every layer (3.3 k ticks in the r08b timeline); here only the x requests of the tail's start are older
+        store_tables((l + 1) & 1, Ln.cin, nts, ntt);
         if (more) {
             load_ctx_params(Ln);
+#if !MV_CB_EARLY_W
             const int nstn = Ln.cin_pad / 64;
             issue_w(0, nstn, Ln.w1, Ln.cin_pad);
             issue_w(1, nstn, Ln.w1, Ln.cin_pad);
+#endif
         }
 
         // ---- phase C: y = conv_k3(h) * gate -> channels [cin, cin + 32) of x; taps outside [0, T2) are the conv's zero padding ----
         {
-            const int ct = wave_t & 1, tg = MV_UNIFORM(wave_t >> 1);  // channel tile, time tiles tg, tg + 4, tg + 8
+            // channel tile ct, time tiles tg, tg + 4, tg + 8.  Waves of time groups 2 / 3 own two tiles: their third accumulator repeats tile 9 and is never
+            // stored -- twelve spare MFMAs instead of a uniform branch per (tap, K step, tile): with the branches the compiler gave every one of the 36 MFMAs
+            // its own block (ds_read, s_waitcnt lgkmcnt(0), MFMA, copies of the accumulators: ~250 cycles each, the 10.4 k ticks of the r08b timeline)
+            const int ct = wave_t & 1, tg = wave_t >> 1;
+            const bool third = tg + 8 < CB_TT;
+            int trow[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) trow[j] = (j < 2 || third ? tg + 4 * j : CB_TT - 1) * 16 + fr_t;
             float4v yc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
@@ -533,36 +640,35 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                     const half8v af = e_wl[tap][kk];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const int tile = tg + 4 * j;
-                        if (tile < CB_TT) {  // uniform per wave
-                            const int r = tile * 16 + fr_t + (tap - 1) * a.dil;
-                            const bool in = r >= 0 && r < CB_ROWS;   // rows T2 .. 159 of h are zero
-                            const int rc = r < 0 ? 0 : (r < CB_ROWS ? r : CB_ROWS - 1);
-                            half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(rc, kk * 4 + fg_t));
-                            bfr = in ? bfr : zero8;
-                            yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
-                        }
+                        const int r = trow[j] + (tap - 1) * a.dil;
+                        const bool in = r >= 0 && r < CB_ROWS;   // rows T2 .. 159 of h are zero
+                        const int rc = r < 0 ? 0 : (r < CB_ROWS ? r : CB_ROWS - 1);
+                        half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(rc, kk * 4 + fg_t));
+                        bfr = in ? bfr : zero8;
+                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // (a tap's twelve fragments in flight, not all 36: the kernel has no registers for them)
             }
             const int co = ct * 16 + 4 * fg_t;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int tile = tg + 4 * j;
-                const int t = tile * 16 + fr_t;
-                if (tile < CB_TT && t < T2) {
-                    const float* gt = gate + (t / a.seg_len) * CB_G + co;
+                const int t = trow[j];
+                if ((j < 2 || third) && t < T2) {
+                    const float* gt = gate + (t >= a.seg_len ? CB_G : 0) + co;   // (two segments at most)
                     half4v hv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(yc[j][r] * gt[r], -65504.0f, 65504.0f);
+#if MV_CB_LAZY_STORES
+                    global_store8_untracked(xb + (int64_t)t * a.ldx + L.cin + co, hv);   // (beside tracked loads a tracked store costs an s_waitcnt vmcnt(0) in the stage loop)
+#else
                     *reinterpret_cast<half4v*>(xb + (int64_t)t * a.ldx + L.cin + co) = hv;
+#endif
                 }
+                if ((j < 2 || third) && trow[j] - fr_t < T2) MV_VM_LOADS(1);   // (a store the wave issued: the layer entry counts it)
             }
         }
-        if (more) {
-            load_wl(Ln);                       // the k = 3 weights of this layer are consumed
-            store_tables((l + 1) & 1, Ln.cin, nts, ntt);  // read by transform() of the next layer, behind its entry barrier
-        }
+        if (more) load_wl(Ln);                 // the k = 3 weights of this layer are consumed
     }
 }
 

@@ -345,7 +345,13 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
 
     // ---- phase C: y = conv_k3(h) * gate -> channels [cin, cin + 32) of x ----
     {
-        const int ct = wave & 1, tg = wave >> 1;  // channel tile, time tiles tg, tg + 4, tg + 8
+        // channel tile ct, time tiles tg, tg + 4, tg + 8; waves of time groups 2 / 3 own two tiles: their third accumulator repeats tile 9 and is never
+        // stored (twelve spare MFMAs instead of a uniform branch -- and a drained LDS queue -- per K step, camblock.hip)
+        const int ct = wave & 1, tg = wave >> 1;
+        const bool third = tg + 8 < CD_TT;
+        int trow[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) trow[j] = (j < 2 || third ? tg + 4 * j : CD_TT - 1) * 16 + fr;
         float4v yc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
@@ -356,21 +362,17 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_layer_kernel(CamDenseArg
                 const half8v af = e_wl[tap][kk];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const int tile = tg + 4 * j;
-                    if (tile < CD_TT) {  // uniform per wave
-                        const int row = tile * 16 + fr + (tap - 1) * a.dil + CD_PAD;
-                        const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
-                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
-                    }
+                    const int row = trow[j] + (tap - 1) * a.dil + CD_PAD;
+                    const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
+                    yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
                 }
             }
         }
         const int co = ct * 16 + 4 * fg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int tile = tg + 4 * j;
-            const int t = tile * 16 + fr;
-            if (tile < CD_TT && t < T2) {
+            const int t = trow[j];
+            if ((j < 2 || third) && t < T2) {
                 const float* gt = gate + (t / a.seg_len) * CD_G + co;
                 half4v hv;
 #pragma unroll
@@ -773,7 +775,13 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_long_conv_kernel(CamLong
     __syncthreads();
     {
         half_t* xb = a.x + ((int64_t)b * T2 + r0) * a.ldx;
+        // channel tile ct, time tiles tg, tg + 4, tg + 8; waves of time groups 2 / 3 own two tiles: their third accumulator repeats tile 9 and is never
+        // stored (twelve spare MFMAs instead of a uniform branch -- and a drained LDS queue -- per K step, camblock.hip)
         const int ct = wave & 1, tg = wave >> 1;
+        const bool third = tg + 8 < CD_TT;
+        int trow[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) trow[j] = (j < 2 || third ? tg + 4 * j : CD_TT - 1) * 16 + fr;
         float4v yc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
@@ -784,21 +792,17 @@ __global__ __launch_bounds__(CD_THREADS) void cam_dense_long_conv_kernel(CamLong
                 const half8v af = e_wl[tap][kk];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const int tile = tg + 4 * j;
-                    if (tile < CD_TT) {  // uniform per wave
-                        const int row = tile * 16 + fr + (tap - 1) * a.dil + CD_PAD;
-                        const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
-                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
-                    }
+                    const int row = trow[j] + (tap - 1) * a.dil + CD_PAD;
+                    const half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(row, kk * 4 + fg));
+                    yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
                 }
             }
         }
         const int co = ct * 16 + 4 * fg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int tile = tg + 4 * j;
-            const int t = tile * 16 + fr;
-            if (tile < CD_TT && t < Tn) {
+            const int t = trow[j];
+            if ((j < 2 || third) && t < Tn) {
                 const float* gt = gate + ((r0 + t) / a.seg_len - first_seg) * CD_G + co;
                 half4v hv;
 #pragma unroll
