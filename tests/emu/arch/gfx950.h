@@ -72,6 +72,17 @@ inline float dpp_mov(float old, float src) {
 }
 template <int CTRL>
 inline float dpp_mov_all(float src) { return dpp_mov<CTRL>(src, src); }
+inline void row16_sum8(float4v& a, float4v& b) {   // (the device form is eight interleaved chains of v_add_f32_dpp: the same additions in the same order)
+    for (int r = 0; r < 4; ++r)
+        for (int which = 0; which < 2; ++which) {
+            float v = which ? b[r] : a[r];
+            v += dpp_mov<0xB1>(0.0f, v);
+            v += dpp_mov<0x4E>(0.0f, v);
+            v += dpp_mov<0x141>(0.0f, v);
+            v += dpp_mov<0x140>(0.0f, v);
+            if (which) b[r] = v; else a[r] = v;
+        }
+}
 inline void row_swap_odd_even(unsigned& x, unsigned& y) {
     const int lane = emu::flat_tid() & 63;
     const bool odd = (lane >> 4) & 1;

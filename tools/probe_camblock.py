@@ -2,8 +2,10 @@
 of workgroup 100 at the phase boundaries of every layer.  usage: python tools/probe_camblock.py (build) | python tools/probe_camblock.py run"""
 import ctypes, glob, os, shutil, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TID = int(os.environ.get('MV_PROBE_TID', '0'))   # the traced thread of workgroup 100 (its wave's view): 0 = wave 0, 448 = wave 7
+LIBNAME = f'libcamblk_trace_t{TID}.so'
 PKG = os.path.join(REPO, 'voiceprintrecognition-pytorch_amd')
-EV = ['layer entry', 'entry wait + barrier passed', 'x(2) requested, stage 0 transformed', 'stage loop done', 'h written', 'context done', 'k=3 conv + stores issued', 'end of layer']
+EV = ['layer entry', 'entry wait passed', 'entry barrier passed', 'x(2) requested, stage 0 transformed', 'stage loop done', 'h written', 'context done', 'k=3 MFMAs done', 'stores + next k=3 weights requested']
 
 
 def build():
@@ -25,20 +27,21 @@ def build():
         idx = s.index(marker)
         pos = idx if before else s.index('\n', idx) + 1
         s = s[:pos] + f'        CB_T({ev});\n' + s[pos:]
-    s = s.replace('namespace mv {\n\nconstexpr int CB_THREADS', 'namespace mv {\n__device__ unsigned long long g_cb_trace[3 * 24 * 8];\n__device__ int g_cb_blk;\n'
-                  '#define CB_T(ev) do { if (blockIdx.x == 100 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); '
-                  'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_cb_trace[(a.blk * 24 + l) * 8 + ev] = t_; } } while (0)\nconstexpr int CB_THREADS', 1)
+    assert s.count('constexpr int CB_THREADS = 512;') == 1
+    s = s.replace('constexpr int CB_THREADS', '__device__ unsigned long long g_cb_trace[3 * 24 * 16];\n__device__ int g_cb_blk;\n'
+                  '#define CB_T(ev) do { if (blockIdx.x == 100 && threadIdx.x == %d) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); '
+                  'asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_cb_trace[(a.blk * 24 + l) * 16 + ev] = t_; } } while (0)\nconstexpr int CB_THREADS' % TID, 1)
     s = s.replace('    int nlayers, T2, dil, seg_len;\n};', '    int nlayers, T2, dil, seg_len, blk;\n};', 1)
     s = s.replace('    a.seg_len = seg_len;\n', '    a.seg_len = seg_len;\n    static int blk_ = 0; a.blk = blk_++ % 3;\n', 1)
     ins('        const float* lbn_t = lbn_s + CB_MAX_CIN;', 0)
-    ins('        __syncthreads();   // every wave\'s stores are in L2', 1)
-    ins('        float4v acc[2][5];', 2, before=True)
-    ins('        wait_vm<0>();   // only padding transfers are left', 3, before=True)
-    ins('        // ---- phase B: context gate per 100-frame segment ----', 4, before=True)
-    ins('        // this layer\'s context parameters are consumed: the next layer\'s take their registers now; the W ring is free again', 5, before=True)
-    ins('            load_wl(Ln);                       // the k = 3 weights of this layer are consumed', 6, before=True)
-    s = s.replace('            store_tables((l + 1) & 1, Ln.cin, nts, ntt);  // read by transform() of the next layer, behind its entry barrier\n        }\n',
-                  '            store_tables((l + 1) & 1, Ln.cin, nts, ntt);  // read by transform() of the next layer, behind its entry barrier\n        }\n        CB_T(7);\n', 1)
+    ins('        __syncthreads();   // every wave\'s stores are in L2', 1, before=True)
+    ins('        __syncthreads();   // every wave\'s stores are in L2', 2)
+    ins('        float4v acc[2][5];', 3, before=True)
+    ins('        wait_vm<0>();   // only padding transfers are left', 4, before=True)
+    ins('        // ---- phase B: context gate per 100-frame segment ----', 5, before=True)
+    ins('        // The next layer\'s BN1 tables (requested at the start of this tail, read by its transform() behind the entry barrier) go to LDS HERE', 6, before=True)
+    ins('            const int co = ct * 16 + 4 * fg_t;', 7, before=True)
+    ins('            load_wl(Ln);                       // the k = 3 weights of this layer are consumed (twelve requests)', 8)
     s = s.replace('}  // namespace mv', 'extern "C" int mv_camblk_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cb_trace), sizeof(g_cb_trace)); }\n}  // namespace mv', 1)
     # CB_T(6) sits inside `if (more)`: also stamp it for the last layer
     open(p, 'w').write(s)
@@ -46,7 +49,7 @@ def build():
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-inline-asm', '-DNDEBUG', '-I', d, '-I',
                            os.path.join(PKG, 'csrc'), '-x', 'hip', '-c', p, '-o', obj])
     objs = [o for o in glob.glob(os.path.join(PKG, 'build', '*.o')) if not o.endswith('/camblock.hip.o')]
-    out = os.path.join(REPO, 'tools', 'probe', 'libcamblk_trace.so')
+    out = os.path.join(REPO, 'tools', 'probe', LIBNAME)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs + [obj])
     print('built', out)
 
@@ -56,7 +59,7 @@ def run():
     import numpy as np
     import torch
     from mvector import _hip
-    _hip._lib = _hip.bind(ctypes.CDLL(os.path.join(REPO, 'tools', 'probe', 'libcamblk_trace.so')))
+    _hip._lib = _hip.bind(ctypes.CDLL(os.path.join(REPO, 'tools', 'probe', LIBNAME)))
     import bench
     dev = torch.device('cuda', 0)
     featurizer, model, _ = bench.build('campp', dev)
@@ -66,16 +69,16 @@ def run():
         for _ in range(3):
             model(featurizer(wav))
     torch.cuda.synchronize()
-    buf = np.zeros(3 * 24 * 8, dtype=np.uint64)
-    lib = ctypes.CDLL(os.path.join(REPO, 'tools', 'probe', 'libcamblk_trace.so'))
+    buf = np.zeros(3 * 24 * 16, dtype=np.uint64)
+    lib = ctypes.CDLL(os.path.join(REPO, 'tools', 'probe', LIBNAME))
     assert lib.mv_camblk_trace_read(ctypes.c_void_p(buf.ctypes.data)) == 0
-    tr = buf.reshape(3, 24, 8).astype(np.int64)
+    tr = buf.reshape(3, 24, 16).astype(np.int64)[:, :, :9]
     print('cam_dense_block_kernel timeline, workgroup 100 wave 0, s_memtime ticks between events:')
     print('events: ' + ' | '.join(f'{i}={n}' for i, n in enumerate(EV)))
     for blk, n in enumerate((12, 24, 16)):
-        tot = np.zeros(7)
+        tot = np.zeros(8)
         for l in range(n - 1):
-            d = np.diff(tr[blk, l, :8])
+            d = np.diff(tr[blk, l, :9])
             tot += d
             if l in (0, 1, n // 2, n - 2):
                 print(f'  block {blk} layer {l:2d}: ' + ' '.join(f'{int(v):6d}' for v in d) + f'   layer {int(tr[blk, l + 1, 0] - tr[blk, l, 0]):6d}')

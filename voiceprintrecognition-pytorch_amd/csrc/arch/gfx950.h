@@ -67,6 +67,22 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
                                                                  0xf, 0xf, false));
 }
+// sums over the 16 lanes of a DPP row for EIGHT values at once, each result in every lane: four v_add_f32_dpp per value, interleaved so that no
+// instruction reads a register the one in front of it wrote (a DPP read needs two wait states behind a VALU write).  Written out because the SLP
+// vectoriser pairs the additions of neighbouring values into v_pk_add_f32, which has no DPP form: the reduction then costs a v_mov_b32_dpp AND half
+// a v_pk_add_f32 per step.  Bit-identical to eight row16_sum() calls (the same additions in the same order).
+#define MV_DPP_STEP8(CTRL)                                                                                                            \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row16_sum8(float4v& a, float4v& b) {
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    asm volatile("s_nop 1\n\t" MV_DPP_STEP8("quad_perm:[1,0,3,2]") MV_DPP_STEP8("quad_perm:[2,3,0,1]") MV_DPP_STEP8("row_half_mirror") MV_DPP_STEP8("row_mirror")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    a = float4v{a0, a1, a2, a3};
+    b = float4v{b0, b1, b2, b3};
+}
 // for patterns in which every lane has a source lane (mirror, rotate, quad_perm): no `old` operand to initialise
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov_all(float src) {

@@ -7,13 +7,14 @@
 // tail:
 //   * after the stage loop of layer l the rings are idle: x stages 0 and 1 (channels 0..127: never this block's new channels) of layer
 //     l + 1 are requested into ring slots 0 / 1 at once, its BN1 tables into registers;
-//   * h lives in x slots 2 and 3 without halo rows (the k = 3 conv masks its out-of-range taps), the phase B scratch in the idle W ring
-//     (the next layer's W1 stages 0 and 1 follow the context phase: they are L2 hits, the x stages are the slow ones);
-//   * the context parameters of layer l + 1 are requested when layer l's context phase has consumed its own (same registers), the
-//     k = 3 weights after layer l's k = 3 conv;
-//   * layer entry: s_waitcnt vmcnt(0) (this wave's y stores are in L2: another wave's transfer may read them) + barrier, then x stage 2
-//     -- the request pattern of the stage loop (stage s requests x(s + 3) and W1(s + 2), five transfers per wave and stage, counted
-//     waits) is the one of cam_dense_layer_kernel from there on.
+//   * h lives in x slots 2 and 3 without halo rows (the k = 3 conv masks its out-of-range taps); the context's column sums leave the h
+//     epilogue's registers (rows of v_add_f32_dpp, [2 time halves][2 segments][128] partial sums: no scratch, no pass over h);
+//   * the next layer's BN1 tables go to LDS, its W1 stages 0 / 1 and context parameters are requested when layer l's context phase has
+//     consumed its own (same registers), the k = 3 weights after layer l's k = 3 conv;
+//   * layer entry (round 5): a COUNTED wait that leaves the y stores and the k = 3 weight requests in flight + barrier, then x stage 2 --
+//     the stores only have to be in L2 when the last stage (the one with the new channels) is requested, and the stage loop's own
+//     counted waits see to that; the request pattern of the stage loop (stage s requests x(s + 3) and W1(s + 2), five transfers per
+//     wave and stage) is the one of cam_dense_layer_kernel from there on.
 // The first form of "all layers in one launch" (r05t: the layer loop around the unchanged body, vmcnt(0) + barrier between layers)
 // measured 3 % slower than separate launches -- it removed the launch boundary and kept every wait.
 // Measured (profiles/r08a, r08b timeline): 23.1 us per layer against 24.4 (CAM++ 2.28 -> 2.25 ms per step).  The layer entry costs 1.4 us
@@ -36,6 +37,20 @@
 // instructions per cell, the same bits: kept) no change.  What is left of a stage (0.6 of 1.17 us) is the barrier, the five transfer requests
 // and the fourteen fragment reads of a wave.  W1 for free (no W1 transfers, no W1 fragment reads: the upper bound of the Res2Net chain's
 // "weight fragments straight into registers" form, r10q): -4.4 % of the CAM++ step -- not worth the ~48 registers the kernel does not have.
+// Round 5 (r14k-r14m, found by READING THE ISA -- tools/isa_audit.py -- after three rounds of timelines): CAM++ 136.0 k -> 153.1 k utt/s, one
+// utterance 1326 -> 1166 us, the tail + entry of a layer 28 k -> 19 k ticks.  (1) the k = 3 phase's `if (tile < 10)` around each MFMA (uniform per
+// wave, on a value the source had made opaque) had become 36 blocks of ds_read -> s_waitcnt lgkmcnt(0) -> MFMA -> accumulator copies, ~250 cycles
+// each = the 10.4 k ticks the r08b timeline blamed on memory traffic: straight-line code with a spare tile for the waves that own two, fragment
+// reads in six pipelined groups (4.3 k -> 3.0 k); (2) pointers read out of the layer descriptors in LDS carry no address space, so every
+// parameter load was a FLAT load, which counts on lgkmcnt as well: each LDS wait behind one waited for L2 (MV_GLOBAL_PTR); (3) BN1 tables loaded
+// under one `if (more)` and stored under another: the wait-count insertion sees the path on which they are never waited for, carried their
+// registers as pending around the layer loop and put s_waitcnt vmcnt(0) in front of a fragment read IN EVERY STAGE once tracked loads were allowed
+// to stay in flight across the entry (unconditional load + store); their store in front of the k = 3 phase instead of behind it (it was an
+// s_waitcnt vmcnt(0) = a drain of the stores and weight requests at the end of every layer, 3.3 k ticks); (4) the counted entry wait, with the
+// y stores as inline assembly (a tracked store beside tracked loads makes the compiler treat the counter as out of order: vmcnt(0) everywhere);
+// (5) row sums as explicit v_add_f32_dpp chains (the SLP vectoriser had paired the additions into v_pk_add_f32, which has no DPP form).
+// Measured and NOT kept: the next layer's W1 stages requested at the start of the tail (-0.3 %), its context parameters behind the k = 3 phase
+// (MV_CB_LATE_PARAMS 1: -2 %, 23 requests in one burst); the LDS form of the column sums (equal; removed).
 #include "kernels.h"
 
 namespace mv {
@@ -43,16 +58,13 @@ namespace mv {
 #ifndef MV_CB_INTERLEAVE
 #define MV_CB_INTERLEAVE 1  // 0: the stage as three phases (requests, MFMAs, transform), the form of rounds 2-3 (A/B arm)
 #endif
-#ifndef MV_CB_REGSUMS
-#define MV_CB_REGSUMS 1     // 1 (round 5): the context's column sums leave the h epilogue's registers (DPP row sums, [2 time halves][2 segments][128] partials);
-#endif                      // 0: h is read back from LDS by 32 row phases into a 32 KB scratch and summed by 256 threads (two more barriers; A/B arm)
-#ifndef MV_CB_EARLY_W
-#define MV_CB_EARLY_W 0     // 1: the next layer's W1 stages 0 / 1 are requested with its x stages at the start of the tail (the W ring is no scratch with MV_CB_REGSUMS)
-#endif
 #ifndef MV_CB_LAZY_STORES
 #define MV_CB_LAZY_STORES 1 // 1 (round 5): the layer entry leaves the previous layer's y stores and k = 3 weight requests in flight (counted wait); 0: s_waitcnt vmcnt(0)
 #endif
-static_assert(!MV_CB_EARLY_W || MV_CB_REGSUMS, "the early W1 requests need the W ring idle through the context phase");
+#ifndef MV_CB_LATE_PARAMS
+#define MV_CB_LATE_PARAMS 0 // 1: the next layer's context parameters are requested BEHIND the k = 3 phase and stay in flight across the layer entry like the k = 3
+#endif                      // weights (A/B arm, r14m: 149.8 k against 153.1 k utt/s -- 23 requests in one burst cost more than the 38 registers give the k = 3 phase)
+static_assert(!MV_CB_LATE_PARAMS || MV_CB_LAZY_STORES, "late context parameters rely on the counted wait at the layer entry");
 constexpr int CB_THREADS = 512;
 constexpr int CB_TT = 10;                           // time tiles of 16 frames: T2 <= 160
 constexpr int CB_ROWS = CB_TT * 16;
@@ -74,7 +86,6 @@ constexpr int CB_MAX_LAYERS = 24;
 constexpr size_t CB_DESC_OFF = CB_F_OFF + CB_F_END * sizeof(float) + 1024;   // behind the KiB that swallows the padding transfers
 constexpr size_t CB_LDS_BYTES = CB_DESC_OFF + CB_MAX_LAYERS * sizeof(MvCamLayerDesc);
 static_assert(CB_LDS_BYTES <= 160 * 1024, "cam block kernel: LDS");
-static_assert(32 * CB_MAX_SEG * CB_BN * 4 <= CB_RING * CB_WS_BYTES, "phase B scratch lives in the idle W ring");
 
 __device__ __attribute__((aligned(256))) const unsigned char g_cb_zero_page[256] = {0};
 
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         e_wb = *MV_GLOBAL_PTR(float4v, L.wb + (tid >> 4) * 64 + (tid & 15) * 4);
         e_ba = *MV_GLOBAL_PTR(float, L.ba + (tid >> 3));
         e_bb = *MV_GLOBAL_PTR(float, L.bb + (tid >> 4));
+        MV_VM_LOADS(11);
     };
     auto load_wl = [&](const MvCamLayerDesc& L) {
         const half_t* wrow = L.wl + (int64_t)((wave & 1) * 16 + fr) * 3 * CB_BN + 8 * fg;
@@ -254,20 +266,22 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // the entry needs -- x(0), x(1), W1(0), W1(1), the context parameters -- is older.  The stores have to be in L2 before ANY wave requests the x
         // stage that holds the previous layer's 32 channels: that is the LAST stage, requested at stage nst - 4 behind that stage's counted wait (which
         // covers everything older than the last five transfers) and barrier.  So with more than four stages the entry waits for all but those
-        // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.
+        // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.  (With MV_CB_LATE_PARAMS the next layer's context
+        // parameters sit between the stores and the k = 3 weights: needed behind the stage loop, complete at stage 1's counted wait.)
         const bool lazy = MV_CB_LAZY_STORES && l > 0 && nst > 4;   // uniform
         if (lazy) {
             int n_st = 0;   // y stores this wave issued: its time tiles with a frame below T2 (phase C)
 #pragma unroll
             for (int j = 0; j < 3; ++j) n_st += ((wave_u >> 1) + 4 * j < CB_TT && ((wave_u >> 1) + 4 * j) * 16 < T2) ? 1 : 0;
+            constexpr int NP = 12 + (MV_CB_LATE_PARAMS ? 11 : 0);   // parameter requests behind the stores
             if (n_st == 3) {   // (waits the compiler sees: it has the k = 3 weight and context parameter loads on its scoreboard)
-                wait_vm_seen<15>();
+                wait_vm_seen<NP + 3>();
             } else if (n_st == 2) {
-                wait_vm_seen<14>();
+                wait_vm_seen<NP + 2>();
             } else if (n_st == 1) {
-                wait_vm_seen<13>();
+                wait_vm_seen<NP + 1>();
             } else {
-                wait_vm_seen<12>();
+                wait_vm_seen<NP>();
             }
         } else {
             wait_vm_seen<0>();
@@ -450,11 +464,7 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             const int lrow_t = lane_t >> 3, wave_ut = MV_UNIFORM(wave_t);   // (row addresses from the per-layer thread id: hoisted out of the layer loop they were spilled,
             issue_x_from(0, nstn, wave_ut, lrow_t, (lane_t & 7) ^ lrow_t);   //  and the reload's s_waitcnt vmcnt(0) sat behind the first of these requests)
             issue_x_from(1, nstn, wave_ut, lrow_t, (lane_t & 7) ^ lrow_t);
-#if MV_CB_EARLY_W
-            issue_w(0, nstn, Ln.w1, Ln.cin_pad);
-            issue_w(1, nstn, Ln.w1, Ln.cin_pad);
-#endif
-        }   // (MV_CB_REGSUMS 0: its W1 stages follow the context phase: the idle W ring is that phase's scratch)
+        }
         // UNCONDITIONAL (the last layer fetches its own tables again, into the idle buffer): loaded under `if (more)` and stored under a second
         // `if (more)`, the compiler's wait-count insertion sees a path on which the four loads are never waited for, carries their registers as
         // pending around the layer loop, and protects the fragment read that reuses one of them with an s_waitcnt vmcnt(0) in every stage
@@ -462,7 +472,6 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // epilogue A: BN2 + ReLU -> h (fp16, swizzled 16-byte chunks: chunk ^= row & 15); frames >= T2 are zero
         for (int i = T2 * CB_BN * 2 + tid_t * 16; i < CB_ROWS * CB_BN * 2; i += CB_THREADS * 16)
             *reinterpret_cast<float4v*>(hbuf + i) = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-#if MV_CB_REGSUMS
         // column sums of h for the context, taken from the values on their way to LDS (before their rounding to fp16): per lane over its five time
         // tiles, split at the segment boundary by 0 / 1 weights, then over the 16 frames of a tile with DPP row sums; frames >= T2 do not count
         float m0[5], m1[5];
@@ -472,14 +481,11 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             m0[ni] = t < T2 && t < a.seg_len ? 1.0f : 0.0f;
             m1[ni] = t < T2 && t >= a.seg_len ? 1.0f : 0.0f;
         }
-#endif
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int co = (cw_t * 2 + mi) * 16 + 4 * fg_t;
             const float4v sc = e_bn2s[mi], sh = e_bn2t[mi];
-#if MV_CB_REGSUMS
             float4v cs0 = float4v{0.0f, 0.0f, 0.0f, 0.0f}, cs1 = cs0;
-#endif
 #pragma unroll
             for (int ni = 0; ni < 5; ++ni) {
                 const int t = (th_t * 5 + ni) * 16 + fr_t;
@@ -487,74 +493,27 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 float4v hf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hf[r] = fmed3(fmaxf(acc[mi][ni][r] * sc[r] + sh[r], 0.0f), 0.0f, 65504.0f);
+                    hf[r] = fmed3(acc[mi][ni][r] * sc[r] + sh[r], 0.0f, 65504.0f);   // ReLU and the fp16 saturation in one clamp
                     hv[r] = (half_t)hf[r];
                 }
                 if (t < T2) *reinterpret_cast<half4v*>(hbuf + h_off(t, co >> 3) + (co & 7) * 2) = hv;
-#if MV_CB_REGSUMS
                 cs0 += hf * m0[ni];   // (the fp32 value: the reference's context is the mean of an unrounded h)
                 cs1 += hf * m1[ni];
-#endif
             }
-#if MV_CB_REGSUMS
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                cs0[r] = row16_sum(cs0[r]);
-                cs1[r] = row16_sum(cs1[r]);
-            }
+            row16_sum8(cs0, cs1);
             if (fr_t == 0) {
                 *reinterpret_cast<float4v*>(hsum + (th_t * CB_MAX_SEG + 0) * CB_BN + co) = cs0;
                 *reinterpret_cast<float4v*>(hsum + (th_t * CB_MAX_SEG + 1) * CB_BN + co) = cs1;
             }
-#endif
         }
         __syncthreads();
 
         // ---- phase B: context gate per 100-frame segment ----
         {
-#if MV_CB_REGSUMS
             const float inv_t = 1.0f / (float)T2;
             const int len0 = a.seg_len < T2 ? a.seg_len : T2, len1 = T2 - len0;
             const float inv_len[CB_MAX_SEG] = {1.0f / (float)len0, len1 > 0 ? 1.0f / (float)len1 : 0.0f};
             const float has_seg[CB_MAX_SEG] = {1.0f, len1 > 0 ? 1.0f : 0.0f};   // a segment without frames has context 0 (no rows of y read its gate)
-#else
-            // partial sums: thread = (8-channel chunk, 32 row phases); scratch [32][2][128] floats in the idle W ring
-            float* part = reinterpret_cast<float*>(ws);
-            const int cg = tid_t & 15, rp = tid_t >> 4;
-            float sum[CB_MAX_SEG][8];
-#pragma unroll
-            for (int sg = 0; sg < CB_MAX_SEG; ++sg)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum[sg][e] = 0.0f;
-            for (int t = rp; t < T2; t += 32) {
-                const half8v v = *reinterpret_cast<const half8v*>(hbuf + h_off(t, cg));
-                if (t < a.seg_len) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sum[0][e] += (float)v[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sum[1][e] += (float)v[e];
-                }
-            }
-#pragma unroll
-            for (int sg = 0; sg < CB_MAX_SEG; ++sg)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) part[(rp * CB_MAX_SEG + sg) * CB_BN + cg * 8 + e] = sum[sg][e];
-            __syncthreads();
-            if (tid_t < CB_MAX_SEG * CB_BN) {
-                const int sg = tid_t / CB_BN, c = tid_t - sg * CB_BN;
-                const float* part = reinterpret_cast<const float*>(ws);
-                float v = 0.0f, other = 0.0f;
-                for (int p = 0; p < 32; ++p) {
-                    v += part[(p * CB_MAX_SEG + sg) * CB_BN + c];
-                    other += part[(p * CB_MAX_SEG + (1 - sg)) * CB_BN + c];
-                }
-                const int t0 = sg * a.seg_len;
-                const int len = (t0 + a.seg_len < T2 ? t0 + a.seg_len : T2) - t0;
-                ctx[sg * CB_BN + c] = len > 0 ? (v + other) / (float)T2 + v / (float)len : 0.0f;
-            }
-            __syncthreads();
-#endif
             {   // g1 = ReLU(Wa ctx + ba): 8 threads per output row, both segments
                 const int j = tid_t >> 3, part8 = tid_t & 7;
 #pragma unroll
@@ -562,7 +521,6 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                     float v = 0.0f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-#if MV_CB_REGSUMS
                         // ctx = mean over the utterance + mean over the segment, from the four partial sums of a channel
                         const int c = part8 * 16 + 4 * u;
                         const float4v own = *reinterpret_cast<const float4v*>(hsum + (0 * CB_MAX_SEG + sg) * CB_BN + c) +
@@ -572,9 +530,6 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                         float4v c4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) c4[e] = has_seg[sg] * fmaf(own[e] + oth[e], inv_t, own[e] * inv_len[sg]);
-#else
-                        const float4v c4 = *reinterpret_cast<const float4v*>(ctx + sg * CB_BN + part8 * 16 + 4 * u);
-#endif
                         v = fmaf(e_wa[u][0], c4[0], v);
                         v = fmaf(e_wa[u][1], c4[1], v);
                         v = fmaf(e_wa[u][2], c4[2], v);
@@ -602,21 +557,19 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             }
             __syncthreads();
         }
-        // this layer's context parameters are consumed: the next layer's take their registers now; the W ring is free again: the next
-        // layer's first two W1 stages.  (These fifteen vector-memory instructions double the k = 3 phase that follows -- 10.4 k ticks against
-        // 4.8 k in cam_dense_layer_kernel, r08b timeline: every workgroup of the launch is in the same phase at the same moment with its x
-        // prefetch in flight -- but requested behind that phase instead they lengthen the layer entry by more, r08c.)
-        // the next layer's BN1 tables (requested at the start of this tail, read by its transform() behind the entry barrier) go to LDS HERE: behind
+        // The next layer's BN1 tables (requested at the start of this tail, read by its transform() behind the entry barrier) go to LDS HERE: behind
         // the k = 3 phase the compiler's wait for them was an s_waitcnt vmcnt(0) that drained this layer's y stores and the twelve k = 3 weight
-        // requests at the end of every layer (3.3 k ticks in the r08b timeline); here only the x requests of the tail's start are older
+        // requests at the end of every layer (3.3 k ticks in the r08b timeline); here only the x requests of the tail's start are older.
         store_tables((l + 1) & 1, Ln.cin, nts, ntt);
+        // The W ring is free again: the next layer's first two W1 stages (the layer entry waits for them).  Its context parameters take this layer's
+        // registers behind the k = 3 phase (MV_CB_LATE_PARAMS) or here.
         if (more) {
+#if !MV_CB_LATE_PARAMS
             load_ctx_params(Ln);
-#if !MV_CB_EARLY_W
+#endif
             const int nstn = Ln.cin_pad / 64;
             issue_w(0, nstn, Ln.w1, Ln.cin_pad);
             issue_w(1, nstn, Ln.w1, Ln.cin_pad);
-#endif
         }
 
         // ---- phase C: y = conv_k3(h) * gate -> channels [cin, cin + 32) of x; taps outside [0, T2) are the conv's zero padding ----
@@ -633,22 +586,36 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
 #pragma unroll
             for (int j = 0; j < 3; ++j) yc[j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
             const half8v zero8 = half8v{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+            // six groups of (tap, two K steps) x three tiles: the six fragment reads of group g + 1 are in flight under the six MFMAs of group g (left
+            // to itself the compiler reads two fragments at a time into the same eight registers: eighteen LDS round trips one behind the other)
+            half8v fq[2][6];
+            auto read_group = [&](int g, half8v (&f)[6]) {
+                const int tap = g >> 1;
 #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const half8v af = e_wl[tap][kk];
+                    for (int j = 0; j < 3; ++j) {
+                        const int r = trow[j] + (tap - 1) * a.dil;
+                        const int rc = r < 0 ? 0 : (r < CB_ROWS ? r : CB_ROWS - 1);
+                        f[h * 3 + j] = *reinterpret_cast<const half8v*>(hbuf + h_off(rc, ((g & 1) * 2 + h) * 4 + fg_t));
+                    }
+            };
+            read_group(0, fq[0]);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g + 1 < 6) read_group(g + 1, fq[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap = g >> 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int r = trow[j] + (tap - 1) * a.dil;
                         const bool in = r >= 0 && r < CB_ROWS;   // rows T2 .. 159 of h are zero
-                        const int rc = r < 0 ? 0 : (r < CB_ROWS ? r : CB_ROWS - 1);
-                        half8v bfr = *reinterpret_cast<const half8v*>(hbuf + h_off(rc, kk * 4 + fg_t));
-                        bfr = in ? bfr : zero8;
-                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr, yc[j], 0, 0, 0);
+                        const half8v bfr = in ? fq[g & 1][h * 3 + j] : zero8;
+                        yc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_wl[tap][(g & 1) * 2 + h], bfr, yc[j], 0, 0, 0);
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // (a tap's twelve fragments in flight, not all 36: the kernel has no registers for them)
+                __builtin_amdgcn_sched_barrier(0);
             }
             const int co = ct * 16 + 4 * fg_t;
 #pragma unroll
@@ -668,7 +635,12 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 if ((j < 2 || third) && trow[j] - fr_t < T2) MV_VM_LOADS(1);   // (a store the wave issued: the layer entry counts it)
             }
         }
-        if (more) load_wl(Ln);                 // the k = 3 weights of this layer are consumed
+        if (more) {
+#if MV_CB_LATE_PARAMS
+            load_ctx_params(Ln);               // (eleven requests: the layer entry counts them)
+#endif
+            load_wl(Ln);                       // the k = 3 weights of this layer are consumed (twelve requests)
+        }
     }
 }
 
