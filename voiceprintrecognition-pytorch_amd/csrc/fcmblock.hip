@@ -276,38 +276,25 @@ __global__ __launch_bounds__(512) void fcm_block_kernel(FcmBlockArgs a, int n_tt
                 c1_w1[ni] = pn;
             }
         };
-        constexpr int NPRO = SF * (G::LEAD - 1) + 3;   // rows requested (C1: made) in front of the first step
-        if constexpr (C1) {
-            // The window in front of the first row rbase: mel bins rbase - 1, rbase (a band may start inside the map).  Loads from clamped addresses,
-            // ALL of them requested before the first is used: written as `if (in range) w = split(load)` per tile and bin, the compiler put an
-            // s_waitcnt vmcnt(0) behind each of the twelve loads -- twelve HBM round trips one after the other in front of every workgroup's first
-            // step (all 256 start together), and three more for the rows of the prologue loop below (r14n).
-            const int f0 = rbase - 1 < 0 ? 0 : (rbase - 1 < a.Fin ? rbase - 1 : a.Fin - 1), f1 = rbase < 0 ? 0 : (rbase < a.Fin ? rbase : a.Fin - 1);
-            float wf0[NC1], wf1[NC1];
+        if constexpr (C1) {  // the window in front of the first row rbase: mel bins rbase - 1, rbase (a band may start inside the map)
 #pragma unroll
             for (int ni = 0; ni < NC1; ++ni) {
-                wf0[ni] = fb[c1_toff[ni] + f0];
-                wf1[ni] = fb[c1_toff[ni] + f1];
+                c1_w0[ni] = c1_w1[ni] = 0u;
+                if (!((c1_need >> ni) & 1)) continue;
+                if (rbase - 1 >= 0 && rbase - 1 < a.Fin) c1_w0[ni] = c1_split(fb[c1_toff[ni] + rbase - 1], ni);
+                if (rbase >= 0 && rbase < a.Fin) c1_w1[ni] = c1_split(fb[c1_toff[ni] + rbase], ni);
             }
-            RowReq rq[NPRO];
-            float pfp[NPRO][NC1];
-#pragma unroll
-            for (int r = 0; r < NPRO; ++r) {
-                rq[r] = next_row();
-                c1_load(rq[r], pfp[r]);
-            }
-            const bool in0 = rbase - 1 >= 0 && rbase - 1 < a.Fin, in1 = rbase >= 0 && rbase < a.Fin;   // uniform
-#pragma unroll
-            for (int ni = 0; ni < NC1; ++ni) {
-                const bool need = (c1_need >> ni) & 1;
-                c1_w0[ni] = need && in0 ? c1_split(wf0[ni], ni) : 0u;
-                c1_w1[ni] = need && in1 ? c1_split(wf1[ni], ni) : 0u;
-            }
-#pragma unroll
-            for (int r = 0; r < NPRO; ++r) c1_make(rq[r], pfp[r]);
-        } else {
+        }
 #pragma unroll 1
-            for (int r = 0; r < NPRO; ++r) issue_row();
+        for (int r = 0; r < SF * (G::LEAD - 1) + 3; ++r) {
+            if constexpr (C1) {
+                const RowReq rq = next_row();
+                float pf[NC1];
+                c1_load(rq, pf);
+                c1_make(rq, pf);
+            } else {
+                issue_row();
+            }
         }
 
         int cslot = 0;  // ring slot of the first input row of the current step
