@@ -1,6 +1,10 @@
 """Compile every csrc/*.hip to gfx950 assembly (hipcc -S, the product's flags) and report, per kernel, what tends to hide a codegen accident:
 FLAT memory instructions (a pointer that lost its address space: FLAT loads count on lgkmcnt as well, so the next LDS wait waits for L2), scratch
-(spill) instructions, VGPR / spill counts, and MFMAs that sit alone in a basic block (a uniform branch per MFMA: each one waits for its own operands).
+(spill) instructions, VGPR / spill counts, MFMAs that sit alone in a basic block (a uniform branch per MFMA: each one waits for its own operands),
+the number of s_waitcnt vmcnt(0) and how many of them stand directly in front of a load ("wait, then load": loads that go out one round trip at a
+time -- a load under one `if` and its use under another, or two load forms under complementary lane masks into the same registers).
+Round 5 finds (profiles/r14k-o): cam_dense_block_kernel (36 lone MFMAs, 54 FLAT loads, two drains per layer), conv2ds_kernel (28-41 wait-then-load),
+linear_f32_splitk_kernel (12), fcm_block_kernel<5, 2, true> (15: measured, no effect).
 usage: python tools/isa_audit.py [file.hip ...]      (writes /tmp/isa_audit/<file>.s)"""
 import glob, os, re, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +30,7 @@ for src, asm, p in procs:
         m = re.match(r'^(_Z\w+):', line)
         if m:
             kernel = m.group(1)
-            stats[kernel] = dict(flat=0, scratch=0, mfma=0, lone=0, blocks=0, in_block=0)
+            stats[kernel] = dict(flat=0, scratch=0, mfma=0, lone=0, blocks=0, in_block=0, vm0=0, wtl=0, recent=[])
             continue
         if kernel is None:
             continue
@@ -37,6 +41,12 @@ for src, asm, p in procs:
                 st['lone'] += 1
             st['in_block'] = 0
             continue
+        if t and not t.startswith((';', '.')):
+            if t.startswith(('global_load_dword', 'buffer_load_dword', 'flat_load_dword')) and any(p.startswith('s_waitcnt') and 'vmcnt(0)' in p for p in st['recent'][-4:]):
+                st['wtl'] += 1
+            if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
+                st['vm0'] += 1
+            st['recent'] = (st['recent'] + [t])[-4:]
         if t.startswith(('flat_load', 'flat_store', 'flat_atomic')):
             st['flat'] += 1
         elif t.startswith('scratch_'):
@@ -63,7 +73,7 @@ for src, asm, p in procs:
         if k not in meta:
             continue
         md = meta[k]
-        flag = ' <--' if st['flat'] or st['scratch'] or md.get('vgpr_spill_count') or st['lone'] > 2 else ''
+        flag = ' <--' if st['flat'] or st['scratch'] or md.get('vgpr_spill_count') or st['lone'] > 2 or st['wtl'] > 2 else ''
         name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().split('(')[0][:90]
         print(f"  {name:90s} vgpr {md.get('vgpr_count', 0):3d} spill v{md.get('vgpr_spill_count', 0)} s{md.get('sgpr_spill_count', 0):<3d} flat {st['flat']:3d} scratch {st['scratch']:3d} "
-              f"mfma {st['mfma']:4d} (alone in a block: {st['lone']}){flag}")
+              f"mfma {st['mfma']:4d} (alone in a block: {st['lone']}) vmcnt(0) {st['vm0']:3d} (wait-then-load: {st['wtl']}){flag}")

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int
     // K = 6144 layers of the ASP head, three trips instead of six); the guarded loop takes the remainder (and everything when the rows
     // are not 16-byte aligned).
     const int kfull = (xvec && wvec) ? (K & ~15) : 0;
-    int k0 = wave * 16;
+    int k0 = MV_UNIFORM(wave) * 16;   // (a scalar: the loops below branch on it)
     for (; k0 + (U - 1) * 16 * NW < kfull; k0 += U * 16 * NW) {
         float4v xa[U], wb[U];
 #pragma unroll
@@ -87,8 +87,16 @@ __global__ __launch_bounds__(64 * NW) void linear_f32_kernel(const float* x, int
     }
     for (; k0 < K; k0 += 16 * NW) {
         const int k = k0 + 4 * g;
-        const float4v xa = load4_guard(xrow, k, K, xvec);
-        const float4v wb = load4_guard(wrow, k, K, wvec);
+        float4v xa, wb;
+        // (the choice between the 16-byte load and the guarded one is made per WAVE: decided per lane, both forms run one after the other under
+        //  complementary masks into the same registers, and the second waits -- s_waitcnt vmcnt(0) -- for the first: two round trips per block)
+        if (xvec && wvec && k0 + 16 <= K) {
+            xa = *MV_GLOBAL_PTR(float4v, xrow + k);
+            wb = *MV_GLOBAL_PTR(float4v, wrow + k);
+        } else {
+            xa = load4_guard(xrow, k, K, false);
+            wb = load4_guard(wrow, k, K, false);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], wb[e], acc, 0, 0, 0);
         if (cosine) {
@@ -169,15 +177,31 @@ __global__ __launch_bounds__(256) void linear_f32_splitk_kernel(const float* x, 
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     float4v xa[LSK_U][2], wb[LSK_U][2];
+    // wave `wave` takes the blocks of 16 with index == wave (mod 4) of the slice: all loads of the wave in one trip.  Two COPIES of the load loop, chosen
+    // once per workgroup: with the guarded form anywhere near them (chosen per lane by `k + 3 < K`, or per wave inside the loop) the 16-byte loads ran
+    // behind an s_waitcnt vmcnt(0) each -- both forms write the same registers, under complementary masks or on paths the wait-count insertion
+    // cannot tell apart -- and the "one trip" was twelve round trips one after the other (r14o, tools/isa_audit.py).
+    if (xvec && wvec && kb + LSK_SLICE <= K) {   // uniform: every slice but a ragged last one
 #pragma unroll
-    for (int u = 0; u < LSK_U; ++u) {   // wave `wave` takes the blocks of 16 with index == wave (mod 4) of the slice: all loads of the wave in one trip
-        const int k = kb + (u * 4 + wave) * 16 + 4 * g;
-        const int kc = k < ke ? k : kb;   // blocks behind the slice's end: any valid (aligned) address, the values are zeroed below
+        for (int u = 0; u < LSK_U; ++u) {
+            const int k = kb + (u * 4 + wave) * 16 + 4 * g;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            xa[u][m] = load4_guard(xrow[m], kc, K, xvec);
-            wb[u][m] = load4_guard(wrow[m], kc, K, wvec);
-            if (k >= ke) xa[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int m = 0; m < 2; ++m) {
+                xa[u][m] = *MV_GLOBAL_PTR(float4v, xrow[m] + k);
+                wb[u][m] = *MV_GLOBAL_PTR(float4v, wrow[m] + k);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < LSK_U; ++u) {
+            const int k = kb + (u * 4 + wave) * 16 + 4 * g;
+            const int kc = k < ke ? k : kb;   // blocks behind the slice's end: any valid (aligned) address, the values are zeroed below
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                xa[u][m] = load4_guard(xrow[m], kc, K, xvec);
+                wb[u][m] = load4_guard(wrow[m], kc, K, wvec);
+                if (k >= ke) xa[u][m] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
     }
 #pragma unroll
