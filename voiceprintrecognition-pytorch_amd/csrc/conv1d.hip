@@ -961,7 +961,11 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
         } else {
             const bool ch_ok = c0 + kc * 8 < a.cin;
 #pragma unroll
-            for (int i = 0; i < NTX; ++i) dsrc[i] = (xok[i] && ch_ok) ? xrow[i] + c0 : zero;
+            for (int i = 0; i < NTX; ++i) {   // (a select between INTEGERS: as a select between pointers it became a two-entry table in scratch memory -- loaded,
+                //  with an s_waitcnt vmcnt(0), at every tap: 25 scratch instructions in the kernel, tools/isa_audit.py)
+                const uintptr_t px = reinterpret_cast<uintptr_t>(xrow[i] + c0), pz = reinterpret_cast<uintptr_t>(zero);
+                dsrc[i] = reinterpret_cast<const half_t*>((xok[i] && ch_ok) ? px : pz);
+            }
         }
         const int64_t woff = SIMPLE ? (int64_t)c0 : (int64_t)tap * a.cin_pad + c0;
 #pragma unroll
