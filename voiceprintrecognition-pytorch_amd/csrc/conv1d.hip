@@ -31,7 +31,8 @@ constexpr int CV_BK = 64;   // K elements per stage
 constexpr int CV_THREADS = 256;
 constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
 constexpr int CV_LDS_BYTES_WIDE = 2 * (CV_TC + 160) * CV_BK * 2;  // 128 x 160 tile: 72 KiB
-constexpr int CV_LDS_BYTES_SMALL = 2 * (64 + 64) * CV_BK * 2;      // 64 x 64 tile (small problems): 32 KiB
+constexpr int CV_SMALL_NS = 4;                                     // K stages of the 64 x 64 kernel's ring (three in flight)
+constexpr int CV_LDS_BYTES_SMALL = CV_SMALL_NS * (64 + 64) * CV_BK * 2;   // 64 x 64 tile (small problems): 64 KiB
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -455,7 +456,10 @@ __device__ __forceinline__ void input_stats_reduce_store(const ConvArgs& a, cons
 //              kernel is LDS-bandwidth bound (reads + DMA writes ~1200 LDS cycles vs 1024 MFMA cycles per K stage).
 // INSTATS: the fused input statistics as a compile-time variant, so that their VALU work sits in the K loop's basic block next to
 // the MFMAs (the scheduler interleaves them; behind a run-time branch they would run after the matrix pipe's 40 issues)
-template <int WC, int WN, int MI, int NI, bool INSTATS = false>
+// NS > 2 (the 64 x 64 instantiation, round 5): a ring of NS stages with NS - 1 in flight, untracked transfers, counted waits and one LDS-only barrier per
+// stage -- with one stage of prefetch behind `s_waitcnt vmcnt(0)` a stage of these small tiles (16 MFMAs per wave) costs one memory round trip: one 3 s
+// utterance's dense layers 16-48 serial round trips each (r12h: 9 convs = 149 of 459 us).  Same accumulation order: the same bits.
+template <int WC, int WN, int MI, int NI, bool INSTATS = false, int NS = 2>
 __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     constexpr int TC = WC * MI * 16, TN = WN * NI * 16, NW = WC * WN;
     constexpr int NTW = TC / 8 / NW, NTX = TN / 8 / NW;  // 1 KiB transfers per wave per stage
@@ -535,6 +539,55 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     float4v acc[MI][NI];
     conv_acc_init<MI, NI>(a, co0, wc, lane, acc);
 
+    if constexpr (NS > 2) {
+        static_assert(!INSTATS && NS <= 4, "the ring form has no fused statistics; its waits are written out for up to three stages in flight");
+        constexpr int TPS = NTX + NTW;   // transfers per wave and stage: always all of them (zero page for what is missing), so the waits can be counted
+        const unsigned smem_addr = lds_addr(smem);
+        auto issue_ring = [&](int s) {
+            const unsigned wt = smem_addr + (unsigned)((s % NS) * STAGE_BYTES);
+            const unsigned xtile = wt + TC * CV_BK * 2;
+            const int tap = s / kstages_per_tap;
+            const int c0 = (s - tap * kstages_per_tap) * CV_BK;
+            if (tap != cur_tap) {  // uniform
+                cur_tap = tap;
+#pragma unroll
+                for (int i = 0; i < NTX; ++i) {
+                    const int tin = input_time(a, rm[i].t, tap);
+                    xok[i] = rm[i].b >= 0 && tin >= 0;
+                    xrow[i] = xok[i] ? xbase + ((int64_t)rm[i].b * a.T_in + tin) * a.ldx + kc * 8 : zero;
+                }
+            }
+            const bool ch_ok = full_k || c0 + kc * 8 < a.cin;
+#pragma unroll
+            for (int i = 0; i < NTX; ++i) glds16_untracked((xok[i] && ch_ok) ? xrow[i] + c0 : zero, xtile + (unsigned)((wave * NTX + i) * 1024));
+            const int64_t woff = (int64_t)tap * a.cin_pad + c0;
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) glds16_untracked(wsrc[i] != nullptr ? wsrc[i] + woff : zero, wt + (unsigned)((wave * NTW + i) * 1024));
+        };
+        for (int s0 = 0; s0 < NS - 1 && s0 < nstages; ++s0) issue_ring(s0);
+        for (int s = 0; s < nstages; ++s) {
+            const int last = s + NS - 2 < nstages - 1 ? s + NS - 2 : nstages - 1;   // the last stage requested so far
+            const int younger = last - s;                                          // stages requested behind stage s (uniform)
+            if (younger >= 2) {
+                wait_vm<2 * TPS>();
+            } else if (younger == 1) {
+                wait_vm<TPS>();
+            } else {
+                wait_vm<0>();
+            }
+            lds_barrier();   // stage s has landed in every wave; every wave is done with stage s - 1, whose slot is requested now
+            if (s + NS - 1 < nstages) issue_ring(s + NS - 1);
+            const char* wt = smem + (s % NS) * STAGE_BYTES;
+            mma_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, acc);
+        }
+        __syncthreads();   // (nothing in flight: the last stage waited for everything) the staged epilogue reuses the ring
+        if (a.y_f16 && a.sum_dst == nullptr) {
+            conv_epilogue_staged<MI, NI, TC, TN, 64 * NW>(a, smem, n0, n_end, co0, wc, wn, lane, tid, acc);
+        } else {
+            conv_epilogue<MI, NI>(a, n0, n_end, co0, wc, wn, lane, acc);
+        }
+        return;
+    }
     issue(0, 0);
     wait_all_loads();
     __syncthreads();
@@ -1633,7 +1686,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     int smem_set_slot;
     if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
-            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 2, 2>), CV_LDS_BYTES_SMALL) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 2, 2, false, CV_SMALL_NS>), CV_LDS_BYTES_SMALL) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
@@ -1674,7 +1727,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     } else if (wide) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (small) {
-        MV_LAUNCH((conv1d_glds_kernel<2, 2, 2, 2>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_SMALL, stream, a);
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 2, 2, false, CV_SMALL_NS>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_SMALL, stream, a);
     } else if (f16 && !has_x2 && !in_aff) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 4>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES, stream, a);
     } else if (f16 && has_x2 && !in_aff) {
