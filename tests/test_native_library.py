@@ -63,3 +63,36 @@ def test_kernel_sources_have_one_architecture_and_no_emulator_branches():
         assert not bad.search(text), p
         assert 'getenv' not in text, f'{p}: the library reads no environment variable (round 5: the last test hook became MvConv1dDesc.persist_blocks_hint)'
     assert os.path.exists(os.path.join(PKG, 'csrc', 'arch', 'gfx950.h')) and os.path.exists(os.path.join(ROOT, 'tests', 'emu', 'arch', 'gfx950.h'))
+
+
+def test_counted_waits_of_the_cam_block_kernel_match_the_generated_code():
+    """cam_dense_block_kernel's layer entry waits with `s_waitcnt vmcnt(12 + y stores)`: the twelve youngest vector-memory operations of a wave must
+    be the next layer's k = 3 weight loads (camblock.hip, MV_CB_LAZY_STORES).  That number is a property of the GENERATED code, so it is asserted on
+    the gfx950 assembly hipcc produces here (no GPU needed): per layer 12 + 9 sixteen-byte parameter loads, 4 + 2 four-byte ones, 3 y stores from
+    inline assembly, no FLAT and no scratch instruction (a pointer that lost its address space, a spill) -- round 5's ISA audit as a regression test."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, PKG)
+    import build_native
+    if not (shutil.which(build_native.HIPCC) or os.path.exists(build_native.HIPCC)):
+        pytest.skip('hipcc not found')
+    src = os.path.join(PKG, 'csrc', 'camblock.hip')
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, 'camblock.s')
+        subprocess.check_call([build_native.HIPCC] + build_native.FLAGS + build_native._file_flags(src) +
+                              ['-Wno-inline-asm', '--cuda-device-only', '-S', '-x', 'hip', src, '-o', asm], stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    body = text[text.index('_ZN2mv22cam_dense_block_kernelENS_12CamBlockArgsE:'):]
+    body = body[:body.index('.Lfunc_end')]
+    lines = [l.strip() for l in body.split('\n')]
+    loop = lines[max(i for i, l in enumerate(lines) if 'Loop Header: Depth=1' in l):]   # the layer loop is the kernel's last top-level loop
+    count = lambda seq, prefix: sum(1 for l in seq if l.startswith(prefix))
+    assert count(lines, 'flat_') == 0 and count(lines, 'scratch_') == 0
+    assert count(loop, 'global_load_dwordx4') == 21, 'context parameters (9) + k = 3 weights (12) per layer'
+    assert count(loop, 'global_load_dword ') == 6, 'BN1 tables (4) + the two context biases per layer'
+    assert count(loop, 'global_store_dwordx2') == 3, 'one y store per time tile of a wave'
+    assert count(loop, 'v_mfma') == 20 + 36, 'the stage (20) and the k = 3 phase (36), each once'
+    meta = dict(re.findall(r'\.(vgpr_spill_count|sgpr_count|vgpr_count):\s+(\d+)', text[text.index('.name:           _ZN2mv22cam_dense_block_kernel'):][:1500]))
+    assert int(meta['vgpr_spill_count']) == 0
