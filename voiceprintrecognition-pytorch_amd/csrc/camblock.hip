@@ -266,7 +266,8 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // the entry needs -- x(0), x(1), W1(0), W1(1), the context parameters -- is older.  The stores have to be in L2 before ANY wave requests the x
         // stage that holds the previous layer's 32 channels: that is the LAST stage, requested at stage nst - 4 behind that stage's counted wait (which
         // covers everything older than the last five transfers) and barrier.  So with more than four stages the entry waits for all but those
-        // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.  (With MV_CB_LATE_PARAMS the next layer's context
+        // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.  (Loads and stores share vmcnt and retire in issue
+        // order on gfx9 -- the compiler relies on the same: `load; store; store; use of the load` compiles to s_waitcnt vmcnt(2).)  (With MV_CB_LATE_PARAMS the next layer's context
         // parameters sit between the stores and the k = 3 weights: needed behind the stage loop, complete at stage 1's counted wait.)
         const bool lazy = MV_CB_LAZY_STORES && l > 0 && nst > 4;   // uniform
         if (lazy) {
