@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_mfma_kernel(ConvArgs a) {
             for (int e = 0; e < 8; ++e) {
                 float v = raw_get(xr[i], e);
                 if (HAS_X2) v += raw_get(x2r[i], e);
-                if (IN_AFFINE) v = fmaxf(v * isc[e] + ish[e], 0.0f);
+                if (IN_AFFINE) v = fmaxf(__builtin_fmaf(v, isc[e], ish[e]), 0.0f);   // (ONE rounding, spelled out: the device contracts `v * s + t` anyway, the host build of the emulator does not)
                 hv[e] = to_half_sat(v);
             }
             *reinterpret_cast<half8v*>(xtile + lds_off(row, kc)) = hv;
