@@ -35,15 +35,15 @@ def build():
     rep('        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n',
         '        if (wave == 0) CS_T(0, gs, 0);\n        lds_barrier();  // stage gs has landed; every wave has left the slot the producers refill next\n        if (wave == 0) CS_T(0, gs, 1);\n')
     rep('        if (++c < nst) continue;\n', '        if (wave == 0) CS_T(0, gs, 2);\n        if (++c < nst) continue;\n')
-    rep("                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;\n                    }\n                }\n        }\n    }\n}\n",
+    rep("                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;\n                    }\n                }\n        }\n    }\n    if (track) s16_peak_commit(a.peak, pk);",
         "                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y2 + pixo[u] * a.ldy2 * 2 + coff) = w2;\n                    }\n                }\n        }\n        if (wave == 0) CS_T(0, gs, 3);\n    }\n"
-        "    if (tid == 0) g_cs_wg[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memtime();\n}\n")
+        "    if (tid == 0) g_cs_wg[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memtime();\n    if (track) s16_peak_commit(a.peak, pk);")
     rep("    const int HWo = a.Ho * a.Wo;\n\n    if (wave >= a.ncons) {", "    const int HWo = a.Ho * a.Wo;\n    if (tid == 0) g_cs_wg[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memtime();\n\n    if (wave >= a.ncons) {")
     rep('}  // namespace mv\n\nextern "C" {', 'extern "C" int mv_conv2ds_occupancy(int ks, int nbw, int threads, int lds) { int n = -1; hipError_t e;\n'
-        '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 8, 768>, threads, (size_t)lds);\n'
-        '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 8, 512>, threads, (size_t)lds);\n'
-        '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 8, 768>, threads, (size_t)lds);\n'
-        '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 8, 512>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
+        '  if (ks == 3 && nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 1, 8, 768, false>, threads, (size_t)lds);\n'
+        '  else if (ks == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<3, 2, 8, 512, false>, threads, (size_t)lds);\n'
+        '  else if (nbw == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 1, 8, 768, false>, threads, (size_t)lds);\n'
+        '  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv2ds_kernel<1, 2, 8, 512, false>, threads, (size_t)lds);\n  return e == hipSuccess ? n : -(int)e; }\n'
         'extern "C" int mv_conv2ds_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(g_cs_trace)); }\n'
         'extern "C" int mv_conv2ds_wg_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_wg), sizeof(g_cs_wg)); }\n'
         'extern "C" int mv_conv2ds_trace_clear() { static unsigned long long z[2 * %d * 4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), z, sizeof(z)); }\n}  // namespace mv\n\nextern "C" {' % NST)
