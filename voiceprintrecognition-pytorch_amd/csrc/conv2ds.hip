@@ -427,23 +427,31 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
 #pragma unroll
             for (int u = 0; u < EB; ++u)
 #pragma unroll
-                for (int i = 0; i < NBW; ++i) {
-                    const int64_t coff = (int64_t)(i < nb ? blk0 + i : blk0) * 32 + qoff;   // halves inside a pixel
-                    r1[u][i] = r2[u][i] = uint4v{0u, 0u, 0u, 0u};
-                    if (has1) r1[u][i] = *MV_GLOBAL_PTR(uint4v, a.res + pixo[u] * a.ldres * 2 + coff);
-                    if (has2 || has3)
-                        r2[u][i] = *MV_GLOBAL_PTR(uint4v, has2 ? a.res2 + pixo[u] * a.ldres2 * 2 + coff : a.add + pixo[u] * a.ldadd * 2 + coff);
-                }
-            // The operands are USED on every path, here: loaded under `if (has1)` and read under another `if (has1)`, the compiler's wait-count insertion
-            // sees the path on which a load is never waited for, carries its registers as pending around the batch loop -- and protects each load of the
-            // NEXT batch (same registers) with its own s_waitcnt vmcnt(0): six memory round trips one behind the other per batch (r14o, tools/isa_audit.py)
+                for (int i = 0; i < NBW; ++i) r1[u][i] = r2[u][i] = uint4v{0u, 0u, 0u, 0u};
+            // Layers WITH operands to read back (residual, AFF inputs, the addend of the second output): ONE block that requests them and, before it ends,
+            // uses them on every path (MV_OPAQUE) -- loaded under `if (has1)` and read under another `if (has1)`, the compiler's wait-count insertion sees the
+            // path on which a load is never waited for, carries its registers as pending around the batch loop and protects each load of the NEXT batch
+            // (same registers) with its own s_waitcnt vmcnt(0): six memory round trips one behind the other per batch (r14o, tools/isa_audit.py).  Layers
+            // WITHOUT operands never enter the block: its wait is an s_waitcnt vmcnt(0), which also waits for the previous batch's STORES -- executed by
+            // every layer it cost the plain 1x1 layers of the big maps 8 x 1.2 us per tile (r14z timeline: epilogue 9.9 us of a 13.5 us tile).
+            if (has1 || has2 || has3) {
 #pragma unroll
-            for (int u = 0; u < EB; ++u)
+                for (int u = 0; u < EB; ++u)
 #pragma unroll
-                for (int i = 0; i < NBW; ++i) {
-                    MV_OPAQUE(r1[u][i]);
-                    MV_OPAQUE(r2[u][i]);
-                }
+                    for (int i = 0; i < NBW; ++i) {
+                        const int64_t coff = (int64_t)(i < nb ? blk0 + i : blk0) * 32 + qoff;   // halves inside a pixel
+                        if (has1) r1[u][i] = *MV_GLOBAL_PTR(uint4v, a.res + pixo[u] * a.ldres * 2 + coff);
+                        if (has2 || has3)
+                            r2[u][i] = *MV_GLOBAL_PTR(uint4v, has2 ? a.res2 + pixo[u] * a.ldres2 * 2 + coff : a.add + pixo[u] * a.ldadd * 2 + coff);
+                    }
+#pragma unroll
+                for (int u = 0; u < EB; ++u)
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i) {
+                        MV_OPAQUE(r1[u][i]);
+                        MV_OPAQUE(r2[u][i]);
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < EB; ++u)
 #pragma unroll
