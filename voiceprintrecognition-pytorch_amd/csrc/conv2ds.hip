@@ -422,8 +422,28 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
             // odd / even 16-lane rows of the register pairs on the way (the same exchange in both directions): 64 contiguous bytes per pixel
             // and instruction instead of two times 32.
             const int64_t qoff = (q & 1) * 16 + (q >> 1) * 8;   // halves inside the unit: (q & 1) * 32 + (q >> 1) * 16 bytes
-            uint4v r1[EB][NBW], r2[EB][NBW];
             const bool has1 = a.res != nullptr, has2 = a.epi == 2, has3 = a.y2 != nullptr;   // uniform
+            if (a.epi == 0 && !has1 && !has3) {
+                // Plain layers (scale, bias, clamp -- every conv1 and every 3 x 3 of the family): their own copy of the per-unit code.  Through the general
+                // code below a unit is ~100 instructions and half a dozen uniform branches (epilogue mode, operands, second output) for four fma, four clamps,
+                // the hi / lo split and one store; on the big maps a tile's 24 units were 3/4 of a consumer wave's time (r14z timeline).
+#pragma unroll
+                for (int u = 0; u < EB; ++u)
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i) {
+                        if (i >= nb) break;  // uniform
+                        float4v X;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = acc[u0 + u][i][r] * osc64 + bias64[i][r];
+                        if (track && ok[u]) pk = s16_peak_of(pk, float4v{fmaxf(X[0], a.lo * CS_XSCALE), fmaxf(X[1], a.lo * CS_XSCALE), fmaxf(X[2], a.lo * CS_XSCALE), fmaxf(X[3], a.lo * CS_XSCALE)});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r], lo64, hi64);
+                        const uint4v w1 = s16_swap4(X);
+                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y + pixo[u] * a.ldy * 2 + (int64_t)(blk0 + i) * 32 + qoff) = w1;
+                    }
+                continue;
+            }
+            uint4v r1[EB][NBW], r2[EB][NBW];
 #pragma unroll
             for (int u = 0; u < EB; ++u)
 #pragma unroll
