@@ -398,8 +398,58 @@ __global__ __launch_bounds__(MAXT) void conv2ds_kernel(Conv2dsArgs a) {
         // only the stores are predicated), so a tile pays the memory latency once per batch.
         constexpr int EB0 = NBW <= 2 ? 4 : 1;   // (three blocks per wave: 253 registers with one segment's operands in flight)
         constexpr int EB = EB0 < SPW ? EB0 : SPW;
+        // Layers with a residual and nothing else (every conv3: scale, bias, + residual, clamp) in batches of TWO segments with their own per-unit code: a
+        // batch's wait for its residual loads is an s_waitcnt vmcnt(0) that also waits for the previous batch's stores, so a tile pays one store round trip per
+        // batch -- eight per tile with one-segment batches (the general code has no registers for more at three blocks per wave; this lean copy has).
+        constexpr int EBR0 = NBW <= 2 ? 4 : 2;
+        constexpr int EBR = EBR0 < SPW ? EBR0 : SPW;
+        const bool res_only = a.epi == 0 && a.res != nullptr && a.y2 == nullptr;   // uniform
+        if (res_only) {
 #pragma unroll
-        for (int u0 = 0; u0 < SPW; u0 += EB) {
+            for (int u0 = 0; u0 < SPW; u0 += EBR) {
+                if (useg0 + u0 >= nvalid) break;  // uniform
+                int64_t pixo[EBR];
+                bool ok[EBR];
+#pragma unroll
+                for (int u = 0; u < EBR; ++u) {
+                    const int su = useg0 + u0 + u;
+                    const int uu = su < nvalid ? su : nvalid - 1;
+                    if (KS == 3) {
+                        const int wo = wo0 + j16;
+                        ok[u] = su < nvalid && wo < a.Wo;
+                        pixo[u] = (int64_t)b * HWo + (int64_t)(ho0 + uu) * a.Wo + (wo < a.Wo ? wo : a.Wo - 1);
+                    } else {
+                        const int p = p0 + uu * 16 + j16;
+                        ok[u] = su < nvalid && p < HWo;
+                        pixo[u] = (int64_t)b * HWo + (p < HWo ? p : HWo - 1);
+                    }
+                }
+                const int64_t qoff = (q & 1) * 16 + (q >> 1) * 8;
+                uint4v rr[EBR][NBW];
+#pragma unroll
+                for (int u = 0; u < EBR; ++u)
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i)
+                        rr[u][i] = *MV_GLOBAL_PTR(uint4v, a.res + pixo[u] * a.ldres * 2 + (int64_t)(i < nb ? blk0 + i : blk0) * 32 + qoff);
+#pragma unroll
+                for (int u = 0; u < EBR; ++u)
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i) {
+                        if (i >= nb) break;  // uniform
+                        const float4v o1 = s16_unswap4(rr[u][i]);
+                        float4v X;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = acc[u0 + u][i][r] * osc64 + bias64[i][r] + o1[r];
+                        if (track && ok[u]) pk = s16_peak_of(pk, float4v{fmaxf(X[0], a.lo * CS_XSCALE), fmaxf(X[1], a.lo * CS_XSCALE), fmaxf(X[2], a.lo * CS_XSCALE), fmaxf(X[3], a.lo * CS_XSCALE)});
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[r] = s16_clamp(X[r], lo64, hi64);
+                        const uint4v w1 = s16_swap4(X);
+                        if (ok[u]) *reinterpret_cast<uint4v*>(a.y + pixo[u] * a.ldy * 2 + (int64_t)(blk0 + i) * 32 + qoff) = w1;
+                    }
+            }
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < SPW && !res_only; u0 += EB) {
             if (useg0 + u0 >= nvalid) break;  // uniform
             int64_t pixo[EB];
             bool ok[EB];
