@@ -96,3 +96,31 @@ def test_counted_waits_of_the_cam_block_kernel_match_the_generated_code():
     assert count(loop, 'v_mfma') == 20 + 36, 'the stage (20) and the k = 3 phase (36), each once'
     meta = dict(re.findall(r'\.(vgpr_spill_count|sgpr_count|vgpr_count):\s+(\d+)', text[text.index('.name:           _ZN2mv22cam_dense_block_kernel'):][:1500]))
     assert int(meta['vgpr_spill_count']) == 0
+
+
+def test_no_kernel_on_a_model_path_has_flat_or_scratch_instructions():
+    """tools/isa_audit.py over every csrc/*.hip (hipcc -S for gfx950, no GPU): round 5 found a CAM++ kernel whose parameter pointers had lost their address
+    space (FLAT loads count on lgkmcnt: every LDS wait behind one waited for L2), a pointer select that had become a table in scratch memory, and a uniform
+    branch per MFMA.  None of the three may come back: no FLAT instruction anywhere; scratch (spill) instructions only in the kernels listed here -- none of
+    which a shipped configuration launches (the 16-group Fbank instantiations serve windows of no listed length, STATS = 2 of the double-buffer conv no model);
+    no kernel with MFMAs that sit alone in their basic block."""
+    import importlib.util
+    import shutil
+    import sys
+    sys.path.insert(0, PKG)
+    import build_native
+    if not (shutil.which(build_native.HIPCC) or os.path.exists(build_native.HIPCC)):
+        pytest.skip('hipcc not found')
+    spec = importlib.util.spec_from_file_location('isa_audit', os.path.join(ROOT, 'tools', 'isa_audit.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    may_spill = re.compile(r'fbank_kernel<16,|fbank_tile_kernel<16,|conv1d_glds_persistent_kernel<true, 2>')
+    seen = 0
+    for fname, kernels in mod.audit().items():
+        for name, k in kernels.items():
+            seen += 1
+            assert k['flat'] == 0, f'{fname}: {name}: {k["flat"]} FLAT instructions (a pointer without its address space: MV_GLOBAL_PTR)'
+            assert k['lone'] <= 2, f'{fname}: {name}: {k["lone"]} MFMAs alone in a basic block (a branch per MFMA)'
+            if not may_spill.search(name):
+                assert k['scratch'] == 0 and k['vgpr_spill'] == 0, f'{fname}: {name}: scratch {k["scratch"]}, spilled VGPRs {k["vgpr_spill"]}'
+    assert seen > 150

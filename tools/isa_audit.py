@@ -13,67 +13,80 @@ sys.path.insert(0, PKG)
 import build_native
 
 OUT = '/tmp/isa_audit'
-os.makedirs(OUT, exist_ok=True)
-files = [os.path.join(PKG, 'csrc', f) for f in sys.argv[1:]] or sorted(glob.glob(os.path.join(PKG, 'csrc', '*.hip')))
-procs = []
-for src in files:
-    asm = os.path.join(OUT, os.path.basename(src) + '.s')
-    cmd = [build_native.HIPCC] + build_native.FLAGS + build_native._file_flags(src) + ['-Wno-inline-asm', '--cuda-device-only', '-S', '-x', 'hip', src, '-o', asm]
-    procs.append((src, asm, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-for src, asm, p in procs:
-    out, _ = p.communicate()
-    if p.returncode:
-        print(out.decode()[-2000:])
-        raise SystemExit(f'hipcc failed on {src}')
-    kernel, stats = None, {}
-    for line in open(asm):
-        m = re.match(r'^(_Z\w+):', line)
-        if m:
-            kernel = m.group(1)
-            stats[kernel] = dict(flat=0, scratch=0, mfma=0, lone=0, blocks=0, in_block=0, vm0=0, wtl=0, recent=[])
-            continue
-        if kernel is None:
-            continue
-        st = stats[kernel]
-        t = line.strip()
-        if t.startswith('.LBB') or t.startswith('s_cbranch') or t.startswith('s_branch'):
-            if st['in_block'] == 1:
-                st['lone'] += 1
-            st['in_block'] = 0
-            continue
-        if t and not t.startswith((';', '.')):
-            if t.startswith(('global_load_dword', 'buffer_load_dword', 'flat_load_dword')) and any(p.startswith('s_waitcnt') and 'vmcnt(0)' in p for p in st['recent'][-4:]):
-                st['wtl'] += 1
-            if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
-                st['vm0'] += 1
-            st['recent'] = (st['recent'] + [t])[-4:]
-        if t.startswith(('flat_load', 'flat_store', 'flat_atomic')):
-            st['flat'] += 1
-        elif t.startswith('scratch_'):
-            st['scratch'] += 1
-        elif t.startswith('v_mfma'):
-            st['mfma'] += 1
-            st['in_block'] += 1
-        m = re.match(r'\.(vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)', t)
-        if m:
-            pass
-    meta = {}
-    cur = None
-    for line in open(asm):
-        t = line.strip()
-        m = re.match(r'\.name:\s+(\S+)', t)
-        if m:
-            cur = m.group(1)
-            meta.setdefault(cur, {})
-        m = re.match(r'\.(vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)', t)
-        if m and cur:
-            meta[cur][m.group(1)] = int(m.group(2))
-    print(os.path.basename(src))
-    for k, st in stats.items():
-        if k not in meta:
-            continue
-        md = meta[k]
-        flag = ' <--' if st['flat'] or st['scratch'] or md.get('vgpr_spill_count') or st['lone'] > 2 or st['wtl'] > 2 else ''
-        name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().split('(')[0][:90]
-        print(f"  {name:90s} vgpr {md.get('vgpr_count', 0):3d} spill v{md.get('vgpr_spill_count', 0)} s{md.get('sgpr_spill_count', 0):<3d} flat {st['flat']:3d} scratch {st['scratch']:3d} "
-              f"mfma {st['mfma']:4d} (alone in a block: {st['lone']}) vmcnt(0) {st['vm0']:3d} (wait-then-load: {st['wtl']}){flag}")
+
+
+def audit(files=None):
+    """-> {source file name: {demangled kernel name: dict(vgpr, vgpr_spill, sgpr_spill, flat, scratch, mfma, lone, vm0, wtl)}}"""
+    os.makedirs(OUT, exist_ok=True)
+    files = [os.path.join(PKG, 'csrc', f) for f in files] if files else sorted(glob.glob(os.path.join(PKG, 'csrc', '*.hip')))
+    procs = []
+    for src in files:
+        asm = os.path.join(OUT, os.path.basename(src) + '.s')
+        cmd = [build_native.HIPCC] + build_native.FLAGS + build_native._file_flags(src) + ['-Wno-inline-asm', '--cuda-device-only', '-S', '-x', 'hip', src, '-o', asm]
+        procs.append((src, asm, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    result = {}
+    for src, asm, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            raise RuntimeError(f'hipcc failed on {src}:\n' + out.decode()[-2000:])
+        kernel, stats = None, {}
+        for line in open(asm):
+            m = re.match(r'^(_Z\w+):', line)
+            if m:
+                kernel = m.group(1)
+                stats[kernel] = dict(flat=0, scratch=0, mfma=0, lone=0, in_block=0, vm0=0, wtl=0, recent=[])
+                continue
+            if kernel is None:
+                continue
+            st = stats[kernel]
+            t = line.strip()
+            if t.startswith('.LBB') or t.startswith('s_cbranch') or t.startswith('s_branch'):
+                if st['in_block'] == 1:
+                    st['lone'] += 1
+                st['in_block'] = 0
+                continue
+            if t and not t.startswith((';', '.')):
+                if t.startswith(('global_load_dword', 'buffer_load_dword', 'flat_load_dword')) and any(q.startswith('s_waitcnt') and 'vmcnt(0)' in q for q in st['recent'][-4:]):
+                    st['wtl'] += 1
+                if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
+                    st['vm0'] += 1
+                st['recent'] = (st['recent'] + [t])[-4:]
+            if t.startswith(('flat_load', 'flat_store', 'flat_atomic')):
+                st['flat'] += 1
+            elif t.startswith('scratch_'):
+                st['scratch'] += 1
+            elif t.startswith('v_mfma'):
+                st['mfma'] += 1
+                st['in_block'] += 1
+        meta, cur = {}, None
+        for line in open(asm):
+            t = line.strip()
+            m = re.match(r'\.name:\s+(\S+)', t)
+            if m:
+                cur = m.group(1)
+                meta.setdefault(cur, {})
+            m = re.match(r'\.(vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\d+)', t)
+            if m and cur:
+                meta[cur][m.group(1)] = int(m.group(2))
+        kernels = {}
+        for k, st in stats.items():
+            if k not in meta:
+                continue
+            name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().split('(')[0]
+            kernels[name] = dict(vgpr=meta[k].get('vgpr_count', 0), vgpr_spill=meta[k].get('vgpr_spill_count', 0), sgpr_spill=meta[k].get('sgpr_spill_count', 0),
+                                 flat=st['flat'], scratch=st['scratch'], mfma=st['mfma'], lone=st['lone'], vm0=st['vm0'], wtl=st['wtl'])
+        result[os.path.basename(src)] = kernels
+    return result
+
+
+def main():
+    for fname, kernels in audit(sys.argv[1:]).items():
+        print(fname)
+        for name, k in kernels.items():
+            flag = ' <--' if k['flat'] or k['scratch'] or k['vgpr_spill'] or k['lone'] > 2 or k['wtl'] > 2 else ''
+            print(f"  {name[:90]:90s} vgpr {k['vgpr']:3d} spill v{k['vgpr_spill']} s{k['sgpr_spill']:<3d} flat {k['flat']:3d} scratch {k['scratch']:3d} "
+                  f"mfma {k['mfma']:4d} (alone in a block: {k['lone']}) vmcnt(0) {k['vm0']:3d} (wait-then-load: {k['wtl']}){flag}")
+
+
+if __name__ == '__main__':
+    main()
