@@ -30,7 +30,9 @@ Output: ONE JSON line on rank 0 (metric = utterances/sec embedded, BASELINE.json
   * ``other_configs`` (N=1, default model only): the other single-GPU shares of BASELINE.json's configs -- CAM++ (config 3),
     EcapaTdnn-512 + MelSpectrogram (config 4, per-GPU share: this rank's 256 rows scored against a 2048-row gallery) and the
     ~55 M ERes2NetV2 on a 1-10 s length-bucketed batch (config 5, per-GPU share, with the conv2d class against the fp32 MFMA
-    peak) -- each with its own label, throughput and parity over EVERY row (config 5: one row of every length bucket),
+    peak) -- each with its own label, throughput and parity over EVERY row (config 5: two rows of every length bucket, the most padded one included),
+  * ``box``: the yard-stick of the box this run landed on, taken before the timed region (tools/boxprobe): streaming-copy GB/s over 1 GiB, bare
+    fp16 MFMA TFLOP/s at the ring GEMM's residency and the shader clock sustained under it -- what makes lines of different boxes comparable,
   * ``latency_batch1`` (N=1, default model only): p50 / p90 of a ``predict()``-shaped call -- one 3 s utterance resident on the
     device -> features -> embedding -> host -- for EcapaTdnn-1024 and CAM++, eager launches and hipGraph replay.
 """
@@ -173,6 +175,73 @@ def cpu_baseline_all_cores(name, B, seed, threads, host_cores):
             'sample': f'{n} utterances in disjoint chunks of {per}, one chunk per process, wall {wall:.1f} s (slowest worker {slowest:.1f} s)'}
 
 
+def box_probe(dev, copy_bytes=1 << 30, mfma_ms=1.0):
+    """What THIS box offers, measured in this process before the timed region (five rounds of driver numbers came from boxes that
+    differ by 5 % end to end and up to 50 % on single VALU-bound kernels, and nothing in the line let anyone tell box from code):
+      copy_gbs        streaming copy of `copy_bytes` (read + write bytes / time): the HBM path,
+      mfma_f16_tflops bare v_mfma_f32_16x16x32_f16 issue at the ring GEMM's residency (one 512-thread workgroup per CU), no memory traffic,
+      mfma_clock_ghz  the shader clock the box SUSTAINS under that load (s_memtime / s_memrealtime inside the kernel, median workgroup),
+      idle_clock_ghz  the same ratio for a launch of ~20 us (the clock a short VALU-bound kernel such as Fbank is likely to see).
+    tools/boxprobe (measurement infrastructure, its own .so): {'error': ...} when it has not been built."""
+    import ctypes
+    import numpy as np
+    so = os.path.join(ROOT, 'tools', 'probe', 'libmvector_boxprobe.so')
+    if not os.path.exists(so):
+        return {'error': 'tools/probe/libmvector_boxprobe.so missing: run python tools/boxprobe/build.py (or __graft_entry__.build())'}
+    bp = ctypes.CDLL(so)
+    bp.bp_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    bp.bp_mfma.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    props = torch.cuda.get_device_properties(dev)
+    cus = props.multi_processor_count
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(reps):
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    src = torch.empty(copy_bytes, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+
+    def copy():
+        rc = bp.bp_copy(dst.data_ptr(), src.data_ptr(), copy_bytes, cus * 8, stream)
+        assert rc == 0, rc
+    copy()
+    copy_ms = timed(copy, 5)
+    del src, dst
+    ticks = torch.zeros(cus * 4, dtype=torch.int64, device=dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def mfma(iters):
+        rc = bp.bp_mfma(ticks.data_ptr(), sink.data_ptr(), iters, cus, stream)
+        assert rc == 0, rc
+
+    def clock():
+        t = ticks.cpu().numpy().reshape(cus, 4).astype(np.float64)
+        return float(np.median((t[:, 1] - t[:, 0]) / np.maximum(t[:, 3] - t[:, 2], 1.0) * 0.1))   # cycles per 10 ns tick -> GHz
+    mfma(200)
+    t_short = timed(lambda: mfma(40), 3)      # ~20 us
+    idle_clock = clock()
+    t200 = timed(lambda: mfma(200), 3)
+    iters = max(200, int(200 * mfma_ms / max(t200, 1e-3)))
+    t_long = timed(lambda: mfma(iters), 5)
+    flops = cus * 8 * iters * 32 * 16384.0
+    out = {'device': props.name, 'compute_units': cus,
+           'copy_gbs': round(2 * copy_bytes / (copy_ms * 1e-3) / 1e9, 1), 'copy_bytes': copy_bytes,
+           'mfma_f16_tflops': round(flops / (t_long * 1e-3) / 1e12, 1), 'mfma_ms': round(t_long, 3), 'mfma_clock_ghz': round(clock(), 3),
+           'short_launch_clock_ghz': round(idle_clock, 3), 'short_launch_us': round(t_short * 1e3, 1),
+           'note': 'yard-stick of this box, taken before the timed region: streaming copy (read + write bytes), bare v_mfma_f32_16x16x32_f16 at one '
+                   '512-thread workgroup per CU, shader clock = s_memtime / s_memrealtime (100 MHz) inside that kernel (median workgroup)'}
+    torch.cuda.empty_cache()
+    return out
+
+
 def one_minus_cos(a, b):
     return (1 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)).max().item()
 
@@ -232,14 +301,14 @@ def short_run(name, dev, B, steps, warmup, parity_rows, gallery_rows=0, head=Non
     if MODELS[name][4]:
         out['backbone_plus_frontend_tflops'] = round(B * MODELS[name][4] * steps / dt / 1e3, 1)
     if hasattr(model, 'native_head'):
-        out['fcm_head'] = dict(model.native_head() or {}, pinned=head is not None)
+        out['fcm_head'] = dict(model.native_head(range=True) or {}, pinned=head is not None)
     return out
 
 
 def bucketed_run(name, dev, n_utt, passes):
     """BASELINE config 5 (per-GPU share): variable-length 1-10 s utterances, <= 8 length buckets (mvector.parallel.embed_bucketed).
-    Parity: the first row of EVERY bucket against the oracle with predict_batch semantics inside the bucket (padding to the bucket
-    maximum); roofline: the conv2d launches of one profiled pass (algorithmic FLOPs, HIP events) against the dense fp16 MFMA peak -- the layers
+    Parity: two rows of EVERY bucket -- the shortest (most padded) one and the first / longest -- against the oracle with predict_batch semantics
+    inside the bucket (padding to the bucket maximum, CMN over the padded frames); roofline: the conv2d launches of one profiled pass (algorithmic FLOPs, HIP events) against the dense fp16 MFMA peak -- the layers
     run as three fp16 MFMA passes over split operands (conv2ds.hip), so the executed matrix work is 3 x the algorithmic figure."""
     import ctypes
     from mvector import _hip, parallel
@@ -265,16 +334,24 @@ def bucketed_run(name, dev, n_utt, passes):
     cdll.mv_profile_enable(0)
     _hip.check(cdll.mv_profile_read(2, ctypes.byref(n0), ctypes.byref(ms0), ctypes.byref(w0), 1), cdll)
     conv_tflops = w0.value / (ms0.value * 1e-3) / 1e12 if ms0.value > 0 else 0.0
-    worst, rows = 0.0, 0
+    worst, rows, worst_short = 0.0, 0, 0.0
     with torch.no_grad():
         for idx in parallel.length_buckets(lens, 8):
+            # >= 2 rows of every bucket: the bucket's SHORTEST row -- the most padded one, where the time mean over the padded
+            # frames differs most from the utterance's own -- and its first row (or, when that is the shortest, its longest)
             longest = max(lens[i] for i in idx)
-            padded = torch.zeros(1, longest)
-            padded[0, :lens[idx[0]]] = waves[idx[0]].cpu()
-            ratio = torch.tensor([lens[idx[0]] / longest], dtype=torch.float32)
+            short = min(idx, key=lambda i: lens[i])
+            other = idx[0] if idx[0] != short else max(idx, key=lambda i: lens[i])
+            picks = [short] + ([other] if other != short else [])
+            padded = torch.zeros(len(picks), longest)
+            for r, i in enumerate(picks):
+                padded[r, :lens[i]] = waves[i].cpu()
+            ratio = torch.tensor([lens[i] / longest for i in picks], dtype=torch.float32)
             ref = om.FORWARDS[cls](state_cpu, ofe.audio_featurizer(padded, ratio, method, margs))
-            worst = max(worst, one_minus_cos(emb[torch.tensor(idx[:1])].cpu(), ref))
-            rows += 1
+            got = emb[torch.tensor(picks)].cpu()
+            worst = max(worst, one_minus_cos(got, ref))
+            worst_short = max(worst_short, one_minus_cos(got[:1], ref[:1]))
+            rows += len(picks)
     secs = sum(lens) / 16000.0
     return {'metric': f'utterances/sec embedded (1-10 s@16 kHz length-bucketed, Fbank-80, {cls} 54.9 M, {n_utt} utterances)',
             'workload': label.replace('3 s@16 kHz synthetic', f'{n_utt} utterances of 1-10 s (seeded uniform), 8 length buckets'),
@@ -287,7 +364,8 @@ def bucketed_run(name, dev, n_utt, passes):
                          'frac': round(conv_tflops / MFMA_F16_PEAK_TFLOPS, 4), 'executed_tflops_3_passes': round(3 * conv_tflops, 1),
                          'frac_executed': round(3 * conv_tflops / MFMA_F16_PEAK_TFLOPS, 4), 'vs_fp32_pipe_peak': round(conv_tflops / MFMA_F32_PEAK_TFLOPS, 3), 'launches': n0.value,
                          'share_of_pass': round(ms0.value / (dt / passes * 1e3), 3), 'traffic': None},
-            'parity': {'max_one_minus_cos': worst, 'utterances': rows, 'tolerance': 1e-4, 'rows': 'the first row of every length bucket'}}
+            'parity': {'max_one_minus_cos': worst, 'max_one_minus_cos_shortest_rows': worst_short, 'utterances': rows, 'tolerance': 1e-4,
+                       'rows': 'two rows of every length bucket: its shortest (most padded) row and its first (else longest) row'}}
 
 
 def latency_batch1(name, dev, n=200):
@@ -443,7 +521,7 @@ def main():
     ap.add_argument('--dry-launch', action='store_true', help='N ranks rendezvous (gloo), rank 0 prints what it saw, nothing runs on a device')
     args = ap.parse_args()
 
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dry_launch):   # --dry-launch always rendezvouses: also one rank goes through the launcher
         sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -468,6 +546,13 @@ def main():
     if group is not None:   # checkpoint-derived choices of the native handles (CAM++ head precision): rank 0's, pinned on every rank, once
         from mvector import parallel
         parallel.sync_native_choices(model, device=dev, group=group)
+
+    box = None
+    if rank == 0:
+        try:
+            box = box_probe(dev)
+        except Exception as ex:   # the yard-stick must never take the headline with it
+            box = {'error': f'{type(ex).__name__}: {ex}'}
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
@@ -588,6 +673,7 @@ def main():
                          'all_gather': round(stage_ms[2], 4), 'cosine': round(stage_ms[3], 4)},
             'roofline': roof_conv,
             'roofline_fbank': roof_fe,
+            'box': box,
         }
         if gflop_per_utt:
             bb_tflops = B * gflop_per_utt / (bb_ms * 1e-3) / 1e3

@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared in this header are its ONLY dynamic exports besides the HIP
+ * runtime's kernel handles (tests/test_native_library.py checks `nm -D` against this list). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MV_OK 0
 #define MV_ERR_INVALID_ARGUMENT (-1)
@@ -35,7 +40,7 @@ extern "C" {
 #define MV_ERR_WORKSPACE (-4)
 #define MV_ERR_MISSING_TENSOR (-5)
 
-#define MV_ABI_VERSION 4
+#define MV_ABI_VERSION 5
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -72,6 +77,11 @@ typedef struct MvFbankCfg {
     int32_t kernel;               /* MV_FBANK_KERNEL_AUTO (0) | MV_FBANK_KERNEL_GENERIC (fbank_kernel) | MV_FBANK_KERNEL_TILE (fbank_tile_kernel;
                                    * create fails when the mel geometry has no instantiation).  Both kernels implement the same contract; the
                                    * field exists so that tests and tools/bench_fbank.py can run either on any geometry. */
+    /* ---- since ABI 5 ---- */
+    int64_t min_samples;          /* > 0: the threshold of min_duration in SAMPLES, ceil(min_duration * sample_frequency) evaluated by the caller in
+                                   * double as torchaudio compares (`len(waveform) < min_duration * sample_frequency`): the float32 field above
+                                   * rounds 0.1 / 0.2 / 0.3 s upwards and a clip of exactly min_duration lost its frames.  0: derived
+                                   * from min_duration. */
 } MvFbankCfg;
 
 enum { MV_WINDOW_POVEY = 0, MV_WINDOW_HAMMING = 1, MV_WINDOW_HANNING = 2, MV_WINDOW_RECTANGULAR = 3, MV_WINDOW_BLACKMAN = 4 };
@@ -192,7 +202,11 @@ typedef struct MvCamppCfg {
     int32_t init_channels; /* 128 */
     int32_t head_precision; /* MV_CAMPP_HEAD_AUTO (0): decided at create from three probe utterances; _F16 / _F32 pin it -- e.g. the
                              * same value on every rank of a distributed run, so that enrol and verify embeddings share one numerics */
+    int32_t xvector_probe;  /* since ABI 5.  MV_CAMPP_XVEC_PROBE_ON (0): create also measures what the fp16 operands of the x-vector part cost on the
+                             * three probe utterances (MV_INFO_CAMPP_XVEC_*; ~330 small exact-fp32 launches, once); _OFF (1) skips it */
 } MvCamppCfg;
+#define MV_CAMPP_XVEC_PROBE_ON 0
+#define MV_CAMPP_XVEC_PROBE_OFF 1
 #define MV_CAMPP_HEAD_AUTO 0
 #define MV_CAMPP_HEAD_F16 1
 #define MV_CAMPP_HEAD_F32 2
@@ -240,6 +254,15 @@ int mv_model_embd_dim(const MvModel* m, int32_t* embd_dim);
  *   MV_INFO_CAMPP_HEAD_PEAK       largest map value the exact head has wanted to store on the caller's inputs since create (real units; waits for the device)
  *   MV_INFO_CAMPP_HEAD_SATURATED  1.0 when one of them exceeded the range and was clamped (the embedding of that call is not to be trusted) */
 #define MV_INFO_CAMPP_HEAD_GAIN_LOG2 6
+/* since ABI 5 -- what the head probes cannot see (campplus.py:295-357 behind the head): the x-vector part always runs on fp16 operands.  create
+ * evaluates it once more in exact fp32 on the three probes (same head rows, the caller's fp32 weights, exact-fp32 GEMMs) and reports
+ *   MV_INFO_CAMPP_XVEC_SENSITIVITY   largest 1 - cos between the shipped and the exact x-vector part over the probes (-1: probe switched off)
+ *   MV_INFO_CAMPP_XVEC_PROBE0 + p    probe p's figure.
+ * Above MV_CAMPP_XVEC_WARN the 1e-4 contract (1 - cos against the reference's fp32 forward) is at risk on this checkpoint whatever head runs: there
+ * is no exact form of the x-vector part; the Python surface warns (mvector/models/campplus.py). */
+#define MV_INFO_CAMPP_XVEC_SENSITIVITY 10
+#define MV_INFO_CAMPP_XVEC_PROBE0 11
+#define MV_CAMPP_XVEC_WARN 2.5e-5f
 #define MV_INFO_CAMPP_PROBE_PEAK 7
 #define MV_INFO_CAMPP_HEAD_PEAK 8
 #define MV_INFO_CAMPP_HEAD_SATURATED 9
@@ -411,7 +434,11 @@ int mv_res2net_chain_f16(const void* x, void* y, const void* const* w_packed, co
                          const float* const* scale, const float* const* shift, int32_t B, int32_t T, int32_t C,
                          int32_t groups, int32_t k, int32_t dilation, mv_stream_t stream);
 
-/* y[b, o] = act( sum_k x[b, k] * w[o, k] + bias[o] ) in exact fp32 (f32 MFMA). */
+/* y[b, o] = act( sum_k x[b, k] * w[o, k] + bias[o] ) in exact fp32 (f32 MFMA).
+ * ONE summation order per ENTRY POINT, not across them: this call sums K in one sweep (the direct kernel); mv_linear_f32_ws with a sufficient
+ * workspace sums layers of K >= 2048 as slices of 384 added in slice order (what the model handles run) -- the two differ in the last bits
+ * (~1e-7 relative) on such layers, and mv_linear_f32_ws with a NULL / short workspace IS this call.  "A row's bits depend on the row only"
+ * holds within either form for every batch size; a caller that compares bits across the two forms must pick one. */
 int mv_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, int32_t act, float* y, int64_t ldy,
                   int32_t B, int32_t K, int32_t O, mv_stream_t stream);
 /* The same layer with a caller workspace (ABI 4): long reductions (K >= 2048, any number of rows: the [256, 6144] x [192, 6144] final layer of
@@ -489,6 +516,9 @@ int mv_fcm_block_c1_f16(const float* feats, int32_t F, const void* c1a, const fl
 /* host -> host: w fp32 [32 maps][3 mel taps][3 time taps] (BatchNorm scale folded) -> out fp16 [2][64][8], the MFMA operand order of the kernel */
 int mv_fcm_c1_pack(const float* w, void* out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -783,6 +783,24 @@ def fbank_arguments_case(cdll, device, idx, B=3, seconds=0.5, seed=None, check_r
     return fbank_case(cdll, device, wav, ratio, args, kernel=opt.get('kernel', 'auto'), cmn=cmn, num_samples=ns, check_rows=check_rows)
 
 
+def fbank_min_duration_edge(cdll, device):
+    """A clip of EXACTLY min_duration: torchaudio compares `len(waveform) < min_duration * sample_frequency` in double, so 0.1 s at
+    16 kHz = 1600 samples is featurised (8 frames) and 1599 samples are not; the float32 field of the struct alone rounds the threshold to 1601.
+    Rows of 1600 / 1599 / 1601 / 3200 samples through the variable-length entry point on both kernels, and the frame count query."""
+    from oracle import frontend
+    for md, sf in ((0.1, 16000), (0.3, 16000), (0.2, 8000)):
+        args = dict(sample_frequency=sf, num_mel_bins=80 if sf == 16000 else 23, min_duration=md)
+        edge = int(round(md * sf))
+        assert edge == md * sf   # the double product is exact on these values: the edge is the integer itself
+        wav = frontend.synth_waveforms(4, 2 * edge, seed=11)
+        ns = torch.tensor([edge, edge - 1, edge + 1, 2 * edge])
+        for kernel in ('auto', 'generic'):
+            fb = _hip.Fbank(args, cdll=cdll, kernel=kernel)
+            assert fb.num_frames(edge) == frontend.kaldi_fbank(wav[0, :edge].unsqueeze(0), **args).shape[0] > 0, (md, sf, kernel)
+            assert fb.num_frames(edge - 1) == 0
+            fbank_case(cdll, device, wav, None, args, kernel=kernel, num_samples=ns)
+
+
 def fbank_case(cdll, device, wav, ratio, method_args, kernel='auto', cmn=True, num_samples=None, check_rows=None):
     """HIP Fbank (+ time mean + mask) against the fp32 oracle AND the fp64 arbiter of the same algorithm.  `kernel`: 'auto' | 'generic' | 'tile'
     (MvFbankCfg.kernel).  cmn=False: the bare kaldi.fbank rows (KaldiFbank, featurizer.py:114-132).  num_samples: the variable-length entry point
@@ -845,7 +863,7 @@ def fbank_within_stated_bar(out, ref64, scale=1.0, ref32=None):
     return e_hip
 
 
-def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=None, head=0):
+def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=None, head=0, xvec_probe=None):
     """Golden case through the native model handle (weights from the manifest, reference embedding from golden).  `info`: a dict
     that receives {key: mv_model_info(key)} for the keys it holds (CAM++: 1 = head on fp32 maps, 2 = creation-time calibration).
     `frames`: instead of the golden input, one seeded utterance of that many frames with the golden input's statistics, the reference
@@ -887,6 +905,9 @@ def model_case(cdll, device, case, tol=1e-4, max_batch=None, info=None, frames=N
         cfg.input_size, cfg.embd_dim = kw['input_size'], kw.get('embd_dim', 512)
         cfg.growth_rate, cfg.bn_size, cfg.init_channels = kw.get('growth_rate', 32), kw.get('bn_size', 4), kw.get('init_channels', 128)
         cfg.head_precision = head   # MV_CAMPP_HEAD_AUTO (0) / _F16 (1) / _F32 (2)
+        # the creation-time x-vector sensitivity probe (three utterances through ~330 exact-fp32 GEMM launches): on by default on the device,
+        # off under the emulator (5 minutes there) unless a test asks for it
+        cfg.xvector_probe = 0 if (xvec_probe if xvec_probe is not None else str(device) != 'cpu') else 1
         kind = 'campp'
     sd_dev = {k: v.to(device) for k, v in sd.items()}
     m = _hip.Model(kind, cfg, sd_dev, cdll=cdll)

@@ -435,6 +435,10 @@ def test_emu_fbank_arguments(idx):
     lc.fbank_arguments_case(emu_cdll(), 'cpu', idx)
 
 
+def test_emu_fbank_clip_of_exactly_min_duration_keeps_its_frames():
+    lc.fbank_min_duration_edge(emu_cdll(), 'cpu')
+
+
 S16_RANGE_CASES = [
     dict(cin=32, cout=32, ks=3, H=6, W=20, B=1, lo=0.0, hi=3.0e38, peak=True),                                   # peak below the range: reported exactly
     dict(cin=32, cout=32, ks=3, H=6, W=20, B=1, lo=0.0, hi=3.0e38, peak=True, x_scale=200.0, seed=2),            # outputs beyond 1023.5: clamped AND reported

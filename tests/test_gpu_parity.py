@@ -28,7 +28,7 @@ def product_lib():
 def test_gpu_library_is_the_hip_build():
     from mvector import _hip
     lib = product_lib()
-    assert lib.mv_abi_version() == 4
+    assert lib.mv_abi_version() == 5
     assert os.path.basename(_hip.LIB_PATH) == 'libmvector_hip.so'
 
 
@@ -270,6 +270,11 @@ def test_gpu_fbank_arguments(idx):
     mask, and 260 x 0.5 s (more utterances than CUs)"""
     lc.fbank_arguments_case(product_lib(), DEV, idx, B=5, seconds=3.0)
     lc.fbank_arguments_case(product_lib(), DEV, idx, B=260, seconds=0.5, seed=7, check_rows=[0, 1, 2, 3, 4, 130, 255, 256, 257, 258, 259])
+
+
+def test_gpu_fbank_clip_of_exactly_min_duration_keeps_its_frames():
+    """L == min_duration * sample_frequency is featurised (torchaudio's double compare), L - 1 is not -- both kernels, device"""
+    lc.fbank_min_duration_edge(product_lib(), DEV)
 
 
 def test_gpu_kaldi_fbank_module_matches_oracle():

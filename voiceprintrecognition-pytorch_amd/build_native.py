@@ -13,8 +13,9 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'mvector', 'lib')
 OBJ_DIR = os.path.join(HERE, 'build')
 LIB = os.path.join(OUT_DIR, 'libmvector_hip.so')
+EXPORTS = os.path.join(CSRC, 'exports.map')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG', '-I', CSRC]  # <arch/gfx950.h> = csrc/arch
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-DNDEBUG', '-fvisibility=hidden', '-I', CSRC]  # <arch/gfx950.h> = csrc/arch
 
 
 def _file_flags(path):
@@ -61,8 +62,11 @@ def build(force=False, verbose=False):
         with open(stamp, 'w') as f:
             f.write(want)
         rebuilt = True
-    if rebuilt or not os.path.exists(LIB):
-        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    if rebuilt or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(EXPORTS):
+        # exports.map: the dynamic symbol table holds the mv_* entry points of include/mvector_hip.h and nothing else -- hipcc gives every __global__
+        # function's host-side handle default visibility whatever -fvisibility says, the version script makes them local too (the HIP runtime
+        # registers kernels by address from the library's constructor, not by name)
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', f'-Wl,--version-script={EXPORTS}', '-o', LIB] + objs)
     return LIB
 
 

@@ -27,7 +27,7 @@
 // into scalar registers; a select on a loaded table value puts the wait behind the load: index clamp instead; the compiler's own waits for
 // the parameter loads are pulled to the layer entry with MV_OPAQUE touches.  Starting the odd workgroups 4 - 20 us late (so that half the
 // chip is in its stage loop while the other half is in its tail) changed nothing: 2.23 - 2.27 ms for every delay (r08d).
-// Round 3, r10j-r10n: one interleaved schedule per stage (MV_CB_INTERLEAVE, default; 0 = the three-phase stage as an A/B arm): CAM++ 134.5 k ->
+// Round 3, r10j-r10n: one interleaved schedule per stage (the three-phase stage of rounds 2-3 was its A/B arm: tools/variants): CAM++ 134.5 k ->
 // 137.5 k utt/s in one call (1.903 -> 1.862 ms), bit-identical.  Probes on that form (text / macro arms of this file, one call each, wrong results
 // on purpose): the x transfers of the loop reading a constant page instead of the concat buffer (same instructions, no x traffic): no change at
 // all -- the loop is NOT bound by the 2.34 GB per step its x stream moves (every layer re-reads its utterance's prefix; 32 x 305 KB per XCD do
@@ -50,21 +50,11 @@
 // y stores as inline assembly (a tracked store beside tracked loads makes the compiler treat the counter as out of order: vmcnt(0) everywhere);
 // (5) row sums as explicit v_add_f32_dpp chains (the SLP vectoriser had paired the additions into v_pk_add_f32, which has no DPP form).
 // Measured and NOT kept: the next layer's W1 stages requested at the start of the tail (-0.3 %), its context parameters behind the k = 3 phase
-// (MV_CB_LATE_PARAMS 1: -2 %, 23 requests in one burst); the LDS form of the column sums (equal; removed).
+// (requested behind the k = 3 phase instead: -2 %, 23 requests in one burst); the LDS form of the column sums (equal; removed).
 #include "kernels.h"
 
 namespace mv {
 
-#ifndef MV_CB_INTERLEAVE
-#define MV_CB_INTERLEAVE 1  // 0: the stage as three phases (requests, MFMAs, transform), the form of rounds 2-3 (A/B arm)
-#endif
-#ifndef MV_CB_LAZY_STORES
-#define MV_CB_LAZY_STORES 1 // 1 (round 5): the layer entry leaves the previous layer's y stores and k = 3 weight requests in flight (counted wait); 0: s_waitcnt vmcnt(0)
-#endif
-#ifndef MV_CB_LATE_PARAMS
-#define MV_CB_LATE_PARAMS 0 // 1: the next layer's context parameters are requested BEHIND the k = 3 phase and stay in flight across the layer entry like the k = 3
-#endif                      // weights (A/B arm, r14m: 149.8 k against 153.1 k utt/s -- 23 requests in one burst cost more than the 38 registers give the k = 3 phase)
-static_assert(!MV_CB_LATE_PARAMS || MV_CB_LAZY_STORES, "late context parameters rely on the counted wait at the layer entry");
 constexpr int CB_THREADS = 512;
 constexpr int CB_TT = 10;                           // time tiles of 16 frames: T2 <= 160
 constexpr int CB_ROWS = CB_TT * 16;
@@ -267,14 +257,13 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // stage that holds the previous layer's 32 channels: that is the LAST stage, requested at stage nst - 4 behind that stage's counted wait (which
         // covers everything older than the last five transfers) and barrier.  So with more than four stages the entry waits for all but those
         // youngest operations, and stage 0 (whose operands the entry has seen land) waits for nothing.  (Loads and stores share vmcnt and retire in issue
-        // order on gfx9 -- the compiler relies on the same: `load; store; store; use of the load` compiles to s_waitcnt vmcnt(2).)  (With MV_CB_LATE_PARAMS the next layer's context
-        // parameters sit between the stores and the k = 3 weights: needed behind the stage loop, complete at stage 1's counted wait.)
-        const bool lazy = MV_CB_LAZY_STORES && l > 0 && nst > 4;   // uniform
+        // order on gfx9 -- the compiler relies on the same: `load; store; store; use of the load` compiles to s_waitcnt vmcnt(2).)
+        const bool lazy = l > 0 && nst > 4;   // uniform
         if (lazy) {
             int n_st = 0;   // y stores this wave issued: its time tiles with a frame below T2 (phase C)
 #pragma unroll
             for (int j = 0; j < 3; ++j) n_st += ((wave_u >> 1) + 4 * j < CB_TT && ((wave_u >> 1) + 4 * j) * 16 < T2) ? 1 : 0;
-            constexpr int NP = 12 + (MV_CB_LATE_PARAMS ? 11 : 0);   // parameter requests behind the stores
+            constexpr int NP = 12;   // parameter requests behind the stores: the twelve k = 3 weight loads
             if (n_st == 3) {   // (waits the compiler sees: it has the k = 3 weight and context parameter loads on its scoreboard)
                 wait_vm_seen<NP + 3>();
             } else if (n_st == 2) {
@@ -305,7 +294,6 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                 wait_vm<5>();
             }
             lds_barrier();  // ... in every wave; x(s) is transformed; every wave is done with x(s-1) and W1(s-1), whose slots are requested now
-#if MV_CB_INTERLEAVE
             // One schedule for the whole stage (r10j): the five transfer requests of x(s+3) / W1(s+2), the 20 MFMAs on x(s) / W1(s) and the in-place
             // BN1 + ReLU of x(s+1) are interleaved -- requests and transform cells between groups of MFMAs -- instead of running as three phases
             // that every wave of the workgroup enters at the same moment (requests ~750 cycles, MFMAs ~400, transform ~600 of a 2300-cycle stage).
@@ -404,32 +392,6 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
             mm(4);
             if (cell2) *cell_ptr(2) = cell_math(2, r2);
         }
-#else
-            issue_x(s + 3, nst);
-            issue_w(s + 2, nst, L.w1, L.cin_pad);
-            const char* wt = ws + (s % CB_RING) * CB_WS_BYTES;
-            const char* xt = xs + (s & (CB_XRING - 1)) * CB_XS_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                half8v af[2], bf[5];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int row = (cw * 2 + mi) * 16 + fr;
-                    af[mi] = *reinterpret_cast<const half8v*>(wt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < 5; ++ni) {
-                    const int row = (th * 5 + ni) * 16 + fr;
-                    bf[ni] = *reinterpret_cast<const half8v*>(xt + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < 5; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-            }
-            if (s + 1 < nst) transform(s + 1, L.cin, lbn_s, lbn_t);  // uniform
-        }
-#endif
         wait_vm<0>();   // only padding transfers are left: nothing may still be landing when the rings are reused
         // the parameter loads of this layer are the only vector loads the compiler tracks; touching what they deliver puts ITS wait for them
         // here, behind ours -- left where the values are first used (epilogue, context phase, k = 3 conv) it would be an s_waitcnt vmcnt(0)
@@ -563,11 +525,9 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
         // requests at the end of every layer (3.3 k ticks in the r08b timeline); here only the x requests of the tail's start are older.
         store_tables((l + 1) & 1, Ln.cin, nts, ntt);
         // The W ring is free again: the next layer's first two W1 stages (the layer entry waits for them).  Its context parameters take this layer's
-        // registers behind the k = 3 phase (MV_CB_LATE_PARAMS) or here.
+        // registers here (behind the k = 3 phase, as one burst with the k = 3 weights, measured -2 %: r14m).
         if (more) {
-#if !MV_CB_LATE_PARAMS
             load_ctx_params(Ln);
-#endif
             const int nstn = Ln.cin_pad / 64;
             issue_w(0, nstn, Ln.w1, Ln.cin_pad);
             issue_w(1, nstn, Ln.w1, Ln.cin_pad);
@@ -627,19 +587,12 @@ __global__ __launch_bounds__(CB_THREADS) void cam_dense_block_kernel(CamBlockArg
                     half4v hv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hv[r] = (half_t)fmed3(yc[j][r] * gt[r], -65504.0f, 65504.0f);
-#if MV_CB_LAZY_STORES
                     global_store8_untracked(xb + (int64_t)t * a.ldx + L.cin + co, hv);   // (beside tracked loads a tracked store costs an s_waitcnt vmcnt(0) in the stage loop)
-#else
-                    *reinterpret_cast<half4v*>(xb + (int64_t)t * a.ldx + L.cin + co) = hv;
-#endif
                 }
                 if ((j < 2 || third) && trow[j] - fr_t < T2) MV_VM_LOADS(1);   // (a store the wave issued: the layer entry counts it)
             }
         }
         if (more) {
-#if MV_CB_LATE_PARAMS
-            load_ctx_params(Ln);               // (eleven requests: the layer entry counts them)
-#endif
             load_wl(Ln);                       // the k = 3 weights of this layer are consumed (twelve requests)
         }
     }

@@ -668,9 +668,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_in_stats_kernel(ConvArgs a)
 //     epilogue issues no vector loads that would have to queue behind the stage loads;
 //   * the output leaves straight from the accumulators as 16-byte stores (v_permlane16_swap pairs up adjacent channel
 //     tiles so that a lane owns 8 consecutive channels); no LDS staging, no barrier in the epilogue.
-#ifndef CVP_DMA_STEPS
-#define CVP_DMA_STEPS 4
-#endif
+constexpr int CVP_DMA_STEPS = 4;   // over how many of a stage's 8 MFMA steps its 8 transfers are spread (8 measured slower: r02d)
 constexpr int CVP_STAGE_BYTES = 65536;
 constexpr int CVP_PARAM_OFF = 2 * CVP_STAGE_BYTES;
 constexpr int CVP_PARAM_SLOT = 3 * 1024;

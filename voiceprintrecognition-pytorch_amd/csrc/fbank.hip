@@ -967,6 +967,7 @@ void mv_fbank_default_cfg(MvFbankCfg* cfg) {
     cfg->snip_edges = 1;
     cfg->subtract_mean = 0;
     cfg->min_duration = 0.0f;
+    cfg->min_samples = 0;
     cfg->kernel = MV_FBANK_KERNEL_AUTO;
     cfg->vtln_warp = 1.0f;
     cfg->vtln_low = 100.0f;
@@ -995,7 +996,9 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     h->nbins = cfg->num_mel_bins;
     h->padded = 2;
     while (h->padded < win) h->padded *= 2;   // round_to_power_of_two=True (the only form implemented)
-    h->min_samples = (int64_t)ceil((double)cfg->min_duration * (double)cfg->sample_frequency);   // len < min_duration * sf  <=>  len < ceil(...)
+    MV_REQUIRE(cfg->min_samples >= 0, "mv_fbank_create: negative min_samples");
+    // len < min_duration * sf  <=>  len < ceil(...); the caller's own double evaluation (min_samples) wins over the float32 field
+    h->min_samples = cfg->min_samples > 0 ? cfg->min_samples : (int64_t)ceil((double)cfg->min_duration * (double)cfg->sample_frequency);
 
     const double pi = 3.14159265358979323846;
     std::vector<float> window(512, 0.0f), window_half(512, 0.0f), tw256(512), tw512(512);

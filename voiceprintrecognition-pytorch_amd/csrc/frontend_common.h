@@ -7,22 +7,8 @@
 
 namespace mv {
 
-// Complex values {re, im}.  Two spellings of the same arithmetic:
-//   * default: a plain struct -- every operation is scalar fp32 VALU work (v_add / v_mul / v_fma at full rate);
-//   * -DMV_CPLX_PACKED: float2 vectors -- sums, differences and twiddle products become packed fp32 ops (v_pk_add_f32 /
-//     v_pk_mul_f32 / v_pk_fma_f32).  Half the instructions, but PMC on gfx950 (profiles/r03c: 4.05 cycles per VALU instruction
-//     on average in fbank_tile_kernel, a third of them packed) shows the packed forms issuing several times slower than two
-//     scalar ops; kept only as the A/B arm of tools/bench_fbank.py.
-#ifdef MV_CPLX_PACKED
-typedef float2v cplx;
-__device__ __forceinline__ cplx cmake(float r, float i) { return cplx{r, i}; }
-__device__ __forceinline__ cplx cswap(cplx a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ __forceinline__ cplx cscale(cplx a, float s) { return a * cplx{s, s}; }
-__device__ __forceinline__ cplx cconj(cplx a) { return a * cplx{1.0f, -1.0f}; }
-__device__ __forceinline__ cplx mul_mi(cplx a) { return cswap(a) * cplx{1.0f, -1.0f}; }  // a * (-i) = {im, -re}
-// a * (c - i s)
-__device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return a * cplx{c, c} + cswap(a) * cplx{s, -s}; }
-#else
+// Complex values {re, im} as a plain struct: every operation is scalar fp32 VALU work (v_add / v_mul / v_fma at full rate).  The float2-vector spelling
+// (packed v_pk_* ops: half the instructions, identical time -- a packed op issues at half rate; r03c, r12d) was this file's A/B arm through round 5.
 struct alignas(8) cplx {
     float re, im;
     __device__ __forceinline__ float& operator[](int i) { return i == 0 ? re : im; }
@@ -39,7 +25,6 @@ __device__ __forceinline__ cplx cconj(cplx a) { return cplx{a.re, -a.im}; }
 __device__ __forceinline__ cplx mul_mi(cplx a) { return cplx{a.im, -a.re}; }  // a * (-i)
 // a * (c - i s) = (re c + im s) + i (im c - re s)
 __device__ __forceinline__ cplx cmul_conjtw(cplx a, float c, float s) { return cplx{fmaf(a.im, s, a.re * c), fmaf(-a.re, s, a.im * c)}; }
-#endif
 
 // 8-byte load of two consecutive floats as a complex value; elementwise product (window taps on {x[2n], x[2n+1]})
 __device__ __forceinline__ cplx cload(const float* p) {

@@ -260,9 +260,6 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(float* x, int n, int 
 // and 256 take the same form; r14i: with a row threshold the B = 1 / 8 rows of EcapaTdnn-1024 differed from their B = 256 bits).  Workspace:
 // [slices][B][O] floats.
 size_t linear_f32_splitk_floats(int B, int K, int O) {
-#ifdef MV_LINEAR_NO_SPLITK   // A/B arm of tools/gpu_r5i.sh: every layer on the direct kernel
-    return 0;
-#endif
     if (K < 2048 || O < 16 || B < 1 || B > 65535 * 32) return 0;
     return (size_t)ceil_div(K, LSK_SLICE) * B * O;
 }

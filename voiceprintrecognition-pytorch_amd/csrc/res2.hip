@@ -52,10 +52,7 @@
 
 namespace mv {
 
-#ifndef MV_RES2_ASM
-#define MV_RES2_ASM 1  // 0: weight ring in LDS + compiler-scheduled K stage for every width (tools/probe A/B arm only)
-#endif
-constexpr bool R2_DIRECT = MV_RES2_ASM != 0;  // width 128, T <= 304: weights straight into registers, hand-scheduled K stage (below)
+constexpr bool R2_DIRECT = true;  // width 128, T <= 304: weights straight into registers, hand-scheduled K stage (below)
 constexpr int R2_XNEXT_BYTES = 77824;         // direct form: [<= 304 rows][128] fp16 of the next channel group, where the weight ring was
 constexpr int R2_THREADS = 512;
 constexpr int R2_NH = 10;            // time tiles (16 frames) per wave half -> T <= 320

@@ -12,11 +12,7 @@ constexpr float CS_XSCALE_INV = 1.0f / 64.0f;
 // number to clamp -- fminf / fmaxf would turn it into a bound and hide it -- so it travels on.  Kernels that store S16 maps can report the largest
 // |V| they wanted to store (before the clamp) to a device word (s16_peak_*: the float's bits, monotonic under an unsigned max), which is how a
 // handle learns that its maps need a smaller scale (campplus.hip: the exact head's gain) and how saturation on real inputs becomes visible.
-#ifdef MV_S16_PLAIN_CLAMP   // A/B arm of tools/build_variant.py: the NaN-hiding clamp of round 4 (what the NaN test costs: profiles/r14d)
-__device__ __forceinline__ float s16_clamp(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-#else
 __device__ __forceinline__ float s16_clamp(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
-#endif
 __device__ __forceinline__ float s16_clamp(float v) { return s16_clamp(v, -65504.0f, 65504.0f); }
 __device__ __forceinline__ float s16_peak_of(float pk, const float4v& X) {   // (fmaxf drops NaNs: they are reported by the data itself)
     return fmaxf(fmaxf(pk, fmaxf(fabsf(X[0]), fabsf(X[1]))), fmaxf(fabsf(X[2]), fabsf(X[3])));
@@ -29,11 +25,7 @@ __device__ __forceinline__ void s16_peak_commit(unsigned* dst, float pk) {
     //  after the first few, a wave's maximum is almost never a new one)
     if ((threadIdx.x & 63) == 0 && pk > 0.0f) {
         const unsigned bits = __builtin_bit_cast(unsigned, pk);
-#ifdef MV_S16_UNGUARDED_PEAK   // A/B arm (tools/gpu_r5h.sh): every wave's atomic goes out
-        atomicMax(dst, bits);
-#else
         if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
-#endif
     }
 }
 

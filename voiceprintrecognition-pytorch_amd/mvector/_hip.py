@@ -25,7 +25,7 @@ class MvFbankCfg(ctypes.Structure):
                 ('preemphasis_coefficient', c_f32), ('remove_dc_offset', c_i32), ('use_power', c_i32),
                 ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32), ('window_type', c_i32), ('blackman_coeff', c_f32),
                 ('snip_edges', c_i32), ('subtract_mean', c_i32), ('min_duration', c_f32), ('vtln_warp', c_f32), ('vtln_low', c_f32),
-                ('vtln_high', c_f32), ('kernel', c_i32)]
+                ('vtln_high', c_f32), ('kernel', c_i32), ('min_samples', c_i64)]
 
 
 class MvMelSpecCfg(ctypes.Structure):
@@ -46,7 +46,7 @@ class MvEcapaCfg(ctypes.Structure):
 
 class MvCamppCfg(ctypes.Structure):
     _fields_ = [('input_size', c_i32), ('embd_dim', c_i32), ('growth_rate', c_i32), ('bn_size', c_i32),
-                ('init_channels', c_i32), ('head_precision', c_i32)]
+                ('init_channels', c_i32), ('head_precision', c_i32), ('xvector_probe', c_i32)]
 
 
 class MvEres2Cfg(ctypes.Structure):
@@ -180,7 +180,7 @@ def lib():
                 f'{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` or '
                 f'`python voiceprintrecognition-pytorch_amd/build_native.py`). There is no non-HIP device path.')
         cdll = bind(ctypes.CDLL(LIB_PATH))
-        if cdll.mv_abi_version() != 4:
+        if cdll.mv_abi_version() != 5:
             raise RuntimeError('libmvector_hip.so ABI version mismatch')
         _lib = cdll
     return _lib
@@ -241,6 +241,10 @@ class Fbank:
                     raise NotImplementedError(f'Fbank argument {k}={v!r} is not implemented by the HIP kernel')
             elif k not in ignored:
                 raise TypeError(f"fbank() got an unexpected keyword argument '{k}'")
+        # torchaudio compares `len(waveform) < min_duration * sample_frequency` in double: the sample threshold goes down as an integer (the struct's
+        # float32 min_duration rounds 0.1 s to 1601 samples at 16 kHz)
+        import math
+        cfg.min_samples = int(math.ceil(float(args.get('min_duration', 0.0)) * float(args.get('sample_frequency', cfg.sample_frequency))))
         cfg.subtract_time_mean = 1 if subtract_time_mean else 0
         cfg.kernel = self.KERNELS[kernel]
         self.num_mel_bins = cfg.num_mel_bins
@@ -426,12 +430,22 @@ class Model:
         check(self._cdll.mv_model_info(self._h, key, ctypes.byref(v)), self._cdll)
         return v.value
 
-    def campp_head(self):
+    XVEC_WARN = 2.5e-5   # MV_CAMPP_XVEC_WARN (include/mvector_hip.h)
+
+    def campp_head(self, range=False):
         """CAM++ handles: {'head': 'f16' | 'f32', 'calibration': largest probe figure (-1 when pinned), 'probes': the three figures} -- the
-        FCM head the handle chose at create (include/mvector_hip.h, MvCamppCfg.head_precision)"""
-        d = {'head': 'f32' if self.info(1) == 1.0 else 'f16', 'calibration': self.info(2), 'probes': tuple(self.info(3 + p) for p in range(3))}
-        if d['head'] == 'f32':   # the exact head's range (include/mvector_hip.h, MV_INFO_CAMPP_HEAD_*): gain 2^k, probe peak, peak / saturation on real inputs
-            d.update(gain_log2=int(self.info(6)), probe_peak=self.info(7), peak=self.info(8), saturated=self.info(9) == 1.0)
+        FCM head the handle chose at create (include/mvector_hip.h, MvCamppCfg.head_precision).  Host-side getters only: no device call, usable
+        anywhere (also under stream capture).  range=True adds the exact head's peak / saturation on the caller's inputs since create, which WAITS
+        FOR THE DEVICE (hipDeviceSynchronize + a blocking copy, csrc/campplus.hip): a diagnostic, never on a hot path."""
+        d = {'head': 'f32' if self.info(1) == 1.0 else 'f16', 'calibration': self.info(2), 'probes': tuple(self.info(3 + p) for p in [0, 1, 2])}
+        # what the head probes cannot see (since ABI 5): 1 - cos between the shipped (fp16-operand) and an exact-fp32 evaluation of the x-vector part
+        # on the three probes; -1 = not measured.  Above XVEC_WARN the 1e-4 contract is at risk on this checkpoint whatever head runs.
+        d.update(xvector_sensitivity=self.info(10), xvector_probes=tuple(self.info(11 + p) for p in [0, 1, 2]))
+        d['xvector_warning'] = d['xvector_sensitivity'] > self.XVEC_WARN
+        if d['head'] == 'f32':   # the exact head's range (include/mvector_hip.h, MV_INFO_CAMPP_HEAD_*): gain 2^k and the probes' peak, fixed at create
+            d.update(gain_log2=int(self.info(6)), probe_peak=self.info(7))
+            if range:
+                d.update(peak=self.info(8), saturated=self.info(9) == 1.0)
         return d
 
     def forward(self, feats):

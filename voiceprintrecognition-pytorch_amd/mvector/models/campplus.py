@@ -172,6 +172,17 @@ class CAMPPlus(NativeBackbone, nn.Module):
         cfg.head_precision = {'auto': 0, 'f16': 1, 'f32': 2}[self.head_precision]
         return cfg
 
+    def _native_created(self, handle, build):
+        """a fresh handle: say so ONCE per build when the checkpoint is sensitive to the fp16 operands of the x-vector part -- the part that has no
+        exact form to fall back to (csrc/campplus.hip::probe_xvector; DESIGN.md section 3)"""
+        rep = handle.campp_head()
+        if rep.get('xvector_warning'):
+            import warnings
+            warnings.warn(f"CAMPPlus: this checkpoint's embedding moves by 1 - cos = {rep['xvector_sensitivity']:.2e} on the handle's probe utterances when "
+                          f"the x-vector part runs on fp16 operands (threshold {handle.XVEC_WARN:.1e}); the 1e-4 agreement with the fp32 reference is "
+                          f"not guaranteed for it on the MI355X path (mvector.models.CAMPPlus.native_head() reports the figures)", RuntimeWarning, stacklevel=3)
+        return handle
+
     def sync_native_head(self, device=None, group=None, src=0):
         """COLLECTIVE (every rank of ``group`` calls it, once, after the weights are loaded and the module is in eval mode on its device): rank
         ``src``'s FCM head choice becomes every rank's pinned ``head_precision``, so enrol and verify embeddings of a job come out of one numerics.
@@ -196,11 +207,12 @@ class CAMPPlus(NativeBackbone, nn.Module):
             self.invalidate_native()   # (a handle built under 'auto' that chose the same head is rebuilt pinned: same kernels, same bits)
         return want
 
-    def native_head(self):
-        """{'head', 'calibration', 'probes'} of the native handle on the current device (None before the first CUDA forward)"""
+    def native_head(self, range=False):
+        """{'head', 'calibration', 'probes'} of the native handle on the current device (None before the first CUDA forward); range=True adds the
+        exact head's peak / saturation on the inputs seen so far and waits for the device to read them (a diagnostic)"""
         hs = self.__dict__.get('_native_handles', {})
         for h, _, _ in hs.values():
-            return h.campp_head()
+            return h.campp_head(range=range)
         return None
 
     def forward(self, x):
