@@ -204,6 +204,56 @@ __device__ __forceinline__ void mma_stage_8x4(unsigned wt, unsigned xtile, int w
     mfma_hazard_pad();
 }
 
+// The same stage with its LAST group of eight MFMAs carried across the stage barrier (round 6; ring kernel).  In the form above a stage ends with
+// its step-7 MFMAs and the next one begins -- behind the counted wait and the barrier -- with six fragment reads whose LDS round trip nothing
+// covers: the matrix pipe idles from the barrier to the first fragments (~300 of a stage's ~2950 cycles in the r05 timeline, on top of the barrier
+// skew itself).  Here a stage that is followed by another stage of the same tile (HOLD) leaves step 7 undone -- its four B and two A fragments
+// are in registers, complete since the barrier's lgkmcnt(0) -- and the next stage (PENDING) issues those eight MFMAs right behind its own first
+// six fragment requests, so the pipe works through them while the requests travel.  That needs the activation fragments double-buffered by
+// K half (bf0 / bf1: +16 registers; the weight fragments already alternate) and the fragment registers to live in the caller's scope.
+// Accumulation order per accumulator is unchanged (K halves in order, stages in order): bit-identical results.
+// A tile's first stage has nothing pending, its last stage holds nothing back (the epilogue reads complete accumulators).
+template <bool PENDING, bool HOLD, class F>
+__device__ __forceinline__ void mma_stage_8x4_carry(unsigned wt, unsigned xtile, int wc, int wn, int lane, float4v (&acc)[8][4], half8v (&af)[2][2],
+                                                    half8v (&bf0)[4], half8v (&bf1)[4], F&& between) {
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const unsigned arow = wt + (wc * 128 + frow) * 128, brow = xtile + (wn * 64 + frow) * 128;
+    const unsigned sw0 = (unsigned)((fchunk ^ (frow & 7)) << 4), sw1 = (unsigned)(((4 + fchunk) ^ (frow & 7)) << 4);
+    const unsigned a0 = arow + sw0, a1 = arow + sw1, b0 = brow + sw0, b1 = brow + sw1;
+    // K half 0
+    lds_read4(bf0, b0);
+    lds_read2<0, 2048>(af[0][0], af[0][1], a0);
+    if constexpr (PENDING) mfma8_step<6>(acc[6], acc[7], af[1][0], af[1][1], bf1);   // step 7 of the previous stage (no wait: six reads may be out)
+    lds_read2<4096, 6144>(af[1][0], af[1][1], a0);
+    between(0);
+    mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf0);
+    lds_read2<8192, 10240>(af[0][0], af[0][1], a0);
+    between(1);
+    mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf0);
+    lds_read2<12288, 14336>(af[1][0], af[1][1], a0);
+    between(2);
+    mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf0);
+    lds_read2<0, 2048>(af[0][0], af[0][1], a1);
+    between(3);
+    mfma8_step<2>(acc[6], acc[7], af[1][0], af[1][1], bf0);
+    // K half 1
+    lds_read4(bf1, b1);
+    lds_read2<4096, 6144>(af[1][0], af[1][1], a1);
+    between(4);
+    mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf1);
+    lds_read2<8192, 10240>(af[0][0], af[0][1], a1);
+    between(5);
+    mfma8_step<2>(acc[2], acc[3], af[1][0], af[1][1], bf1);
+    lds_read2<12288, 14336>(af[1][0], af[1][1], a1);
+    between(6);
+    mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf1);
+    between(7);
+    if constexpr (!HOLD) {
+        mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);
+        mfma_hazard_pad();
+    }
+}
+
 // lane holds channels co..co+3 (rows) of time step n (column); cout is a multiple of 4, so a lane's four channels are
 // all valid or all invalid and every per-channel parameter is one float4 load (uniform branches only).
 __device__ __forceinline__ float4v act4(float4v v, int act) {
@@ -1298,7 +1348,8 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     // One K stage: counted wait, barrier, [first stage of a tile: epilogue of the previous tile, accumulator init], 64 MFMAs with the
     // weight transfers of stage s + 1 under steps 0-1, the activation transfers of stage s + 2 under steps 2-3 and the streams' advance
     // (at the end of a tile: the next tile's offsets) under steps 4-5.
-    auto stage = [&](auto first) {
+    half8v af[2][2], bf0[4], bf1[4];   // fragment registers of the K stage: they carry a stage's last MFMA group across the barrier (mma_stage_8x4_carry)
+    auto stage = [&](auto first, auto carry_in, auto carry_out) {   // carry_in: the previous stage left its step 7 undone; carry_out: so does this one
         const bool do_w = w_more, do_x = x_more;
         if (x_ahead) {
             wait_vm<NTX>();
@@ -1318,7 +1369,7 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
             }
         }
         const unsigned wt = smem_base + cw_slot * CVR_SLOT_BYTES, xt = smem_base + CVR_X_OFF + cx_slot * CVR_SLOT_BYTES;
-        mma_stage_8x4(wt, xt, wc, wn, lane, acc, [&](int i) {
+        mma_stage_8x4_carry<decltype(carry_in)::value, decltype(carry_out)::value>(wt, xt, wc, wn, lane, acc, af, bf0, bf1, [&](int i) {
             if (i < 2) {
                 if (do_w) {
                     dma_w(2 * i);
@@ -1342,8 +1393,13 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
     while (c_vb < total) {
-        stage(yes{});
-        for (int s = 1; s < nstages; ++s) stage(no{});
+        if (nstages == 1) {
+            stage(yes{}, no{}, no{});
+        } else {
+            stage(yes{}, no{}, yes{});                                   // nothing pending, step 7 held
+            for (int s = 1; s < nstages - 1; ++s) stage(no{}, yes{}, yes{});
+            stage(no{}, yes{}, no{});                                    // the tile's last stage completes its accumulators
+        }
         e_n0 = c_n0;
         e_co0 = c_co0;
         pending = true;
