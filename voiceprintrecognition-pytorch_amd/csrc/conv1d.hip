@@ -234,10 +234,10 @@ __device__ __forceinline__ void mma_stage_8x4_carry(unsigned wt, unsigned xtile,
     between(2);
     mfma8_step<2>(acc[4], acc[5], af[0][0], af[0][1], bf0);
     lds_read2<0, 2048>(af[0][0], af[0][1], a1);
+    lds_read4(bf1, b1);   // K half 1's activation fragments one step early: bf1 is free since the carried group was issued (the single-buffered form had to wait for step 3)
     between(3);
-    mfma8_step<2>(acc[6], acc[7], af[1][0], af[1][1], bf0);
+    mfma8_step<6>(acc[6], acc[7], af[1][0], af[1][1], bf0);
     // K half 1
-    lds_read4(bf1, b1);
     lds_read2<4096, 6144>(af[1][0], af[1][1], a1);
     between(4);
     mfma8_step<2>(acc[0], acc[1], af[0][0], af[0][1], bf1);
@@ -590,6 +590,9 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     conv_acc_init<MI, NI>(a, co0, wc, lane, acc);
 
     if constexpr (NS > 2) {
+        // (The fused input statistics as such a ring -- the 128 x 160 tile with three stages in flight, 144 KiB, ONE workgroup per CU -- measured 197-212 us
+        //  against 150-160 us for the double buffer with two workgroups per CU on the ASP hidden layer, r15b: four waves per CU cannot overlap a stage's
+        //  MFMA / statistics chain with another workgroup's; parked as tools/variants/conv1d_in_stats_ring.patch.txt.)
         static_assert(!INSTATS && NS <= 4, "the ring form has no fused statistics; its waits are written out for up to three stages in flight");
         constexpr int TPS = NTX + NTW;   // transfers per wave and stage: always all of them (zero page for what is missing), so the waits can be counted
         const unsigned smem_addr = lds_addr(smem);
@@ -1348,8 +1351,11 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     // One K stage: counted wait, barrier, [first stage of a tile: epilogue of the previous tile, accumulator init], 64 MFMAs with the
     // weight transfers of stage s + 1 under steps 0-1, the activation transfers of stage s + 2 under steps 2-3 and the streams' advance
     // (at the end of a tile: the next tile's offsets) under steps 4-5.
-    half8v af[2][2], bf0[4], bf1[4];   // fragment registers of the K stage: they carry a stage's last MFMA group across the barrier (mma_stage_8x4_carry)
-    auto stage = [&](auto first, auto carry_in, auto carry_out) {   // carry_in: the previous stage left its step 7 undone; carry_out: so does this one
+    // af / bf0 / bf1: fragment registers of the K stage.  EVERY stage leaves its step-7 MFMAs undone (mma_stage_8x4_carry): a tile's later stages issue
+    // the previous stage's behind their own first fragment requests; a tile's first stage issues the previous TILE's last group right behind the barrier,
+    // in front of that tile's epilogue (two stage forms, as before the carry; four -- with a complete last stage -- made the register allocator spill).
+    half8v af[2][2], bf0[4], bf1[4];
+    auto stage = [&](auto first) {
         const bool do_w = w_more, do_x = x_more;
         if (x_ahead) {
             wait_vm<NTX>();
@@ -1358,7 +1364,11 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
         }
         lds_barrier();  // this stage has landed for every wave; every wave is done with the slots requested below
         if (decltype(first)::value) {
-            if (pending) persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+            if (pending) {
+                mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);   // the previous tile's last MFMA group (operands in registers since the barrier)
+                mfma_hazard_pad();
+                persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+            }
             if (c_co0 != held_co0) load_params(c_co0);  // uniform, at most once per launch on the shipped shapes
             // accumulators start from the bias of their 4 channels
 #pragma unroll
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
             }
         }
         const unsigned wt = smem_base + cw_slot * CVR_SLOT_BYTES, xt = smem_base + CVR_X_OFF + cx_slot * CVR_SLOT_BYTES;
-        mma_stage_8x4_carry<decltype(carry_in)::value, decltype(carry_out)::value>(wt, xt, wc, wn, lane, acc, af, bf0, bf1, [&](int i) {
+        mma_stage_8x4_carry<!decltype(first)::value, true>(wt, xt, wc, wn, lane, acc, af, bf0, bf1, [&](int i) {
             if (i < 2) {
                 if (do_w) {
                     dma_w(2 * i);
@@ -1393,13 +1403,8 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
     while (c_vb < total) {
-        if (nstages == 1) {
-            stage(yes{}, no{}, no{});
-        } else {
-            stage(yes{}, no{}, yes{});                                   // nothing pending, step 7 held
-            for (int s = 1; s < nstages - 1; ++s) stage(no{}, yes{}, yes{});
-            stage(no{}, yes{}, no{});                                    // the tile's last stage completes its accumulators
-        }
+        stage(yes{});
+        for (int s = 1; s < nstages; ++s) stage(no{});
         e_n0 = c_n0;
         e_co0 = c_co0;
         pending = true;
@@ -1408,6 +1413,9 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
         c_n0 = n_tile * TN;
         c_co0 = co_tile * TC;
     }
+    lds_wait<0>(af[1][0], af[1][1]);   // the last stage's step-7 fragments
+    mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);
+    mfma_hazard_pad();
     persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
 }
 
