@@ -238,8 +238,57 @@ def box_probe(dev, copy_bytes=1 << 30, mfma_ms=1.0):
            'short_launch_clock_ghz': round(idle_clock, 3), 'short_launch_us': round(t_short * 1e3, 1),
            'note': 'yard-stick of this box, taken before the timed region: streaming copy (read + write bytes), bare v_mfma_f32_16x16x32_f16 at one '
                    '512-thread workgroup per CU, shader clock = s_memtime / s_memrealtime (100 MHz) inside that kernel (median workgroup)'}
+    try:
+        out.update(ring_clock_probe(dev, cus))
+    except Exception as ex:
+        out['ring_k3072_error'] = f'{type(ex).__name__}: {ex}'
     torch.cuda.empty_cache()
     return out
+
+
+def ring_clock_probe(dev, cus, B=256, T=298, C=3072):
+    """The sustained shader clock INSIDE the dominant kernel: one launch of the product's ring GEMM on the MFA layer's shape (3072 -> 3072 over
+    B x T rows; bias / ReLU / BatchNorm epilogue) with MvConv1dDesc.clock_probe -- every workgroup leaves s_memtime / s_memrealtime at entry and exit
+    (the method of profiles/HISTORY.md r05v, now a field of the C ABI instead of a text-edited probe build)."""
+    import ctypes
+    import numpy as np
+    from mvector import _hip
+    cdll = _hip.lib()
+    x = (torch.randn(B, T, C, device=dev) * 0.5).half()
+    w = torch.randn(C, C, 1, device=dev) * (2.0 / C) ** 0.5
+    packed = torch.zeros(cdll.mv_conv1d_packed_elems(C, C, 1), dtype=torch.float16, device=dev)
+    st = _hip.current_stream(x)
+    _hip.check(cdll.mv_conv1d_pack_weight(w.data_ptr(), C, C, 1, packed.data_ptr(), st), cdll)
+    bias, scale, shift = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    y = torch.empty(B, T, C, dtype=torch.float16, device=dev)
+    nwg = (cus + 7) // 8 * 8
+    probe = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+    d = _hip.MvConv1dDesc()
+    d.x, d.x_dtype, d.ldx = x.data_ptr(), _hip.MV_DT_F16, C
+    d.w_packed, d.bias, d.scale, d.shift = packed.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.pre_act, d.post_act = 1, 0
+    d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, C
+    d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, C, C, 1, 1, 1
+    d.pad, d.pad_mode, d.tile = 0, _hip.MV_PAD_REFLECT, 256
+    d.clock_probe = probe.data_ptr()
+    for _ in range(2):
+        _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), st), cdll)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    us = []
+    for _ in range(3):
+        e0.record()
+        cdll.mv_conv1d_forward(ctypes.byref(d), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
+    t = probe.cpu().numpy().reshape(nwg, 4).astype(np.float64)
+    t = t[t[:, 3] > t[:, 2]]
+    ghz = float(np.median((t[:, 1] - t[:, 0]) / (t[:, 3] - t[:, 2]) * 0.1))
+    t_us = sorted(us)[1]
+    tf = 2.0 * B * T * C * C / t_us / 1e6
+    return {'ring_k3072_us': round(t_us, 1), 'ring_k3072_tflops': round(tf, 1), 'ring_k3072_clock_ghz': round(ghz, 3),
+            'ring_k3072_frac_of_2p5pf': round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+            'ring_k3072_frac_at_sustained_clock': round(tf / (cus * 4 * 1024 * 2 * ghz * 1e9 / 1e12 / 2), 4)}
 
 
 def one_minus_cos(a, b):

@@ -412,6 +412,10 @@ typedef struct MvConv1dDesc {
     int32_t persist_blocks_hint;  /* 0 = one resident workgroup per CU; otherwise that many (rounded up to 8) workgroups walk the tiles of the
                                    * persistent kernels -- tests make small problems walk several tiles per workgroup; never the bits of a result
                                    * (since ABI 4; replaces the MV_CONV_PERSIST_BLOCKS environment hook: no getenv is left in the library) */
+    uint64_t* clock_probe;        /* since ABI 5, optional: device array [resident workgroups (<= CUs rounded up to 8)][4].  The dense 1x1 persistent
+                                   * (ring) kernel leaves {shader-clock cycles at entry, at exit, 100 MHz reference at entry, at exit} of every
+                                   * workgroup there: (exit - entry cycles) / (exit - entry reference ticks) x 100 MHz = the shader clock the launch
+                                   * SUSTAINED (bench.py's `box` block prices the 2.5 PFLOP/s peak's 2.4 GHz against it).  Other kernels ignore it. */
 } MvConv1dDesc;
 int mv_conv1d_forward(const MvConv1dDesc* d, mv_stream_t stream);
 /* floats in one partial-statistics buffer, and the reduction of the partial rows to per-utterance mean[b, c] (and

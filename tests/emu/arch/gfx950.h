@@ -132,6 +132,9 @@ inline void lds_barrier() {   // (no drain of transfers in flight: s_waitcnt lgk
     emu::syncthreads();
 }
 inline void barrier_only() { emu::syncthreads(); }
+// clock probes (MvConv1dDesc.clock_probe): the emulator has no clocks -- a monotonic count of calls (1 GHz "shader" against the 100 MHz reference)
+inline unsigned long long shader_clock() { static thread_local unsigned long long t = 0; return t += 10; }
+inline unsigned long long ref_clock_100mhz() { static thread_local unsigned long long t = 0; return t += 1; }
 inline void glds16_untracked(const void* gsrc, unsigned lds_wave_base_addr) {
     emu::dma_issue(const_cast<char*>(lds_ptr(lds_wave_base_addr)) + (emu::flat_tid() & 63) * 16, gsrc);
 }

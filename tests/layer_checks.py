@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0, clock_probe=False):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -84,9 +84,18 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
         isum = torch.full((nin,), float('nan'), device=device)
         isq = torch.full((nin,), float('nan'), device=device)
         d.in_stat_sum, d.in_stat_sq = isum.data_ptr(), isq.data_ptr()
+    if clock_probe:   # MvConv1dDesc.clock_probe (ABI 5): the ring kernel's workgroups leave their entry / exit clocks
+        probe = torch.zeros(4 * 264, dtype=torch.int64, device=device)
+        d.clock_probe = probe.data_ptr()
     _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), _stream(xd)), cdll)
     if device != 'cpu':
         torch.cuda.synchronize()
+    if clock_probe:
+        t = probe.cpu().reshape(-1, 4)
+        t = t[t[:, 3] > t[:, 2]]
+        assert t.shape[0] >= 1 and bool((t[:, 1] > t[:, 0]).all()), 'no workgroup left its clocks'
+        ghz = ((t[:, 1] - t[:, 0]).double() / (t[:, 3] - t[:, 2]).double() * 0.1).median().item()
+        assert 0.3 < ghz < 3.5, ghz   # (the emulator's stand-in counters read 1.0)
     if in_stats:
         imean = torch.empty(B, 2 * cin, device=device)
         _hip.check(cdll.mv_conv1d_in_stats_finish(isum.data_ptr(), isq.data_ptr(), B, T, cin, imean.data_ptr(),
@@ -427,6 +436,7 @@ CONV_CASES = [
     dict(k=1, dil=1, cin=72, cout=64, T=160, B=2, in_stats=True, extra_ld=0),                            # exact tile, partial K stage, fp16 out with epilogue
     dict(k=1, dil=1, cin=128, cout=128, T=1, B=5, in_stats=True, y_f32=True, pre_act=0, affine=False),    # single frame: std = sqrt(eps)
     dict(k=1, dil=1, stride=2, pad_mode='zero', cin=128, cout=256, T=151, B=4, tile=256),   # persistent, 1x1 with a time stride: the double-buffer kernel's plain form (the ring kernel takes dense rows only)
+    dict(k=1, dil=1, cin=192, cout=256, T=200, B=6, tile=256, clock_probe=True),   # ring kernel with MvConv1dDesc.clock_probe, three K stages (first / middle / last form of the carried MFMA group)
 ]
 
 

@@ -171,6 +171,10 @@ __device__ __forceinline__ void glds16_untracked_so(const void* sbase, unsigned 
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain transfers still in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// counters for in-kernel clock probes (MvConv1dDesc.clock_probe): shader-clock cycles and the 100 MHz constant reference; both scalar
+__device__ __forceinline__ unsigned long long shader_clock() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned long long ref_clock_100mhz() { return __builtin_amdgcn_s_memrealtime(); }
+
 // bare workgroup barrier: no wait for this wave's outstanding LDS reads (they may stay in flight across it when nobody writes what they
 // read); everything else a barrier has to order is the caller's business
 __device__ __forceinline__ void barrier_only() { asm volatile("s_barrier" ::: "memory"); }

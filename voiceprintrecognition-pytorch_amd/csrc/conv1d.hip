@@ -62,6 +62,7 @@ struct ConvArgs {
     int per_utt, tiles_per_utt;
     float* in_sum;
     float* in_sq;
+    unsigned long long* clock_probe;  // optional (ring kernel): [workgroup][4] shader-clock / reference ticks at entry and exit
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -1244,6 +1245,11 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     const int kc = (lane & 7) ^ (lrow & 7);
     const int total = ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;  // virtual workgroup ids of tile_of_index
     const int step = (int)gridDim.x;
+    unsigned long long clk0 = 0, ref0 = 0;   // (scalar registers) MvConv1dDesc.clock_probe
+    if (a.clock_probe != nullptr) {
+        clk0 = shader_clock();
+        ref0 = ref_clock_100mhz();
+    }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* wb = reinterpret_cast<const char*>(a.w);
     const unsigned xrow_bytes = (unsigned)a.ldx * 2u, wrow_bytes = (unsigned)a.cin_pad * 2u;
@@ -1417,6 +1423,13 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);
     mfma_hazard_pad();
     persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+    if (a.clock_probe != nullptr && tid == 0) {
+        unsigned long long* p = a.clock_probe + 4 * (size_t)blockIdx.x;
+        p[0] = clk0;
+        p[1] = shader_clock();
+        p[2] = ref0;
+        p[3] = ref_clock_100mhz();
+    }
 }
 
 // Wave priorities (r10k): s_setprio 1 around every group of eight MFMAs, and the opposite (priority outside the groups), as probe builds of
@@ -1669,6 +1682,8 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     a.tiles_per_utt = 1;
     a.in_sum = d.in_stat_sum;
     a.in_sq = d.in_stat_sq;
+    a.clock_probe = reinterpret_cast<unsigned long long*>(d.clock_probe);
+    MV_REQUIRE((reinterpret_cast<uintptr_t>(d.clock_probe) & 7) == 0, "conv1d: clock_probe must be 8-byte aligned");
     const bool in_stats = d.in_stat_sum != nullptr;
     MV_REQUIRE((d.in_stat_sum == nullptr) == (d.in_stat_sq == nullptr), "conv1d: in_stat_sum / in_stat_sq go together");
     const int stats = d.stat_sum == nullptr ? 0 : (d.stat_sq == nullptr ? 1 : 2);

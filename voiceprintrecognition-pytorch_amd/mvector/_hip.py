@@ -76,7 +76,7 @@ class MvConv1dDesc(ctypes.Structure):
                 ('ld_sum', c_i64), ('B', c_i32), ('T_in', c_i32), ('T_out', c_i32),
                 ('cin', c_i32), ('cout', c_i32), ('k', c_i32), ('dilation', c_i32), ('stride', c_i32), ('pad', c_i32),
                 ('pad_mode', c_i32), ('tile', c_i32), ('stat_sum', c_vp), ('stat_sq', c_vp), ('in_stat_sum', c_vp), ('in_stat_sq', c_vp),
-                ('persist_blocks_hint', c_i32)]
+                ('persist_blocks_hint', c_i32), ('clock_probe', c_vp)]
 
 
 _SIGNATURES = {
