@@ -466,8 +466,17 @@ def test_gpu_eres2netv2_variable_length_bucketed():
     lens = [int(v) for v in torch.randint(16000, 160001, (24,), generator=g)]
     lens[0], lens[1] = 16000, 160000
     wav = frontend.synth_waveforms(len(lens), max(lens), seed=5)
-    emb = embed_bucketed(fz, m, [wav[i, :n] for i, n in enumerate(lens)], max_buckets=8, device=torch.device(DEV)).cpu()
+    waves = [wav[i, :n] for i, n in enumerate(lens)]
+    emb = embed_bucketed(fz, m, waves, max_buckets=8, device=torch.device(DEV)).cpu()
     assert emb.shape == (24, 192) and torch.isfinite(emb).all() and m.__dict__.get('_native_handles')
+    # round 6: the buckets run on two HIP streams in turn (one native handle, one workspace per stream); the same rows on ONE stream carry the same
+    # bits, also when the passes are repeated back to back (a workspace shared by two forwards in flight would show here)
+    one = embed_bucketed(fz, m, waves, max_buckets=8, device=torch.device(DEV), streams=1).cpu()
+    assert torch.equal(emb, one)
+    for _ in range(3):
+        assert torch.equal(embed_bucketed(fz, m, waves, max_buckets=8, device=torch.device(DEV), streams=2).cpu(), one)
+    (h, _, _), = m.__dict__['_native_handles'].values()
+    assert len(h._ws) >= 2, 'two streams, two workspaces'
     buckets = length_buckets(lens, 8)
     for idx in (buckets[0], buckets[-1]):
         longest = max(lens[i] for i in idx)

@@ -33,6 +33,10 @@ for name, cin, cout, k, dil in shapes:
         d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout + PADX
         d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, cin, cout, k, dil, 1
         d.pad, d.pad_mode, d.tile = dil * (k - 1) // 2, _hip.MV_PAD_REFLECT, tile
+        probe = None
+        if os.environ.get('MV_BENCH_CLOCK') == '1' and hasattr(d, 'clock_probe'):   # the launch's sustained shader clock (ring kernel only)
+            probe = torch.zeros(4 * 264, dtype=torch.int64, device='cuda')
+            d.clock_probe = probe.data_ptr()
         st = _hip.current_stream(x)
         for _ in range(3):
             _hip.check(lib.mv_conv1d_forward(ctypes.byref(d), st))
@@ -46,4 +50,10 @@ for name, cin, cout, k, dil in shapes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         tf = 2.0 * B * T * cin * cout * k / us / 1e6
-        print(json.dumps(dict(B=B, shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))), flush=True)
+        rec = dict(B=B, shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))
+        if probe is not None:
+            t = probe.cpu().reshape(-1, 4).double()
+            t = t[t[:, 3] > t[:, 2]]
+            if t.shape[0]:
+                rec['clock_ghz'] = round(((t[:, 1] - t[:, 0]) / (t[:, 3] - t[:, 2]) * 0.1).median().item(), 3)
+        print(json.dumps(rec), flush=True)

@@ -417,7 +417,7 @@ class Model:
         e = c_i32()
         check(self._cdll.mv_model_embd_dim(self._h, ctypes.byref(e)), self._cdll)
         self.embd_dim = e.value
-        self._ws = None
+        self._ws = {}   # one workspace per (device, stream): forwards of ONE handle on different streams run concurrently (the C ABI's contract)
 
     def workspace_bytes(self, B, T):
         n = c_sz()
@@ -456,11 +456,16 @@ class Model:
         if B == 0:
             return emb
         nbytes = self.workspace_bytes(B, T)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != feats.device:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
-        check(self._cdll.mv_model_forward(self._h, feats.data_ptr(), B, T, emb.data_ptr(), self._ws.data_ptr(),
-                                          self._ws.numel(), current_stream(feats)), self._cdll)
+        stream = current_stream(feats)
+        key = (str(feats.device), stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.pop(key, None)   # (drop the smaller buffer before the larger one is allocated)
+            ws = None
+            if len(self._ws) >= 4:    # a caller that creates streams by the dozen must not pin a workspace for each
+                self._ws.clear()
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
+        check(self._cdll.mv_model_forward(self._h, feats.data_ptr(), B, T, emb.data_ptr(), ws.data_ptr(), ws.numel(), stream), self._cdll)
         return emb
 
     def __del__(self):

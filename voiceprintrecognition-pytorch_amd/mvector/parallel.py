@@ -5,6 +5,8 @@ exchange step -- an all-gather of the ``[B_local, D]`` embedding shards (RCCL ov
 The reference has no counterpart (its inference is single-process: mvector/predict.py, trainer.py:403-485); the
 only collective it ever issues is DDP's gradient all-reduce in training (trainer.py:356).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -82,30 +84,64 @@ def length_buckets(num_samples, max_buckets=8):
     return [b for b in buckets if b]
 
 
+_bucket_streams = {}
+
+
+def _side_streams(device, n):
+    """n HIP streams of ``device`` for embed_bucketed, created once per device"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key not in _bucket_streams:
+        _bucket_streams[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return _bucket_streams[key]
+
+
 @torch.no_grad()
-def embed_bucketed(featurizer, model, waveforms, max_buckets=8, device=None):
+def embed_bucketed(featurizer, model, waveforms, max_buckets=8, device=None, streams=2):
     """Embeddings [N, D] (input order, on every rank) of N variable-length waveforms (1-D float tensors).
 
     Utterances are bucketed by length (``length_buckets``); every bucket is sharded over the ranks like a fixed-length
     batch (``shard_rows``), zero-padded to the bucket's longest utterance, featurised with the length ratios and embedded;
-    the shards travel through one all-gather per bucket (padded to equal row counts, RCCL on GPUs)."""
+    the shards travel through one all-gather per bucket (padded to equal row counts, RCCL on GPUs).
+
+    On a CUDA device the buckets are embedded on ``streams`` HIP streams in turn (round 6): a bucket is a handful of utterances, and the late
+    stages of a 2-D backbone on a handful of utterances are launches of a few dozen workgroups (ERes2NetV2 54.9 M: 1 256 launches per pass, most of
+    them on a fraction of the chip) -- two buckets in flight fill each other's gaps.  One native handle serves both streams (every forward brings the
+    workspace of its own stream: the C ABI's contract); a row's bits do not depend on it.  Collectives are issued afterwards, in bucket order, on
+    the caller's stream.  ``streams=1``: everything on the caller's stream."""
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
     if device is None:
         device = next(model.parameters()).device
+    device = torch.device(device)
     lens = [int(w.numel()) for w in waveforms]
     out = None
-    for idx in length_buckets(lens, max_buckets):
+    buckets = length_buckets(lens, max_buckets)
+    side = _side_streams(device, streams) if device.type == 'cuda' and streams > 1 and len(buckets) > 1 else None
+    main = torch.cuda.current_stream(device) if side else None
+    if side:
+        for s in side:
+            s.wait_stream(main)   # the waveforms (and the weights) were produced on the caller's stream
+    local = []
+    for k, idx in enumerate(buckets):
         longest = max(lens[i] for i in idx)
         lo, hi = shard_rows(len(idx), rank, world)
         mine = idx[lo:hi]
-        per = -(-len(idx) // world)  # rows every rank contributes to the all-gather (padded)
         emb_local = None
         if mine:
-            wav = torch.stack([F.pad(waveforms[i].to(device=device, dtype=torch.float32), (0, longest - lens[i])) for i in mine])
-            ratio = torch.tensor([lens[i] / longest for i in mine], dtype=torch.float32, device=device)
-            emb_local = model(featurizer(wav, ratio))
+            with (torch.cuda.stream(side[k % len(side)]) if side else contextlib.nullcontext()):
+                wav = torch.stack([F.pad(waveforms[i].to(device=device, dtype=torch.float32), (0, longest - lens[i])) for i in mine])
+                ratio = torch.tensor([lens[i] / longest for i in mine], dtype=torch.float32, device=device)
+                emb_local = model(featurizer(wav, ratio))
+                if side:
+                    emb_local.record_stream(main)   # (allocated on the side stream, consumed on the caller's)
+        local.append(emb_local)
+    if side:
+        for s in side:
+            main.wait_stream(s)
+    for idx, emb_local in zip(buckets, local):
+        lo, hi = shard_rows(len(idx), rank, world)
+        per = -(-len(idx) // world)  # rows every rank contributes to the all-gather (padded)
         if out is None:
             dim = emb_local.shape[1] if emb_local is not None else model.embd_dim
             out = torch.zeros((len(waveforms), dim), dtype=torch.float32, device=device)
