@@ -589,7 +589,11 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(AspArgs a) {
 //   * the element math runs on float2 (v_pk_add/mul/fma_f32): 2 cvt + 2 exp + 5 packed operations per channel pair.
 // LDS tiles: x 16 rows x 128 B, 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7); h 16 rows x 2A B, chunk c of row r
 // at position c ^ (r & (2A/16 - 1)): the 16 lanes of a fragment group read 16 different bank groups.
-constexpr int ASP_XRING = 6, ASP_HRING = 6;
+// Ring depth (round 6, r15j/k: the kernel alone at 256 x 3 s): 4 tiles = 48 KiB per workgroup = three workgroups per CU 149-158 us, 6 tiles (rounds 2-5: 72 KiB, two per
+// CU) 158-163, 5 tiles 152-158, 8 tiles (96 KiB, one per CU) 228-234: occupancy beats prefetch depth.
+constexpr int ASP_RING = 4;                          // tiles per ring: a step requests h(tt + ASP_RING - 1) and x(tt + ASP_RING)
+constexpr int ASP_XRING = ASP_RING, ASP_HRING = ASP_RING;
+constexpr int ASP_YOUNGER = 2 + 3 * (ASP_RING - 2);  // transfers of a wave younger than its part of h(tt + 1) when step tt waits (8 for four tiles, 14 for six)
 
 template <int KS>
 __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
     };
     issue_x(0, 0);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < ASP_RING - 1; ++i) {
         issue_h(i, i);
         issue_x(i + 1, i + 1);
     }
@@ -750,14 +754,14 @@ __global__ __launch_bounds__(256) void asp_pool_ring_kernel(AspArgs a) {
 
     float4v la[4], lb[4];
     half8v xa0, xa1, xb0, xb1;
-    wait_vm<14>();
+    wait_vm<ASP_YOUNGER>();
     lds_barrier();
     fetch(0, 0, 0, la, xa0, xa1);
-    int hs = 5, xs = 0;  // ring slots of h(tt+5) and x(tt+6)
+    int hs = ASP_RING - 1, xs = 0;  // ring slots of h(tt+5) and x(tt+6)
     auto step = [&](int tt, float4v (&lcur)[4], half8v& xc0, half8v& xc1, float4v (&lnext)[4], half8v& xn0, half8v& xn1) {
-        issue_h(tt + 5, hs);
-        issue_x(tt + 6, xs);
-        wait_vm<14>();
+        issue_h(tt + ASP_RING - 1, hs);
+        issue_x(tt + ASP_RING, xs);
+        wait_vm<ASP_YOUNGER>();
         lds_barrier();
         hs = hs == ASP_HRING - 1 ? 0 : hs + 1;   // now the slot of h(tt)  ... and of h(tt+6) next step
         xs = xs == ASP_XRING - 1 ? 0 : xs + 1;   // the slot of x(tt+1)   ... and of x(tt+7) next step
