@@ -1078,3 +1078,10 @@ def test_gpu_bench_under_a_launcher_runs_its_collectives_on_the_rccl_group():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['ranks'] == {'seen_at_rendezvous': 1, 'rccl_world_size': 1, 'launcher': 'torch.distributed.run'}
     assert d['value'] > 10000 and d['parity']['max_one_minus_cos'] < 1e-4
+    # round 6: the box yard-stick travels with every line -- streaming copy, bare MFMA rate and clock, and the clock INSIDE a ring-GEMM launch
+    # (MvConv1dDesc.clock_probe): sane ranges for an MI355X, and the in-kernel clock at or below the bare-MFMA one
+    box = d['box']
+    assert 'error' not in box and 'ring_k3072_error' not in box, box
+    assert 1500 < box['copy_gbs'] < 8000 and 800 < box['mfma_f16_tflops'] < 2600, box
+    assert 0.8 < box['ring_k3072_clock_ghz'] <= box['short_launch_clock_ghz'] + 0.05 and 0.8 < box['mfma_clock_ghz'] < 2.6, box
+    assert 0.2 < box['ring_k3072_frac_of_2p5pf'] < box['ring_k3072_frac_at_sustained_clock'] < 1.0, box
