@@ -9,7 +9,7 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $REPO
 for rep in 1 2 3; do
-  for lib in product ring_dma8 ring_dma2 ring_dmalate; do
+  for lib in; do
     if [ $lib = product ]; then unset MV_PROBE_LIB; else export MV_PROBE_LIB=$REPO/tools/probe/lib$lib.so; fi
     MV_BENCH_CLOCK=1 MV_BENCH_TILES=256 MV_BENCH_SHAPES="c2c 1024,mfa 3072" timeout 300 python tools/bench_conv.py 2>/dev/null | grep "^{" | python -c "
 import sys, json
@@ -21,7 +21,7 @@ unset MV_PROBE_LIB
 P0=$REPO/voiceprintrecognition-pytorch_amd/mvector/lib/libmvector_hip.so
 cd /tmp && export TMPDIR=/tmp
 for rep in 1 2; do
-  for lib in product gate_u2 gate_g8k gate_g2k; do
+  for lib in product gate_g8k gate_g16384 gate_g65536; do
     if [ $lib = product ]; then P=$P0; else P=$REPO/tools/probe/lib$lib.so; fi
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$lib -o k -- python $REPO/tools/bench_with_lib.py $P --no-cpu-baseline --no-other-configs --no-box > $OUT/b.log 2>&1
     f=$(find $OUT/prof_$lib -name "*kernel_stats.csv" | head -1)

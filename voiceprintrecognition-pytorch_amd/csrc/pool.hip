@@ -11,6 +11,16 @@
 
 namespace mv {
 
+// Grid of the element-wise passes (one 16-byte group per thread): ONE group per thread, no grid-stride walk over a capped grid.  Round 6 (r15n / o):
+// se_gate_residual over [256 x 298, 1024] with 2048 / 4096 / 8192 / 16384 / 38144 (= all) workgroups 82.7 / 82.1 / 78.9 / 76.6 / 73.1 us -- the kernels keep their
+// loops (a cap of 2^20 workgroups still bounds the grid), the hardware's workgroup dispatcher spreads the memory traffic better than a fixed stride does.
+constexpr int64_t EW_MAX_GRID = (int64_t)1 << 20;
+static inline int ew_grid(int64_t groups) {
+    const int64_t g = (groups + 255) / 256;
+    return (int)(g < 1 ? 1 : (g < EW_MAX_GRID ? g : EW_MAX_GRID));
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // mean / std over time.  Workgroup = (utterance, 128-channel group): lane (c16 = lane & 15) owns 8 channels, the four
 // 16-lane groups of a wave and the four waves take interleaved time steps (16 rows in flight per workgroup), so a
@@ -228,7 +238,7 @@ int se_gate_residual_launch(const half_t* y, int64_t ldy, const float* gate, con
     MV_REQUIRE(C % 8 == 0 && ldy % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0, "se_gate_residual: channels must be a multiple of 8");
     const int64_t n_rows = (int64_t)B * T;
     const int64_t total = n_rows * (C / 8);
-    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    const int grid = ew_grid(total);
     MV_LAUNCH(se_gate_residual_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, y, ldy, gate, res, ldr, out, ldo, T, C, n_rows);
     return check_launch("se_gate_residual_kernel");
 }
@@ -264,7 +274,7 @@ int cast_rows_f32_f16_launch(const float* src, int64_t lds_, half_t* dst, int64_
                              hipStream_t stream) {
     MV_REQUIRE(src != nullptr && dst != nullptr && ldd >= C, "cast_rows: bad argument");
     const int64_t total = n_rows * ldd;
-    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    const int grid = ew_grid(total);
     MV_LAUNCH(cast_rows_f32_f16_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, lds_, dst, ldd, n_rows, C);
     return check_launch("cast_rows_f32_f16_kernel");
 }
@@ -294,7 +304,7 @@ int cast_reflect_pad_launch(const float* src, half_t* dst, int B, int T, int C, 
     MV_REQUIRE(src != nullptr && dst != nullptr && pad >= 0 && pad < T && C % 8 == 0, "cast_reflect_pad: bad argument");
     const int64_t total = (int64_t)B * (T + 2 * pad) * (C / 8);
     MV_REQUIRE(total < (int64_t)1 << 31, "cast_reflect_pad: batch too large");
-    const int grid = (int)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    const int grid = ew_grid(total);
     MV_LAUNCH(cast_reflect_pad_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, dst, B, T, C, pad);
     return check_launch("cast_reflect_pad_kernel");
 }
@@ -302,7 +312,7 @@ int cast_reflect_pad_launch(const float* src, half_t* dst, int B, int T, int C, 
 int copy_slice_launch(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int C, int64_t n_rows, hipStream_t stream) {
     MV_REQUIRE(C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_slice: channels must be a multiple of 8");
     const int64_t total = n_rows * (C / 8);
-    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    const int grid = ew_grid(total);
     MV_LAUNCH(copy_slice_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, src, lds_, dst, ldd, C, n_rows);
     return check_launch("copy_slice_kernel");
 }
@@ -363,7 +373,7 @@ int bn_relu_rows_launch(const half_t* x, int64_t ldx, const float* scale, const 
                    (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(shift) & 15) == 0,
                "bn_relu_rows: rows and parameters must be 16-byte aligned, channels a multiple of 8");
     const int64_t total = n_rows * (C / 8);
-    const int grid = (int)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+    const int grid = ew_grid(total);
     MV_LAUNCH(bn_relu_rows_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, x, ldx, scale, shift, y, ldy, n_rows, C / 8);
     return check_launch("bn_relu_rows_kernel");
 }
@@ -372,7 +382,7 @@ int asp_hidden_act_launch(half_t* zh, const float* row_bias, const float* scale,
     MV_REQUIRE(zh != nullptr && row_bias != nullptr && scale != nullptr && shift != nullptr, "asp_hidden_act: null tensor");
     MV_REQUIRE(B > 0 && T > 0 && A > 0 && A % 8 == 0, "asp_hidden_act: bad geometry");
     const int64_t total8 = (int64_t)B * T * (A / 8);
-    const int grid = (int)(ceil_div(total8, 256) < 4096 ? ceil_div(total8, 256) : 4096);
+    const int grid = ew_grid(total8);
     MV_LAUNCH(asp_hidden_act_kernel, (grid, 1, 1), (256, 1, 1), 0, stream, zh, row_bias, scale, shift, total8, T, A / 8);
     return check_launch("asp_hidden_act_kernel");
 }
