@@ -206,6 +206,14 @@ def box_probe(dev, copy_bytes=1 << 30, mfma_ms=1.0):
             ts.append(e0.elapsed_time(e1))
         return sorted(ts)[len(ts) // 2]
 
+    # the product's own kernel first: behind the bare-MFMA loop below the chip's power management holds the clock down for a while (r15m / r15z: the same
+    # ring launch 1.48 GHz and 1542 us behind it, 1.6-1.7 GHz and 1330-1390 us in tools/bench_conv.py and inside a step)
+    ring = {}
+    try:
+        ring = ring_clock_probe(dev, cus)
+    except Exception as ex:
+        ring = {'ring_k3072_error': f'{type(ex).__name__}: {ex}'}
+    torch.cuda.empty_cache()
     src = torch.empty(copy_bytes, dtype=torch.uint8, device=dev).fill_(1)
     dst = torch.empty_like(src)
 
@@ -238,10 +246,7 @@ def box_probe(dev, copy_bytes=1 << 30, mfma_ms=1.0):
            'short_launch_clock_ghz': round(idle_clock, 3), 'short_launch_us': round(t_short * 1e3, 1),
            'note': 'yard-stick of this box, taken before the timed region: streaming copy (read + write bytes), bare v_mfma_f32_16x16x32_f16 at one '
                    '512-thread workgroup per CU, shader clock = s_memtime / s_memrealtime (100 MHz) inside that kernel (median workgroup)'}
-    try:
-        out.update(ring_clock_probe(dev, cus))
-    except Exception as ex:
-        out['ring_k3072_error'] = f'{type(ex).__name__}: {ex}'
+    out.update(ring)
     torch.cuda.empty_cache()
     return out
 
@@ -271,8 +276,8 @@ def ring_clock_probe(dev, cus, B=256, T=298, C=3072):
     d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, C, C, 1, 1, 1
     d.pad, d.pad_mode, d.tile = 0, _hip.MV_PAD_REFLECT, 256
     d.clock_probe = probe.data_ptr()
-    for _ in range(2):
-        _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), st), cdll)
+    for _ in range(24):   # ~35 ms of the same launch first: from an idle chip the first launches run 10-15 % slower at a lower clock (r15r: 1515-1550 us at
+        _hip.check(cdll.mv_conv1d_forward(ctypes.byref(d), st), cdll)   # 1.50-1.57 GHz with two warm-ups; the layer inside a step: 1330-1390 us)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 4   # back to back, as the layer runs inside a step (a lone launch between two synchronisations measures ~10 % longer: launch ramp and tail)
     e0.record()
@@ -569,8 +574,11 @@ def rendezvous(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    # defaults (round 6): 10 + 60 steps = 0.23 s of device time.  The chip's clock under a given kernel depends on how long it has been under load (the box
+    # block's ring launch: 1.50-1.57 GHz behind two warm-up launches, 1.80 GHz behind twenty-four): with 5 + 20 steps the headline read 76.7-76.8 k, with
+    # 30-100 warm-up steps or 100-300 timed ones 77.1-77.8 k on the same box (profiles/r15t)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=256, help='utterances per GPU')
     ap.add_argument('--model', default='ecapa1024', choices=sorted(MODELS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
