@@ -10,7 +10,7 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd $REPO
 for rep in 1 2; do
-  for lib in product ring_probe_fewreads ring_probe_nobf1 ring_probe_now; do
+  for lib in product ring_probe_noepi ring_probe_nostore; do
     if [ $lib = product ]; then unset MV_PROBE_LIB; else export MV_PROBE_LIB=$REPO/tools/probe/lib$lib.so; fi
     MV_BENCH_CLOCK=1 MV_BENCH_TILES=256 MV_BENCH_SHAPES="c2c 1024,mfa 3072" timeout 300 python tools/bench_conv.py 2>/dev/null | grep "^{" | python -c "
 import sys, json
