@@ -247,6 +247,16 @@ def box_probe(dev, copy_bytes=1 << 30, mfma_ms=1.0):
            'note': 'yard-stick of this box, taken before the timed region: streaming copy (read + write bytes), bare v_mfma_f32_16x16x32_f16 at one '
                    '512-thread workgroup per CU, shader clock = s_memtime / s_memrealtime (100 MHz) inside that kernel (median workgroup)'}
     out.update(ring)
+    try:   # what the platform says about the card (read-only): performance level, power cap, temperature behind the probes
+        import subprocess
+        smi = json.loads(subprocess.run(['rocm-smi', '--showperflevel', '--showmaxpower', '--showpower', '--showtemp', '--json'], capture_output=True, text=True,
+                                        timeout=10).stdout)
+        card = smi.get(f'card{dev.index or 0}', {})
+        out['smi'] = {'performance_level': card.get('Performance Level'), 'max_power_w': card.get('Max Graphics Package Power (W)'),
+                      'power_w_after_probes': card.get('Current Socket Graphics Package Power (W)'),
+                      'junction_temperature_c': card.get('Temperature (Sensor junction) (C)')}
+    except Exception as ex:
+        out['smi'] = {'error': f'{type(ex).__name__}: {ex}'[:200]}
     torch.cuda.empty_cache()
     return out
 
