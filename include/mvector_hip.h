@@ -470,6 +470,7 @@ int mv_bn_relu_rows_f16(const void* x, int64_t ldx, const float* scale, const fl
 #define MV_PROF_CONV1D 0
 #define MV_PROF_FBANK 1
 #define MV_PROF_CONV2D 2 /* work = 2*B*Ho*Wo*cin*cout*ks*ks FLOPs on the layer's own (unpadded) channel counts */
+#define MV_PROF_CONV1D_RING 3 /* since ABI 5: the launches of the dense 1x1 persistent (ring) GEMM alone -- a subset of MV_PROF_CONV1D, which keeps counting them */
 int mv_profile_enable(int32_t on);
 int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, double* total_work, int32_t reset);
 

@@ -406,6 +406,34 @@ def conv2d_first_case(cdll, device, B=2, T=50, F_=16, C=32, seed=0, s16=False):
     return err
 
 
+def profile_classes_case(cdll, device):
+    """mv_profile_read classes (include/mvector_hip.h): a ring-kernel launch is recorded as MV_PROF_CONV1D_RING (3) AND counted by a read of
+    MV_PROF_CONV1D (0); any other conv1d launch is class 0 only.  bench.py's `roofline` (the ring kernel alone) and `roofline_conv1d_class` rest on it."""
+    import ctypes
+    def read(k, reset=0):
+        n, ms, w = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _hip.check(cdll.mv_profile_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(w), reset), cdll)
+        return n.value, ms.value, w.value
+    read(0, 1)
+    cdll.mv_profile_enable(1)
+    try:
+        ring = dict(k=1, dil=1, cin=128, cout=256, T=150, B=2, tile=256)                       # dense 1x1 rows, no statistics: the ring kernel
+        taps = dict(k=3, dil=2, cin=64, cout=256, T=130, B=2, tile=256, pre_act=0, affine=False)   # persistent, taps: the double-buffer kernel
+        conv1d_case(cdll, device, seed=1, **ring)
+        assert read(3)[0] == 1 and read(0)[0] == 1
+        conv1d_case(cdll, device, seed=2, **taps)
+        conv1d_case(cdll, device, seed=3)                                                      # small non-persistent layer
+        n3, ms3, w3 = read(3)
+        n0, ms0, w0 = read(0)
+        assert (n3, n0) == (1, 3), (n3, n0)
+        assert w3 == 2.0 * 2 * 150 * 128 * 256 and w0 > w3 and ms0 >= ms3 >= 0.0
+        assert read(1)[0] == 0 and read(2)[0] == 0
+    finally:
+        cdll.mv_profile_enable(0)
+        read(0, 1)
+    assert read(3)[0] == 0
+
+
 CONV_CASES = [
     dict(),                                                           # reflect k3 d2
     dict(k=5, dil=1, cin=80, cout=64, x_f32=True, T=50),              # first layer: fp32 features in

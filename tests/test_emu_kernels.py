@@ -41,6 +41,10 @@ def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
 
 
+def test_emu_profile_classes_ring_is_a_subset_of_conv1d():
+    lc.profile_classes_case(emu_cdll(), 'cpu')
+
+
 def test_emu_conv1d_input_statistics_two_launch_forms_agree():
     """fused kernel (3 utterances on the emulator's 8-CU chip) vs stand-alone statistics + small-tile conv (1 utterance): identical bits"""
     lc.in_stats_forms_case(emu_cdll(), 'cpu', B_big=3, T=298, cin=192)

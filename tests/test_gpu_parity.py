@@ -59,6 +59,10 @@ def test_conv1d_window(cfg):
     lc.conv1d_window_case(product_lib(), DEV, **cfg)
 
 
+def test_gpu_profile_classes_ring_is_a_subset_of_conv1d():
+    lc.profile_classes_case(product_lib(), DEV)
+
+
 @pytest.mark.parametrize('idx', range(len(lc.CONV_CASES)))
 def test_gpu_conv1d(idx):
     lc.conv1d_case(product_lib(), DEV, seed=idx, **lc.CONV_CASES[idx])

@@ -11,6 +11,8 @@ timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke r
 timeout 1200 python bench.py > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?"; python - <<PY
 import json
 d = json.loads([l for l in open('$OUT/bench.log') if l.startswith('{')][-1])
+rc = d.get('roofline_conv1d_class', {})
+print('ring', d['roofline']['frac'], d['roofline']['launches'], d['roofline']['avg_launch_us'], d['roofline']['share_of_step'], 'class', rc.get('frac'), rc.get('launches'), rc.get('share_of_step'))
 print('headline', d['value'], d['ms_per_step'], 'conv frac', d['roofline']['frac'], 'fbank', d['roofline_fbank']['avg_launch_us'], d['roofline_fbank']['frac'])
 print('box', {k: v for k, v in d['box'].items() if k != 'note'})
 for k, v in d.get('other_configs', {}).items():

@@ -73,7 +73,7 @@ int mv_profile_read(int32_t kernel_class, int32_t* calls, double* total_ms, doub
     *total_ms = 0.0;
     *total_work = 0.0;
     for (const auto& r : mv::g_prof) {
-        if (r.cls != kernel_class) continue;
+        if (r.cls != kernel_class && !(kernel_class == MV_PROF_CONV1D && r.cls == MV_PROF_CONV1D_RING)) continue;   // (the ring GEMM's launches are conv1d launches)
         MV_HIP_OK(hipEventSynchronize(r.stop));
         float ms = 0.0f;
         MV_HIP_OK(hipEventElapsedTime(&ms, r.start, r.stop));

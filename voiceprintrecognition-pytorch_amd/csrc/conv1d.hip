@@ -1778,15 +1778,16 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
             return fail(MV_ERR_HIP, "conv1d: cannot reserve dynamic LDS");
         device_once_done(smem_set, smem_set_slot);
     }
-    const int prof = prof_begin(MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
+    const bool simple = d.k == 1 && d.cin % CV_BK == 0;
+    // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
+    const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
+                            (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
+    const bool ring = persist && stats == 0 && dense_rows;
+    const int prof = prof_begin(ring ? MV_PROF_CONV1D_RING : MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks(d) ? round_up(tiles, 8) : persistent_blocks(d));
-        const bool simple = d.k == 1 && d.cin % CV_BK == 0;
-        // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
-        const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
-                                (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
-        if (stats == 0 && dense_rows) {
+        if (ring) {
             MV_LAUNCH(conv1d_ring_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVR_LDS_BYTES, stream, a);
         } else if (stats == 2) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
