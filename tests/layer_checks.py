@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0, clock_probe=False):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0, clock_probe=False, return_y=False):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -151,7 +151,32 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
         got2 = sumdst.cpu().float()
         assert torch.all(got2[..., cout:] == 5.0)
         assert (got2[..., :cout] - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
-    return err
+    return y.cpu() if return_y else err
+
+
+def ring_tail_case(cdll, device, blocks=8, profile=True, **cfg):
+    """The ring GEMM's tail (conv1d_launch): with `blocks` resident workgroups the walk's last partial round runs as 128 x 128 quarter tiles on the
+    four-stage form of the 128 x 128 kernel; with one workgroup per tile (blocks = a multiple of 8 >= the tile count) nothing is split.  Both launches
+    pass conv1d_case's check against torch -- and carry THE SAME BITS (a row / channel split keeps every element's accumulation order).  Returns the
+    numbers of (ring, all conv1d) launches the split form recorded."""
+    import ctypes
+    def read(k, reset=0):
+        n, ms, w = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _hip.check(cdll.mv_profile_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(w), reset), cdll)
+        return n.value, w.value
+    read(0, 1)
+    cdll.mv_profile_enable(1)
+    try:
+        y_split = conv1d_case(cdll, device, persist_blocks=blocks, return_y=True, **cfg)
+        (n3, w3), (n0, w0) = read(3), read(0)
+    finally:
+        cdll.mv_profile_enable(0)
+        read(0, 1)
+    y_whole = conv1d_case(cdll, device, persist_blocks=4096, return_y=True, **cfg)
+    assert torch.equal(y_split, y_whole), (y_split.float() - y_whole.float()).abs().max().item()
+    B, T, cin, cout = cfg['B'], cfg['T'], cfg['cin'], cfg['cout']
+    assert w0 == 2.0 * B * T * cin * cout, (w0, 2.0 * B * T * cin * cout)   # ring part + quarters = the layer's algorithmic FLOPs
+    return n3, n0, w3, w0
 
 
 def conv1d_window_case(cdll, device, B=3, T=300, F_=80, k=5, cout=512, tile=0, seed=0):

@@ -45,6 +45,16 @@ def test_emu_profile_classes_ring_is_a_subset_of_conv1d():
     lc.profile_classes_case(emu_cdll(), 'cpu')
 
 
+@pytest.mark.parametrize('cfg,blocks,launches', [
+    (dict(k=1, dil=1, cin=512, cout=512, T=298, B=19, tile=256), 40, 2),   # 23 x 2 tiles, 48 virtual ids: one round of 40 + 8 ids (7 tiles, ragged rows) as 28 quarters
+    (dict(k=1, dil=1, cin=256, cout=512, T=298, B=19, tile=256), 40, 1),   # four K stages: below the tail's threshold
+    (dict(k=1, dil=1, cin=512, cout=512, T=300, B=12, tile=256), 24, 1),   # 7 tiles in the partial round = 28 quarters > 24 workgroups: not split
+])
+def test_emu_ring_tail_quarter_tiles_carry_the_same_bits(cfg, blocks, launches):
+    n3, n0, w3, w0 = lc.ring_tail_case(emu_cdll(), 'cpu', blocks=blocks, **cfg)
+    assert (n3, n0) == (1, launches) and (w3 < w0) == (launches == 2)
+
+
 def test_emu_conv1d_input_statistics_two_launch_forms_agree():
     """fused kernel (3 utterances on the emulator's 8-CU chip) vs stand-alone statistics + small-tile conv (1 utterance): identical bits"""
     lc.in_stats_forms_case(emu_cdll(), 'cpu', B_big=3, T=298, cin=192)

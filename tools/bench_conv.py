@@ -6,7 +6,7 @@ import torch
 from mvector import _hip
 import layer_checks as lc
 lib = _hip.bind_partial(ctypes.CDLL(os.environ['MV_PROBE_LIB'])) if os.environ.get('MV_PROBE_LIB') else _hip.lib()
-B, T = int(os.environ.get('MV_BENCH_B', '256')), 298
+B, T = int(os.environ.get('MV_BENCH_B', '256')), int(os.environ.get('MV_BENCH_T', '298'))
 TILES = [int(t) for t in os.environ.get('MV_BENCH_TILES', '128,256').split(',')]
 shapes = [('c2c 1024->1024 k1', 1024, 1024, 1, 1), ('mfa 3072->3072 k1', 3072, 3072, 1, 1), ('asp 3072->128 k1', 3072, 128, 1, 1),
           ('res2 128->128 k3d3', 128, 128, 3, 3), ('c2c 512->512 k1', 512, 512, 1, 1), ('mfa 1536->1536', 1536, 1536, 1, 1)]
@@ -38,19 +38,32 @@ for name, cin, cout, k, dil in shapes:
             probe = torch.zeros(4 * 264, dtype=torch.int64, device='cuda')
             d.clock_probe = probe.data_ptr()
         st = _hip.current_stream(x)
-        for _ in range(3):
+        for _ in range(int(os.environ.get('MV_BENCH_WARM', '3'))):   # (the chip needs ~30 ms under load to reach its clock: MV_BENCH_WARM=30 for hot figures)
             _hip.check(lib.mv_conv1d_forward(ctypes.byref(d), st))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 10
+        prof = os.environ.get('MV_BENCH_PROF') == '1'   # per-launch HIP events of the library: the ring kernel (class 3) and the other conv1d launches of the call
+        def prof_read(k, reset=0):
+            c, ms, w = ctypes.c_int32(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+            lib.mv_profile_read(k, ctypes.byref(c), ctypes.byref(ms), ctypes.byref(w), reset)
+            return c.value, ms.value
+        if prof:
+            prof_read(0, 1)
+            lib.mv_profile_enable(1)
         e0.record()
         for _ in range(n):
             lib.mv_conv1d_forward(ctypes.byref(d), st)
         e1.record()
         torch.cuda.synchronize()
+        extra = {}
+        if prof:
+            lib.mv_profile_enable(0)
+            (c3, ms3), (c0, ms0) = prof_read(3), prof_read(0, 1)
+            extra = dict(ring_us=round(ms3 / max(c3, 1) * 1e3, 1), other_launches=(c0 - c3) // n, other_us=round((ms0 - ms3) / n * 1e3, 1))
         us = e0.elapsed_time(e1) / n * 1e3
         tf = 2.0 * B * T * cin * cout * k / us / 1e6
-        rec = dict(B=B, shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1))
+        rec = dict(B=B, shape=name, tile=tile, us=round(us, 1), TFLOPs=round(tf, 1), **extra)
         if probe is not None:
             t = probe.cpu().reshape(-1, 4).double()
             t = t[t[:, 3] > t[:, 2]]

@@ -33,6 +33,8 @@ constexpr int CV_LDS_BYTES = 2 * (CV_TC + CV_TN) * CV_BK * 2;  // 64 KiB
 constexpr int CV_LDS_BYTES_WIDE = 2 * (CV_TC + 160) * CV_BK * 2;  // 128 x 160 tile: 72 KiB
 constexpr int CV_SMALL_NS = 4;                                     // K stages of the 64 x 64 kernel's ring (three in flight)
 constexpr int CV_LDS_BYTES_SMALL = CV_SMALL_NS * (64 + 64) * CV_BK * 2;   // 64 x 64 tile (small problems): 64 KiB
+constexpr int CV_TAIL_NS = 4;                                      // K stages of the 128 x 128 kernel's ring when it runs the ring GEMM's tail (conv1d_launch)
+constexpr int CV_LDS_BYTES_TAIL = CV_TAIL_NS * (CV_TC + CV_TN) * CV_BK * 2;   // 128 KiB: one workgroup per CU
 constexpr int CV_LDS_BYTES_BIG = 256 * (256 * 2 + 8);          // 256^2 tile: 2 x 64 KiB stages, 130 KiB staged epilogue
 
 struct ConvArgs {
@@ -63,6 +65,11 @@ struct ConvArgs {
     float* in_sum;
     float* in_sq;
     unsigned long long* clock_probe;  // optional (ring kernel): [workgroup][4] shader-clock / reference ticks at entry and exit
+    // The ring walk's last PARTIAL round as quarter tiles (conv1d_launch, "tail"): the ring kernel stops at virtual tile id ring_vb_end (0: walks all),
+    // and a launch of the 128 x 128 kernel takes the tail_nv virtual ids from tail_vb0 on -- workgroup b computes quarter b / tail_nv of the
+    // 256 x 256 tile (tail_n_tiles x tail_co_tiles geometry) with virtual id tail_vb0 + b % tail_nv.  tail_nv == 0: the kernel's own tile walk.
+    int ring_vb_end = 0;
+    int tail_vb0 = 0, tail_nv = 0, tail_n_tiles = 0, tail_co_tiles = 0;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -417,7 +424,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
     }
 }
 
-__device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n_tile, int& co_tile) {
+__host__ __device__ __forceinline__ bool tile_of_index_geom(int n_tiles, int co_tiles, int bid, int& n_tile, int& co_tile) {
     // XCD-aware super-tiles.  Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with a private L2.
     // XCD x owns the n-tiles x, x+8, ...; inside an XCD the blocks walk groups of <= 8 co-tiles: for each group, for each
     // owned n-tile, for each co-tile of the group.  The ~64 workgroups resident on an XCD therefore cover ~8 n-tiles x 8
@@ -425,18 +432,31 @@ __device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n
     // is reused ~8 times before it is evicted.
     const int xcd = bid & 7;
     const int seq = bid >> 3;
-    const int nx = (a.n_tiles + 7) >> 3;          // n-tiles per XCD (upper bound)
+    const int nx = (n_tiles + 7) >> 3;            // n-tiles per XCD (upper bound)
     const int group = seq / (nx * 8);             // full groups come first
     const int base = group * 8;
-    const int gw = a.co_tiles - base < 8 ? a.co_tiles - base : 8;
+    const int gw = co_tiles - base < 8 ? co_tiles - base : 8;
     const int idx = seq - nx * base;
     const int n_local = idx / gw;
     co_tile = base + idx - n_local * gw;
     n_tile = xcd + 8 * n_local;
-    return n_tile < a.n_tiles;
+    return n_tile < n_tiles;
+}
+
+__device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n_tile, int& co_tile) {
+    return tile_of_index_geom(a.n_tiles, a.co_tiles, bid, n_tile, co_tile);
 }
 
 __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
+    if (a.tail_nv > 0) {   // (uniform) a quarter of a 256 x 256 tile of the ring walk's last partial round; tail_vb0 % 8 == 0 and tail_nv % 8 == 0, so the
+                           // workgroup sits on the XCD the ring walk gives that tile (id mod 8)
+        const int sub = (int)blockIdx.x / a.tail_nv, v = (int)blockIdx.x - sub * a.tail_nv;
+        int nt = 0, ct = 0;
+        if (!tile_of_index_geom(a.tail_n_tiles, a.tail_co_tiles, a.tail_vb0 + v, nt, ct)) return false;
+        n_tile = 2 * nt + (sub & 1);
+        co_tile = 2 * ct + (sub >> 1);
+        return n_tile < a.n_tiles;
+    }
     return tile_of_index(a, blockIdx.x, n_tile, co_tile);
 }
 
@@ -1243,7 +1263,8 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     const int wc = wave / 4, wn = wave % 4;
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ (lrow & 7);
-    const int total = ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;  // virtual workgroup ids of tile_of_index
+    // virtual workgroup ids of tile_of_index -- all of them, or the whole rounds only (the launcher hands the last partial round to quarter tiles)
+    const int total = a.ring_vb_end > 0 ? a.ring_vb_end : ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;
     const int step = (int)gridDim.x;
     unsigned long long clk0 = 0, ref0 = 0;   // (scalar registers) MvConv1dDesc.clock_probe
     if (a.clock_probe != nullptr) {
@@ -1764,6 +1785,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     if (device_once_pending(smem_set, &smem_set_slot)) {
         if (MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 4>), CV_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 2, 2, false, CV_SMALL_NS>), CV_LDS_BYTES_SMALL) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<4, 2, 2, 4, false, CV_TAIL_NS>), CV_LDS_BYTES_TAIL) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
@@ -1783,12 +1805,65 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
                             (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
     const bool ring = persist && stats == 0 && dense_rows;
-    const int prof = prof_begin(ring ? MV_PROF_CONV1D_RING : MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k, stream);
+    // The ring walk's tail.  A launch lasts as many tile times as its longest walk: 3600 tiles of the MFA layer (76 800 rows x 3072 channels) on 256
+    // workgroups are 14.06 rounds, so 15 -- the last one with 48 workgroups at work.  Splitting K over workgroups (stream-K) would fill it, but sums a tile
+    // in another order, and WHICH tiles are split follows the batch: a row's bits would depend on its neighbours.  Splitting a tile's ROWS and CHANNELS
+    // keeps every output element's sum as it is (test_gpu_embedding_bits_do_not_depend_on_the_batch_size holds the 64 / 128 / 256 tiles to one
+    // accumulation order): when the last partial round's tiles, cut into four 128 x 128 quarters, still fit one round of the chip, the ring kernel walks
+    // the whole rounds only and the quarters run at once on the 128 x 128 kernel with a four-stage ring (128 KiB of LDS, one workgroup per CU), eight
+    // waves of 32 channels x 64 rows.  Measured (r15ae, per-launch events, MFA layer of the headline batch): the ring part 1253-1269 -> 1202-1210 us --
+    // the last round costs 55 us, not a tile time of 84: its 48 workgroups have the memory system to themselves --, the quarters 44 us with eight waves
+    // (60 with four of 64 x 64: one wave per SIMD cannot overlap its fragment reads with its MFMAs; three stages in flight instead of two change
+    // nothing: the 128 x 128 tile is bound by LDS bandwidth, 96 KiB of fragment reads + 32 KiB of transfers per stage = ~0.9 us where the ring
+    // kernel's 256 x 256 stage of four times the FLOPs takes 1.7).  So a tail that needs more than one round of quarters does not pay (the K = 1024
+    // layers: 176 tiles in the last round = 2.75 rounds of quarters), and K stages below eight are not worth a second launch.
+    int tail_vb0 = 0, tail_nv = 0;
+    double tail_work = 0.0;
+    if (ring) {
+        const int blocks = persistent_blocks(d);
+        const int total_v = (int)round_up(a.n_tiles, 8) * a.co_tiles;
+        const int whole = total_v / blocks * blocks;
+        if (whole > 0 && whole < total_v && a.cin_pad / CV_BK >= 8) {
+            int valid = 0;
+            for (int v = whole; v < total_v; ++v) {
+                int nt = 0, ct = 0;
+                if (!tile_of_index_geom(a.n_tiles, a.co_tiles, v, nt, ct)) continue;
+                ++valid;
+                const int rows = a.n_rows - nt * 256 < 256 ? a.n_rows - nt * 256 : 256;
+                tail_work += 2.0 * rows * 256.0 * (double)d.cin;
+            }
+            if (valid > 0 && 4 * valid <= blocks) {
+                tail_vb0 = whole;
+                tail_nv = total_v - whole;   // (a multiple of 8, like `whole`)
+            }
+        }
+        if (tail_nv == 0) tail_work = 0.0;
+    }
+    const int prof = prof_begin(ring ? MV_PROF_CONV1D_RING : MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k - tail_work, stream);
     if (persist) {
         const int64_t tiles = (int64_t)a.n_tiles * a.co_tiles;
         const int pgrid = (int)(tiles < persistent_blocks(d) ? round_up(tiles, 8) : persistent_blocks(d));
         if (ring) {
+            a.ring_vb_end = tail_vb0;
             MV_LAUNCH(conv1d_ring_persistent_kernel, (pgrid, 1, 1), (512, 1, 1), CVR_LDS_BYTES, stream, a);
+            if (tail_nv > 0) {
+                prof_end(prof, stream);
+                int rc = check_launch("conv1d_ring_persistent_kernel");
+                if (rc != MV_OK) return rc;
+                ConvArgs t = a;
+                t.ring_vb_end = 0;
+                t.clock_probe = nullptr;
+                t.tail_vb0 = tail_vb0;
+                t.tail_nv = tail_nv;
+                t.tail_n_tiles = a.n_tiles;
+                t.tail_co_tiles = a.co_tiles;
+                t.n_tiles = (int)ceil_div(a.n_rows, CV_TN);
+                t.co_tiles = (int)ceil_div(d.cout, CV_TC);
+                const int tprof = prof_begin(MV_PROF_CONV1D, tail_work, stream);
+                MV_LAUNCH((conv1d_glds_kernel<4, 2, 2, 4, false, CV_TAIL_NS>), (4 * tail_nv, 1, 1), (512, 1, 1), CV_LDS_BYTES_TAIL, stream, t);
+                prof_end(tprof, stream);
+                return check_launch("conv1d_glds_kernel (ring tail)");
+            }
         } else if (stats == 2) {
             MV_LAUNCH((conv1d_glds_persistent_kernel<true, 2>), (pgrid, 1, 1), (512, 1, 1), CVP_LDS_BYTES, stream, a);
         } else if (stats == 1) {
