@@ -155,8 +155,8 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
 
 
 def ring_tail_case(cdll, device, blocks=8, profile=True, **cfg):
-    """The ring GEMM's tail (conv1d_launch): with `blocks` resident workgroups the walk's last partial round runs as 128 x 128 quarter tiles on the
-    four-stage form of the 128 x 128 kernel; with one workgroup per tile (blocks = a multiple of 8 >= the tile count) nothing is split.  Both launches
+    """The ring GEMM's tail (conv1d_launch): with `blocks` resident workgroups the walk's last partial round runs as 64 x 64 / 128 x 128 sub-tiles on the
+    four-stage forms of the small-tile kernels; with one workgroup per tile (blocks = a multiple of 8 >= the tile count) nothing is split.  Both launches
     pass conv1d_case's check against torch -- and carry THE SAME BITS (a row / channel split keeps every element's accumulation order).  Returns the
     numbers of (ring, all conv1d) launches the split form recorded."""
     import ctypes

@@ -46,11 +46,12 @@ def test_emu_profile_classes_ring_is_a_subset_of_conv1d():
 
 
 @pytest.mark.parametrize('cfg,blocks,launches', [
-    (dict(k=1, dil=1, cin=512, cout=512, T=298, B=19, tile=256), 40, 2),   # 23 x 2 tiles, 48 virtual ids: one round of 40 + 8 ids (7 tiles, ragged rows) as 28 quarters
-    (dict(k=1, dil=1, cin=256, cout=512, T=298, B=19, tile=256), 40, 1),   # four K stages: below the tail's threshold
-    (dict(k=1, dil=1, cin=512, cout=512, T=300, B=12, tile=256), 24, 1),   # 7 tiles in the partial round = 28 quarters > 24 workgroups: not split
+    (dict(k=1, dil=1, cin=512, cout=512, T=250, B=5, tile=256), 8, 2),     # 5 x 2 = 10 tiles: one round of 8 + 2 tiles (the ragged last rows) as 8 quarters
+    (dict(k=1, dil=1, cin=512, cout=256, T=290, B=15, tile=256), 16, 2),   # 17 tiles: one round of 16 + the tile of the ragged last rows as 16 sixteenths
+    (dict(k=1, dil=1, cin=256, cout=512, T=250, B=5, tile=256), 8, 1),     # four K stages: below the tail's threshold
+    (dict(k=1, dil=1, cin=512, cout=512, T=250, B=6, tile=256), 8, 1),     # 4 tiles in the partial round = 16 quarters > 8 workgroups: not split
 ])
-def test_emu_ring_tail_quarter_tiles_carry_the_same_bits(cfg, blocks, launches):
+def test_emu_ring_tail_sub_tiles_carry_the_same_bits(cfg, blocks, launches):
     n3, n0, w3, w0 = lc.ring_tail_case(emu_cdll(), 'cpu', blocks=blocks, **cfg)
     assert (n3, n0) == (1, launches) and (w3 < w0) == (launches == 2)
 

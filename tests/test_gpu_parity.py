@@ -81,13 +81,14 @@ def test_gpu_conv1d_persistent_walks_many_tiles():
 
 
 @pytest.mark.parametrize('cfg,blocks,launches', [
-    (dict(k=1, dil=1, cin=512, cout=512, T=298, B=19, tile=256), 40, 2),
-    (dict(k=1, dil=1, cin=512, cout=768, T=300, B=21, tile=256), 64, 2),     # 25 x 3 tiles, 96 virtual ids: 11 valid tiles of the last 32 ids as 44 quarters
-    (dict(k=1, dil=1, cin=3072, cout=3072, T=300, B=128), 0, 2),              # half the headline batch through the MFA layer on the whole chip: 1800 tiles = 7.03 rounds
+    (dict(k=1, dil=1, cin=512, cout=512, T=298, B=19, tile=256), 40, 2),     # 6 of 46 tiles as 24 quarters (ragged last rows)
+    (dict(k=1, dil=1, cin=512, cout=768, T=300, B=21, tile=256), 64, 2),     # 11 of 75 tiles as 44 quarters
+    (dict(k=1, dil=1, cin=512, cout=512, T=300, B=14, tile=256), 32, 2),     # 2 of 34 tiles as 32 sixteenths
+    (dict(k=1, dil=1, cin=3072, cout=3072, T=300, B=128), 0, 2),              # half the headline batch through the MFA layer on the whole chip: 1800 tiles = 7 rounds + 8 tiles as 128 sixteenths
     (dict(k=1, dil=1, cin=1024, cout=1024, T=300, B=256), 0, 1),              # a K = 1024 layer of the headline batch: 176 tiles in the last round, not split
 ])
-def test_gpu_ring_tail_quarter_tiles_carry_the_same_bits(cfg, blocks, launches):
-    """conv1d_launch runs the ring GEMM walk's last partial round as 128 x 128 quarter tiles when they fit one round of the chip: same bits as the
+def test_gpu_ring_tail_sub_tiles_carry_the_same_bits(cfg, blocks, launches):
+    """conv1d_launch runs the ring GEMM walk's last partial round as 64 x 64 or 128 x 128 sub-tiles when they fit one round of the chip: same bits as the
     unsplit launch, the profile classes add up to the layer's FLOPs"""
     n3, n0, w3, w0 = lc.ring_tail_case(product_lib(), DEV, blocks=blocks, **cfg)
     assert (n3, n0) == (1, launches) and (w3 < w0) == (launches == 2)

@@ -69,7 +69,7 @@ struct ConvArgs {
     // and a launch of the 128 x 128 kernel takes the tail_nv virtual ids from tail_vb0 on -- workgroup b computes quarter b / tail_nv of the
     // 256 x 256 tile (tail_n_tiles x tail_co_tiles geometry) with virtual id tail_vb0 + b % tail_nv.  tail_nv == 0: the kernel's own tile walk.
     int ring_vb_end = 0;
-    int tail_vb0 = 0, tail_nv = 0, tail_n_tiles = 0, tail_co_tiles = 0;
+    int tail_vb0 = 0, tail_nv = 0, tail_n_tiles = 0, tail_co_tiles = 0, tail_split = 2;   // tail_split: sub-tiles per side of a 256 x 256 tile (2: 128 x 128, 4: 64 x 64)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -425,22 +425,32 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs& a, char* sm
 }
 
 __host__ __device__ __forceinline__ bool tile_of_index_geom(int n_tiles, int co_tiles, int bid, int& n_tile, int& co_tile) {
-    // XCD-aware super-tiles.  Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with a private L2.
-    // XCD x owns the n-tiles x, x+8, ...; inside an XCD the blocks walk groups of <= 8 co-tiles: for each group, for each
-    // owned n-tile, for each co-tile of the group.  The ~64 workgroups resident on an XCD therefore cover ~8 n-tiles x 8
-    // co-tiles and stream K in near lockstep, so every activation slice and every weight slice fetched into that L2
-    // is reused ~8 times before it is evicted.
+    // XCD-aware super-tiles over a DENSE id space: ids 0 .. n_tiles * co_tiles - 1 are all tiles (round 6: the walk used to run over
+    // round_up(n_tiles, 8) * co_tiles virtual ids with holes where an XCD owned one n-tile fewer -- 48 of 3648 on the MFA layer of the headline batch,
+    // which left 32 persistent workgroups a tile short and 48 instead of 16 tiles in the last partial round).
+    // Workgroup ids are dealt round-robin to the 8 XCDs (id mod 8), each with a private L2.  XCD x owns the n-tiles x, x+8, ... of the `nfull` complete
+    // rows of eight; inside an XCD the blocks walk groups of <= 8 co-tiles: for each group, for each owned n-tile, for each co-tile of the group.  The
+    // ~64 workgroups resident on an XCD therefore cover ~8 n-tiles x 8 co-tiles and stream K in near lockstep, so every activation slice and every
+    // weight slice fetched into that L2 is reused ~8 times before it is evicted.  The n_tiles % 8 leftover n-tiles come last, co-tile by co-tile.
+    const int nfull = n_tiles >> 3, rest = n_tiles & 7;
+    const int main_ids = nfull * 8 * co_tiles;
+    if (bid >= main_ids) {
+        const int j = bid - main_ids;
+        if (j >= rest * co_tiles) return false;
+        co_tile = j / rest;
+        n_tile = 8 * nfull + j - co_tile * rest;
+        return true;
+    }
     const int xcd = bid & 7;
     const int seq = bid >> 3;
-    const int nx = (n_tiles + 7) >> 3;            // n-tiles per XCD (upper bound)
-    const int group = seq / (nx * 8);             // full groups come first
+    const int group = seq / (nfull * 8);          // full groups come first
     const int base = group * 8;
     const int gw = co_tiles - base < 8 ? co_tiles - base : 8;
-    const int idx = seq - nx * base;
+    const int idx = seq - nfull * base;
     const int n_local = idx / gw;
     co_tile = base + idx - n_local * gw;
     n_tile = xcd + 8 * n_local;
-    return n_tile < n_tiles;
+    return true;
 }
 
 __device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n_tile, int& co_tile) {
@@ -448,13 +458,13 @@ __device__ __forceinline__ bool tile_of_index(const ConvArgs& a, int bid, int& n
 }
 
 __device__ __forceinline__ bool tile_of_block(const ConvArgs& a, int& n_tile, int& co_tile) {
-    if (a.tail_nv > 0) {   // (uniform) a quarter of a 256 x 256 tile of the ring walk's last partial round; tail_vb0 % 8 == 0 and tail_nv % 8 == 0, so the
+    if (a.tail_nv > 0) {   // (uniform) a sub-tile of a 256 x 256 tile of the ring walk's last partial round; tail_vb0 % 8 == 0, so
                            // workgroup sits on the XCD the ring walk gives that tile (id mod 8)
         const int sub = (int)blockIdx.x / a.tail_nv, v = (int)blockIdx.x - sub * a.tail_nv;
         int nt = 0, ct = 0;
         if (!tile_of_index_geom(a.tail_n_tiles, a.tail_co_tiles, a.tail_vb0 + v, nt, ct)) return false;
-        n_tile = 2 * nt + (sub & 1);
-        co_tile = 2 * ct + (sub >> 1);
+        n_tile = a.tail_split * nt + (sub & (a.tail_split - 1));
+        co_tile = a.tail_split * ct + sub / a.tail_split;
         return n_tile < a.n_tiles;
     }
     return tile_of_index(a, blockIdx.x, n_tile, co_tile);
@@ -1019,7 +1029,7 @@ __global__ __launch_bounds__(512) void conv1d_glds_persistent_kernel(ConvArgs a)
     const int wc = wave / WN, wn = wave % WN;
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ (lrow & 7);
-    const int total = ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;  // virtual workgroup ids of tile_of_index
+    const int total = a.n_tiles * a.co_tiles;  // workgroup ids of tile_of_index
     const half_t* xbase = reinterpret_cast<const half_t*>(a.x);
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
     const int kstages_per_tap = a.cin_pad / CV_BK;
@@ -1263,8 +1273,8 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     const int wc = wave / 4, wn = wave % 4;
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ (lrow & 7);
-    // virtual workgroup ids of tile_of_index -- all of them, or the whole rounds only (the launcher hands the last partial round to quarter tiles)
-    const int total = a.ring_vb_end > 0 ? a.ring_vb_end : ((a.n_tiles + 7) >> 3) * 8 * a.co_tiles;
+    // tile ids of tile_of_index -- all of them, or the whole rounds only (the launcher hands the last partial round to sub-tiles)
+    const int total = a.ring_vb_end > 0 ? a.ring_vb_end : a.n_tiles * a.co_tiles;
     const int step = (int)gridDim.x;
     unsigned long long clk0 = 0, ref0 = 0;   // (scalar registers) MvConv1dDesc.clock_probe
     if (a.clock_probe != nullptr) {
@@ -1779,7 +1789,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const int tn = big ? 256 : (wide ? 160 : (small ? 64 : CV_TN)), tc = big ? 256 : (small ? 64 : CV_TC);
     a.n_tiles = a.per_utt ? d.B * a.tiles_per_utt : (int)ceil_div(a.n_rows, tn);
     a.co_tiles = (int)ceil_div(d.cout, tc);
-    const int grid = (int)round_up(a.n_tiles, 8) * a.co_tiles;
+    const int grid = a.n_tiles * a.co_tiles;
     static DeviceOnce smem_set;   // (per device: the attribute belongs to the current device's code object)
     int smem_set_slot;
     if (device_once_pending(smem_set, &smem_set_slot)) {
@@ -1805,39 +1815,37 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
                             (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
     const bool ring = persist && stats == 0 && dense_rows;
-    // The ring walk's tail.  A launch lasts as many tile times as its longest walk: 3600 tiles of the MFA layer (76 800 rows x 3072 channels) on 256
-    // workgroups are 14.06 rounds, so 15 -- the last one with 48 workgroups at work.  Splitting K over workgroups (stream-K) would fill it, but sums a tile
+    // The ring walk's tail.  A launch lasts as many tile times as its longest walk: 3600 tiles of an MFA layer (256 utterances of 300 frames x 3072
+    // channels) on 256 workgroups are 14.06 rounds, so 15 -- the last one with 16 workgroups at work.  (The headline batch has 298 frames: 3576 tiles =
+    // 13.97 rounds, nothing to split -- since the tile ids are dense; with the holes of the walk before round 6 it was 15 rounds as well.)  Splitting K over workgroups (stream-K) would fill it, but sums a tile
     // in another order, and WHICH tiles are split follows the batch: a row's bits would depend on its neighbours.  Splitting a tile's ROWS and CHANNELS
     // keeps every output element's sum as it is (test_gpu_embedding_bits_do_not_depend_on_the_batch_size holds the 64 / 128 / 256 tiles to one
-    // accumulation order): when the last partial round's tiles, cut into four 128 x 128 quarters, still fit one round of the chip, the ring kernel walks
-    // the whole rounds only and the quarters run at once on the 128 x 128 kernel with a four-stage ring (128 KiB of LDS, one workgroup per CU), eight
-    // waves of 32 channels x 64 rows.  Measured (r15ae, per-launch events, MFA layer of the headline batch): the ring part 1253-1269 -> 1202-1210 us --
-    // the last round costs 55 us, not a tile time of 84: its 48 workgroups have the memory system to themselves --, the quarters 44 us with eight waves
-    // (60 with four of 64 x 64: one wave per SIMD cannot overlap its fragment reads with its MFMAs; three stages in flight instead of two change
-    // nothing: the 128 x 128 tile is bound by LDS bandwidth, 96 KiB of fragment reads + 32 KiB of transfers per stage = ~0.9 us where the ring
-    // kernel's 256 x 256 stage of four times the FLOPs takes 1.7).  So a tail that needs more than one round of quarters does not pay (the K = 1024
-    // layers: 176 tiles in the last round = 2.75 rounds of quarters), and K stages below eight are not worth a second launch.
-    int tail_vb0 = 0, tail_nv = 0;
+    // accumulation order): when the last partial round's tiles, cut into sixteen 64 x 64 or four 128 x 128 sub-tiles, still fit one round of the chip,
+    // the ring kernel walks the whole rounds only and the sub-tiles run at once on the small-tile kernels (four-stage rings).
+    // Measured (r15ae / r15ag, per-launch events, MFA layer of the headline batch): the last round of the unsplit launch costs 50-55 us, not a tile time
+    // of 84 -- its workgroups have the memory system to themselves; 192 quarters (48 tiles: the walk with holes of r15ae) take 44 us on eight waves of
+    // 32 channels x 64 rows (60 on four of 64 x 64: one wave per SIMD cannot overlap its fragment reads with its MFMAs; two instead of three stages in
+    // flight change nothing: the 128 x 128 tile is bound by LDS bandwidth, 96 KiB of fragment reads + 32 KiB of transfers per K stage = ~0.9 us where
+    // the ring kernel's stage of four times the FLOPs takes 1.7).  So a tail that needs more than one round of sub-tiles does not pay (the K = 1024
+    // layers: 176 tiles in the last round), and K stages below eight are not worth a second launch.
+    int tail_vb0 = 0, tail_nv = 0, tail_split = 0;
     double tail_work = 0.0;
     if (ring) {
         const int blocks = persistent_blocks(d);
-        const int total_v = (int)round_up(a.n_tiles, 8) * a.co_tiles;
-        const int whole = total_v / blocks * blocks;
-        if (whole > 0 && whole < total_v && a.cin_pad / CV_BK >= 8) {
-            int valid = 0;
-            for (int v = whole; v < total_v; ++v) {
+        const int total_ids = a.n_tiles * a.co_tiles;
+        const int whole = total_ids / blocks * blocks;
+        const int left = total_ids - whole;
+        if (whole > 0 && left > 0 && 4 * left <= blocks && a.cin_pad / CV_BK >= 8) {
+            tail_vb0 = whole;
+            tail_nv = left;
+            tail_split = 16 * left <= blocks ? 4 : 2;
+            for (int v = whole; v < total_ids; ++v) {
                 int nt = 0, ct = 0;
-                if (!tile_of_index_geom(a.n_tiles, a.co_tiles, v, nt, ct)) continue;
-                ++valid;
+                tile_of_index_geom(a.n_tiles, a.co_tiles, v, nt, ct);
                 const int rows = a.n_rows - nt * 256 < 256 ? a.n_rows - nt * 256 : 256;
                 tail_work += 2.0 * rows * 256.0 * (double)d.cin;
             }
-            if (valid > 0 && 4 * valid <= blocks) {
-                tail_vb0 = whole;
-                tail_nv = total_v - whole;   // (a multiple of 8, like `whole`)
-            }
         }
-        if (tail_nv == 0) tail_work = 0.0;
     }
     const int prof = prof_begin(ring ? MV_PROF_CONV1D_RING : MV_PROF_CONV1D, 2.0 * a.n_rows * (double)d.cin * d.cout * d.k - tail_work, stream);
     if (persist) {
@@ -1857,10 +1865,17 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
                 t.tail_nv = tail_nv;
                 t.tail_n_tiles = a.n_tiles;
                 t.tail_co_tiles = a.co_tiles;
-                t.n_tiles = (int)ceil_div(a.n_rows, CV_TN);
-                t.co_tiles = (int)ceil_div(d.cout, CV_TC);
+                t.tail_split = tail_split;
                 const int tprof = prof_begin(MV_PROF_CONV1D, tail_work, stream);
-                MV_LAUNCH((conv1d_glds_kernel<4, 2, 2, 4, false, CV_TAIL_NS>), (4 * tail_nv, 1, 1), (512, 1, 1), CV_LDS_BYTES_TAIL, stream, t);
+                if (tail_split == 4) {
+                    t.n_tiles = (int)ceil_div(a.n_rows, 64);
+                    t.co_tiles = (int)ceil_div(d.cout, 64);
+                    MV_LAUNCH((conv1d_glds_kernel<2, 2, 2, 2, false, CV_SMALL_NS>), (16 * tail_nv, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_SMALL, stream, t);
+                } else {
+                    t.n_tiles = (int)ceil_div(a.n_rows, CV_TN);
+                    t.co_tiles = (int)ceil_div(d.cout, CV_TC);
+                    MV_LAUNCH((conv1d_glds_kernel<4, 2, 2, 4, false, CV_TAIL_NS>), (4 * tail_nv, 1, 1), (512, 1, 1), CV_LDS_BYTES_TAIL, stream, t);
+                }
                 prof_end(tprof, stream);
                 return check_launch("conv1d_glds_kernel (ring tail)");
             }
