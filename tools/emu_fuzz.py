@@ -109,6 +109,11 @@ def g_conv1d(r):
             kw.pop(key, None)
         if kw['tile'] == 256:
             kw['cout'] = r.choice([256, 512, 768])
+            if r.random() < 0.5:   # persistent walks of several rounds on a few resident workgroups (dense tile ids; with >= 8 K stages the ring kernel's last
+                #                    partial round leaves as 64 x 64 / 128 x 128 sub-tiles)
+                kw['persist_blocks'] = r.choice([8, 16, 24, 40])
+                if k == 1 and r.random() < 0.6:
+                    kw['cin'] = r.choice([512, 576, 1024])
     if kw.get('in_stats'):
         kw['cout'] = r.choice([64, 128])
         kw.pop('stride', None)
