@@ -33,6 +33,7 @@ for name, cin, cout, k, dil in shapes:
         d.y, d.y_dtype, d.ldy = y.data_ptr(), _hip.MV_DT_F16, cout + PADX
         d.B, d.T_in, d.T_out, d.cin, d.cout, d.k, d.dilation, d.stride = B, T, T, cin, cout, k, dil, 1
         d.pad, d.pad_mode, d.tile = dil * (k - 1) // 2, _hip.MV_PAD_REFLECT, tile
+        d.persist_blocks_hint = int(os.environ.get('MV_BENCH_BLOCKS', '0'))   # resident workgroups of the persistent kernels (0: one per CU)
         probe = None
         if os.environ.get('MV_BENCH_CLOCK') == '1' and hasattr(d, 'clock_probe'):   # the launch's sustained shader clock (ring kernel only)
             probe = torch.zeros(4 * 264, dtype=torch.int64, device='cuda')
