@@ -82,6 +82,13 @@ typedef struct MvFbankCfg {
                                    * double as torchaudio compares (`len(waveform) < min_duration * sample_frequency`): the float32 field above
                                    * rounds 0.1 / 0.2 / 0.3 s upwards and a clip of exactly min_duration lost its frames.  0: derived
                                    * from min_duration. */
+    int32_t use_energy;           /* 0.  1: one more column, the log energy of every frame -- out is [B, T, num_mel_bins + 1] (kaldi.fbank's use_energy;
+                                   * AudioFeaturizer.feature_dim, featurizer.py:110-111, keeps reporting num_mel_bins, as the reference's does).  The
+                                   * mel columns come from the same kernels through the caller workspace (mv_fbank_workspace_bytes; the forwards
+                                   * without a workspace refuse), the energy column from fbank_energy_kernel; time mean and mask cover it too. */
+    int32_t raw_energy;           /* 1: energy of the frame after the DC removal, before pre-emphasis and window; 0: of the windowed frame */
+    float energy_floor;           /* 1.0: log energies below log(energy_floor) are raised to it; 0 = no floor (kaldi.fbank's rule) */
+    int32_t htk_compat;           /* 0: the energy is column 0; 1: the last column */
 } MvFbankCfg;
 
 enum { MV_WINDOW_POVEY = 0, MV_WINDOW_HAMMING = 1, MV_WINDOW_HANNING = 2, MV_WINDOW_RECTANGULAR = 3, MV_WINDOW_BLACKMAN = 4 };
@@ -99,7 +106,7 @@ int mv_fbank_num_frames(const MvFbank* h, int64_t num_samples, int64_t* num_fram
 int mv_fbank_info(const MvFbank* h, int32_t* tile_kernel, int32_t* pass_steps);
 /* wav: [B, L] fp32 rows ``wav_stride`` elements apart.  lens_ratio: [B] fp32 or NULL
  * (featurizer.py:80-90: frames t >= round_half_even(ratio * T) are zeroed).  out: [B, T, num_mel_bins]
- * fp32, contiguous. */
+ * fp32, contiguous ([B, T, num_mel_bins + 1] with MvFbankCfg.use_energy, which needs mv_fbank_forward_ws). */
 int mv_fbank_forward(const MvFbank* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
                      const float* lens_ratio, float* out, mv_stream_t stream);
 /* The same forward with a caller workspace.  A batch of fewer utterances than the chip has CUs (predict()'s single utterance,

@@ -826,7 +826,15 @@ FBANK_ARG_CASES = (
     [(dict(_FB80, vtln_warp=1.1), {}), (dict(_FB80, vtln_warp=0.9), dict(cmn=False)), (dict(sample_frequency=16000, num_mel_bins=40, vtln_warp=1.2, vtln_low=300.0, vtln_high=-800.0), {}),
      (dict(sample_frequency=8000, num_mel_bins=23, vtln_warp=0.85, vtln_high=-300.0), dict(varlen=True))] +    # kaldi's VTLN warp of the filter edges
     [(dict(_FB80), dict(cmn=False)), (dict(_FB80), dict(cmn=False, kernel='generic')), (dict(_FB80), dict(varlen=True, kernel='generic')),
-     (dict(sample_frequency=16000, num_mel_bins=23), dict(cmn=False))])
+     (dict(sample_frequency=16000, num_mel_bins=23), dict(cmn=False))] +
+    # use_energy (round 6): the log-energy column in front of / behind the mel columns, raw or windowed, floored or not; with the time mean and the mask,
+    # bare, on true lengths, on the mirrored signal, on both kernels
+    [(dict(_FB80, use_energy=True), {}), (dict(_FB80, use_energy=True, htk_compat=True), dict(kernel='generic')),
+     (dict(_FB80, use_energy=True, raw_energy=False), {}), (dict(_FB80, use_energy=True, raw_energy=False, energy_floor=0.0), dict(cmn=False)),
+     (dict(_FB80, use_energy=True, energy_floor=0.0, remove_dc_offset=False), dict(varlen=True)),
+     (dict(sample_frequency=8000, num_mel_bins=23, use_energy=True, energy_floor=1e-3, snip_edges=False, htk_compat=True), {}),
+     (dict(_FB80, use_energy=True, raw_energy=False, preemphasis_coefficient=0.0, window_type='hamming', subtract_mean=True), dict(cmn=False)),
+     (dict(sample_frequency=16000, num_mel_bins=40, use_energy=True, energy_floor=0.0, snip_edges=False), dict(varlen=True))])
 
 
 def fbank_arguments_case(cdll, device, idx, B=3, seconds=0.5, seed=None, check_rows=None):

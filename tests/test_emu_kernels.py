@@ -119,7 +119,7 @@ def test_emu_fbank_edge_cases():
         lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40, frame_length=40), cdll=emu_cdll())
     with pytest.raises(RuntimeError, match='fbank_tile_kernel is instantiated'):
         lc._hip.Fbank(dict(sample_frequency=16000, num_mel_bins=40), cdll=emu_cdll(), kernel='tile')
-    for bad in (dict(dither=1.0), dict(use_energy=True), dict(round_to_power_of_two=False)):
+    for bad in (dict(dither=1.0), dict(round_to_power_of_two=False)):
         with pytest.raises(NotImplementedError):
             lc._hip.Fbank(dict(FB, **bad), cdll=emu_cdll())
     with pytest.raises(RuntimeError, match='bad VTLN options'):   # (torchaudio asserts on these)

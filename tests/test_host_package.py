@@ -523,7 +523,7 @@ def test_cpu_featurizer_takes_the_wider_method_args():
         out = AudioFeaturizer('MelSpectrogram', method_args=args)(wav, ratio)
         ref = frontend.audio_featurizer(wav, ratio, 'MelSpectrogram', args)
         assert out.shape == ref.shape and (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), args
-    for bad in (dict(dither=0.1), dict(use_energy=True), dict(round_to_power_of_two=False)):
+    for bad in (dict(dither=0.1), dict(round_to_power_of_two=False)):
         with pytest.raises(NotImplementedError):
             AudioFeaturizer('Fbank', method_args=dict(FB, **bad))
     for bad in (dict(pad=10), dict(pad_mode='constant'), dict(onesided=False), dict(power=None)):

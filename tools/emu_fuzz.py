@@ -197,6 +197,14 @@ def g_fbank(r):
             extra['use_power'] = False
         if r.random() < 0.2:
             extra['use_log_fbank'] = False
+        if r.random() < 0.2:   # the log-energy column
+            extra['use_energy'] = True
+            if r.random() < 0.5:
+                extra['raw_energy'] = False
+            if r.random() < 0.5:
+                extra['energy_floor'] = r.choice([0.0, 1e-4, 10.0])
+            if r.random() < 0.5:
+                extra['htk_compat'] = True
         # more mel bins than a quarter of the transform's bins: filters narrower than two FFT bins, where a log energy IS one bin's power and the
         # per-bin rounding of a 512-point fp32 transform shows undamped (device fuzz r14b: 128 bins on kaldi's 128-point FFT at 8 kHz / 10 ms,
         # 29 of 832 k values 1e-3 .. 3e-3 from the fp64 arbiter where torch's 128-point fp32 transform stays within 7.4e-4) -- not a

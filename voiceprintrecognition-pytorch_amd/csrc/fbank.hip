@@ -746,6 +746,91 @@ __global__ __launch_bounds__(256) void fbank_cmn_finish_kernel(float* out, const
     }
 }
 
+// use_energy (torchaudio.compliance.kaldi.fbank: `_get_window`'s signal_log_energy, concatenated in front of -- htk_compat: behind -- the mel columns before
+// subtract_mean): the mel kernels have written their [B, T, nbins] rows (time mean and mask applied) to the caller workspace; this pass writes the
+// [B, T, nbins + 1] output: the mel columns copied, the energy column = log(max(sum of squares of the frame, eps)) -- of the frame after the DC removal
+// (raw_energy) or of the pre-emphasised, windowed frame -- raised to log(energy_floor), minus its own time mean over the utterance's frames, zero from the
+// mask length on.  One workgroup per utterance, thread i takes the frames i, i + 256, ...; a frame's sums run in four interleaved accumulators, the
+// utterance's mean in one fixed order (per-thread sums in frame order, then a tree over the 256 threads): a row's bits do not depend on the batch.
+// An option no shipped configuration sets: written for clarity, not for speed (a frame's samples are read twice by one thread).
+struct FbankEnergyArgs {
+    const float* wav;
+    int64_t wav_stride;
+    const float* lens_ratio;
+    const int64_t* num_samples;
+    const float* mel;      // [B, T, nbins]
+    float* out;            // [B, T, nbins + 1]
+    const float* window;   // [512]
+    int T, win, shift, nbins;
+    float preemph, inv_win;
+    int remove_dc, raw_energy, cmn, energy_col, mel_col, has_floor;
+    float log_floor;
+    int64_t min_len;
+};
+
+__global__ __launch_bounds__(256) void fbank_energy_kernel(FbankEnergyArgs a) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tout = a.T;
+    int T = a.T;
+    if (a.num_samples != nullptr) {   // (as in the mel kernels)
+        const int64_t ns = a.num_samples[b];
+        const int64_t tb = ns < a.min_len ? 0 : 1 + (ns - a.win) / a.shift;
+        T = (int)(tb < a.T ? tb : a.T);
+    }
+    const int ld = a.nbins + 1;
+    const float* wrow = a.wav + (int64_t)b * a.wav_stride;
+    float* orow = a.out + (int64_t)b * Tout * ld;
+    const float* mrow = a.mel + (int64_t)b * Tout * a.nbins;
+    const float eps = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps (kaldi.fbank's EPSILON)
+    float part = 0.0f;
+    for (int t = tid; t < T; t += 256) {
+        const float* x = wrow + (int64_t)t * a.shift;
+        float mean = 0.0f;
+        if (a.remove_dc) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int i = 0; i < a.win; ++i) s[i & 3] += x[i];
+            mean = ((s[0] + s[1]) + (s[2] + s[3])) * a.inv_win;
+        }
+        float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.raw_energy) {
+            for (int i = 0; i < a.win; ++i) {
+                const float c = x[i] - mean;
+                e[i & 3] = fmaf(c, c, e[i & 3]);
+            }
+        } else {
+            float prev = x[0] - mean;   // replicate padding on the left: frame[0] - preemph * frame[0]
+            for (int i = 0; i < a.win; ++i) {
+                const float c = x[i] - mean;
+                const float y = (c - a.preemph * prev) * a.window[i];
+                e[i & 3] = fmaf(y, y, e[i & 3]);
+                prev = c;
+            }
+        }
+        float le = logf(fmaxf((e[0] + e[1]) + (e[2] + e[3]), eps));
+        if (a.has_floor) le = fmaxf(le, a.log_floor);
+        orow[(int64_t)t * ld + a.energy_col] = le;
+        part += le;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float mean_e = (a.cmn && T > 0) ? red[0] / (float)T : 0.0f;
+    int mask_len = T;
+    if (a.lens_ratio != nullptr) mask_len = (int)rintf(a.lens_ratio[b] * (float)T);  // round half to even
+    for (int t = tid; t < Tout; t += 256) {   // (a thread re-reads what it wrote itself)
+        float* p = orow + (int64_t)t * ld + a.energy_col;
+        *p = t < T && t < mask_len ? *p - mean_e : 0.0f;
+    }
+    for (int i = tid; i < Tout * a.nbins; i += 256) {
+        const int t = i / a.nbins, m = i - t * a.nbins;
+        orow[(int64_t)t * ld + a.mel_col + m] = mrow[i];
+    }
+}
+
 // snip_edges = False (torchaudio.compliance.kaldi._get_strided): T = (n + shift / 2) / shift frames over the signal mirrored at both ends --
 // frame f covers the samples f * shift - pad ... + win - 1 with pad = win / 2 - shift / 2, index -1 - j reads x[j], index n + j reads x[n - 1 - j].
 // This pre-pass writes the mirrored row [0, (T - 1) * shift + win) to the caller workspace (one extra pass over the waveform for a non-default
@@ -972,6 +1057,10 @@ void mv_fbank_default_cfg(MvFbankCfg* cfg) {
     cfg->vtln_warp = 1.0f;
     cfg->vtln_low = 100.0f;
     cfg->vtln_high = -500.0f;
+    cfg->use_energy = 0;
+    cfg->raw_energy = 1;
+    cfg->energy_floor = 1.0f;
+    cfg->htk_compat = 0;
 }
 
 int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
@@ -989,6 +1078,8 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     MV_REQUIRE(cfg->kernel >= MV_FBANK_KERNEL_AUTO && cfg->kernel <= MV_FBANK_KERNEL_TILE, "mv_fbank_create: unknown kernel selector");
     MV_REQUIRE(cfg->min_duration >= 0.0f, "mv_fbank_create: negative min_duration");
     MV_REQUIRE(cfg->vtln_warp > 0.0f, "mv_fbank_create: vtln_warp must be positive");
+    MV_REQUIRE((cfg->use_energy == 0 || cfg->use_energy == 1) && (cfg->raw_energy == 0 || cfg->raw_energy == 1) && (cfg->htk_compat == 0 || cfg->htk_compat == 1) &&
+                   cfg->energy_floor >= 0.0f, "mv_fbank_create: use_energy / raw_energy / htk_compat are 0 or 1, energy_floor is not negative");
     MvFbank* h = new MvFbank();
     h->cfg = *cfg;
     h->win = win;
@@ -1132,10 +1223,24 @@ struct FbankPlan {
     int64_t mirror_len = 0, mirror_stride = 0;
     size_t mirror_bytes = 0;
     size_t chunk_bytes = 0;
+    // use_energy: the mel kernels' [B, T, nbins] rows come last (mel_off, a multiple of 256)
+    size_t mel_off = 0, mel_bytes = 0;
     size_t workspace_bytes = 0;
 };
 
+static FbankPlan fbank_plan_mel(const MvFbank* h, int32_t B, int64_t L);
+
 static FbankPlan fbank_plan(const MvFbank* h, int32_t B, int64_t L) {
+    FbankPlan p = fbank_plan_mel(h, B, L);
+    if (h->cfg.use_energy && B > 0 && p.T > 0) {
+        p.mel_off = (size_t)mv::round_up((int64_t)p.workspace_bytes, (int64_t)256);
+        p.mel_bytes = (size_t)B * (size_t)p.T * (size_t)h->nbins * sizeof(float);
+        p.workspace_bytes = p.mel_off + p.mel_bytes;
+    }
+    return p;
+}
+
+static FbankPlan fbank_plan_mel(const MvFbank* h, int32_t B, int64_t L) {
     FbankPlan p;
     mv_fbank_num_frames(h, L, &p.T);
     if (B <= 0 || p.T <= 0) return p;
@@ -1203,7 +1308,15 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
     mv_fbank_num_frames(h, L, &T);
     if (B == 0 || T == 0) return MV_OK;  // empty output, like kaldi.fbank on a too-short input
     MV_REQUIRE(wav != nullptr && out != nullptr, "mv_fbank_forward: null buffer");
-    MV_REQUIRE(T * h->nbins < (int64_t)1 << 31, "mv_fbank_forward: utterance too long for 32-bit row indexing");
+    MV_REQUIRE(T * (h->nbins + 1) < (int64_t)1 << 31, "mv_fbank_forward: utterance too long for 32-bit row indexing");
+    float* const final_out = out;
+    if (h->cfg.use_energy) {   // the mel kernels write to the workspace, fbank_energy_kernel composes the [B, T, nbins + 1] output
+        if (workspace == nullptr || workspace_bytes < plan.workspace_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+            return mv::fail(MV_ERR_WORKSPACE, "mv_fbank_forward: use_energy writes the mel columns to the caller workspace first "
+                                            "(mv_fbank_workspace_bytes, 16-byte aligned; mv_fbank_forward_ws / mv_fbank_forward_varlen_ws)");
+        out = reinterpret_cast<float*>(static_cast<char*>(workspace) + plan.mel_off);
+        workspace_bytes = plan.mel_off;   // what the other sections may use
+    }
     mv::FbankArgs a;
     a.wav = wav;
     a.wav_stride = wav_stride;
@@ -1283,6 +1396,35 @@ static int fbank_forward_impl(const MvFbank* h, const float* wav, int32_t B, int
         }
     } else {
         fbank_launch(B, h->smem_bytes, static_cast<hipStream_t>(stream), a, h->waves, vec2);
+    }
+    if (h->cfg.use_energy) {
+        int rc = mv::check_launch(h->tile_kernel ? "fbank_tile_kernel" : "fbank_kernel");
+        if (rc != MV_OK) return rc;
+        mv::FbankEnergyArgs e;
+        e.wav = a.wav;
+        e.wav_stride = a.wav_stride;
+        e.lens_ratio = lens_ratio;
+        e.num_samples = a.num_samples;
+        e.mel = out;
+        e.out = final_out;
+        e.window = h->tab.window;
+        e.T = (int)T;
+        e.win = h->win;
+        e.shift = h->shift;
+        e.nbins = h->nbins;
+        e.preemph = a.preemph;
+        e.inv_win = a.inv_win;
+        e.remove_dc = a.remove_dc;
+        e.raw_energy = h->cfg.raw_energy;
+        e.cmn = a.cmn;
+        e.energy_col = h->cfg.htk_compat ? h->nbins : 0;
+        e.mel_col = h->cfg.htk_compat ? 0 : 1;
+        e.has_floor = h->cfg.energy_floor != 0.0f;
+        e.log_floor = e.has_floor ? (float)log((double)h->cfg.energy_floor) : 0.0f;
+        e.min_len = a.min_len;
+        MV_LAUNCH(mv::fbank_energy_kernel, ((unsigned)B, 1, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), e);
+        mv::prof_end(prof, static_cast<hipStream_t>(stream));
+        return mv::check_launch("fbank_energy_kernel");
     }
     mv::prof_end(prof, static_cast<hipStream_t>(stream));
     return mv::check_launch(h->tile_kernel ? "fbank_tile_kernel" : "fbank_kernel");

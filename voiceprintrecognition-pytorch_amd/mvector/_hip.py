@@ -25,7 +25,8 @@ class MvFbankCfg(ctypes.Structure):
                 ('preemphasis_coefficient', c_f32), ('remove_dc_offset', c_i32), ('use_power', c_i32),
                 ('use_log_fbank', c_i32), ('subtract_time_mean', c_i32), ('window_type', c_i32), ('blackman_coeff', c_f32),
                 ('snip_edges', c_i32), ('subtract_mean', c_i32), ('min_duration', c_f32), ('vtln_warp', c_f32), ('vtln_low', c_f32),
-                ('vtln_high', c_f32), ('kernel', c_i32), ('min_samples', c_i64)]
+                ('vtln_high', c_f32), ('kernel', c_i32), ('min_samples', c_i64), ('use_energy', c_i32), ('raw_energy', c_i32),
+                ('energy_floor', c_f32), ('htk_compat', c_i32)]
 
 
 class MvMelSpecCfg(ctypes.Structure):
@@ -220,12 +221,13 @@ class Fbank:
                    'high_freq': 'high_freq', 'preemphasis_coefficient': 'preemphasis_coefficient',
                    'remove_dc_offset': 'remove_dc_offset', 'use_power': 'use_power', 'use_log_fbank': 'use_log_fbank',
                    'blackman_coeff': 'blackman_coeff', 'snip_edges': 'snip_edges', 'subtract_mean': 'subtract_mean',
-                   'min_duration': 'min_duration', 'vtln_warp': 'vtln_warp', 'vtln_low': 'vtln_low', 'vtln_high': 'vtln_high'}
-        # arguments whose other values are not implemented (dither draws random numbers; use_energy adds a column that
-        # AudioFeaturizer.feature_dim, featurizer.py:110-111, does not count -- the reference's own models would refuse the features;
-        # non-power-of-two FFT sizes) and arguments that only matter together with those (raw_energy, energy_floor, htk_compat: use_energy)
-        fixed = {'dither': 0.0, 'use_energy': False, 'round_to_power_of_two': True, 'channel': (-1, 0)}
-        ignored = ('raw_energy', 'energy_floor', 'htk_compat')
+                   'min_duration': 'min_duration', 'vtln_warp': 'vtln_warp', 'vtln_low': 'vtln_low', 'vtln_high': 'vtln_high',
+                   'use_energy': 'use_energy', 'raw_energy': 'raw_energy', 'energy_floor': 'energy_floor', 'htk_compat': 'htk_compat'}
+        # arguments whose other values are not implemented (dither draws random numbers; non-power-of-two FFT sizes).  use_energy (since round 6) adds
+        # the log-energy column: the output has num_mel_bins + 1 columns, which AudioFeaturizer.feature_dim -- like the reference's,
+        # featurizer.py:110-111 -- does not count
+        fixed = {'dither': 0.0, 'round_to_power_of_two': True, 'channel': (-1, 0)}
+        ignored = ()
         for k, v in args.items():
             if k in mapping:
                 field = mapping[k]
@@ -248,7 +250,8 @@ class Fbank:
         cfg.subtract_time_mean = 1 if subtract_time_mean else 0
         cfg.kernel = self.KERNELS[kernel]
         self.num_mel_bins = cfg.num_mel_bins
-        self._snip_edges = bool(cfg.snip_edges)
+        self.num_columns = cfg.num_mel_bins + (1 if cfg.use_energy else 0)
+        self._needs_ws = (not cfg.snip_edges) or bool(cfg.use_energy)   # forms that cannot run without the caller workspace
         self._h = c_vp()
         check(self._cdll.mv_fbank_create(ctypes.byref(cfg), ctypes.byref(self._h)), self._cdll)
 
@@ -273,7 +276,7 @@ class Fbank:
             wav = wav.contiguous()
         B, L = wav.shape
         T = self.num_frames(L)
-        out = torch.empty((B, T, self.num_mel_bins), dtype=torch.float32, device=wav.device)
+        out = torch.empty((B, T, self.num_columns), dtype=torch.float32, device=wav.device)
         if B == 0 or T == 0:
             return out
         # per-call scratch (the several-workgroups-per-utterance form of long utterances / batches smaller than the chip; the mirrored signal
@@ -281,7 +284,7 @@ class Fbank:
         # owns no mutable state)
         need = ctypes.c_size_t()
         check(self._cdll.mv_fbank_workspace_bytes(self._h, B, L, ctypes.byref(need)), self._cdll)
-        ws = torch.empty(need.value, dtype=torch.uint8, device=wav.device) if need.value and (workspace or not self._snip_edges) else None
+        ws = torch.empty(need.value, dtype=torch.uint8, device=wav.device) if need.value and (workspace or self._needs_ws) else None
         if num_samples is not None:
             num_samples = num_samples.to(device=wav.device, dtype=torch.int64).contiguous()
             if ws is None:

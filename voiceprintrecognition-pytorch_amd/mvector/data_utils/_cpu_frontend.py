@@ -13,12 +13,12 @@ import torch
 _FBANK_KEYS = {'sample_frequency': 16000.0, 'frame_length': 25.0, 'frame_shift': 10.0, 'num_mel_bins': 23,
                'low_freq': 20.0, 'high_freq': 0.0, 'preemphasis_coefficient': 0.97, 'remove_dc_offset': True,
                'use_power': True, 'use_log_fbank': True, 'window_type': 'povey', 'blackman_coeff': 0.42, 'snip_edges': True,
-               'subtract_mean': False, 'min_duration': 0.0, 'vtln_warp': 1.0, 'vtln_low': 100.0, 'vtln_high': -500.0}
-# not implemented beyond these values: dither draws random numbers, use_energy adds a column AudioFeaturizer.feature_dim does not count
-# (featurizer.py:110-111), FFT sizes that are not powers of two
-_FBANK_FIXED = {'dither': (0.0,), 'use_energy': (False,), 'round_to_power_of_two': (True,), 'channel': (-1, 0)}
-# arguments that only act together with use_energy
-_FBANK_IGNORED = ('raw_energy', 'energy_floor', 'htk_compat')
+               'subtract_mean': False, 'min_duration': 0.0, 'vtln_warp': 1.0, 'vtln_low': 100.0, 'vtln_high': -500.0,
+               'use_energy': False, 'raw_energy': True, 'energy_floor': 1.0, 'htk_compat': False}
+# not implemented beyond these values: dither draws random numbers, FFT sizes that are not powers of two.  (use_energy adds a column
+# AudioFeaturizer.feature_dim -- like the reference's, featurizer.py:110-111 -- does not count.)
+_FBANK_FIXED = {'dither': (0.0,), 'round_to_power_of_two': (True,), 'channel': (-1, 0)}
+_FBANK_IGNORED = ()
 _WINDOWS = ('povey', 'hamming', 'hanning', 'rectangular', 'blackman')
 _MEL_KEYS = {'sample_rate', 'n_fft', 'win_length', 'hop_length', 'f_min', 'f_max', 'pad', 'n_mels', 'power',
              'normalized', 'center', 'pad_mode', 'onesided', 'norm', 'mel_scale', 'window_fn', 'wkwargs'}
@@ -116,31 +116,43 @@ def fbank_batch(wav, args):
                                                           float(a['low_freq']), float(a['high_freq']), a['window_type'],
                                                           float(a['blackman_coeff']), float(a['vtln_warp']), float(a['vtln_low']), float(a['vtln_high']))
     B, L = wav.shape
+    ncol = int(a['num_mel_bins']) + int(bool(a['use_energy']))
+    eps = torch.finfo(torch.float32).eps
+
+    def log_energy(fr):   # kaldi._get_log_energy
+        le = fr.pow(2).sum(2).clamp(min=eps).log()
+        return le if float(a['energy_floor']) == 0.0 else le.clamp(min=math.log(float(a['energy_floor'])))
     if L < float(a['min_duration']) * float(a['sample_frequency']) or (a['snip_edges'] and L < size):
-        return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
+        return wav.new_zeros((B, 0, ncol))
     if not a['snip_edges']:  # (L + shift // 2) // shift frames over the signal mirrored at both ends (kaldi._get_strided)
         m = (L + shift // 2) // shift
         pad = size // 2 - shift // 2
         rev = torch.flip(wav, [1])
         wav = torch.cat((rev[:, L - pad:], wav, rev), dim=1) if pad > 0 else torch.cat((wav[:, -pad:], rev), dim=1)
         if m == 0:
-            return wav.new_zeros((B, 0, int(a['num_mel_bins'])))
+            return wav.new_zeros((B, 0, ncol))
         if (m - 1) * shift + size > wav.shape[1] or pad > L:
             raise RuntimeError('snip_edges=False: the signal is too short to be mirrored over its frames')
         wav = wav[:, :(m - 1) * shift + size]
     frames = wav.unfold(1, size, shift)  # [B, m, size]
     if a['remove_dc_offset']:
         frames = frames - frames.mean(dim=2, keepdim=True)
+    if a['use_energy'] and a['raw_energy']:
+        energy = log_energy(frames)
     pc = float(a['preemphasis_coefficient'])
     if pc != 0.0:
         frames = frames - pc * torch.cat([frames[..., :1], frames[..., :-1]], dim=2)
     frames = frames * window
+    if a['use_energy'] and not a['raw_energy']:
+        energy = log_energy(frames)
     spec = torch.fft.rfft(frames, n=padded).abs()
     if a['use_power']:
         spec = spec.pow(2.0)
     mel = spec @ banks_t
     if a['use_log_fbank']:
-        mel = torch.clamp(mel, min=torch.finfo(torch.float32).eps).log()
+        mel = torch.clamp(mel, min=eps).log()
+    if a['use_energy']:
+        mel = torch.cat((mel, energy.unsqueeze(2)), dim=2) if a['htk_compat'] else torch.cat((energy.unsqueeze(2), mel), dim=2)
     if a['subtract_mean']:
         mel = mel - mel.mean(dim=1, keepdim=True)
     return mel
