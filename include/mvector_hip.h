@@ -152,7 +152,14 @@ typedef struct MvMelSpecCfg {
     int32_t norm;        /* 0 = None | MV_MEL_NORM_SLANEY (1): filter j times 2 / (f[j + 2] - f[j]) */
     int32_t normalized;  /* 0 = False | MV_STFT_NORM_WINDOW (1; True): spectrum / sqrt(sum window^2) | MV_STFT_NORM_FRAME_LENGTH (2): / sqrt(n_fft) */
     const float* window; /* NULL = periodic Hann | HOST array [win_length]: what window_fn(win_length, **wkwargs) returned (copied at create) */
+    /* ---- since ABI 5 ---- */
+    int32_t pad;         /* 0.  Zeros in front of and behind the signal before the transform (torchaudio.functional.spectrogram's `pad`) */
+    int32_t pad_mode;    /* MV_STFT_PAD_REFLECT (0) | CONSTANT | REPLICATE | CIRCULAR: how torch.stft(center=True) extends the signal by n_fft / 2.
+                          * pad > 0 or a mode other than reflect writes the extended signal to the caller workspace first (one more pass over the
+                          * waveform for a non-default argument); the transform kernels then run on it unchanged */
 } MvMelSpecCfg;
+
+enum { MV_STFT_PAD_REFLECT = 0, MV_STFT_PAD_CONSTANT = 1, MV_STFT_PAD_REPLICATE = 2, MV_STFT_PAD_CIRCULAR = 3 };
 
 enum { MV_MEL_HTK = 0, MV_MEL_SLANEY = 1 };
 enum { MV_MEL_NORM_NONE = 0, MV_MEL_NORM_SLANEY = 1 };

@@ -297,8 +297,8 @@ def mel_spectrogram(waveforms, **kwargs):
     if unknown:
         raise TypeError(f'unexpected MelSpectrogram arguments {sorted(unknown)}')
     a.update(kwargs)
-    if a['pad'] != 0 or a['power'] is None or a['onesided'] not in (None, True):
-        raise NotImplementedError('oracle restates MelSpectrogram without signal padding, with a real exponent, one-sided')
+    if a['power'] is None or a['onesided'] not in (None, True):
+        raise NotImplementedError('oracle restates MelSpectrogram with a real exponent, one-sided')
     if a['normalized'] not in (False, True, 'window', 'frame_length'):
         raise ValueError(f"Invalid normalized parameter: {a['normalized']}")
     n_fft = a['n_fft']
@@ -307,6 +307,8 @@ def mel_spectrogram(waveforms, **kwargs):
     sr = a['sample_rate']
     f_max = a['f_max'] if a['f_max'] is not None else float(sr // 2)
     x = torch.as_tensor(waveforms, dtype=torch.float32)
+    if a['pad'] > 0:   # torchaudio.functional.spectrogram: `waveform = torch.nn.functional.pad(waveform, (pad, pad), "constant")` in front of the stft
+        x = F.pad(x, (a['pad'], a['pad']), 'constant')
     window = a['window_fn'](win, **(a['wkwargs'] or {})) if a['window_fn'] is not None else torch.hann_window(win)
     spec = torch.stft(x, n_fft, hop, win, window, center=a['center'], pad_mode=a['pad_mode'], normalized=a['normalized'] == 'frame_length',
                       onesided=True, return_complex=True)

@@ -1016,6 +1016,10 @@ MELSPEC_ARG_CASES = [
     dict(sample_rate=8000, n_fft=256, n_mels=40, f_min=60.0, f_max=3800.0, mel_scale='slaney'),
     dict(sample_rate=22050, n_fft=1024, hop_length=256, n_mels=80, f_min=0.0, f_max=8000.0, norm='slaney', mel_scale='slaney'),   # librosa-style
     dict(n_fft=400, win_length=320, hop_length=160, n_mels=80, normalized=True, window_fn=torch.hann_window, wkwargs=dict(periodic=False)),
+    # pad / pad_mode (round 6): zeros around the signal, the centre extension in torch.stft's other modes -- on the n_fft = 400 FFT kernel, the
+    # power-of-two FFT kernel and the dense DFT
+    dict(pad=37), dict(pad_mode='constant'), dict(pad_mode='replicate', n_fft=512), dict(pad_mode='circular', n_fft=480, n_mels=64),
+    dict(pad=200, pad_mode='constant', center=True, n_fft=256, n_mels=40), dict(pad=64, center=False), dict(pad=5, pad_mode='circular', hop_length=160),
 ]
 
 

@@ -526,7 +526,7 @@ def test_cpu_featurizer_takes_the_wider_method_args():
     for bad in (dict(dither=0.1), dict(round_to_power_of_two=False)):
         with pytest.raises(NotImplementedError):
             AudioFeaturizer('Fbank', method_args=dict(FB, **bad))
-    for bad in (dict(pad=10), dict(pad_mode='constant'), dict(onesided=False), dict(power=None)):
+    for bad in (dict(pad_mode='symmetric'), dict(onesided=False), dict(power=None)):
         with pytest.raises(NotImplementedError):
             AudioFeaturizer('MelSpectrogram', method_args=bad)
     for bad in (dict(norm='area'), dict(mel_scale='bark'), dict(normalized='sqrt')):

@@ -235,6 +235,10 @@ def g_melspec(r):
         args['center'] = False
     if r.random() < 0.2:
         args['power'] = r.choice([1.0, 2.0])
+    if r.random() < 0.2:   # zeros around the signal / the centre extension in torch.stft's other modes (the extended signal goes through the workspace)
+        args['pad'] = r.choice([1, 7, 100, n_fft])
+    if r.random() < 0.2:
+        args['pad_mode'] = r.choice(['constant', 'replicate', 'circular', 'reflect'])
     L = _pick(r, [n_fft, n_fft + 1, 1500, 2000, 3333, 5003, 9000], [48000, 160000])
     if L < n_fft:
         L = n_fft

@@ -38,6 +38,37 @@ struct StftArgs {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 
+// pad / pad_mode (torchaudio.functional.spectrogram: F.pad(waveform, (pad, pad)) with zeros, then torch.stft(center=True, pad_mode=...) extends by
+// n_fft / 2 on either side): the extended signal, written once; the transform kernels then see a centre = False problem
+__global__ __launch_bounds__(256) void melspec_extend_kernel(const float* wav, int64_t wav_stride, int64_t L, float* dst, int64_t dst_stride, int64_t L2,
+                                                             int pad, int centre, int mode) {
+    const int b = blockIdx.y;
+    const int64_t Lp = L + 2 * (int64_t)pad;
+    const float* src = wav + (int64_t)b * wav_stride;
+    float* row = dst + (int64_t)b * dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < (int64_t)(blockIdx.x + 1) * 1024 && i < dst_stride; i += 256) {
+        float v = 0.0f;
+        if (i < L2) {
+            int64_t u = i - centre;   // position in the zero-padded signal of Lp samples
+            bool zero = false;
+            if (u < 0 || u >= Lp) {
+                if (mode == MV_STFT_PAD_REFLECT) {
+                    u = u < 0 ? -u : 2 * (Lp - 1) - u;
+                } else if (mode == MV_STFT_PAD_REPLICATE) {
+                    u = u < 0 ? 0 : Lp - 1;
+                } else if (mode == MV_STFT_PAD_CIRCULAR) {
+                    u = u < 0 ? u + Lp : u - Lp;
+                } else {
+                    zero = true;
+                }
+            }
+            const int64_t k = u - pad;
+            if (!zero && k >= 0 && k < L) v = src[k];
+        }
+        row[i] = v;
+    }
+}
+
 __device__ __forceinline__ int reflect_index(int64_t i, int64_t L) {
     if (i < 0) i = -i;
     if (i >= L) i = 2 * (L - 1) - i;
@@ -506,6 +537,7 @@ __global__ __launch_bounds__(256) void cmn_mask_kernel(float* out, int T, int C,
 struct MvMelSpec {
     MvMelSpecCfg cfg;
     int nbin, nbin_pad, kpad, pad;
+    bool pre_pad = false;   // cfg.pad > 0 or a centre padding other than reflect: melspec_extend_kernel writes the extended signal to the workspace first
     float* d_window = nullptr;
     float* d_cos = nullptr;
     float* d_sin = nullptr;
@@ -553,6 +585,8 @@ void mv_melspec_default_cfg(MvMelSpecCfg* cfg) {
     cfg->norm = MV_MEL_NORM_NONE;
     cfg->normalized = MV_STFT_NORM_NONE;
     cfg->window = nullptr;
+    cfg->pad = 0;
+    cfg->pad_mode = MV_STFT_PAD_REFLECT;
 }
 
 int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
@@ -565,6 +599,8 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     MV_REQUIRE(cfg->mel_scale == MV_MEL_HTK || cfg->mel_scale == MV_MEL_SLANEY, "mv_melspec_create: unknown mel_scale");
     MV_REQUIRE(cfg->norm == MV_MEL_NORM_NONE || cfg->norm == MV_MEL_NORM_SLANEY, "mv_melspec_create: unknown norm");
     MV_REQUIRE(cfg->normalized >= MV_STFT_NORM_NONE && cfg->normalized <= MV_STFT_NORM_FRAME_LENGTH, "mv_melspec_create: unknown normalized mode");
+    MV_REQUIRE(cfg->pad >= 0 && cfg->pad < (1 << 24), "mv_melspec_create: pad must be a non-negative sample count");
+    MV_REQUIRE(cfg->pad_mode >= MV_STFT_PAD_REFLECT && cfg->pad_mode <= MV_STFT_PAD_CIRCULAR, "mv_melspec_create: unknown pad_mode");
     MvMelSpec* h = new MvMelSpec();
     h->cfg = *cfg;
     h->cfg.window = nullptr;   // (the caller's host array is read below and not kept)
@@ -573,6 +609,7 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     h->nbin_pad = (int)mv::round_up(h->nbin, 16);
     h->kpad = (int)mv::round_up(n_fft / 2 + 1, 16);  // folded transform length, padded to the MFMA K block
     h->pad = cfg->center ? n_fft / 2 : 0;
+    h->pre_pad = cfg->pad > 0 || (cfg->center && cfg->pad_mode != MV_STFT_PAD_REFLECT);
     const double pi = 3.14159265358979323846;
     // the window (periodic Hann of win_length unless the caller passed window_fn's values), centred in n_fft (torch.stft pads it on both sides)
     std::vector<float> window(n_fft, 0.0f);
@@ -707,6 +744,7 @@ int mv_melspec_destroy(MvMelSpec* h) {
 
 int mv_melspec_num_frames(const MvMelSpec* h, int64_t num_samples, int64_t* num_frames) {
     MV_REQUIRE(h != nullptr && num_frames != nullptr, "mv_melspec_num_frames: null argument");
+    num_samples += 2 * (int64_t)h->cfg.pad;
     if (h->cfg.center) {
         *num_frames = 1 + num_samples / h->cfg.hop_length;
     } else {
@@ -715,11 +753,18 @@ int mv_melspec_num_frames(const MvMelSpec* h, int64_t num_samples, int64_t* num_
     return MV_OK;
 }
 
+// the extended signal of a pre_pad handle: [B][stride] floats in front of the other workspace sections (a multiple of 256 bytes)
+static int64_t melspec_extended_len(const MvMelSpec* h, int64_t L) { return L + 2 * (int64_t)h->cfg.pad + 2 * (int64_t)h->pad; }
+static int64_t melspec_extended_stride(const MvMelSpec* h, int64_t L) { return mv::round_up(melspec_extended_len(h, L), (int64_t)4); }
+static size_t melspec_extended_bytes(const MvMelSpec* h, int32_t B, int64_t L) {
+    return h->pre_pad ? (size_t)mv::round_up((int64_t)B * melspec_extended_stride(h, L) * (int64_t)sizeof(float), (int64_t)256) : 0;
+}
+
 size_t mv_melspec_workspace_bytes(const MvMelSpec* h, int32_t B, int64_t L) {
     if (h == nullptr || B <= 0) return 0;
     int64_t T = 0;
     mv_melspec_num_frames(h, L, &T);
-    return (size_t)B * (size_t)T * h->nbin_pad * sizeof(float);
+    return melspec_extended_bytes(h, B, L) + (size_t)B * (size_t)T * h->nbin_pad * sizeof(float);
 }
 
 int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t L, int64_t wav_stride,
@@ -730,12 +775,34 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
     mv_melspec_num_frames(h, L, &T);
     if (B == 0 || T == 0) return MV_OK;
     MV_REQUIRE(wav != nullptr && out != nullptr && workspace != nullptr, "mv_melspec_forward: null buffer");
-    if (h->cfg.center) MV_REQUIRE(L > h->pad, "mv_melspec_forward: reflect padding needs more than n_fft/2 samples (torch.stft raises too)");
+    int centre_pad = h->pad;   // what the transform kernels still have to reflect themselves
+    if (h->pre_pad) {
+        const int64_t Lp = L + 2 * (int64_t)h->cfg.pad;
+        if (h->cfg.center && h->cfg.pad_mode == MV_STFT_PAD_REFLECT) MV_REQUIRE(Lp > h->pad, "mv_melspec_forward: reflect padding needs more than n_fft/2 samples (torch.stft raises too)");
+        if (h->cfg.center && h->cfg.pad_mode == MV_STFT_PAD_CIRCULAR) MV_REQUIRE(Lp >= h->pad, "mv_melspec_forward: circular padding needs at least n_fft/2 samples (torch.stft raises too)");
+        const size_t ext = melspec_extended_bytes(h, B, L);
+        MV_REQUIRE(workspace_bytes >= ext && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mv_melspec_forward: workspace too small for the extended signal (mv_melspec_workspace_bytes)");
+        MV_REQUIRE(B <= 65535, "mv_melspec_forward: pad / pad_mode take at most 65535 rows per call");
+        const int64_t L2 = melspec_extended_len(h, L), stride2 = melspec_extended_stride(h, L);
+        float* dst = static_cast<float*>(workspace);
+        MV_LAUNCH(mv::melspec_extend_kernel, ((unsigned)mv::ceil_div(L2, (int64_t)1024), (unsigned)B, 1), (256, 1, 1), 0, static_cast<hipStream_t>(stream), wav, wav_stride, L,
+                  dst, stride2, L2, h->cfg.pad, h->pad, h->cfg.pad_mode);
+        int rc = mv::check_launch("melspec_extend_kernel");
+        if (rc != MV_OK) return rc;
+        wav = dst;
+        wav_stride = stride2;
+        L = L2;
+        centre_pad = 0;
+        workspace = static_cast<char*>(workspace) + ext;
+        workspace_bytes -= ext;
+    } else if (h->cfg.center) {
+        MV_REQUIRE(L > h->pad, "mv_melspec_forward: reflect padding needs more than n_fft/2 samples (torch.stft raises too)");
+    }
     if (h->tile_kernel && (int64_t)T * h->cfg.n_mels < ((int64_t)1 << 31)) {
         mv::MelTileArgs t;
         t.wav = wav; t.wav_stride = wav_stride; t.L = L; t.lens_ratio = lens_ratio; t.out = out;
         t.window = h->d_window; t.tw400 = h->d_tw400; t.melb = h->d_melb;
-        t.B = B; t.T = (int)T; t.hop = h->cfg.hop_length; t.pad = h->pad; t.n_mels = h->cfg.n_mels; t.cmn = h->cfg.subtract_time_mean;
+        t.B = B; t.T = (int)T; t.hop = h->cfg.hop_length; t.pad = centre_pad; t.n_mels = h->cfg.n_mels; t.cmn = h->cfg.subtract_time_mean;
         t.plan = h->plan;
         // feature rows that fit next to the wave slots stay in LDS until the time mean is known; the rest go through global memory
         const size_t slots = (size_t)mv::MST_WAVES * mv::MST_SLOT_FLOATS * sizeof(float);
@@ -752,7 +819,7 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
         mv::MelFftArgs t;
         t.wav = wav; t.wav_stride = wav_stride; t.L = L; t.lens_ratio = lens_ratio; t.out = out;
         t.window = h->d_window; t.tw512 = h->d_tw512; t.w1024 = h->d_w1024; t.melb = h->d_melb;
-        t.B = B; t.T = (int)T; t.n_fft = h->cfg.n_fft; t.hop = h->cfg.hop_length; t.pad = h->pad; t.n_mels = h->cfg.n_mels;
+        t.B = B; t.T = (int)T; t.n_fft = h->cfg.n_fft; t.hop = h->cfg.hop_length; t.pad = centre_pad; t.n_mels = h->cfg.n_mels;
         t.cmn = h->cfg.subtract_time_mean;
         t.plan = h->plan;
         const size_t fixed = mv::melfft_fixed_lds_bytes();
@@ -765,7 +832,7 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
         mv::prof_end(prof, static_cast<hipStream_t>(stream));
         return rc;
     }
-    MV_REQUIRE(workspace_bytes >= mv_melspec_workspace_bytes(h, B, L), "mv_melspec_forward: workspace too small");
+    MV_REQUIRE(workspace_bytes >= (size_t)B * (size_t)T * h->nbin_pad * sizeof(float), "mv_melspec_forward: workspace too small");
     MV_REQUIRE((int64_t)B * T < ((int64_t)1 << 31), "mv_melspec_forward: too many frames");
     hipStream_t st = static_cast<hipStream_t>(stream);
     mv::StftArgs a;
@@ -781,7 +848,7 @@ int mv_melspec_forward(const MvMelSpec* h, const float* wav, int32_t B, int64_t 
     a.n_fft = h->cfg.n_fft;
     a.kpad = h->kpad;
     a.hop = h->cfg.hop_length;
-    a.pad = h->pad;
+    a.pad = centre_pad;
     a.nbin = h->nbin;
     a.nbin_pad = h->nbin_pad;
     a.power = h->cfg.power;

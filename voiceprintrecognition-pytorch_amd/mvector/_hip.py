@@ -32,7 +32,8 @@ class MvFbankCfg(ctypes.Structure):
 class MvMelSpecCfg(ctypes.Structure):
     _fields_ = [('sample_rate', c_i32), ('n_fft', c_i32), ('win_length', c_i32), ('hop_length', c_i32),
                 ('f_min', c_f32), ('f_max', c_f32), ('n_mels', c_i32), ('power', c_f32), ('center', c_i32),
-                ('subtract_time_mean', c_i32), ('mel_scale', c_i32), ('norm', c_i32), ('normalized', c_i32), ('window', c_vp)]
+                ('subtract_time_mean', c_i32), ('mel_scale', c_i32), ('norm', c_i32), ('normalized', c_i32), ('window', c_vp),
+                ('pad', c_i32), ('pad_mode', c_i32)]
 
 
 class MvTensorRef(ctypes.Structure):
@@ -311,6 +312,8 @@ class Fbank:
 class MelSpec:
     """Handle of the MelSpectrogram + CMN + mask path (mv_melspec_*)."""
 
+    PAD_MODES = {'reflect': 0, 'constant': 1, 'replicate': 2, 'circular': 3}
+
     def __init__(self, method_args=None, subtract_time_mean=True, cdll=None):
         self._cdll = cdll or lib()
         cfg = MvMelSpecCfg()
@@ -321,10 +324,11 @@ class MelSpec:
         for k in a:
             if k not in allowed:
                 raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
-        # not implemented: zero padding of the signal (pad), padding modes of the centred frames other than reflect, two-sided spectra
-        # (torchaudio's own MelScale refuses their bin count), power=None (a complex spectrogram has no mel scale)
-        if a.get('pad', 0) != 0 or a.get('pad_mode', 'reflect') != 'reflect' or a.get('onesided') not in (None, True) or a.get('power', 2.0) is None:
+        # not implemented: two-sided spectra (torchaudio's own MelScale refuses their bin count), power=None (a complex spectrogram has no mel scale)
+        if a.get('onesided') not in (None, True) or a.get('power', 2.0) is None:
             raise NotImplementedError('MelSpectrogram option not implemented by the HIP kernel')
+        if a.get('pad_mode', 'reflect') not in self.PAD_MODES:
+            raise NotImplementedError(f"Unrecognised padding mode {a.get('pad_mode')}")   # (torch.nn.functional.pad's own error class)
         if a.get('norm') not in (None, 'slaney'):
             raise ValueError('norm must be one of None or "slaney"')          # torchaudio.functional.melscale_fbanks' own messages
         if a.get('mel_scale', 'htk') not in ('htk', 'slaney'):
@@ -347,6 +351,8 @@ class MelSpec:
         cfg.mel_scale = 1 if a.get('mel_scale', 'htk') == 'slaney' else 0
         cfg.norm = 1 if a.get('norm') == 'slaney' else 0
         cfg.normalized = {False: 0, True: 1, 'window': 1, 'frame_length': 2}[a.get('normalized', False)]
+        cfg.pad = int(a.get('pad', 0))
+        cfg.pad_mode = self.PAD_MODES[a.get('pad_mode', 'reflect')]
         win_host = None
         if a.get('window_fn') is not None:   # torchaudio evaluates window_fn(win_length, **wkwargs) once, at construction: so does this
             win_host = a['window_fn'](cfg.win_length, **(a.get('wkwargs') or {})).detach().to(device='cpu', dtype=torch.float32).contiguous()

@@ -40,9 +40,10 @@ def validate_args(method, args):
         for k in args:
             if k not in _MEL_KEYS:
                 raise TypeError(f"MelSpectrogram got an unexpected keyword argument '{k}'")
-        if args.get('pad', 0) != 0 or args.get('pad_mode', 'reflect') != 'reflect' or args.get('onesided') not in (None, True) or \
-                args.get('power', 2.0) is None:
+        if args.get('onesided') not in (None, True) or args.get('power', 2.0) is None:
             raise NotImplementedError('MelSpectrogram option not implemented')
+        if args.get('pad_mode', 'reflect') not in ('reflect', 'constant', 'replicate', 'circular'):
+            raise NotImplementedError(f"Unrecognised padding mode {args.get('pad_mode')}")
         if args.get('norm') not in (None, 'slaney'):
             raise ValueError('norm must be one of None or "slaney"')
         if args.get('mel_scale', 'htk') not in ('htk', 'slaney'):
@@ -205,7 +206,9 @@ def melspec_batch(wav, args):
     fb = _mel_fbank(sr, n_fft, float(args.get('f_min', 0.0)), f_max, int(args.get('n_mels', 128)), args.get('mel_scale', 'htk'), args.get('norm'))
     window = args['window_fn'](win, **(args.get('wkwargs') or {})).float() if args.get('window_fn') is not None else torch.hann_window(win)
     normalized = args.get('normalized', False)
-    spec = torch.stft(wav, n_fft, hop, win, window, center=bool(args.get('center', True)), pad_mode='reflect',
+    if int(args.get('pad', 0)) > 0:   # torchaudio.functional.spectrogram: zeros on both sides of the signal
+        wav = torch.nn.functional.pad(wav, (int(args['pad']), int(args['pad'])), 'constant')
+    spec = torch.stft(wav, n_fft, hop, win, window, center=bool(args.get('center', True)), pad_mode=args.get('pad_mode', 'reflect'),
                       normalized=normalized == 'frame_length', onesided=True, return_complex=True)
     if normalized in (True, 'window'):
         spec = spec / window.pow(2.0).sum().sqrt()
