@@ -95,6 +95,19 @@ inline void row_swap_odd_even(unsigned& x, unsigned& y) {
 inline float lane_gather(float v, int byte_index) { return emu::shfl_from(v, (byte_index >> 2) & 63); }
 
 inline float fmed3(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// MODE.FP16_OVFL stand-ins: the emulator saturates where the hardware mode would (finite overflow -> +-65504; infinities and NaNs pass)
+inline void fp16_saturation_on() {}
+inline half_t half_hwsat(float v) { return (half_t)((v > 65504.0f && v < INFINITY) ? 65504.0f : ((v < -65504.0f && v > -INFINITY) ? -65504.0f : v)); }
+template <class V>
+inline V pk_add_hwsat(V a, V b) {
+    V r = a + b;
+    for (unsigned i = 0; i < sizeof(V) / sizeof(half_t); ++i) {
+        const float fa = (float)a[i], fb = (float)b[i], s = fa + fb;   // (an overflowed sum of finite operands saturates; inf / NaN operands pass)
+        if (fa - fa == 0.0f && fb - fb == 0.0f) r[i] = (half_t)(s > 65504.0f ? 65504.0f : (s < -65504.0f ? -65504.0f : s));
+    }
+    return r;
+}
 inline float max_raw(float v, float lo) { return fmaxf(v, lo); }
 inline float exp2_fast(float v) { return exp2f(v); }
 inline float rcp_fast(float v) { return 1.0f / v; }

@@ -27,7 +27,7 @@ def pack_weight(cdll, w):
 
 def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, pad_mode='reflect', valid=False,
                 x_f32=False, y_f32=False, with_x2=False, in_affine=False, pre_act=1, affine=True, post_act=0,
-                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0, clock_probe=False, return_y=False):
+                row_bias=False, gate_seg=0, extra_ld=8, second_out=False, tile=0, stats=0, in_stats=False, seed=0, persist_blocks=0, clock_probe=False, return_y=False, out_gain=1.0):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     ldx = cin + extra_ld
@@ -35,7 +35,7 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
     x2full = rn(B, T, ldx) if with_x2 else None
     w = rn(cout, cin, k) * (2.0 / (cin * k)) ** 0.5
     bias = rn(cout) * 0.1
-    scale = torch.rand(cout, generator=g) + 0.5 if affine else None
+    scale = (torch.rand(cout, generator=g) + 0.5) * out_gain if affine else None   # out_gain: drives the outputs beyond the fp16 range (saturation at +-65504)
     shift = rn(cout) * 0.1 if affine else None
     in_s = torch.rand(cin, generator=g) + 0.5 if in_affine else None
     in_t = rn(cin) * 0.2 if in_affine else None
@@ -130,6 +130,11 @@ def conv1d_case(cdll, device, B=2, T=37, cin=24, cout=40, k=3, dil=2, stride=1, 
         ref = ref * gate[:, seg, :]
     got = y.cpu().float()
     assert torch.all(got[..., cout:] == 7.0), 'kernel wrote outside its channel slice'
+    if not y_f32:   # fp16 outputs saturate instead of overflowing (v_med3 / MODE.FP16_OVFL)
+        assert bool(torch.isfinite(got).all()), 'the kernel produced an infinity or a NaN'
+        ref = ref.clamp(-65504.0, 65504.0)
+        if out_gain > 1.0:
+            assert (ref.abs() == 65504.0).float().mean().item() > 0.05, 'the case does not saturate'
     err = (got[..., :cout] - ref).abs().max().item()
     tol = 2e-4 if y_f32 else 4e-3 * max(1.0, ref.abs().max().item())
     assert err < tol, f'conv1d mismatch {err} (tol {tol})'
@@ -1032,14 +1037,16 @@ def melspec_arguments_case(cdll, device, idx, B=3, seconds=0.5):
     return melspec_case(cdll, device, wav, ratio, args)
 
 
-def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0, alone_rows=0):
-    """Fused Res2Net chain vs a torch fp32 evaluation that rounds to fp16 exactly where the kernel does."""
+def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, seed=0, alone_rows=0, gain=1.0):
+    """Fused Res2Net chain vs a torch fp32 evaluation that rounds to fp16 exactly where the kernel does.  gain: multiplies the BatchNorm scales --
+    large values drive the step outputs and the next-input sums beyond the fp16 range, where the kernel saturates at +-65504 (MODE.FP16_OVFL since
+    round 6; v_med3 / packed min / max before) and never produces an infinity."""
     g = torch.Generator().manual_seed(seed)
     C = width * groups
     x = torch.randn(B, T, C, generator=g).half()
     ws = [torch.randn(width, width, k, generator=g) * (2.0 / (width * k)) ** 0.5 for _ in range(groups - 1)]
     bs = [torch.randn(width, generator=g) * 0.1 for _ in range(groups - 1)]
-    ss = [torch.rand(width, generator=g) + 0.5 for _ in range(groups - 1)]
+    ss = [(torch.rand(width, generator=g) + 0.5) * gain for _ in range(groups - 1)]
     ts = [torch.randn(width, generator=g) * 0.1 for _ in range(groups - 1)]
     xd = x.to(device)
     y = torch.full((B, T, C), 9.0, dtype=torch.float16, device=device)
@@ -1057,13 +1064,24 @@ def res2_chain_case(cdll, device, B=2, T=45, width=64, groups=8, k=3, dil=3, see
     for j in range(1, groups):
         inp = xs[:, j * width:(j + 1) * width]
         if j > 1:
-            inp = (inp + prev).half().float()
+            inp = (inp + prev).clamp(-65504.0, 65504.0).half().float()
         z = F.conv1d(F.pad(inp, (pad, pad), mode='reflect'), ws[j - 1].half().float(), bs[j - 1], dilation=dil)
         z = torch.relu(z) * ss[j - 1].view(1, -1, 1) + ts[j - 1].view(1, -1, 1)
-        prev = z.half().float()
+        prev = z.clamp(-65504.0, 65504.0).half().float()
         outs.append(prev)
     ref = torch.cat(outs, 1).transpose(1, 2)
-    err = (y.cpu().float() - ref).abs().max().item()
+    got = y.cpu().float()
+    assert bool(torch.isfinite(got).all()), 'the chain produced an infinity or a NaN'
+    if gain > 1.0:
+        assert (ref.abs() == 65504.0).float().mean().item() > 0.05, 'the case does not saturate'
+        sat = ref.abs() == 65504.0
+        assert bool((got[sat] == ref[sat]).float().mean() > 0.99), 'saturated values differ'
+        # (sums of saturated inputs cancel: where a pre-activation lands within rounding of zero, ReLU x gain turns an fp32 ordering difference into
+        #  0 against 65504 -- a property of the case, not of the kernel; the bulk must agree)
+        far = ((got - ref).abs() > 1e-2 * 65504.0).float().mean().item()
+        assert far < 0.01, far
+        return far
+    err = (got - ref).abs().max().item()
     assert err < 1e-2 * max(1.0, ref.abs().max().item()), err
     if alone_rows:
         # the same utterances one at a time: a small batch takes the 5-tile chunk form (<= 160 frames per workgroup, halo rows), a batch that

@@ -41,6 +41,13 @@ def test_emu_conv1d(idx):
     lc.conv1d_case(emu_cdll(), 'cpu', seed=idx, **lc.CONV_CASES[idx])
 
 
+@pytest.mark.parametrize('cfg', [dict(k=1, dil=1, cin=128, cout=256, T=150, B=2, tile=256),                  # ring kernel: MODE.FP16_OVFL
+                                 dict(k=1, dil=1, cin=128, cout=256, T=150, B=2, tile=256, post_act=1),       # post-activation: the double-buffer kernel (v_med3)
+                                 dict(k=3, dil=2, cin=64, cout=128, T=70, B=2), dict(k=1, dil=1, cin=64, cout=64, T=33, B=1)])   # 128 / 64 tiles
+def test_emu_conv1d_saturates_at_the_fp16_range(cfg):
+    lc.conv1d_case(emu_cdll(), 'cpu', seed=5, out_gain=1.0e5, **cfg)
+
+
 def test_emu_profile_classes_ring_is_a_subset_of_conv1d():
     lc.profile_classes_case(emu_cdll(), 'cpu')
 
@@ -280,6 +287,12 @@ def test_emu_asp_pool(cfg):
                                  dict(width=64, T=400, dil=2, B=1), dict(width=128, T=331, dil=4, B=1)])   # > 320 frames: two chunks with halo rows
 def test_emu_res2net_fused_chain(cfg):
     lc.res2_chain_case(emu_cdll(), 'cpu', **cfg)
+
+
+@pytest.mark.parametrize('cfg', [dict(B=2, T=45, width=64, dil=3), dict(B=1, T=100, width=128, dil=2), dict(B=3, T=170, width=128, dil=4)])
+def test_emu_res2net_chain_saturates_at_the_fp16_range(cfg):
+    """BatchNorm scales of 3e4: step outputs and next-input sums leave the fp16 range; the chain saturates at +-65504 (ring, direct and 5-tile forms)"""
+    lc.res2_chain_case(emu_cdll(), 'cpu', seed=11, gain=3.0e4, **cfg)
 
 
 def test_emu_res2net_chain_small_batch_form_carries_the_same_bits():

@@ -59,6 +59,15 @@ def test_conv1d_window(cfg):
     lc.conv1d_window_case(product_lib(), DEV, **cfg)
 
 
+@pytest.mark.parametrize('cfg', [dict(k=1, dil=1, cin=128, cout=256, T=150, B=2, tile=256), dict(k=1, dil=1, cin=1024, cout=1024, T=298, B=64),
+                                 dict(k=1, dil=1, cin=128, cout=256, T=150, B=2, tile=256, post_act=1),
+                                 dict(k=3, dil=2, cin=64, cout=128, T=70, B=2), dict(k=1, dil=1, cin=64, cout=64, T=33, B=1)])
+def test_gpu_conv1d_saturates_at_the_fp16_range(cfg):
+    """BatchNorm scales of 1e5: fp16 outputs saturate at +-65504 and never become infinite -- the ring kernel through MODE.FP16_OVFL
+    (tools/fp16_ovfl_probe.hip), every other kernel through its v_med3"""
+    lc.conv1d_case(product_lib(), DEV, seed=5, out_gain=1.0e5, **cfg)
+
+
 def test_gpu_profile_classes_ring_is_a_subset_of_conv1d():
     lc.profile_classes_case(product_lib(), DEV)
 
@@ -796,6 +805,13 @@ def test_gpu_fcm_block_with_first_conv(idx):
                                  dict(width=128, T=321, dil=4, B=3), dict(width=128, T=998, dil=2, B=2), dict(width=64, T=600, dil=3, B=2), dict(width=128, T=600, dil=3, B=128)])   # > 320 frames: chunks with halo rows
 def test_gpu_res2net_fused_chain(cfg):
     lc.res2_chain_case(product_lib(), DEV, **cfg)
+
+
+@pytest.mark.parametrize('cfg', [dict(B=2, T=45, width=64, dil=3), dict(B=1, T=100, width=128, dil=2), dict(B=3, T=170, width=128, dil=4), dict(B=300, T=298, width=128, dil=3)])
+def test_gpu_res2net_chain_saturates_at_the_fp16_range(cfg):
+    """BatchNorm scales of 3e4: step outputs and next-input sums leave the fp16 range; the chain saturates at +-65504 through MODE.FP16_OVFL
+    (tools/fp16_ovfl_probe.hip) on every launch form -- ring, direct, 5-tile chunks, a batch that fills the chip"""
+    lc.res2_chain_case(product_lib(), DEV, seed=11, gain=3.0e4, **cfg)
 
 
 @pytest.mark.parametrize('cfg', [dict(T=298, dil=2), dict(T=298, dil=3), dict(T=298, dil=4), dict(T=150, dil=3), dict(T=500, dil=2), dict(T=81, dil=4)])

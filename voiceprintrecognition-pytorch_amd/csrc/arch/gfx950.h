@@ -103,6 +103,15 @@ __device__ __forceinline__ float lane_gather(float v, int byte_index) {
 
 // ---- arithmetic with a single-instruction spelling ---------------------------------------------------------------------------
 __device__ __forceinline__ float fmed3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+
+// MODE.FP16_OVFL (bit 23 of the wave's mode register): an fp16 RESULT that overflows -- a conversion from fp32, a packed fp16 sum -- is clamped to
+// +-65504 instead of becoming +-inf; true infinities and NaNs pass (tools/fp16_ovfl_probe.hip, profiles/r15ap: gfx950 honours it).  One s_setreg per
+// wave then stands for the saturation the epilogues spelled out per value (v_med3_f32 against +-65504) and per pair (v_pk_min_f16 + v_pk_max_f16).
+// A kernel that converts with half_hwsat / adds with pk_add_hwsat calls fp16_saturation_on() first -- every wave, before any fp16 arithmetic.
+__device__ __forceinline__ void fp16_saturation_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 4" ::: "memory"); }
+__device__ __forceinline__ half_t half_hwsat(float v) { return (half_t)v; }
+template <class V>
+__device__ __forceinline__ V pk_add_hwsat(V a, V b) { return a + b; }
 // max(v, lo) as exactly one v_max_f32: fmaxf / v_med3 against +inf are lowered to a canonicalising v_max v, v, v plus the
 // max itself, which doubled the activation cost of the 128-value epilogues
 __device__ __forceinline__ float max_raw(float v, float lo) {

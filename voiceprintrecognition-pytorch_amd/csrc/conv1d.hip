@@ -798,9 +798,12 @@ struct LaneParams {  // ring kernel (no LDS left): lane L of the wave holds chan
     __device__ __forceinline__ float4v shift4(int mi) const { return get(t, mi); }
 };
 
-template <int STATS, class P>
+// HWSAT (ring kernel; STATS == 0, no post-activation -- the launcher sends everything else to the double-buffer kernel): the fp16 saturation is the
+// wave's MODE.FP16_OVFL (arch/gfx950.h: fp16_saturation_on / half_hwsat), not a v_med3 per value: 2.5 instead of 3.5 vector issue slots per value.
+template <int STATS, bool HWSAT = false, class P>
 __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& par, int n0, int co0, int wc, int wn, int lane,
                                                     float4v (&acc)[8][4]) {
+    static_assert(!HWSAT || STATS == 0, "the hardware-saturated form is the plain epilogue");
     const int r = lane & 15, q = lane >> 4;
     half_t* y = reinterpret_cast<half_t*>(a.y);
     // host admits none / ReLU only: max(v, -inf) is the identity
@@ -830,10 +833,17 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
                 v0 = v0 * float2v{sc[u][0], sc[u][1]} + float2v{sh[u][0], sh[u][1]};
                 v1 = v1 * float2v{sc[u][2], sc[u][3]} + float2v{sh[u][2], sh[u][3]};
                 half4v hv;
-                hv[0] = (half_t)clamp3(v0[0], lo_post, 65504.0f);
-                hv[1] = (half_t)clamp3(v0[1], lo_post, 65504.0f);
-                hv[2] = (half_t)clamp3(v1[0], lo_post, 65504.0f);
-                hv[3] = (half_t)clamp3(v1[1], lo_post, 65504.0f);
+                if constexpr (HWSAT) {
+                    hv[0] = half_hwsat(v0[0]);
+                    hv[1] = half_hwsat(v0[1]);
+                    hv[2] = half_hwsat(v1[0]);
+                    hv[3] = half_hwsat(v1[1]);
+                } else {
+                    hv[0] = (half_t)clamp3(v0[0], lo_post, 65504.0f);
+                    hv[1] = (half_t)clamp3(v0[1], lo_post, 65504.0f);
+                    hv[2] = (half_t)clamp3(v1[0], lo_post, 65504.0f);
+                    hv[3] = (half_t)clamp3(v1[1], lo_post, 65504.0f);
+                }
                 return hv;
             };
 #pragma unroll
@@ -1267,6 +1277,7 @@ constexpr int CVR_LDS_BYTES = 5 * CVR_SLOT_BYTES;  // 163 840 B
 __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a) {
     constexpr int MI = 8, NI = 4, TC = 256, TN = 256, NTW = 4, NTX = 4;
     MV_DYN_SMEM(smem);
+    fp16_saturation_on();   // the epilogue converts with half_hwsat
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = MV_UNIFORM(tid >> 6);  // scalar: LDS destinations of the transfers are SGPR math
@@ -1404,7 +1415,7 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
             if (pending) {
                 mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);   // the previous tile's last MFMA group (operands in registers since the barrier)
                 mfma_hazard_pad();
-                persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+                persistent_epilogue<0, true>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
             }
             if (c_co0 != held_co0) load_params(c_co0);  // uniform, at most once per launch on the shipped shapes
             // accumulators start from the bias of their 4 channels
@@ -1453,7 +1464,7 @@ __global__ __launch_bounds__(512) void conv1d_ring_persistent_kernel(ConvArgs a)
     lds_wait<0>(af[1][0], af[1][1]);   // the last stage's step-7 fragments
     mfma8_step<0>(acc[6], acc[7], af[1][0], af[1][1], bf1);
     mfma_hazard_pad();
-    persistent_epilogue<0>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
+    persistent_epilogue<0, true>(a, hp, e_n0, e_co0, wc, wn, lane, acc);
     if (a.clock_probe != nullptr && tid == 0) {
         unsigned long long* p = a.clock_probe + 4 * (size_t)blockIdx.x;
         p[0] = clk0;
@@ -1814,7 +1825,9 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     // dense 1x1 rows (input row == output row) with 32-bit byte offsets into both tensors: the ring kernel's loader
     const bool dense_rows = simple && d.stride == 1 && d.pad == 0 && d.T_in == d.T_out &&
                             (int64_t)a.n_rows * d.ldx * 2 < ((int64_t)1 << 32) && (int64_t)d.cout * a.cin_pad * 2 < ((int64_t)1 << 32);
-    const bool ring = persist && stats == 0 && dense_rows;
+    // (a post-activation stays with the double-buffer kernel: the ring kernel's epilogue leaves the fp16 saturation to the hardware and has no v_med3 to
+    //  fold a lower bound into -- no layer of the models has one behind its BatchNorm)
+    const bool ring = persist && stats == 0 && dense_rows && d.post_act == MV_ACT_NONE;
     // The ring walk's tail.  A launch lasts as many tile times as its longest walk: 3600 tiles of an MFA layer (256 utterances of 300 frames x 3072
     // channels) on 256 workgroups are 14.06 rounds, so 15 -- the last one with 16 workgroups at work.  (The headline batch has 298 frames: 3576 tiles =
     // 13.97 rounds, nothing to split -- since the tile ids are dense; with the holes of the walk before round 6 it was 15 rounds as well.)  Splitting K over workgroups (stream-K) would fill it, but sums a tile

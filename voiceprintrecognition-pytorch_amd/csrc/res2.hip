@@ -96,6 +96,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     constexpr int ROWS_T = 2 * NHT * 16 + 2 * R2_MAXPAD;            // rows of the activation buffer
     constexpr int XNEXT_T = NHT == R2_NH ? R2_XNEXT_BYTES : 2 * NHT * 16 * 64 * MI * 2;   // direct form: the next channel group's rows
     MV_DYN_SMEM(smem);
+    fp16_saturation_on();                // the epilogue's fp16 conversions and packed sums saturate in hardware (half_hwsat / pk_add_hwsat)
     constexpr int WIDTH = 64 * MI;
     constexpr int CPR = WIDTH / 8;       // 16-byte chunks per activation row
     constexpr int ROWB = WIDTH * 2;      // bytes per activation row
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 for (int mi = 0; mi < 2; ++mi) {
                     half4v hv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[r] = (half_t)r2_clamp_h(fmaxf(acc[mi][ni][r] + bias4[mi][r], 0.0f) * scale4[mi][r] + shift4[mi][r]);
+                    for (int r = 0; r < 4; ++r) hv[r] = half_hwsat(fmaxf(acc[mi][ni][r] + bias4[mi][r], 0.0f) * scale4[mi][r] + shift4[mi][r]);   // (saturating: FP16_OVFL)
                     __builtin_memcpy(w[mi], &hv, 8);
                 }
                 row_swap_odd_even(w[0][0], w[1][0]);
@@ -458,8 +459,6 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 const unsigned o[4] = {w[0][0], w[0][1], w[1][0], w[1][1]};
                 half8v ov;
                 __builtin_memcpy(&ov, o, 16);
-                const half8v hi8 = {(half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f,
-                                    (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f};
                 half8v xnext;
                 if constexpr (!DIRECT) {
                     xnext = xp[ni];
@@ -467,7 +466,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     const int tc = t < T ? t : T - 1;
                     xnext = *reinterpret_cast<const half8v*>(wbuf + tc * ROWB + (((co8 >> 3) ^ (tc & 15)) << 4));
                 }
-                const half8v nv = __builtin_elementwise_max(__builtin_elementwise_min(ov + xnext, hi8), -hi8);
+                const half8v nv = pk_add_hwsat(ov, xnext);   // the packed sum saturates in hardware (FP16_OVFL)
                 if (t >= st0 && t < st1) *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
                 if (t < T) {
                     if (more) {
@@ -489,15 +488,11 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 const int t = (nh0 + ni) * 16 + fr;
                 half4v hv, nv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (half_t)r2_clamp_h(fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r]);
+                for (int r = 0; r < 4; ++r) hv[r] = half_hwsat(fmaxf(acc[mi][ni][r] + bias4[r], 0.0f) * scale4[r] + shift4[r]);
                 // x_{j+1} + y_j in packed fp16: the sum of two fp16 values rounded once IS what float-add-then-round gives;
                 // saturation by packed min / max (the in-kernel timeline shows the epilogue as expensive as the whole K loop:
                 // ~16 k of ~42 k cycles per step, all VALU)
-                {
-                    const half4v sum = hv + xn[mi][ni];
-                    const half4v hi4 = {(half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f, (half_t)65504.0f};
-                    nv = __builtin_elementwise_max(__builtin_elementwise_min(sum, hi4), -hi4);
-                }
+                nv = pk_add_hwsat(hv, xn[mi][ni]);
                 if (t >= st0 && t < st1) *reinterpret_cast<half4v*>(yb + (int64_t)t * a.C + j * WIDTH + co) = hv;
                 if (t < T) {
                     if (more) {
