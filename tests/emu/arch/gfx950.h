@@ -94,7 +94,7 @@ inline void row_swap_odd_even(unsigned& x, unsigned& y) {
 
 inline float lane_gather(float v, int byte_index) { return emu::shfl_from(v, (byte_index >> 2) & 63); }
 
-inline float fmed3(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+inline float fmed3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }   // the median of three, whatever their order (v_med3_f32)
 
 // MODE.FP16_OVFL stand-ins: the emulator saturates where the hardware mode would (finite overflow -> +-65504; infinities and NaNs pass)
 inline void fp16_saturation_on() {}
