@@ -40,6 +40,15 @@
 // fragment loads the compiler waits for, every fragment wait now also waits for the stores of the stage before (the chain without ANY y
 // stores: 95 us, so the stores cost 15 us in the epilogue and 26 us in the loop).  Parked.
 //
+// Round 6 (r15bb-bd, ISA reading): every weight-fragment request used to sit behind a condition ("is there such a stage / a next step"), i.e. in a block the
+// wave may skip, and at each join the compiler's wait-count insertion assumes a skipped request: its waits came out four to eight operations too strict --
+// vmcnt(1) / vmcnt(0) in the middle of every step's last stage, right behind the four requests just issued.  The direct form is now straight-line code (k = 3
+// only: six written-out stages, requests unconditional, the last step re-requests its own weights, the first two stages requested in front of the prologue copy)
+// and the compiler's waits are the vmcnt(9) / vmcnt(8) the two-stage lead was written for; the epilogue's parameters are requested in front of the step's last
+// ten MFMAs.  Chain alone 104-111 -> 100-105 us; IN SITU (per-dispatch medians of the headline step) 103-105 -> 102.5-103 us -- behind the tdnn1 GEMM the chain is
+// not bound by these waits.  All ten y stores first and the LDS part in a second pass: +4 us (one LDS round trip per tile with nothing to hide it behind).
+// Every second workgroup of an XCD started 1-6 us late (is the y-store burst of 256 workgroups in lockstep what the next step waits for?): slower by the delay.
+//
 // Long utterances (r10u): beyond 320 frames the launcher cuts an utterance into chunks (Res2Args::nchunks / useful / halo) -- the kernel body runs
 // unchanged on a chunk's rows + halo, only the row base and the y store mask are per chunk: EcapaTdnn-1024 at 6 s 177 -> 204 k audio-seconds/s
 // against one launch per step.
@@ -119,27 +128,15 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
     half_t* yb = a.y + rowbase * a.C;
     auto a_off = [&](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CPR - 1))) << 4); };
 
-    // ---- slice 0 passes through; slice 1 (with its reflected halo) becomes the first step's input; rows beyond stay zero ----
-    for (int i = tid; i < ROWS_T * CPR; i += R2_THREADS) {
-        const int row = i / CPR, ch = i - row * CPR;
-        const int t = row - PAD;
-        half8v v1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v1[e] = (half_t)0.0f;
-        if (t >= -PAD && t < T + PAD) {
-            const int ts = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
-            v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)ts * a.C + WIDTH + ch * 8);
-            if (t >= st0 && t < st1)
-                *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + ch * 8) = *reinterpret_cast<const half8v*>(xb + (int64_t)t * a.C + ch * 8);
-        }
-        *reinterpret_cast<half8v*>(abuf + a_off(row, ch)) = v1;
-    }
-
     const int cw = wave & 3;   // channel tile group
     const int th = wave >> 2;  // time half
     const int nh0 = th * NHT;  // first time tile of this wave
-    const int kstages_per_tap = a.kpad / 64;
-    const int nstages = a.k * kstages_per_tap;
+    // direct form: k = 3 and width 128 (launcher), so a step is SIX K stages of 64 channels, two per tap -- compile-time, the K loop is straight-line code
+    // (behind a run-time trip count the wait-count insertion merged "loop not entered" with "loop left" at the loop's exit and again waited for all but the
+    // youngest four requests, i.e. also for the stage requested one stage earlier)
+    const int kstages_per_tap = DIRECT ? 2 : a.kpad / 64;
+    const int nstages = DIRECT ? 6 : a.k * kstages_per_tap;
+    const int wk = DIRECT ? 3 : a.k, wkpad = DIRECT ? 128 : a.kpad;   // weight layout [width][k][kpad]
     // weight transfers: a stage is [WIDTH rows][64] = WIDTH/8 transfers of 1 KiB; wave w issues transfers w, w+8
     const int lrow = lane >> 3;
     const int kc = (lane & 7) ^ lrow;
@@ -169,27 +166,44 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int row = (cw * 2 + mi) * 16 + fr;
-                dst[kk][mi] = *MV_GLOBAL_PTR(half8v, wj + ((int64_t)row * a.k + tap) * a.kpad + c0 + (kk * 4 + fg) * 8);
+                dst[kk][mi] = *MV_GLOBAL_PTR(half8v, wj + ((int64_t)row * wk + tap) * wkpad + c0 + (kk * 4 + fg) * 8);
             }
         MV_VM_LOADS(4);   // (the direct form's r2_wait_vm<4>() behind the last stage counts these four)
     };
-    // weight fragments of the stage that runs `ahead` stages after stage s of step j (possibly in the next step; nothing after the last)
-    auto load_ahead = [&](int j, int s, half8v (&dst)[2][2]) {
-        if (s < nstages) {
-            load_wf(a.w[j - 1], s, dst);
-        } else if (j < a.steps) {
-            load_wf(a.w[j], s - nstages, dst);
-        }
-    };
+    // The fragments of the stage two stages ahead are requested UNCONDITIONALLY, by straight-line code: the last two stages of a step request stages 0 and 1 of
+    // the next step's weights, the last step re-requests its own (values never used).  Behind a condition ("is there a next step") each request sat in a
+    // skipped block, and at every join the compiler's wait-count insertion assumed it had NOT been issued: its waits for the fragments of the running stage came
+    // out four to eight operations too strict -- vmcnt(1) / vmcnt(0) in the middle of the last stage, right behind the four requests just issued (one exposed L2
+    // round trip per step), vmcnt(5) / vmcnt(4) elsewhere (a lead of one stage where two were written), and a scalar load of the weight pointer with
+    // s_waitcnt lgkmcnt(0) -- which also drains the LDS fragment reads issued a phase ahead -- in front of every request (ISA of round 6, r15bb).
+    // (the first two stages' fragments are requested in FRONT of the prologue copy below: its own waits retire them, so the first step starts without a wait the
+    // compiler would otherwise carry into every step's stage 0 through the loop header -- and there it waits for the previous epilogue's y stores as well)
     if constexpr (DIRECT) {
-        load_ahead(1, 0, wf[0]);
-        load_ahead(1, 1, wf[1]);
+        load_wf(a.w[0], 0, wf[0]);
+        load_wf(a.w[0], 1, wf[1]);
+    }
+
+    // ---- slice 0 passes through; slice 1 (with its reflected halo) becomes the first step's input; rows beyond stay zero ----
+    for (int i = tid; i < ROWS_T * CPR; i += R2_THREADS) {
+        const int row = i / CPR, ch = i - row * CPR;
+        const int t = row - PAD;
+        half8v v1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v1[e] = (half_t)0.0f;
+        if (t >= -PAD && t < T + PAD) {
+            const int ts = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            v1 = *reinterpret_cast<const half8v*>(xb + (int64_t)ts * a.C + WIDTH + ch * 8);
+            if (t >= st0 && t < st1)
+                *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + ch * 8) = *reinterpret_cast<const half8v*>(xb + (int64_t)t * a.C + ch * 8);
+        }
+        *reinterpret_cast<half8v*>(abuf + a_off(row, ch)) = v1;
     }
 
 
     for (int j = 1; j <= a.steps; ++j) {
 
         const half_t* wj = a.w[j - 1];
+        [[maybe_unused]] const half_t* wnext = a.w[j < a.steps ? j : j - 1];   // direct form: the weights whose first two stages the last two stages request
         auto issue_w = [&](int s, int buf) {
             const int tap = s / kstages_per_tap;
             const int c0 = (s - tap * kstages_per_tap) * 64;
@@ -306,8 +320,18 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 const int chunk = (c0 >> 3) + fg + 4 * khalf;
                 return lds_addr(abuf) + (unsigned)(row0 * ROWB + ((chunk ^ (row0 & (CPR - 1))) << 4));
             };
-            auto stage = [&](int s, half8v (&cur)[2][2], half8v (&ahead)[2][2], auto LAST) __attribute__((always_inline)) {
-                load_ahead(j, s + 2, ahead);
+            auto request_params = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int co = (cw * 2 + mi) * 16 + 4 * fg;
+                    pbias4[mi] = *MV_GLOBAL_PTR(float4v, a.bias[j - 1] + co);
+                    pscale4[mi] = *MV_GLOBAL_PTR(float4v, a.scale[j - 1] + co);
+                    pshift4[mi] = *MV_GLOBAL_PTR(float4v, a.shift[j - 1] + co);
+                }
+                MV_VM_LOADS(6);
+            };
+            auto stage = [&](int s, half8v (&cur)[2][2], half8v (&ahead)[2][2], auto LAST, const half_t* w_ahead, int s_ahead) __attribute__((always_inline)) {
+                load_wf(w_ahead, s_ahead, ahead);
                 const unsigned bp1 = b_addr(s, 1);
                 if constexpr (NHT == 5) {
                     // one group of five time tiles: bA holds K half 0 of this stage (requested one phase earlier), bB takes K half 1 while the
@@ -364,6 +388,9 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp1);
                 mfma10_step<5>(&acc[0][0], &acc[1][0], cur[1][0], cur[1][1], bA);
                 if constexpr (decltype(LAST)::value) {
+                    // the epilogue's bias / scale / shift are requested HERE, in front of the step's last ten MFMAs (the first fragment group and the K half 0
+                    // fragments are dead: their registers take them) -- requested at the start of the epilogue they are one exposed L2 round trip per step
+                    request_params();
                     mfma10_step<0>(&acc[0][NG], &acc[1][NG], cur[1][0], cur[1][1], bB);
                 } else {
                     const unsigned np0 = b_addr(s + 1, 0);
@@ -380,39 +407,30 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                 lds_read5<0, 16 * ROWB>(bA, bp0);
                 if constexpr (NHT != 5) lds_read5<NG * 16 * ROWB, 16 * ROWB>(bB, bp0);
             }
-            // nstages is a multiple of 3 here (launcher), so the rotation of the three fragment sets is static
-            for (int s = 0; s + 3 < nstages; s += 3) {
-                stage(s, wf[0], wf[2], std::false_type{});
-                stage(s + 1, wf[1], wf[0], std::false_type{});
-                stage(s + 2, wf[2], wf[1], std::false_type{});
-            }
-            stage(nstages - 3, wf[0], wf[2], std::false_type{});
-            stage(nstages - 2, wf[1], wf[0], std::false_type{});
+            // six stages, the three fragment sets in rotation, every set requested two stages ahead of its use
+            stage(0, wf[0], wf[2], std::false_type{}, wj, 2);
+            stage(1, wf[1], wf[0], std::false_type{}, wj, 3);
+            stage(2, wf[2], wf[1], std::false_type{}, wj, 4);
+            stage(3, wf[0], wf[2], std::false_type{}, wj, 5);
+            stage(4, wf[1], wf[0], std::false_type{}, wnext, 0);
             // Small-batch form: the epilogue's bias / scale / shift are requested HERE, one stage ahead of their use (older than the last stage's four
             // fragment loads, so the counted wait behind the K loop covers them) -- requested at the start of the epilogue they are one exposed L2 round
-            // trip per step: one utterance 427.7 -> 420.5 us of GPU time (r14v).  The full-batch form keeps them in the epilogue: there the same change
-            // measured -0.9 % on the headline (18 more registers through the last stage; the chain alone unchanged).
-            if constexpr (NHT == 5) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int co = (cw * 2 + mi) * 16 + 4 * fg;
-                    pbias4[mi] = *MV_GLOBAL_PTR(float4v, a.bias[j - 1] + co);
-                    pscale4[mi] = *MV_GLOBAL_PTR(float4v, a.scale[j - 1] + co);
-                    pshift4[mi] = *MV_GLOBAL_PTR(float4v, a.shift[j - 1] + co);
-                }
-                MV_VM_LOADS(6);
-            }
-            stage(nstages - 1, wf[2], wf[1], std::true_type{});
+            // trip per step: one utterance 427.7 -> 420.5 us of GPU time (r14v).  The full-batch form requests them inside the last stage, in front of its last
+            // ten MFMAs, where two fragment groups have died (r15bc; one stage earlier it measured -0.9 % on the headline in round 5: 18 more registers
+            // through the whole stage -- and, as the ISA of round 6 showed, behind waits that drained them at once).
+            if constexpr (NHT == 5) request_params();
+            stage(5, wf[2], wf[1], std::true_type{}, wnext, 1);
             mfma_hazard_pad();  // the assembly MFMAs are invisible to the compiler's hazard padding
             // x_{j+1} has landed for this wave once at most the fragment loads of the last stage (younger than every transfer; none after
             // the last step) are outstanding; the barrier below then publishes every wave's rows
             // (at most 10 transfers per wave, XPS = 2 per stage: the last ones leave in stage 4 at the latest, and nstages >= 6, so the
             // four fragment loads of the last stage are younger.  Requesting the next step's stage-2 fragments here, ahead of the epilogue's
             // y stores, moved the late stage from 2 to 3 and made stage 0 and the epilogue longer: 115 us instead of 108, r05h.)
-            if (more) {
+            // (the last step's four are its own fragments once more: never used, gone with the wave; the full-batch form's six parameter requests are younger still)
+            if constexpr (NHT == 5) {
                 r2_wait_vm<4>();
             } else {
-                r2_wait_vm<0>();
+                r2_wait_vm<10>();
             }
         } else {
             for (int s = 0; s + 1 < nstages; ++s) do_stage(s, std::false_type{});
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
             float4v bias4[2], scale4[2], shift4[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                if constexpr (DIRECT && NHT == 5) {   // (requested in front of the last K stage)
+                if constexpr (DIRECT) {   // (requested in front of the last K stage / of its last MFMA group)
                     bias4[mi] = pbias4[mi];
                     scale4[mi] = pscale4[mi];
                     shift4[mi] = pshift4[mi];
@@ -467,6 +485,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
                     xnext = *reinterpret_cast<const half8v*>(wbuf + tc * ROWB + (((co8 >> 3) ^ (tc & 15)) << 4));
                 }
                 const half8v nv = pk_add_hwsat(ov, xnext);   // the packed sum saturates in hardware (FP16_OVFL)
+                // (the y store stays HERE, between this tile's arithmetic and its LDS writes: all ten stores first and the LDS part in a second pass over the tiles
+                // measured +4 us on the chain -- the second pass is one LDS round trip per tile with nothing to hide it behind, r15bc)
                 if (t >= st0 && t < st1) *reinterpret_cast<half8v*>(yb + (int64_t)t * a.C + j * WIDTH + co8) = ov;
                 if (t < T) {
                     if (more) {
@@ -512,8 +532,8 @@ __global__ __launch_bounds__(R2_THREADS) void res2_chain_kernel(Res2Args a) {
 }
 
 
-static bool res2_direct(int T, int width, int k) {  // (k * 2 K stages per step: the rotation of three fragment sets wants a multiple of 3)
-    return R2_DIRECT && width == 128 && k % 3 == 0 && ((T + 3) & ~3) * width * 2 <= R2_XNEXT_BYTES;
+static bool res2_direct(int T, int width, int k) {  // (six K stages per step, written out: k = 3, two 64-channel stages per tap)
+    return R2_DIRECT && width == 128 && k == 3 && ((T + 3) & ~3) * width * 2 <= R2_XNEXT_BYTES;
 }
 
 constexpr int R2_SMALL_ROWS = 160;   // frames a workgroup of the 5-tile direct form holds (small batches)
@@ -525,7 +545,7 @@ size_t res2_chain_lds_bytes(int T, int width, int k) {
 }
 
 // frames one workgroup can hold (direct form: the x_{j+1} region; ring form: the 20 time tiles of the accumulators)
-static int res2_local_limit(int width, int k) { return R2_DIRECT && width == 128 && k % 3 == 0 ? 304 : 16 * 2 * R2_NH; }
+static int res2_local_limit(int width, int k) { return R2_DIRECT && width == 128 && k == 3 ? 304 : 16 * 2 * R2_NH; }
 
 // utterances beyond 320 frames: chunks of equal useful length with steps * pad halo rows per side (Res2Args); {1, T} when one workgroup holds it.
 // Small batches of the direct form's geometry (B utterances on a chip of many more CUs) are cut into chunks of <= 160 frames for the 5-tile
@@ -536,7 +556,7 @@ static void res2_chunking(int B, int T, int width, int steps, int k, int dil, in
     *useful = T;
     *small = false;
     const int halo2 = 2 * steps * (dil * (k - 1) / 2);
-    if (R2_DIRECT && width == 128 && k % 3 == 0 && R2_SMALL_ROWS - halo2 >= 64 && T > R2_SMALL_ROWS / 2) {
+    if (R2_DIRECT && width == 128 && k == 3 && R2_SMALL_ROWS - halo2 >= 64 && T > R2_SMALL_ROWS / 2) {
         const int per = R2_SMALL_ROWS - halo2;
         const int n0 = (T + per - 1) / per;
         if ((int64_t)B * n0 <= device_cu_count()) {   // (the chunks fit the chip in one round: 64 x 3 s = 192 workgroups of 59-66 us against 64 of 91 us)
