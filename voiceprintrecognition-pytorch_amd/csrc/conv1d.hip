@@ -817,6 +817,11 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
         // per-block broadcast reads of the parameters used to cost more LDS cycles than the whole K stage), the bias is
         // already in the accumulators (see the init in stage 0), and the two 64-byte halves of a 128-byte output line are
         // still written by consecutive stores.
+        // The row check of a store is per WAVE where it can be (round 6): all of the tensor's row tiles but the last hold valid rows only, and a wave whose 64
+        // time steps are all inside the tensor writes its sixteen stores as straight-line code -- behind a per-lane condition every store sat in its own
+        // skipped block (v_cmp, s_and_saveexec, s_cbranch_execz, s_or per store, and nothing scheduled across the block boundaries).
+        const bool wave_full = MV_UNIFORM(n0 + wn * 64 + 64 <= a.n_rows);
+        auto halves = [&](auto FULL) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4v sc[4], sh[4];
@@ -862,9 +867,15 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
                     const unsigned o[4] = {xa[0], xa[1], xb[0], xb[1]};
                     half8v ov;
                     __builtin_memcpy(&ov, o, 16);
-                    if (n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
+                    if (decltype(FULL)::value || n < a.n_rows) *reinterpret_cast<half8v*>(yrow + p * 32) = ov;
                 }
             }
+        }
+        };
+        if (wave_full) {
+            halves(std::true_type{});
+        } else {
+            halves(std::false_type{});
         }
         return;
     }
