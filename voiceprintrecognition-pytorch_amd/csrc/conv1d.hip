@@ -528,6 +528,51 @@ __device__ __forceinline__ void input_stats_reduce_store(const ConvArgs& a, cons
     }
 }
 
+// The fused form's route for the same partial rows (round 6): the reduced sums of a stage go to a small LDS buffer (groups of four stages, two buffers) and a
+// finished group leaves as ONE 16-byte store per thread at the top of a stage, in FRONT of that stage's transfers.  Stored straight from the reduction -- four
+// stores per wave in the middle of every stage, two lanes each -- they were the youngest operations in front of the stage's closing s_waitcnt vmcnt(0): every one
+// of the 48 stages waited for a store round trip (timing probes r15bh: 147-152 us with the stores, 136 without, 112 without statistics).  Same values, same
+// addresses: the finish kernel and the stand-alone statistics kernel see no difference.
+constexpr int CV_IN_STATS_GROUP = 4;                                             // stages per flush
+constexpr int CV_IN_STATS_BUF_BYTES = 2 * 2 * CV_IN_STATS_GROUP * CV_BK * 4;     // [buffer][sum | sq][stage of the group][64 channels] fp32 = 4 KiB
+__device__ __forceinline__ void input_stats_reduce_to_lds(const InStats& st, float* sbuf, int s, int wave, int lane) {
+    const int chunk = 2 * wave + (lane >> 5), g = lane & 31;
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {   // (the reduction of input_stats_reduce_store)
+        float t1 = st.s1[e >> 1][e & 1], t2 = st.s2[e >> 1][e & 1];
+        MV_OPAQUE(t1);
+        MV_OPAQUE(t2);
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        t1 += dpp_mov<DPP_ROW_BCAST15>(0.0f, t1);
+        t2 += dpp_mov<DPP_ROW_BCAST15>(0.0f, t2);
+        MV_OPAQUE(t1);
+        MV_OPAQUE(t2);
+        r1[e] = t1;
+        r2[e] = t2;
+    }
+    if (g == 16) {
+        float* b = sbuf + ((s / CV_IN_STATS_GROUP) & 1) * (2 * CV_IN_STATS_GROUP * CV_BK) + (s % CV_IN_STATS_GROUP) * CV_BK + chunk * 8;
+        *reinterpret_cast<float4v*>(b) = float4v{r1[0], r1[1], r1[2], r1[3]};
+        *reinterpret_cast<float4v*>(b + 4) = float4v{r1[4], r1[5], r1[6], r1[7]};
+        *reinterpret_cast<float4v*>(b + CV_IN_STATS_GROUP * CV_BK) = float4v{r2[0], r2[1], r2[2], r2[3]};
+        *reinterpret_cast<float4v*>(b + CV_IN_STATS_GROUP * CV_BK + 4) = float4v{r2[4], r2[5], r2[6], r2[7]};
+    }
+}
+// the group whose last stage is s_last (a barrier lies between its last reduction and this call): threads 0 .. 127, 16 bytes each
+__device__ __forceinline__ void input_stats_flush(const ConvArgs& a, const float* sbuf, int s_last, int n_tile, int tid) {
+    if (tid >= 2 * CV_IN_STATS_GROUP * CV_BK / 4) return;
+    const int grp = s_last / CV_IN_STATS_GROUP;
+    const int arr = tid / (CV_IN_STATS_GROUP * CV_BK / 4), idx = tid - arr * (CV_IN_STATS_GROUP * CV_BK / 4);   // idx: float4 inside [stage][64 channels]
+    const int sl = idx / (CV_BK / 4), c4 = (idx - sl * (CV_BK / 4)) * 4;
+    const int s = grp * CV_IN_STATS_GROUP + sl, c = s * CV_BK + c4;
+    if (s > s_last || c >= a.cin) return;   // (cin % 8 == 0: a group of four channels is inside or outside)
+    const float4v v = *reinterpret_cast<const float4v*>(sbuf + (grp & 1) * (2 * CV_IN_STATS_GROUP * CV_BK) + arr * (CV_IN_STATS_GROUP * CV_BK) + sl * CV_BK + c4);
+    float* dst = (arr ? a.in_sq : a.in_sum) + (int64_t)n_tile * a.cin + c;
+    *reinterpret_cast<float4v*>(dst) = v;
+}
+
 // ---- fast path: fp16 input, no input transform: global -> LDS directly (global_load_lds), no register staging ----
 // Workgroup tile = (WC*MI*16) output channels x (WN*NI*16) time steps, WC x WN waves.  Two instances are built:
 //   <2,2,4,4>  128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU)  -- narrow layers
@@ -675,9 +720,13 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
     issue(0, 0);
     wait_all_loads();
     __syncthreads();
-    InStats st;  // (INSTATS) time sums of the stage before the current one, reduced and stored under the current stage's MFMAs
+    InStats st;  // (INSTATS) time sums of the stage before the current one, reduced under the current stage's MFMAs
+    [[maybe_unused]] float* sbuf = reinterpret_cast<float*>(smem + NS * STAGE_BYTES);   // (INSTATS) reduced sums of up to two groups of stages
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
+        if constexpr (INSTATS) {   // stage s - 2 was reduced during stage s - 1 (a barrier ago): when it closed a group, the group leaves now (uniform)
+            if (s >= 2 && (s - 1) % CV_IN_STATS_GROUP == 0) input_stats_flush(a, sbuf, s - 2, n_tile, tid);
+        }
         if (s + 1 < nstages) issue(s + 1, buf ^ 1);  // lands while this stage computes
         const char* wt = smem + buf * STAGE_BYTES;
         if constexpr (INSTATS) {
@@ -685,7 +734,7 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
             // the vector unit runs the ~100 VALU operations written after them (a single channel tile here: cout <= 128)
             static_assert(NW == 4 && TN % 32 == 0, "input statistics: 256 threads, whole groups of 32 rows");
             mma_half_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, 0, acc);
-            if (s > 0) input_stats_reduce_store(a, st, (s - 1) * CV_BK, n_tile, wave, lane);  // the previous stage's sums (uniform)
+            if (s > 0) input_stats_reduce_to_lds(st, sbuf, s - 1, wave, lane);  // the previous stage's sums (uniform)
             mma_half_stage<MI, NI>(wt, wt + TC * CV_BK * 2, wc, wn, lane, 1, acc);
             input_stats_accumulate<TN>(st, wt + TC * CV_BK * 2, wave, lane);
         } else {
@@ -694,7 +743,14 @@ __global__ __launch_bounds__(64 * WC * WN) void conv1d_glds_kernel(ConvArgs a) {
         wait_all_loads();
         __syncthreads();
     }
-    if constexpr (INSTATS) input_stats_reduce_store(a, st, (nstages - 1) * CV_BK, n_tile, wave, lane);
+    if constexpr (INSTATS) {
+        // the last stage's sums, then what the buffer still holds: the group of stage nstages - 2 when that stage closed one (its flush would have come at the
+        // top of a stage nstages), and the group of the last stage
+        input_stats_reduce_to_lds(st, sbuf, nstages - 1, wave, lane);
+        __syncthreads();
+        if (nstages >= 2 && (nstages - 1) % CV_IN_STATS_GROUP == 0) input_stats_flush(a, sbuf, nstages - 2, n_tile, tid);
+        input_stats_flush(a, sbuf, nstages - 1, n_tile, tid);
+    }
     if (a.y_f16 && a.sum_dst == nullptr) {
         conv_epilogue_staged<MI, NI, TC, TN, 64 * NW>(a, smem, n0, n_end, co0, wc, wn, lane, tid, acc);
     } else {
@@ -1819,7 +1875,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 2, 2, false, CV_SMALL_NS>), CV_LDS_BYTES_SMALL) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<4, 2, 2, 4, false, CV_TAIL_NS>), CV_LDS_BYTES_TAIL) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5>), CV_LDS_BYTES_WIDE) != hipSuccess ||
-            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE) != hipSuccess ||
+            MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 2, 4, 5, true>), CV_LDS_BYTES_WIDE + CV_IN_STATS_BUF_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_kernel<2, 4, 8, 4>), CV_LDS_BYTES_BIG) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 0>), CVP_LDS_BYTES) != hipSuccess ||
             MV_SET_MAX_SMEM((conv1d_glds_persistent_kernel<true, 1>), CVP_LDS_BYTES) != hipSuccess ||
@@ -1915,7 +1971,7 @@ int conv1d_launch(const MvConv1dDesc& d, hipStream_t stream) {
     } else if (big) {
         MV_LAUNCH((conv1d_glds_kernel<2, 4, 8, 4>), (grid, 1, 1), (512, 1, 1), CV_LDS_BYTES_BIG, stream, a);
     } else if (wide && in_stats) {
-        MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5, true>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
+        MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5, true>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE + CV_IN_STATS_BUF_BYTES, stream, a);
     } else if (wide) {
         MV_LAUNCH((conv1d_glds_kernel<2, 2, 4, 5>), (grid, 1, 1), (CV_THREADS, 1, 1), CV_LDS_BYTES_WIDE, stream, a);
     } else if (small) {
