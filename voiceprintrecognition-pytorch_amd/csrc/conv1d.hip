@@ -928,7 +928,9 @@ __device__ __forceinline__ void persistent_epilogue(const ConvArgs& a, const P& 
             }
         }
         };
-        if (wave_full) {
+        // (ring kernel only: in the double-buffer kernel -- LDS parameters, 242 registers -- the second copy of the epilogue made the register allocator spill,
+        // 256 VGPRs + 48 bytes of scratch, and block 0 of the backbone went from 88-92 to 101-104 us: r15bk)
+        if (HWSAT && wave_full) {
             halves(std::true_type{});
         } else {
             halves(std::false_type{});
