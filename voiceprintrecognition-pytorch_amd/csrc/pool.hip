@@ -30,7 +30,10 @@ static inline int ew_grid(int64_t groups) {
 //   mean = k + s1 / T,   var = (s2 - s1^2 / T) / (T or T - 1)
 // Optional pre-activation: v = relu(v * in_scale[c] + in_shift[c]) (CAM++ out_nonlinear, campplus.py:344-345).
 // PIPE: four rows in flight per lane (small grids; costs registers, i.e. waves per SIMD, which a full batch needs more than the overlap)
-template <bool PIPE>
+// LEAN: the mean alone of a plain tensor (no pre-activation, no std: the SE squeeze) -- conversion, subtraction, addition per value.  The general form spends
+// seven vector operations per value (a run-time select around the pre-activation, the second moment) and is bound by them, not by HBM: 11.4 M vector
+// instructions per launch at the headline shape = 21 us of issue in a 29 us kernel (PMC r15ay).  Same additions in the same order: the same mean.
+template <bool PIPE, bool LEAN = false>
 __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_t ld, int T, int C, float* mean,
                                                          float* stdv, int64_t ld_out, int unbiased, float clamp_eps,
                                                          const float* in_scale, const float* in_shift) {
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
     const half_t* xb = x + (int64_t)b * T * ld + c0;
     const int t_first = wave * 4 + rp;  // this lane's rows: t_first, t_first + 16, ...
     float s1[8], s2[8], k8[8], isc[8], ish[8];
-    const bool pre = in_scale != nullptr;
+    const bool pre = !LEAN && in_scale != nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         s1[e] = s2[e] = k8[e] = 0.0f;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
                     for (int e = 0; e < 8; ++e) {
                         const float d = val(v4[u][e], e) - k8[e];
                         s1[e] += d;
-                        s2[e] = fmaf(d, d, s2[e]);
+                        if (!LEAN) s2[e] = fmaf(d, d, s2[e]);
                     }
                 }
             }
@@ -92,13 +95,13 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
                 for (int e = 0; e < 8; ++e) {
                     const float d = val(v[e], e) - k8[e];
                     s1[e] += d;
-                    s2[e] = fmaf(d, d, s2[e]);
+                    if (!LEAN) s2[e] = fmaf(d, d, s2[e]);
                 }
             } else {
                 for (int e = 0; e < nvalid; ++e) {
                     const float d = val(p[e], e) - k8[e];
                     s1[e] += d;
-                    s2[e] = fmaf(d, d, s2[e]);
+                    if (!LEAN) s2[e] = fmaf(d, d, s2[e]);
                 }
             }
         }
@@ -109,11 +112,13 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
         float a1 = s1[e], a2 = s2[e];
         a1 += __shfl_xor(a1, 16);
         a1 += __shfl_xor(a1, 32);
-        a2 += __shfl_xor(a2, 16);
-        a2 += __shfl_xor(a2, 32);
+        if (!LEAN) {
+            a2 += __shfl_xor(a2, 16);
+            a2 += __shfl_xor(a2, 32);
+        }
         if (rp == 0) {
             red[0][wave][c16 * 8 + e] = a1;
-            red[1][wave][c16 * 8 + e] = a2;
+            if (!LEAN) red[1][wave][c16 * 8 + e] = a2;
         }
     }
     __syncthreads();
@@ -122,9 +127,9 @@ __global__ __launch_bounds__(256) void time_stats_kernel(const half_t* x, int64_
         float kc = (float)x[(int64_t)b * T * ld + cg0 + tid];
         if (pre) kc = fmaxf(kc * in_scale[cg0 + tid] + in_shift[cg0 + tid], 0.0f);
         const float z1 = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
-        const float z2 = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+        const float z2 = LEAN ? 0.0f : red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
         mean[(int64_t)b * ld_out + cg0 + tid] = kc + z1 / (float)T;
-        if (stdv != nullptr) {
+        if (!LEAN && stdv != nullptr) {
             const float denom = unbiased ? (float)(T - 1) : (float)T;
             float var = fmaxf(z2 - z1 * z1 / (float)T, 0.0f) / denom;
             if (clamp_eps > 0.0f) var = fmaxf(var, clamp_eps);
@@ -139,8 +144,12 @@ int time_stats_launch(const half_t* x, int64_t ld, int B, int T, int C, float* m
     MV_REQUIRE(ld > 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "time_stats: rows must be 16-byte aligned");
     MV_REQUIRE(ld_out >= C, "time_stats: output leading dimension");
     if (unbiased) MV_REQUIRE(T > 1, "time_stats: unbiased std needs T > 1");
+    const bool lean = stdv == nullptr && in_scale == nullptr;
     if (ceil_div(C, 128) * (int64_t)B <= 1024) {
         MV_LAUNCH(time_stats_kernel<true>, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
+                  ld_out, unbiased, clamp_eps, in_scale, in_shift);
+    } else if (lean) {
+        MV_LAUNCH((time_stats_kernel<false, true>), ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
                   ld_out, unbiased, clamp_eps, in_scale, in_shift);
     } else {
         MV_LAUNCH(time_stats_kernel<false>, ((unsigned)ceil_div(C, 128), (unsigned)B, 1), (256, 1, 1), 0, stream, x, ld, T, C, mean, stdv,
