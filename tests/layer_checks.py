@@ -784,9 +784,21 @@ def fcm_block_c1_case(cdll, device, B, F, T, seed=0, scale=4.0, outlier=True):
     ref = ref.clamp(min=0, max=65504).permute(0, 2, 3, 1)
     out = y.cpu().double()
     assert torch.isfinite(out).all(), 'unwritten outputs'
-    err = ((out - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+    errs = (out - ref).abs() / ref.abs().clamp(min=1.0)
+    err = errs.max().item()
     # fp16 rounding of the stored result + fp16 ulp flips of the two intermediate maps where the fp32 accumulation order differs
-    assert err < 4e-3, err
+    if errs.numel() <= 10_000_000:
+        assert err < 4e-3, err
+        return err
+    # The maximum of this metric grows with the number of outputs.  At the device fuzzer's largest shape (B = 64, F = 80, T = 998: 81.7 M outputs) twelve seeds
+    # read 2.5e-3 ... 4.8e-3, two of them beyond 4e-3 with ONE output each (profiles/r15br/diag_fcm_c1_tail.log: 3.5-5.7 k outputs beyond 1e-3, 58-148 beyond 2e-3,
+    # 0-12 beyond 3e-3, at scattered interior positions), every output inside what one fp16 ulp flip of each intermediate value in its receptive field can move it
+    # (the largest ones 4.6 x or more inside).  Large maps are held to that distribution and to that bound instead of to the small maps' maximum.
+    assert err < 6e-3 and int((errs > 4e-3).sum()) <= 1 + errs.numel() // 50_000_000, (err, int((errs > 4e-3).sum()))
+    ulp = lambda v: torch.where(v > 0, torch.exp2(torch.floor(torch.log2(v.clamp(min=2.0 ** -14))) - 10), torch.zeros_like(v))
+    bound = Fn.conv2d(ulp(mid), k33(w2).abs(), None, padding=1) + Fn.conv2d(ulp(c1), w2[9].double().abs().reshape(32, 32, 1, 1), None, stride=(2, 1))
+    bound = bound.permute(0, 2, 3, 1) + 0.5 * ulp(ref.clamp(min=2.0 ** -14))
+    assert bool(((out - ref).abs() <= bound).all()), 'an output beyond the one-ulp-flip bound of its receptive field'
     return err
 
 
