@@ -57,9 +57,9 @@ typedef struct MvFbankCfg {
     float sample_frequency;       /* 16000 */
     float frame_length_ms;        /* 25 */
     float frame_shift_ms;         /* 10 */
-    int32_t num_mel_bins;         /* 80 (<= 128) */
-    float low_freq;               /* 20 */
-    float high_freq;              /* 0 => Nyquist (+ high_freq if <= 0, as Kaldi) */
+    int32_t num_mel_bins;         /* 80 (4 .. 128: torchaudio's get_mel_banks asserts num_bins > 3) */
+    float low_freq;               /* 20 (0 <= low_freq < Nyquist, low_freq < high_freq: refused otherwise, as get_mel_banks asserts) */
+    float high_freq;              /* 0 => Nyquist (+ high_freq if <= 0, as Kaldi); beyond Nyquist: refused (get_mel_banks asserts) */
     float preemphasis_coefficient;/* 0.97 */
     int32_t remove_dc_offset;     /* 1 */
     int32_t use_power;            /* 1 */

@@ -81,8 +81,11 @@ def kaldi_mel_banks(num_bins, padded, sample_freq, low_freq, high_freq, vtln_low
     """
     num_fft_bins = padded // 2
     nyquist = 0.5 * sample_freq
+    assert num_bins > 3, 'Must have at least 3 mel bins'   # (get_mel_banks' own first line)
     if high_freq <= 0.0:
         high_freq += nyquist
+    assert (0.0 <= low_freq < nyquist) and (0.0 < high_freq <= nyquist) and (low_freq < high_freq), \
+        f'Bad values in options: low-freq {low_freq} and high-freq {high_freq} vs. nyquist {nyquist}'
     fft_bin_width = sample_freq / padded
     mel_lo = 1127.0 * math.log(1.0 + low_freq / 700.0)
     mel_hi = 1127.0 * math.log(1.0 + high_freq / 700.0)

@@ -927,6 +927,10 @@ def fbank_case(cdll, device, wav, ratio, method_args, kernel='auto', cmn=True, n
     ref64 = oracle(frontend.kaldi_fbank_f64)
     scale = 1.0 if dict(method_args).get('use_log_fbank', True) else max(float(ref64.abs().max()), 1e-30)
     d = (out - ref).abs() / scale
+    # ... and where the fp32 oracle ITSELF sits more than 1e-3 from the arbiter it is no yard-stick for the kernel: those values are left to the arbiter's bar below
+    # (device fuzz r15bt, reproduced bit for bit on the emulator: magnitude spectrum, 26 ms frames, the utterance's lowest log energy at -10.7 against a median of 0.5:
+    # torch-fp32 6.5e-3 from the arbiter, the kernel 6.0e-4 -- the pair 7.1e-3 apart)
+    d = torch.where(((ref.double() - ref64).abs() / scale) > 1e-3, torch.zeros_like(d), d)
     # Two fp32 evaluations of a near-floor log energy (a small difference of fp32 spectra: the bins next to DC, where the pre-emphasis leaves 1e-3 of
     # the power and the transform's rounding noise is that of the whole frame) differ by more than either differs from the exact value.  So the STATED
     # bar (SURVEY 8(c) / BASELINE.md 3: max-abs <= 1e-3) is asserted against the fp64 arbiter of the same algorithm, and as what fp32 can keep: every

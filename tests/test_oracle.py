@@ -204,6 +204,11 @@ def test_oracle_widened_front_end_arguments_against_independent_code_and_propert
     assert abs(wf[3].item() - 1000.0 / 1.1) < 1e-3 and torch.all(wf[1:7][1:] > wf[1:7][:-1])                             # scaled middle, monotonic
     with pytest.raises(AssertionError):
         frontend.kaldi_mel_banks(80, 512, 16000.0, 20.0, 0.0, vtln_low=10.0, vtln_warp=1.1)
+    # get_mel_banks' band and bin-count assertions (the product and the CPU front-end refuse the same configurations)
+    for args in ((80, 512, 16000.0, 20.0, 8100.0), (80, 512, 16000.0, -1.0, 0.0), (80, 512, 16000.0, 7700.0, -400.0), (64, 256, 11025.0, 20.0, 7600.0), (3, 512, 16000.0, 20.0, 0.0)):
+        with pytest.raises(AssertionError):
+            frontend.kaldi_mel_banks(*args)
+    assert frontend.kaldi_mel_banks(4, 512, 16000.0, 0.0, 8000.0).shape == (4, 256)
     # MelSpectrogram: Slaney mel points / norm against transformers' (librosa-style) filterbanks; normalisation modes as scalings
     for ms, nm in (('slaney', 'slaney'), ('slaney', None), ('htk', 'slaney')):
         with warnings.catch_warnings():

@@ -210,6 +210,8 @@ def g_fbank(r):
         # 29 of 832 k values 1e-3 .. 3e-3 from the fp64 arbiter where torch's 128-point fp32 transform stays within 7.4e-4) -- not a
         # configuration anybody featurises with; the generator keeps to at most half as many filters as bins
         sf = extra.get('sample_frequency', 16000)
+        if extra.get('high_freq', 0.0) > 0.5 * sf:   # (beyond Nyquist: torchaudio's get_mel_banks asserts, the library refuses -- r15bt drew 7600 Hz at 11.025 kHz)
+            extra['high_freq'] = 0.45 * sf
         size = int(sf * extra.get('frame_length', 25.0) * 0.001)
         padded = 1 << max(1, (size - 1).bit_length())
         if kw['bins'] > padded // 4:   # (at most half as many filters as the transform has bins)

@@ -1068,8 +1068,13 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     const int win = (int)(cfg->sample_frequency * cfg->frame_length_ms * 0.001f);
     const int shift = (int)(cfg->sample_frequency * cfg->frame_shift_ms * 0.001f);
     MV_REQUIRE(shift >= 1, "mv_fbank_create: frame shift must be at least one sample");
-    MV_REQUIRE(cfg->num_mel_bins >= 1 && cfg->num_mel_bins <= 64 * mv::FB_MAX_PASSES,
-               "mv_fbank_create: num_mel_bins must be in [1, 128]");
+    MV_REQUIRE(cfg->num_mel_bins >= 4 && cfg->num_mel_bins <= 64 * mv::FB_MAX_PASSES,
+               "mv_fbank_create: num_mel_bins must be in [4, 128] (torchaudio's get_mel_banks asserts num_bins > 3)");
+    {   // torchaudio.compliance.kaldi.get_mel_banks asserts on the band the same way ("Bad values in options: low-freq ... and high-freq ... vs. nyquist ...")
+        const float nyq = 0.5f * cfg->sample_frequency, hi = cfg->high_freq <= 0.0f ? cfg->high_freq + nyq : cfg->high_freq;
+        MV_REQUIRE(cfg->low_freq >= 0.0f && cfg->low_freq < nyq && hi > 0.0f && hi <= nyq && cfg->low_freq < hi,
+                   "mv_fbank_create: bad band (need 0 <= low_freq < nyquist, 0 < high_freq <= nyquist and low_freq < high_freq; high_freq <= 0 counts from nyquist)");
+    }
     if (win < 2 || win > mv::FB_NFFT)
         return mv::fail(MV_ERR_UNSUPPORTED,
                         "mv_fbank_create: only frame lengths of 2 .. 512 samples (an FFT of up to 512 points, e.g. 25 ms at 16 kHz) are "

@@ -88,6 +88,10 @@ def _fbank_tables(sf, frame_length, frame_shift, nbins, low, high, window_type, 
     window = _window(window_type, size, blackman_coeff)
     nfft_bins = padded // 2
     high = high + 0.5 * sf if high <= 0.0 else high
+    if nbins <= 3:   # (torchaudio.compliance.kaldi.get_mel_banks asserts on both)
+        raise AssertionError('Must have at least 3 mel bins')
+    if not (0.0 <= low < 0.5 * sf and 0.0 < high <= 0.5 * sf and low < high):
+        raise AssertionError(f'Bad values in options: low-freq {low} and high-freq {high} vs. nyquist {0.5 * sf}')
     mel_lo = 1127.0 * math.log(1.0 + low / 700.0)
     mel_hi = 1127.0 * math.log(1.0 + high / 700.0)
     delta = (mel_hi - mel_lo) / (nbins + 1)
