@@ -189,6 +189,7 @@ def _kaldi_fbank_impl(waveform, kwargs, dtype):
     if a['raw_energy']:
         energy = log_energy(frames)
     pc = a['preemphasis_coefficient']
+    assert 0.0 <= pc <= 1.0, '`preemphasis_coefficient` must be between [0,1]'   # (_get_waveform_and_window_properties)
     if pc != 0.0:
         prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)  # replicate-pad on the left
         frames = frames - pc * prev

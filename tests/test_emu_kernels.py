@@ -134,6 +134,8 @@ def test_emu_fbank_edge_cases():
     for bad in (dict(high_freq=8100.0), dict(low_freq=-1.0), dict(low_freq=7700.0, high_freq=-400.0), dict(sample_frequency=11025, high_freq=7600.0)):
         with pytest.raises(RuntimeError, match='bad band'):      # (get_mel_banks asserts 0 <= low < nyquist, 0 < high <= nyquist, low < high)
             lc._hip.Fbank(dict(FB, **bad), cdll=emu_cdll())
+    with pytest.raises(RuntimeError, match='preemphasis_coefficient must be in'):
+        lc._hip.Fbank(dict(FB, preemphasis_coefficient=1.5), cdll=emu_cdll())
     with pytest.raises(RuntimeError, match=r'\[4, 128\]'):         # (... and num_bins > 3)
         lc._hip.Fbank(dict(FB, num_mel_bins=3), cdll=emu_cdll())
     lc._hip.Fbank(dict(FB, high_freq=8000.0, low_freq=0.0, num_mel_bins=4), cdll=emu_cdll())   # the edges themselves are valid

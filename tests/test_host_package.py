@@ -526,7 +526,7 @@ def test_cpu_featurizer_takes_the_wider_method_args():
     for bad in (dict(dither=0.1), dict(round_to_power_of_two=False)):
         with pytest.raises(NotImplementedError):
             AudioFeaturizer('Fbank', method_args=dict(FB, **bad))
-    for bad in (dict(high_freq=8100.0), dict(low_freq=7700.0, high_freq=-400.0), dict(num_mel_bins=3)):   # torchaudio's get_mel_banks asserts on these
+    for bad in (dict(high_freq=8100.0), dict(low_freq=7700.0, high_freq=-400.0), dict(num_mel_bins=3), dict(preemphasis_coefficient=-0.1)):   # torchaudio asserts on these
         with pytest.raises(AssertionError):
             AudioFeaturizer('Fbank', method_args=dict(FB, **bad))(wav, ratio)
     for bad in (dict(pad_mode='symmetric'), dict(onesided=False), dict(power=None)):

@@ -209,6 +209,8 @@ def test_oracle_widened_front_end_arguments_against_independent_code_and_propert
         with pytest.raises(AssertionError):
             frontend.kaldi_mel_banks(*args)
     assert frontend.kaldi_mel_banks(4, 512, 16000.0, 0.0, 8000.0).shape == (4, 256)
+    with pytest.raises(AssertionError):
+        frontend.kaldi_fbank(torch.zeros(1, 1600), preemphasis_coefficient=1.5)
     # MelSpectrogram: Slaney mel points / norm against transformers' (librosa-style) filterbanks; normalisation modes as scalings
     for ms, nm in (('slaney', 'slaney'), ('slaney', None), ('htk', 'slaney')):
         with warnings.catch_warnings():

@@ -1082,6 +1082,8 @@ int mv_fbank_create(const MvFbankCfg* cfg, MvFbank** out) {
     MV_REQUIRE(cfg->window_type >= MV_WINDOW_POVEY && cfg->window_type <= MV_WINDOW_BLACKMAN, "mv_fbank_create: unknown window_type");
     MV_REQUIRE(cfg->kernel >= MV_FBANK_KERNEL_AUTO && cfg->kernel <= MV_FBANK_KERNEL_TILE, "mv_fbank_create: unknown kernel selector");
     MV_REQUIRE(cfg->min_duration >= 0.0f, "mv_fbank_create: negative min_duration");
+    MV_REQUIRE(cfg->preemphasis_coefficient >= 0.0f && cfg->preemphasis_coefficient <= 1.0f,
+               "mv_fbank_create: preemphasis_coefficient must be in [0, 1] (torchaudio asserts the same)");
     MV_REQUIRE(cfg->vtln_warp > 0.0f, "mv_fbank_create: vtln_warp must be positive");
     MV_REQUIRE((cfg->use_energy == 0 || cfg->use_energy == 1) && (cfg->raw_energy == 0 || cfg->raw_energy == 1) && (cfg->htk_compat == 0 || cfg->htk_compat == 1) &&
                    cfg->energy_floor >= 0.0f, "mv_fbank_create: use_energy / raw_energy / htk_compat are 0 or 1, energy_floor is not negative");

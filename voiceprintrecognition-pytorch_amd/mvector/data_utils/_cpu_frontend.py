@@ -145,6 +145,8 @@ def fbank_batch(wav, args):
     if a['use_energy'] and a['raw_energy']:
         energy = log_energy(frames)
     pc = float(a['preemphasis_coefficient'])
+    if not 0.0 <= pc <= 1.0:   # (kaldi._get_waveform_and_window_properties asserts)
+        raise AssertionError('`preemphasis_coefficient` must be between [0,1]')
     if pc != 0.0:
         frames = frames - pc * torch.cat([frames[..., :1], frames[..., :-1]], dim=2)
     frames = frames * window
