@@ -310,6 +310,8 @@ def mel_spectrogram(waveforms, **kwargs):
     hop = a['hop_length'] if a['hop_length'] is not None else win // 2
     sr = a['sample_rate']
     f_max = a['f_max'] if a['f_max'] is not None else float(sr // 2)
+    if a['f_min'] > f_max:   # torchaudio.transforms.MelScale.__init__
+        raise ValueError(f"Require f_min: {a['f_min']} <= f_max: {f_max}")
     x = torch.as_tensor(waveforms, dtype=torch.float32)
     if a['pad'] > 0:   # torchaudio.functional.spectrogram: `waveform = torch.nn.functional.pad(waveform, (pad, pad), "constant")` in front of the stft
         x = F.pad(x, (a['pad'], a['pad']), 'constant')

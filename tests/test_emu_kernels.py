@@ -240,6 +240,8 @@ def test_emu_melspec_fft_kernel_and_dft_kernel():
     assert _hip.MelSpec({}, cdll=emu_cdll()).info()['tile_kernel']
     assert _hip.MelSpec(dict(n_fft=512), cdll=emu_cdll()).info()['kernel'] == 'melspec_pow2_kernel'
     assert not _hip.MelSpec(dict(n_fft=600, win_length=600), cdll=emu_cdll()).info()['tile_kernel']   # neither 400 nor a power of two: dense DFT
+    with pytest.raises(RuntimeError, match='Require f_min <= f_max'):   # (MelScale.__init__ raises ValueError on it)
+        _hip.MelSpec(dict(f_min=4000.0, f_max=3000.0), cdll=emu_cdll())
     wav = frontend.synth_waveforms(2, 48000, seed=31)
     lc.melspec_case(emu_cdll(), 'cpu', wav, torch.tensor([0.71, 1.0]), {})          # T = 241: 212 rows in LDS, 29 through global
     lc.melspec_case(emu_cdll(), 'cpu', wav[:1, :5000 + 3], None, {})                # T = 26, odd length

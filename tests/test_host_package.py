@@ -535,3 +535,7 @@ def test_cpu_featurizer_takes_the_wider_method_args():
     for bad in (dict(norm='area'), dict(mel_scale='bark'), dict(normalized='sqrt')):
         with pytest.raises(ValueError):
             AudioFeaturizer('MelSpectrogram', method_args=bad)
+    with pytest.raises(ValueError, match='Require f_min'):   # (torchaudio.transforms.MelScale.__init__)
+        AudioFeaturizer('MelSpectrogram', method_args=dict(f_min=4000.0, f_max=3000.0))(wav, ratio)
+    with pytest.raises(ValueError, match='Require f_min'):
+        frontend.mel_spectrogram(wav, f_min=4000.0, f_max=3000.0)

@@ -595,6 +595,7 @@ int mv_melspec_create(const MvMelSpecCfg* cfg, MvMelSpec** out) {
     MV_REQUIRE(cfg->win_length >= 1 && cfg->win_length <= cfg->n_fft, "mv_melspec_create: win_length must be in [1, n_fft]");
     MV_REQUIRE(cfg->hop_length >= 1, "mv_melspec_create: hop_length must be positive");
     MV_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= 256, "mv_melspec_create: n_mels must be in [1, 256]");
+    MV_REQUIRE(cfg->f_min <= cfg->f_max, "mv_melspec_create: Require f_min <= f_max (torchaudio's MelScale raises the same)");
     MV_REQUIRE(cfg->power > 0.0f && cfg->power < 64.0f, "mv_melspec_create: power must be a positive exponent (power=None, the complex spectrogram, has no mel scale)");
     MV_REQUIRE(cfg->mel_scale == MV_MEL_HTK || cfg->mel_scale == MV_MEL_SLANEY, "mv_melspec_create: unknown mel_scale");
     MV_REQUIRE(cfg->norm == MV_MEL_NORM_NONE || cfg->norm == MV_MEL_NORM_SLANEY, "mv_melspec_create: unknown norm");

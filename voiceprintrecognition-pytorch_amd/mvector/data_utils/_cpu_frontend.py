@@ -208,6 +208,8 @@ def melspec_batch(wav, args):
     hop = int(hop if hop is not None else win // 2)
     f_max = args.get('f_max')
     f_max = float(f_max if f_max is not None else sr // 2)
+    if float(args.get('f_min', 0.0)) > f_max:   # torchaudio.transforms.MelScale.__init__
+        raise ValueError(f"Require f_min: {float(args.get('f_min', 0.0))} <= f_max: {f_max}")
     power = float(args.get('power', 2.0))
     fb = _mel_fbank(sr, n_fft, float(args.get('f_min', 0.0)), f_max, int(args.get('n_mels', 128)), args.get('mel_scale', 'htk'), args.get('norm'))
     window = args['window_fn'](win, **(args.get('wkwargs') or {})).float() if args.get('window_fn') is not None else torch.hann_window(win)
